@@ -1,0 +1,232 @@
+/*
+ * mrhash_hip.h — C ABI of the MI355X-native voxel-hash TSDF fusion engine.
+ *
+ * This is the drop-in boundary between a C++/Python host (the GeoWrapper facade) and the
+ * gfx950 HIP layer (libmrhash_hip.so).  Every entry point replaces one C++ member call the
+ * reference host makes on its CUDA subsystems; the citation after each declaration names the
+ * reference interface it stands in for (paths relative to the reference checkout,
+ * mrhash/src/sdf/...).
+ *
+ * Conventions
+ *   - plain C, plain pointers and sizes; no C++/torch types cross this boundary
+ *   - every function returns an int status: 0 = MRH_OK, negative = mrh_status error code;
+ *     a human-readable message for the last failure on a context is available through
+ *     mrh_last_error()
+ *   - one host thread per context; calls are ordered on the context's HIP stream.  Calls
+ *     that hand data back to the host (mrh_stats, mrh_dump_blocks, mrh_extract_triangles,
+ *     mrh_extract_mesh, mrh_sync) block until the stream has drained; mrh_integrate only
+ *     enqueues work.
+ *   - all inputs are copied (or consumed) before the call returns unless the name says
+ *     `_device`, in which case the pointer is a device pointer that must stay valid until
+ *     the next mrh_sync()/blocking call.
+ *
+ * The same ABI is implemented by the CPU oracle (oracle/mrh_oracle.c -> libmrh_oracle.so),
+ * which exists only so that tests can drive both implementations through identical code.
+ * The product library never links, loads or calls the oracle.
+ */
+#ifndef MRHASH_HIP_H
+#define MRHASH_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MRH_ABI_VERSION 1
+
+typedef enum mrh_status {
+  MRH_OK                = 0,
+  MRH_ERR_INVALID_ARG   = -1, /* null pointer, bad shape, bad enum                         */
+  MRH_ERR_DEVICE        = -2, /* HIP runtime error (message carries hipGetErrorString)     */
+  MRH_ERR_NO_DEVICE     = -3, /* no gfx950 device visible                                  */
+  MRH_ERR_CAPACITY      = -4, /* block pool / hash table / triangle buffer exhausted       */
+  MRH_ERR_STATE         = -5, /* call order violated (e.g. integrate before set_camera)    */
+  MRH_ERR_UNSUPPORTED   = -6, /* feature outside this library's scope                      */
+  MRH_ERR_OUT_OF_RANGE  = -7  /* block coordinate outside the packed-key range (+-2^20)    */
+} mrh_status;
+
+typedef enum mrh_camera_model {
+  MRH_CAMERA_PINHOLE   = 0, /* camera.cuh:9 CameraModel::Pinhole   */
+  MRH_CAMERA_SPHERICAL = 1  /* camera.cuh:9 CameraModel::Spherical */
+} mrh_camera_model;
+
+/* Construction parameters: the GeoWrapper constructor arguments that reach the fusion path
+ * (geowrapper.cpp:9-81, pybind/pygeowrapper.cpp:14-29) plus explicit capacities (the
+ * reference derives them from cudaMemGetInfo, geowrapper.cpp:37-54; 0 here means "apply the
+ * same rule to the free HBM of the selected device"). */
+typedef struct mrh_params {
+  uint32_t abi_version;               /* must be MRH_ABI_VERSION                                         */
+  float    sdf_truncation;            /* metres                                                          */
+  float    sdf_truncation_scale;      /* truncation grows by scale * depth (vhu.cuh:184-187)             */
+  int32_t  integration_weight_sample; /* per-observation weight (passed to kernels as u8, vds.cu:1101)   */
+  int32_t  integration_weight_max;    /* weight clamp, params.h:25 = 255                                 */
+  float    virtual_voxel_size;        /* metres, finest voxel                                            */
+  int32_t  n_frames_invalidate_voxels;/* 0 = no GC; >0 = GC every frame, starve every n-th frame         */
+  int32_t  voxel_extents_scale;       /* only 1 is coherent in the reference (vhu.cuh:90-92 vs :138-140) */
+  float    marching_cubes_threshold;
+  uint8_t  min_weight_threshold;
+  uint8_t  projective_sdf;            /* kept for signature parity; RGB-D path is always projective      */
+  uint8_t  reserved0[2];
+  float    min_depth;                 /* initial camera thresholds (geowrapper.cpp:80)                   */
+  float    max_depth;
+  float    sdf_var_threshold;         /* >0 enables variance-adaptive fine->coarse blocks                */
+  float    vertices_merging_threshold;
+  uint64_t num_sdf_blocks;            /* capacity in fine (8^3) blocks; 0 = reference sizing rule        */
+  uint64_t hash_slots;                /* open-address table slots (power of two); 0 = 4 x num_sdf_blocks */
+  uint64_t max_triangles;             /* triangle buffer capacity; 0 = reference sizing rule             */
+  int32_t  device_id;                 /* HIP device ordinal                                              */
+  /* Multi-GPU tile sharding (new design, no reference counterpart): this context owns the
+   * blocks whose 8-block-cube chunk hashes to shard_rank modulo shard_count. 1 = own all. */
+  int32_t  shard_rank;
+  int32_t  shard_count;
+  int32_t  reserved1;
+} mrh_params;
+
+/* Reference `Voxel` (voxel_hash_utils.cuh:8-22): 12 bytes. Used only at the dump/restore
+ * boundary; the device layout is private. */
+typedef struct mrh_voxel {
+  float   sdf;
+  float   sum_squared;
+  uint8_t rgb[3];
+  uint8_t weight;
+} mrh_voxel;
+
+/* One allocated block as seen from outside: position in block units, resolution level
+ * (0 = 8^3 voxels, 1 = 4^3 voxels at 2x spacing).  Mirrors the host-side `SDFBlockDesc`
+ * (streamer.cuh:40-80) minus the private heap pointer. */
+typedef struct mrh_block_desc {
+  int32_t x, y, z;
+  int32_t resolution;
+} mrh_block_desc;
+
+/* Reference `Vertex` / `Triangle` (voxel_hash_utils.cuh:46-64): 24 / 72 bytes. */
+typedef struct mrh_vertex {
+  float p[3];
+  float c[3];
+} mrh_vertex;
+
+typedef struct mrh_triangle {
+  mrh_vertex v[3];
+} mrh_triangle;
+
+typedef struct mrh_stats {
+  uint64_t frames_integrated;     /* VoxelContainer::num_integrated_frames_                             */
+  uint64_t num_sdf_blocks;        /* capacity                                                           */
+  uint64_t occupied_fine;         /* live 8^3 blocks                                                    */
+  uint64_t occupied_coarse;       /* live 4^3 blocks                                                    */
+  int64_t  free_fine;             /* = getHeapHighFreeCount(), voxel_data_structures.cpp:148-153        */
+  int64_t  free_coarse;           /* = getHeapLowFreeCount(),  voxel_data_structures.cpp:156-161        */
+  uint64_t last_compact_blocks;   /* M: in-frustum blocks of the last frame (current_occupied_blocks_)  */
+  uint64_t last_updated_voxels;   /* U: voxels written by the last integrate kernel (profile mode only) */
+  uint64_t last_inserted_blocks;  /* blocks inserted by the last frame's allocation (profile mode only) */
+  uint64_t last_freed_blocks;     /* blocks freed by the last frame's GC (profile mode only)            */
+  uint64_t total_updated_voxels;  /* running sums of the two above since create/reset (profile mode)    */
+  uint64_t total_compact_blocks;
+  uint64_t last_triangles;        /* triangles produced by the last extraction                          */
+  float    last_integrate_kernel_ms; /* HIP-event time of the last integrate kernel (profile mode)      */
+  float    sum_integrate_kernel_ms;  /* running sum over frames since mrh_set_profile(ctx, 1)           */
+  uint64_t n_integrate_kernel;       /* number of launches in that sum                                  */
+  uint32_t error_flags;           /* sticky device-side flags: bit0 pool exhausted, bit1 table full,
+                                     bit2 key out of range, bit3 triangle buffer full                   */
+  uint32_t reserved;
+} mrh_stats;
+
+typedef struct mrh_ctx mrh_ctx;
+
+/* ---- lifetime ------------------------------------------------------------------------ */
+
+/* Replaces GeoWrapper::GeoWrapper + VoxelContainer/MarchingCubesExtractor constructors
+ * (geowrapper.cpp:9-81, voxel_data_structures.cuh:63-100, mesh_extractor.cuh:53-56). */
+int mrh_create(const mrh_params* params, mrh_ctx** out_ctx);
+
+/* Replaces the subsystem destructors (voxel_data_structures.cuh:117-170). NULL is a no-op. */
+int mrh_destroy(mrh_ctx* ctx);
+
+/* Replaces GeoWrapper::clearBuffers -> VoxelContainer::resetBuffers
+ * (voxel_data_structures.cpp:58-87): empties table, pools and frame counter. */
+int mrh_reset(mrh_ctx* ctx);
+
+/* Message of the last failing call on this context ("" if none); never NULL.
+ * With ctx == NULL returns the message of the last failing mrh_create on this thread.
+ * Replaces CUDA_CHECK's print-and-exit (cuda_utils.cuh:9-17). */
+const char* mrh_last_error(const mrh_ctx* ctx);
+
+/* ---- per-frame inputs ------------------------------------------------------------------ */
+
+/* Replaces GeoWrapper::setCamera -> Camera::Camera + setIntegrationDistance
+ * (geowrapper.cpp:98-116, camera.cuh:13-40). */
+int mrh_set_camera(mrh_ctx* ctx, float fx, float fy, float cx, float cy, int rows, int cols,
+                   float min_depth, float max_depth, int camera_model);
+
+/* Replaces Camera::setCamInWorld (camera.cuh:72). R is the row-major 3x3 rotation of the
+ * camera in the world, t its translation (geowrapper.cpp:86-92 after toRotationMatrix). */
+int mrh_set_pose(mrh_ctx* ctx, const float R_row_major[9], const float t[3]);
+
+/* Replaces depth_img_.toDevice() (geowrapper.cpp:125): host float32 [rows, cols], row-major. */
+int mrh_upload_depth(mrh_ctx* ctx, const float* depth, int rows, int cols);
+
+/* Replaces rgb_img_.toDevice() (geowrapper.cpp:126): host uint8 [rows, cols, 3]. */
+int mrh_upload_rgb(mrh_ctx* ctx, const uint8_t* rgb, int rows, int cols);
+
+/* Zero-copy variants: the images already live in HBM (e.g. a resident frame queue). The
+ * pointers are used by the next mrh_integrate and must stay valid until it has executed. */
+int mrh_set_depth_device(mrh_ctx* ctx, const float* d_depth, int rows, int cols);
+int mrh_set_rgb_device(mrh_ctx* ctx, const uint8_t* d_rgb, int rows, int cols);
+
+/* ---- the hot path ---------------------------------------------------------------------- */
+
+/* One frame of fusion = Camera::computeCloud + VoxelContainer::integrate
+ * (camera.cu:21-26, voxel_data_structures.cpp:90-110): block allocation along every pixel
+ * ray, frustum compaction, depth->TSDF integration, optional variance-driven coarsening,
+ * optional starve + garbage collection.  n_frames_invalidate < 0 uses the constructor value.
+ * Enqueues on the context stream and returns without waiting. */
+int mrh_integrate(mrh_ctx* ctx, int n_frames_invalidate);
+
+/* Blocks until every enqueued frame has executed; surfaces sticky device error flags as
+ * MRH_ERR_CAPACITY / MRH_ERR_OUT_OF_RANGE. */
+int mrh_sync(mrh_ctx* ctx);
+
+/* Replaces MeshExtractor::extractMesh = flatAndReduceHashTable() + extractIsoSurface
+ * (mesh_extractor.cpp:95-98, marching_cubes.cu:264-305): marching cubes over every live
+ * block.  Triangles come back in canonical order (block position ascending in (x,y,z), then
+ * voxel index, then triangle number); the buffer is owned by ctx until the next extraction. */
+int mrh_extract_triangles(mrh_ctx* ctx, const mrh_triangle** out_triangles, uint64_t* out_n);
+
+/* Replaces MeshExtractor::processTriangles (mesh_extractor.cpp:9-76) applied to the triangles
+ * of the last mrh_extract_triangles: f64 vertices [V,3], i32 faces [F,3], f64 colours [V,3],
+ * after vertex merge (exact, or quantised by vertices_merging_threshold), degenerate- and
+ * duplicate-face removal.  Buffers are owned by ctx until the next extraction. */
+int mrh_extract_mesh(mrh_ctx* ctx, const double** out_vertices, uint64_t* out_nv,
+                     const int32_t** out_faces, uint64_t* out_nf, const double** out_colors);
+
+/* ---- introspection --------------------------------------------------------------------- */
+
+/* Replaces the scalar read-backs getHeapHighFreeCount / getHeapLowFreeCount /
+ * current_occupied_blocks_ (voxel_data_structures.cpp:148-161, vds.cu:447). Blocks. */
+int mrh_get_stats(mrh_ctx* ctx, mrh_stats* out);
+
+/* 1 = bracket the integrate kernel with HIP events and count updated voxels / inserted /
+ * freed blocks on the device (used by bench.py for the roofline figures); 0 = off. */
+int mrh_set_profile(mrh_ctx* ctx, int enabled);
+
+/* Copies every live block out: descs[i] and 512 reference-layout voxels at
+ * voxels[i*512 .. i*512+511] (coarse blocks use the first 64).  With descs == NULL only the
+ * count is returned.  Replaces the device->host half of Streamer::streamAllOut
+ * (streamer.cpp:250-281) as far as tests and checkpointing need it.  Order is unspecified. */
+int mrh_dump_blocks(mrh_ctx* ctx, mrh_block_desc* descs, mrh_voxel* voxels, uint64_t capacity,
+                    uint64_t* out_n);
+
+/* Looks one voxel up by integer voxel coordinate = VoxelContainer::getVoxel(int3)
+ * (vds.cu:163-176); a miss returns a zero voxel and *out_found = 0. Test helper. */
+int mrh_get_voxel(mrh_ctx* ctx, int32_t vx, int32_t vy, int32_t vz, mrh_voxel* out, int* out_found);
+
+/* Library build info: "mrhash_hip <abi> gfx950 ..." (or "mrh_oracle ..." for the oracle). */
+const char* mrh_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* MRHASH_HIP_H */

@@ -1,0 +1,318 @@
+"""ctypes binding of the C ABI declared in include/mrhash_hip.h.
+
+`Engine` drives any shared library that implements that ABI.  The product library is
+`mrhash_amd/csrc/libmrhash_hip.so` (hand-written gfx950 HIP kernels); tests additionally load
+the CPU oracle (`oracle/_build/libmrh_oracle.so`) through the very same class so that parity
+tests run identical host code against both.  Nothing in this module falls back from one to
+the other: `load_hip()` raises if the HIP library is missing.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import numpy as np
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIP_LIB_PATH = os.path.join(_ROOT, "mrhash_amd", "csrc", "libmrhash_hip.so")
+
+MRH_ABI_VERSION = 1
+
+MRH_OK = 0
+MRH_ERR_INVALID_ARG = -1
+MRH_ERR_DEVICE = -2
+MRH_ERR_NO_DEVICE = -3
+MRH_ERR_CAPACITY = -4
+MRH_ERR_STATE = -5
+MRH_ERR_UNSUPPORTED = -6
+MRH_ERR_OUT_OF_RANGE = -7
+
+PINHOLE, SPHERICAL = 0, 1
+
+
+class MrhParams(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_uint32),
+        ("sdf_truncation", C.c_float),
+        ("sdf_truncation_scale", C.c_float),
+        ("integration_weight_sample", C.c_int32),
+        ("integration_weight_max", C.c_int32),
+        ("virtual_voxel_size", C.c_float),
+        ("n_frames_invalidate_voxels", C.c_int32),
+        ("voxel_extents_scale", C.c_int32),
+        ("marching_cubes_threshold", C.c_float),
+        ("min_weight_threshold", C.c_uint8),
+        ("projective_sdf", C.c_uint8),
+        ("reserved0", C.c_uint8 * 2),
+        ("min_depth", C.c_float),
+        ("max_depth", C.c_float),
+        ("sdf_var_threshold", C.c_float),
+        ("vertices_merging_threshold", C.c_float),
+        ("num_sdf_blocks", C.c_uint64),
+        ("hash_slots", C.c_uint64),
+        ("max_triangles", C.c_uint64),
+        ("device_id", C.c_int32),
+        ("shard_rank", C.c_int32),
+        ("shard_count", C.c_int32),
+        ("reserved1", C.c_int32),
+    ]
+
+
+class MrhStats(C.Structure):
+    _fields_ = [
+        ("frames_integrated", C.c_uint64),
+        ("num_sdf_blocks", C.c_uint64),
+        ("occupied_fine", C.c_uint64),
+        ("occupied_coarse", C.c_uint64),
+        ("free_fine", C.c_int64),
+        ("free_coarse", C.c_int64),
+        ("last_compact_blocks", C.c_uint64),
+        ("last_updated_voxels", C.c_uint64),
+        ("last_inserted_blocks", C.c_uint64),
+        ("last_freed_blocks", C.c_uint64),
+        ("total_updated_voxels", C.c_uint64),
+        ("total_compact_blocks", C.c_uint64),
+        ("last_triangles", C.c_uint64),
+        ("last_integrate_kernel_ms", C.c_float),
+        ("sum_integrate_kernel_ms", C.c_float),
+        ("n_integrate_kernel", C.c_uint64),
+        ("error_flags", C.c_uint32),
+        ("reserved", C.c_uint32),
+    ]
+
+
+VOXEL_DTYPE = np.dtype(
+    [("sdf", "<f4"), ("sum_squared", "<f4"), ("rgb", "u1", (3,)), ("weight", "u1")], align=False
+)
+assert VOXEL_DTYPE.itemsize == 12
+DESC_DTYPE = np.dtype([("x", "<i4"), ("y", "<i4"), ("z", "<i4"), ("resolution", "<i4")])
+TRI_DTYPE = np.dtype([("p", "<f4", (3,)), ("c", "<f4", (3,))])  # one vertex; a triangle is 3 of them
+assert TRI_DTYPE.itemsize == 24
+
+# every symbol include/mrhash_hip.h declares
+ABI_SYMBOLS = (
+    "mrh_create mrh_destroy mrh_reset mrh_last_error mrh_set_camera mrh_set_pose mrh_upload_depth "
+    "mrh_upload_rgb mrh_set_depth_device mrh_set_rgb_device mrh_integrate mrh_sync "
+    "mrh_extract_triangles mrh_extract_mesh mrh_get_stats mrh_set_profile mrh_dump_blocks "
+    "mrh_get_voxel mrh_version"
+).split()
+
+
+class MrhError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"mrh error {code}: {msg}")
+        self.code = code
+
+
+def _declare(lib: C.CDLL) -> C.CDLL:
+    P = C.POINTER
+    lib.mrh_create.argtypes = [P(MrhParams), P(C.c_void_p)]
+    lib.mrh_destroy.argtypes = [C.c_void_p]
+    lib.mrh_reset.argtypes = [C.c_void_p]
+    lib.mrh_last_error.argtypes = [C.c_void_p]
+    lib.mrh_last_error.restype = C.c_char_p
+    lib.mrh_set_camera.argtypes = [C.c_void_p] + [C.c_float] * 4 + [C.c_int, C.c_int, C.c_float, C.c_float, C.c_int]
+    lib.mrh_set_pose.argtypes = [C.c_void_p, P(C.c_float), P(C.c_float)]
+    lib.mrh_upload_depth.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    lib.mrh_upload_rgb.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    lib.mrh_set_depth_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    lib.mrh_set_rgb_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    lib.mrh_integrate.argtypes = [C.c_void_p, C.c_int]
+    lib.mrh_sync.argtypes = [C.c_void_p]
+    lib.mrh_extract_triangles.argtypes = [C.c_void_p, P(C.c_void_p), P(C.c_uint64)]
+    lib.mrh_extract_mesh.argtypes = [C.c_void_p, P(C.c_void_p), P(C.c_uint64), P(C.c_void_p), P(C.c_uint64), P(C.c_void_p)]
+    lib.mrh_get_stats.argtypes = [C.c_void_p, P(MrhStats)]
+    lib.mrh_set_profile.argtypes = [C.c_void_p, C.c_int]
+    lib.mrh_dump_blocks.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, P(C.c_uint64)]
+    lib.mrh_get_voxel.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, P(C.c_int)]
+    lib.mrh_version.argtypes = []
+    lib.mrh_version.restype = C.c_char_p
+    for name in ABI_SYMBOLS:
+        fn = getattr(lib, name)
+        if name not in ("mrh_last_error", "mrh_version"):
+            fn.restype = C.c_int
+    return lib
+
+
+def load_library(path: str) -> C.CDLL:
+    if not os.path.exists(path):
+        raise FileNotFoundError(
+            f"{path} not found - build it first (python -c 'import __graft_entry__ as g; g.build()')"
+        )
+    return _declare(C.CDLL(path))
+
+
+_hip_lib: Optional[C.CDLL] = None
+
+
+def load_hip() -> C.CDLL:
+    """The product library. Raises (never falls back) when it has not been built."""
+    global _hip_lib
+    if _hip_lib is None:
+        _hip_lib = load_library(HIP_LIB_PATH)
+    return _hip_lib
+
+
+@dataclass
+class Params:
+    sdf_truncation: float
+    sdf_truncation_scale: float = 0.0
+    integration_weight_sample: int = 1
+    integration_weight_max: int = 255
+    virtual_voxel_size: float = 0.01
+    n_frames_invalidate_voxels: int = 0
+    voxel_extents_scale: int = 1
+    marching_cubes_threshold: float = 1.5
+    min_weight_threshold: int = 5
+    projective_sdf: bool = True
+    min_depth: float = 0.01
+    max_depth: float = 30.0
+    sdf_var_threshold: float = 0.0
+    vertices_merging_threshold: float = 0.0
+    num_sdf_blocks: int = 0
+    hash_slots: int = 0
+    max_triangles: int = 0
+    device_id: int = 0
+    shard_rank: int = 0
+    shard_count: int = 1
+
+    def to_c(self) -> MrhParams:
+        p = MrhParams()
+        p.abi_version = MRH_ABI_VERSION
+        for f in (
+            "sdf_truncation sdf_truncation_scale integration_weight_sample integration_weight_max "
+            "virtual_voxel_size n_frames_invalidate_voxels voxel_extents_scale marching_cubes_threshold "
+            "min_weight_threshold min_depth max_depth sdf_var_threshold vertices_merging_threshold "
+            "num_sdf_blocks hash_slots max_triangles device_id shard_rank shard_count"
+        ).split():
+            setattr(p, f, getattr(self, f))
+        p.projective_sdf = 1 if self.projective_sdf else 0
+        return p
+
+
+class Engine:
+    """One fusion context behind the C ABI (HIP product library or, in tests, the oracle)."""
+
+    def __init__(self, lib: C.CDLL, params: Params):
+        self.lib = lib
+        self.params = params
+        self._ctx = C.c_void_p()
+        cp = params.to_c()
+        rc = lib.mrh_create(C.byref(cp), C.byref(self._ctx))
+        if rc != MRH_OK:
+            raise MrhError(rc, lib.mrh_last_error(None).decode())
+        self._keep = []  # device tensors referenced by *_device setters
+
+    # -- helpers -------------------------------------------------------------------------------
+    def _check(self, rc: int):
+        if rc != MRH_OK:
+            raise MrhError(rc, self.lib.mrh_last_error(self._ctx).decode())
+
+    def close(self):
+        if self._ctx:
+            self.lib.mrh_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- inputs --------------------------------------------------------------------------------
+    def set_camera(self, fx, fy, cx, cy, rows, cols, min_depth, max_depth, model=PINHOLE):
+        self._check(self.lib.mrh_set_camera(self._ctx, fx, fy, cx, cy, rows, cols, min_depth, max_depth, model))
+
+    def set_pose(self, R: np.ndarray, t: np.ndarray):
+        R = np.ascontiguousarray(R, dtype=np.float32).reshape(9)
+        t = np.ascontiguousarray(t, dtype=np.float32).reshape(3)
+        self._check(
+            self.lib.mrh_set_pose(self._ctx, R.ctypes.data_as(C.POINTER(C.c_float)), t.ctypes.data_as(C.POINTER(C.c_float)))
+        )
+
+    def upload_depth(self, depth: np.ndarray):
+        if depth.ndim != 2:
+            raise RuntimeError("setDepthImage|input should be a 2D numpy array")
+        d = np.ascontiguousarray(depth, dtype=np.float32)
+        self._check(self.lib.mrh_upload_depth(self._ctx, d.ctypes.data, d.shape[0], d.shape[1]))
+
+    def upload_rgb(self, rgb: np.ndarray):
+        if rgb.ndim != 3 or rgb.shape[2] != 3:
+            raise RuntimeError("setRGBImage|input should be a 3D numpy array with 3 channels")
+        r = np.ascontiguousarray(rgb, dtype=np.uint8)
+        self._check(self.lib.mrh_upload_rgb(self._ctx, r.ctypes.data, r.shape[0], r.shape[1]))
+
+    def set_depth_device(self, ptr: int, rows: int, cols: int):
+        self._check(self.lib.mrh_set_depth_device(self._ctx, ptr, rows, cols))
+
+    def set_rgb_device(self, ptr: int, rows: int, cols: int):
+        self._check(self.lib.mrh_set_rgb_device(self._ctx, ptr, rows, cols))
+
+    # -- hot path ------------------------------------------------------------------------------
+    def integrate(self, n_frames_invalidate: int = -1):
+        self._check(self.lib.mrh_integrate(self._ctx, n_frames_invalidate))
+
+    def sync(self):
+        self._check(self.lib.mrh_sync(self._ctx))
+
+    def reset(self):
+        self._check(self.lib.mrh_reset(self._ctx))
+
+    def set_profile(self, enabled: bool):
+        self._check(self.lib.mrh_set_profile(self._ctx, 1 if enabled else 0))
+
+    def stats(self) -> MrhStats:
+        s = MrhStats()
+        self._check(self.lib.mrh_get_stats(self._ctx, C.byref(s)))
+        return s
+
+    # -- outputs -------------------------------------------------------------------------------
+    def extract_triangles(self) -> np.ndarray:
+        """[T, 3] structured array of vertices (p[3], c[3]) in canonical triangle order."""
+        ptr = C.c_void_p()
+        n = C.c_uint64()
+        self._check(self.lib.mrh_extract_triangles(self._ctx, C.byref(ptr), C.byref(n)))
+        if n.value == 0:
+            return np.zeros((0, 3), dtype=TRI_DTYPE)
+        buf = (C.c_char * (n.value * 72)).from_address(ptr.value)
+        return np.frombuffer(buf, dtype=TRI_DTYPE).reshape(n.value, 3).copy()
+
+    def extract_mesh(self) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+        """(V f64[nv,3], F i32[nf,3], C f64[nv,3]) of the last extract_triangles()."""
+        pv, pf, pc = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        nv, nf = C.c_uint64(), C.c_uint64()
+        self._check(self.lib.mrh_extract_mesh(self._ctx, C.byref(pv), C.byref(nv), C.byref(pf), C.byref(nf), C.byref(pc)))
+
+        def arr(p, n, dt):
+            if n == 0 or not p.value:
+                return np.zeros((0, 3), dtype=dt)
+            sz = n * 3 * np.dtype(dt).itemsize
+            return np.frombuffer((C.c_char * sz).from_address(p.value), dtype=dt).reshape(n, 3).copy()
+
+        return arr(pv, nv.value, np.float64), arr(pf, nf.value, np.int32), arr(pc, nv.value, np.float64)
+
+    def dump_blocks(self) -> Tuple[np.ndarray, np.ndarray]:
+        """Canonical dump: (descs sorted by (x,y,z), voxels[n,512]) in the reference Voxel layout."""
+        n = C.c_uint64()
+        self._check(self.lib.mrh_dump_blocks(self._ctx, None, None, 0, C.byref(n)))
+        cap = max(int(n.value), 1)
+        descs = np.zeros(cap, dtype=DESC_DTYPE)
+        voxels = np.zeros((cap, 512), dtype=VOXEL_DTYPE)
+        self._check(self.lib.mrh_dump_blocks(self._ctx, descs.ctypes.data, voxels.ctypes.data, cap, C.byref(n)))
+        descs, voxels = descs[: n.value], voxels[: n.value]
+        order = np.lexsort((descs["z"], descs["y"], descs["x"]))
+        return descs[order], voxels[order]
+
+    def get_voxel(self, vx: int, vy: int, vz: int):
+        out = np.zeros(1, dtype=VOXEL_DTYPE)
+        found = C.c_int()
+        self._check(self.lib.mrh_get_voxel(self._ctx, vx, vy, vz, out.ctypes.data, C.byref(found)))
+        return out[0], bool(found.value)

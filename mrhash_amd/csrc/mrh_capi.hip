@@ -1,0 +1,695 @@
+// mrh_capi.hip — implementation of the C ABI (include/mrhash_hip.h) on top of the gfx950 kernels.
+//
+// Host side of the thin HIP layer: owns the device buffers, enqueues the per-frame kernel chain on one
+// stream with no host round trip, and only synchronises in the calls that hand data back.
+// There is NO CPU fallback in this file: without a HIP device mrh_create fails with MRH_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <array>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/mrhash_hip.h"
+#include "mrh_kernels.h"
+#include "mrh_mc.h"
+
+using namespace mrh;
+
+namespace {
+
+thread_local std::string g_create_err;
+
+struct EvPair {
+  hipEvent_t a, b;
+};
+
+}  // namespace
+
+struct mrh_ctx {
+  mrh_params p;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  Cam cam;
+  Map map;
+  Tab tab;
+  bool has_camera = false;
+  bool spherical = false;
+  // images
+  float* d_depth_own = nullptr;
+  uint8_t* d_rgb_own = nullptr;
+  size_t depth_cap = 0, rgb_cap = 0;
+  const float* d_depth = nullptr;
+  const uint8_t* d_rgb = nullptr;
+  int depth_rows = 0, depth_cols = 0, rgb_rows = 0, rgb_cols = 0;
+  // scratch
+  u32* d_decision = nullptr;
+  u64* d_zbuf = nullptr;  // 2 * npix
+  size_t zbuf_n = 0;
+  int4* d_realloc = nullptr;
+  int4* d_reint = nullptr;
+  int* d_flag = nullptr;
+  u64* d_upd_partials = nullptr;
+  u32* d_misc = nullptr;  // 4 words for k_get_voxel
+  int integrate_grid = 1024;
+  int low_blocks_to_allocate = 0;
+  uint64_t num_blocks = 0, slots = 0, max_triangles = 0;
+  uint64_t frames = 0;
+  // mesh (host)
+  std::vector<mrh_triangle> tris;
+  std::vector<double> V, C;
+  std::vector<int32_t> F;
+  // profiling
+  int profile = 0;
+  std::vector<EvPair> ev_pool;
+  std::vector<EvPair> ev_pending;
+  float sum_ms = 0.f, last_ms = 0.f;
+  uint64_t n_ms = 0;
+  uint64_t prev_total_updated = 0, prev_inserted = 0, prev_freed = 0, total_compact = 0;
+  uint64_t last_triangles = 0;
+  std::string err;
+};
+
+namespace {
+
+int fail(mrh_ctx* c, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (c) c->err = buf;
+  else g_create_err = buf;
+  return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                                   \
+  do {                                                                                                       \
+    hipError_t e__ = (expr);                                                                                 \
+    if (e__ != hipSuccess) return fail(ctx, MRH_ERR_DEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+  } while (0)
+
+uint64_t next_pow2(uint64_t v) {
+  uint64_t r = 1;
+  while (r < v) r <<= 1;
+  return r;
+}
+
+void free_all(mrh_ctx* c) {
+  if (!c) return;
+  (void) hipSetDevice(c->device);
+  if (c->stream) (void) hipStreamSynchronize(c->stream);
+  auto F = [](void* p) { if (p) (void) hipFree(p); };
+  F(c->tab.keys); F(c->tab.vals); F(c->tab.heap_fine); F(c->tab.heap_coarse); F(c->tab.desc_fine); F(c->tab.desc_coarse);
+  F(c->tab.pool); F(c->tab.compact); F(c->tab.ctr); F(c->tab.prof);
+  F(c->d_depth_own); F(c->d_rgb_own); F(c->d_decision); F(c->d_zbuf); F(c->d_realloc); F(c->d_reint); F(c->d_flag);
+  F(c->d_upd_partials); F(c->d_misc);
+  for (auto& e : c->ev_pool) { (void) hipEventDestroy(e.a); (void) hipEventDestroy(e.b); }
+  for (auto& e : c->ev_pending) { (void) hipEventDestroy(e.a); (void) hipEventDestroy(e.b); }
+  if (c->stream) (void) hipStreamDestroy(c->stream);
+}
+
+// (re)initialises every device structure to the empty map (voxel_data_structures.cpp:58-87 + ctor counters)
+int init_buffers(mrh_ctx* c) {
+  hipStream_t s = c->stream;
+  const Tab& t = c->tab;
+  k_init_table<<<1024, 256, 0, s>>>(t.keys, c->slots);
+  k_init_heap<<<1024, 256, 0, s>>>(t.heap_fine, (u32) c->num_blocks);
+  HIP_TRY(c, hipMemsetAsync(t.vals, 0, c->slots * sizeof(u32), s));
+  HIP_TRY(c, hipMemsetAsync(t.desc_fine, 0, c->num_blocks * sizeof(int4), s));
+  if (t.multi_res) HIP_TRY(c, hipMemsetAsync(t.desc_coarse, 0, c->num_blocks * 8 * sizeof(int4), s));
+  HIP_TRY(c, hipMemsetAsync(t.pool, 0, c->num_blocks * (size_t) kFineBytes, s));
+  int h_ctr[CTR_COUNT];
+  memset(h_ctr, 0, sizeof h_ctr);
+  h_ctr[CTR_HEAP_FINE] = (int) c->num_blocks - 1;  // voxel_data_structures.cuh:91-92
+  h_ctr[CTR_HEAP_COARSE] = -1;                     // :94-95
+  HIP_TRY(c, hipMemcpyAsync(t.ctr, h_ctr, sizeof h_ctr, hipMemcpyHostToDevice, s));
+  HIP_TRY(c, hipMemsetAsync(t.prof, 0, PROF_COUNT * sizeof(u64), s));
+  HIP_TRY(c, hipMemsetAsync(c->d_upd_partials, 0, (size_t) c->integrate_grid * sizeof(u64), s));
+  HIP_TRY(c, hipStreamSynchronize(s));
+  c->frames = 0;
+  c->prev_total_updated = c->prev_inserted = c->prev_freed = c->total_compact = 0;
+  c->sum_ms = c->last_ms = 0.f;
+  c->n_ms = 0;
+  c->tris.clear(); c->V.clear(); c->C.clear(); c->F.clear();
+  c->last_triangles = 0;
+  return MRH_OK;
+}
+
+int drain_events(mrh_ctx* c) {
+  for (auto& e : c->ev_pending) {
+    float ms = 0.f;
+    HIP_TRY(c, hipEventElapsedTime(&ms, e.a, e.b));
+    c->sum_ms += ms;
+    c->last_ms = ms;
+    c->n_ms++;
+    c->ev_pool.push_back(e);
+  }
+  c->ev_pending.clear();
+  return MRH_OK;
+}
+
+int check_device_flags(mrh_ctx* c, u32 flags) {
+  if (flags & ERR_RANGE) return fail(c, MRH_ERR_OUT_OF_RANGE, "a block coordinate left the packed-key range of +-2^20 blocks");
+  if (flags & ERR_POOL) return fail(c, MRH_ERR_CAPACITY, "SDF block pool exhausted (num_sdf_blocks = %llu)", (unsigned long long) c->num_blocks);
+  if (flags & ERR_TABLE) return fail(c, MRH_ERR_CAPACITY, "hash table probe limit reached (hash_slots = %llu)", (unsigned long long) c->slots);
+  if (flags & ERR_TRI) return fail(c, MRH_ERR_CAPACITY, "triangle buffer full (max_triangles = %llu)", (unsigned long long) c->max_triangles);
+  return MRH_OK;
+}
+
+int ensure_ready(mrh_ctx* c, const char* who) {
+  if (!c) return MRH_ERR_INVALID_ARG;
+  hipError_t e = hipSetDevice(c->device);
+  if (e != hipSuccess) return fail(c, MRH_ERR_DEVICE, "%s: hipSetDevice failed: %s", who, hipGetErrorString(e));
+  return MRH_OK;
+}
+
+// compacts every live block (no frustum filter) and returns the count; blocking
+int compact_all(mrh_ctx* c, int* out_n) {
+  hipStream_t s = c->stream;
+  HIP_TRY(c, hipMemsetAsync(&c->tab.ctr[CTR_COMPACT], 0, sizeof(int), s));
+  k_compact<<<512, 256, 0, s>>>(c->cam, c->map, c->tab, 0);
+  int n = 0;
+  HIP_TRY(c, hipMemcpyAsync(&n, &c->tab.ctr[CTR_COMPACT], sizeof(int), hipMemcpyDeviceToHost, s));
+  HIP_TRY(c, hipStreamSynchronize(s));
+  HIP_TRY(c, hipGetLastError());
+  *out_n = n;
+  return MRH_OK;
+}
+
+struct KeyHash3 {
+  size_t operator()(const std::array<uint64_t, 3>& k) const {
+    uint64_t h = k[0] * 0x9E3779B97F4A7C15ull;
+    h ^= (k[1] + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2));
+    h ^= (k[2] + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2));
+    return (size_t) h;
+  }
+};
+struct FaceHash {
+  size_t operator()(const std::array<int32_t, 3>& f) const {
+    uint64_t h = (uint64_t) (uint32_t) f[0] * 0x9E3779B97F4A7C15ull;
+    h ^= ((uint64_t) (uint32_t) f[1] + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2));
+    h ^= ((uint64_t) (uint32_t) f[2] + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2));
+    return (size_t) h;
+  }
+};
+
+// MeshExtractor::processTriangles for a single extraction (mesh_extractor.cpp:9-76):
+// soup -> vertex merge (exact bit pattern, or floor(v/eps) cells; first occurrence keeps index and colour)
+// -> drop degenerate faces -> drop repeated faces keeping the first.
+void process_triangles(mrh_ctx* c) {
+  const size_t nt = c->tris.size();
+  c->V.clear(); c->C.clear(); c->F.clear();
+  if (nt == 0) return;
+  const double eps = (double) c->p.vertices_merging_threshold;
+  const double inv_eps = eps != 0.0 ? 1.0 / eps : 0.0;
+  std::unordered_map<std::array<uint64_t, 3>, int32_t, KeyHash3> vmap;
+  vmap.reserve(nt * 3);
+  std::vector<int32_t> faces(nt * 3);
+  for (size_t i = 0; i < nt; i++)
+    for (int k = 0; k < 3; k++) {
+      const mrh_vertex& v = c->tris[i].v[k];
+      const double p[3] = {(double) v.p[0], (double) v.p[1], (double) v.p[2]};
+      std::array<uint64_t, 3> key;
+      for (int a = 0; a < 3; a++) {
+        if (eps == 0.0) memcpy(&key[a], &p[a], 8);
+        else key[a] = (uint64_t) (uint32_t) (int32_t) std::floor(p[a] * inv_eps);
+      }
+      auto it = vmap.find(key);
+      int32_t idx;
+      if (it != vmap.end()) idx = it->second;
+      else {
+        idx = (int32_t) (c->V.size() / 3);
+        vmap.emplace(key, idx);
+        c->V.insert(c->V.end(), {p[0], p[1], p[2]});
+        c->C.insert(c->C.end(), {(double) v.c[0], (double) v.c[1], (double) v.c[2]});
+      }
+      faces[i * 3 + k] = idx;
+    }
+  std::unordered_map<std::array<int32_t, 3>, char, FaceHash> seen;
+  seen.reserve(nt);
+  for (size_t i = 0; i < nt; i++) {
+    const std::array<int32_t, 3> f = {faces[i * 3], faces[i * 3 + 1], faces[i * 3 + 2]};
+    if (f[0] == f[1] || f[0] == f[2] || f[1] == f[2]) continue;
+    if (!seen.emplace(f, 1).second) continue;
+    c->F.insert(c->F.end(), {f[0], f[1], f[2]});
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* mrh_version(void) { return "mrhash_hip abi1 gfx950 hand-written-hip"; }
+
+const char* mrh_last_error(const mrh_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+int mrh_create(const mrh_params* p, mrh_ctx** out) {
+  if (!p || !out) return fail(nullptr, MRH_ERR_INVALID_ARG, "mrh_create: null argument");
+  if (p->abi_version != MRH_ABI_VERSION) return fail(nullptr, MRH_ERR_INVALID_ARG, "mrh_create: abi_version mismatch");
+  if (!(p->virtual_voxel_size > 0.f)) return fail(nullptr, MRH_ERR_INVALID_ARG, "mrh_create: virtual_voxel_size must be > 0");
+  if (p->voxel_extents_scale != 0 && p->voxel_extents_scale != 1)
+    return fail(nullptr, MRH_ERR_UNSUPPORTED, "mrh_create: voxel_extents_scale != 1 is incoherent in the reference (vhu.cuh:90-92 vs 138-140)");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(nullptr, MRH_ERR_NO_DEVICE, "mrh_create: no HIP device visible");
+  if (p->device_id < 0 || p->device_id >= ndev) return fail(nullptr, MRH_ERR_INVALID_ARG, "mrh_create: device_id %d out of range (%d devices)", p->device_id, ndev);
+  if (p->shard_count > 1 && (p->shard_rank < 0 || p->shard_rank >= p->shard_count))
+    return fail(nullptr, MRH_ERR_INVALID_ARG, "mrh_create: shard_rank out of range");
+
+  mrh_ctx* c = new mrh_ctx();
+  c->p = *p;
+  if (c->p.integration_weight_max == 0) c->p.integration_weight_max = 255;
+  if (c->p.voxel_extents_scale == 0) c->p.voxel_extents_scale = 1;
+  if (c->p.shard_count < 1) c->p.shard_count = 1;
+  c->device = p->device_id;
+  memset(&c->tab, 0, sizeof c->tab);
+  memset(&c->cam, 0, sizeof c->cam);
+#define CREATE_TRY(expr)                                                                                         \
+  do {                                                                                                           \
+    hipError_t e__ = (expr);                                                                                     \
+    if (e__ != hipSuccess) {                                                                                     \
+      fail(nullptr, MRH_ERR_DEVICE, "mrh_create: %s failed: %s", #expr, hipGetErrorString(e__));                 \
+      free_all(c);                                                                                               \
+      delete c;                                                                                                  \
+      return MRH_ERR_DEVICE;                                                                                     \
+    }                                                                                                            \
+  } while (0)
+  CREATE_TRY(hipSetDevice(c->device));
+  CREATE_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+
+  // capacities: geowrapper.cpp:37-54 when not given explicitly
+  size_t free_b = 0, total_b = 0;
+  CREATE_TRY(hipMemGetInfo(&free_b, &total_b));
+  const double to_alloc = (double) free_b * 0.70;  // SDFBlocks_ratio
+  c->num_blocks = p->num_sdf_blocks ? p->num_sdf_blocks : (uint64_t) ((to_alloc * 0.70) / (12.0 * 512.0));
+  if (c->num_blocks >= (1ull << 28)) c->num_blocks = (1ull << 28) - 1;  // 31-bit coarse unit ids
+  c->max_triangles = p->max_triangles ? p->max_triangles : (uint64_t) ((to_alloc * 0.25) / 72.0);
+  c->slots = next_pow2(p->hash_slots ? p->hash_slots : 4 * c->num_blocks);
+  if (c->slots < 1024) c->slots = 1024;
+  c->low_blocks_to_allocate = (int) ((float) c->num_blocks * 0.1f);  // voxel_data_structures.cuh:57-61
+
+  Tab& t = c->tab;
+  t.slot_mask = (u32) (c->slots - 1);
+  t.max_probe = 512;
+  t.cap_blocks = (u32) c->num_blocks;
+  t.multi_res = p->sdf_var_threshold > 0.f ? 1u : 0u;
+  CREATE_TRY(hipMalloc((void**) &t.keys, c->slots * sizeof(u64)));
+  CREATE_TRY(hipMalloc((void**) &t.vals, c->slots * sizeof(u32)));
+  CREATE_TRY(hipMalloc((void**) &t.heap_fine, (c->num_blocks + 1) * sizeof(u32)));
+  CREATE_TRY(hipMalloc((void**) &t.desc_fine, c->num_blocks * sizeof(int4)));
+  if (t.multi_res) {
+    CREATE_TRY(hipMalloc((void**) &t.heap_coarse, (c->num_blocks * 8 + 9) * sizeof(u32)));
+    CREATE_TRY(hipMalloc((void**) &t.desc_coarse, c->num_blocks * 8 * sizeof(int4)));
+    CREATE_TRY(hipMalloc((void**) &c->d_realloc, c->num_blocks * sizeof(int4)));
+    CREATE_TRY(hipMalloc((void**) &c->d_reint, c->num_blocks * sizeof(int4)));
+  }
+  CREATE_TRY(hipMalloc((void**) &t.pool, c->num_blocks * (size_t) kFineBytes));
+  CREATE_TRY(hipMalloc((void**) &t.compact, c->num_blocks * (t.multi_res ? 9 : 1) * sizeof(int4)));
+  CREATE_TRY(hipMalloc((void**) &c->d_decision, c->num_blocks * (t.multi_res ? 9 : 1) * sizeof(u32)));
+  CREATE_TRY(hipMalloc((void**) &t.ctr, CTR_COUNT * sizeof(int)));
+  CREATE_TRY(hipMalloc((void**) &t.prof, PROF_COUNT * sizeof(u64)));
+  CREATE_TRY(hipMalloc((void**) &c->d_flag, sizeof(int)));
+  CREATE_TRY(hipMalloc((void**) &c->d_misc, 4 * sizeof(u32)));
+  CREATE_TRY(hipMalloc((void**) &c->d_upd_partials, (size_t) c->integrate_grid * sizeof(u64)));
+#undef CREATE_TRY
+
+  Map& m = c->map;
+  m.vs = p->virtual_voxel_size;
+  m.trunc = p->sdf_truncation;
+  m.trunc_scale = p->sdf_truncation_scale;
+  m.var_threshold = p->sdf_var_threshold;
+  m.mc_threshold = p->marching_cubes_threshold;
+  m.weight_sample = p->integration_weight_sample & 0xFF;
+  m.weight_max = c->p.integration_weight_max & 0xFF;
+  m.min_weight_threshold = p->min_weight_threshold;
+  m.shard_rank = c->p.shard_rank;
+  m.shard_count = c->p.shard_count;
+
+  int rc = init_buffers(c);
+  if (rc != MRH_OK) {
+    g_create_err = c->err;
+    free_all(c);
+    delete c;
+    return rc;
+  }
+  // identity pose; camera must be set by the caller (geowrapper.cpp:80 installs a 1x1 placeholder)
+  const float I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  const float z[3] = {0, 0, 0};
+  mrh_set_pose(c, I, z);
+  c->cam.min_depth = p->min_depth;
+  c->cam.max_depth = p->max_depth;
+  *out = c;
+  return MRH_OK;
+}
+
+int mrh_destroy(mrh_ctx* c) {
+  if (!c) return MRH_OK;
+  free_all(c);
+  delete c;
+  return MRH_OK;
+}
+
+int mrh_reset(mrh_ctx* c) {
+  int rc = ensure_ready(c, "mrh_reset");
+  if (rc) return rc;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  rc = drain_events(c);
+  if (rc) return rc;
+  return init_buffers(c);
+}
+
+int mrh_set_camera(mrh_ctx* c, float fx, float fy, float cx, float cy, int rows, int cols, float min_depth, float max_depth, int model) {
+  if (!c) return MRH_ERR_INVALID_ARG;
+  if (rows <= 0 || cols <= 0 || (model != MRH_CAMERA_PINHOLE && model != MRH_CAMERA_SPHERICAL))
+    return fail(c, MRH_ERR_INVALID_ARG, "mrh_set_camera: bad rows/cols/model");
+  Cam& k = c->cam;
+  // camera.cuh:19-34
+  k.fx = fx; k.fy = fy; k.ifx = 1.f / fx; k.ify = 1.f / fy; k.cx = cx; k.cy = cy;
+  k.rows = rows; k.cols = cols;
+  k.row_thr = (int) ((float) (unsigned) rows * 0.5f);
+  k.col_thr = (int) ((float) (unsigned) cols * 0.5f);
+  k.min_depth = min_depth; k.max_depth = max_depth;
+  k.max_int_dist = max_depth;  // geowrapper.cpp:111 setIntegrationDistance(max_depth)
+  c->spherical = model == MRH_CAMERA_SPHERICAL;
+  c->has_camera = true;
+  return MRH_OK;
+}
+
+int mrh_set_pose(mrh_ctx* c, const float R[9], const float t[3]) {
+  if (!c || !R || !t) return MRH_ERR_INVALID_ARG;
+  Cam& k = c->cam;
+  memcpy(k.R, R, 36);
+  memcpy(k.t, t, 12);
+  // cuda_algebra.cuh:45-57, 137-143 (the reference recomputes this per thread on the device)
+  k.Ri[0] = R[0]; k.Ri[1] = R[3]; k.Ri[2] = R[6];
+  k.Ri[3] = R[1]; k.Ri[4] = R[4]; k.Ri[5] = R[7];
+  k.Ri[6] = R[2]; k.Ri[7] = R[5]; k.Ri[8] = R[8];
+  // evaluated with separate products and sums (no FMA): this TU is built with -ffp-contract=off
+  const float x = k.Ri[0] * t[0] + k.Ri[1] * t[1] + k.Ri[2] * t[2];
+  const float y = k.Ri[3] * t[0] + k.Ri[4] * t[1] + k.Ri[5] * t[2];
+  const float z = k.Ri[6] * t[0] + k.Ri[7] * t[1] + k.Ri[8] * t[2];
+  k.ti[0] = -x; k.ti[1] = -y; k.ti[2] = -z;
+  return MRH_OK;
+}
+
+int mrh_upload_depth(mrh_ctx* c, const float* depth, int rows, int cols) {
+  int rc = ensure_ready(c, "mrh_upload_depth");
+  if (rc) return rc;
+  if (!depth || rows <= 0 || cols <= 0) return fail(c, MRH_ERR_INVALID_ARG, "mrh_upload_depth: bad argument");
+  const size_t bytes = (size_t) rows * cols * sizeof(float);
+  if (bytes > c->depth_cap) {
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->d_depth_own) HIP_TRY(c, hipFree(c->d_depth_own));
+    c->d_depth_own = nullptr;
+    HIP_TRY(c, hipMalloc((void**) &c->d_depth_own, bytes));
+    c->depth_cap = bytes;
+  }
+  HIP_TRY(c, hipMemcpyAsync(c->d_depth_own, depth, bytes, hipMemcpyHostToDevice, c->stream));
+  c->d_depth = c->d_depth_own;
+  c->depth_rows = rows; c->depth_cols = cols;
+  return MRH_OK;
+}
+
+int mrh_upload_rgb(mrh_ctx* c, const uint8_t* rgb, int rows, int cols) {
+  int rc = ensure_ready(c, "mrh_upload_rgb");
+  if (rc) return rc;
+  if (!rgb || rows <= 0 || cols <= 0) return fail(c, MRH_ERR_INVALID_ARG, "mrh_upload_rgb: bad argument");
+  const size_t bytes = (size_t) rows * cols * 3;
+  if (bytes > c->rgb_cap) {
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->d_rgb_own) HIP_TRY(c, hipFree(c->d_rgb_own));
+    c->d_rgb_own = nullptr;
+    HIP_TRY(c, hipMalloc((void**) &c->d_rgb_own, bytes));
+    c->rgb_cap = bytes;
+  }
+  HIP_TRY(c, hipMemcpyAsync(c->d_rgb_own, rgb, bytes, hipMemcpyHostToDevice, c->stream));
+  c->d_rgb = c->d_rgb_own;
+  c->rgb_rows = rows; c->rgb_cols = cols;
+  return MRH_OK;
+}
+
+int mrh_set_depth_device(mrh_ctx* c, const float* d_depth, int rows, int cols) {
+  if (!c || !d_depth || rows <= 0 || cols <= 0) return fail(c, MRH_ERR_INVALID_ARG, "mrh_set_depth_device: bad argument");
+  c->d_depth = d_depth; c->depth_rows = rows; c->depth_cols = cols;
+  return MRH_OK;
+}
+
+int mrh_set_rgb_device(mrh_ctx* c, const uint8_t* d_rgb, int rows, int cols) {
+  if (!c || !d_rgb || rows <= 0 || cols <= 0) return fail(c, MRH_ERR_INVALID_ARG, "mrh_set_rgb_device: bad argument");
+  c->d_rgb = d_rgb; c->rgb_rows = rows; c->rgb_cols = cols;
+  return MRH_OK;
+}
+
+// voxel_data_structures.cpp:90-110 VoxelContainer::integrate, as one sync-free kernel chain
+int mrh_integrate(mrh_ctx* c, int n_frames_invalidate) {
+  int rc = ensure_ready(c, "mrh_integrate");
+  if (rc) return rc;
+  if (!c->has_camera) return fail(c, MRH_ERR_STATE, "mrh_integrate: set_camera has not been called");
+  if (c->spherical) return fail(c, MRH_ERR_UNSUPPORTED, "mrh_integrate: spherical (LiDAR) camera model is outside this round's scope");
+  if (!c->d_depth || !c->d_rgb) return fail(c, MRH_ERR_STATE, "mrh_integrate: depth and rgb images are required");
+  const Cam& k = c->cam;
+  if (c->depth_rows != k.rows || c->depth_cols != k.cols || c->rgb_rows != k.rows || c->rgb_cols != k.cols)
+    return fail(c, MRH_ERR_INVALID_ARG, "mrh_integrate: image shape does not match the camera");
+  const int max_num_frames = n_frames_invalidate < 0 ? c->p.n_frames_invalidate_voxels : n_frames_invalidate;
+  hipStream_t s = c->stream;
+  const Tab& t = c->tab;
+  const Map& m = c->map;
+
+  if (t.multi_res) {
+    // vds.cu:885-891 (coarse free-list refill), decided on the device
+    k_refill_decide<<<1, 64, 0, s>>>(t, c->low_blocks_to_allocate, c->d_flag);
+    k_refill<<<(c->low_blocks_to_allocate + 255) / 256, 256, 0, s>>>(t, c->low_blocks_to_allocate, c->d_flag);
+  }
+  const dim3 tiles((k.cols + kTile - 1) / kTile, (k.rows + kTile - 1) / kTile);
+  if (c->profile) k_alloc<true><<<tiles, dim3(kTile, kTile), 0, s>>>(k, m, t, c->d_depth);
+  else k_alloc<false><<<tiles, dim3(kTile, kTile), 0, s>>>(k, m, t, c->d_depth);
+  k_compact<<<512, 256, 0, s>>>(k, m, t, 1);
+
+  if (c->profile) {
+    EvPair ev;
+    if (!c->ev_pool.empty()) { ev = c->ev_pool.back(); c->ev_pool.pop_back(); }
+    else {
+      if (c->ev_pending.size() >= 4096) { HIP_TRY(c, hipStreamSynchronize(s)); rc = drain_events(c); if (rc) return rc; ev = c->ev_pool.back(); c->ev_pool.pop_back(); }
+      else { HIP_TRY(c, hipEventCreate(&ev.a)); HIP_TRY(c, hipEventCreate(&ev.b)); }
+    }
+    HIP_TRY(c, hipEventRecord(ev.a, s));
+    k_integrate<true><<<c->integrate_grid, 512, 0, s>>>(k, m, t, c->d_depth, c->d_rgb, c->d_upd_partials);
+    HIP_TRY(c, hipEventRecord(ev.b, s));
+    c->ev_pending.push_back(ev);
+  } else {
+    k_integrate<false><<<c->integrate_grid, 512, 0, s>>>(k, m, t, c->d_depth, c->d_rgb, c->d_upd_partials);
+  }
+
+  if (t.multi_res && c->frames > 0) {
+    // checkVarSDF -> reallocBlocks -> flatAndReduceHashTable(camera) -> reintegrateDepthMap
+    HIP_TRY(c, hipMemsetAsync(&t.ctr[CTR_NREALLOC], 0, 2 * sizeof(int), s));  // NREALLOC, NREINT
+    k_check_var<<<2048, 64, 0, s>>>(m, t, c->d_realloc);
+    k_realloc<<<64, 256, 0, s>>>(t, c->d_realloc, c->d_reint);
+    k_compact<<<512, 256, 0, s>>>(k, m, t, 1);
+    k_reintegrate<<<1024, 64, 0, s>>>(k, m, t, c->d_depth, c->d_rgb, c->d_reint);
+  }
+
+  if (max_num_frames > 0) {
+    // voxel_data_structures.cpp:137-145 garbageCollect
+    if (c->frames > 0 && c->frames % (uint64_t) max_num_frames == 0) {
+      const size_t npix = (size_t) k.rows * k.cols;
+      if (c->zbuf_n < npix) {
+        HIP_TRY(c, hipStreamSynchronize(s));
+        if (c->d_zbuf) HIP_TRY(c, hipFree(c->d_zbuf));
+        c->d_zbuf = nullptr;
+        HIP_TRY(c, hipMalloc((void**) &c->d_zbuf, 2 * npix * sizeof(u64)));
+        c->zbuf_n = npix;
+      }
+      HIP_TRY(c, hipMemsetAsync(c->d_zbuf, 0xFF, 2 * npix * sizeof(u64), s));
+      k_starve<0><<<c->integrate_grid, 512, 0, s>>>(k, m, t, c->d_zbuf, c->d_zbuf + npix);
+      k_starve<1><<<c->integrate_grid, 512, 0, s>>>(k, m, t, c->d_zbuf, c->d_zbuf + npix);
+      k_starve<2><<<c->integrate_grid, 512, 0, s>>>(k, m, t, c->d_zbuf, c->d_zbuf + npix);
+    }
+    const float thr = m.trunc + m.trunc_scale * k.max_depth;  // getTruncation(camera.maxDepth(), ...), vds.cu:1720
+    k_gc_identify<<<c->integrate_grid, 512, 0, s>>>(t, thr, c->d_decision);
+    if (c->profile) k_gc_free<true><<<256, 256, 0, s>>>(t, c->d_decision);
+    else k_gc_free<false><<<256, 256, 0, s>>>(t, c->d_decision);
+  }
+  c->frames++;
+  HIP_TRY(c, hipGetLastError());
+  return MRH_OK;
+}
+
+int mrh_sync(mrh_ctx* c) {
+  int rc = ensure_ready(c, "mrh_sync");
+  if (rc) return rc;
+  u32 flags = 0;
+  HIP_TRY(c, hipMemcpyAsync(&flags, &c->tab.ctr[CTR_ERROR], sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipGetLastError());
+  rc = drain_events(c);
+  if (rc) return rc;
+  return check_device_flags(c, flags);
+}
+
+int mrh_set_profile(mrh_ctx* c, int enabled) {
+  if (!c) return MRH_ERR_INVALID_ARG;
+  c->profile = enabled ? 1 : 0;
+  return MRH_OK;
+}
+
+int mrh_get_stats(mrh_ctx* c, mrh_stats* out) {
+  int rc = ensure_ready(c, "mrh_get_stats");
+  if (rc) return rc;
+  if (!out) return MRH_ERR_INVALID_ARG;
+  hipStream_t s = c->stream;
+  HIP_TRY(c, hipMemsetAsync(&c->tab.ctr[CTR_LIVE_FINE], 0, 2 * sizeof(int), s));
+  k_count_live<<<256, 256, 0, s>>>(c->tab);
+  int h_ctr[CTR_COUNT];
+  u64 h_prof[PROF_COUNT];
+  std::vector<u64> partials((size_t) c->integrate_grid);
+  HIP_TRY(c, hipMemcpyAsync(h_ctr, c->tab.ctr, sizeof h_ctr, hipMemcpyDeviceToHost, s));
+  HIP_TRY(c, hipMemcpyAsync(h_prof, c->tab.prof, sizeof h_prof, hipMemcpyDeviceToHost, s));
+  HIP_TRY(c, hipMemcpyAsync(partials.data(), c->d_upd_partials, partials.size() * sizeof(u64), hipMemcpyDeviceToHost, s));
+  HIP_TRY(c, hipStreamSynchronize(s));
+  HIP_TRY(c, hipGetLastError());
+  rc = drain_events(c);
+  if (rc) return rc;
+  u64 total_upd = 0;
+  for (u64 v : partials) total_upd += v;
+  memset(out, 0, sizeof *out);
+  out->frames_integrated = c->frames;
+  out->num_sdf_blocks = c->num_blocks;
+  out->occupied_fine = (uint64_t) h_ctr[CTR_LIVE_FINE];
+  out->occupied_coarse = (uint64_t) h_ctr[CTR_LIVE_COARSE];
+  out->free_fine = (int64_t) h_ctr[CTR_HEAP_FINE] + 1;
+  out->free_coarse = (int64_t) h_ctr[CTR_HEAP_COARSE] + 1;
+  out->last_compact_blocks = (uint64_t) h_ctr[CTR_COMPACT];
+  out->total_updated_voxels = total_upd;
+  out->last_updated_voxels = total_upd - c->prev_total_updated;
+  out->last_inserted_blocks = h_prof[PROF_INSERTED] - c->prev_inserted;
+  out->last_freed_blocks = h_prof[PROF_FREED] - c->prev_freed;
+  c->prev_total_updated = total_upd;
+  c->prev_inserted = h_prof[PROF_INSERTED];
+  c->prev_freed = h_prof[PROF_FREED];
+  out->total_compact_blocks = h_prof[PROF_COMPACT];
+  out->last_triangles = c->last_triangles;
+  out->last_integrate_kernel_ms = c->last_ms;
+  out->sum_integrate_kernel_ms = c->sum_ms;
+  out->n_integrate_kernel = c->n_ms;
+  out->error_flags = (u32) h_ctr[CTR_ERROR];
+  return MRH_OK;
+}
+
+int mrh_extract_triangles(mrh_ctx* c, const mrh_triangle** out_tris, uint64_t* out_n) {
+  int rc = ensure_ready(c, "mrh_extract_triangles");
+  if (rc) return rc;
+  if (!out_tris || !out_n) return MRH_ERR_INVALID_ARG;
+  hipStream_t s = c->stream;
+  int n = 0;
+  rc = compact_all(c, &n);
+  if (rc) return rc;
+  c->tris.clear();
+  c->last_triangles = 0;
+  if (n > 0) {
+    // canonical order: sort the block list by position (packed-key order == (x,y,z) order)
+    std::vector<int4> list((size_t) n);
+    HIP_TRY(c, hipMemcpy(list.data(), c->tab.compact, (size_t) n * sizeof(int4), hipMemcpyDeviceToHost));
+    std::sort(list.begin(), list.end(), [](const int4& a, const int4& b) {
+      if (a.x != b.x) return a.x < b.x;
+      if (a.y != b.y) return a.y < b.y;
+      return a.z < b.z;
+    });
+    HIP_TRY(c, hipMemcpy(c->tab.compact, list.data(), (size_t) n * sizeof(int4), hipMemcpyHostToDevice));
+    u32* d_counts = nullptr;
+    u64* d_offsets = nullptr;
+    HIP_TRY(c, hipMalloc((void**) &d_counts, (size_t) n * sizeof(u32)));
+    HIP_TRY(c, hipMalloc((void**) &d_offsets, (size_t) n * sizeof(u64)));
+    const int grid = n < 4096 ? n : 4096;
+    k_mc<false><<<grid, 512, 0, s>>>(c->map, c->tab, c->tab.compact, n, d_counts, nullptr, nullptr, 0);
+    std::vector<u32> counts((size_t) n);
+    HIP_TRY(c, hipMemcpyAsync(counts.data(), d_counts, (size_t) n * sizeof(u32), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    std::vector<u64> offsets((size_t) n);
+    u64 total = 0;
+    for (int i = 0; i < n; i++) { offsets[i] = total; total += counts[i]; }
+    if (total > c->max_triangles) {
+      (void) hipFree(d_counts); (void) hipFree(d_offsets);
+      return fail(c, MRH_ERR_CAPACITY, "triangle buffer full: %llu triangles > max_triangles %llu", (unsigned long long) total, (unsigned long long) c->max_triangles);
+    }
+    if (total > 0) {
+      mrh_triangle* d_tris = nullptr;
+      HIP_TRY(c, hipMalloc((void**) &d_tris, total * sizeof(mrh_triangle)));
+      HIP_TRY(c, hipMemcpyAsync(d_offsets, offsets.data(), (size_t) n * sizeof(u64), hipMemcpyHostToDevice, s));
+      k_mc<true><<<grid, 512, 0, s>>>(c->map, c->tab, c->tab.compact, n, d_counts, d_offsets, d_tris, total);
+      c->tris.resize(total);
+      HIP_TRY(c, hipMemcpyAsync(c->tris.data(), d_tris, total * sizeof(mrh_triangle), hipMemcpyDeviceToHost, s));
+      HIP_TRY(c, hipStreamSynchronize(s));
+      HIP_TRY(c, hipFree(d_tris));
+    }
+    HIP_TRY(c, hipFree(d_counts));
+    HIP_TRY(c, hipFree(d_offsets));
+    HIP_TRY(c, hipGetLastError());
+  }
+  c->last_triangles = c->tris.size();
+  process_triangles(c);
+  *out_tris = c->tris.empty() ? nullptr : c->tris.data();
+  *out_n = c->tris.size();
+  return MRH_OK;
+}
+
+int mrh_extract_mesh(mrh_ctx* c, const double** v, uint64_t* nv, const int32_t** f, uint64_t* nf, const double** col) {
+  if (!c || !v || !nv || !f || !nf || !col) return MRH_ERR_INVALID_ARG;
+  *v = c->V.empty() ? nullptr : c->V.data();
+  *nv = c->V.size() / 3;
+  *f = c->F.empty() ? nullptr : c->F.data();
+  *nf = c->F.size() / 3;
+  *col = c->C.empty() ? nullptr : c->C.data();
+  return MRH_OK;
+}
+
+int mrh_dump_blocks(mrh_ctx* c, mrh_block_desc* descs, mrh_voxel* voxels, uint64_t capacity, uint64_t* out_n) {
+  int rc = ensure_ready(c, "mrh_dump_blocks");
+  if (rc) return rc;
+  if (!out_n) return MRH_ERR_INVALID_ARG;
+  int n = 0;
+  rc = compact_all(c, &n);
+  if (rc) return rc;
+  *out_n = (uint64_t) n;
+  if (!descs) return MRH_OK;
+  if ((uint64_t) n > capacity) return fail(c, MRH_ERR_CAPACITY, "mrh_dump_blocks: capacity %llu < %d live blocks", (unsigned long long) capacity, n);
+  const int chunk = 8192;  // 48 MiB of voxels per round trip
+  int4* d_descs = nullptr;
+  char* d_vox = nullptr;
+  HIP_TRY(c, hipMalloc((void**) &d_descs, (size_t) chunk * sizeof(int4)));
+  HIP_TRY(c, hipMalloc((void**) &d_vox, (size_t) chunk * kFineBytes));
+  for (int first = 0; first < n; first += chunk) {
+    const int cnt = (n - first) < chunk ? (n - first) : chunk;
+    k_dump<<<cnt < 2048 ? cnt : 2048, 512, 0, c->stream>>>(c->tab, first, cnt, d_descs, d_vox);
+    HIP_TRY(c, hipMemcpyAsync(&descs[first], d_descs, (size_t) cnt * sizeof(int4), hipMemcpyDeviceToHost, c->stream));
+    if (voxels) HIP_TRY(c, hipMemcpyAsync(&voxels[(size_t) first * 512], d_vox, (size_t) cnt * kFineBytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+  }
+  HIP_TRY(c, hipFree(d_descs));
+  HIP_TRY(c, hipFree(d_vox));
+  HIP_TRY(c, hipGetLastError());
+  return MRH_OK;
+}
+
+int mrh_get_voxel(mrh_ctx* c, int32_t vx, int32_t vy, int32_t vz, mrh_voxel* out, int* out_found) {
+  int rc = ensure_ready(c, "mrh_get_voxel");
+  if (rc) return rc;
+  if (!out) return MRH_ERR_INVALID_ARG;
+  k_get_voxel<<<1, 1, 0, c->stream>>>(c->map, c->tab, vx, vy, vz, c->d_misc);
+  u32 h[4];
+  HIP_TRY(c, hipMemcpyAsync(h, c->d_misc, sizeof h, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  memcpy(&out->sdf, &h[0], 4);
+  memcpy(&out->sum_squared, &h[1], 4);
+  out->rgb[0] = h[2] & 0xFF; out->rgb[1] = (h[2] >> 8) & 0xFF; out->rgb[2] = (h[2] >> 16) & 0xFF;
+  out->weight = (uint8_t) (h[2] >> 24);
+  if (out_found) *out_found = (int) h[3];
+  return MRH_OK;
+}
+
+}  // extern "C"

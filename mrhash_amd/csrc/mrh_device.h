@@ -1,0 +1,295 @@
+// mrh_device.h — POD parameter blocks and device-side arithmetic for the gfx950 fusion kernels.
+//
+// Arithmetic spec (shared, by construction, with the CPU oracle used in tests): IEEE-754 binary32,
+// no FMA contraction (-ffp-contract=off), correctly rounded / and sqrt
+// (-fhip-fp32-correctly-rounded-divide-sqrt), rsqrtf restated as 1.0f / sqrtf, float->int conversions
+// saturating with NaN -> 0.  Each helper cites the reference lines whose semantics it restates
+// (paths relative to mrhash/src/sdf/ of rvp-group/mrhash).
+//
+// Kernels receive these structs BY VALUE (kernarg segment -> SGPRs); the reference instead
+// dereferences device-resident copies of host C++ objects (voxel_data_structures.cuh:63,116-118).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mrh {
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+// ---- capacities / constants (params.h:4-38) ----------------------------------------------------
+constexpr int kBlockSide = 8;            // sdf_block_size
+constexpr int kBlockVoxels = 512;        // total_sdf_block_size
+constexpr int kCoarseVoxels = 64;
+constexpr int kFineBytes = 6144;         // 512 * 12
+constexpr int kCoarseBytes = 768;        // 64 * 12
+constexpr u32 kMaxDdaIter = 1024;        // max_dda_iteration_count
+constexpr float kFloatEps = 1e-6f;       // FLOAT_EPSILON
+
+constexpr u64 kKeyEmpty = 0xFFFFFFFFFFFFFFFFull;
+constexpr u64 kKeyTomb = 0xFFFFFFFFFFFFFFFEull;
+constexpr int kKeyBias = 1 << 20;        // block coordinates in [-2^20, 2^20)
+constexpr u32 kValCoarseBit = 0x80000000u;
+
+// device counters (one int array, indices below)
+enum Ctr : int {
+  CTR_HEAP_FINE = 0,     // stack top of the fine free list  (= d_heapCounterHigh_, vds.cu:33-40)
+  CTR_HEAP_COARSE = 1,   // stack top of the coarse free list (= d_heapCounterLow_)
+  CTR_COMPACT = 2,       // number of compact (in-frustum) entries of this frame
+  CTR_HWM_FINE = 3,      // 1 + highest fine block index ever handed out
+  CTR_ERROR = 4,         // sticky error flags
+  CTR_NREALLOC = 5,
+  CTR_NREINT = 6,
+  CTR_LIVE_FINE = 7,
+  CTR_LIVE_COARSE = 8,
+  CTR_TOMBS = 9,
+  CTR_NTRI = 10,
+  CTR_DUMP = 11,
+  CTR_COUNT = 16
+};
+// 64-bit profile counters
+enum Prof : int { PROF_UPDATED = 0, PROF_INSERTED = 1, PROF_FREED = 2, PROF_COMPACT = 3, PROF_COUNT = 4 };
+
+enum ErrBit : u32 { ERR_POOL = 1u, ERR_TABLE = 2u, ERR_RANGE = 4u, ERR_TRI = 8u };
+
+struct Cam {
+  float fx, fy, cx, cy, ifx, ify;
+  int rows, cols, row_thr, col_thr;
+  float min_depth, max_depth, max_int_dist;
+  float R[9], t[3];    // camera in world
+  float Ri[9], ti[3];  // world in camera = (R^T, -(R^T t))   cuda_algebra.cuh:137-143
+};
+
+struct Map {
+  float vs;           // virtual_voxel_size
+  float trunc;        // sdf_truncation
+  float trunc_scale;  // sdf_truncation_scale
+  float var_threshold;
+  float mc_threshold;
+  int weight_sample;  // as u8 (vds.cu:1101)
+  int weight_max;     // as u8 (vds.cu:1102)
+  int min_weight_threshold;
+  int shard_rank, shard_count;
+};
+
+// Open-address table + pools.  Layout in HBM:
+//   keys[slots]      u64  packed (x,y,z) | EMPTY | TOMB, linear probing
+//   vals[slots]      u32  bit31 = coarse, bits0..30 = fine block index H or coarse unit u = 8H + k
+//   desc_fine[cap]   int4 {x, y, z, live}   indexed by H
+//   desc_coarse[8cap] int4 {x, y, z, live}  indexed by u
+//   pool[cap * 6144] per fine block: sdf f32[512] | sum_squared f32[512] | rgbw u32[512]
+//                    a coarse unit u lives at H*6144 + k*768 as sdf f32[64] | sum_sq f32[64] | rgbw u32[64]
+struct Tab {
+  u64* keys;
+  u32* vals;
+  u32 slot_mask;
+  u32 max_probe;
+  u32* heap_fine;
+  u32* heap_coarse;
+  int4* desc_fine;
+  int4* desc_coarse;
+  char* pool;
+  int4* compact;  // {x, y, z, val}
+  int* ctr;
+  u64* prof;
+  u32 cap_blocks;
+  u32 multi_res;  // 1 when sdf_var_threshold > 0
+};
+
+// ---- scalar helpers -----------------------------------------------------------------------------
+
+// float -> int: truncate toward zero, saturate, NaN -> 0 (what v_cvt_i32_f32 does; spelled out so the
+// compiler cannot exploit out-of-range UB).
+__device__ __forceinline__ int f2i(float v) {
+  if (v != v) return 0;
+  if (v >= 2147483648.0f) return 2147483647;
+  if (v <= -2147483648.0f) return (-2147483647 - 1);
+  return (int) v;
+}
+// cuda_math.cuh:62-64
+__device__ __forceinline__ int signi(float v) { return (0.f < v) - (v < 0.f); }
+// cuda_math.cuh:947-949
+__device__ __forceinline__ float clampf(float f, float a, float b) { return fmaxf(a, fminf(f, b)); }
+
+struct f3 { float x, y, z; };
+struct i3 { int x, y, z; };
+__device__ __forceinline__ f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ i3 mki3(int x, int y, int z) { i3 r; r.x = x; r.y = y; r.z = z; return r; }
+
+// cuda_algebra.cuh:71-75, 146-148: rotation * point + translation (sum left to right, then + t)
+__device__ __forceinline__ f3 se3_apply(const float* R, const float* t, f3 p) {
+  f3 r;
+  r.x = R[0] * p.x + R[1] * p.y + R[2] * p.z;
+  r.y = R[3] * p.x + R[4] * p.y + R[5] * p.z;
+  r.z = R[6] * p.x + R[7] * p.y + R[8] * p.z;
+  r.x = r.x + t[0];
+  r.y = r.y + t[1];
+  r.z = r.z + t[2];
+  return r;
+}
+
+// vhu.cuh:66-68
+__device__ __forceinline__ f3 voxel_to_world(float vs, i3 v) { return mk3(v.x * vs, v.y * vs, v.z * vs); }
+
+// vhu.cuh:143-151 worldPointToVirtualVoxelPos
+__device__ __forceinline__ i3 world_to_voxel(float vs, f3 pt) {
+  const f3 p = mk3(pt.x / vs, pt.y / vs, pt.z / vs);
+  const float epsilon = 1e-5;
+  f3 a = mk3(p.x + (float) signi(p.x) * 0.5f, p.y + (float) signi(p.y) * 0.5f, p.z + (float) signi(p.z) * 0.5f);
+  a.x = (a.x >= 0) ? floorf(a.x + epsilon) : ceilf(a.x - epsilon);
+  a.y = (a.y >= 0) ? floorf(a.y + epsilon) : ceilf(a.y - epsilon);
+  a.z = (a.z >= 0) ? floorf(a.z + epsilon) : ceilf(a.z - epsilon);
+  return mki3(f2i(a.x), f2i(a.y), f2i(a.z));
+}
+
+// vhu.cuh:75-103 virtualVoxelPosToSDFBlock (through float world coordinates, absolute 1e-5 epsilon)
+__device__ __forceinline__ i3 voxel_to_block(i3 v, float vs) {
+  const float epsilon = 1e-5;
+  if (v.x < 0) v.x -= (kBlockSide - 1);
+  if (v.y < 0) v.y -= (kBlockSide - 1);
+  if (v.z < 0) v.z -= (kBlockSide - 1);
+  const f3 pw = voxel_to_world(vs, v);
+  const float mbs = (1.0f * (float) kBlockSide) * vs;  // voxel_extents == 1 (only coherent value)
+  i3 b;
+  b.x = f2i((pw.x >= 0) ? floorf((pw.x + epsilon) / mbs) : ceilf((pw.x - epsilon) / mbs));
+  b.y = f2i((pw.y >= 0) ? floorf((pw.y + epsilon) / mbs) : ceilf((pw.y - epsilon) / mbs));
+  b.z = f2i((pw.z >= 0) ? floorf((pw.z + epsilon) / mbs) : ceilf((pw.z - epsilon) / mbs));
+  return b;
+}
+__device__ __forceinline__ i3 world_to_block(float vs, f3 pt) { return voxel_to_block(world_to_voxel(vs, pt), vs); }
+
+// vhu.cuh:184-187
+__device__ __forceinline__ float get_truncation(float z, float trunc, float scale) { return trunc + scale * z; }
+
+// local index of a voxel inside its block, dense in the block's own side (fine: 8, coarse: 4);
+// see DESIGN.md "coarse reads" for why this is not vhu.cuh:110-128's stride-8 form.
+__device__ __forceinline__ u32 voxel_local_index(i3 v, int res) {
+  int lx = v.x % kBlockSide, ly = v.y % kBlockSide, lz = v.z % kBlockSide;
+  if (lx < 0) lx += kBlockSide;
+  if (ly < 0) ly += kBlockSide;
+  if (lz < 0) lz += kBlockSide;
+  const int side = kBlockSide >> res;
+  lx >>= res; ly >>= res; lz >>= res;
+  return (u32) (lz * side * side + ly * side + lx);
+}
+
+// ---- camera (pinhole): camera.cuh:84-203 ----------------------------------------------------------
+
+// camera.cuh:88
+__device__ __forceinline__ f3 inverse_projection(const Cam& c, u32 row, u32 col, float d) {
+  return mk3(d * (c.ifx * ((float) col - c.cx - 0.5f)), d * (c.ify * ((float) row - c.cy - 0.5f)), d * 1.f);
+}
+
+// camera.cuh:131-147 (exact image bounds) / :167-182 (bounds enlarged by half the image, APPROX)
+template <bool APPROX>
+__device__ __forceinline__ bool project_point(const Cam& c, f3 pc, int& row, int& col) {
+  if (pc.z <= c.min_depth || pc.z > c.max_depth) return false;
+  row = f2i((c.fy * pc.y / pc.z + c.cy) + 0.5f);
+  col = f2i((c.fx * pc.x / pc.z + c.cx) + 0.5f);
+  if (APPROX)
+    return row >= -c.row_thr && col >= -c.col_thr && row < (c.rows + c.row_thr) && col < (c.cols + c.col_thr);
+  return row >= 0 && col >= 0 && row < c.rows && col < c.cols;
+}
+
+// vds.cu:66-77 isSDFBlockInCameraFrustumApprox: any of the 8 corner voxels (offsets 0 / 7, params.h:41-49)
+__device__ __forceinline__ bool block_in_frustum_approx(const Cam& c, float vs, i3 b) {
+#pragma unroll 1
+  for (int i = 0; i < 8; i++) {
+    // params.h:41-49 order: z toggles fastest, then y, then x
+    const i3 v = mki3(b.x * kBlockSide + ((i & 4) ? 7 : 0), b.y * kBlockSide + ((i & 2) ? 7 : 0), b.z * kBlockSide + ((i & 1) ? 7 : 0));
+    const f3 pc = se3_apply(c.Ri, c.ti, voxel_to_world(vs, v));
+    int r, cc;
+    if (project_point<true>(c, pc, r, cc)) return true;
+  }
+  return false;
+}
+
+// ---- packed block key ------------------------------------------------------------------------------
+
+__device__ __forceinline__ bool pack_key(i3 b, u64& k) {
+  const u32 x = (u32) (b.x + kKeyBias), y = (u32) (b.y + kKeyBias), z = (u32) (b.z + kKeyBias);
+  if ((x | y | z) >> 21) return false;
+  k = ((u64) x << 42) | ((u64) y << 21) | (u64) z;  // order of keys == (x, y, z) lexicographic order
+  return true;
+}
+__device__ __forceinline__ i3 unpack_key(u64 k) {
+  return mki3((int) ((k >> 42) & 0x1FFFFF) - kKeyBias, (int) ((k >> 21) & 0x1FFFFF) - kKeyBias, (int) (k & 0x1FFFFF) - kKeyBias);
+}
+__device__ __forceinline__ u32 hash_key(u64 k) {
+  k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33;
+  return (u32) k;
+}
+
+// multi-GPU tile ownership: 8x8x8-block chunks, hashed (DESIGN.md "sharding")
+__device__ __forceinline__ bool owns_block(const Map& m, i3 b) {
+  if (m.shard_count <= 1) return true;
+  const u32 cx = (u32) (b.x >> 3), cy = (u32) (b.y >> 3), cz = (u32) (b.z >> 3);
+  const u32 h = (cx * 73856093u) ^ (cy * 19349669u) ^ (cz * 83492791u);
+  return (int) ((h ^ (h >> 15)) % (u32) m.shard_count) == m.shard_rank;
+}
+
+// ---- voxel pool addressing -----------------------------------------------------------------------
+
+struct VoxPtr {
+  float* sdf;
+  float* sumsq;
+  u32* rgbw;
+};
+__device__ __forceinline__ VoxPtr vox_ptr(const Tab& t, u32 val) {
+  VoxPtr p;
+  if (val & kValCoarseBit) {
+    const u32 u = val & ~kValCoarseBit;
+    char* base = t.pool + (size_t) (u >> 3) * kFineBytes + (size_t) (u & 7) * kCoarseBytes;
+    p.sdf = (float*) base; p.sumsq = (float*) (base + 256); p.rgbw = (u32*) (base + 512);
+  } else {
+    char* base = t.pool + (size_t) val * kFineBytes;
+    p.sdf = (float*) base; p.sumsq = (float*) (base + 2048); p.rgbw = (u32*) (base + 4096);
+  }
+  return p;
+}
+
+// ---- hash table --------------------------------------------------------------------------------
+
+// lookup: slot index or -1.  vds.cu:80-127 getHashEntry (semantics: find the entry of a block position)
+__device__ __forceinline__ int hash_find(const Tab& t, u64 key) {
+  u32 s = hash_key(key) & t.slot_mask;
+  for (u32 i = 0; i < t.max_probe; i++) {
+    const u64 k = t.keys[s];
+    if (k == key) return (int) s;
+    if (k == kKeyEmpty) return -1;
+    s = (s + 1) & t.slot_mask;
+  }
+  return -1;
+}
+
+// concurrent insert.  Returns slot >= 0 if THIS thread inserted the key (it must then publish vals[slot]),
+// -1 if the key is already present (possibly inserted concurrently by another thread), -2 on overflow.
+// Lock-free: a slot only ever goes EMPTY/TOMB -> key during an insert kernel, every thread holding the same
+// key walks the same probe sequence and CASes the first claimable slot, so exactly one of them wins
+// (replaces the bucket mutex + host retry loop of vds.cu:502-624, 874-922).
+__device__ __forceinline__ int hash_insert(const Tab& t, u64 key) {
+  const u32 h = hash_key(key) & t.slot_mask;
+  // phase A: is the key present before the first never-used slot?  (a TOMB may only be claimed once the key
+  // is known to be absent further down the probe sequence; EMPTY slots have never been occupied)
+  for (u32 i = 0; i < t.max_probe; i++) {
+    const u64 k = __hip_atomic_load(&t.keys[(h + i) & t.slot_mask], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (k == key) return -1;
+    if (k == kKeyEmpty) break;
+  }
+  // phase B: claim the first claimable slot in probe order
+  for (u32 i = 0; i < t.max_probe; i++) {
+    const u32 s = (h + i) & t.slot_mask;
+    u64 k = __hip_atomic_load(&t.keys[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (k == key) return -1;
+    if (k == kKeyEmpty || k == kKeyTomb) {
+      const u64 old = atomicCAS(&t.keys[s], k, key);
+      if (old == k) return (int) s;
+      if (old == key) return -1;
+      // another key took it; keep walking
+    }
+  }
+  return -2;
+}
+
+}  // namespace mrh
