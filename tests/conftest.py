@@ -1,0 +1,29 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """CPU restatement of the reference (test infrastructure; built on demand with gcc)."""
+    import parity_utils as pu
+
+    return pu.oracle_lib()
+
+
+@pytest.fixture(scope="session")
+def hip():
+    """The product library. No fallback: a missing build or a missing device is a hard failure."""
+    from mrhash_amd import capi
+
+    return capi.load_hip()

@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/cfg1_golden.json from the CPU oracle (the reference cannot be built or run here, and
+its own tests store no golden values for this path — SURVEY.md §8c).  The fixture holds, per case, the
+parameters, a description of the synthetic frames, summary counts and SHA-256 of the canonical buffers:
+sorted occupancy list, position-keyed voxel payload, canonical triangle buffer and face index buffer."""
+import hashlib
+import json
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+import parity_utils as pu  # noqa: E402
+from mrhash_amd import synth  # noqa: E402
+
+CASES = {
+    "plane_1frame": dict(params=dict(synth.CFG1_PARAMS), frames=[dict(kind="plane", z=1.0)]),
+    "sphere_3frames_gc": dict(params=dict(synth.CFG1_PARAMS, n_frames_invalidate_voxels=2),
+                              frames=[dict(kind="sphere", zc=1.5), dict(kind="sphere", zc=1.51), dict(kind="sphere", zc=1.5)]),
+    "sphere_multires": dict(params=dict(synth.CFG1_PARAMS, sdf_var_threshold=0.5, n_frames_invalidate_voxels=3),
+                            frames=[dict(kind="sphere", zc=1.5), dict(kind="sphere", zc=1.52), dict(kind="sphere", zc=1.49), dict(kind="sphere", zc=1.5)]),
+}
+
+
+def main():
+    orc = pu.oracle_lib()
+    out = {"generator": "tests/golden/make_golden.py (oracle/mrh_oracle.c)", "cases": {}}
+    for name, case in CASES.items():
+        e = pu.make_engine(orc, synth.CFG1, case["params"], 16384)
+        for spec in case["frames"]:
+            pu.feed(e, pu.frame_from_spec(spec))
+        d, v = e.dump_blocks()
+        t = e.extract_triangles()
+        V, F, C = e.extract_mesh()
+        out["cases"][name] = dict(
+            params=case["params"], frames=case["frames"], blocks=int(len(d)), coarse_blocks=int((d["resolution"] == 1).sum()),
+            weighted_voxels=int((v["weight"] > 0).sum()), triangles=int(t.shape[0]), vertices=int(V.shape[0]), faces=int(F.shape[0]),
+            sha256_occupancy=hashlib.sha256(d.tobytes()).hexdigest(), sha256_payload=hashlib.sha256(v.tobytes()).hexdigest(),
+            sha256_triangles=hashlib.sha256(t.tobytes()).hexdigest(), sha256_faces=hashlib.sha256(F.tobytes()).hexdigest(),
+        )
+        print(name, {k: out["cases"][name][k] for k in ("blocks", "coarse_blocks", "weighted_voxels", "triangles", "faces")})
+    json.dump(out, open(os.path.join(HERE, "cfg1_golden.json"), "w"), indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    main()

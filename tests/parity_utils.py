@@ -84,3 +84,12 @@ def compare_meshes(a: capi.Engine, b: capi.Engine, tol: float = FLOAT_TOL) -> di
     assert dv <= tol, f"mesh vertices differ by {dv}"
     return dict(triangles=int(ta.shape[0]), vertices=int(Va.shape[0]), faces=int(Fa.shape[0]), max_dp=dp,
                 pos_bit_exact=bool(np.array_equal(ta["p"].view(np.uint32), tb["p"].view(np.uint32))))
+
+
+def frame_from_spec(spec: dict) -> synth.Frame:
+    """Rebuilds a cfg1 frame from the tiny description stored in the golden fixture."""
+    if spec["kind"] == "plane":
+        return synth.cfg1_plane(z=spec["z"])
+    if spec["kind"] == "sphere":
+        return synth.cfg1_sphere(radius=spec.get("radius", 0.5), zc=spec["zc"])
+    raise ValueError(spec)

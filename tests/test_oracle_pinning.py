@@ -1,0 +1,201 @@
+"""Pins the CPU oracle against everything the reference's own tests hold for this path:
+host-computable known answers from voxel_hash_utils.cuh, and the invariants asserted by
+tests/test_hash_utils.cu, tests/test_projections.cu and tests/test_marching_cubes.cpp, restated on the
+oracle's literal data structures.  (The reference stores no golden values for integrate / GC / marching
+cubes, so those stay "parity unpinned against reference GPU output"; see oracle/mrh_oracle.c header.)"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import parity_utils as pu
+from mrhash_amd import capi, synth
+
+HASH_ENTRY = np.dtype([("pos", "<i4", (3,)), ("offset", "<u4"), ("ptr", "<i4"), ("resolution", "<i4")])
+FREE_ENTRY = -2
+
+
+def _table(orc, eng, fn="orc_hash_table", dtype=HASH_ENTRY):
+    f = getattr(orc, fn)
+    f.restype = C.c_void_p
+    f.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    n = C.c_uint64()
+    p = f(eng._ctx, C.byref(n))
+    return np.frombuffer((C.c_char * (n.value * dtype.itemsize)).from_address(p), dtype=dtype).copy()
+
+
+def _heap(orc, eng):
+    orc.orc_heap_high.restype = C.c_void_p
+    orc.orc_heap_high.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_int)]
+    n, ctr = C.c_uint64(), C.c_int()
+    p = orc.orc_heap_high(eng._ctx, C.byref(n), C.byref(ctr))
+    return np.frombuffer((C.c_char * (n.value * 4)).from_address(p), dtype=np.uint32).copy(), ctr.value
+
+
+def test_struct_layouts():
+    # voxel_hash_utils.cuh:8-64 (verified by host compile in SURVEY.md §8c): Voxel 12, HashEntry 24, Vertex 24, Triangle 72
+    assert capi.VOXEL_DTYPE.itemsize == 12 and capi.VOXEL_DTYPE.fields["rgb"][1] == 8 and capi.VOXEL_DTYPE.fields["weight"][1] == 11
+    assert HASH_ENTRY.itemsize == 24 and HASH_ENTRY.fields["ptr"][1] == 16
+    assert capi.TRI_DTYPE.itemsize * 3 == 72
+
+
+def test_known_answers_from_reference_host_functions(oracle):
+    # captured by compiling voxel_hash_utils.cuh's __host__ functions
+    oracle.orc_kat_voxel_to_block_index.restype = C.c_uint
+    assert oracle.orc_kat_voxel_to_block_index(-9, 17, 3, 8) == 207
+    assert oracle.orc_kat_voxel_to_block_index(-9, 17, 3, 4) == 67
+    out = (C.c_int * 3)()
+    oracle.orc_kat_delinearize(77, 8, out)
+    assert list(out) == [5, 1, 1]
+
+
+@pytest.mark.parametrize("block_size", [8, 4, 2])
+def test_voxel_roundtrips(oracle, block_size):
+    # tests/test_hash_utils.cu:40-163 VOXEL.*: world -> voxel -> world within 1e-4 at voxel size 1e-6 is not
+    # representable for every point; the reference draws points of magnitude ~1e-5..1e-3. Same construction here.
+    rng = np.random.default_rng(0)
+    vs = np.float32(1e-6)
+    oracle.orc_kat_world_to_voxel.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_int)]
+    for _ in range(200):
+        p = rng.uniform(-1e-3, 1e-3, 3).astype(np.float32)
+        out = (C.c_int * 3)()
+        oracle.orc_kat_world_to_voxel(vs, p.ctypes.data_as(C.POINTER(C.c_float)), out)
+        back = np.array(list(out), dtype=np.float32) * vs
+        assert np.all(np.abs(back - p) <= 1e-4)
+    # world -> voxel-index -> local position round trip (delinearize o linearize == id)
+    for idx in range(block_size ** 3):
+        o = (C.c_int * 3)()
+        oracle.orc_kat_delinearize(idx, block_size, o)
+        assert o[2] * block_size * block_size + o[1] * block_size + o[0] == idx
+
+
+def test_voxel_to_block_is_floor_division(oracle):
+    # vhu.cuh:75-103 goes through float world coordinates; for |pw| < 256 m it must equal floor(v / 8)
+    oracle.orc_kat_voxel_to_block.argtypes = [C.POINTER(C.c_int), C.c_float, C.POINTER(C.c_int)]
+    rng = np.random.default_rng(1)
+    for vs in (0.01, 0.02, 0.005, 0.2):
+        v = rng.integers(-20000, 20000, size=(500, 3)).astype(np.int32)
+        v[:8] = [[0, 0, 0], [7, 8, -1], [-8, -9, 15], [-7, -16, 16], [63, 64, 65], [-64, -63, -65], [1, -1, 0], [8, -8, 7]]
+        for row in v:
+            if np.max(np.abs(row)) * vs >= 256:
+                continue
+            out = (C.c_int * 3)()
+            oracle.orc_kat_voxel_to_block((C.c_int * 3)(*row.tolist()), vs, out)
+            assert list(out) == [int(np.floor(x / 8)) for x in row], (row, vs)
+
+
+def test_buffer_initialisation(oracle):
+    # tests/test_hash_utils.cu:306-376 HASHTABLE.BufferInitialization
+    N = 4096
+    e = pu.make_engine(oracle, synth.CFG1, synth.CFG1_PARAMS, N)
+    heap, ctr = _heap(oracle, e)
+    assert ctr == N - 1
+    assert np.array_equal(heap, N - 1 - np.arange(N, dtype=np.uint32))
+    for fn in ("orc_hash_table", "orc_compact_table"):
+        t = _table(oracle, e, fn)
+        assert len(t) == N * 10
+        assert np.all(t["pos"] == 0) and np.all(t["offset"] == 0) and np.all(t["ptr"] == FREE_ENTRY)
+    oracle.orc_bucket_mutex.restype = C.c_void_p
+    oracle.orc_bucket_mutex.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    n = C.c_uint64()
+    p = oracle.orc_bucket_mutex(e._ctx, C.byref(n))
+    assert np.all(np.frombuffer((C.c_char * (n.value * 4)).from_address(p), dtype=np.int32) == FREE_ENTRY)
+    s = e.stats()
+    assert s.last_compact_blocks == 0 and s.free_fine == N and s.free_coarse == 0
+
+
+def test_heap_sanity_after_one_frame(oracle):
+    # tests/test_hash_utils.cu:378-526 HASHTABLE.HeapSanityCheck, scaled down: 400x400 plane at 1 m, K = 400,
+    # voxel 5 mm, truncation 0.02 + 0.01 d, weight 3 -> here 200x200, K = 200 (same geometry, 1/4 the rays)
+    K = synth.Intrinsics(200.0, 200.0, 100.0, 100.0, 200, 200)
+    N = 60000
+    params = dict(synth.CFG1_PARAMS, sdf_truncation=0.02, sdf_truncation_scale=0.01, virtual_voxel_size=0.005,
+                  integration_weight_sample=3, min_depth=0.01, max_depth=5.0)
+    e = pu.make_engine(oracle, K, params, N)
+    depth = np.full((K.rows, K.cols), 1.0, np.float32)
+    rgb = np.zeros((K.rows, K.cols, 3), np.uint8)
+    rgb[..., 0] = 255
+    e.set_pose(np.eye(3, dtype=np.float32), np.zeros(3, np.float32))
+    e.upload_depth(depth)
+    e.upload_rgb(rgb)
+    e.integrate(0)
+    heap, ctr = _heap(oracle, e)
+    n_free = ctr + 1
+    free_ptrs = heap[:n_free]
+    assert len(np.unique(free_ptrs)) == n_free  # free-heap pointers unique
+    t = _table(oracle, e)
+    occ = t[t["ptr"] != FREE_ENTRY]
+    assert len(occ) > 0
+    alloc_ptrs = occ["ptr"] // 512
+    assert len(np.intersect1d(alloc_ptrs, free_ptrs)) == 0  # no allocated ptr also on the free heap
+    assert len(np.unique(alloc_ptrs)) == len(occ)
+    assert len(occ) + n_free == N  # every block is either free or allocated (no leak)
+    assert len(np.unique(occ["pos"], axis=0)) == len(occ)  # no duplicate block positions
+    assert e.stats().occupied_fine == len(occ)
+
+
+def test_allocation_deletion(oracle):
+    # tests/test_hash_utils.cu:192-304 HASHTABLE.AllocationDeletion: integrate -> zero all weights -> garbageCollect
+    N = 20000
+    e = pu.make_engine(oracle, synth.CFG1, dict(synth.CFG1_PARAMS, n_frames_invalidate_voxels=1000), N)
+    f = synth.cfg1_plane()
+    pu.feed(e, f, 0)
+    before = e.stats()
+    assert before.occupied_fine > 0
+    compacted = before.last_compact_blocks
+    oracle.orc_zero_all_weights(e._ctx)
+    # a second frame with an empty depth image allocates nothing and integrates nothing; GC then sees weight 0 everywhere
+    e.upload_depth(np.zeros_like(f.depth))
+    e.integrate(1000)
+    after = e.stats()
+    assert after.free_fine + after.occupied_fine == N
+    assert after.occupied_fine == 0  # everything that was compacted (in frustum) got freed
+    oracle.orc_decisions.restype = C.c_void_p
+    oracle.orc_decisions.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    n = C.c_uint64()
+    p = oracle.orc_decisions(e._ctx, C.byref(n))
+    dec = np.frombuffer((C.c_char * (n.value * 4)).from_address(p), dtype=np.int32)
+    assert int((dec > 0).sum()) == compacted  # decisions > 0 == number of blocks that were compacted
+    e.upload_depth(f.depth)
+
+
+def test_inverse_projection_pinhole(oracle):
+    # tests/test_projections.cu:41-107 INV_PROJECTION: 480x640, K = (517.3, 516.5, 318.6, 255.3): z == depth
+    K = synth.Intrinsics(517.3, 516.5, 318.6, 255.3, 480, 640)
+    e = pu.make_engine(oracle, K, dict(synth.CFG1_PARAMS, min_depth=0.1, max_depth=10.0))
+    oracle.orc_inverse_projection.argtypes = [C.c_void_p, C.c_uint, C.c_uint, C.c_float, C.POINTER(C.c_float)]
+    rng = np.random.default_rng(2)
+    out = (C.c_float * 3)()
+    for _ in range(2000):
+        r, c = int(rng.integers(0, 480)), int(rng.integers(0, 640))
+        d = np.float32(rng.uniform(0.2, 9.9))
+        oracle.orc_inverse_projection(e._ctx, r, c, d, out)
+        assert np.float32(out[2]) == d  # ASSERT_FLOAT_EQ
+
+
+def test_projection_roundtrip_and_row_col_convention(oracle):
+    # tests/test_projections.cu:109-141 PROJECTIONS.Dummy: project then inverse-project within 1e-2; pimg = (row, col)
+    K = synth.Intrinsics(517.3, 516.5, 318.6, 255.3, 480, 640)
+    e = pu.make_engine(oracle, K, dict(synth.CFG1_PARAMS, min_depth=0.1, max_depth=10.0))
+    oracle.orc_inverse_projection.argtypes = [C.c_void_p, C.c_uint, C.c_uint, C.c_float, C.POINTER(C.c_float)]
+    oracle.orc_project_point.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_int)]
+    rng = np.random.default_rng(3)
+    n_ok = 0
+    for _ in range(5000):
+        r, c = int(rng.integers(0, 480)), int(rng.integers(0, 640))
+        d = np.float32(rng.uniform(0.2, 9.9))
+        p = (C.c_float * 3)()
+        oracle.orc_inverse_projection(e._ctx, r, c, d, p)
+        px = (C.c_int * 2)()
+        ok = oracle.orc_project_point(e._ctx, p, 0, px)
+        assert ok == 1
+        assert abs(px[0] - r) <= 1 and abs(px[1] - c) <= 1  # (row, col) order, test_projections.cu:128-130
+        q = (C.c_float * 3)()
+        oracle.orc_inverse_projection(e._ctx, px[0], px[1], d, q)
+        assert max(abs(q[i] - p[i]) for i in range(3)) <= d / 500.0 + 1e-2
+        n_ok += 1
+    assert n_ok == 5000
+    # (-1, 0) after +0.5 truncates to pixel 0 (camera.cuh:137-140 quirk)
+    px = (C.c_int * 2)()
+    pt = (C.c_float * 3)(np.float32((-0.7 - 318.6) / 517.3), 0.0, 1.0)
+    assert oracle.orc_project_point(e._ctx, pt, 0, px) == 1 and px[1] == 0

@@ -1,0 +1,283 @@
+"""Parity of the gfx950 HIP path against the CPU oracle, through the C ABI.  Runs on the GPU box (-m gpu).
+
+Bars: canonical occupancy list, u8 payload (colour, weight) and the triangle index buffer bit-exact; TSDF
+values / sum_squared / vertex positions within 1e-5 (north_star).  Both sides share one arithmetic spec, so
+the float comparisons are additionally reported as bit-exact or not."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import parity_utils as pu
+from mrhash_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _pair(hip, oracle, K, params, nb=65536, **extra):
+    return pu.make_engine(hip, K, params, nb, **extra), pu.make_engine(oracle, K, params, nb, **extra)
+
+
+def test_native_library_is_the_one_that_runs(hip):
+    # guards against a silent fallback: the context must come from libmrhash_hip.so on a real device
+    assert hip.mrh_version().startswith(b"mrhash_hip")
+    e = pu.make_engine(hip, synth.CFG1, synth.CFG1_PARAMS, 4096)
+    s = e.stats()
+    assert s.num_sdf_blocks == 4096 and s.free_fine == 4096 and s.occupied_fine == 0
+    maps = open("/proc/self/maps").read()
+    assert "libmrhash_hip.so" in maps and "libamdhip64" in maps
+    e.close()
+
+
+def test_cfg1_plane_single_frame(hip, oracle):
+    a, b = _pair(hip, oracle, synth.CFG1, synth.CFG1_PARAMS)
+    f = synth.cfg1_plane()
+    pu.feed(a, f)
+    pu.feed(b, f)
+    a.sync()
+    r = pu.compare_maps(a, b)
+    assert r["blocks"] == 100 and r["sdf_bit_exact"] and r["sumsq_bit_exact"]
+    m = pu.compare_meshes(a, b)
+    assert m["triangles"] > 4000 and m["pos_bit_exact"]
+    V, F, C = a.extract_mesh()
+    assert np.allclose(V[:, 2], 1.0, atol=1e-6)  # the plane z = 1 m is recovered
+
+
+def test_cfg1_sphere_multi_frame_weights_accumulate(hip, oracle):
+    a, b = _pair(hip, oracle, synth.CFG1, synth.CFG1_PARAMS)
+    for _ in range(4):
+        f = synth.cfg1_sphere()
+        pu.feed(a, f)
+        pu.feed(b, f)
+    a.sync()
+    r = pu.compare_maps(a, b)
+    _, v = a.dump_blocks()
+    assert v["weight"].max() == 4
+    pu.compare_meshes(a, b)
+
+
+def test_weight_clamp_and_colour_blend(hip, oracle):
+    # integration_weight_sample 100 -> weights saturate at 255 on the third frame (vhu.cuh:179)
+    params = dict(synth.CFG1_PARAMS, integration_weight_sample=100)
+    a, b = _pair(hip, oracle, synth.CFG1, params)
+    rng = np.random.default_rng(5)
+    for i in range(4):
+        f = synth.cfg1_sphere()
+        f.rgb = rng.integers(0, 256, size=f.rgb.shape, dtype=np.uint8)
+        pu.feed(a, f)
+        pu.feed(b, f)
+    a.sync()
+    pu.compare_maps(a, b)
+    _, v = a.dump_blocks()
+    assert v["weight"].max() == 255
+
+
+def test_gc_every_frame_and_starve(hip, oracle):
+    # n_frames_invalidate = 2: GC each frame, starve on frames 2 and 4 (voxel_data_structures.cpp:137-145)
+    params = dict(synth.CFG1_PARAMS, n_frames_invalidate_voxels=2)
+    a, b = _pair(hip, oracle, synth.CFG1, params)
+    for i in range(6):
+        f = synth.cfg1_sphere(zc=1.5 + 0.01 * (i % 3))
+        pu.feed(a, f)
+        pu.feed(b, f)
+        sa, sb = a.stats(), b.stats()
+        assert (sa.occupied_fine, sa.free_fine, sa.last_compact_blocks) == (sb.occupied_fine, sb.free_fine, sb.last_compact_blocks)
+    a.sync()
+    pu.compare_maps(a, b)
+    pu.compare_meshes(a, b)
+
+
+def test_starve_tie_break_is_canonical(hip, oracle):
+    # identity pose + plane: many voxels share exactly one camera depth and one pixel
+    params = dict(synth.CFG1_PARAMS, n_frames_invalidate_voxels=1, virtual_voxel_size=0.004, sdf_truncation=0.02)
+    a, b = _pair(hip, oracle, synth.CFG1, params)
+    for i in range(3):
+        f = synth.cfg1_plane(z=2.0)
+        pu.feed(a, f)
+        pu.feed(b, f)
+    a.sync()
+    pu.compare_maps(a, b)
+
+
+def test_moving_camera_rotated_poses(hip, oracle):
+    K = synth.Intrinsics(160.0, 160.0, 79.5, 59.5, 120, 160)
+    params = dict(synth.REPLICA_PARAMS, virtual_voxel_size=0.02, sdf_truncation=0.08)
+    a, b = _pair(hip, oracle, K, params, 65536)
+    scene = synth.scannet_room()
+    for t, q in synth.walk_poses(6, seed=3):
+        f = synth.render(scene, K, t, q, depth_scaling=5000.0)
+        pu.feed(a, f)
+        pu.feed(b, f)
+    a.sync()
+    r = pu.compare_maps(a, b)
+    assert r["blocks"] > 500
+    pu.compare_meshes(a, b)
+
+
+def test_variance_adaptive_multires(hip, oracle):
+    params = dict(synth.CFG1_PARAMS, sdf_var_threshold=0.5, n_frames_invalidate_voxels=3)
+    a, b = _pair(hip, oracle, synth.CFG1, params, 16384)
+    seq = [synth.cfg1_sphere(), synth.cfg1_sphere(zc=1.52), synth.cfg1_sphere(zc=1.49), synth.cfg1_sphere(), synth.cfg1_sphere(zc=1.5)]
+    saw_coarse = False
+    for f in seq:
+        pu.feed(a, f)
+        pu.feed(b, f)
+        sa, sb = a.stats(), b.stats()
+        assert (sa.occupied_fine, sa.occupied_coarse, sa.free_fine, sa.free_coarse) == (sb.occupied_fine, sb.occupied_coarse, sb.free_fine, sb.free_coarse)
+        saw_coarse |= sa.occupied_coarse > 0
+    assert saw_coarse, "the scenario must actually coarsen blocks"
+    a.sync()
+    r = pu.compare_maps(a, b)
+    d, _ = a.dump_blocks()
+    assert set(np.unique(d["resolution"])) == {0, 1}
+    pu.compare_meshes(a, b)
+
+
+def test_multires_noisy_stream(hip, oracle):
+    # the project page's sigma values (0.001 .. 0.01) on a noisy plane: mixed fine/coarse map + mesh
+    params = dict(synth.CFG1_PARAMS, sdf_var_threshold=0.01, n_frames_invalidate_voxels=0)
+    a, b = _pair(hip, oracle, synth.CFG1, params, 16384)
+    rng = np.random.default_rng(7)
+    for i in range(5):
+        f = synth.cfg1_plane(z=1.0)
+        f.depth = (f.depth + rng.normal(0, 0.002, f.depth.shape)).astype(np.float32)
+        pu.feed(a, f)
+        pu.feed(b, f)
+    a.sync()
+    pu.compare_maps(a, b)
+    pu.compare_meshes(a, b)
+
+
+def test_edge_inputs(hip, oracle):
+    # empty depth image, depth beyond max_depth, NaN / negative pixels, ragged validity mask
+    a, b = _pair(hip, oracle, synth.CFG1, dict(synth.CFG1_PARAMS, max_depth=3.0))
+    f = synth.cfg1_plane()
+    f.depth[:] = 0
+    pu.feed(a, f); pu.feed(b, f)
+    a.sync()
+    assert a.stats().occupied_fine == 0 and b.stats().occupied_fine == 0
+    assert a.extract_triangles().shape[0] == 0
+    g = synth.cfg1_sphere(background=5.0)  # background beyond max_depth -> ignored (camera.cu:13-14)
+    g.depth[::7, ::5] = np.nan
+    g.depth[3::11, 2::9] = -1.0
+    g.depth[5::13, :] = 0.0
+    pu.feed(a, g); pu.feed(b, g)
+    a.sync()
+    pu.compare_maps(a, b)
+    pu.compare_meshes(a, b)
+
+
+def test_error_behaviour(hip):
+    e = capi.Engine(hip, capi.Params(num_sdf_blocks=4096, **synth.CFG1_PARAMS))
+    with pytest.raises(capi.MrhError) as ei:
+        e.integrate()  # no camera yet
+    assert ei.value.code == capi.MRH_ERR_STATE
+    K = synth.CFG1
+    e.set_camera(K.fx, K.fy, K.cx, K.cy, K.rows, K.cols, 0.01, 30.0)
+    with pytest.raises(RuntimeError):
+        e.upload_depth(np.zeros((4, 4, 1), np.float32))  # GeoWrapper::setDepthImage ndim check
+    with pytest.raises(RuntimeError):
+        e.upload_rgb(np.zeros((4, 4), np.uint8))
+    e.upload_depth(np.ones((64, 64), np.float32))
+    e.upload_rgb(np.zeros((64, 64, 3), np.uint8))
+    with pytest.raises(capi.MrhError) as ei:
+        e.integrate()  # image shape != camera
+    assert ei.value.code == capi.MRH_ERR_INVALID_ARG
+    e.close()
+
+
+def test_pool_exhaustion_is_reported(hip):
+    e = pu.make_engine(hip, synth.CFG1, synth.CFG1_PARAMS, 32)  # the plane needs 100 blocks
+    pu.feed(e, synth.cfg1_plane())
+    with pytest.raises(capi.MrhError) as ei:
+        e.sync()
+    assert ei.value.code == capi.MRH_ERR_CAPACITY
+    s = e.stats()
+    assert s.occupied_fine == 32 and s.free_fine == 0
+    e.close()
+
+
+def test_reset_returns_to_empty_and_is_reproducible(hip):
+    e = pu.make_engine(hip, synth.CFG1, synth.CFG1_PARAMS, 8192)
+    f = synth.cfg1_sphere()
+    pu.feed(e, f)
+    d1, v1 = e.dump_blocks()
+    e.reset()
+    s = e.stats()
+    assert s.occupied_fine == 0 and s.free_fine == 8192 and s.frames_integrated == 0
+    pu.feed(e, f)
+    d2, v2 = e.dump_blocks()
+    assert np.array_equal(d1, d2) and np.array_equal(v1.view(np.uint8), v2.view(np.uint8))
+    e.close()
+
+
+def test_get_voxel_lookup(hip, oracle):
+    a, b = _pair(hip, oracle, synth.CFG1, synth.CFG1_PARAMS)
+    f = synth.cfg1_plane()
+    pu.feed(a, f); pu.feed(b, f)
+    for v in [(0, 0, 50), (-3, 7, 49), (10, -10, 52), (0, 0, 10), (1000, 0, 0)]:
+        va, fa = a.get_voxel(*v)
+        vb, fb = b.get_voxel(*v)
+        assert fa == fb and va.tobytes() == vb.tobytes()
+
+
+def test_replica_640x480_stream(hip, oracle):
+    """BASELINE configs[1] at full resolution, replica.cfg parameters (GC every frame), 4 frames."""
+    a, b = _pair(hip, oracle, synth.REPLICA_640, synth.REPLICA_PARAMS, 131072)
+    for f in synth.replica_stream(4):
+        pu.feed(a, f)
+        pu.feed(b, f)
+    a.sync()
+    r = pu.compare_maps(a, b)
+    assert r["blocks"] > 5000 and r["sdf_bit_exact"]
+
+
+def test_golden_fixtures(hip):
+    """Committed fixtures (generated by tests/golden/make_golden.py from the oracle): canonical buffers
+    of cfg1 hashed with SHA-256 plus summary counts."""
+    g = json.load(open(os.path.join(GOLDEN, "cfg1_golden.json")))
+    for name, case in g["cases"].items():
+        e = pu.make_engine(hip, synth.CFG1, case["params"], 16384)
+        for spec in case["frames"]:
+            pu.feed(e, pu.frame_from_spec(spec))
+        e.sync()
+        d, v = e.dump_blocks()
+        assert len(d) == case["blocks"], name
+        assert hashlib.sha256(d.tobytes()).hexdigest() == case["sha256_occupancy"], name
+        assert hashlib.sha256(v.tobytes()).hexdigest() == case["sha256_payload"], name
+        t = e.extract_triangles()
+        V, F, C = e.extract_mesh()
+        assert t.shape[0] == case["triangles"], name
+        assert hashlib.sha256(F.tobytes()).hexdigest() == case["sha256_faces"], name
+        assert hashlib.sha256(t.tobytes()).hexdigest() == case["sha256_triangles"], name
+        e.close()
+
+
+def test_full_size_properties(hip):
+    """Size-independent properties at the bench workload (640x480, 30 frames, no oracle):
+    heap conservation, no duplicate blocks, idempotent dump, weights bounded by frame count,
+    and a second identical run reproduces the map bit for bit (the engine is deterministic)."""
+    def run():
+        e = pu.make_engine(hip, synth.REPLICA_640, synth.REPLICA_PARAMS, 131072)
+        for f in synth.replica_stream(30):
+            pu.feed(e, f)
+        e.sync()
+        return e
+    e = run()
+    s = e.stats()
+    assert s.occupied_fine + s.free_fine == 131072  # test_hash_utils.cu:464-520 conservation
+    d, v = e.dump_blocks()
+    assert len(d) == s.occupied_fine
+    assert len(np.unique(d[["x", "y", "z"]])) == len(d)  # no duplicate block positions
+    assert v["weight"].max() <= 30
+    d2, v2 = e.dump_blocks()
+    assert np.array_equal(d, d2) and np.array_equal(v.view(np.uint8), v2.view(np.uint8))  # dump is read-only
+    sdf_abs = np.abs(v["sdf"][v["weight"] > 0])
+    assert sdf_abs.max() <= 0.07 + 1e-6  # truncation bound
+    e2 = run()
+    d3, v3 = e2.dump_blocks()
+    assert np.array_equal(d, d3) and np.array_equal(v.view(np.uint8), v3.view(np.uint8))
+    e.close(); e2.close()
