@@ -222,6 +222,11 @@ int mrh_dump_blocks(mrh_ctx* ctx, mrh_block_desc* descs, mrh_voxel* voxels, uint
  * (vds.cu:163-176); a miss returns a zero voxel and *out_found = 0. Test helper. */
 int mrh_get_voxel(mrh_ctx* ctx, int32_t vx, int32_t vy, int32_t vz, mrh_voxel* out, int* out_found);
 
+/* Device self-test of the arithmetic spec: the shared-reciprocal division the integrate kernel uses must be
+ * bit-identical to a correctly rounded IEEE fp32 divide.  Runs `samples` pseudo-random operand pairs on the
+ * context's device and returns the number of mismatches in *out_mismatches (0 expected). */
+int mrh_selftest_division(mrh_ctx* ctx, uint64_t samples, uint64_t seed, uint64_t* out_mismatches);
+
 /* Library build info: "mrhash_hip <abi> gfx950 ..." (or "mrh_oracle ..." for the oracle). */
 const char* mrh_version(void);
 

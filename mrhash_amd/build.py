@@ -40,7 +40,7 @@ def hipcc() -> str:
 
 
 def build_hip(force: bool = False, verbose: bool = True) -> str:
-    srcs = [os.path.join(CSRC, f) for f in ("mrh_capi.hip", "mrh_kernels.h", "mrh_device.h", "mrh_mc.h")]
+    srcs = [os.path.join(CSRC, f) for f in ("mrh_capi.hip", "mrh_kernels.h", "mrh_device.h", "mrh_mc.h", "mrh_fast.h")]
     srcs += [os.path.join(ROOT, "include", f) for f in ("mrhash_hip.h", "mrh_mc_tables.h")]
     if not force and _newer(HIP_LIB, srcs):
         return HIP_LIB
@@ -64,6 +64,7 @@ def build_pybind(force: bool = False, verbose: bool = True) -> str:
     out = os.path.join(ROOT, "mrhash_amd", "pygeowrapper" + ext)
     srcs = [os.path.join(CSRC, f) for f in ("geowrapper.cpp", "geowrapper.h", "pygeowrapper.cpp")]
     srcs.append(os.path.join(ROOT, "include", "mrhash_hip.h"))
+    srcs.append(HIP_LIB)
     if not all(os.path.exists(s) for s in srcs):
         return ""
     if not force and _newer(out, srcs):
@@ -72,7 +73,7 @@ def build_pybind(force: bool = False, verbose: bool = True) -> str:
         "g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fvisibility=hidden",
         "-I", pybind11.get_include(), "-I", sysconfig.get_paths()["include"], "-I", os.path.join(ROOT, "include"),
         os.path.join(CSRC, "geowrapper.cpp"), os.path.join(CSRC, "pygeowrapper.cpp"),
-        "-o", out, "-ldl",
+        "-o", out, "-L", CSRC, "-lmrhash_hip", "-Wl,-rpath,$ORIGIN/csrc",
     ]
     if verbose:
         print("[build]", " ".join(cmd), flush=True)

@@ -96,7 +96,7 @@ ABI_SYMBOLS = (
     "mrh_create mrh_destroy mrh_reset mrh_last_error mrh_set_camera mrh_set_pose mrh_upload_depth "
     "mrh_upload_rgb mrh_set_depth_device mrh_set_rgb_device mrh_integrate mrh_sync "
     "mrh_extract_triangles mrh_extract_mesh mrh_get_stats mrh_set_profile mrh_dump_blocks "
-    "mrh_get_voxel mrh_version"
+    "mrh_get_voxel mrh_selftest_division mrh_version"
 ).split()
 
 
@@ -127,6 +127,7 @@ def _declare(lib: C.CDLL) -> C.CDLL:
     lib.mrh_set_profile.argtypes = [C.c_void_p, C.c_int]
     lib.mrh_dump_blocks.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, P(C.c_uint64)]
     lib.mrh_get_voxel.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, P(C.c_int)]
+    lib.mrh_selftest_division.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, P(C.c_uint64)]
     lib.mrh_version.argtypes = []
     lib.mrh_version.restype = C.c_char_p
     for name in ABI_SYMBOLS:
@@ -310,6 +311,11 @@ class Engine:
         descs, voxels = descs[: n.value], voxels[: n.value]
         order = np.lexsort((descs["z"], descs["y"], descs["x"]))
         return descs[order], voxels[order]
+
+    def selftest_division(self, samples: int = 1 << 26, seed: int = 1) -> int:
+        n = C.c_uint64()
+        self._check(self.lib.mrh_selftest_division(self._ctx, samples, seed, C.byref(n)))
+        return int(n.value)
 
     def get_voxel(self, vx: int, vy: int, vz: int):
         out = np.zeros(1, dtype=VOXEL_DTYPE)

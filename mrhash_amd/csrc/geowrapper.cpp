@@ -1,0 +1,225 @@
+// geowrapper.cpp — host facade over the C ABI; mirrors pygeowrapper::GeoWrapper (geowrapper.cpp:9-577 of the
+// reference) for the setDepthImage / compute() / extractMesh() path.  Errors that the reference turns into
+// print-and-exit (cuda_utils.cuh:9-17) are raised as std::runtime_error instead.
+#include "geowrapper.h"
+
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <stdexcept>
+
+namespace pygeowrapper {
+
+void GeoWrapper::check(int rc, const char* what) {
+  if (rc != MRH_OK) throw std::runtime_error(std::string("GeoWrapper::") + what + " | " + mrh_last_error(ctx_));
+}
+
+GeoWrapper::GeoWrapper(float sdf_truncation, float sdf_truncation_scale, int integration_weight_sample, float virtual_voxel_size,
+                       int n_frames_invalidate_voxels, int voxel_extents_scale, bool /*viewer_active*/, float marching_cubes_threshold,
+                       uint8_t min_weight_threshold, float min_depth, float max_depth, const std::string& gs_optimization_param_path,
+                       float sdf_var_threshold, float vertices_merging_threshold, bool projective_sdf)
+    : sdf_truncation_(sdf_truncation), sdf_truncation_scale_(sdf_truncation_scale), integration_weight_sample_(integration_weight_sample),
+      virtual_voxel_size_(virtual_voxel_size), n_frames_invalidate_voxels_(n_frames_invalidate_voxels), voxel_extents_scale_(voxel_extents_scale),
+      min_weight_threshold_(min_weight_threshold), sdf_var_threshold_(sdf_var_threshold), vertices_merging_threshold_(vertices_merging_threshold) {
+  if (!gs_optimization_param_path.empty())
+    std::cerr << "GeoWrapper::GeoWrapper | Gaussian-splatting optimisation is outside this library's scope; '" << gs_optimization_param_path
+              << "' is ignored" << std::endl;
+  mrh_params p;
+  std::memset(&p, 0, sizeof p);
+  p.abi_version = MRH_ABI_VERSION;
+  p.sdf_truncation = sdf_truncation;
+  p.sdf_truncation_scale = sdf_truncation_scale;
+  p.integration_weight_sample = integration_weight_sample;
+  p.integration_weight_max = integration_weight_max_;
+  p.virtual_voxel_size = virtual_voxel_size;
+  p.n_frames_invalidate_voxels = n_frames_invalidate_voxels;
+  p.voxel_extents_scale = voxel_extents_scale;
+  p.marching_cubes_threshold = marching_cubes_threshold;
+  p.min_weight_threshold = min_weight_threshold;
+  p.projective_sdf = projective_sdf ? 1 : 0;
+  p.min_depth = min_depth;
+  p.max_depth = max_depth;
+  p.sdf_var_threshold = sdf_var_threshold;
+  p.vertices_merging_threshold = vertices_merging_threshold;
+  // capacities: 0 = the reference rule applied to the free HBM of the device (geowrapper.cpp:37-54);
+  // MRHASH_NUM_SDF_BLOCKS / MRHASH_DEVICE override
+  if (const char* e = std::getenv("MRHASH_NUM_SDF_BLOCKS")) p.num_sdf_blocks = std::strtoull(e, nullptr, 10);
+  if (const char* e = std::getenv("MRHASH_DEVICE")) p.device_id = std::atoi(e);
+  p.shard_count = 1;
+  int rc = mrh_create(&p, &ctx_);
+  if (rc != MRH_OK) throw std::runtime_error(std::string("GeoWrapper::GeoWrapper | ") + mrh_last_error(nullptr));
+  mrh_stats st;
+  check(mrh_get_stats(ctx_, &st), "GeoWrapper");
+  num_sdf_blocks_ = (int) st.num_sdf_blocks;
+  hash_num_buckets_ = num_sdf_blocks_;  // geowrapper.cpp:50
+  max_num_sdf_block_integrate_from_global_hash_ = (int) (st.num_sdf_blocks / 7);  // 0.10 / 0.70 of the block budget, :53-54
+  pose_ = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  camera_in_lidar_ = pose_;
+}
+
+GeoWrapper::~GeoWrapper() { mrh_destroy(ctx_); }
+
+void GeoWrapper::setCurrPose(const std::array<float, 3>& t, const std::array<float, 4>& q) {
+  // Eigen::Quaternionf(qw,qx,qy,qz).toRotationMatrix() (Eigen 3.4.0 Quaternion.h), float arithmetic, no normalisation
+  const float x = q[0], y = q[1], z = q[2], w = q[3];
+  const float tx = 2.f * x, ty = 2.f * y, tz = 2.f * z;
+  const float twx = tx * w, twy = ty * w, twz = tz * w;
+  const float txx = tx * x, txy = ty * x, txz = tz * x;
+  const float tyy = ty * y, tyz = tz * y, tzz = tz * z;
+  pose_ = {1.f - (tyy + tzz), txy - twz, txz + twy, t[0],
+           txy + twz, 1.f - (txx + tzz), tyz - twx, t[1],
+           txz - twy, tyz + twx, 1.f - (txx + tyy), t[2],
+           0.f, 0.f, 0.f, 1.f};
+}
+
+void GeoWrapper::setCamera(float fx, float fy, float cx, float cy, int rows, int cols, float min_depth, float max_depth, int camera_model) {
+  check(mrh_set_camera(ctx_, fx, fy, cx, cy, rows, cols, min_depth, max_depth, camera_model), "setCamera");
+}
+
+void GeoWrapper::setDepthImage(const float* data, size_t rows, size_t cols) {
+  depth_.assign(data, data + rows * cols);
+  depth_rows_ = rows;
+  depth_cols_ = cols;
+}
+
+void GeoWrapper::setRGBImage(const uint8_t* data, size_t rows, size_t cols) {
+  rgb_.assign(data, data + rows * cols * 3);
+  rgb_rows_ = rows;
+  rgb_cols_ = cols;
+}
+
+void GeoWrapper::setPointCloud(const float* pts, size_t n, const float* normals_or_null) {
+  point_cloud_.assign(pts, pts + 3 * n);
+  if (normals_or_null) normals_.assign(normals_or_null, normals_or_null + 3 * n);
+  else normals_.clear();
+}
+
+void GeoWrapper::compute() {
+  if (!point_cloud_.empty())
+    throw std::runtime_error("GeoWrapper::compute | LiDAR point-cloud integration (integrate3D) is outside this library's scope (SURVEY.md §8f-2)");
+  const float R[9] = {pose_[0], pose_[1], pose_[2], pose_[4], pose_[5], pose_[6], pose_[8], pose_[9], pose_[10]};
+  const float t[3] = {pose_[3], pose_[7], pose_[11]};
+  check(mrh_set_pose(ctx_, R, t), "compute");
+  if (!depth_.empty() && !rgb_.empty()) {  // geowrapper.cpp:140
+    check(mrh_upload_depth(ctx_, depth_.data(), (int) depth_rows_, (int) depth_cols_), "compute");
+    check(mrh_upload_rgb(ctx_, rgb_.data(), (int) rgb_rows_, (int) rgb_cols_), "compute");
+    check(mrh_integrate(ctx_, n_frames_invalidate_voxels_), "compute");
+  }
+}
+
+void GeoWrapper::extractMesh(const std::string& filename) {
+  const mrh_triangle* tris = nullptr;
+  uint64_t nt = 0;
+  std::cout << "GeoWrapper::extractMesh | extracting..." << std::endl;
+  check(mrh_extract_triangles(ctx_, &tris, &nt), "extractMesh");
+  std::cout << "MarchingCubesExtractor::extractIsoSurface | triangles extracted: " << nt << std::endl;
+  const double *v = nullptr, *c = nullptr;
+  const int32_t* f = nullptr;
+  uint64_t nv = 0, nf = 0;
+  check(mrh_extract_mesh(ctx_, &v, &nv, &f, &nf, &c), "extractMesh");
+  V_.assign(v, v + nv * 3);
+  C_.assign(c, c + nv * 3);
+  F_.assign(f, f + nf * 3);
+
+  // ASCII PLY, same header and value formatting as geowrapper.cpp:194-227
+  std::ofstream ply(filename);
+  if (!ply.is_open()) {
+    std::cerr << "GeoWrapper::extractMesh | Failed to open file for writing: " << filename << std::endl;
+    return;
+  }
+  ply << "ply\nformat ascii 1.0\nelement vertex " << nv << "\nproperty float x\nproperty float y\nproperty float z\n"
+      << "property uchar red\nproperty uchar green\nproperty uchar blue\nelement face " << nf
+      << "\nproperty list uchar int vertex_indices\nend_header\n";
+  for (uint64_t i = 0; i < nv; ++i) {
+    const unsigned char col[3] = {(unsigned char) (C_[i * 3]), (unsigned char) (C_[i * 3 + 1]), (unsigned char) (C_[i * 3 + 2])};
+    ply << V_[i * 3] << " " << V_[i * 3 + 1] << " " << V_[i * 3 + 2] << " " << static_cast<int>(col[0]) << " " << static_cast<int>(col[1]) << " "
+        << static_cast<int>(col[2]) << "\n";
+  }
+  for (uint64_t i = 0; i < nf; ++i) ply << "3 " << F_[i * 3] << " " << F_[i * 3 + 1] << " " << F_[i * 3 + 2] << "\n";
+  ply.close();
+  std::cout << "GeoWrapper::extractMesh | written " << nv << " vertices and " << nf << " faces to " << filename << std::endl;
+}
+
+void GeoWrapper::streamAllOut() {
+  // The reference pages every block to the host chunk grid here (streamer.cpp:250-281).  Host paging is
+  // outside this round's scope; the map stays resident in HBM, so this only drains the stream.
+  check(mrh_sync(ctx_), "streamAllOut");
+}
+
+void GeoWrapper::clearBuffers() {
+  std::cout << "clearing buffers..." << std::endl;
+  check(mrh_reset(ctx_), "clearBuffers");
+}
+
+void GeoWrapper::serializeData(const std::string& filename_hash, const std::string& filename_voxel) {
+  // PLY point clouds of block origins and weighted voxels (streamer.cpp:104-160): x y z r g b weight [sdf]
+  uint64_t n = 0;
+  check(mrh_dump_blocks(ctx_, nullptr, nullptr, 0, &n), "serializeData");
+  std::vector<mrh_block_desc> descs(n ? n : 1);
+  std::vector<mrh_voxel> vox((n ? n : 1) * 512);
+  check(mrh_dump_blocks(ctx_, descs.data(), vox.data(), n, &n), "serializeData");
+  struct Pt { float x, y, z, r, g, b, w, s; };
+  std::vector<Pt> hash_pts, voxel_pts;
+  for (uint64_t k = 0; k < n; ++k) {
+    const mrh_block_desc& d = descs[k];
+    const float bx = (float) (d.x * 8) * virtual_voxel_size_, by = (float) (d.y * 8) * virtual_voxel_size_, bz = (float) (d.z * 8) * virtual_voxel_size_;
+    const int side = 8 >> d.resolution, sf = 1 << d.resolution;
+    float wsum = 0.f;
+    unsigned valid = 0;
+    for (int l = 0; l < side * side * side; ++l) {
+      const mrh_voxel& v = vox[k * 512 + l];
+      if (v.weight == 0) continue;
+      const int lx = (l % side) * sf, ly = ((l % (side * side)) / side) * sf, lz = (l / (side * side)) * sf;
+      voxel_pts.push_back({bx + lx * virtual_voxel_size_, by + ly * virtual_voxel_size_, bz + lz * virtual_voxel_size_,
+                           d.resolution == 0 ? 1.f : 0.f, d.resolution == 1 ? 1.f : 0.f, 0.f, (float) v.weight, v.sdf});
+      wsum += (float) v.weight;
+      valid++;
+    }
+    if (valid) hash_pts.push_back({bx, by, bz, d.resolution == 0 ? 1.f : 0.f, d.resolution == 1 ? 1.f : 0.f, 0.f, wsum / (float) valid, 0.f});
+  }
+  auto write = [](const std::string& fn, const std::vector<Pt>& pts, bool with_sdf) {
+    std::ofstream o(fn);
+    if (!o.is_open()) { std::cerr << "GeoWrapper::serializeData | cannot open " << fn << std::endl; return; }
+    o << "ply\nformat ascii 1.0\nelement vertex " << pts.size() << "\nproperty float x\nproperty float y\nproperty float z\n"
+      << "property float red\nproperty float green\nproperty float blue\nproperty float weight\n" << (with_sdf ? "property float sdf\n" : "") << "end_header\n";
+    for (const Pt& p : pts) {
+      o << p.x << " " << p.y << " " << p.z << " " << p.r << " " << p.g << " " << p.b << " " << p.w;
+      if (with_sdf) o << " " << p.s;
+      o << "\n";
+    }
+  };
+  write(filename_hash, hash_pts, false);
+  write(filename_voxel, voxel_pts, true);
+  std::cout << "Streamer::serializeData | written " << hash_pts.size() << " hash points and " << voxel_pts.size() << " voxels to " << filename_hash
+            << " and " << filename_voxel << std::endl;
+}
+
+void GeoWrapper::serializeGrid(const std::string& filename) {
+  // flat documented format instead of cista (serializer.h:16-77): "MRHGRID1" u64 n, then n x {mrh_block_desc, 512 x mrh_voxel}
+  uint64_t n = 0;
+  check(mrh_dump_blocks(ctx_, nullptr, nullptr, 0, &n), "serializeGrid");
+  std::vector<mrh_block_desc> descs(n ? n : 1);
+  std::vector<mrh_voxel> vox((n ? n : 1) * 512);
+  check(mrh_dump_blocks(ctx_, descs.data(), vox.data(), n, &n), "serializeGrid");
+  std::ofstream o(filename, std::ios::binary);
+  if (!o.is_open()) throw std::runtime_error("GeoWrapper::serializeGrid | cannot open " + filename);
+  o.write("MRHGRID1", 8);
+  o.write((const char*) &n, 8);
+  for (uint64_t k = 0; k < n; ++k) {
+    o.write((const char*) &descs[k], sizeof(mrh_block_desc));
+    o.write((const char*) &vox[k * 512], 512 * sizeof(mrh_voxel));
+  }
+}
+
+void GeoWrapper::deserializeGrid(const std::string& /*filename*/) {
+  throw std::runtime_error("GeoWrapper::deserializeGrid | restoring a grid needs the block stream-in path (SURVEY.md §8f-1), not built yet");
+}
+
+void GeoWrapper::GSSavePointCloud(const std::string& /*folder*/) {
+  std::cerr << "GeoWrapper::GSSavePointCloud | GS container not initialized" << std::endl;  // geowrapper.cpp:233-236
+}
+
+void GeoWrapper::GSFinalOpt() {}  // geowrapper.cpp:241-244: no-op without a GS container
+
+}  // namespace pygeowrapper

@@ -1,0 +1,106 @@
+// geowrapper.h — C++ host facade with the reference's GeoWrapper surface (geowrapper.h:18-260 of
+// rvp-group/mrhash), sitting on the C ABI of include/mrhash_hip.h.  No CUDA/HIP types appear here: the
+// facade owns host-side copies of the inputs (the reference's setters copy too, geowrapper.cpp:246-321)
+// and one opaque mrh_ctx.
+#pragma once
+
+#include <array>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "mrhash_hip.h"
+
+namespace pygeowrapper {
+
+class GeoWrapper {
+public:
+  // same 15 arguments, same order, same defaults as geowrapper.h:63-78 / pygeowrapper.cpp:14-29
+  GeoWrapper(float sdf_truncation, float sdf_truncation_scale, int integration_weight_sample, float virtual_voxel_size,
+             int n_frames_invalidate_voxels, int voxel_extents_scale, bool viewer_active, float marching_cubes_threshold,
+             uint8_t min_weight_threshold, float min_depth, float max_depth, const std::string& gs_optimization_param_path = "",
+             float sdf_var_threshold = 0.f, float vertices_merging_threshold = 0.f, bool projective_sdf = true);
+  ~GeoWrapper();
+  GeoWrapper(const GeoWrapper&) = delete;
+  GeoWrapper& operator=(const GeoWrapper&) = delete;
+
+  // getters / setters: like the reference they only touch the cached host copy (geowrapper.h:80-109)
+  int getHashNumBuckets() const { return hash_num_buckets_; }
+  int getNumSdfBlocks() const { return num_sdf_blocks_; }
+  int getHashBucketSize() const { return hash_bucket_size_; }
+  float getSdfTruncation() const { return sdf_truncation_; }
+  float getSdfTruncationScale() const { return sdf_truncation_scale_; }
+  int getIntegrationWeightSample() const { return integration_weight_sample_; }
+  int getIntegrationWeightMax() const { return integration_weight_max_; }
+  float getVirtualVoxelSize() const { return virtual_voxel_size_; }
+  int getLinkedListSize() const { return linked_list_size_; }
+  int getNFramesInvalidateVoxels() const { return n_frames_invalidate_voxels_; }
+  int getMaxNumSdfBlockIntegrateFromGlobalHash() const { return max_num_sdf_block_integrate_from_global_hash_; }
+  int getVoxelExtentsScale() const { return voxel_extents_scale_; }
+  void setHashNumBuckets(int v) { hash_num_buckets_ = v; }
+  void setNumSdfBlocks(int v) { num_sdf_blocks_ = v; }
+  void setHashBucketSize(int v) { hash_bucket_size_ = v; }
+  void setSdfTruncation(float v) { sdf_truncation_ = v; }
+  void setSdfTruncationScale(float v) { sdf_truncation_scale_ = v; }
+  void setIntegrationWeightSample(int v) { integration_weight_sample_ = v; }
+  void setIntegrationWeightMax(int v) { integration_weight_max_ = v; }
+  void setVirtualVoxelSize(float v) { virtual_voxel_size_ = v; }
+  void setLinkedListSize(int v) { linked_list_size_ = v; }
+  void setNFramesInvalidateVoxels(int v) { n_frames_invalidate_voxels_ = v; }
+  void setMaxNumSdfBlockIntegrateFromGlobalHash(int v) { max_num_sdf_block_integrate_from_global_hash_ = v; }
+  void setVoxelExtentsScale(int v) { voxel_extents_scale_ = v; }
+
+  // translation <tx,ty,tz>, quaternion <qx,qy,qz,qw> (geowrapper.cpp:86-92)
+  void setCurrPose(const std::array<float, 3>& t, const std::array<float, 4>& q);
+  const std::array<float, 16>& getCurrPose() const { return pose_; }  // row-major 4x4
+  void setCameraInLidar(const std::array<float, 16>& m) { camera_in_lidar_ = m; }
+  void setCamera(float fx, float fy, float cx, float cy, int rows, int cols, float min_depth, float max_depth, int camera_model);
+
+  // raw-pointer forms of the numpy setters; shape checks live in the binding (geowrapper.cpp:246-321)
+  void setDepthImage(const float* data, size_t rows, size_t cols);
+  void setRGBImage(const uint8_t* data, size_t rows, size_t cols);
+  void setPointCloud(const float* pts, size_t n, const float* normals_or_null);
+  const std::vector<float>& pointCloud() const { return point_cloud_; }
+  const std::vector<float>& normals() const { return normals_; }
+
+  void compute();                                // geowrapper.cpp:118-148
+  void extractMesh(const std::string& filename);  // geowrapper.cpp:150-230
+  const std::vector<double>& vertices() const { return V_; }
+  const std::vector<int32_t>& faces() const { return F_; }
+  const std::vector<double>& colors() const { return C_; }
+
+  void streamAllOut();
+  void clearBuffers();
+  void serializeData(const std::string& filename_hash, const std::string& filename_voxel);
+  void serializeGrid(const std::string& filename);
+  void deserializeGrid(const std::string& filename);
+  void GSSavePointCloud(const std::string& folder);
+  void GSFinalOpt();
+
+  mrh_ctx* ctx() { return ctx_; }
+
+private:
+  void check(int rc, const char* what);
+
+  int hash_num_buckets_ = 0, num_sdf_blocks_ = 0, hash_bucket_size_ = 10;
+  float sdf_truncation_, sdf_truncation_scale_;
+  int integration_weight_sample_, integration_weight_max_ = 255;
+  float virtual_voxel_size_;
+  int linked_list_size_ = 7;
+  int n_frames_invalidate_voxels_;
+  int max_num_sdf_block_integrate_from_global_hash_ = 0;
+  int voxel_extents_scale_;
+  uint8_t min_weight_threshold_;
+  float sdf_var_threshold_, vertices_merging_threshold_;
+  std::array<float, 16> pose_;
+  std::array<float, 16> camera_in_lidar_;
+  std::vector<float> depth_;
+  std::vector<uint8_t> rgb_;
+  size_t depth_rows_ = 0, depth_cols_ = 0, rgb_rows_ = 0, rgb_cols_ = 0;
+  std::vector<float> point_cloud_, normals_;
+  std::vector<double> V_, C_;
+  std::vector<int32_t> F_;
+  mrh_ctx* ctx_ = nullptr;
+};
+
+}  // namespace pygeowrapper

@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <unordered_map>
@@ -18,6 +19,7 @@
 #include "../../include/mrhash_hip.h"
 #include "mrh_kernels.h"
 #include "mrh_mc.h"
+#include "mrh_fast.h"
 
 using namespace mrh;
 
@@ -56,6 +58,11 @@ struct mrh_ctx {
   int* d_flag = nullptr;
   u64* d_upd_partials = nullptr;
   u32* d_misc = nullptr;  // 4 words for k_get_voxel
+  Fast fast;              // single-resolution fast path buffers
+  size_t fast_npix = 0;
+  u64* d_cnt_partials = nullptr;
+  int fused_grid = 2048;  // x 4 waves
+  int fused_nb = 2;       // voxel batches per wave: 2 = block per wave, 1 = half block per wave
   int integrate_grid = 1024;
   int low_blocks_to_allocate = 0;
   uint64_t num_blocks = 0, slots = 0, max_triangles = 0;
@@ -108,7 +115,7 @@ void free_all(mrh_ctx* c) {
   F(c->tab.keys); F(c->tab.vals); F(c->tab.heap_fine); F(c->tab.heap_coarse); F(c->tab.desc_fine); F(c->tab.desc_coarse);
   F(c->tab.pool); F(c->tab.compact); F(c->tab.ctr); F(c->tab.prof);
   F(c->d_depth_own); F(c->d_rgb_own); F(c->d_decision); F(c->d_zbuf); F(c->d_realloc); F(c->d_reint); F(c->d_flag);
-  F(c->d_upd_partials); F(c->d_misc);
+  F(c->d_upd_partials); F(c->d_misc); F(c->fast.depth_clean); F(c->fast.rgbx); F(c->fast.summary); F(c->fast.bbox); F(c->d_cnt_partials);
   for (auto& e : c->ev_pool) { (void) hipEventDestroy(e.a); (void) hipEventDestroy(e.b); }
   for (auto& e : c->ev_pending) { (void) hipEventDestroy(e.a); (void) hipEventDestroy(e.b); }
   if (c->stream) (void) hipStreamDestroy(c->stream);
@@ -131,6 +138,7 @@ int init_buffers(mrh_ctx* c) {
   HIP_TRY(c, hipMemcpyAsync(t.ctr, h_ctr, sizeof h_ctr, hipMemcpyHostToDevice, s));
   HIP_TRY(c, hipMemsetAsync(t.prof, 0, PROF_COUNT * sizeof(u64), s));
   HIP_TRY(c, hipMemsetAsync(c->d_upd_partials, 0, (size_t) c->integrate_grid * sizeof(u64), s));
+  HIP_TRY(c, hipMemsetAsync(c->d_cnt_partials, 0, (size_t) 8192 * 4 * sizeof(u64), s));
   HIP_TRY(c, hipStreamSynchronize(s));
   c->frames = 0;
   c->prev_total_updated = c->prev_inserted = c->prev_freed = c->total_compact = 0;
@@ -220,12 +228,13 @@ void process_triangles(mrh_ctx* c) {
         if (eps == 0.0) memcpy(&key[a], &p[a], 8);
         else key[a] = (uint64_t) (uint32_t) (int32_t) std::floor(p[a] * inv_eps);
       }
-      auto it = vmap.find(key);
+      const bool has_nan = p[0] != p[0] || p[1] != p[1] || p[2] != p[2];  // never equal to anything (Vector3dEqual)
+      auto it = has_nan ? vmap.end() : vmap.find(key);
       int32_t idx;
       if (it != vmap.end()) idx = it->second;
       else {
         idx = (int32_t) (c->V.size() / 3);
-        vmap.emplace(key, idx);
+        if (!has_nan) vmap.emplace(key, idx);
         c->V.insert(c->V.end(), {p[0], p[1], p[2]});
         c->C.insert(c->C.end(), {(double) v.c[0], (double) v.c[1], (double) v.c[2]});
       }
@@ -316,6 +325,11 @@ int mrh_create(const mrh_params* p, mrh_ctx** out) {
   CREATE_TRY(hipMalloc((void**) &c->d_flag, sizeof(int)));
   CREATE_TRY(hipMalloc((void**) &c->d_misc, 4 * sizeof(u32)));
   CREATE_TRY(hipMalloc((void**) &c->d_upd_partials, (size_t) c->integrate_grid * sizeof(u64)));
+  CREATE_TRY(hipMalloc((void**) &c->d_cnt_partials, (size_t) 8192 * 4 * sizeof(u64)));  // max MRH_FUSED_GRID
+  memset(&c->fast, 0, sizeof c->fast);
+  CREATE_TRY(hipMalloc((void**) &c->fast.summary, c->num_blocks * sizeof(uint2)));
+  c->fast.compact_cap = (u32) c->num_blocks;
+  CREATE_TRY(hipMalloc((void**) &c->fast.bbox, c->num_blocks * sizeof(int4)));
 #undef CREATE_TRY
 
   Map& m = c->map;
@@ -330,6 +344,11 @@ int mrh_create(const mrh_params* p, mrh_ctx** out) {
   m.shard_rank = c->p.shard_rank;
   m.shard_count = c->p.shard_count;
 
+  if (const char* g = getenv("MRH_FUSED_GRID")) {  // tuning knob: workgroups (x4 waves) of the fused integrate kernel
+    const int v = atoi(g);
+    if (v > 0 && v <= 8192) c->fused_grid = v;
+  }
+  if (const char* g = getenv("MRH_FUSED_NB")) c->fused_nb = atoi(g) == 1 ? 1 : 2;
   int rc = init_buffers(c);
   if (rc != MRH_OK) {
     g_create_err = c->err;
@@ -460,6 +479,64 @@ int mrh_integrate(mrh_ctx* c, int n_frames_invalidate) {
   const Tab& t = c->tab;
   const Map& m = c->map;
 
+  if (!t.multi_res) {
+    // ---- single-resolution fast path: alloc -> compact+cull -> fused integrate/summary -> free (mrh_fast.h)
+    const size_t npix = (size_t) k.rows * k.cols;
+    if (c->fast_npix < npix) {
+      HIP_TRY(c, hipStreamSynchronize(s));
+      if (c->fast.depth_clean) HIP_TRY(c, hipFree(c->fast.depth_clean));
+      if (c->fast.rgbx) HIP_TRY(c, hipFree(c->fast.rgbx));
+      c->fast.depth_clean = nullptr; c->fast.rgbx = nullptr;
+      HIP_TRY(c, hipMalloc((void**) &c->fast.depth_clean, npix * sizeof(float)));
+      HIP_TRY(c, hipMalloc((void**) &c->fast.rgbx, npix * sizeof(u32)));
+      c->fast_npix = npix;
+    }
+    const Fast& f = c->fast;
+    const dim3 tiles2((k.cols + kTile - 1) / kTile, (k.rows + kTile - 1) / kTile);
+    if (c->profile) k_alloc2<true><<<tiles2, dim3(kTile, kTile), 0, s>>>(k, m, t, f, c->d_depth, c->d_rgb);
+    else k_alloc2<false><<<tiles2, dim3(kTile, kTile), 0, s>>>(k, m, t, f, c->d_depth, c->d_rgb);
+    if (c->fused_nb == 1) k_compact2<true><<<1024, 512, 0, s>>>(k, m, t, f);
+    else k_compact2<false><<<1024, 512, 0, s>>>(k, m, t, f);
+    if (c->profile) {
+      k_count_updates<<<c->fused_grid, 256, 0, s>>>(k, m, t, f, c->d_cnt_partials);
+      EvPair ev;
+      if (!c->ev_pool.empty()) { ev = c->ev_pool.back(); c->ev_pool.pop_back(); }
+      else if (c->ev_pending.size() >= 4096) { HIP_TRY(c, hipStreamSynchronize(s)); rc = drain_events(c); if (rc) return rc; ev = c->ev_pool.back(); c->ev_pool.pop_back(); }
+      else { HIP_TRY(c, hipEventCreate(&ev.a)); HIP_TRY(c, hipEventCreate(&ev.b)); }
+      HIP_TRY(c, hipEventRecord(ev.a, s));
+      if (c->fused_nb == 1) k_fused<true, 1><<<c->fused_grid, 256, 0, s>>>(k, m, t, f);
+      else k_fused<true, 2><<<c->fused_grid, 256, 0, s>>>(k, m, t, f);
+      HIP_TRY(c, hipEventRecord(ev.b, s));
+      c->ev_pending.push_back(ev);
+    } else {
+      if (c->fused_nb == 1) k_fused<true, 1><<<c->fused_grid, 256, 0, s>>>(k, m, t, f);
+      else k_fused<true, 2><<<c->fused_grid, 256, 0, s>>>(k, m, t, f);
+    }
+    if (max_num_frames > 0) {
+      if (c->frames > 0 && c->frames % (uint64_t) max_num_frames == 0) {
+        if (c->zbuf_n < npix) {
+          HIP_TRY(c, hipStreamSynchronize(s));
+          if (c->d_zbuf) HIP_TRY(c, hipFree(c->d_zbuf));
+          c->d_zbuf = nullptr;
+          HIP_TRY(c, hipMalloc((void**) &c->d_zbuf, 2 * npix * sizeof(u64)));
+          c->zbuf_n = npix;
+        }
+        HIP_TRY(c, hipMemsetAsync(c->d_zbuf, 0xFF, 2 * npix * sizeof(u64), s));
+        // culled blocks have no voxel inside the image, so starving the visible list is starving the compact list
+        k_starve<0><<<c->integrate_grid, 512, 0, s>>>(k, m, t, c->d_zbuf, c->d_zbuf + npix);
+        k_starve<1><<<c->integrate_grid, 512, 0, s>>>(k, m, t, c->d_zbuf, c->d_zbuf + npix);
+        k_starve<2><<<c->integrate_grid, 512, 0, s>>>(k, m, t, c->d_zbuf, c->d_zbuf + npix);
+        k_fused<false, 2><<<c->fused_grid, 256, 0, s>>>(k, m, t, f);  // weights changed: refresh the summaries
+      }
+      const float thr = m.trunc + m.trunc_scale * k.max_depth;
+      if (c->profile) k_free2<true><<<256, 256, 0, s>>>(t, f, thr);
+      else k_free2<false><<<256, 256, 0, s>>>(t, f, thr);
+    }
+    c->frames++;
+    HIP_TRY(c, hipGetLastError());
+    return MRH_OK;
+  }
+
   if (t.multi_res) {
     // vds.cu:885-891 (coarse free-list refill), decided on the device
     k_refill_decide<<<1, 64, 0, s>>>(t, c->low_blocks_to_allocate, c->d_flag);
@@ -547,10 +624,11 @@ int mrh_get_stats(mrh_ctx* c, mrh_stats* out) {
   k_count_live<<<256, 256, 0, s>>>(c->tab);
   int h_ctr[CTR_COUNT];
   u64 h_prof[PROF_COUNT];
-  std::vector<u64> partials((size_t) c->integrate_grid);
+  const bool fastp = !c->tab.multi_res;
+  std::vector<u64> partials(fastp ? (size_t) 8192 * 4 : (size_t) c->integrate_grid);
   HIP_TRY(c, hipMemcpyAsync(h_ctr, c->tab.ctr, sizeof h_ctr, hipMemcpyDeviceToHost, s));
   HIP_TRY(c, hipMemcpyAsync(h_prof, c->tab.prof, sizeof h_prof, hipMemcpyDeviceToHost, s));
-  HIP_TRY(c, hipMemcpyAsync(partials.data(), c->d_upd_partials, partials.size() * sizeof(u64), hipMemcpyDeviceToHost, s));
+  HIP_TRY(c, hipMemcpyAsync(partials.data(), fastp ? c->d_cnt_partials : c->d_upd_partials, partials.size() * sizeof(u64), hipMemcpyDeviceToHost, s));
   HIP_TRY(c, hipStreamSynchronize(s));
   HIP_TRY(c, hipGetLastError());
   rc = drain_events(c);
@@ -564,7 +642,7 @@ int mrh_get_stats(mrh_ctx* c, mrh_stats* out) {
   out->occupied_coarse = (uint64_t) h_ctr[CTR_LIVE_COARSE];
   out->free_fine = (int64_t) h_ctr[CTR_HEAP_FINE] + 1;
   out->free_coarse = (int64_t) h_ctr[CTR_HEAP_COARSE] + 1;
-  out->last_compact_blocks = (uint64_t) h_ctr[CTR_COMPACT];
+  out->last_compact_blocks = (uint64_t) h_ctr[CTR_COMPACT] + (fastp ? (uint64_t) h_ctr[CTR_CULLED] : 0);
   out->total_updated_voxels = total_upd;
   out->last_updated_voxels = total_upd - c->prev_total_updated;
   out->last_inserted_blocks = h_prof[PROF_INSERTED] - c->prev_inserted;
@@ -689,6 +767,24 @@ int mrh_get_voxel(mrh_ctx* c, int32_t vx, int32_t vy, int32_t vz, mrh_voxel* out
   out->rgb[0] = h[2] & 0xFF; out->rgb[1] = (h[2] >> 8) & 0xFF; out->rgb[2] = (h[2] >> 16) & 0xFF;
   out->weight = (uint8_t) (h[2] >> 24);
   if (out_found) *out_found = (int) h[3];
+  return MRH_OK;
+}
+
+int mrh_selftest_division(mrh_ctx* c, uint64_t samples, uint64_t seed, uint64_t* out_mismatches) {
+  int rc = ensure_ready(c, "mrh_selftest_division");
+  if (rc) return rc;
+  if (!out_mismatches) return MRH_ERR_INVALID_ARG;
+  u64* d = nullptr;
+  HIP_TRY(c, hipMalloc((void**) &d, sizeof(u64)));
+  HIP_TRY(c, hipMemsetAsync(d, 0, sizeof(u64), c->stream));
+  const u32 threads = 1024 * 256;
+  const u32 iters = (u32) ((samples + threads - 1) / threads);
+  k_selftest_division<<<1024, 256, 0, c->stream>>>(seed, iters, d);
+  u64 h = 0;
+  HIP_TRY(c, hipMemcpyAsync(&h, d, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipFree(d));
+  *out_mismatches = h;
   return MRH_OK;
 }
 

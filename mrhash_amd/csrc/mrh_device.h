@@ -107,6 +107,34 @@ __device__ __forceinline__ int f2i(float v) {
   if (v <= -2147483648.0f) return (-2147483647 - 1);
   return (int) v;
 }
+// float -> int with the same semantics in ONE instruction: v_cvt_i32_f32 truncates, saturates and maps NaN to 0
+// on gfx950; inline asm so the compiler cannot treat out-of-range inputs as undefined.  Bit-identical to f2i.
+__device__ __forceinline__ int f2i_hw(float v) {
+  int r;
+  asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(v));
+  return r;
+}
+
+// Correctly rounded fp32 division for operands that need no exponent pre-scaling.  hipcc expands `a / b`
+// (with -fhip-fp32-correctly-rounded-divide-sqrt) into v_div_scale x2, v_rcp, one Newton step on the
+// reciprocal, q = a*r, two residual corrections (the second one as v_div_fmas) and v_div_fixup.  v_div_scale
+// only rescales when an exponent is extreme / denormal and v_div_fixup only patches inf/nan/zero operands, so
+// for ordinary operands the value is exactly the chain below.  rcp_refined(b) can be shared by every division
+// with the same denominator (both pixel coordinates divide by pc.z; delta and delta2 divide by vs/2).
+// mrh_selftest_division() checks bit equality against `a / b` on the device.
+__device__ __forceinline__ float rcp_refined(float b) {
+  const float r = __builtin_amdgcn_rcpf(b);
+  const float e = fmaf(-b, r, 1.0f);
+  return fmaf(e, r, r);
+}
+__device__ __forceinline__ float div_rr(float a, float b, float r) {
+  float q = a * r;
+  float e = fmaf(-b, q, a);
+  q = fmaf(e, r, q);
+  e = fmaf(-b, q, a);
+  return fmaf(e, r, q);
+}
+
 // cuda_math.cuh:62-64
 __device__ __forceinline__ int signi(float v) { return (0.f < v) - (v < 0.f); }
 // cuda_math.cuh:947-949

@@ -643,4 +643,33 @@ __global__ void k_get_voxel(const Map m, const Tab t, const int vx, const int vy
   out[3] = 1;
 }
 
+// Self-test: div_rr(a, b, rcp_refined(b)) must equal the compiler's correctly rounded a / b bit for bit on the
+// operand domains the fused kernel uses it for (pixel projection, running mean, variance deltas) plus a broad
+// log-uniform domain.  Returns the number of mismatching samples.
+__device__ __forceinline__ u32 st_rand(u64& s) {
+  s = s * 6364136223846793005ull + 1442695040888963407ull;
+  return (u32) (s >> 33) ^ (u32) (s >> 11);
+}
+__global__ __launch_bounds__(256) void k_selftest_division(const u64 seed, const u32 iters, u64* __restrict__ mismatches) {
+  u64 st = seed * 0x9E3779B97F4A7C15ull + (u64) (blockIdx.x * 256 + threadIdx.x) * 0xD1B54A32D192ED03ull + 1;
+  u32 bad = 0;
+  for (u32 it = 0; it < iters; it++) {
+    const u32 dom = st_rand(st) & 3;
+    float a, b;
+    const float ua = (float) (int) (st_rand(st) >> 8) * (1.0f / 16777216.0f);  // [0,1)
+    const float ub = (float) (int) (st_rand(st) >> 8) * (1.0f / 16777216.0f);
+    if (dom == 0) { a = (ua - 0.5f) * 2.0e5f; b = 0.01f + ub * 30.0f; }              // f * x / z
+    else if (dom == 1) { a = (ua - 0.5f) * 40.0f; b = (float) (1 + (st_rand(st) % 510)); }  // weighted mean
+    else if (dom == 2) { a = (ua - 0.5f) * 0.5f; b = 0.0005f + ub * 0.2f; }           // delta / (vs / 2)
+    else {  // log-uniform magnitudes 2^-40 .. 2^40, random signs
+      a = __uint_as_float(((st_rand(st) % 80 + 87) << 23) | (st_rand(st) & 0x7FFFFF) | (st_rand(st) & 0x80000000u));
+      b = __uint_as_float(((st_rand(st) % 80 + 87) << 23) | (st_rand(st) & 0x7FFFFF) | (st_rand(st) & 0x80000000u));
+    }
+    const float q_ref = a / b;
+    const float q = div_rr(a, b, rcp_refined(b));
+    if (__float_as_uint(q) != __float_as_uint(q_ref)) bad++;
+  }
+  if (bad) atomicAdd(mismatches, (u64) bad);
+}
+
 }  // namespace mrh

@@ -50,6 +50,16 @@ def feed(e: capi.Engine, f: synth.Frame, n_frames_invalidate: int = -1):
     e.integrate(n_frames_invalidate)
 
 
+def _max_abs_diff(x: np.ndarray, y: np.ndarray) -> float:
+    """max |x - y| where NaNs must sit at the same places on both sides (a NaN depth pixel propagates a NaN
+    TSDF value through the reference's formulas; both implementations must agree on where)."""
+    nx, ny = np.isnan(x), np.isnan(y)
+    assert np.array_equal(nx, ny), "NaN positions differ"
+    if nx.all():
+        return 0.0
+    return float(np.max(np.abs(x[~nx] - y[~nx]), initial=0.0))
+
+
 def compare_maps(a: capi.Engine, b: capi.Engine, tol: float = FLOAT_TOL) -> dict:
     """Asserts canonical occupancy + payload parity; returns summary numbers."""
     da, va = a.dump_blocks()
@@ -58,8 +68,8 @@ def compare_maps(a: capi.Engine, b: capi.Engine, tol: float = FLOAT_TOL) -> dict
     assert np.array_equal(da, db), "occupancy list (x,y,z,resolution) differs"
     assert np.array_equal(va["weight"], vb["weight"]), "voxel weights differ"
     assert np.array_equal(va["rgb"], vb["rgb"]), "voxel colours differ"
-    dsdf = float(np.max(np.abs(va["sdf"] - vb["sdf"]), initial=0.0))
-    dss = float(np.max(np.abs(va["sum_squared"] - vb["sum_squared"]), initial=0.0))
+    dsdf = _max_abs_diff(va["sdf"], vb["sdf"])
+    dss = _max_abs_diff(va["sum_squared"], vb["sum_squared"])
     assert dsdf <= tol, f"TSDF values differ by {dsdf}"
     assert dss <= tol, f"sum_squared differs by {dss}"
     bit_sdf = bool(np.array_equal(va["sdf"].view(np.uint32), vb["sdf"].view(np.uint32)))
@@ -72,15 +82,15 @@ def compare_meshes(a: capi.Engine, b: capi.Engine, tol: float = FLOAT_TOL) -> di
     ta = a.extract_triangles()
     tb = b.extract_triangles()
     assert ta.shape == tb.shape, f"triangle count differs: {ta.shape[0]} vs {tb.shape[0]}"
-    dp = float(np.max(np.abs(ta["p"] - tb["p"]), initial=0.0))
-    dc = float(np.max(np.abs(ta["c"] - tb["c"]), initial=0.0))
+    dp = _max_abs_diff(ta["p"], tb["p"])
+    dc = _max_abs_diff(ta["c"], tb["c"])
     assert dp <= tol, f"triangle vertex positions differ by {dp}"
     assert dc <= tol * 255, f"triangle vertex colours differ by {dc}"
     Va, Fa, Ca = a.extract_mesh()
     Vb, Fb, Cb = b.extract_mesh()
     assert Fa.shape == Fb.shape and np.array_equal(Fa, Fb), "triangle index buffer differs"
     assert Va.shape == Vb.shape
-    dv = float(np.max(np.abs(Va - Vb), initial=0.0))
+    dv = _max_abs_diff(Va, Vb)
     assert dv <= tol, f"mesh vertices differ by {dv}"
     return dict(triangles=int(ta.shape[0]), vertices=int(Va.shape[0]), faces=int(Fa.shape[0]), max_dp=dp,
                 pos_bit_exact=bool(np.array_equal(ta["p"].view(np.uint32), tb["p"].view(np.uint32))))

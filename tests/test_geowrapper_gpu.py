@@ -1,0 +1,96 @@
+"""The drop-in surface: `from mrhash.src.pygeowrapper import GeoWrapper` (pybind11 over the C++ host over the C ABI)
+driven exactly like the reference's runner does (mrhash/apps/rgbd_runner.py:136-150), checked against the oracle."""
+import os
+
+import numpy as np
+import pytest
+
+import parity_utils as pu
+from mrhash_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def geowrapper_cls(monkeypatch):
+    monkeypatch.setenv("MRHASH_NUM_SDF_BLOCKS", "32768")
+    from mrhash.src.pygeowrapper import GeoWrapper
+
+    return GeoWrapper
+
+
+def _make(GeoWrapper, **over):
+    kw = dict(sdf_truncation=0.06, sdf_truncation_scale=0.0, integration_weight_sample=1, virtual_voxel_size=0.02,
+              n_frames_invalidate_voxels=2, voxel_extents_scale=1, viewer_active=False, marching_cubes_threshold=1.5,
+              min_weight_threshold=5, min_depth=0.01, max_depth=30.0)
+    kw.update(over)
+    return GeoWrapper(**kw)
+
+
+def test_runner_call_sequence_matches_oracle(geowrapper_cls, oracle, tmp_path):
+    g = _make(geowrapper_cls)
+    K = synth.CFG1
+    g.setCamera(K.fx, K.fy, K.cx, K.cy, K.rows, K.cols, 0.01, 30.0, 0)
+    params = dict(synth.CFG1_PARAMS, n_frames_invalidate_voxels=2)
+    b = pu.make_engine(oracle, K, params, 32768)
+    frames = [synth.cfg1_sphere(), synth.cfg1_sphere(zc=1.51), synth.cfg1_sphere(zc=1.5)]
+    for f in frames:
+        g.setCurrPose(f.t, f.q)
+        g.setDepthImage(f.depth)
+        g.setRGBImage(f.rgb)
+        g.compute()
+        pu.feed(b, f)
+    g.streamAllOut()
+    out = tmp_path / "mesh.ply"
+    g.extractMesh(str(out))
+    V, F, C = g.getVertices(), g.getFaces(), g.getColors()
+    b.extract_triangles()
+    Vb, Fb, Cb = b.extract_mesh()
+    assert V.dtype == np.float64 and F.dtype == np.int32 and C.dtype == np.float64
+    assert V.shape == Vb.shape and np.array_equal(F, Fb)
+    assert np.array_equal(V, Vb) and np.allclose(C, Cb, atol=1e-5)
+    # ASCII PLY with the reference's header (geowrapper.cpp:201-212)
+    txt = out.read_text().splitlines()
+    assert txt[0] == "ply" and txt[1] == "format ascii 1.0"
+    assert txt[2] == f"element vertex {len(V)}" and f"element face {len(F)}" in txt
+    hdr_end = txt.index("end_header")
+    assert len(txt) == hdr_end + 1 + len(V) + len(F)
+    first = txt[hdr_end + 1].split()
+    assert len(first) == 6 and abs(float(first[0]) - V[0, 0]) < 1e-4
+    assert txt[hdr_end + 1 + len(V)].split() == ["3"] + [str(int(x)) for x in F[0]]
+    P = g.getCurrPose()
+    assert P.shape == (4, 4) and np.allclose(P[:3, :3], frames[-1].R) and np.allclose(P[:3, 3], frames[-1].t)
+
+
+def test_getters_setters_and_errors(geowrapper_cls):
+    g = _make(geowrapper_cls)
+    assert g.getNumSdfBlocks() == 32768 and g.getHashNumBuckets() == 32768 and g.getHashBucketSize() == 10
+    assert g.getIntegrationWeightMax() == 255 and g.getLinkedListSize() == 7
+    assert abs(g.getVirtualVoxelSize() - 0.02) < 1e-9 and g.getNFramesInvalidateVoxels() == 2
+    g.setSdfTruncation(0.1)
+    assert abs(g.getSdfTruncation() - 0.1) < 1e-9  # host copy only, like the reference (geowrapper.h:98-109)
+    with pytest.raises(RuntimeError, match="2D numpy array"):
+        g.setDepthImage(np.zeros((4, 4, 1), np.float32))
+    with pytest.raises(RuntimeError, match="3D numpy array"):
+        g.setRGBImage(np.zeros((4, 4), np.uint8))
+    with pytest.raises(RuntimeError, match="3 channels"):
+        g.setRGBImage(np.zeros((4, 4, 4), np.uint8))
+    with pytest.raises(RuntimeError):
+        g.setDepthImage(np.ones((8, 8), np.float32)); g.setRGBImage(np.zeros((8, 8, 3), np.uint8)); g.compute()  # no camera
+    g.setRGBImage(np.zeros((8, 8, 3), np.float32))  # the reference runner passes float32 RGB (depth_reader.py:88-91)
+    g.GSFinalOpt()
+    g.clearBuffers()
+
+
+def test_serialize_outputs(geowrapper_cls, tmp_path):
+    g = _make(geowrapper_cls, n_frames_invalidate_voxels=0)
+    K = synth.CFG1
+    g.setCamera(K.fx, K.fy, K.cx, K.cy, K.rows, K.cols, 0.01, 30.0, 0)
+    f = synth.cfg1_plane()
+    g.setCurrPose(f.t, f.q); g.setDepthImage(f.depth); g.setRGBImage(f.rgb); g.compute()
+    g.serializeData(str(tmp_path / "hash.ply"), str(tmp_path / "vox.ply"))
+    assert "element vertex 100" in (tmp_path / "hash.ply").read_text()
+    g.serializeGrid(str(tmp_path / "grid.bin"))
+    raw = (tmp_path / "grid.bin").read_bytes()
+    assert raw[:8] == b"MRHGRID1" and int.from_bytes(raw[8:16], "little") == 100
+    assert len(raw) == 16 + 100 * (16 + 512 * 12)

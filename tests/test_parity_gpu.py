@@ -32,6 +32,15 @@ def test_native_library_is_the_one_that_runs(hip):
     e.close()
 
 
+def test_shared_reciprocal_division_is_ieee_exact(hip):
+    """The fused kernel divides with one refined reciprocal per denominator (mrh_device.h div_rr); it must be
+    bit-identical to the correctly rounded fp32 divide the arithmetic spec prescribes."""
+    e = pu.make_engine(hip, synth.CFG1, synth.CFG1_PARAMS, 1024)
+    for seed in (1, 2, 3):
+        assert e.selftest_division(1 << 28, seed) == 0
+    e.close()
+
+
 def test_cfg1_plane_single_frame(hip, oracle):
     a, b = _pair(hip, oracle, synth.CFG1, synth.CFG1_PARAMS)
     f = synth.cfg1_plane()
