@@ -78,10 +78,11 @@ typedef struct mrh_params {
   uint64_t max_triangles;             /* triangle buffer capacity; 0 = reference sizing rule             */
   int32_t  device_id;                 /* HIP device ordinal                                              */
   /* Multi-GPU tile sharding (new design, no reference counterpart): this context owns the
-   * blocks whose 8-block-cube chunk hashes to shard_rank modulo shard_count. 1 = own all. */
+   * blocks whose chunk (cube of 2^shard_chunk_log2 blocks) hashes to shard_rank modulo shard_count.
+   * shard_count 1 = own all.  Marching cubes then emits triangles for owned blocks only. */
   int32_t  shard_rank;
   int32_t  shard_count;
-  int32_t  reserved1;
+  int32_t  shard_chunk_log2;          /* ownership granularity: cubes of 2^k blocks per side; 0 = default 3     */
 } mrh_params;
 
 /* Reference `Voxel` (voxel_hash_utils.cuh:8-22): 12 bytes. Used only at the dump/restore
@@ -184,6 +185,17 @@ int mrh_set_rgb_device(mrh_ctx* ctx, const uint8_t* d_rgb, int rows, int cols);
  * Enqueues on the context stream and returns without waiting. */
 int mrh_integrate(mrh_ctx* ctx, int n_frames_invalidate);
 
+/* Tile-sharded contexts (shard_count > 1) only.  On a starve frame (voxel_data_structures.cpp:139) the per-pixel
+ * z-buffer of starveVoxelsKernel (vds.cu:1597-1649) must hold the minimum over the voxels of ALL shards, so the
+ * frame is split at the two points where a reduction over shards is needed: mrh_integrate returns
+ * MRH_PENDING_EXCHANGE (> 0, not an error) after filling the buffer; the host min-reduces the int64 buffer
+ * returned by mrh_exchange_buffer across ranks (RCCL all-reduce MIN over xGMI; every value is < 2^63) and calls
+ * mrh_integrate_resume, which may return MRH_PENDING_EXCHANGE once more before it returns MRH_OK.
+ * Unsharded contexts never return MRH_PENDING_EXCHANGE. */
+#define MRH_PENDING_EXCHANGE 1
+int mrh_exchange_buffer(mrh_ctx* ctx, void** out_ptr, uint64_t* out_count_int64, int* out_is_device_memory);
+int mrh_integrate_resume(mrh_ctx* ctx);
+
 /* Blocks until every enqueued frame has executed; surfaces sticky device error flags as
  * MRH_ERR_CAPACITY / MRH_ERR_OUT_OF_RANGE. */
 int mrh_sync(mrh_ctx* ctx);
@@ -217,6 +229,21 @@ int mrh_set_profile(mrh_ctx* ctx, int enabled);
  * (streamer.cpp:250-281) as far as tests and checkpointing need it.  Order is unspecified. */
 int mrh_dump_blocks(mrh_ctx* ctx, mrh_block_desc* descs, mrh_voxel* voxels, uint64_t capacity,
                     uint64_t* out_n);
+
+/* Inserts n blocks given in the mrh_dump_blocks format (descs[i], 512 reference-layout voxels each; coarse blocks
+ * use the first 64).  A block that already exists is overwritten.  Used to restore a dumped map and to bring
+ * boundary ("halo") blocks of neighbouring shards in before mesh extraction.  Replaces the host->device half
+ * of the streamer (Streamer::streamInToGPU, streamer.cpp:358-378) as far as this library needs it.  Blocks. */
+int mrh_import_blocks(mrh_ctx* ctx, const mrh_block_desc* descs, const mrh_voxel* voxels, uint64_t n);
+
+/* Per-block triangle counts of the last mrh_extract_triangles, in the same canonical block order as the
+ * triangle buffer (blocks with zero triangles included).  Lets sharded ranks merge their buffers into the
+ * single-GPU order.  Buffers are owned by ctx until the next extraction. */
+int mrh_get_triangle_blocks(mrh_ctx* ctx, const mrh_block_desc** out_descs, const uint32_t** out_counts, uint64_t* out_n);
+
+/* MeshExtractor::processTriangles (mesh_extractor.cpp:9-76) on a caller-supplied triangle buffer; the result is
+ * read back with mrh_extract_mesh.  Used by rank 0 on the merged buffer of all shards. */
+int mrh_process_triangles(mrh_ctx* ctx, const mrh_triangle* triangles, uint64_t n);
 
 /* Looks one voxel up by integer voxel coordinate = VoxelContainer::getVoxel(int3)
  * (vds.cu:163-176); a miss returns a zero voxel and *out_found = 0. Test helper. */

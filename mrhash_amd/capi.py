@@ -21,6 +21,7 @@ HIP_LIB_PATH = os.path.join(_ROOT, "mrhash_amd", "csrc", "libmrhash_hip.so")
 MRH_ABI_VERSION = 1
 
 MRH_OK = 0
+MRH_PENDING_EXCHANGE = 1
 MRH_ERR_INVALID_ARG = -1
 MRH_ERR_DEVICE = -2
 MRH_ERR_NO_DEVICE = -3
@@ -56,7 +57,7 @@ class MrhParams(C.Structure):
         ("device_id", C.c_int32),
         ("shard_rank", C.c_int32),
         ("shard_count", C.c_int32),
-        ("reserved1", C.c_int32),
+        ("shard_chunk_log2", C.c_int32),
     ]
 
 
@@ -94,9 +95,9 @@ assert TRI_DTYPE.itemsize == 24
 # every symbol include/mrhash_hip.h declares
 ABI_SYMBOLS = (
     "mrh_create mrh_destroy mrh_reset mrh_last_error mrh_set_camera mrh_set_pose mrh_upload_depth "
-    "mrh_upload_rgb mrh_set_depth_device mrh_set_rgb_device mrh_integrate mrh_sync "
+    "mrh_upload_rgb mrh_set_depth_device mrh_set_rgb_device mrh_integrate mrh_integrate_resume mrh_exchange_buffer mrh_sync "
     "mrh_extract_triangles mrh_extract_mesh mrh_get_stats mrh_set_profile mrh_dump_blocks "
-    "mrh_get_voxel mrh_selftest_division mrh_version"
+    "mrh_get_voxel mrh_import_blocks mrh_get_triangle_blocks mrh_process_triangles mrh_selftest_division mrh_version"
 ).split()
 
 
@@ -120,6 +121,8 @@ def _declare(lib: C.CDLL) -> C.CDLL:
     lib.mrh_set_depth_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
     lib.mrh_set_rgb_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
     lib.mrh_integrate.argtypes = [C.c_void_p, C.c_int]
+    lib.mrh_integrate_resume.argtypes = [C.c_void_p]
+    lib.mrh_exchange_buffer.argtypes = [C.c_void_p, P(C.c_void_p), P(C.c_uint64), P(C.c_int)]
     lib.mrh_sync.argtypes = [C.c_void_p]
     lib.mrh_extract_triangles.argtypes = [C.c_void_p, P(C.c_void_p), P(C.c_uint64)]
     lib.mrh_extract_mesh.argtypes = [C.c_void_p, P(C.c_void_p), P(C.c_uint64), P(C.c_void_p), P(C.c_uint64), P(C.c_void_p)]
@@ -127,6 +130,9 @@ def _declare(lib: C.CDLL) -> C.CDLL:
     lib.mrh_set_profile.argtypes = [C.c_void_p, C.c_int]
     lib.mrh_dump_blocks.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, P(C.c_uint64)]
     lib.mrh_get_voxel.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, P(C.c_int)]
+    lib.mrh_import_blocks.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
+    lib.mrh_get_triangle_blocks.argtypes = [C.c_void_p, P(C.c_void_p), P(C.c_void_p), P(C.c_uint64)]
+    lib.mrh_process_triangles.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
     lib.mrh_selftest_division.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, P(C.c_uint64)]
     lib.mrh_version.argtypes = []
     lib.mrh_version.restype = C.c_char_p
@@ -178,6 +184,7 @@ class Params:
     device_id: int = 0
     shard_rank: int = 0
     shard_count: int = 1
+    shard_chunk_log2: int = 0
 
     def to_c(self) -> MrhParams:
         p = MrhParams()
@@ -186,7 +193,7 @@ class Params:
             "sdf_truncation sdf_truncation_scale integration_weight_sample integration_weight_max "
             "virtual_voxel_size n_frames_invalidate_voxels voxel_extents_scale marching_cubes_threshold "
             "min_weight_threshold min_depth max_depth sdf_var_threshold vertices_merging_threshold "
-            "num_sdf_blocks hash_slots max_triangles device_id shard_rank shard_count"
+            "num_sdf_blocks hash_slots max_triangles device_id shard_rank shard_count shard_chunk_log2"
         ).split():
             setattr(p, f, getattr(self, f))
         p.projective_sdf = 1 if self.projective_sdf else 0
@@ -258,8 +265,28 @@ class Engine:
         self._check(self.lib.mrh_set_rgb_device(self._ctx, ptr, rows, cols))
 
     # -- hot path ------------------------------------------------------------------------------
-    def integrate(self, n_frames_invalidate: int = -1):
-        self._check(self.lib.mrh_integrate(self._ctx, n_frames_invalidate))
+    def integrate(self, n_frames_invalidate: int = -1) -> bool:
+        """Enqueues one frame.  Returns True when a sharded context stopped for a min-reduction over ranks
+        (MRH_PENDING_EXCHANGE): reduce `exchange_buffer()` and call `integrate_resume()` until it returns False
+        (mrhash_amd.parallel.integrate does this)."""
+        rc = self.lib.mrh_integrate(self._ctx, n_frames_invalidate)
+        if rc == MRH_PENDING_EXCHANGE:
+            return True
+        self._check(rc)
+        return False
+
+    def integrate_resume(self) -> bool:
+        rc = self.lib.mrh_integrate_resume(self._ctx)
+        if rc == MRH_PENDING_EXCHANGE:
+            return True
+        self._check(rc)
+        return False
+
+    def exchange_buffer(self) -> Tuple[int, int, bool]:
+        """(pointer, number of int64 elements, is_device_memory) of the buffer awaiting a MIN all-reduce."""
+        ptr, n, dev = C.c_void_p(), C.c_uint64(), C.c_int()
+        self._check(self.lib.mrh_exchange_buffer(self._ctx, C.byref(ptr), C.byref(n), C.byref(dev)))
+        return int(ptr.value), int(n.value), bool(dev.value)
 
     def sync(self):
         self._check(self.lib.mrh_sync(self._ctx))
@@ -311,6 +338,26 @@ class Engine:
         descs, voxels = descs[: n.value], voxels[: n.value]
         order = np.lexsort((descs["z"], descs["y"], descs["x"]))
         return descs[order], voxels[order]
+
+    def import_blocks(self, descs: np.ndarray, voxels: np.ndarray):
+        """Inverse of dump_blocks (restore a map, or bring halo blocks of other shards in)."""
+        d = np.ascontiguousarray(descs, dtype=DESC_DTYPE)
+        v = np.ascontiguousarray(voxels, dtype=VOXEL_DTYPE).reshape(len(d), 512)
+        self._check(self.lib.mrh_import_blocks(self._ctx, d.ctypes.data, v.ctypes.data, len(d)))
+
+    def triangle_blocks(self) -> Tuple[np.ndarray, np.ndarray]:
+        """(descs, per-block triangle counts) of the last extract_triangles(), canonical block order."""
+        pd, pc, n = C.c_void_p(), C.c_void_p(), C.c_uint64()
+        self._check(self.lib.mrh_get_triangle_blocks(self._ctx, C.byref(pd), C.byref(pc), C.byref(n)))
+        if n.value == 0:
+            return np.zeros(0, DESC_DTYPE), np.zeros(0, np.uint32)
+        d = np.frombuffer((C.c_char * (n.value * 16)).from_address(pd.value), dtype=DESC_DTYPE).copy()
+        c = np.frombuffer((C.c_char * (n.value * 4)).from_address(pc.value), dtype=np.uint32).copy()
+        return d, c
+
+    def process_triangles(self, tris: np.ndarray):
+        t = np.ascontiguousarray(tris, dtype=TRI_DTYPE).reshape(-1, 3)
+        self._check(self.lib.mrh_process_triangles(self._ctx, t.ctypes.data, len(t)))
 
     def selftest_division(self, samples: int = 1 << 26, seed: int = 1) -> int:
         n = C.c_uint64()

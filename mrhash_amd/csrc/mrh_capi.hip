@@ -63,12 +63,18 @@ struct mrh_ctx {
   u64* d_cnt_partials = nullptr;
   int fused_grid = 2048;  // x 4 waves
   int fused_nb = 2;       // voxel batches per wave: 2 = block per wave, 1 = half block per wave
+  int fused_pipe = 0;     // 1 = software-pipelined variant (k_fused_pipe)
+  int fused_wg = 256;     // threads per workgroup of k_fused (64 / 128 / 256)
   int integrate_grid = 1024;
   int low_blocks_to_allocate = 0;
   uint64_t num_blocks = 0, slots = 0, max_triangles = 0;
   uint64_t frames = 0;
+  int pending = 0;           // sharded starve frames: 1 after pass 0, 2 after pass 1
+  int pending_max_frames = 0;
   // mesh (host)
   std::vector<mrh_triangle> tris;
+  std::vector<mrh_block_desc> tri_blocks;
+  std::vector<uint32_t> tri_counts;
   std::vector<double> V, C;
   std::vector<int32_t> F;
   // profiling
@@ -138,7 +144,7 @@ int init_buffers(mrh_ctx* c) {
   HIP_TRY(c, hipMemcpyAsync(t.ctr, h_ctr, sizeof h_ctr, hipMemcpyHostToDevice, s));
   HIP_TRY(c, hipMemsetAsync(t.prof, 0, PROF_COUNT * sizeof(u64), s));
   HIP_TRY(c, hipMemsetAsync(c->d_upd_partials, 0, (size_t) c->integrate_grid * sizeof(u64), s));
-  HIP_TRY(c, hipMemsetAsync(c->d_cnt_partials, 0, (size_t) 8192 * 4 * sizeof(u64), s));
+  HIP_TRY(c, hipMemsetAsync(c->d_cnt_partials, 0, (size_t) 32768 * 4 * sizeof(u64), s));
   HIP_TRY(c, hipStreamSynchronize(s));
   c->frames = 0;
   c->prev_total_updated = c->prev_inserted = c->prev_freed = c->total_compact = 0;
@@ -188,6 +194,20 @@ int compact_all(mrh_ctx* c, int* out_n) {
   HIP_TRY(c, hipGetLastError());
   *out_n = n;
   return MRH_OK;
+}
+
+void launch_fused(mrh_ctx* c) {
+  const int g = c->fused_grid;
+  hipStream_t s = c->stream;
+  if (c->fused_pipe) {
+    if (c->fused_nb == 1) k_fused_pipe<1><<<g, 256, 0, s>>>(c->cam, c->map, c->tab, c->fast);
+    else k_fused_pipe<2><<<g, 256, 0, s>>>(c->cam, c->map, c->tab, c->fast);
+  } else {
+    const int wg = c->fused_wg;
+    const size_t lds = (size_t) (wg / 64) * kTileMaxPx * sizeof(uint2);
+    if (c->fused_nb == 1) k_fused<true, 1><<<g, wg, lds, s>>>(c->cam, c->map, c->tab, c->fast);
+    else k_fused<true, 2><<<g, wg, lds, s>>>(c->cam, c->map, c->tab, c->fast);
+  }
 }
 
 struct KeyHash3 {
@@ -248,6 +268,79 @@ void process_triangles(mrh_ctx* c) {
     if (!seen.emplace(f, 1).second) continue;
     c->F.insert(c->F.end(), {f[0], f[1], f[2]});
   }
+}
+
+
+int ensure_zbuf(mrh_ctx* c, size_t npix) {
+  if (c->zbuf_n < npix) {
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->d_zbuf) HIP_TRY(c, hipFree(c->d_zbuf));
+    c->d_zbuf = nullptr;
+    HIP_TRY(c, hipMalloc((void**) &c->d_zbuf, 2 * npix * sizeof(u64)));
+    c->zbuf_n = npix;
+  }
+  return MRH_OK;
+}
+
+// one of the three starve passes over the current compact (fast path: visible) list
+int launch_starve(mrh_ctx* c, int pass) {
+  const Cam& k = c->cam;
+  const size_t npix = (size_t) k.rows * k.cols;
+  hipStream_t s = c->stream;
+  if (pass == 0) {
+    int rc = ensure_zbuf(c, npix);
+    if (rc) return rc;
+    // "empty" = INT64_MAX: above every key (depth bits of a finite positive float < 0x7F800000) in both the
+    // unsigned and the signed reading, so shards can be min-reduced as int64
+    k_fill_u64<<<256, 256, 0, s>>>(c->d_zbuf, 2 * npix, 0x7FFFFFFFFFFFFFFFull);
+    k_starve<0><<<c->integrate_grid, 512, 0, s>>>(k, c->map, c->tab, c->d_zbuf, c->d_zbuf + npix);
+  } else if (pass == 1) {
+    k_starve<1><<<c->integrate_grid, 512, 0, s>>>(k, c->map, c->tab, c->d_zbuf, c->d_zbuf + npix);
+  } else {
+    k_starve<2><<<c->integrate_grid, 512, 0, s>>>(k, c->map, c->tab, c->d_zbuf, c->d_zbuf + npix);
+  }
+  return MRH_OK;
+}
+
+// everything of a frame that follows the starve step
+int frame_tail(mrh_ctx* c, bool starved, int max_num_frames) {
+  hipStream_t s = c->stream;
+  const Cam& k = c->cam;
+  const Map& m = c->map;
+  const Tab& t = c->tab;
+  const float thr = m.trunc + m.trunc_scale * k.max_depth;  // getTruncation(camera.maxDepth(), ...), vds.cu:1720
+  if (!t.multi_res) {
+    if (starved) k_fused<false, 2><<<c->fused_grid, 256, 16, s>>>(k, m, t, c->fast);  // weights changed: refresh the summaries
+    if (max_num_frames > 0) {
+      if (c->profile) k_free2<true><<<256, 256, 0, s>>>(t, c->fast, thr);
+      else k_free2<false><<<256, 256, 0, s>>>(t, c->fast, thr);
+    }
+  } else if (max_num_frames > 0) {
+    k_gc_identify<<<c->integrate_grid, 512, 0, s>>>(t, thr, c->d_decision);
+    if (c->profile) k_gc_free<true><<<256, 256, 0, s>>>(t, c->d_decision);
+    else k_gc_free<false><<<256, 256, 0, s>>>(t, c->d_decision);
+  }
+  c->frames++;
+  HIP_TRY(c, hipGetLastError());
+  return MRH_OK;
+}
+
+// starve (voxel_data_structures.cpp:139) + the rest of the frame; sharded contexts stop for the host's min-reduction
+int starve_and_tail(mrh_ctx* c, int max_num_frames) {
+  const bool starve = max_num_frames > 0 && c->frames > 0 && c->frames % (uint64_t) max_num_frames == 0;
+  if (starve) {
+    int rc = launch_starve(c, 0);
+    if (rc) return rc;
+    if (c->p.shard_count > 1) {
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
+      c->pending = 1;
+      c->pending_max_frames = max_num_frames;
+      return MRH_PENDING_EXCHANGE;
+    }
+    launch_starve(c, 1);
+    launch_starve(c, 2);
+  }
+  return frame_tail(c, starve, max_num_frames);
 }
 
 }  // namespace
@@ -325,7 +418,7 @@ int mrh_create(const mrh_params* p, mrh_ctx** out) {
   CREATE_TRY(hipMalloc((void**) &c->d_flag, sizeof(int)));
   CREATE_TRY(hipMalloc((void**) &c->d_misc, 4 * sizeof(u32)));
   CREATE_TRY(hipMalloc((void**) &c->d_upd_partials, (size_t) c->integrate_grid * sizeof(u64)));
-  CREATE_TRY(hipMalloc((void**) &c->d_cnt_partials, (size_t) 8192 * 4 * sizeof(u64)));  // max MRH_FUSED_GRID
+  CREATE_TRY(hipMalloc((void**) &c->d_cnt_partials, (size_t) 32768 * 4 * sizeof(u64)));  // max MRH_FUSED_GRID
   memset(&c->fast, 0, sizeof c->fast);
   CREATE_TRY(hipMalloc((void**) &c->fast.summary, c->num_blocks * sizeof(uint2)));
   c->fast.compact_cap = (u32) c->num_blocks;
@@ -343,12 +436,15 @@ int mrh_create(const mrh_params* p, mrh_ctx** out) {
   m.min_weight_threshold = p->min_weight_threshold;
   m.shard_rank = c->p.shard_rank;
   m.shard_count = c->p.shard_count;
+  m.shard_chunk_log2 = (p->shard_chunk_log2 > 0 && p->shard_chunk_log2 < 16) ? p->shard_chunk_log2 : 3;
 
   if (const char* g = getenv("MRH_FUSED_GRID")) {  // tuning knob: workgroups (x4 waves) of the fused integrate kernel
     const int v = atoi(g);
-    if (v > 0 && v <= 8192) c->fused_grid = v;
+    if (v > 0 && v <= 32768) c->fused_grid = v;
   }
   if (const char* g = getenv("MRH_FUSED_NB")) c->fused_nb = atoi(g) == 1 ? 1 : 2;
+  if (const char* g = getenv("MRH_FUSED_PIPE")) c->fused_pipe = atoi(g) ? 1 : 0;
+  if (const char* g = getenv("MRH_FUSED_WG")) { const int v = atoi(g); if (v == 64 || v == 128 || v == 256) c->fused_wg = v; }
   int rc = init_buffers(c);
   if (rc != MRH_OK) {
     g_create_err = c->err;
@@ -468,6 +564,7 @@ int mrh_set_rgb_device(mrh_ctx* c, const uint8_t* d_rgb, int rows, int cols) {
 int mrh_integrate(mrh_ctx* c, int n_frames_invalidate) {
   int rc = ensure_ready(c, "mrh_integrate");
   if (rc) return rc;
+  if (c->pending) return fail(c, MRH_ERR_STATE, "mrh_integrate: an exchange is pending (call mrh_integrate_resume)");
   if (!c->has_camera) return fail(c, MRH_ERR_STATE, "mrh_integrate: set_camera has not been called");
   if (c->spherical) return fail(c, MRH_ERR_UNSUPPORTED, "mrh_integrate: spherical (LiDAR) camera model is outside this round's scope");
   if (!c->d_depth || !c->d_rgb) return fail(c, MRH_ERR_STATE, "mrh_integrate: depth and rgb images are required");
@@ -504,37 +601,13 @@ int mrh_integrate(mrh_ctx* c, int n_frames_invalidate) {
       else if (c->ev_pending.size() >= 4096) { HIP_TRY(c, hipStreamSynchronize(s)); rc = drain_events(c); if (rc) return rc; ev = c->ev_pool.back(); c->ev_pool.pop_back(); }
       else { HIP_TRY(c, hipEventCreate(&ev.a)); HIP_TRY(c, hipEventCreate(&ev.b)); }
       HIP_TRY(c, hipEventRecord(ev.a, s));
-      if (c->fused_nb == 1) k_fused<true, 1><<<c->fused_grid, 256, 0, s>>>(k, m, t, f);
-      else k_fused<true, 2><<<c->fused_grid, 256, 0, s>>>(k, m, t, f);
+      launch_fused(c);
       HIP_TRY(c, hipEventRecord(ev.b, s));
       c->ev_pending.push_back(ev);
     } else {
-      if (c->fused_nb == 1) k_fused<true, 1><<<c->fused_grid, 256, 0, s>>>(k, m, t, f);
-      else k_fused<true, 2><<<c->fused_grid, 256, 0, s>>>(k, m, t, f);
+      launch_fused(c);
     }
-    if (max_num_frames > 0) {
-      if (c->frames > 0 && c->frames % (uint64_t) max_num_frames == 0) {
-        if (c->zbuf_n < npix) {
-          HIP_TRY(c, hipStreamSynchronize(s));
-          if (c->d_zbuf) HIP_TRY(c, hipFree(c->d_zbuf));
-          c->d_zbuf = nullptr;
-          HIP_TRY(c, hipMalloc((void**) &c->d_zbuf, 2 * npix * sizeof(u64)));
-          c->zbuf_n = npix;
-        }
-        HIP_TRY(c, hipMemsetAsync(c->d_zbuf, 0xFF, 2 * npix * sizeof(u64), s));
-        // culled blocks have no voxel inside the image, so starving the visible list is starving the compact list
-        k_starve<0><<<c->integrate_grid, 512, 0, s>>>(k, m, t, c->d_zbuf, c->d_zbuf + npix);
-        k_starve<1><<<c->integrate_grid, 512, 0, s>>>(k, m, t, c->d_zbuf, c->d_zbuf + npix);
-        k_starve<2><<<c->integrate_grid, 512, 0, s>>>(k, m, t, c->d_zbuf, c->d_zbuf + npix);
-        k_fused<false, 2><<<c->fused_grid, 256, 0, s>>>(k, m, t, f);  // weights changed: refresh the summaries
-      }
-      const float thr = m.trunc + m.trunc_scale * k.max_depth;
-      if (c->profile) k_free2<true><<<256, 256, 0, s>>>(t, f, thr);
-      else k_free2<false><<<256, 256, 0, s>>>(t, f, thr);
-    }
-    c->frames++;
-    HIP_TRY(c, hipGetLastError());
-    return MRH_OK;
+    return starve_and_tail(c, max_num_frames);
   }
 
   if (t.multi_res) {
@@ -571,29 +644,33 @@ int mrh_integrate(mrh_ctx* c, int n_frames_invalidate) {
     k_reintegrate<<<1024, 64, 0, s>>>(k, m, t, c->d_depth, c->d_rgb, c->d_reint);
   }
 
-  if (max_num_frames > 0) {
-    // voxel_data_structures.cpp:137-145 garbageCollect
-    if (c->frames > 0 && c->frames % (uint64_t) max_num_frames == 0) {
-      const size_t npix = (size_t) k.rows * k.cols;
-      if (c->zbuf_n < npix) {
-        HIP_TRY(c, hipStreamSynchronize(s));
-        if (c->d_zbuf) HIP_TRY(c, hipFree(c->d_zbuf));
-        c->d_zbuf = nullptr;
-        HIP_TRY(c, hipMalloc((void**) &c->d_zbuf, 2 * npix * sizeof(u64)));
-        c->zbuf_n = npix;
-      }
-      HIP_TRY(c, hipMemsetAsync(c->d_zbuf, 0xFF, 2 * npix * sizeof(u64), s));
-      k_starve<0><<<c->integrate_grid, 512, 0, s>>>(k, m, t, c->d_zbuf, c->d_zbuf + npix);
-      k_starve<1><<<c->integrate_grid, 512, 0, s>>>(k, m, t, c->d_zbuf, c->d_zbuf + npix);
-      k_starve<2><<<c->integrate_grid, 512, 0, s>>>(k, m, t, c->d_zbuf, c->d_zbuf + npix);
-    }
-    const float thr = m.trunc + m.trunc_scale * k.max_depth;  // getTruncation(camera.maxDepth(), ...), vds.cu:1720
-    k_gc_identify<<<c->integrate_grid, 512, 0, s>>>(t, thr, c->d_decision);
-    if (c->profile) k_gc_free<true><<<256, 256, 0, s>>>(t, c->d_decision);
-    else k_gc_free<false><<<256, 256, 0, s>>>(t, c->d_decision);
+  return starve_and_tail(c, max_num_frames);
+}
+
+int mrh_integrate_resume(mrh_ctx* c) {
+  int rc = ensure_ready(c, "mrh_integrate_resume");
+  if (rc) return rc;
+  if (c->pending == 1) {
+    launch_starve(c, 1);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->pending = 2;
+    return MRH_PENDING_EXCHANGE;
   }
-  c->frames++;
-  HIP_TRY(c, hipGetLastError());
+  if (c->pending == 2) {
+    launch_starve(c, 2);
+    c->pending = 0;
+    return frame_tail(c, true, c->pending_max_frames);
+  }
+  return fail(c, MRH_ERR_STATE, "mrh_integrate_resume: no exchange is pending");
+}
+
+int mrh_exchange_buffer(mrh_ctx* c, void** out_ptr, uint64_t* out_n, int* out_is_device) {
+  if (!c || !out_ptr || !out_n) return MRH_ERR_INVALID_ARG;
+  if (c->pending == 0) return fail(c, MRH_ERR_STATE, "mrh_exchange_buffer: no exchange is pending");
+  const size_t npix = (size_t) c->cam.rows * c->cam.cols;
+  *out_ptr = c->pending == 1 ? (void*) c->d_zbuf : (void*) (c->d_zbuf + npix);
+  *out_n = npix;
+  if (out_is_device) *out_is_device = 1;
   return MRH_OK;
 }
 
@@ -625,7 +702,7 @@ int mrh_get_stats(mrh_ctx* c, mrh_stats* out) {
   int h_ctr[CTR_COUNT];
   u64 h_prof[PROF_COUNT];
   const bool fastp = !c->tab.multi_res;
-  std::vector<u64> partials(fastp ? (size_t) 8192 * 4 : (size_t) c->integrate_grid);
+  std::vector<u64> partials(fastp ? (size_t) 32768 * 4 : (size_t) c->integrate_grid);
   HIP_TRY(c, hipMemcpyAsync(h_ctr, c->tab.ctr, sizeof h_ctr, hipMemcpyDeviceToHost, s));
   HIP_TRY(c, hipMemcpyAsync(h_prof, c->tab.prof, sizeof h_prof, hipMemcpyDeviceToHost, s));
   HIP_TRY(c, hipMemcpyAsync(partials.data(), fastp ? c->d_cnt_partials : c->d_upd_partials, partials.size() * sizeof(u64), hipMemcpyDeviceToHost, s));
@@ -668,6 +745,8 @@ int mrh_extract_triangles(mrh_ctx* c, const mrh_triangle** out_tris, uint64_t* o
   rc = compact_all(c, &n);
   if (rc) return rc;
   c->tris.clear();
+  c->tri_blocks.clear();
+  c->tri_counts.clear();
   c->last_triangles = 0;
   if (n > 0) {
     // canonical order: sort the block list by position (packed-key order == (x,y,z) order)
@@ -691,6 +770,9 @@ int mrh_extract_triangles(mrh_ctx* c, const mrh_triangle** out_tris, uint64_t* o
     std::vector<u64> offsets((size_t) n);
     u64 total = 0;
     for (int i = 0; i < n; i++) { offsets[i] = total; total += counts[i]; }
+    c->tri_counts = counts;
+    c->tri_blocks.resize((size_t) n);
+    for (int i = 0; i < n; i++) c->tri_blocks[i] = {list[i].x, list[i].y, list[i].z, (list[i].w & (int) kValCoarseBit) ? 1 : 0};
     if (total > c->max_triangles) {
       (void) hipFree(d_counts); (void) hipFree(d_offsets);
       return fail(c, MRH_ERR_CAPACITY, "triangle buffer full: %llu triangles > max_triangles %llu", (unsigned long long) total, (unsigned long long) c->max_triangles);
@@ -767,6 +849,47 @@ int mrh_get_voxel(mrh_ctx* c, int32_t vx, int32_t vy, int32_t vz, mrh_voxel* out
   out->rgb[0] = h[2] & 0xFF; out->rgb[1] = (h[2] >> 8) & 0xFF; out->rgb[2] = (h[2] >> 16) & 0xFF;
   out->weight = (uint8_t) (h[2] >> 24);
   if (out_found) *out_found = (int) h[3];
+  return MRH_OK;
+}
+
+int mrh_import_blocks(mrh_ctx* c, const mrh_block_desc* descs, const mrh_voxel* voxels, uint64_t n) {
+  int rc = ensure_ready(c, "mrh_import_blocks");
+  if (rc) return rc;
+  if (n == 0) return MRH_OK;
+  if (!descs || !voxels) return fail(c, MRH_ERR_INVALID_ARG, "mrh_import_blocks: null argument");
+  const uint64_t chunk = 8192;
+  int4* d_descs = nullptr;
+  char* d_vox = nullptr;
+  HIP_TRY(c, hipMalloc((void**) &d_descs, chunk * sizeof(int4)));
+  HIP_TRY(c, hipMalloc((void**) &d_vox, chunk * (size_t) kFineBytes));
+  for (uint64_t first = 0; first < n; first += chunk) {
+    const uint64_t cnt = (n - first) < chunk ? (n - first) : chunk;
+    HIP_TRY(c, hipMemcpyAsync(d_descs, &descs[first], cnt * sizeof(int4), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(d_vox, &voxels[first * 512], cnt * (size_t) kFineBytes, hipMemcpyHostToDevice, c->stream));
+    k_import<<<(int) (cnt < 2048 ? cnt : 2048), 512, 0, c->stream>>>(c->tab, c->fast.summary, (int) cnt, d_descs, d_vox);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+  }
+  HIP_TRY(c, hipFree(d_descs));
+  HIP_TRY(c, hipFree(d_vox));
+  HIP_TRY(c, hipGetLastError());
+  u32 flags = 0;
+  HIP_TRY(c, hipMemcpy(&flags, &c->tab.ctr[CTR_ERROR], sizeof(u32), hipMemcpyDeviceToHost));
+  return check_device_flags(c, flags);
+}
+
+int mrh_get_triangle_blocks(mrh_ctx* c, const mrh_block_desc** out_descs, const uint32_t** out_counts, uint64_t* out_n) {
+  if (!c || !out_descs || !out_counts || !out_n) return MRH_ERR_INVALID_ARG;
+  *out_descs = c->tri_blocks.empty() ? nullptr : c->tri_blocks.data();
+  *out_counts = c->tri_counts.empty() ? nullptr : c->tri_counts.data();
+  *out_n = c->tri_blocks.size();
+  return MRH_OK;
+}
+
+int mrh_process_triangles(mrh_ctx* c, const mrh_triangle* triangles, uint64_t n) {
+  if (!c || (n && !triangles)) return MRH_ERR_INVALID_ARG;
+  c->tris.assign(triangles, triangles + n);
+  c->last_triangles = n;
+  process_triangles(c);
   return MRH_OK;
 }
 

@@ -70,7 +70,7 @@ struct Map {
   int weight_sample;  // as u8 (vds.cu:1101)
   int weight_max;     // as u8 (vds.cu:1102)
   int min_weight_threshold;
-  int shard_rank, shard_count;
+  int shard_rank, shard_count, shard_chunk_log2;
 };
 
 // Open-address table + pools.  Layout in HBM:
@@ -249,10 +249,12 @@ __device__ __forceinline__ u32 hash_key(u64 k) {
   return (u32) k;
 }
 
-// multi-GPU tile ownership: 8x8x8-block chunks, hashed (DESIGN.md "sharding")
+// multi-GPU tile ownership: cubes of 2^shard_chunk_log2 blocks, hashed (DESIGN.md "sharding");
+// mirrored on the host by mrhash_amd/parallel.py:owner_of_blocks
 __device__ __forceinline__ bool owns_block(const Map& m, i3 b) {
   if (m.shard_count <= 1) return true;
-  const u32 cx = (u32) (b.x >> 3), cy = (u32) (b.y >> 3), cz = (u32) (b.z >> 3);
+  const int sh = m.shard_chunk_log2;
+  const u32 cx = (u32) (b.x >> sh), cy = (u32) (b.y >> sh), cz = (u32) (b.z >> sh);
   const u32 h = (cx * 73856093u) ^ (cy * 19349669u) ^ (cz * 83492791u);
   return (int) ((h ^ (h >> 15)) % (u32) m.shard_count) == m.shard_rank;
 }

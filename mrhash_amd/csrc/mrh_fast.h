@@ -384,6 +384,56 @@ __device__ __forceinline__ void blend4(const Map& m, const Proj4& P, const u32 m
   }
 }
 
+// ---- LDS pixel tile ----------------------------------------------------------------------------------------
+// dense, row-contiguous fill of the block's pixel footprint {depth bits, colour}
+__device__ __forceinline__ void tile_fill(const Cam& c, const Fast& f, const int4 bb, const int lane, uint2* tile) {
+  const int npx = bb.z * bb.w;
+  if (npx <= 0) return;
+  const float inv_w = 1.0f / (float) bb.z;
+  for (int p = lane; p < npx; p += 64) {
+    const int r = (int) (((float) p + 0.5f) * inv_w);  // p / w for p < 2^10 (exact: slack 0.5 / w >> fp32 error)
+    const int cc = p - r * bb.z;
+    const u32 g = (u32) (__mul24(bb.y + r, c.cols) + bb.x + cc);
+    tile[p] = make_uint2(__float_as_uint(f.depth_clean[g]), f.rgbx[g]);
+  }
+}
+
+// branch-free lookups: all NB x 4 ds_read_b64 are issued back to back; pixels outside the footprint (or blocks
+// without a tile) take ONE wave-uniform fallback branch with direct gathers.
+template <int NB>
+__device__ __forceinline__ void tile_lookup(const Fast& f, const int4 bb, const uint2* tile, const Proj4 (&P)[NB],
+                                            float (&d)[NB][4], u32 (&cpx)[NB][4]) {
+  u32 miss = 0;
+  u32 li[NB][4];
+#pragma unroll
+  for (int b = 0; b < NB; b++)
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const u32 lr = (u32) (P[b].row[k] - bb.y), lc = (u32) (P[b].col[k] - bb.x);
+      const bool in = lr < (u32) bb.w && lc < (u32) bb.z;
+      li[b][k] = in ? lr * (u32) bb.z + lc : 0u;
+      if (!in && ((P[b].mask >> k) & 1u)) miss |= 1u << (b * 4 + k);
+    }
+#pragma unroll
+  for (int b = 0; b < NB; b++)
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const uint2 px = tile[li[b][k]];
+      d[b][k] = __uint_as_float(px.x);
+      cpx[b][k] = px.y;
+    }
+  if (__ballot(miss != 0)) {
+#pragma unroll
+    for (int b = 0; b < NB; b++)
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+        if ((miss >> (b * 4 + k)) & 1u) {
+          d[b][k] = f.depth_clean[P[b].pix[k]];
+          cpx[b][k] = f.rgbx[P[b].pix[k]];
+        }
+  }
+}
+
 // One wave owns NB x 256 voxels: NB = 2 -> a whole block per wave (summary written with a plain store),
 // NB = 1 -> half a block per wave (twice the parallelism; the two halves meet in the summary through
 // atomicMin / atomicMax on the raw bits — |sdf| >= 0, so float order == unsigned order; k_compact2 resets it).
@@ -393,12 +443,13 @@ __device__ __forceinline__ void blend4(const Map& m, const Proj4& P, const u32 m
 // the depth gather (same pixel index) instead of after the depth test.
 template <bool INTEGRATE, int NB>
 __global__ __launch_bounds__(256) void k_fused(const Cam c, const Map m, const Tab t, const Fast f) {
-  __shared__ uint2 s_tile[INTEGRATE ? 4 * kTileMaxPx : 1];
+  extern __shared__ __attribute__((aligned(16))) uint2 s_tile[];  // (blockDim.x / 64) x kTileMaxPx
   const int nvis = t.ctr[CTR_COMPACT];
   const int nitems = nvis * (2 / NB);
   const int lane = threadIdx.x & 63;
-  const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int nw = gridDim.x * 4;
+  const int wpw = blockDim.x >> 6;
+  const int gw = blockIdx.x * wpw + (threadIdx.x >> 6);
+  const int nw = gridDim.x * wpw;
   const float r_half_vs = rcp_refined(m.vs / 2);
   for (int e = gw; e < nitems; e += nw) {
     const int4 ent = t.compact[NB == 2 ? e : (e >> 1)];
@@ -423,37 +474,14 @@ __global__ __launch_bounds__(256) void k_fused(const Cam c, const Map m, const T
       // loads; the per-voxel lookups then hit LDS instead of issuing 64-address global gathers (one lane per
       // cycle in the texture addresser — measured as half of this kernel's time)
       const int4 bb = f.bbox[NB == 2 ? e : (e >> 1)];
-      const int npx = bb.z * bb.w;
       uint2* tile = &s_tile[(threadIdx.x >> 6) * kTileMaxPx];
-      if (npx > 0) {
-        const float inv_w = 1.0f / (float) bb.z;
-        for (int p = lane; p < npx; p += 64) {
-          const int r = (int) (((float) p + 0.5f) * inv_w);
-          const int cc = p - r * bb.z;
-          const u32 g = (u32) (__mul24(bb.y + r, c.cols) + bb.x + cc);
-          tile[p] = make_uint2(__float_as_uint(f.depth_clean[g]), f.rgbx[g]);
-        }
-      }
+      tile_fill(c, f, bb, lane, tile);
 #pragma unroll
       for (int b = 0; b < NB; b++) P[b] = project4(c, m, ent, lane + 64 * (b + half));
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-      for (int b = 0; b < NB; b++) {
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-          const u32 lr = (u32) (P[b].row[k] - bb.y), lc = (u32) (P[b].col[k] - bb.x);
-          if (lr < (u32) bb.w && lc < (u32) bb.z) {
-            const uint2 px = tile[lr * (u32) bb.z + lc];
-            d[b][k] = __uint_as_float(px.x);
-            cpx[b][k] = px.y;
-          } else {  // outside the footprint (or no tile): direct gather; pix is 0 for voxels that project nowhere
-            d[b][k] = f.depth_clean[P[b].pix[k]];
-            cpx[b][k] = f.rgbx[P[b].pix[k]];
-          }
-        }
-      }
+      tile_lookup<NB>(f, bb, tile, P, d, cpx);
       __builtin_amdgcn_wave_barrier();  // the tile is rewritten by this wave's next item
     }
     float mn = kFltMax;
@@ -500,6 +528,128 @@ __global__ __launch_bounds__(256) void k_fused(const Cam c, const Map m, const T
         atomicMax(&f.summary[H].y, mx);
       }
     }
+  }
+}
+
+// Software-pipelined variant: a wave that owns several items requests the voxel planes of item i+1 right after
+// item i's pixel tile has been consumed, so the HBM latency of the next block hides under the blend arithmetic
+// and the stores of the current one (the plain variant has every wave of the chip load, compute and store in
+// lock-step, which leaves the memory system idle while the VALUs work and vice versa).
+template <int NB>
+__global__ __launch_bounds__(256) void k_fused_pipe(const Cam c, const Map m, const Tab t, const Fast f) {
+  __shared__ uint2 s_tile[4 * kTileMaxPx];
+  const int nvis = t.ctr[CTR_COMPACT];
+  const int nitems = nvis * (2 / NB);
+  const int lane = threadIdx.x & 63;
+  const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int nw = gridDim.x * 4;
+  const float r_half_vs = rcp_refined(m.vs / 2);
+  uint2* tile = &s_tile[(threadIdx.x >> 6) * kTileMaxPx];
+  int e = gw;
+  if (e >= nitems) return;
+  int4 ent = t.compact[NB == 2 ? e : (e >> 1)];
+  int4 bb = f.bbox[NB == 2 ? e : (e >> 1)];
+  float4 S[NB];
+  uint4 W[NB];
+  {
+    const float4* ps = (const float4*) (t.pool + (size_t) (u32) ent.w * kFineBytes);
+    const uint4* pw = (const uint4*) (ps + 256);
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+      const int q = lane + 64 * (b + (NB == 2 ? 0 : (e & 1)));
+      S[b] = ps[q];
+      W[b] = pw[q];
+    }
+  }
+  while (true) {
+    const int half = NB == 2 ? 0 : (e & 1);
+    const int en = e + nw;
+    const bool more = en < nitems;
+    // (1) pixel tile of the current item
+    tile_fill(c, f, bb, lane, tile);
+    // (2) descriptor of the next item (tiny loads, consumed after the blend)
+    int4 ent_n = ent, bb_n = bb;
+    if (more) {
+      ent_n = t.compact[NB == 2 ? en : (en >> 1)];
+      bb_n = f.bbox[NB == 2 ? en : (en >> 1)];
+    }
+    // (3) projections, then tile lookups
+    Proj4 P[NB];
+    float d[NB][4];
+    u32 cpx[NB][4];
+#pragma unroll
+    for (int b = 0; b < NB; b++) P[b] = project4(c, m, ent, lane + 64 * (b + half));
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    tile_lookup<NB>(f, bb, tile, P, d, cpx);
+    __builtin_amdgcn_wave_barrier();
+    // (4) voxel planes of the next item: in flight during the blend + stores below
+    float4 Sn[NB];
+    uint4 Wn[NB];
+#pragma unroll
+    for (int b = 0; b < NB; b++) { Sn[b] = S[b]; Wn[b] = W[b]; }
+    if (more) {
+      const float4* psn = (const float4*) (t.pool + (size_t) (u32) ent_n.w * kFineBytes);
+      const uint4* pwn = (const uint4*) (psn + 256);
+#pragma unroll
+      for (int b = 0; b < NB; b++) {
+        const int q = lane + 64 * (b + (NB == 2 ? 0 : (en & 1)));
+        Sn[b] = psn[q];
+        Wn[b] = pwn[q];
+      }
+    }
+    // (5) blend + stores + summary of the current item
+    const u32 H = (u32) ent.w;
+    float4* ps = (float4*) (t.pool + (size_t) H * kFineBytes);
+    float4* pq = ps + 128;
+    uint4* pw = (uint4*) (ps + 256);
+    float mn = kFltMax;
+    u32 mx = 0;
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+      const int q = lane + 64 * (b + half);
+      float s[4] = {S[b].x, S[b].y, S[b].z, S[b].w};
+      u32 w[4] = {W[b].x, W[b].y, W[b].z, W[b].w};
+      float ss[4] = {0.f, 0.f, 0.f, 0.f};
+      const u32 mask = update_mask4(c, m, P[b], d[b]);
+      blend4(m, P[b], mask, d[b], cpx[b], r_half_vs, s, w, ss);
+      if (mask) {
+        ps[q] = make_float4(s[0], s[1], s[2], s[3]);
+        pw[q] = make_uint4(w[0], w[1], w[2], w[3]);
+        if (mask == 0xF) {
+          pq[q] = make_float4(ss[0], ss[1], ss[2], ss[3]);
+        } else {
+          float* pqs = (float*) (pq + q);
+#pragma unroll
+          for (int k = 0; k < 4; k++)
+            if (mask & (1u << k)) pqs[k] = ss[k];
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const u32 wk = w[k] >> 24;
+        if (wk != 0) mn = fminf(mn, fabsf(s[k]));
+        mx = wk > mx ? wk : mx;
+      }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+      mn = fminf(mn, __shfl_xor(mn, off));
+      const u32 o = __shfl_xor(mx, off);
+      mx = o > mx ? o : mx;
+    }
+    if (lane == 0) {
+      if (NB == 2) {
+        f.summary[H] = make_uint2(__float_as_uint(mn), mx);
+      } else {
+        atomicMin(&f.summary[H].x, __float_as_uint(mn));
+        atomicMax(&f.summary[H].y, mx);
+      }
+    }
+    if (!more) break;
+    e = en; ent = ent_n; bb = bb_n;
+#pragma unroll
+    for (int b = 0; b < NB; b++) { S[b] = Sn[b]; W[b] = Wn[b]; }
   }
 }
 

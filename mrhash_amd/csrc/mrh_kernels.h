@@ -582,6 +582,9 @@ __global__ __launch_bounds__(64) void k_reintegrate(const Cam c, const Map m, co
 __global__ __launch_bounds__(256) void k_init_table(u64* keys, const size_t slots) {
   for (size_t i = (size_t) blockIdx.x * 256 + threadIdx.x; i < slots; i += (size_t) gridDim.x * 256) keys[i] = kKeyEmpty;
 }
+__global__ __launch_bounds__(256) void k_fill_u64(u64* p, const size_t n, const u64 v) {
+  for (size_t i = (size_t) blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t) gridDim.x * 256) p[i] = v;
+}
 // heap[i] = N - 1 - i (voxel_data_structures.cpp:60-66)
 __global__ __launch_bounds__(256) void k_init_heap(u32* heap, const u32 n) {
   for (size_t i = (size_t) blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t) gridDim.x * 256) heap[i] = n - 1 - (u32) i;
@@ -622,6 +625,83 @@ __global__ __launch_bounds__(512) void k_dump(const Tab t, const int first, cons
     out[0] = __float_as_uint(sdf);
     out[1] = __float_as_uint(ss);
     out[2] = rgbw;
+  }
+}
+
+// reference 12-byte Voxel AoS -> SoA pool, one workgroup per imported block (inverse of k_dump)
+__global__ __launch_bounds__(512) void k_import(const Tab t, uint2* __restrict__ summary, const int n, const int4* __restrict__ descs,
+                                                const char* __restrict__ voxels) {
+  __shared__ u32 s_val;
+  __shared__ float s_min[8];
+  __shared__ u32 s_max[8];
+  const int v = threadIdx.x;
+  for (int e = blockIdx.x; e < n; e += gridDim.x) {
+    const int4 d = descs[e];
+    const bool coarse = d.w != 0;
+    if (v == 0) {
+      u32 val = 0xFFFFFFFFu;
+      u64 key;
+      if (!pack_key(mki3(d.x, d.y, d.z), key)) {
+        atomicOr((u32*) &t.ctr[CTR_ERROR], ERR_RANGE);
+      } else {
+        int slot = hash_find(t, key);
+        if (slot >= 0 && ((t.vals[slot] & kValCoarseBit) != 0) == coarse) {
+          val = t.vals[slot];  // overwrite in place
+        } else if (slot >= 0) {
+          atomicOr((u32*) &t.ctr[CTR_ERROR], ERR_TABLE);  // same position at another resolution: not supported
+        } else {
+          slot = hash_insert(t, key);
+          if (slot < 0) {
+            atomicOr((u32*) &t.ctr[CTR_ERROR], ERR_TABLE);
+          } else {
+            const int idx = atomicSub(&t.ctr[coarse ? CTR_HEAP_COARSE : CTR_HEAP_FINE], 1);
+            if (idx < 0) {
+              atomicAdd(&t.ctr[coarse ? CTR_HEAP_COARSE : CTR_HEAP_FINE], 1);
+              atomicExch(&t.keys[slot], kKeyTomb);
+              atomicOr((u32*) &t.ctr[CTR_ERROR], ERR_POOL);
+            } else if (coarse) {
+              const u32 u = t.heap_coarse[idx];
+              val = u | kValCoarseBit;
+              t.vals[slot] = val;
+              t.desc_coarse[u] = make_int4(d.x, d.y, d.z, 1);
+            } else {
+              const u32 H = t.heap_fine[idx];
+              val = H;
+              t.vals[slot] = val;
+              t.desc_fine[H] = make_int4(d.x, d.y, d.z, 1);
+              atomicMax(&t.ctr[CTR_HWM_FINE], (int) H + 1);
+            }
+          }
+        }
+      }
+      s_val = val;
+    }
+    __syncthreads();
+    const u32 val = s_val;
+    float mn = 3.402823466e+38f;
+    u32 mx = 0;
+    if (val != 0xFFFFFFFFu && (!coarse || v < kCoarseVoxels)) {
+      const u32* in = (const u32*) (voxels + ((size_t) e * kBlockVoxels + v) * 12);
+      const VoxPtr vp = vox_ptr(t, val);
+      const float sdf = __uint_as_float(in[0]);
+      vp.sdf[v] = sdf;
+      vp.sumsq[v] = __uint_as_float(in[1]);
+      vp.rgbw[v] = in[2];
+      mx = in[2] >> 24;
+      if (mx != 0) mn = fabsf(sdf);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+      mn = fminf(mn, __shfl_xor(mn, off));
+      const u32 o = __shfl_xor(mx, off);
+      mx = o > mx ? o : mx;
+    }
+    if (lane_id() == 0) { s_min[v >> 6] = mn; s_max[v >> 6] = mx; }
+    __syncthreads();
+    if (v == 0 && val != 0xFFFFFFFFu && !coarse && summary) {
+      for (int i = 1; i < 8; i++) { mn = fminf(mn, s_min[i]); mx = s_max[i] > mx ? s_max[i] : mx; }
+      summary[val] = make_uint2(__float_as_uint(mn), mx);  // GC summary of the fast path
+    }
+    __syncthreads();
   }
 }
 

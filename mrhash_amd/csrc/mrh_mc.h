@@ -215,7 +215,8 @@ __global__ __launch_bounds__(512) void k_mc(const Map m, const Tab t, const int4
     const bool coarse = (val & kValCoarseBit) != 0;
     int ntri = 0;
     mrh_triangle tris[5];
-    if (!coarse || v < kCoarseVoxels) {
+    // sharded maps: halo blocks imported from other ranks are read by the lookups but emit nothing themselves
+    if ((!coarse || v < kCoarseVoxels) && owns_block(m, mki3(ent.x, ent.y, ent.z))) {
       i3 pi;
       if (!coarse) pi = mki3(ent.x * kBlockSide + (v & 7), ent.y * kBlockSide + ((v >> 3) & 7), ent.z * kBlockSide + (v >> 6));
       else pi = mki3(ent.x * kBlockSide + 2 * (v & 3), ent.y * kBlockSide + 2 * ((v >> 2) & 3), ent.z * kBlockSide + 2 * (v >> 4));

@@ -120,9 +120,13 @@ struct mrh_ctx {
   uint64_t* depth_buff;
   size_t depth_buff_n;
   uint64_t frames;
+  int pending; /* 0 none, 1 after starve pass 0, 2 after pass 1 (sharded contexts) */
   /* mesh */
   mrh_triangle* tris;
   uint64_t ntris, cap_tris, max_triangles;
+  mrh_block_desc* tri_blocks;
+  uint32_t* tri_counts;
+  uint64_t n_tri_blocks;
   double* V;
   double* C;
   int32_t* F;
@@ -604,6 +608,16 @@ static int trilinear(const mrh_ctx* c, f3 pos, float* dist) {
   return 1;
 }
 
+/* multi-GPU tile ownership (no reference counterpart; mirrors mrh_device.h owns_block so that the sharded host
+ * logic can be tested on the CPU with gloo) */
+static int owns_block(const mrh_ctx* c, i3 b) {
+  if (c->p.shard_count <= 1) return 1;
+  const int sh = (c->p.shard_chunk_log2 > 0 && c->p.shard_chunk_log2 < 16) ? c->p.shard_chunk_log2 : 3;
+  const uint32_t cx = (uint32_t) (b.x >> sh), cy = (uint32_t) (b.y >> sh), cz = (uint32_t) (b.z >> sh);
+  const uint32_t h = (cx * P0) ^ (cy * P1) ^ (cz * P2);
+  return (int) ((h ^ (h >> 15)) % (uint32_t) c->p.shard_count) == c->p.shard_rank;
+}
+
 /* ---- allocation: vds.cu:758-922 ----------------------------------------------------------- */
 
 /* vds.cu:758-857 allocBlocksKernel, one pixel */
@@ -645,7 +659,7 @@ static void alloc_pixel(mrh_ctx* c, unsigned row, unsigned col) {
 
   unsigned iter = 0;
   while (iter < MAX_DDA_ITERATION_COUNT) {
-    if (block_in_frustum_approx(c, cur)) (void) alloc_block(c, cur, 0, 0);
+    if (owns_block(c, cur) && block_in_frustum_approx(c, cur)) (void) alloc_block(c, cur, 0, 0);
     if (t_max.x < t_max.y && t_max.x < t_max.z) {
       cur.x = f2i((float) cur.x + step.x);
       if (cur.x == bound.x) return;
@@ -860,48 +874,56 @@ static void reintegrate_depth_map(mrh_ctx* c) {
 
 /* ---- garbage collection: voxel_data_structures.cpp:137-145, vds.cu:1583-1713, 1827-1844 -- */
 
-static inline uint64_t pack_tid_depth(int a, float b) {
-  uint32_t bb, aa;
-  memcpy(&bb, &b, 4);
-  memcpy(&aa, &a, 4);
-  return (((uint64_t) bb) << 32) + aa;
+/* vds.cu:1583-1585 pack(tid, depth) = (depth bits << 32) + tid.  The thread id is the race-ordered compact index
+ * in the reference; the canonical tie-break (C1) is (block position, voxel index), which needs 63 + 9 bits, so the
+ * key is split over two min-buffers: hi = depth bits << 32 | key72 >> 40, lo = key72 & (2^40 - 1), with
+ * key72 = packed block position << 9 | voxel index.  For one map this orders candidates exactly like
+ * pack(512 * sorted_block_index + voxel, depth); for tile shards it is also independent of which rank holds a
+ * block, so an element-wise MIN over ranks gives the single-map z-buffer. */
+static inline uint64_t pack_block_key(i3 b) {
+  return ((uint64_t) (uint32_t) (b.x + (1 << 20)) << 42) | ((uint64_t) (uint32_t) (b.y + (1 << 20)) << 21) | (uint64_t) (uint32_t) (b.z + (1 << 20));
 }
 
-static void starve_voxels(mrh_ctx* c) {
+/* pass 0: zbuf0 = min hi; pass 1: among hi-winners zbuf1 = min lo; pass 2: the winner loses one weight */
+static void starve_pass(mrh_ctx* c, int pass) {
   const size_t npix = (size_t) c->rows * c->cols;
-  if (c->depth_buff_n < npix) {
-    free(c->depth_buff);
-    c->depth_buff = (uint64_t*) malloc(npix * sizeof(uint64_t));
-    c->depth_buff_n = npix;
+  if (pass == 0) {
+    if (c->depth_buff_n < npix) {
+      free(c->depth_buff);
+      c->depth_buff = (uint64_t*) malloc(2 * npix * sizeof(uint64_t));
+      c->depth_buff_n = npix;
+    }
+    for (size_t i = 0; i < 2 * npix; i++) c->depth_buff[i] = (uint64_t) INT64_MAX;
   }
-  for (size_t i = 0; i < npix; i++) c->depth_buff[i] = UINT64_MAX;
-  if (c->current_occupied == 0) return;
+  uint64_t* z0 = c->depth_buff;
+  uint64_t* z1 = c->depth_buff + npix;
   const float vs = c->p.virtual_voxel_size;
-  for (int pass = 0; pass < 2; pass++) {
-    for (unsigned b = 0; b < c->current_occupied; b++) {
-      const HashEntry* entry = &c->compact[b];
-      const unsigned nthreads = entry->resolution == 0 ? 512u : 64u; /* D3 */
-      const i3 base = block_to_voxel(entry->pos);
-      for (unsigned i = 0; i < nthreads; i++) {
-        const i3 lc = delinearize(i, SDF_BLOCK_SIZE);
-        const i3 pi = {base.x + lc.x, base.y + lc.y, base.z + lc.z};
-        const f3 pf = voxel_to_world(vs, pi);
-        const f3 pcam = se3_apply(c->Ri, c->ti, pf);
-        const float depth = get_depth(c, pcam);
-        if (depth < c->min_depth) continue;
-        int row, col;
-        if (!project_point(c, pcam, 0, &row, &col)) continue;
-        const int unique_tid = (int) (512u * b + i);
-        const uint64_t key = pack_tid_depth(unique_tid, depth);
-        uint64_t* cell = &c->depth_buff[(size_t) row * c->cols + col];
-        if (pass == 0) {
-          if (key < *cell) *cell = key;
-        } else {
-          if (key != *cell) continue;
-          Voxel* v = &c->blocks[(size_t) entry->ptr + i];
-          const int w = (int) v->weight - 1;
-          v->weight = (uint8_t) (w > 0 ? w : 0);
-        }
+  for (unsigned b = 0; b < c->current_occupied; b++) {
+    const HashEntry* entry = &c->compact[b];
+    const unsigned nthreads = entry->resolution == 0 ? 512u : 64u; /* D3 */
+    const i3 base = block_to_voxel(entry->pos);
+    const uint64_t key = pack_block_key(entry->pos);
+    for (unsigned i = 0; i < nthreads; i++) {
+      const i3 lc = delinearize(i, SDF_BLOCK_SIZE);
+      const i3 pi = {base.x + lc.x, base.y + lc.y, base.z + lc.z};
+      const f3 pcam = se3_apply(c->Ri, c->ti, voxel_to_world(vs, pi));
+      const float depth = get_depth(c, pcam);
+      if (depth < c->min_depth) continue;
+      int row, col;
+      if (!project_point(c, pcam, 0, &row, &col)) continue;
+      uint32_t dbits;
+      memcpy(&dbits, &depth, 4);
+      const uint64_t hi = ((uint64_t) dbits << 32) | (key >> 31);
+      const uint64_t lo = ((key & 0x7FFFFFFFull) << 9) | (uint64_t) i;
+      const size_t pix = (size_t) row * c->cols + col;
+      if (pass == 0) {
+        if (hi < z0[pix]) z0[pix] = hi;
+      } else if (pass == 1) {
+        if (z0[pix] == hi && lo < z1[pix]) z1[pix] = lo;
+      } else if (z0[pix] == hi && z1[pix] == lo) {
+        Voxel* v = &c->blocks[(size_t) entry->ptr + i];
+        const int w = (int) v->weight - 1;
+        v->weight = (uint8_t) (w > 0 ? w : 0);
       }
     }
   }
@@ -940,8 +962,12 @@ static void gc_free(mrh_ctx* c) {
   }
 }
 
-static void garbage_collect(mrh_ctx* c, int max_num_frames) {
-  if (c->frames > 0 && c->frames % (uint64_t) max_num_frames == 0) starve_voxels(c);
+static int is_starve_frame(const mrh_ctx* c, int max_num_frames) {
+  return max_num_frames > 0 && c->frames > 0 && c->frames % (uint64_t) max_num_frames == 0;
+}
+
+/* garbageCollect after the (optional) starve: identify, resetHashBucketMutex, free */
+static void gc_tail(mrh_ctx* c) {
   gc_identify(c);
   reset_mutex(c);
   gc_free(c);
@@ -1057,17 +1083,26 @@ static void extract_at_position(mrh_ctx* c, f3 pf) {
 static void extract_iso_surface(mrh_ctx* c) {
   flat_and_reduce(c, 0);
   c->ntris = 0;
+  free(c->tri_blocks); free(c->tri_counts);
+  c->n_tri_blocks = c->current_occupied;
+  c->tri_blocks = (mrh_block_desc*) calloc(c->current_occupied ? c->current_occupied : 1, sizeof(mrh_block_desc));
+  c->tri_counts = (uint32_t*) calloc(c->current_occupied ? c->current_occupied : 1, sizeof(uint32_t));
   const float vs = c->p.virtual_voxel_size;
   for (unsigned e = 0; e < c->current_occupied; e++) {
     const HashEntry* entry = &c->compact[e];
     const int scaling = 1 << entry->resolution;
     const unsigned nv = (unsigned) num_voxels_of(entry->resolution);
     const i3 base = block_to_voxel(entry->pos);
-    for (unsigned v = 0; v < nv; v++) {
-      const i3 lc = delinearize(v, SDF_BLOCK_SIZE / scaling);
-      const i3 pi = {base.x + scaling * lc.x, base.y + scaling * lc.y, base.z + scaling * lc.z};
-      extract_at_position(c, voxel_to_world(vs, pi));
-    }
+    const uint64_t before = c->ntris;
+    if (owns_block(c, entry->pos)) /* halo blocks of other shards are looked up but emit nothing */
+      for (unsigned v = 0; v < nv; v++) {
+        const i3 lc = delinearize(v, SDF_BLOCK_SIZE / scaling);
+        const i3 pi = {base.x + scaling * lc.x, base.y + scaling * lc.y, base.z + scaling * lc.z};
+        extract_at_position(c, voxel_to_world(vs, pi));
+      }
+    c->tri_blocks[e].x = entry->pos.x; c->tri_blocks[e].y = entry->pos.y; c->tri_blocks[e].z = entry->pos.z;
+    c->tri_blocks[e].resolution = entry->resolution;
+    c->tri_counts[e] = (uint32_t) (c->ntris - before);
   }
 }
 
@@ -1261,7 +1296,7 @@ int mrh_destroy(mrh_ctx* c) {
   if (!c) return MRH_OK;
   free(c->table); free(c->compact); free(c->decision); free(c->mutex); free(c->heap_high); free(c->heap_low);
   free(c->blocks); free(c->realloc_pos); free(c->realloc_res); free(c->reintegrate); free(c->depth_buff);
-  free(c->depth); free(c->rgb); free(c->cloud); free(c->tris); free(c->V); free(c->C); free(c->F);
+  free(c->depth); free(c->rgb); free(c->cloud); free(c->tris); free(c->tri_blocks); free(c->tri_counts); free(c->V); free(c->C); free(c->F);
   free(c);
   return MRH_OK;
 }
@@ -1321,6 +1356,7 @@ int mrh_set_rgb_device(mrh_ctx* c, const uint8_t* d, int rows, int cols) { retur
 /* voxel_data_structures.cpp:90-110 VoxelContainer::integrate (+ camera.cu:21-26) */
 int mrh_integrate(mrh_ctx* c, int n_frames_invalidate) {
   if (!c) return MRH_ERR_INVALID_ARG;
+  if (c->pending) return fail(c, MRH_ERR_STATE, "mrh_integrate: an exchange is pending (call mrh_integrate_resume)");
   if (!c->has_camera) return fail(c, MRH_ERR_STATE, "mrh_integrate: set_camera has not been called");
   if (!c->depth || !c->rgb) return fail(c, MRH_ERR_STATE, "mrh_integrate: depth and rgb images are required");
   if (c->depth_rows != (int) c->rows || c->depth_cols != (int) c->cols || c->rgb_rows != (int) c->rows || c->rgb_cols != (int) c->cols)
@@ -1338,8 +1374,37 @@ int mrh_integrate(mrh_ctx* c, int n_frames_invalidate) {
     flat_and_reduce(c, 1);
     reintegrate_depth_map(c);
   }
-  if (max_num_frames > 0) garbage_collect(c, max_num_frames);
+  if (is_starve_frame(c, max_num_frames)) {
+    starve_pass(c, 0);
+    if (c->p.shard_count > 1) { c->pending = 1; return MRH_PENDING_EXCHANGE; }
+    starve_pass(c, 1);
+    starve_pass(c, 2);
+  }
+  if (max_num_frames > 0) gc_tail(c);
   c->frames++;
+  return MRH_OK;
+}
+
+int mrh_integrate_resume(mrh_ctx* c) {
+  if (!c) return MRH_ERR_INVALID_ARG;
+  if (c->pending == 1) { starve_pass(c, 1); c->pending = 2; return MRH_PENDING_EXCHANGE; }
+  if (c->pending == 2) {
+    starve_pass(c, 2);
+    gc_tail(c);
+    c->frames++;
+    c->pending = 0;
+    return MRH_OK;
+  }
+  return fail(c, MRH_ERR_STATE, "mrh_integrate_resume: no exchange is pending");
+}
+
+int mrh_exchange_buffer(mrh_ctx* c, void** ptr, uint64_t* n, int* is_device) {
+  if (!c || !ptr || !n) return MRH_ERR_INVALID_ARG;
+  if (c->pending == 0) return fail(c, MRH_ERR_STATE, "mrh_exchange_buffer: no exchange is pending");
+  const size_t npix = (size_t) c->rows * c->cols;
+  *ptr = c->pending == 1 ? (void*) c->depth_buff : (void*) (c->depth_buff + npix);
+  *n = npix;
+  if (is_device) *is_device = 0;
   return MRH_OK;
 }
 
@@ -1413,6 +1478,44 @@ int mrh_get_voxel(mrh_ctx* c, int32_t vx, int32_t vy, int32_t vz, mrh_voxel* out
   const HashEntry e = get_hash_entry(c, voxel_to_block(v, c->p.virtual_voxel_size, (float) c->p.voxel_extents_scale));
   if (found) *found = e.ptr != FREE_ENTRY;
   *out = get_voxel_i(c, v, NULL);
+  return MRH_OK;
+}
+
+int mrh_import_blocks(mrh_ctx* c, const mrh_block_desc* descs, const mrh_voxel* voxels, uint64_t n) {
+  if (!c || (n && (!descs || !voxels))) return MRH_ERR_INVALID_ARG;
+  for (uint64_t k = 0; k < n; k++) {
+    const i3 pos = {descs[k].x, descs[k].y, descs[k].z};
+    HashEntry e = get_hash_entry(c, pos);
+    if (e.ptr == FREE_ENTRY) {
+      int prev_free = heap_high_free(c) + heap_low_free(c);
+      for (;;) { /* allocBlock's retry protocol, vds.cu:901-921 */
+        reset_mutex(c);
+        (void) alloc_block(c, pos, descs[k].resolution, 0);
+        const int cur = heap_high_free(c) + heap_low_free(c);
+        if (cur == prev_free) break;
+        prev_free = cur;
+      }
+      e = get_hash_entry(c, pos);
+      if (e.ptr == FREE_ENTRY) return fail(c, MRH_ERR_CAPACITY, "mrh_import_blocks: could not insert block");
+    }
+    memcpy(&c->blocks[(size_t) e.ptr], &voxels[k * 512], (size_t) num_voxels_of(e.resolution) * sizeof(Voxel));
+  }
+  return MRH_OK;
+}
+
+int mrh_get_triangle_blocks(mrh_ctx* c, const mrh_block_desc** d, const uint32_t** n_per_block, uint64_t* n) {
+  if (!c || !d || !n_per_block || !n) return MRH_ERR_INVALID_ARG;
+  *d = c->tri_blocks; *n_per_block = c->tri_counts; *n = c->n_tri_blocks;
+  return MRH_OK;
+}
+
+int mrh_process_triangles(mrh_ctx* c, const mrh_triangle* tris, uint64_t n) {
+  if (!c || (n && !tris)) return MRH_ERR_INVALID_ARG;
+  mrh_triangle* copy = (mrh_triangle*) malloc((n ? n : 1) * sizeof(mrh_triangle));
+  if (n) memcpy(copy, tris, n * sizeof(mrh_triangle));
+  free(c->tris);
+  c->tris = copy; c->ntris = n; c->cap_tris = n ? n : 1;
+  process_triangles(c);
   return MRH_OK;
 }
 

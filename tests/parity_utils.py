@@ -43,11 +43,16 @@ def make_engine(lib, K: synth.Intrinsics, params: dict, num_sdf_blocks: int = 65
     return e
 
 
-def feed(e: capi.Engine, f: synth.Frame, n_frames_invalidate: int = -1):
+def feed(e: capi.Engine, f: synth.Frame, n_frames_invalidate: int = -1, dist=None):
     e.set_pose(f.R, f.t)
     e.upload_depth(f.depth)
     e.upload_rgb(f.rgb)
-    e.integrate(n_frames_invalidate)
+    if dist is not None:
+        from mrhash_amd import parallel
+
+        parallel.integrate(e, dist, n_frames_invalidate)
+    else:
+        assert not e.integrate(n_frames_invalidate), "sharded context needs parallel.integrate"
 
 
 def _max_abs_diff(x: np.ndarray, y: np.ndarray) -> float:

@@ -66,9 +66,9 @@ def test_getters_setters_and_errors(geowrapper_cls):
     g = _make(geowrapper_cls)
     assert g.getNumSdfBlocks() == 32768 and g.getHashNumBuckets() == 32768 and g.getHashBucketSize() == 10
     assert g.getIntegrationWeightMax() == 255 and g.getLinkedListSize() == 7
-    assert abs(g.getVirtualVoxelSize() - 0.02) < 1e-9 and g.getNFramesInvalidateVoxels() == 2
+    assert abs(g.getVirtualVoxelSize() - 0.02) < 1e-6 and g.getNFramesInvalidateVoxels() == 2
     g.setSdfTruncation(0.1)
-    assert abs(g.getSdfTruncation() - 0.1) < 1e-9  # host copy only, like the reference (geowrapper.h:98-109)
+    assert abs(g.getSdfTruncation() - 0.1) < 1e-6  # host copy only, like the reference (geowrapper.h:98-109)
     with pytest.raises(RuntimeError, match="2D numpy array"):
         g.setDepthImage(np.zeros((4, 4, 1), np.float32))
     with pytest.raises(RuntimeError, match="3D numpy array"):
