@@ -29,6 +29,22 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01", "bench_pmc_summary.txt")
+
+
+def pmc_traffic_bytes():
+    """HBM bytes per launch of the integrate kernel from the committed rocprofv3 PMC passes of this same command
+    (separate --pmc runs for FETCH_SIZE and WRITE_SIZE, tools/profile_bench.sh).  Units are KiB; on gfx950
+    FETCH_SIZE counts a wide coalesced read at half its bytes, so it is doubled (MI355X_MICROARCH.md, HBM)."""
+    try:
+        lines = open(PMC_SUMMARY).read().splitlines()
+        for i, l in enumerate(lines):
+            if l.startswith("mrh::k_fused<true"):
+                kv = dict(tok.split("=") for tok in lines[i + 1].split())
+                return (2.0 * float(kv["FETCH_SIZE"]) + float(kv["WRITE_SIZE"])) * 1024.0
+    except Exception:
+        pass
+    return None
 
 
 def main():
@@ -175,8 +191,11 @@ def main():
                        "frames_per_gpu": K, "voxel_size_m": 0.01, "truncation_m": 0.07,
                        "parallelism": "frame-sharded sub-maps, no data-path collective" if world > 1 else "single GPU",
                        "live_blocks_end": occupied},
-            "roofline": {"bound": "hbm", "kernel": "k_integrate", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "roofline": {"bound": "hbm", "kernel": "k_fused (depth->TSDF integrate + GC summary)", "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic_bytes(),
+                         "traffic_note": "bytes per launch from profiles/r01/bench_pmc_summary.txt (rocprofv3 PMC passes of this "
+                                         "command, 2 x FETCH_SIZE + WRITE_SIZE); the ~85 MB working set stays in the 256 MiB "
+                                         "Infinity Cache between frames",
                          "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms_avg": k_ms, "launches": n_k,
                          "updated_voxels_per_launch": U, "compact_blocks_per_launch": M,
                          "profiled_pass_ms_per_step": prof_elapsed / K * 1e3},

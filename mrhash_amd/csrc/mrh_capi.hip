@@ -65,6 +65,9 @@ struct mrh_ctx {
   int fused_nb = 2;       // voxel batches per wave: 2 = block per wave, 1 = half block per wave
   int fused_pipe = 0;     // 1 = software-pipelined variant (k_fused_pipe)
   int fused_wg = 256;     // threads per workgroup of k_fused (64 / 128 / 256)
+  int alloc_tile = 16;    // pixel tile side of k_alloc2 (8 or 16)
+  int gc_inline_enabled = 1;  // MRH_GC_INLINE=0 keeps the separate k_free2 launch
+  bool frame_gc_inline = false;
   int integrate_grid = 1024;
   int low_blocks_to_allocate = 0;
   uint64_t num_blocks = 0, slots = 0, max_triangles = 0;
@@ -196,17 +199,31 @@ int compact_all(mrh_ctx* c, int* out_n) {
   return MRH_OK;
 }
 
-void launch_fused(mrh_ctx* c) {
+// free_inline: the frame's GC runs inside k_compact2 (culled blocks) and k_fused (visible blocks): only when GC is on,
+// the frame does not starve (starve changes weights after the integrate pass) and a whole block is owned by one wave
+bool gc_inline(const mrh_ctx* c, int max_num_frames) {
+  const bool starve = max_num_frames > 0 && c->frames > 0 && c->frames % (uint64_t) max_num_frames == 0;
+  return max_num_frames > 0 && !starve && c->fused_nb == 2 && !c->fused_pipe && c->gc_inline_enabled;
+}
+
+void launch_fused(mrh_ctx* c, bool free_inline) {
   const int g = c->fused_grid;
   hipStream_t s = c->stream;
+  const float thr = c->map.trunc + c->map.trunc_scale * c->cam.max_depth;
+  if (free_inline) {
+    const int wg = c->fused_wg;
+    const size_t lds = (size_t) (wg / 64) * kTileMaxPx * sizeof(uint2);
+    k_fused<true, 2, true><<<g, wg, lds, s>>>(c->cam, c->map, c->tab, c->fast, thr);
+    return;
+  }
   if (c->fused_pipe) {
     if (c->fused_nb == 1) k_fused_pipe<1><<<g, 256, 0, s>>>(c->cam, c->map, c->tab, c->fast);
     else k_fused_pipe<2><<<g, 256, 0, s>>>(c->cam, c->map, c->tab, c->fast);
   } else {
     const int wg = c->fused_wg;
     const size_t lds = (size_t) (wg / 64) * kTileMaxPx * sizeof(uint2);
-    if (c->fused_nb == 1) k_fused<true, 1><<<g, wg, lds, s>>>(c->cam, c->map, c->tab, c->fast);
-    else k_fused<true, 2><<<g, wg, lds, s>>>(c->cam, c->map, c->tab, c->fast);
+    if (c->fused_nb == 1) k_fused<true, 1, false><<<g, wg, lds, s>>>(c->cam, c->map, c->tab, c->fast, thr);
+    else k_fused<true, 2, false><<<g, wg, lds, s>>>(c->cam, c->map, c->tab, c->fast, thr);
   }
 }
 
@@ -310,8 +327,8 @@ int frame_tail(mrh_ctx* c, bool starved, int max_num_frames) {
   const Tab& t = c->tab;
   const float thr = m.trunc + m.trunc_scale * k.max_depth;  // getTruncation(camera.maxDepth(), ...), vds.cu:1720
   if (!t.multi_res) {
-    if (starved) k_fused<false, 2><<<c->fused_grid, 256, 16, s>>>(k, m, t, c->fast);  // weights changed: refresh the summaries
-    if (max_num_frames > 0) {
+    if (starved) k_fused<false, 2, false><<<c->fused_grid, 256, 16, s>>>(k, m, t, c->fast, thr);  // weights changed: refresh the summaries
+    if (max_num_frames > 0 && !c->frame_gc_inline) {
       if (c->profile) k_free2<true><<<256, 256, 0, s>>>(t, c->fast, thr);
       else k_free2<false><<<256, 256, 0, s>>>(t, c->fast, thr);
     }
@@ -444,6 +461,8 @@ int mrh_create(const mrh_params* p, mrh_ctx** out) {
   }
   if (const char* g = getenv("MRH_FUSED_NB")) c->fused_nb = atoi(g) == 1 ? 1 : 2;
   if (const char* g = getenv("MRH_FUSED_PIPE")) c->fused_pipe = atoi(g) ? 1 : 0;
+  if (const char* g = getenv("MRH_GC_INLINE")) c->gc_inline_enabled = atoi(g) ? 1 : 0;
+  if (const char* g = getenv("MRH_ALLOC_TILE")) c->alloc_tile = atoi(g) == 8 ? 8 : 16;
   if (const char* g = getenv("MRH_FUSED_WG")) { const int v = atoi(g); if (v == 64 || v == 128 || v == 256) c->fused_wg = v; }
   int rc = init_buffers(c);
   if (rc != MRH_OK) {
@@ -589,11 +608,20 @@ int mrh_integrate(mrh_ctx* c, int n_frames_invalidate) {
       c->fast_npix = npix;
     }
     const Fast& f = c->fast;
-    const dim3 tiles2((k.cols + kTile - 1) / kTile, (k.rows + kTile - 1) / kTile);
-    if (c->profile) k_alloc2<true><<<tiles2, dim3(kTile, kTile), 0, s>>>(k, m, t, f, c->d_depth, c->d_rgb);
-    else k_alloc2<false><<<tiles2, dim3(kTile, kTile), 0, s>>>(k, m, t, f, c->d_depth, c->d_rgb);
-    if (c->fused_nb == 1) k_compact2<true><<<1024, 512, 0, s>>>(k, m, t, f);
-    else k_compact2<false><<<1024, 512, 0, s>>>(k, m, t, f);
+    if (c->alloc_tile == 8) {
+      const dim3 tiles2((k.cols + 7) / 8, (k.rows + 7) / 8);
+      if (c->profile) k_alloc2<true, 8><<<tiles2, dim3(8, 8), 0, s>>>(k, m, t, f, c->d_depth, c->d_rgb);
+      else k_alloc2<false, 8><<<tiles2, dim3(8, 8), 0, s>>>(k, m, t, f, c->d_depth, c->d_rgb);
+    } else {
+      const dim3 tiles2((k.cols + 15) / 16, (k.rows + 15) / 16);
+      if (c->profile) k_alloc2<true, 16><<<tiles2, dim3(16, 16), 0, s>>>(k, m, t, f, c->d_depth, c->d_rgb);
+      else k_alloc2<false, 16><<<tiles2, dim3(16, 16), 0, s>>>(k, m, t, f, c->d_depth, c->d_rgb);
+    }
+    c->frame_gc_inline = gc_inline(c, max_num_frames);
+    const float gc_thr = m.trunc + m.trunc_scale * k.max_depth;
+    if (c->frame_gc_inline) k_compact2<false, true><<<1024, 512, 0, s>>>(k, m, t, f, gc_thr);
+    else if (c->fused_nb == 1) k_compact2<true, false><<<1024, 512, 0, s>>>(k, m, t, f, gc_thr);
+    else k_compact2<false, false><<<1024, 512, 0, s>>>(k, m, t, f, gc_thr);
     if (c->profile) {
       k_count_updates<<<c->fused_grid, 256, 0, s>>>(k, m, t, f, c->d_cnt_partials);
       EvPair ev;
@@ -601,11 +629,11 @@ int mrh_integrate(mrh_ctx* c, int n_frames_invalidate) {
       else if (c->ev_pending.size() >= 4096) { HIP_TRY(c, hipStreamSynchronize(s)); rc = drain_events(c); if (rc) return rc; ev = c->ev_pool.back(); c->ev_pool.pop_back(); }
       else { HIP_TRY(c, hipEventCreate(&ev.a)); HIP_TRY(c, hipEventCreate(&ev.b)); }
       HIP_TRY(c, hipEventRecord(ev.a, s));
-      launch_fused(c);
+      launch_fused(c, c->frame_gc_inline);
       HIP_TRY(c, hipEventRecord(ev.b, s));
       c->ev_pending.push_back(ev);
     } else {
-      launch_fused(c);
+      launch_fused(c, c->frame_gc_inline);
     }
     return starve_and_tail(c, max_num_frames);
   }
@@ -719,7 +747,7 @@ int mrh_get_stats(mrh_ctx* c, mrh_stats* out) {
   out->occupied_coarse = (uint64_t) h_ctr[CTR_LIVE_COARSE];
   out->free_fine = (int64_t) h_ctr[CTR_HEAP_FINE] + 1;
   out->free_coarse = (int64_t) h_ctr[CTR_HEAP_COARSE] + 1;
-  out->last_compact_blocks = (uint64_t) h_ctr[CTR_COMPACT] + (fastp ? (uint64_t) h_ctr[CTR_CULLED] : 0);
+  out->last_compact_blocks = (uint64_t) h_ctr[CTR_COMPACT] + (fastp ? (uint64_t) h_ctr[CTR_CULLED] + (uint64_t) h_ctr[CTR_FREED_EARLY] : 0);
   out->total_updated_voxels = total_upd;
   out->last_updated_voxels = total_upd - c->prev_total_updated;
   out->last_inserted_blocks = h_prof[PROF_INSERTED] - c->prev_inserted;

@@ -21,6 +21,7 @@
 namespace mrh {
 
 constexpr int CTR_CULLED = 12;  // number of culled compact entries (stored from the back of Tab::compact)
+constexpr int CTR_FREED_EARLY = 13;  // culled blocks freed inside k_compact2 this frame (counted into M)
 constexpr float kFltMax = 3.402823466e+38f;
 constexpr int kTileMaxPx = 576;  // LDS depth+colour tile per wave: 576 px x 8 B = 4.5 KiB (24 x 24 px: blocks beyond ~1.2 m)
 
@@ -57,26 +58,30 @@ __device__ __forceinline__ void alloc_commit2(const Tab& t, const Fast& f, bool 
   t.vals[slot] = H;
   t.desc_fine[H] = make_int4(b.x, b.y, b.z, 1);
   f.summary[H] = make_uint2(0x7F7FFFFFu, 0u);
-  atomicMax(&t.ctr[CTR_HWM_FINE], (int) H + 1);
+  // the high-water mark only moves while the pool is being touched for the first time: skip the same-address
+  // atomic (one per inserted block otherwise) whenever a plain read already shows a large enough value
+  if ((int) H >= __hip_atomic_load(&t.ctr[CTR_HWM_FINE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&t.ctr[CTR_HWM_FINE], (int) H + 1);
 }
 
-template <bool PROFILE>
-__global__ __launch_bounds__(256) void k_alloc2(const Cam c, const Map m, const Tab t, const Fast f,
+template <bool PROFILE, int TILE>
+__global__ __launch_bounds__(TILE * TILE) void k_alloc2(const Cam c, const Map m, const Tab t, const Fast f,
                                                 const float* __restrict__ depth, const uint8_t* __restrict__ rgb) {
-  __shared__ u64 set[kSetCap];
-  __shared__ u64 list[kListCap];
+  constexpr int NT = TILE * TILE;            // threads = pixels per tile
+  constexpr int CAP = NT * 4;                // LDS key-set / list capacity
+  __shared__ u64 set[CAP];
+  __shared__ u64 list[CAP];
   __shared__ u32 s_count, s_inserted;
-  const int tid = threadIdx.y * kTile + threadIdx.x;
-  for (int i = tid; i < kSetCap; i += 256) set[i] = kKeyEmpty;
+  const int tid = threadIdx.y * TILE + threadIdx.x;
+  for (int i = tid; i < CAP; i += NT) set[i] = kKeyEmpty;
   if (tid == 0) {
     s_count = 0;
     s_inserted = 0;
-    if (blockIdx.x == 0 && blockIdx.y == 0) { t.ctr[CTR_COMPACT] = 0; t.ctr[CTR_CULLED] = 0; }
+    if (blockIdx.x == 0 && blockIdx.y == 0) { t.ctr[CTR_COMPACT] = 0; t.ctr[CTR_CULLED] = 0; t.ctr[CTR_FREED_EARLY] = 0; }
   }
   __syncthreads();
 
-  const int row = blockIdx.y * kTile + threadIdx.y;
-  const int col = blockIdx.x * kTile + threadIdx.x;
+  const int row = blockIdx.y * TILE + threadIdx.y;
+  const int col = blockIdx.x * TILE + threadIdx.x;
   u32 my_inserted = 0;
   const bool in_img = row < c.rows && col < c.cols;
   float d = 0.f;
@@ -119,7 +124,7 @@ __global__ __launch_bounds__(256) void k_alloc2(const Cam c, const Map m, const 
       if (!pack_key(cur, key)) {
         atomicOr((u32*) &t.ctr[CTR_ERROR], ERR_RANGE);
       } else if (owns_block(m, cur)) {
-        u32 s = hash_key(key) & (kSetCap - 1);
+        u32 s = hash_key(key) & (CAP - 1);
         bool placed = false;
 #pragma unroll 1
         for (int p = 0; p < kSetProbe; p++) {
@@ -130,7 +135,7 @@ __global__ __launch_bounds__(256) void k_alloc2(const Cam c, const Map m, const 
             break;
           }
           if (old == key) { placed = true; break; }
-          s = (s + 1) & (kSetCap - 1);
+          s = (s + 1) & (CAP - 1);
         }
         if (!placed && block_in_frustum_approx(c, m.vs, cur)) {
           // LDS set saturated (far, sparse rays): insert directly, un-aggregated
@@ -147,7 +152,7 @@ __global__ __launch_bounds__(256) void k_alloc2(const Cam c, const Map m, const 
               t.vals[slot] = H;
               t.desc_fine[H] = make_int4(cur.x, cur.y, cur.z, 1);
               f.summary[H] = make_uint2(0x7F7FFFFFu, 0u);
-              atomicMax(&t.ctr[CTR_HWM_FINE], (int) H + 1);
+              if ((int) H >= __hip_atomic_load(&t.ctr[CTR_HWM_FINE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&t.ctr[CTR_HWM_FINE], (int) H + 1);
               if (PROFILE) my_inserted++;
             }
           }
@@ -172,7 +177,7 @@ __global__ __launch_bounds__(256) void k_alloc2(const Cam c, const Map m, const 
   // the tile's distinct blocks, densely packed: frustum test + global insert, usually a single round
   const int n = (int) s_count;
 #pragma unroll 1
-  for (int base = 0; base < n; base += 256) {
+  for (int base = 0; base < n; base += NT) {
     const int i = base + tid;
     const bool active = i < n;
     const u64 key = active ? list[i] : kKeyEmpty;
@@ -194,6 +199,25 @@ __global__ __launch_bounds__(256) void k_alloc2(const Cam c, const Map m, const 
   }
 }
 
+// frees one fine block from inside a wave: tombstones its key, returns its slot to the free list, clears its
+// descriptor and zeroes its 6 KiB with the whole wave (garbageCollectFree + deleteHashEntryElement,
+// vds.cu:1727-1844).  Called with wave-uniform arguments.
+__device__ __forceinline__ void wave_free_block(const Tab& t, const int4 ent, const int lane) {
+  const u32 H = (u32) ent.w;
+  if (lane == 0) {
+    u64 key;
+    pack_key(mki3(ent.x, ent.y, ent.z), key);
+    hash_erase(t, key);
+    const int idx = atomicAdd(&t.ctr[CTR_HEAP_FINE], 1);
+    t.heap_fine[idx + 1] = H;  // vds.cu:53-57
+    t.desc_fine[H].w = 0;
+  }
+  uint4* p = (uint4*) (t.pool + (size_t) H * kFineBytes);
+  const uint4 z = make_uint4(0, 0, 0, 0);
+#pragma unroll
+  for (int k = 0; k < kFineBytes / 16 / kWave; k++) p[k * kWave + lane] = z;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // K2'  compaction with exact-image cull
 // ---------------------------------------------------------------------------------------------------------
@@ -209,8 +233,10 @@ __global__ __launch_bounds__(256) void k_alloc2(const Cam c, const Map m, const 
 //
 // Eight lanes per block, one corner each (lane & 7 = corner, params.h:41-49 order), combined with three
 // xor-shuffles: 8x the parallelism and 1/8 of the dependent chain of a thread-per-block sweep.
-template <bool RESET_SUMMARY>
-__global__ __launch_bounds__(512) void k_compact2(const Cam c, const Map m, const Tab t, const Fast f) {
+// FREE_CULLED: a culled block is not touched by this frame's integrate pass, so its GC decision (from the stored
+// summary) can be taken — and the block freed — right here; such a block is not even entered into the culled list.
+template <bool RESET_SUMMARY, bool FREE_CULLED>
+__global__ __launch_bounds__(512) void k_compact2(const Cam c, const Map m, const Tab t, const Fast f, const float trunc_threshold) {
   __shared__ int s_cls[64];
   __shared__ int4 s_desc[64];
   __shared__ int4 s_bbox[64];
@@ -265,8 +291,29 @@ __global__ __launch_bounds__(512) void k_compact2(const Cam c, const Map m, cons
     }
     __syncthreads();
     if (threadIdx.x < 64) {  // wave 0: one ballot + at most two atomics for the whole 64-block batch
-      const int cls = s_cls[threadIdx.x];
+      int cls = s_cls[threadIdx.x];
       const int4 e = s_desc[threadIdx.x];
+      if (FREE_CULLED) {
+        bool fr = false;
+        if (cls == 2) {
+          const uint2 sm = f.summary[e.w];
+          fr = (__uint_as_float(sm.x) >= trunc_threshold) || (sm.y == 0u);
+        }
+        u64 todo = __ballot(fr);
+        if (todo) {
+          if (threadIdx.x == 0) {
+            atomicAdd(&t.ctr[CTR_FREED_EARLY], __popcll(todo));  // still part of M (stats)
+            if (t.prof) atomicAdd(&t.prof[PROF_FREED], (u64) __popcll(todo));
+          }
+          while (todo) {
+            const int src = __ffsll((long long) todo) - 1;
+            todo &= todo - 1;
+            const int4 fe = make_int4(__shfl(e.x, src), __shfl(e.y, src), __shfl(e.z, src), __shfl(e.w, src));
+            wave_free_block(t, fe, (int) threadIdx.x);
+          }
+          if (fr) cls = 0;
+        }
+      }
       const u64 bv = __ballot(cls == 1), bc = __ballot(cls == 2);
       int wbv = 0, wbc = 0;
       if (threadIdx.x == 0) {
@@ -441,8 +488,10 @@ __device__ __forceinline__ void tile_lookup(const Fast& f, const int4 bb, const 
 // Dependency chain of a wave: block entry -> { voxel planes (HBM)  ||  projections -> depth+colour gathers (L2) }
 // -> blend -> stores.  All loads are in flight before the first wait; the colour gather is issued together with
 // the depth gather (same pixel index) instead of after the depth test.
-template <bool INTEGRATE, int NB>
-__global__ __launch_bounds__(256) void k_fused(const Cam c, const Map m, const Tab t, const Fast f) {
+// FREE (NB == 2 only): the wave that just computed a block's summary also takes the garbage-collection decision
+// (vds.cu:1708-1711) and frees the block on the spot, so the fast path needs no separate free kernel.
+template <bool INTEGRATE, int NB, bool FREE>
+__global__ __launch_bounds__(256) void k_fused(const Cam c, const Map m, const Tab t, const Fast f, const float trunc_threshold) {
   extern __shared__ __attribute__((aligned(16))) uint2 s_tile[];  // (blockDim.x / 64) x kTileMaxPx
   const int nvis = t.ctr[CTR_COMPACT];
   const int nitems = nvis * (2 / NB);
@@ -527,6 +576,10 @@ __global__ __launch_bounds__(256) void k_fused(const Cam c, const Map m, const T
         atomicMin(&f.summary[H].x, __float_as_uint(mn));
         atomicMax(&f.summary[H].y, mx);
       }
+    }
+    if (FREE && NB == 2 && (mn >= trunc_threshold || mx == 0)) {
+      wave_free_block(t, ent, lane);
+      if (lane == 0 && t.prof) atomicAdd(&t.prof[PROF_FREED], 1ull);
     }
   }
 }
@@ -675,7 +728,7 @@ __global__ __launch_bounds__(256) void k_count_updates(const Cam c, const Map m,
   for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
   if (lane == 0) {
     partials[gw] += (u64) cnt;
-    if (gw == 0) t.prof[PROF_COMPACT] += (u64) (nvis + t.ctr[CTR_CULLED]);
+    if (gw == 0) t.prof[PROF_COMPACT] += (u64) (nvis + t.ctr[CTR_CULLED] + t.ctr[CTR_FREED_EARLY]);
   }
 }
 
