@@ -40,7 +40,7 @@ def hipcc() -> str:
 
 
 def build_hip(force: bool = False, verbose: bool = True) -> str:
-    srcs = [os.path.join(CSRC, f) for f in ("mrh_capi.hip", "mrh_kernels.h", "mrh_device.h", "mrh_mc.h", "mrh_fast.h")]
+    srcs = [os.path.join(CSRC, f) for f in ("mrh_capi.hip", "mrh_kernels.h", "mrh_device.h", "mrh_mc.h", "mrh_fast.h", "mrh_pipe.h", "mrh_fast2.h")]
     srcs += [os.path.join(ROOT, "include", f) for f in ("mrhash_hip.h", "mrh_mc_tables.h")]
     if not force and _newer(HIP_LIB, srcs):
         return HIP_LIB

@@ -20,6 +20,8 @@
 #include "mrh_kernels.h"
 #include "mrh_mc.h"
 #include "mrh_fast.h"
+#include "mrh_pipe.h"
+#include "mrh_fast2.h"
 
 using namespace mrh;
 
@@ -58,10 +60,26 @@ struct mrh_ctx {
   int* d_flag = nullptr;
   u64* d_upd_partials = nullptr;
   u32* d_misc = nullptr;  // 4 words for k_get_voxel
-  Fast fast;              // single-resolution fast path buffers
+  Fast fast;              // single-resolution fast path buffers (depth_clean / rgbx point at the current frame's pair)
   size_t fast_npix = 0;
+  // allocation overlap (mrh_pipe.h): rays of frame f+1 are marched on stream_in while frame f integrates on stream
+  hipStream_t stream_in = nullptr;
+  static constexpr int kBufs = 3;  // input-side buffer sets: the ray kernel may run up to two frames ahead of the map
+  hipEvent_t ev_rays[kBufs] = {}, ev_done[kBufs] = {};
+  float* dc_buf[kBufs] = {};
+  u32* rgbx_buf[kBufs] = {};
+  u64* tile_keys[kBufs] = {};
+  u32* tile_count[kBufs] = {};
+  int overlap = 0;        // MRH_OVERLAP=1: rays of frame f+1 on a second stream (mrh_pipe.h; host-bound, off by default)
+  int merged = 1;         // MRH_MERGED=0: three-launch path (k_alloc2 / k_compact2 / k_fused) instead of k_front / k_back
+  int4* d_cfree = nullptr;
+  uint64_t fast_frames = 0;  // fast-path frames issued: parity selects the list-counter set
+  int frame_parity = 0;
+  uint64_t frames_enqueued = 0;  // fast-path frames whose rays were issued (parity selects the buffer pair)
   u64* d_cnt_partials = nullptr;
   int fused_grid = 2048;  // x 4 waves
+  int stagger = 0;        // MRH_STAGGER: start delay (x ~3.4 us) of odd workgroups of k_back
+  int sweep_wgs = 128;    // descriptor-sweep workgroups appended to the allocation launch (k_front)
   int fused_nb = 2;       // voxel batches per wave: 2 = block per wave, 1 = half block per wave
   int fused_pipe = 0;     // 1 = software-pipelined variant (k_fused_pipe)
   int fused_wg = 256;     // threads per workgroup of k_fused (64 / 128 / 256)
@@ -119,12 +137,19 @@ uint64_t next_pow2(uint64_t v) {
 void free_all(mrh_ctx* c) {
   if (!c) return;
   (void) hipSetDevice(c->device);
+  if (c->stream_in) (void) hipStreamSynchronize(c->stream_in);
   if (c->stream) (void) hipStreamSynchronize(c->stream);
   auto F = [](void* p) { if (p) (void) hipFree(p); };
+  for (int i = 0; i < mrh_ctx::kBufs; i++) {
+    F(c->dc_buf[i]); F(c->rgbx_buf[i]); F(c->tile_keys[i]); F(c->tile_count[i]);
+    if (c->ev_rays[i]) (void) hipEventDestroy(c->ev_rays[i]);
+    if (c->ev_done[i]) (void) hipEventDestroy(c->ev_done[i]);
+  }
+  if (c->stream_in) (void) hipStreamDestroy(c->stream_in);
   F(c->tab.keys); F(c->tab.vals); F(c->tab.heap_fine); F(c->tab.heap_coarse); F(c->tab.desc_fine); F(c->tab.desc_coarse);
   F(c->tab.pool); F(c->tab.compact); F(c->tab.ctr); F(c->tab.prof);
   F(c->d_depth_own); F(c->d_rgb_own); F(c->d_decision); F(c->d_zbuf); F(c->d_realloc); F(c->d_reint); F(c->d_flag);
-  F(c->d_upd_partials); F(c->d_misc); F(c->fast.depth_clean); F(c->fast.rgbx); F(c->fast.summary); F(c->fast.bbox); F(c->d_cnt_partials);
+  F(c->d_upd_partials); F(c->d_misc); F(c->d_cfree); F(c->fast.summary); F(c->fast.bbox); F(c->d_cnt_partials);
   for (auto& e : c->ev_pool) { (void) hipEventDestroy(e.a); (void) hipEventDestroy(e.b); }
   for (auto& e : c->ev_pending) { (void) hipEventDestroy(e.a); (void) hipEventDestroy(e.b); }
   if (c->stream) (void) hipStreamDestroy(c->stream);
@@ -133,6 +158,9 @@ void free_all(mrh_ctx* c) {
 // (re)initialises every device structure to the empty map (voxel_data_structures.cpp:58-87 + ctor counters)
 int init_buffers(mrh_ctx* c) {
   hipStream_t s = c->stream;
+  if (c->stream_in) HIP_TRY(c, hipStreamSynchronize(c->stream_in));
+  c->frames_enqueued = 0;
+  c->fast_frames = 0;
   const Tab& t = c->tab;
   k_init_table<<<1024, 256, 0, s>>>(t.keys, c->slots);
   k_init_heap<<<1024, 256, 0, s>>>(t.heap_fine, (u32) c->num_blocks);
@@ -288,6 +316,9 @@ void process_triangles(mrh_ctx* c) {
 }
 
 
+// stream the frame inputs are consumed on: the ray kernel's stream in the overlapped fast path, else the map stream
+hipStream_t in_stream(mrh_ctx* c) { return (!c->tab.multi_res && c->overlap) ? c->stream_in : c->stream; }
+
 int ensure_zbuf(mrh_ctx* c, size_t npix) {
   if (c->zbuf_n < npix) {
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -329,7 +360,10 @@ int frame_tail(mrh_ctx* c, bool starved, int max_num_frames) {
   if (!t.multi_res) {
     if (starved) k_fused<false, 2, false><<<c->fused_grid, 256, 16, s>>>(k, m, t, c->fast, thr);  // weights changed: refresh the summaries
     if (max_num_frames > 0 && !c->frame_gc_inline) {
-      if (c->profile) k_free2<true><<<256, 256, 0, s>>>(t, c->fast, thr);
+      if (c->merged) {
+        const Lists L = {t.compact, c->fast.bbox, c->d_cfree, (u32) c->num_blocks};
+        k_free_lists<<<256, 256, 0, s>>>(t, c->fast, L, c->frame_parity, thr);
+      } else if (c->profile) k_free2<true><<<256, 256, 0, s>>>(t, c->fast, thr);
       else k_free2<false><<<256, 256, 0, s>>>(t, c->fast, thr);
     }
   } else if (max_num_frames > 0) {
@@ -337,6 +371,8 @@ int frame_tail(mrh_ctx* c, bool starved, int max_num_frames) {
     if (c->profile) k_gc_free<true><<<256, 256, 0, s>>>(t, c->d_decision);
     else k_gc_free<false><<<256, 256, 0, s>>>(t, c->d_decision);
   }
+  if (!t.multi_res && c->overlap && c->frames_enqueued > 0)
+    HIP_TRY(c, hipEventRecord(c->ev_done[(c->frames_enqueued - 1) % mrh_ctx::kBufs], s));  // this frame's image/key buffers are free again
   c->frames++;
   HIP_TRY(c, hipGetLastError());
   return MRH_OK;
@@ -400,6 +436,11 @@ int mrh_create(const mrh_params* p, mrh_ctx** out) {
   } while (0)
   CREATE_TRY(hipSetDevice(c->device));
   CREATE_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  CREATE_TRY(hipStreamCreateWithFlags(&c->stream_in, hipStreamNonBlocking));
+  for (int i = 0; i < mrh_ctx::kBufs; i++) {
+    CREATE_TRY(hipEventCreateWithFlags(&c->ev_rays[i], hipEventDisableTiming));
+    CREATE_TRY(hipEventCreateWithFlags(&c->ev_done[i], hipEventDisableTiming));
+  }
 
   // capacities: geowrapper.cpp:37-54 when not given explicitly
   size_t free_b = 0, total_b = 0;
@@ -440,6 +481,7 @@ int mrh_create(const mrh_params* p, mrh_ctx** out) {
   CREATE_TRY(hipMalloc((void**) &c->fast.summary, c->num_blocks * sizeof(uint2)));
   c->fast.compact_cap = (u32) c->num_blocks;
   CREATE_TRY(hipMalloc((void**) &c->fast.bbox, c->num_blocks * sizeof(int4)));
+  CREATE_TRY(hipMalloc((void**) &c->d_cfree, c->num_blocks * sizeof(int4)));
 #undef CREATE_TRY
 
   Map& m = c->map;
@@ -459,8 +501,13 @@ int mrh_create(const mrh_params* p, mrh_ctx** out) {
     const int v = atoi(g);
     if (v > 0 && v <= 32768) c->fused_grid = v;
   }
+  if (const char* g = getenv("MRH_STAGGER")) { const int v = atoi(g); if (v >= 0 && v <= 16) c->stagger = v; }
+  if (const char* g = getenv("MRH_SWEEP_WGS")) { const int v = atoi(g); if (v > 0 && v <= 4096) c->sweep_wgs = v; }
   if (const char* g = getenv("MRH_FUSED_NB")) c->fused_nb = atoi(g) == 1 ? 1 : 2;
   if (const char* g = getenv("MRH_FUSED_PIPE")) c->fused_pipe = atoi(g) ? 1 : 0;
+  if (const char* g = getenv("MRH_OVERLAP")) c->overlap = atoi(g) ? 1 : 0;
+  if (const char* g = getenv("MRH_MERGED")) c->merged = atoi(g) ? 1 : 0;
+  if (c->overlap) c->merged = 0;
   if (const char* g = getenv("MRH_GC_INLINE")) c->gc_inline_enabled = atoi(g) ? 1 : 0;
   if (const char* g = getenv("MRH_ALLOC_TILE")) c->alloc_tile = atoi(g) == 8 ? 8 : 16;
   if (const char* g = getenv("MRH_FUSED_WG")) { const int v = atoi(g); if (v == 64 || v == 128 || v == 256) c->fused_wg = v; }
@@ -537,13 +584,14 @@ int mrh_upload_depth(mrh_ctx* c, const float* depth, int rows, int cols) {
   if (!depth || rows <= 0 || cols <= 0) return fail(c, MRH_ERR_INVALID_ARG, "mrh_upload_depth: bad argument");
   const size_t bytes = (size_t) rows * cols * sizeof(float);
   if (bytes > c->depth_cap) {
+    HIP_TRY(c, hipStreamSynchronize(c->stream_in));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (c->d_depth_own) HIP_TRY(c, hipFree(c->d_depth_own));
     c->d_depth_own = nullptr;
     HIP_TRY(c, hipMalloc((void**) &c->d_depth_own, bytes));
     c->depth_cap = bytes;
   }
-  HIP_TRY(c, hipMemcpyAsync(c->d_depth_own, depth, bytes, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->d_depth_own, depth, bytes, hipMemcpyHostToDevice, in_stream(c)));
   c->d_depth = c->d_depth_own;
   c->depth_rows = rows; c->depth_cols = cols;
   return MRH_OK;
@@ -555,13 +603,14 @@ int mrh_upload_rgb(mrh_ctx* c, const uint8_t* rgb, int rows, int cols) {
   if (!rgb || rows <= 0 || cols <= 0) return fail(c, MRH_ERR_INVALID_ARG, "mrh_upload_rgb: bad argument");
   const size_t bytes = (size_t) rows * cols * 3;
   if (bytes > c->rgb_cap) {
+    HIP_TRY(c, hipStreamSynchronize(c->stream_in));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (c->d_rgb_own) HIP_TRY(c, hipFree(c->d_rgb_own));
     c->d_rgb_own = nullptr;
     HIP_TRY(c, hipMalloc((void**) &c->d_rgb_own, bytes));
     c->rgb_cap = bytes;
   }
-  HIP_TRY(c, hipMemcpyAsync(c->d_rgb_own, rgb, bytes, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->d_rgb_own, rgb, bytes, hipMemcpyHostToDevice, in_stream(c)));
   c->d_rgb = c->d_rgb_own;
   c->rgb_rows = rows; c->rgb_cols = cols;
   return MRH_OK;
@@ -598,17 +647,71 @@ int mrh_integrate(mrh_ctx* c, int n_frames_invalidate) {
   if (!t.multi_res) {
     // ---- single-resolution fast path: alloc -> compact+cull -> fused integrate/summary -> free (mrh_fast.h)
     const size_t npix = (size_t) k.rows * k.cols;
+    const int tiles_x = (k.cols + kRayTile - 1) / kRayTile, tiles_y = (k.rows + kRayTile - 1) / kRayTile;
     if (c->fast_npix < npix) {
+      HIP_TRY(c, hipStreamSynchronize(c->stream_in));
       HIP_TRY(c, hipStreamSynchronize(s));
-      if (c->fast.depth_clean) HIP_TRY(c, hipFree(c->fast.depth_clean));
-      if (c->fast.rgbx) HIP_TRY(c, hipFree(c->fast.rgbx));
-      c->fast.depth_clean = nullptr; c->fast.rgbx = nullptr;
-      HIP_TRY(c, hipMalloc((void**) &c->fast.depth_clean, npix * sizeof(float)));
-      HIP_TRY(c, hipMalloc((void**) &c->fast.rgbx, npix * sizeof(u32)));
+      for (int i = 0; i < mrh_ctx::kBufs; i++) {
+        if (c->dc_buf[i]) HIP_TRY(c, hipFree(c->dc_buf[i]));
+        if (c->rgbx_buf[i]) HIP_TRY(c, hipFree(c->rgbx_buf[i]));
+        if (c->tile_keys[i]) HIP_TRY(c, hipFree(c->tile_keys[i]));
+        if (c->tile_count[i]) HIP_TRY(c, hipFree(c->tile_count[i]));
+        c->dc_buf[i] = nullptr; c->rgbx_buf[i] = nullptr; c->tile_keys[i] = nullptr; c->tile_count[i] = nullptr;
+        HIP_TRY(c, hipMalloc((void**) &c->dc_buf[i], npix * sizeof(float)));
+        HIP_TRY(c, hipMalloc((void**) &c->rgbx_buf[i], npix * sizeof(u32)));
+        HIP_TRY(c, hipMalloc((void**) &c->tile_keys[i], (size_t) tiles_x * tiles_y * kRayCap * sizeof(u64)));
+        HIP_TRY(c, hipMalloc((void**) &c->tile_count[i], (size_t) tiles_x * tiles_y * sizeof(u32)));
+      }
       c->fast_npix = npix;
     }
+    // buffer pair of this frame: the previous frame's pair may still be read by its integrate kernel
+    const int buf = (int) (c->frames_enqueued % mrh_ctx::kBufs);
+    c->fast.depth_clean = c->dc_buf[buf];
+    c->fast.rgbx = c->rgbx_buf[buf];
     const Fast& f = c->fast;
-    if (c->alloc_tile == 8) {
+    if (c->merged) {
+      // ---- two launches per frame (mrh_fast2.h)
+      const int parity = (int) (c->fast_frames & 1);
+      c->frame_parity = parity;
+      c->fast_frames++;
+      c->frames_enqueued++;
+      const u32 stamp = (u32) ((c->frames + 1) & 0x3FFFFFFFu);
+      const float gc_thr = m.trunc + m.trunc_scale * k.max_depth;  // getTruncation(camera.maxDepth(), ...), vds.cu:1720
+      const Lists L = {t.compact, c->fast.bbox, c->d_cfree, (u32) c->num_blocks};
+      const int n_tiles = tiles_x * tiles_y;
+      const bool starve = max_num_frames > 0 && c->frames > 0 && c->frames % (uint64_t) max_num_frames == 0;
+      c->frame_gc_inline = max_num_frames > 0 && !starve;
+      if (c->profile) k_front<true><<<n_tiles + c->sweep_wgs, 256, 0, s>>>(k, m, t, f, L, c->d_depth, c->d_rgb, tiles_x, n_tiles, stamp, parity, max_num_frames > 0 ? 1 : 0, gc_thr);
+      else k_front<false><<<n_tiles + c->sweep_wgs, 256, 0, s>>>(k, m, t, f, L, c->d_depth, c->d_rgb, tiles_x, n_tiles, stamp, parity, max_num_frames > 0 ? 1 : 0, gc_thr);
+      const int wg = c->fused_wg;
+      const size_t lds = (size_t) (wg / 64) * kTileMaxPx * sizeof(uint2);
+      EvPair ev;
+      if (c->profile) {
+        k_count_updates<<<c->fused_grid, 256, 0, s>>>(k, m, t, f, c->d_cnt_partials, CTR_SET0 + 4 * parity);
+        if (!c->ev_pool.empty()) { ev = c->ev_pool.back(); c->ev_pool.pop_back(); }
+        else if (c->ev_pending.size() >= 4096) { HIP_TRY(c, hipStreamSynchronize(s)); rc = drain_events(c); if (rc) return rc; ev = c->ev_pool.back(); c->ev_pool.pop_back(); }
+        else { HIP_TRY(c, hipEventCreate(&ev.a)); HIP_TRY(c, hipEventCreate(&ev.b)); }
+        HIP_TRY(c, hipEventRecord(ev.a, s));
+      }
+      if (c->frame_gc_inline && c->profile) k_back<true, true><<<c->fused_grid, wg, lds, s>>>(k, m, t, f, L, parity, gc_thr, c->stagger);
+      else if (c->frame_gc_inline) k_back<true, false><<<c->fused_grid, wg, lds, s>>>(k, m, t, f, L, parity, gc_thr, c->stagger);
+      else k_back<false, false><<<c->fused_grid, wg, lds, s>>>(k, m, t, f, L, parity, gc_thr, c->stagger);
+      if (c->profile) {
+        HIP_TRY(c, hipEventRecord(ev.b, s));
+        c->ev_pending.push_back(ev);
+      }
+      return starve_and_tail(c, max_num_frames);
+    }
+    if (c->overlap) {
+      hipStream_t sin = c->stream_in;
+      if (c->frames_enqueued >= (uint64_t) mrh_ctx::kBufs) HIP_TRY(c, hipStreamWaitEvent(sin, c->ev_done[buf], 0));  // frame f-3 released this set
+      k_rays<<<dim3(tiles_x, tiles_y), dim3(kRayTile, kRayTile), 0, sin>>>(k, m, t, c->d_depth, c->d_rgb, c->dc_buf[buf], c->rgbx_buf[buf],
+                                                                          c->tile_keys[buf], c->tile_count[buf]);
+      HIP_TRY(c, hipEventRecord(c->ev_rays[buf], sin));
+      HIP_TRY(c, hipStreamWaitEvent(s, c->ev_rays[buf], 0));
+      if (c->profile) k_insert<true><<<tiles_x * tiles_y, 64, 0, s>>>(k, m, t, f, c->tile_keys[buf], c->tile_count[buf], tiles_x);
+      else k_insert<false><<<tiles_x * tiles_y, 64, 0, s>>>(k, m, t, f, c->tile_keys[buf], c->tile_count[buf], tiles_x);
+    } else if (c->alloc_tile == 8) {
       const dim3 tiles2((k.cols + 7) / 8, (k.rows + 7) / 8);
       if (c->profile) k_alloc2<true, 8><<<tiles2, dim3(8, 8), 0, s>>>(k, m, t, f, c->d_depth, c->d_rgb);
       else k_alloc2<false, 8><<<tiles2, dim3(8, 8), 0, s>>>(k, m, t, f, c->d_depth, c->d_rgb);
@@ -617,13 +720,14 @@ int mrh_integrate(mrh_ctx* c, int n_frames_invalidate) {
       if (c->profile) k_alloc2<true, 16><<<tiles2, dim3(16, 16), 0, s>>>(k, m, t, f, c->d_depth, c->d_rgb);
       else k_alloc2<false, 16><<<tiles2, dim3(16, 16), 0, s>>>(k, m, t, f, c->d_depth, c->d_rgb);
     }
+    c->frames_enqueued++;
     c->frame_gc_inline = gc_inline(c, max_num_frames);
     const float gc_thr = m.trunc + m.trunc_scale * k.max_depth;
     if (c->frame_gc_inline) k_compact2<false, true><<<1024, 512, 0, s>>>(k, m, t, f, gc_thr);
     else if (c->fused_nb == 1) k_compact2<true, false><<<1024, 512, 0, s>>>(k, m, t, f, gc_thr);
     else k_compact2<false, false><<<1024, 512, 0, s>>>(k, m, t, f, gc_thr);
     if (c->profile) {
-      k_count_updates<<<c->fused_grid, 256, 0, s>>>(k, m, t, f, c->d_cnt_partials);
+      k_count_updates<<<c->fused_grid, 256, 0, s>>>(k, m, t, f, c->d_cnt_partials, -1);
       EvPair ev;
       if (!c->ev_pool.empty()) { ev = c->ev_pool.back(); c->ev_pool.pop_back(); }
       else if (c->ev_pending.size() >= 4096) { HIP_TRY(c, hipStreamSynchronize(s)); rc = drain_events(c); if (rc) return rc; ev = c->ev_pool.back(); c->ev_pool.pop_back(); }

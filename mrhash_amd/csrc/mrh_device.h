@@ -46,7 +46,7 @@ enum Ctr : int {
   CTR_TOMBS = 9,
   CTR_NTRI = 10,
   CTR_DUMP = 11,
-  CTR_COUNT = 16
+  CTR_COUNT = 32  // slots 16..23: the two list-counter sets of the two-launch fast path (mrh_fast2.h)
 };
 // 64-bit profile counters
 enum Prof : int { PROF_UPDATED = 0, PROF_INSERTED = 1, PROF_FREED = 2, PROF_COMPACT = 3, PROF_COUNT = 4 };
@@ -186,6 +186,39 @@ __device__ __forceinline__ i3 voxel_to_block(i3 v, float vs) {
   return b;
 }
 __device__ __forceinline__ i3 world_to_block(float vs, f3 pt) { return voxel_to_block(world_to_voxel(vs, pt), vs); }
+
+// The same two conversions with the divisions by the (kernel-uniform) voxel size / block size done through one
+// shared refined reciprocal each (div_rr is bit-identical to the IEEE divide for these operands; a -0 quotient may
+// come out as +0, which both sign(.) and the >= 0 tests below treat identically).
+struct GridRcp {
+  float vs, r_vs, mbs, r_mbs;
+};
+__device__ __forceinline__ GridRcp make_grid_rcp(float vs) {
+  GridRcp g;
+  g.vs = vs;
+  g.r_vs = rcp_refined(vs);
+  g.mbs = (1.0f * (float) kBlockSide) * vs;
+  g.r_mbs = rcp_refined(g.mbs);
+  return g;
+}
+__device__ __forceinline__ i3 world_to_block_r(const GridRcp& g, f3 pt) {
+  const float epsilon = 1e-5;
+  const f3 p = mk3(div_rr(pt.x, g.vs, g.r_vs), div_rr(pt.y, g.vs, g.r_vs), div_rr(pt.z, g.vs, g.r_vs));
+  f3 a = mk3(p.x + (float) signi(p.x) * 0.5f, p.y + (float) signi(p.y) * 0.5f, p.z + (float) signi(p.z) * 0.5f);
+  a.x = (a.x >= 0) ? floorf(a.x + epsilon) : ceilf(a.x - epsilon);
+  a.y = (a.y >= 0) ? floorf(a.y + epsilon) : ceilf(a.y - epsilon);
+  a.z = (a.z >= 0) ? floorf(a.z + epsilon) : ceilf(a.z - epsilon);
+  i3 v = mki3(f2i_hw(a.x), f2i_hw(a.y), f2i_hw(a.z));
+  if (v.x < 0) v.x -= (kBlockSide - 1);
+  if (v.y < 0) v.y -= (kBlockSide - 1);
+  if (v.z < 0) v.z -= (kBlockSide - 1);
+  const f3 pw = voxel_to_world(g.vs, v);
+  i3 b;
+  b.x = f2i_hw((pw.x >= 0) ? floorf(div_rr(pw.x + epsilon, g.mbs, g.r_mbs)) : ceilf(div_rr(pw.x - epsilon, g.mbs, g.r_mbs)));
+  b.y = f2i_hw((pw.y >= 0) ? floorf(div_rr(pw.y + epsilon, g.mbs, g.r_mbs)) : ceilf(div_rr(pw.y - epsilon, g.mbs, g.r_mbs)));
+  b.z = f2i_hw((pw.z >= 0) ? floorf(div_rr(pw.z + epsilon, g.mbs, g.r_mbs)) : ceilf(div_rr(pw.z - epsilon, g.mbs, g.r_mbs)));
+  return b;
+}
 
 // vhu.cuh:184-187
 __device__ __forceinline__ float get_truncation(float z, float trunc, float scale) { return trunc + scale * z; }

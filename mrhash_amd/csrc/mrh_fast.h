@@ -103,14 +103,19 @@ __global__ __launch_bounds__(TILE * TILE) void k_alloc2(const Cam c, const Map m
     const f3 dd = mk3(pw_max.x - pw_min.x, pw_max.y - pw_min.y, pw_max.z - pw_min.z);
     const float inv_len = 1.0f / sqrtf(dd.x * dd.x + dd.y * dd.y + dd.z * dd.z);
     const f3 dir = mk3(dd.x * inv_len, dd.y * inv_len, dd.z * inv_len);
-    i3 cur = world_to_block(m.vs, pw_min);
-    const i3 end = world_to_block(m.vs, pw_max);
+    const GridRcp grid = make_grid_rcp(m.vs);
+    i3 cur = world_to_block_r(grid, pw_min);
+    const i3 end = world_to_block_r(grid, pw_max);
     const f3 step = mk3((float) signi(dir.x), (float) signi(dir.y), (float) signi(dir.z));
     const i3 nb = mki3(cur.x + f2i(clampf(step.x, 0.0f, 1.f)), cur.y + f2i(clampf(step.y, 0.0f, 1.f)), cur.z + f2i(clampf(step.z, 0.0f, 1.f)));
     const f3 bw = voxel_to_world(m.vs, mki3(nb.x * kBlockSide, nb.y * kBlockSide, nb.z * kBlockSide));
     const f3 boundary = mk3(bw.x - 0.5f * m.vs, bw.y - 0.5f * m.vs, bw.z - 0.5f * m.vs);
-    f3 t_max = mk3((boundary.x - pw_min.x) / dir.x, (boundary.y - pw_min.y) / dir.y, (boundary.z - pw_min.z) / dir.z);
-    f3 t_delta = mk3((step.x * (float) kBlockSide * m.vs) / dir.x, (step.y * (float) kBlockSide * m.vs) / dir.y, (step.z * (float) kBlockSide * m.vs) / dir.z);
+    // t_max and t_delta of an axis divide by the same direction component: one refined reciprocal per axis.  (For
+    // |dir| < 1e-6 an IEEE divide would give inf / nan where this gives nan; both are overwritten just below.)
+    const f3 rd = mk3(rcp_refined(dir.x), rcp_refined(dir.y), rcp_refined(dir.z));
+    f3 t_max = mk3(div_rr(boundary.x - pw_min.x, dir.x, rd.x), div_rr(boundary.y - pw_min.y, dir.y, rd.y), div_rr(boundary.z - pw_min.z, dir.z, rd.z));
+    f3 t_delta = mk3(div_rr(step.x * (float) kBlockSide * m.vs, dir.x, rd.x), div_rr(step.y * (float) kBlockSide * m.vs, dir.y, rd.y),
+                     div_rr(step.z * (float) kBlockSide * m.vs, dir.z, rd.z));
     const i3 bound = mki3(f2i((float) end.x + step.x), f2i((float) end.y + step.y), f2i((float) end.z + step.z));
     if (fabsf(dir.x) < kFloatEps) { t_max.x = kFltMax; t_delta.x = kFltMax; }
     if (fabsf(boundary.x - dir.x) < kFloatEps) { t_max.x = kFltMax; t_delta.x = kFltMax; }
@@ -124,7 +129,9 @@ __global__ __launch_bounds__(TILE * TILE) void k_alloc2(const Cam c, const Map m
       if (!pack_key(cur, key)) {
         atomicOr((u32*) &t.ctr[CTR_ERROR], ERR_RANGE);
       } else if (owns_block(m, cur)) {
-        u32 s = hash_key(key) & (CAP - 1);
+        // tile-local set: a cheap 24-bit multiply-add mix is enough (the 64-bit murmur mix costs ~10 quarter-rate ops)
+        u32 s = (u32) __mul24(cur.z, 5851) + (u32) __mul24(cur.y, 73) + (u32) cur.x;
+        s = (s ^ (s >> 7)) & (CAP - 1);
         bool placed = false;
 #pragma unroll 1
         for (int p = 0; p < kSetProbe; p++) {
@@ -247,7 +254,7 @@ __global__ __launch_bounds__(512) void k_compact2(const Cam c, const Map m, cons
     const int i = base + slot;
     int4 d = make_int4(0, 0, 0, 0);
     if (i < hwm) d = t.desc_fine[i];
-    const bool live = i < hwm && d.w == 1;
+    const bool live = i < hwm && (d.w & 1);
     const i3 v = mki3(d.x * kBlockSide + ((corner & 4) ? 7 : 0), d.y * kBlockSide + ((corner & 2) ? 7 : 0), d.z * kBlockSide + ((corner & 1) ? 7 : 0));
     const f3 pc = se3_apply(c.Ri, c.ti, voxel_to_world(m.vs, v));
     int r, cc;
@@ -708,8 +715,10 @@ __global__ __launch_bounds__(256) void k_fused_pipe(const Cam c, const Map m, co
 
 // profile mode only: U = voxels the next k_fused launch will write (the predicate depends on pose, depth image and
 // block list only, not on voxel contents), M = compact blocks.  Runs outside the timed bracket.
-__global__ __launch_bounds__(256) void k_count_updates(const Cam c, const Map m, const Tab t, const Fast f, u64* __restrict__ partials) {
-  const int nvis = t.ctr[CTR_COMPACT];
+__global__ __launch_bounds__(256) void k_count_updates(const Cam c, const Map m, const Tab t, const Fast f, u64* __restrict__ partials,
+                                                       const int merged_set) {
+  // merged_set >= 0: list counters of the two-launch path live at ctr[merged_set .. merged_set + 2]
+  const int nvis = merged_set >= 0 ? t.ctr[merged_set] : t.ctr[CTR_COMPACT];
   const int lane = threadIdx.x & 63;
   const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int nw = gridDim.x * 4;
@@ -728,7 +737,9 @@ __global__ __launch_bounds__(256) void k_count_updates(const Cam c, const Map m,
   for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
   if (lane == 0) {
     partials[gw] += (u64) cnt;
-    if (gw == 0) t.prof[PROF_COMPACT] += (u64) (nvis + t.ctr[CTR_CULLED] + t.ctr[CTR_FREED_EARLY]);
+    if (gw == 0)
+      t.prof[PROF_COMPACT] += merged_set >= 0 ? (u64) (nvis + t.ctr[merged_set + 1] + t.ctr[merged_set + 2])
+                                              : (u64) (nvis + t.ctr[CTR_CULLED] + t.ctr[CTR_FREED_EARLY]);
   }
 }
 

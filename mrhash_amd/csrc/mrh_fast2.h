@@ -1,0 +1,457 @@
+// mrh_fast2.h — the single-resolution fast path as TWO launches per frame.
+//
+//   k_front   workgroups [0, n_tiles):      block allocation for one 16x16 pixel tile (rays -> LDS key set -> lock-free
+//                                           insert); a newly inserted block is classified and listed by its inserter
+//             workgroups [n_tiles, grid):   sweep of the block descriptors that existed before this frame:
+//                                           approx-frustum predicate + exact-image cull -> VISIBLE list (+ pixel
+//                                           footprint) or, for culled blocks whose stored summary says "collect",
+//                                           the CULLED-FREE list
+//             The two halves never touch the same block (descriptors carry the frame stamp of their insertion), the
+//             allocation half only POPS the free list and nothing is freed in this launch, so both halves run
+//             concurrently: the latency-bound sweep hides completely under the ray marching.
+//   k_back    one wave per visible block:   depth->TSDF integration + GC summary + GC decision + free (k_fused);
+//             then the same waves free the CULLED-FREE list.  This launch only PUSHES the free list.
+//
+// List counters are double-buffered by frame parity: k_front(f) appends to set f&1, k_back(f) reads it and zeroes
+// set (f+1)&1 for the next frame, so no reset launch or memset is needed.
+// Reference mapping: allocBlocksKernel vds.cu:758-857, flatAndReduceHashTableKernel :406-434, integrateDepthMapKernel
+// :1095-1181, garbageCollectIdentify/Free :1674-1713 / :1827-1844 — four+ launches with host round trips there.
+#pragma once
+
+#include "mrh_pipe.h"
+
+namespace mrh {
+
+// counter slots (ints) inside Tab::ctr for the two list sets
+constexpr int CTR_SET0 = 16;       // set p lives at CTR_SET0 + 4 * p: {n_visible, n_culled_kept, n_culled_free, unused}
+constexpr int kCtrTotal = 32;
+
+struct Lists {
+  int4* vis;        // = Tab::compact (front)
+  int4* bbox;       // pixel footprint per visible entry
+  int4* cfree;      // culled blocks to free this frame {x, y, z, H}
+  u32 cap;
+};
+
+__device__ __forceinline__ int desc_w(u32 stamp) { return (int) (1u | (stamp << 1)); }
+
+// serial 8-corner classification (used by the inserter of a new block; the sweep does it with 8 lanes per block).
+// Returns 0 = outside the approx frustum, 1 = visible candidate (bb filled), 2 = culled.  See k_compact2 for the argument.
+__device__ __forceinline__ int classify_block_serial(const Cam& c, const float vs, const i3 b, int4& bb) {
+  bool any_approx = false;
+  float zmin = kFltMax, zmax = -kFltMax, umin = kFltMax, umax = -kFltMax, vmin = kFltMax, vmax = -kFltMax;
+#pragma unroll 1
+  for (int i = 0; i < 8; i++) {
+    const i3 v = mki3(b.x * kBlockSide + ((i & 4) ? 7 : 0), b.y * kBlockSide + ((i & 2) ? 7 : 0), b.z * kBlockSide + ((i & 1) ? 7 : 0));
+    const f3 pc = se3_apply(c.Ri, c.ti, voxel_to_world(vs, v));
+    int r, cc;
+    any_approx |= project_point<true>(c, pc, r, cc);
+    zmin = fminf(zmin, pc.z);
+    zmax = fmaxf(zmax, pc.z);
+    if (pc.z >= 0.05f) {
+      const float u = c.fx * pc.x / pc.z + c.cx;
+      const float w = c.fy * pc.y / pc.z + c.cy;
+      umin = fminf(umin, u); umax = fmaxf(umax, u);
+      vmin = fminf(vmin, w); vmax = fmaxf(vmax, w);
+    }
+  }
+  bb = make_int4(0, 0, 0, 0);
+  if (!any_approx) return 0;
+  bool cull = (zmax <= c.min_depth - 1e-3f) || (zmin > c.max_depth + 1e-3f);
+  if (!cull && zmin >= 0.05f) cull = umax < -3.f || umin > (float) c.cols + 1.f || vmax < -3.f || vmin > (float) c.rows + 1.f;
+  if (cull) return 2;
+  if (zmin >= 0.05f) {
+    int c0 = f2i_hw(floorf(umin + 0.5f)) - 1, c1 = f2i_hw(floorf(umax + 0.5f)) + 1;
+    int r0 = f2i_hw(floorf(vmin + 0.5f)) - 1, r1 = f2i_hw(floorf(vmax + 0.5f)) + 1;
+    c0 = c0 < 0 ? 0 : c0; r0 = r0 < 0 ? 0 : r0;
+    c1 = c1 > c.cols - 1 ? c.cols - 1 : c1; r1 = r1 > c.rows - 1 ? c.rows - 1 : r1;
+    const int bw = c1 - c0 + 1, bh = r1 - r0 + 1;
+    if (bw > 0 && bh > 0 && bw * bh <= kTileMaxPx) bb = make_int4(c0, r0, bw, bh);
+  }
+  return 1;
+}
+
+// wave-aggregated append of classified blocks to the lists of set `cs` (ctr index base)
+__device__ __forceinline__ void append_classified(const Tab& t, const Lists& L, const int cs, const int cls, const bool collect,
+                                                  const int4 ent, const int4 bb) {
+  const bool is_vis = cls == 1, is_keep = cls == 2 && !collect, is_free = cls == 2 && collect;
+  const u64 bv = __ballot(is_vis), bk = __ballot(is_keep), bf = __ballot(is_free);
+  if (bv) {
+    const int leader = __ffsll((long long) bv) - 1;
+    int base = 0;
+    if ((int) lane_id() == leader) base = atomicAdd(&t.ctr[cs + 0], __popcll(bv));
+    base = __shfl(base, leader);
+    if (is_vis) {
+      const int idx = base + __popcll(bv & lanemask_lt());
+      L.vis[idx] = ent;
+      L.bbox[idx] = bb;
+    }
+  }
+  if (bk && (int) lane_id() == __ffsll((long long) bk) - 1) atomicAdd(&t.ctr[cs + 1], __popcll(bk));
+  if (bf) {
+    const int leader = __ffsll((long long) bf) - 1;
+    int base = 0;
+    if ((int) lane_id() == leader) base = atomicAdd(&t.ctr[cs + 2], __popcll(bf));
+    base = __shfl(base, leader);
+    if (is_free) L.cfree[base + __popcll(bf & lanemask_lt())] = ent;
+  }
+}
+
+template <bool PROFILE>
+__global__ __launch_bounds__(256) void k_front(const Cam c, const Map m, const Tab t, const Fast f, const Lists L,
+                                               const float* __restrict__ depth, const uint8_t* __restrict__ rgb, const int tiles_x,
+                                               const int n_tiles, const u32 stamp, const int parity, const int gc_on,
+                                               const float trunc_threshold) {
+  constexpr int NT = 256;
+  __shared__ u64 set[kRayCap];
+  __shared__ u64 list[kRayCap];
+  __shared__ u32 s_count, s_inserted;
+  const int tid = threadIdx.x;
+  const int cs = CTR_SET0 + 4 * parity;
+
+  const int n_sweep = (int) gridDim.x - n_tiles;  // the sweep workgroups come FIRST in the grid so that they start first
+  if ((int) blockIdx.x >= n_sweep) {
+    const int tile_id = (int) blockIdx.x - n_sweep;
+    // ------------------------------------------------------------------ allocation for one pixel tile
+    for (int i = tid; i < kRayCap; i += NT) set[i] = kKeyEmpty;
+    if (tid == 0) { s_count = 0; s_inserted = 0; }
+    __syncthreads();
+    const int ty = tile_id / tiles_x, tx = tile_id - ty * tiles_x;
+    const int row = ty * kRayTile + (tid >> 4), col = tx * kRayTile + (tid & 15);
+    if (row < c.rows && col < c.cols) {
+      const size_t pix = (size_t) row * c.cols + col;
+      float d = depth[pix];
+      if (d <= c.min_depth || d > c.max_depth) d = 0.f;  // camera.cu:13-18
+      f.depth_clean[pix] = d;
+      const uint8_t* px = rgb + pix * 3;
+      f.rgbx[pix] = (u32) px[0] | ((u32) px[1] << 8) | ((u32) px[2] << 16);
+      walk_ray(c, m, t, row, col, d, [&](const i3 cur, const u64 key) {
+        u32 s = (u32) __mul24(cur.z, 5851) + (u32) __mul24(cur.y, 73) + (u32) cur.x;
+        s = (s ^ (s >> 7)) & (kRayCap - 1);
+#pragma unroll 1
+        for (int p = 0; p < kSetProbe; p++) {
+          const u64 old = atomicCAS(&set[s], kKeyEmpty, key);
+          if (old == kKeyEmpty) { list[atomicAdd(&s_count, 1u)] = key; return; }
+          if (old == key) return;
+          s = (s + 1) & (kRayCap - 1);
+        }
+        // LDS set saturated (far, sparse rays): insert directly; the new block is listed below like any other
+        if (!block_in_frustum_approx(c, m.vs, cur)) return;
+        const int slot = hash_insert(t, key);
+        if (slot == -2) atomicOr((u32*) &t.ctr[CTR_ERROR], ERR_TABLE);
+        if (slot < 0) return;
+        const int idx = atomicSub(&t.ctr[CTR_HEAP_FINE], 1);
+        if (idx < 0) {
+          atomicAdd(&t.ctr[CTR_HEAP_FINE], 1);
+          atomicExch(&t.keys[slot], kKeyTomb);
+          atomicOr((u32*) &t.ctr[CTR_ERROR], ERR_POOL);
+          return;
+        }
+        const u32 H = t.heap_fine[idx];
+        t.vals[slot] = H;
+        t.desc_fine[H] = make_int4(cur.x, cur.y, cur.z, desc_w(stamp));
+        f.summary[H] = make_uint2(0x7F7FFFFFu, 0u);
+        if ((int) H >= __hip_atomic_load(&t.ctr[CTR_HWM_FINE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&t.ctr[CTR_HWM_FINE], (int) H + 1);
+        const int li = atomicAdd(&t.ctr[cs + 0], 1);  // unclassified, no footprint (see below)
+        L.vis[li] = make_int4(cur.x, cur.y, cur.z, (int) H);
+        L.bbox[li] = make_int4(0, 0, 0, 0);
+        if (PROFILE) atomicAdd(&t.prof[PROF_INSERTED], 1ull);
+      });
+    }
+    __syncthreads();
+    const int n = (int) s_count;
+    u32 my_inserted = 0;
+#pragma unroll 1
+    for (int base = 0; base < n; base += NT) {
+      const int i = base + tid;
+      const bool active = i < n;
+      const u64 key = active ? list[i] : kKeyEmpty;
+      const i3 b = active ? unpack_key(key) : mki3(0, 0, 0);
+      bool won = false;
+      int slot = -1;
+      if (active && block_in_frustum_approx(c, m.vs, b)) {
+        slot = hash_insert(t, key);
+        if (slot == -2) atomicOr((u32*) &t.ctr[CTR_ERROR], ERR_TABLE);
+        won = slot >= 0;
+      }
+      // wave-aggregated pop of the fine free list (alloc_commit2 with a stamped descriptor)
+      const u64 ballot = __ballot(won);
+      int cls = 0;
+      int4 ent = make_int4(0, 0, 0, 0), bb = make_int4(0, 0, 0, 0);
+      if (ballot) {
+        const int leader = __ffsll((long long) ballot) - 1;
+        int hb = 0;
+        if ((int) lane_id() == leader) hb = atomicSub(&t.ctr[CTR_HEAP_FINE], __popcll(ballot));
+        hb = __shfl(hb, leader);
+        if (won) {
+          const int idx = hb - __popcll(ballot & lanemask_lt());
+          if (idx < 0) {
+            atomicAdd(&t.ctr[CTR_HEAP_FINE], 1);
+            atomicExch(&t.keys[slot], kKeyTomb);
+            atomicOr((u32*) &t.ctr[CTR_ERROR], ERR_POOL);
+          } else {
+            const u32 H = t.heap_fine[idx];
+            t.vals[slot] = H;
+            t.desc_fine[H] = make_int4(b.x, b.y, b.z, desc_w(stamp));
+            f.summary[H] = make_uint2(0x7F7FFFFFu, 0u);
+            if ((int) H >= __hip_atomic_load(&t.ctr[CTR_HWM_FINE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&t.ctr[CTR_HWM_FINE], (int) H + 1);
+            // a new block goes on the visible list unclassified and without a pixel footprint (k_back then gathers
+            // its pixels directly): a few hundred blocks per frame, not worth 8 serial corner projections on the
+            // allocation workgroup's critical path.  If no voxel of it lands in the image it stays at weight 0 and
+            // k_back collects it, exactly what GC does with it in the reference.
+            cls = 1;
+            ent = make_int4(b.x, b.y, b.z, (int) H);
+            if (PROFILE) my_inserted++;
+          }
+        }
+        append_classified(t, L, cs, cls, false, ent, bb);
+      }
+    }
+    if (PROFILE) {
+      if (my_inserted) atomicAdd(&s_inserted, my_inserted);
+      __syncthreads();
+      if (tid == 0 && s_inserted) atomicAdd(&t.prof[PROF_INSERTED], (u64) s_inserted);
+    }
+    return;
+  }
+
+  // -------------------------------------------------------------------- sweep of the pre-existing descriptors
+  // Same-address atomics retire at roughly one per 7-10 ns on this chip, so a sweep that appends per 32-block batch
+  // (~3 atomics x 1250 batches per frame) is bound by exactly that.  Each sweep workgroup therefore owns one
+  // contiguous chunk of descriptors, stages its results in LDS (aliasing the key set / list of the allocation half)
+  // and publishes them with three atomics per workgroup.
+  const int hwm = t.ctr[CTR_HWM_FINE];
+  const int sw = (int) blockIdx.x;
+  const int chunk = (((hwm + n_sweep - 1) / n_sweep) + 63) & ~63;
+  const int lo = sw * chunk, hi = min(hwm, lo + chunk);
+  int4* st_vis = (int4*) list;   // 256 x {entry, bbox}
+  int4* st_free = (int4*) set;   // 512 entries
+  constexpr int kStVis = kRayCap * 8 / 32, kStFree = kRayCap * 8 / 16;
+  __shared__ int s_nvis, s_nfree, s_nkeep, s_bv, s_bf;
+  if (tid == 0) { s_nvis = 0; s_nfree = 0; s_nkeep = 0; }
+  __syncthreads();
+  auto flush = [&]() {  // all threads of the workgroup
+    __syncthreads();
+    if (tid == 0) {
+      s_bv = s_nvis ? atomicAdd(&t.ctr[cs + 0], s_nvis) : 0;
+      s_bf = s_nfree ? atomicAdd(&t.ctr[cs + 2], s_nfree) : 0;
+    }
+    __syncthreads();
+    for (int i = tid; i < s_nvis; i += NT) { L.vis[s_bv + i] = st_vis[2 * i]; L.bbox[s_bv + i] = st_vis[2 * i + 1]; }
+    for (int i = tid; i < s_nfree; i += NT) L.cfree[s_bf + i] = st_free[i];
+    __syncthreads();
+    if (tid == 0) { s_nvis = 0; s_nfree = 0; }
+    __syncthreads();
+  };
+  const int grp = tid >> 2;      // block within the 64-block batch
+  const int sub = tid & 3;       // this lane evaluates corners sub and sub + 4
+  int4 d_next = make_int4(0, 0, 0, 0);
+  uint2 sm_next = make_uint2(0, 0);
+  if (lo + grp < hi) { d_next = t.desc_fine[lo + grp]; sm_next = f.summary[lo + grp]; }
+  for (int base = lo; base < hi; base += 64) {
+    const int i = base + grp;
+    const int4 d = d_next;
+    const uint2 sm = sm_next;
+    if (i + 64 < hi) { d_next = t.desc_fine[i + 64]; sm_next = f.summary[i + 64]; }  // next batch in flight during this one
+    // live and not inserted by this very launch (those are handled by their inserter)
+    const bool live = i < hi && (d.w & 1) && ((u32) d.w >> 1) != stamp;
+    int any_approx = 0;
+    float zmin = kFltMax, zmax = -kFltMax, umin = kFltMax, umax = -kFltMax, vmin = kFltMax, vmax = -kFltMax;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const int corner = sub + 4 * h;
+      const i3 v = mki3(d.x * kBlockSide + ((corner & 4) ? 7 : 0), d.y * kBlockSide + ((corner & 2) ? 7 : 0), d.z * kBlockSide + ((corner & 1) ? 7 : 0));
+      const f3 pc = se3_apply(c.Ri, c.ti, voxel_to_world(m.vs, v));
+      int r, cc;
+      any_approx |= project_point<true>(c, pc, r, cc) ? 1 : 0;
+      zmin = fminf(zmin, pc.z); zmax = fmaxf(zmax, pc.z);
+      if (pc.z >= 0.05f) {
+        const float u = c.fx * pc.x / pc.z + c.cx;
+        const float w = c.fy * pc.y / pc.z + c.cy;
+        umin = fminf(umin, u); umax = fmaxf(umax, u);
+        vmin = fminf(vmin, w); vmax = fmaxf(vmax, w);
+      }
+    }
+#pragma unroll
+    for (int off = 1; off < 4; off <<= 1) {
+      any_approx |= __shfl_xor(any_approx, off);
+      zmin = fminf(zmin, __shfl_xor(zmin, off)); zmax = fmaxf(zmax, __shfl_xor(zmax, off));
+      umin = fminf(umin, __shfl_xor(umin, off)); umax = fmaxf(umax, __shfl_xor(umax, off));
+      vmin = fminf(vmin, __shfl_xor(vmin, off)); vmax = fmaxf(vmax, __shfl_xor(vmax, off));
+    }
+    if (sub == 0 && live && any_approx) {
+      bool cull = (zmax <= c.min_depth - 1e-3f) || (zmin > c.max_depth + 1e-3f);
+      if (!cull && zmin >= 0.05f) cull = umax < -3.f || umin > (float) c.cols + 1.f || vmax < -3.f || vmin > (float) c.rows + 1.f;
+      const int4 e = make_int4(d.x, d.y, d.z, i);
+      if (!cull) {
+        int4 bb = make_int4(0, 0, 0, 0);
+        if (zmin >= 0.05f) {
+          int c0 = f2i_hw(floorf(umin + 0.5f)) - 1, c1 = f2i_hw(floorf(umax + 0.5f)) + 1;
+          int r0 = f2i_hw(floorf(vmin + 0.5f)) - 1, r1 = f2i_hw(floorf(vmax + 0.5f)) + 1;
+          c0 = c0 < 0 ? 0 : c0; r0 = r0 < 0 ? 0 : r0;
+          c1 = c1 > c.cols - 1 ? c.cols - 1 : c1; r1 = r1 > c.rows - 1 ? c.rows - 1 : r1;
+          const int bw = c1 - c0 + 1, bh = r1 - r0 + 1;
+          if (bw > 0 && bh > 0 && bw * bh <= kTileMaxPx) bb = make_int4(c0, r0, bw, bh);
+        }
+        const int k2 = atomicAdd(&s_nvis, 1);
+        st_vis[2 * k2] = e;
+        st_vis[2 * k2 + 1] = bb;
+      } else {
+        bool collect = false;
+        if (gc_on) {  // culled: untouched by this frame, so the stored summary already decides (vds.cu:1708-1711)
+          collect = (__uint_as_float(sm.x) >= trunc_threshold) || (sm.y == 0u);
+        }
+        if (collect) st_free[atomicAdd(&s_nfree, 1)] = e;
+        else atomicAdd(&s_nkeep, 1);
+      }
+    }
+    // the staging areas hold at least 4 / 8 more batches than one iteration can add: flush only when nearly full
+    __syncthreads();
+    if (s_nvis > kStVis - 64 || s_nfree > kStFree - 64) flush();
+  }
+  flush();
+  if (tid == 0 && s_nkeep) atomicAdd(&t.ctr[cs + 1], s_nkeep);
+}
+
+// pixel footprint of a block computed by the wave that is about to integrate it (lanes 0..7 take one corner each):
+// used for blocks inserted this frame, which k_front lists without a footprint.  Returns {0,0,0,0} when a corner
+// is closer than 5 cm or the footprint exceeds the tile (the lookups then fall back to direct gathers).
+__device__ __forceinline__ int4 wave_bbox(const Cam& c, const float vs, const int4 ent, const int lane) {
+  const int corner = lane & 7;
+  const i3 v = mki3(ent.x * kBlockSide + ((corner & 4) ? 7 : 0), ent.y * kBlockSide + ((corner & 2) ? 7 : 0), ent.z * kBlockSide + ((corner & 1) ? 7 : 0));
+  const f3 pc = se3_apply(c.Ri, c.ti, voxel_to_world(vs, v));
+  float zmin = pc.z;
+  float umin = c.fx * pc.x / pc.z + c.cx, umax = umin;
+  float vmin = c.fy * pc.y / pc.z + c.cy, vmax = vmin;
+#pragma unroll
+  for (int off = 1; off < 8; off <<= 1) {
+    zmin = fminf(zmin, __shfl_xor(zmin, off));
+    umin = fminf(umin, __shfl_xor(umin, off)); umax = fmaxf(umax, __shfl_xor(umax, off));
+    vmin = fminf(vmin, __shfl_xor(vmin, off)); vmax = fmaxf(vmax, __shfl_xor(vmax, off));
+  }
+  int4 bb = make_int4(0, 0, 0, 0);
+  if (zmin >= 0.05f) {
+    int c0 = f2i_hw(floorf(umin + 0.5f)) - 1, c1 = f2i_hw(floorf(umax + 0.5f)) + 1;
+    int r0 = f2i_hw(floorf(vmin + 0.5f)) - 1, r1 = f2i_hw(floorf(vmax + 0.5f)) + 1;
+    c0 = c0 < 0 ? 0 : c0; r0 = r0 < 0 ? 0 : r0;
+    c1 = c1 > c.cols - 1 ? c.cols - 1 : c1; r1 = r1 > c.rows - 1 ? c.rows - 1 : r1;
+    const int bw = c1 - c0 + 1, bh = r1 - r0 + 1;
+    if (bw > 0 && bh > 0 && bw * bh <= kTileMaxPx) bb = make_int4(c0, r0, bw, bh);
+  }
+  return make_int4(__shfl(bb.x, 0), __shfl(bb.y, 0), __shfl(bb.z, 0), __shfl(bb.w, 0));
+}
+
+// K2: integrate + summary + GC of the visible list (k_fused's body), then the culled-free list; zeroes the other list set
+template <bool FREE, bool PROFILE>
+__global__ __launch_bounds__(256) void k_back(const Cam c, const Map m, const Tab t, const Fast f, const Lists L, const int parity,
+                                              const float trunc_threshold, const int stagger) {
+  extern __shared__ __attribute__((aligned(16))) uint2 s_tile[];
+  (void) stagger;  // (a delayed start of every other workgroup was measured: it only lengthens the launch)
+  const int cs = CTR_SET0 + 4 * parity;
+  const int nvis = t.ctr[cs + 0];
+  const int ncfree = FREE ? t.ctr[cs + 2] : 0;
+  const int lane = threadIdx.x & 63;
+  const int wpw = blockDim.x >> 6;
+  const int gw = blockIdx.x * wpw + (threadIdx.x >> 6);
+  const int nw = gridDim.x * wpw;
+  if (gw == 0 && lane < 4) t.ctr[CTR_SET0 + 4 * (parity ^ 1) + lane] = 0;  // next frame's k_front appends there
+  if (gw == 0 && lane == 0) {  // stats mirror for the host (M = visible + culled)
+    t.ctr[CTR_COMPACT] = nvis;
+    t.ctr[CTR_CULLED] = t.ctr[cs + 1] + t.ctr[cs + 2];
+    t.ctr[CTR_FREED_EARLY] = 0;
+  }
+  const float r_half_vs = rcp_refined(m.vs / 2);
+  uint2* tile = &s_tile[(threadIdx.x >> 6) * kTileMaxPx];
+  for (int e = gw; e < nvis; e += nw) {
+    const int4 ent = L.vis[e];
+    int4 bb = L.bbox[e];
+    const u32 H = (u32) ent.w;
+    float4* ps = (float4*) (t.pool + (size_t) H * kFineBytes);
+    float4* pq = ps + 128;
+    uint4* pw = (uint4*) (ps + 256);
+    float4 S[2];
+    uint4 W[2];
+#pragma unroll
+    for (int b = 0; b < 2; b++) { S[b] = ps[lane + 64 * b]; W[b] = pw[lane + 64 * b]; }
+    if (bb.z == 0) bb = wave_bbox(c, m.vs, ent, lane);  // listed without a footprint (inserted this frame)
+    Proj4 P[2];
+    float d[2][4];
+    u32 cpx[2][4];
+    tile_fill(c, f, bb, lane, tile);
+#pragma unroll
+    for (int b = 0; b < 2; b++) P[b] = project4(c, m, ent, lane + 64 * b);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    tile_lookup<2>(f, bb, tile, P, d, cpx);
+    __builtin_amdgcn_wave_barrier();
+    float mn = kFltMax;
+    u32 mx = 0;
+#pragma unroll
+    for (int b = 0; b < 2; b++) {
+      const int q = lane + 64 * b;
+      float s[4] = {S[b].x, S[b].y, S[b].z, S[b].w};
+      u32 w[4] = {W[b].x, W[b].y, W[b].z, W[b].w};
+      float ss[4] = {0.f, 0.f, 0.f, 0.f};
+      const u32 mask = update_mask4(c, m, P[b], d[b]);
+      blend4(m, P[b], mask, d[b], cpx[b], r_half_vs, s, w, ss);
+      if (mask) {
+        ps[q] = make_float4(s[0], s[1], s[2], s[3]);
+        pw[q] = make_uint4(w[0], w[1], w[2], w[3]);
+        if (mask == 0xF) {
+          pq[q] = make_float4(ss[0], ss[1], ss[2], ss[3]);
+        } else {
+          float* pqs = (float*) (pq + q);
+#pragma unroll
+          for (int k = 0; k < 4; k++)
+            if (mask & (1u << k)) pqs[k] = ss[k];
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const u32 wk = w[k] >> 24;
+        if (wk != 0) mn = fminf(mn, fabsf(s[k]));
+        mx = wk > mx ? wk : mx;
+      }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+      mn = fminf(mn, __shfl_xor(mn, off));
+      const u32 o = __shfl_xor(mx, off);
+      mx = o > mx ? o : mx;
+    }
+    if (lane == 0) f.summary[H] = make_uint2(__float_as_uint(mn), mx);
+    if (FREE && (mn >= trunc_threshold || mx == 0)) {
+      wave_free_block(t, ent, lane);
+      if (PROFILE && lane == 0) atomicAdd(&t.prof[PROF_FREED], 1ull);
+    }
+  }
+  if (FREE) {
+    for (int e = gw; e < ncfree; e += nw) {
+      wave_free_block(t, L.cfree[e], lane);
+      if (PROFILE && lane == 0) atomicAdd(&t.prof[PROF_FREED], 1ull);
+    }
+  }
+}
+
+// starve frames: GC after the weights changed — visible list by refreshed summary, plus the culled-free list
+__global__ __launch_bounds__(256) void k_free_lists(const Tab t, const Fast f, const Lists L, const int parity, const float trunc_threshold) {
+  const int cs = CTR_SET0 + 4 * parity;
+  const int nvis = t.ctr[cs + 0], ncfree = t.ctr[cs + 2];
+  const int lane = threadIdx.x & 63;
+  const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int nw = gridDim.x * 4;
+  for (int e = gw; e < nvis + ncfree; e += nw) {
+    const int4 ent = e < nvis ? L.vis[e] : L.cfree[e - nvis];
+    bool fr = e >= nvis;
+    if (!fr) {
+      const uint2 sm = f.summary[ent.w];
+      fr = (__uint_as_float(sm.x) >= trunc_threshold) || (sm.y == 0u);
+    }
+    if (fr) {
+      wave_free_block(t, ent, lane);
+      if (lane == 0) atomicAdd(&t.prof[PROF_FREED], 1ull);
+    }
+  }
+}
+
+}  // namespace mrh

@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256) void k_compact(const Cam c, const Map m, const
     if (i < total) {
       if (i < hwm) { d = t.desc_fine[i]; val = (u32) i; }
       else { const u32 u = (u32) (i - hwm); d = t.desc_coarse[u]; val = u | kValCoarseBit; }
-      if (d.w == 1) keep = !use_camera || block_in_frustum_approx(c, m.vs, mki3(d.x, d.y, d.z));
+      if (d.w & 1) keep = !use_camera || block_in_frustum_approx(c, m.vs, mki3(d.x, d.y, d.z));  // bit 0 = live (upper bits: insertion stamp)
     }
     const u64 ballot = __ballot(keep);
     if (ballot) {
@@ -596,8 +596,8 @@ __global__ __launch_bounds__(256) void k_count_live(const Tab t) {
     const int i = base + threadIdx.x;
     bool lf = false, lc = false;
     if (i < total) {
-      if (i < hwm) lf = t.desc_fine[i].w == 1;
-      else lc = t.desc_coarse[i - hwm].w == 1;
+      if (i < hwm) lf = (t.desc_fine[i].w & 1) != 0;
+      else lc = (t.desc_coarse[i - hwm].w & 1) != 0;
     }
     const u64 bf = __ballot(lf), bc = __ballot(lc);
     if (lane_id() == 0) {
