@@ -212,8 +212,24 @@ void GeoWrapper::serializeGrid(const std::string& filename) {
   }
 }
 
-void GeoWrapper::deserializeGrid(const std::string& /*filename*/) {
-  throw std::runtime_error("GeoWrapper::deserializeGrid | restoring a grid needs the block stream-in path (SURVEY.md §8f-1), not built yet");
+void GeoWrapper::deserializeGrid(const std::string& filename) {
+  // inverse of serializeGrid: blocks are inserted (or overwritten) through mrh_import_blocks, the stream-in half of
+  // the reference's streamer (Streamer::streamInToGPU, streamer.cpp:358-378) as far as a resident map needs it
+  std::ifstream in(filename, std::ios::binary);
+  if (!in.is_open()) throw std::runtime_error("GeoWrapper::deserializeGrid | cannot open " + filename);
+  char magic[8];
+  uint64_t n = 0;
+  in.read(magic, 8);
+  in.read((char*) &n, 8);
+  if (!in || std::memcmp(magic, "MRHGRID1", 8) != 0) throw std::runtime_error("GeoWrapper::deserializeGrid | not a MRHGRID1 file: " + filename);
+  std::vector<mrh_block_desc> descs(n ? n : 1);
+  std::vector<mrh_voxel> vox((n ? n : 1) * 512);
+  for (uint64_t k = 0; k < n; ++k) {
+    in.read((char*) &descs[k], sizeof(mrh_block_desc));
+    in.read((char*) &vox[k * 512], 512 * sizeof(mrh_voxel));
+  }
+  if (!in) throw std::runtime_error("GeoWrapper::deserializeGrid | truncated file: " + filename);
+  check(mrh_import_blocks(ctx_, descs.data(), vox.data(), n), "deserializeGrid");
 }
 
 void GeoWrapper::GSSavePointCloud(const std::string& /*folder*/) {

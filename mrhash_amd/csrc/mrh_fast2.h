@@ -169,7 +169,9 @@ __global__ __launch_bounds__(256) void k_front(const Cam c, const Map m, const T
       const i3 b = active ? unpack_key(key) : mki3(0, 0, 0);
       bool won = false;
       int slot = -1;
-      if (active && block_in_frustum_approx(c, m.vs, b)) {
+      // probe first: ~95 % of a tile's blocks already exist, and for those neither the 8-corner frustum test nor
+      // the insert protocol is needed
+      if (active && hash_find(t, key) < 0 && block_in_frustum_approx(c, m.vs, b)) {
         slot = hash_insert(t, key);
         if (slot == -2) atomicOr((u32*) &t.ctr[CTR_ERROR], ERR_TABLE);
         won = slot >= 0;

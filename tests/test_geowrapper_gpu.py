@@ -94,3 +94,17 @@ def test_serialize_outputs(geowrapper_cls, tmp_path):
     raw = (tmp_path / "grid.bin").read_bytes()
     assert raw[:8] == b"MRHGRID1" and int.from_bytes(raw[8:16], "little") == 100
     assert len(raw) == 16 + 100 * (16 + 512 * 12)
+    # checkpoint / resume: a fresh wrapper restored from the grid file yields the same mesh and keeps fusing identically
+    g.extractMesh(str(tmp_path / "a.ply"))
+    h = _make(geowrapper_cls, n_frames_invalidate_voxels=0)
+    h.setCamera(K.fx, K.fy, K.cx, K.cy, K.rows, K.cols, 0.01, 30.0, 0)
+    h.deserializeGrid(str(tmp_path / "grid.bin"))
+    h.extractMesh(str(tmp_path / "b.ply"))
+    assert np.array_equal(g.getVertices(), h.getVertices()) and np.array_equal(g.getFaces(), h.getFaces())
+    f2 = synth.cfg1_plane(z=1.01)
+    for w in (g, h):
+        w.setCurrPose(f2.t, f2.q); w.setDepthImage(f2.depth); w.setRGBImage(f2.rgb); w.compute()
+        w.extractMesh(str(tmp_path / "c.ply"))
+    assert np.array_equal(g.getVertices(), h.getVertices()) and np.array_equal(g.getFaces(), h.getFaces())
+    with pytest.raises(RuntimeError):
+        h.deserializeGrid(str(tmp_path / "hash.ply"))

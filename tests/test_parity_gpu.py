@@ -244,6 +244,66 @@ def test_replica_640x480_stream(hip, oracle):
     assert r["blocks"] > 5000 and r["sdf_bit_exact"]
 
 
+def test_scannet_640x480_furnished_walk(hip, oracle):
+    """BASELINE configs[3] stand-in at full resolution: furnished room (depth discontinuities), hand-held-like walk
+    with rotated poses, ScanNet intrinsics / depth quantisation, scannet.cfg parameters."""
+    a, b = _pair(hip, oracle, synth.SCANNET, synth.SCANNET_PARAMS, 131072)
+    for f in synth.scannet_stream(5, start=40):
+        pu.feed(a, f)
+        pu.feed(b, f)
+        sa, sb = a.stats(), b.stats()
+        assert (sa.occupied_fine, sa.free_fine, sa.last_compact_blocks) == (sb.occupied_fine, sb.free_fine, sb.last_compact_blocks)
+    a.sync()
+    r = pu.compare_maps(a, b)
+    assert r["blocks"] > 3000 and r["sdf_bit_exact"] and r["sumsq_bit_exact"]
+
+
+def test_replica_native_1200x680(hip, oracle):
+    """The resolution the reference's Replica numbers are quoted on (replica.cfg:20-21)."""
+    a, b = _pair(hip, oracle, synth.REPLICA_NATIVE, synth.REPLICA_PARAMS, 262144)
+    for f in synth.replica_stream(2, K=synth.REPLICA_NATIVE):
+        pu.feed(a, f)
+        pu.feed(b, f)
+    a.sync()
+    r = pu.compare_maps(a, b)
+    assert r["blocks"] > 5000 and r["sdf_bit_exact"]
+
+
+def test_multires_640x480(hip, oracle):
+    """BASELINE configs[2] stand-in: variance-adaptive map at full resolution with sensor noise (sigma 2 mm), the
+    project page's threshold 0.005; occupancy (incl. which blocks went coarse) and payload must match."""
+    params = dict(synth.REPLICA_PARAMS, sdf_var_threshold=0.005)
+    a, b = _pair(hip, oracle, synth.REPLICA_640, params, 131072)
+    saw_coarse = False
+    for f in synth.replica_stream(4, noise_sigma=0.002):
+        pu.feed(a, f)
+        pu.feed(b, f)
+        sa, sb = a.stats(), b.stats()
+        assert (sa.occupied_fine, sa.occupied_coarse) == (sb.occupied_fine, sb.occupied_coarse)
+        saw_coarse |= sa.occupied_coarse > 0
+    a.sync()
+    pu.compare_maps(a, b)
+    assert saw_coarse
+
+
+@pytest.mark.parametrize("env", [{}, {"MRH_MERGED": "0"}, {"MRH_MERGED": "0", "MRH_FUSED_NB": "1"},
+                                 {"MRH_MERGED": "0", "MRH_GC_INLINE": "0"}, {"MRH_OVERLAP": "1"}, {"MRH_MERGED": "0", "MRH_FUSED_PIPE": "1"}],
+                         ids=["two-launch", "three-launch", "half-block-waves", "separate-free", "overlapped-rays", "pipelined"])
+def test_fast_path_variants_agree_with_oracle(hip, oracle, monkeypatch, env):
+    """Every tuning variant of the single-resolution path (selected through environment knobs read at mrh_create)
+    must produce the same map: GC each frame, starve on frames 2 and 4, 640x480."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    params = dict(synth.REPLICA_PARAMS, n_frames_invalidate_voxels=2)
+    a, b = _pair(hip, oracle, synth.REPLICA_640, params, 131072)
+    for f in synth.replica_stream(5):
+        pu.feed(a, f)
+        pu.feed(b, f)
+    a.sync()
+    r = pu.compare_maps(a, b)
+    assert r["sdf_bit_exact"]
+
+
 def test_golden_fixtures(hip):
     """Committed fixtures (generated by tests/golden/make_golden.py from the oracle): canonical buffers
     of cfg1 hashed with SHA-256 plus summary counts."""
