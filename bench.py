@@ -209,7 +209,7 @@ def main():
                        "frames_per_gpu": K, "voxel_size_m": 0.01, "truncation_m": 0.07,
                        "parallelism": "frame-sharded sub-maps, no data-path collective" if world > 1 else "single GPU",
                        "live_blocks_end": occupied},
-            "roofline": {"bound": "hbm", "kernel": "k_fused (depth->TSDF integrate + GC summary)", "achieved": achieved,
+            "roofline": {"bound": "hbm", "kernel": "k_back (depth->TSDF integrate + GC summary + GC decision)", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic_bytes(),
                          "traffic_note": "bytes per launch from profiles/r01/bench_pmc_summary.txt (rocprofv3 PMC passes of this "
                                          "command, 2 x FETCH_SIZE + WRITE_SIZE); the ~85 MB working set stays in the 256 MiB "

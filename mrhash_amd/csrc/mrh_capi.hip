@@ -73,6 +73,7 @@ struct mrh_ctx {
   int overlap = 0;        // MRH_OVERLAP=1: rays of frame f+1 on a second stream (mrh_pipe.h; host-bound, off by default)
   int merged = 1;         // MRH_MERGED=0: three-launch path (k_alloc2 / k_compact2 / k_fused) instead of k_front / k_back
   int4* d_cfree = nullptr;
+  float* d_zmin = nullptr;   // per visible-list entry (Lists::zmin)
   uint64_t fast_frames = 0;  // fast-path frames issued: parity selects the list-counter set
   int frame_parity = 0;
   uint64_t frames_enqueued = 0;  // fast-path frames whose rays were issued (parity selects the buffer pair)
@@ -149,7 +150,7 @@ void free_all(mrh_ctx* c) {
   F(c->tab.keys); F(c->tab.vals); F(c->tab.heap_fine); F(c->tab.heap_coarse); F(c->tab.desc_fine); F(c->tab.desc_coarse);
   F(c->tab.pool); F(c->tab.compact); F(c->tab.ctr); F(c->tab.prof);
   F(c->d_depth_own); F(c->d_rgb_own); F(c->d_decision); F(c->d_zbuf); F(c->d_realloc); F(c->d_reint); F(c->d_flag);
-  F(c->d_upd_partials); F(c->d_misc); F(c->d_cfree); F(c->fast.summary); F(c->fast.bbox); F(c->d_cnt_partials);
+  F(c->d_upd_partials); F(c->d_misc); F(c->d_cfree); F(c->d_zmin); F(c->fast.summary); F(c->fast.bbox); F(c->d_cnt_partials);
   for (auto& e : c->ev_pool) { (void) hipEventDestroy(e.a); (void) hipEventDestroy(e.b); }
   for (auto& e : c->ev_pending) { (void) hipEventDestroy(e.a); (void) hipEventDestroy(e.b); }
   if (c->stream) (void) hipStreamDestroy(c->stream);
@@ -361,7 +362,7 @@ int frame_tail(mrh_ctx* c, bool starved, int max_num_frames) {
     if (starved) k_fused<false, 2, false><<<c->fused_grid, 256, 16, s>>>(k, m, t, c->fast, thr);  // weights changed: refresh the summaries
     if (max_num_frames > 0 && !c->frame_gc_inline) {
       if (c->merged) {
-        const Lists L = {t.compact, c->fast.bbox, c->d_cfree, (u32) c->num_blocks};
+        const Lists L = {t.compact, c->fast.bbox, c->d_cfree, c->d_zmin, (u32) c->num_blocks};
         k_free_lists<<<256, 256, 0, s>>>(t, c->fast, L, c->frame_parity, thr);
       } else if (c->profile) k_free2<true><<<256, 256, 0, s>>>(t, c->fast, thr);
       else k_free2<false><<<256, 256, 0, s>>>(t, c->fast, thr);
@@ -408,6 +409,8 @@ int mrh_create(const mrh_params* p, mrh_ctx** out) {
   if (!p || !out) return fail(nullptr, MRH_ERR_INVALID_ARG, "mrh_create: null argument");
   if (p->abi_version != MRH_ABI_VERSION) return fail(nullptr, MRH_ERR_INVALID_ARG, "mrh_create: abi_version mismatch");
   if (!(p->virtual_voxel_size > 0.f)) return fail(nullptr, MRH_ERR_INVALID_ARG, "mrh_create: virtual_voxel_size must be > 0");
+  if (!(p->sdf_truncation >= 0.f) || !(p->sdf_truncation_scale >= 0.f))
+    return fail(nullptr, MRH_ERR_INVALID_ARG, "mrh_create: sdf_truncation and sdf_truncation_scale must be >= 0");
   if (p->voxel_extents_scale != 0 && p->voxel_extents_scale != 1)
     return fail(nullptr, MRH_ERR_UNSUPPORTED, "mrh_create: voxel_extents_scale != 1 is incoherent in the reference (vhu.cuh:90-92 vs 138-140)");
   int ndev = 0;
@@ -481,7 +484,12 @@ int mrh_create(const mrh_params* p, mrh_ctx** out) {
   CREATE_TRY(hipMalloc((void**) &c->fast.summary, c->num_blocks * sizeof(uint2)));
   c->fast.compact_cap = (u32) c->num_blocks;
   CREATE_TRY(hipMalloc((void**) &c->fast.bbox, c->num_blocks * sizeof(int4)));
+#ifdef MRH_TRACE
+  CREATE_TRY(hipMalloc((void**) &c->fast.trace, c->num_blocks * 8 * sizeof(u64)));
+  CREATE_TRY(hipMemset(c->fast.trace, 0, c->num_blocks * 8 * sizeof(u64)));
+#endif
   CREATE_TRY(hipMalloc((void**) &c->d_cfree, c->num_blocks * sizeof(int4)));
+  CREATE_TRY(hipMalloc((void**) &c->d_zmin, c->num_blocks * sizeof(float)));
 #undef CREATE_TRY
 
   Map& m = c->map;
@@ -530,6 +538,17 @@ int mrh_create(const mrh_params* p, mrh_ctx** out) {
 
 int mrh_destroy(mrh_ctx* c) {
   if (!c) return MRH_OK;
+#ifdef MRH_TRACE
+  if (const char* path = getenv("MRH_TRACE_FILE")) {  // tuning builds: phase timestamps of the last k_back launch
+    if (c->fast.trace) {
+      hipDeviceSynchronize();
+      const size_t n = std::min<size_t>(c->num_blocks, 40960) * 8;
+      std::vector<u64> h(n);
+      hipMemcpy(h.data(), c->fast.trace, n * sizeof(u64), hipMemcpyDeviceToHost);
+      if (FILE* fp = fopen(path, "wb")) { fwrite(h.data(), sizeof(u64), n, fp); fclose(fp); }
+    }
+  }
+#endif
   free_all(c);
   delete c;
   return MRH_OK;
@@ -677,7 +696,7 @@ int mrh_integrate(mrh_ctx* c, int n_frames_invalidate) {
       c->frames_enqueued++;
       const u32 stamp = (u32) ((c->frames + 1) & 0x3FFFFFFFu);
       const float gc_thr = m.trunc + m.trunc_scale * k.max_depth;  // getTruncation(camera.maxDepth(), ...), vds.cu:1720
-      const Lists L = {t.compact, c->fast.bbox, c->d_cfree, (u32) c->num_blocks};
+      const Lists L = {t.compact, c->fast.bbox, c->d_cfree, c->d_zmin, (u32) c->num_blocks};
       const int n_tiles = tiles_x * tiles_y;
       const bool starve = max_num_frames > 0 && c->frames > 0 && c->frames % (uint64_t) max_num_frames == 0;
       c->frame_gc_inline = max_num_frames > 0 && !starve;

@@ -135,6 +135,48 @@ __device__ __forceinline__ float div_rr(float a, float b, float r) {
   return fmaf(e, r, q);
 }
 
+// ---- two-wide fp32 (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32: full rate on CDNA3/4, each element rounded exactly
+// like its scalar instruction, so pairing two voxels halves the instruction count without changing a bit) -------
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f mk2(float a, float b) { v2f r; r.x = a; r.y = b; return r; }
+__device__ __forceinline__ v2f splat2(float a) { v2f r; r.x = a; r.y = a; return r; }
+__device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ v2f rcp_refined2(v2f b) {
+  const v2f r = mk2(__builtin_amdgcn_rcpf(b.x), __builtin_amdgcn_rcpf(b.y));
+  const v2f e = fma2(-b, r, splat2(1.0f));
+  return fma2(e, r, r);
+}
+__device__ __forceinline__ v2f div_rr2(v2f a, v2f b, v2f r) {
+  v2f q = a * r;
+  v2f e = fma2(-b, q, a);
+  q = fma2(e, r, q);
+  e = fma2(-b, q, a);
+  return fma2(e, r, q);
+}
+
+// ---- wave64 reductions on the VALU (DPP), result wave-uniform in an SGPR: no LDS traffic, no NaN canonicalisation
+#define MRH_DPP_STEP(OP, x, ctrl, rmask) x = OP(x, (u32) __builtin_amdgcn_update_dpp((int) (x), (int) (x), ctrl, rmask, 0xF, false))
+__device__ __forceinline__ u32 umin_(u32 a, u32 b) { return a < b ? a : b; }
+__device__ __forceinline__ u32 umax_(u32 a, u32 b) { return a > b ? a : b; }
+__device__ __forceinline__ u32 wave_min_u32(u32 x) {
+  MRH_DPP_STEP(umin_, x, 0xB1, 0xF);   // quad_perm [1,0,3,2]
+  MRH_DPP_STEP(umin_, x, 0x4E, 0xF);   // quad_perm [2,3,0,1]
+  MRH_DPP_STEP(umin_, x, 0x141, 0xF);  // row_half_mirror
+  MRH_DPP_STEP(umin_, x, 0x140, 0xF);  // row_mirror
+  MRH_DPP_STEP(umin_, x, 0x142, 0xA);  // row_bcast:15 -> rows 1, 3
+  MRH_DPP_STEP(umin_, x, 0x143, 0xC);  // row_bcast:31 -> rows 2, 3
+  return (u32) __builtin_amdgcn_readlane((int) x, 63);
+}
+__device__ __forceinline__ u32 wave_max_u32(u32 x) {
+  MRH_DPP_STEP(umax_, x, 0xB1, 0xF);
+  MRH_DPP_STEP(umax_, x, 0x4E, 0xF);
+  MRH_DPP_STEP(umax_, x, 0x141, 0xF);
+  MRH_DPP_STEP(umax_, x, 0x140, 0xF);
+  MRH_DPP_STEP(umax_, x, 0x142, 0xA);
+  MRH_DPP_STEP(umax_, x, 0x143, 0xC);
+  return (u32) __builtin_amdgcn_readlane((int) x, 63);
+}
+
 // cuda_math.cuh:62-64
 __device__ __forceinline__ int signi(float v) { return (0.f < v) - (v < 0.f); }
 // cuda_math.cuh:947-949

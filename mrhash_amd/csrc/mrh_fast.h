@@ -31,7 +31,25 @@ struct Fast {
   uint2* summary;      // [cap_blocks] {bits of min |sdf| over weighted voxels (FLT_MAX if none), max weight}
   u32 compact_cap;     // entries in Tab::compact
   int4* bbox;          // [compact_cap] per VISIBLE compact entry: pixel footprint {col0, row0, w, h}; w == 0: none
+#ifdef MRH_TRACE
+  u64* trace;          // [compact_cap * 8] per-block phase timestamps of the last k_back launch (tuning builds only)
+#endif
 };
+
+#ifdef MRH_TRACE
+__device__ __forceinline__ u64 trace_now() {
+  u64 t;
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory");
+  return t;
+}
+#define MRH_TS(slot) do { if (lane == 0) f.trace[(size_t) e * 8 + (slot)] = trace_now(); } while (0)
+// k_front: one record per workgroup, stored after the k_back records (offset kTraceFront blocks)
+constexpr size_t kTraceFront = 32768;
+#define MRH_TSF(slot) do { if (threadIdx.x == 0) f.trace[(kTraceFront + blockIdx.x) * 8 + (slot)] = trace_now(); } while (0)
+#else
+#define MRH_TS(slot) do { } while (0)
+#define MRH_TSF(slot) do { } while (0)
+#endif
 
 // ---------------------------------------------------------------------------------------------------------
 // K1'  allocation
@@ -355,7 +373,6 @@ __global__ __launch_bounds__(512) void k_compact2(const Cam c, const Map m, cons
 
 struct Proj4 {
   float pcz[4];
-  u32 pix[4];
   int row[4], col[4];
   u32 mask;  // bit k: voxel k projects into the image (camera.cuh:131-147)
 };
@@ -382,7 +399,6 @@ __device__ __forceinline__ Proj4 project4(const Cam& c, const Map& m, const int4
     const int row = f2i_hw((div_rr(c.fy * Y, Z, rz) + c.cy) + 0.5f);
     const int col = f2i_hw((div_rr(c.fx * X, Z, rz) + c.cx) + 0.5f);
     const bool ok = depth_ok && row >= 0 && col >= 0 && row < c.rows && col < c.cols;
-    P.pix[k] = ok ? (u32) (__mul24(row, c.cols) + col) : 0u;
     P.row[k] = row;
     P.col[k] = col;
     P.mask |= ok ? (1u << k) : 0u;
@@ -391,7 +407,8 @@ __device__ __forceinline__ Proj4 project4(const Cam& c, const Map& m, const int4
 }
 
 // which of the 4 voxels get written: depth valid and sdf > -truncation (vds.cu:1134-1145)
-__device__ __forceinline__ u32 update_mask4(const Cam& c, const Map& m, const Proj4& P, const float (&d)[4]) {
+template <typename PT>
+__device__ __forceinline__ u32 update_mask4(const Cam& c, const Map& m, const PT& P, const float (&d)[4]) {
   u32 mask = P.mask;
 #pragma unroll
   for (int k = 0; k < 4; k++) {
@@ -403,59 +420,92 @@ __device__ __forceinline__ u32 update_mask4(const Cam& c, const Map& m, const Pr
   return mask;
 }
 
-// running weighted mean, colour blend, weight clamp, variance term (vds.cu:1147-1180, vhu.cuh:167-181)
-__device__ __forceinline__ void blend4(const Map& m, const Proj4& P, const u32 mask, const float (&d)[4], const u32 (&cpx)[4],
+// running weighted mean, colour blend, weight clamp, variance term (vds.cu:1147-1180, vhu.cuh:167-181), two voxels
+// per instruction where the arithmetic is plain fp32 (mrh_device.h, v2f).  The clamp `sd >= 0 ? min(t, sd) :
+// max(-t, sd)` is one v_med3_f32 (t >= 0 is checked at mrh_create; a NaN sd yields -t on both sides).
+template <typename PT>
+__device__ __forceinline__ void blend4(const Map& m, const PT& P, const u32 mask, const float (&d)[4], const u32 (&cpx)[4],
                                        const float r_half_vs, float (&s)[4], u32 (&w)[4], float (&ss)[4]) {
   const u32 w1 = (u32) (m.weight_sample & 0xFF);
   const u32 wmax = (u32) (m.weight_max & 0xFF);
-  const float half_vs = m.vs / 2;
+  const v2f half_vs = splat2(m.vs / 2), rh = splat2(r_half_vs), w1f = splat2((float) w1);
 #pragma unroll
-  for (int k = 0; k < 4; k++) {
-    const float trn = get_truncation(d[k], m.trunc, m.trunc_scale);
-    float sd = d[k] - P.pcz[k];
-    if (sd >= 0.f) sd = fminf(trn, sd);
-    else sd = fmaxf(-trn, sd);
-    const float s0 = s[k];
-    const u32 old = w[k];
-    const u32 w0 = old >> 24;
-    const float curr_mean = (w0 > 0) ? s0 : sd;
-    const float delta = div_rr(sd - curr_mean, half_vs, r_half_vs);
-    // combineVoxel's colour (vhu.cuh:170-176): u8(0.5*c0 + 0.5*c1 + 0.5) per channel, with c0 := c1 for a fresh voxel.
-    // 0.5*c0 + 0.5*c1 + 0.5 is exact in fp32 for 8-bit inputs and truncates to (c0 + c1 + 1) >> 1, i.e. the
-    // rounded-up byte average; computed for the three channels at once: (a | b) - (((a ^ b) >> 1) & 0x7f7f7f).
-    const u32 c1x = cpx[k] & 0x00FFFFFFu;
-    const u32 c0x = (w0 == 0) ? c1x : (old & 0x00FFFFFFu);
-    const u32 rgbn = (c0x | c1x) - (((c0x ^ c1x) >> 1) & 0x007F7F7Fu);
-    const float wsum = (float) (int) (w0 + w1);
-    const float sn = div_rr(s0 * (float) w0 + sd * (float) w1, wsum, rcp_refined(wsum));
-    const u32 wn = (w0 + w1) < wmax ? (w0 + w1) : wmax;
-    const float delta2 = div_rr(sd - sn, half_vs, r_half_vs);
-    if ((mask >> k) & 1u) {
-      s[k] = sn;
-      w[k] = rgbn | (wn << 24);
-      ss[k] = 0.f + delta * delta2;
+  for (int k = 0; k < 4; k += 2) {
+    const v2f dd = mk2(d[k], d[k + 1]);
+    const v2f trn = splat2(m.trunc) + splat2(m.trunc_scale) * dd;  // get_truncation
+    v2f sd = dd - mk2(P.pcz[k], P.pcz[k + 1]);
+    sd = mk2(__builtin_amdgcn_fmed3f(sd.x, -trn.x, trn.x), __builtin_amdgcn_fmed3f(sd.y, -trn.y, trn.y));
+    const v2f s0 = mk2(s[k], s[k + 1]);
+    const u32 old0 = w[k], old1 = w[k + 1];
+    const u32 w00 = old0 >> 24, w01 = old1 >> 24;
+    const v2f curr_mean = mk2(w00 > 0 ? s0.x : sd.x, w01 > 0 ? s0.y : sd.y);
+    const v2f delta = div_rr2(sd - curr_mean, half_vs, rh);
+    const v2f wsum = mk2((float) (int) (w00 + w1), (float) (int) (w01 + w1));
+    const v2f sn = div_rr2(s0 * mk2((float) w00, (float) w01) + sd * w1f, wsum, rcp_refined2(wsum));
+    const v2f delta2 = div_rr2(sd - sn, half_vs, rh);
+    const v2f sq = splat2(0.f) + delta * delta2;
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      // combineVoxel's colour (vhu.cuh:170-176): u8(0.5*c0 + 0.5*c1 + 0.5) per channel, with c0 := c1 for a fresh voxel.
+      // 0.5*c0 + 0.5*c1 + 0.5 is exact in fp32 for 8-bit inputs and truncates to (c0 + c1 + 1) >> 1, i.e. the
+      // rounded-up byte average; computed for the three channels at once: (a | b) - (((a ^ b) >> 1) & 0x7f7f7f).
+      const u32 old = j ? old1 : old0, w0 = j ? w01 : w00;
+      const u32 c1x = cpx[k + j] & 0x00FFFFFFu;
+      const u32 c0x = (w0 == 0) ? c1x : (old & 0x00FFFFFFu);
+      const u32 rgbn = (c0x | c1x) - (((c0x ^ c1x) >> 1) & 0x007F7F7Fu);
+      const u32 wn = (w0 + w1) < wmax ? (w0 + w1) : wmax;
+      if ((mask >> (k + j)) & 1u) {
+        s[k + j] = j ? sn.y : sn.x;
+        w[k + j] = rgbn | (wn << 24);
+        ss[k + j] = j ? sq.y : sq.x;
+      }
     }
   }
 }
 
 // ---- LDS pixel tile ----------------------------------------------------------------------------------------
 // dense, row-contiguous fill of the block's pixel footprint {depth bits, colour}
-__device__ __forceinline__ void tile_fill(const Cam& c, const Fast& f, const int4 bb, const int lane, uint2* tile) {
+__device__ __forceinline__ float pixel_reach(const Cam& c, const Map& m, const float d) {
+  // d == 0 (invalid pixel, camera.cu:13-18) or d > max_int_dist: rejected for every voxel (vds.cu:1134-1137) -> 0;
+  // d > 0: d + truncation(d); anything else (negative, NaN): not provably skippable -> FLT_MAX
+  const bool rejected = (d == 0.f) || (d > c.max_int_dist);
+  return rejected ? 0.f : (d > 0.f ? d + get_truncation(d, m.trunc, m.trunc_scale) : kFltMax);
+}
+// Returns this lane's largest d + truncation(d) over the valid pixels it staged (0 if none): k_back's early-out.
+// Depths are > 0, so the float maximum is also the maximum of the raw bits.
+__device__ __forceinline__ float tile_fill(const Cam& c, const Map& m, const Fast& f, const int4 bb, const int lane, uint2* tile) {
   const int npx = bb.z * bb.w;
-  if (npx <= 0) return;
+  float reach = 0.f;
+  if (npx <= 0) return reach;
   const float inv_w = 1.0f / (float) bb.z;
-  for (int p = lane; p < npx; p += 64) {
-    const int r = (int) (((float) p + 0.5f) * inv_w);  // p / w for p < 2^10 (exact: slack 0.5 / w >> fp32 error)
-    const int cc = p - r * bb.z;
-    const u32 g = (u32) (__mul24(bb.y + r, c.cols) + bb.x + cc);
-    tile[p] = make_uint2(__float_as_uint(f.depth_clean[g]), f.rgbx[g]);
+#pragma unroll 1
+  for (int p0 = lane; p0 < npx; p0 += 256) {  // 4 pixels per lane and round: all 8 gathers in flight before the first wait
+    float dv[4];
+    u32 cv[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int p = min(p0 + 64 * j, npx - 1);  // lanes past the end re-read the last pixel (same cache line, no branch)
+      const int r = (int) (((float) p + 0.5f) * inv_w);  // p / w for p < 2^10 (exact: slack 0.5 / w >> fp32 error)
+      const int cc = p - r * bb.z;
+      const u32 g = (u32) (__mul24(bb.y + r, c.cols) + bb.x + cc);
+      dv[j] = f.depth_clean[g];
+      cv[j] = f.rgbx[g];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int p = p0 + 64 * j;
+      const float d = dv[j];
+      if (p < npx) tile[p] = make_uint2(__float_as_uint(d), cv[j]);
+      reach = __uint_as_float(umax_(__float_as_uint(reach), __float_as_uint(pixel_reach(c, m, d))));
+    }
   }
+  return reach;
 }
 
 // branch-free lookups: all NB x 4 ds_read_b64 are issued back to back; pixels outside the footprint (or blocks
 // without a tile) take ONE wave-uniform fallback branch with direct gathers.
 template <int NB>
-__device__ __forceinline__ void tile_lookup(const Fast& f, const int4 bb, const uint2* tile, const Proj4 (&P)[NB],
+__device__ __forceinline__ void tile_lookup(const Fast& f, const int cols, const int4 bb, const uint2* tile, const Proj4 (&P)[NB],
                                             float (&d)[NB][4], u32 (&cpx)[NB][4]) {
   u32 miss = 0;
   u32 li[NB][4];
@@ -482,8 +532,9 @@ __device__ __forceinline__ void tile_lookup(const Fast& f, const int4 bb, const 
 #pragma unroll
       for (int k = 0; k < 4; k++)
         if ((miss >> (b * 4 + k)) & 1u) {
-          d[b][k] = f.depth_clean[P[b].pix[k]];
-          cpx[b][k] = f.rgbx[P[b].pix[k]];
+          const u32 pix = (u32) (__mul24(P[b].row[k], cols) + P[b].col[k]);  // miss implies the voxel is in the image
+          d[b][k] = f.depth_clean[pix];
+          cpx[b][k] = f.rgbx[pix];
         }
   }
 }
@@ -531,13 +582,13 @@ __global__ __launch_bounds__(256) void k_fused(const Cam c, const Map m, const T
       // cycle in the texture addresser — measured as half of this kernel's time)
       const int4 bb = f.bbox[NB == 2 ? e : (e >> 1)];
       uint2* tile = &s_tile[(threadIdx.x >> 6) * kTileMaxPx];
-      tile_fill(c, f, bb, lane, tile);
+      tile_fill(c, m, f, bb, lane, tile);
 #pragma unroll
       for (int b = 0; b < NB; b++) P[b] = project4(c, m, ent, lane + 64 * (b + half));
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      tile_lookup<NB>(f, bb, tile, P, d, cpx);
+      tile_lookup<NB>(f, c.cols, bb, tile, P, d, cpx);
       __builtin_amdgcn_wave_barrier();  // the tile is rewritten by this wave's next item
     }
     float mn = kFltMax;
@@ -626,7 +677,7 @@ __global__ __launch_bounds__(256) void k_fused_pipe(const Cam c, const Map m, co
     const int en = e + nw;
     const bool more = en < nitems;
     // (1) pixel tile of the current item
-    tile_fill(c, f, bb, lane, tile);
+    tile_fill(c, m, f, bb, lane, tile);
     // (2) descriptor of the next item (tiny loads, consumed after the blend)
     int4 ent_n = ent, bb_n = bb;
     if (more) {
@@ -642,7 +693,7 @@ __global__ __launch_bounds__(256) void k_fused_pipe(const Cam c, const Map m, co
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    tile_lookup<NB>(f, bb, tile, P, d, cpx);
+    tile_lookup<NB>(f, c.cols, bb, tile, P, d, cpx);
     __builtin_amdgcn_wave_barrier();
     // (4) voxel planes of the next item: in flight during the blend + stores below
     float4 Sn[NB];
@@ -730,7 +781,7 @@ __global__ __launch_bounds__(256) void k_count_updates(const Cam c, const Map m,
       const Proj4 P = project4(c, m, ent, lane + 64 * b);
       float d[4];
 #pragma unroll
-      for (int k = 0; k < 4; k++) d[k] = f.depth_clean[P.pix[k]];
+      for (int k = 0; k < 4; k++) d[k] = f.depth_clean[((P.mask >> k) & 1u) ? (u32) (__mul24(P.row[k], c.cols) + P.col[k]) : 0u];
       cnt += __popc(update_mask4(c, m, P, d));
     }
   }

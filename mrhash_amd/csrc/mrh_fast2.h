@@ -30,6 +30,7 @@ struct Lists {
   int4* vis;        // = Tab::compact (front)
   int4* bbox;       // pixel footprint per visible entry
   int4* cfree;      // culled blocks to free this frame {x, y, z, H}
+  float* zmin;      // per visible entry: smallest camera-frame z of the block's corners (= of all its voxels)
   u32 cap;
 };
 
@@ -84,7 +85,7 @@ __device__ __forceinline__ void append_classified(const Tab& t, const Lists& L, 
     if (is_vis) {
       const int idx = base + __popcll(bv & lanemask_lt());
       L.vis[idx] = ent;
-      L.bbox[idx] = bb;
+      L.bbox[idx] = bb;  // {0,0,0,0}: k_back derives footprint and zmin itself
     }
   }
   if (bk && (int) lane_id() == __ffsll((long long) bk) - 1) atomicAdd(&t.ctr[cs + 1], __popcll(bk));
@@ -110,12 +111,14 @@ __global__ __launch_bounds__(256) void k_front(const Cam c, const Map m, const T
   const int cs = CTR_SET0 + 4 * parity;
 
   const int n_sweep = (int) gridDim.x - n_tiles;  // the sweep workgroups come FIRST in the grid so that they start first
+  MRH_TSF(0);
   if ((int) blockIdx.x >= n_sweep) {
     const int tile_id = (int) blockIdx.x - n_sweep;
     // ------------------------------------------------------------------ allocation for one pixel tile
     for (int i = tid; i < kRayCap; i += NT) set[i] = kKeyEmpty;
     if (tid == 0) { s_count = 0; s_inserted = 0; }
     __syncthreads();
+    MRH_TSF(1);
     const int ty = tile_id / tiles_x, tx = tile_id - ty * tiles_x;
     const int row = ty * kRayTile + (tid >> 4), col = tx * kRayTile + (tid & 15);
     if (row < c.rows && col < c.cols) {
@@ -158,7 +161,9 @@ __global__ __launch_bounds__(256) void k_front(const Cam c, const Map m, const T
         if (PROFILE) atomicAdd(&t.prof[PROF_INSERTED], 1ull);
       });
     }
+    MRH_TSF(2);
     __syncthreads();
+    MRH_TSF(3);
     const int n = (int) s_count;
     u32 my_inserted = 0;
 #pragma unroll 1
@@ -209,6 +214,10 @@ __global__ __launch_bounds__(256) void k_front(const Cam c, const Map m, const T
         append_classified(t, L, cs, cls, false, ent, bb);
       }
     }
+    MRH_TSF(4);
+#ifdef MRH_TRACE
+    if (tid == 0) f.trace[(kTraceFront + blockIdx.x) * 8 + 7] = (u64) n;
+#endif
     if (PROFILE) {
       if (my_inserted) atomicAdd(&s_inserted, my_inserted);
       __syncthreads();
@@ -239,7 +248,12 @@ __global__ __launch_bounds__(256) void k_front(const Cam c, const Map m, const T
       s_bf = s_nfree ? atomicAdd(&t.ctr[cs + 2], s_nfree) : 0;
     }
     __syncthreads();
-    for (int i = tid; i < s_nvis; i += NT) { L.vis[s_bv + i] = st_vis[2 * i]; L.bbox[s_bv + i] = st_vis[2 * i + 1]; }
+    for (int i = tid; i < s_nvis; i += NT) {
+      const int4 pk = st_vis[2 * i + 1];  // {col0, row0, w | h << 16, bits(zmin)}
+      L.vis[s_bv + i] = st_vis[2 * i];
+      L.bbox[s_bv + i] = make_int4(pk.x, pk.y, pk.z & 0xFFFF, (int) ((u32) pk.z >> 16));
+      L.zmin[s_bv + i] = __int_as_float(pk.w);
+    }
     for (int i = tid; i < s_nfree; i += NT) L.cfree[s_bf + i] = st_free[i];
     __syncthreads();
     if (tid == 0) { s_nvis = 0; s_nfree = 0; }
@@ -293,7 +307,7 @@ __global__ __launch_bounds__(256) void k_front(const Cam c, const Map m, const T
           c0 = c0 < 0 ? 0 : c0; r0 = r0 < 0 ? 0 : r0;
           c1 = c1 > c.cols - 1 ? c.cols - 1 : c1; r1 = r1 > c.rows - 1 ? c.rows - 1 : r1;
           const int bw = c1 - c0 + 1, bh = r1 - r0 + 1;
-          if (bw > 0 && bh > 0 && bw * bh <= kTileMaxPx) bb = make_int4(c0, r0, bw, bh);
+          if (bw > 0 && bh > 0 && bw * bh <= kTileMaxPx) bb = make_int4(c0, r0, bw | (bh << 16), __float_as_int(zmin));
         }
         const int k2 = atomicAdd(&s_nvis, 1);
         st_vis[2 * k2] = e;
@@ -313,12 +327,16 @@ __global__ __launch_bounds__(256) void k_front(const Cam c, const Map m, const T
   }
   flush();
   if (tid == 0 && s_nkeep) atomicAdd(&t.ctr[cs + 1], s_nkeep);
+  MRH_TSF(4);
+#ifdef MRH_TRACE
+  if (tid == 0) f.trace[(kTraceFront + blockIdx.x) * 8 + 7] = (u64) (hi - lo) | (1ull << 63);
+#endif
 }
 
 // pixel footprint of a block computed by the wave that is about to integrate it (lanes 0..7 take one corner each):
 // used for blocks inserted this frame, which k_front lists without a footprint.  Returns {0,0,0,0} when a corner
 // is closer than 5 cm or the footprint exceeds the tile (the lookups then fall back to direct gathers).
-__device__ __forceinline__ int4 wave_bbox(const Cam& c, const float vs, const int4 ent, const int lane) {
+__device__ __forceinline__ int4 wave_bbox(const Cam& c, const float vs, const int4 ent, const int lane, float& zmin_out) {
   const int corner = lane & 7;
   const i3 v = mki3(ent.x * kBlockSide + ((corner & 4) ? 7 : 0), ent.y * kBlockSide + ((corner & 2) ? 7 : 0), ent.z * kBlockSide + ((corner & 1) ? 7 : 0));
   const f3 pc = se3_apply(c.Ri, c.ti, voxel_to_world(vs, v));
@@ -340,6 +358,7 @@ __device__ __forceinline__ int4 wave_bbox(const Cam& c, const float vs, const in
     const int bw = c1 - c0 + 1, bh = r1 - r0 + 1;
     if (bw > 0 && bh > 0 && bw * bh <= kTileMaxPx) bb = make_int4(c0, r0, bw, bh);
   }
+  zmin_out = __shfl(zmin, 0);
   return make_int4(__shfl(bb.x, 0), __shfl(bb.y, 0), __shfl(bb.z, 0), __shfl(bb.w, 0));
 }
 
@@ -365,8 +384,10 @@ __global__ __launch_bounds__(256) void k_back(const Cam c, const Map m, const Ta
   const float r_half_vs = rcp_refined(m.vs / 2);
   uint2* tile = &s_tile[(threadIdx.x >> 6) * kTileMaxPx];
   for (int e = gw; e < nvis; e += nw) {
+    MRH_TS(0);
     const int4 ent = L.vis[e];
     int4 bb = L.bbox[e];
+    float zmin = L.zmin[e];
     const u32 H = (u32) ent.w;
     float4* ps = (float4*) (t.pool + (size_t) H * kFineBytes);
     float4* pq = ps + 128;
@@ -375,20 +396,40 @@ __global__ __launch_bounds__(256) void k_back(const Cam c, const Map m, const Ta
     uint4 W[2];
 #pragma unroll
     for (int b = 0; b < 2; b++) { S[b] = ps[lane + 64 * b]; W[b] = pw[lane + 64 * b]; }
-    if (bb.z == 0) bb = wave_bbox(c, m.vs, ent, lane);  // listed without a footprint (inserted this frame)
+    if (bb.z == 0) bb = wave_bbox(c, m.vs, ent, lane, zmin);  // listed without a footprint (inserted this frame)
     Proj4 P[2];
     float d[2][4];
     u32 cpx[2][4];
-    tile_fill(c, f, bb, lane, tile);
+    MRH_TS(1);
+    const float reach = tile_fill(c, m, f, bb, lane, tile);
+    // Early out (exact): camera-frame z is monotone in each voxel coordinate under fp32 rounding, so every voxel of
+    // the block has pc.z >= zmin (the smallest corner value); every in-image voxel projects into the footprint
+    // (convexity, +-1 px slack).  If d + trunc(d) + 1e-4 <= zmin for every valid footprint pixel, then
+    // fl(d - pc.z) <= -trunc(d) for every voxel (1e-4 >> the rounding of the two sums), i.e. integrateDepthMapKernel
+    // (vds.cu:1134-1145) updates nothing: the block, and therefore its stored summary, stay as they are.
+    const bool skip = bb.z != 0 && __uint_as_float(wave_max_u32(__float_as_uint(reach))) + 1e-4f <= zmin;  // wave-uniform
+    float mn;
+    u32 mx;
+#ifdef MRH_TRACE
+    u32 trace_upd = 0;
+#endif
+    if (skip) {
+      const uint2 sm = f.summary[H];
+      mn = __uint_as_float(sm.x);
+      mx = sm.y;
+    } else {
+    MRH_TS(2);
 #pragma unroll
     for (int b = 0; b < 2; b++) P[b] = project4(c, m, ent, lane + 64 * b);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    tile_lookup<2>(f, bb, tile, P, d, cpx);
+    MRH_TS(3);
+    tile_lookup<2>(f, c.cols, bb, tile, P, d, cpx);
     __builtin_amdgcn_wave_barrier();
-    float mn = kFltMax;
-    u32 mx = 0;
+    MRH_TS(4);
+    u32 mnb = 0x7F7FFFFFu;  // bits of min |sdf| over weighted voxels: |x| >= 0, so unsigned order == float order, and
+    mx = 0;                 // NaN / inf patterns sort above FLT_MAX exactly as fminf ignores them
 #pragma unroll
     for (int b = 0; b < 2; b++) {
       const int q = lane + 64 * b;
@@ -396,6 +437,9 @@ __global__ __launch_bounds__(256) void k_back(const Cam c, const Map m, const Ta
       u32 w[4] = {W[b].x, W[b].y, W[b].z, W[b].w};
       float ss[4] = {0.f, 0.f, 0.f, 0.f};
       const u32 mask = update_mask4(c, m, P[b], d[b]);
+#ifdef MRH_TRACE
+      trace_upd += __popc(mask);
+#endif
       blend4(m, P[b], mask, d[b], cpx[b], r_half_vs, s, w, ss);
       if (mask) {
         ps[q] = make_float4(s[0], s[1], s[2], s[3]);
@@ -412,20 +456,25 @@ __global__ __launch_bounds__(256) void k_back(const Cam c, const Map m, const Ta
 #pragma unroll
       for (int k = 0; k < 4; k++) {
         const u32 wk = w[k] >> 24;
-        if (wk != 0) mn = fminf(mn, fabsf(s[k]));
-        mx = wk > mx ? wk : mx;
+        const u32 ab = __float_as_uint(s[k]) & 0x7FFFFFFFu;
+        mnb = umin_(mnb, wk != 0 ? ab : 0xFFFFFFFFu);
+        mx = umax_(mx, wk);
       }
     }
-    for (int off = 32; off > 0; off >>= 1) {
-      mn = fminf(mn, __shfl_xor(mn, off));
-      const u32 o = __shfl_xor(mx, off);
-      mx = o > mx ? o : mx;
-    }
+    mn = __uint_as_float(wave_min_u32(mnb));
+    mx = wave_max_u32(mx);
+    MRH_TS(5);
     if (lane == 0) f.summary[H] = make_uint2(__float_as_uint(mn), mx);
+    }
     if (FREE && (mn >= trunc_threshold || mx == 0)) {
       wave_free_block(t, ent, lane);
       if (PROFILE && lane == 0) atomicAdd(&t.prof[PROF_FREED], 1ull);
     }
+    MRH_TS(6);
+#ifdef MRH_TRACE
+    for (int off = 32; off > 0; off >>= 1) trace_upd += __shfl_xor(trace_upd, off);
+    if (lane == 0) { u32 hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); f.trace[(size_t) e * 8 + 7] = hw | ((u64) trace_upd << 32) | ((u64) ((bb.z * bb.w) & 0x7FFF) << 48) | ((u64) (skip ? 1 : 0) << 63); }
+#endif
   }
   if (FREE) {
     for (int e = gw; e < ncfree; e += nw) {

@@ -1254,6 +1254,8 @@ int mrh_create(const mrh_params* p, mrh_ctx** out) {
   if (!p || !out) return fail(NULL, MRH_ERR_INVALID_ARG, "mrh_create: null argument");
   if (p->abi_version != MRH_ABI_VERSION) return fail(NULL, MRH_ERR_INVALID_ARG, "mrh_create: abi_version mismatch");
   if (!(p->virtual_voxel_size > 0.f)) return fail(NULL, MRH_ERR_INVALID_ARG, "mrh_create: virtual_voxel_size must be > 0");
+  if (!(p->sdf_truncation >= 0.f) || !(p->sdf_truncation_scale >= 0.f))
+    return fail(NULL, MRH_ERR_INVALID_ARG, "mrh_create: sdf_truncation and sdf_truncation_scale must be >= 0");
   mrh_ctx* c = (mrh_ctx*) calloc(1, sizeof(mrh_ctx));
   if (!c) return fail(NULL, MRH_ERR_DEVICE, "mrh_create: out of host memory");
   c->p = *p;
