@@ -368,6 +368,26 @@ __device__ __forceinline__ int hash_find(const Tab& t, u64 key) {
   return -1;
 }
 
+// lookup that also remembers where an insert of this key would land: `claim` = first TOMB on the probe path, else the
+// EMPTY slot that ended it (-1: path exhausted), `claim_val` = what that slot held.  Feeds hash_insert_at.
+__device__ __forceinline__ int hash_find_claim(const Tab& t, u64 key, int& claim, u64& claim_val) {
+  u32 s = hash_key(key) & t.slot_mask;
+  claim = -1;
+  claim_val = kKeyTomb;
+  for (u32 i = 0; i < t.max_probe; i++) {
+    const u64 k = t.keys[s];
+    if (k == key) return (int) s;
+    if (k == kKeyEmpty) {
+      if (claim < 0) { claim = (int) s; claim_val = kKeyEmpty; }
+      return -1;
+    }
+    if (k == kKeyTomb && claim < 0) claim = (int) s;
+    s = (s + 1) & t.slot_mask;
+  }
+  claim = -1;  // no EMPTY within max_probe: absence is not established, use the general protocol
+  return -1;
+}
+
 // concurrent insert.  Returns slot >= 0 if THIS thread inserted the key (it must then publish vals[slot]),
 // -1 if the key is already present (possibly inserted concurrently by another thread), -2 on overflow.
 // Lock-free: a slot only ever goes EMPTY/TOMB -> key during an insert kernel, every thread holding the same
@@ -395,6 +415,21 @@ __device__ __forceinline__ int hash_insert(const Tab& t, u64 key) {
     }
   }
   return -2;
+}
+
+// Insert of a key that hash_find_claim just reported absent: ONE CAS on the remembered slot instead of two more walks
+// of the probe path (each step of which is a dependent memory round trip on the inserting workgroup's critical path).
+// Why this is hash_insert's protocol: the walk established "absent before the first EMPTY" (phase A).  Slots before
+// `claim` held other keys at that time, and an occupied slot stays occupied for the rest of the launch, so neither
+// this key nor a claimable slot can appear before `claim` later: `claim` is still the first candidate of phase B, for
+// every thread holding this key.  If the CAS loses to another key, the general protocol continues.
+__device__ __forceinline__ int hash_insert_at(const Tab& t, u64 key, int claim, u64 claim_val) {
+  if (claim >= 0) {
+    const u64 old = atomicCAS(&t.keys[claim], claim_val, key);
+    if (old == claim_val) return claim;
+    if (old == key) return -1;
+  }
+  return hash_insert(t, key);
 }
 
 }  // namespace mrh

@@ -502,6 +502,63 @@ __device__ __forceinline__ float tile_fill(const Cam& c, const Map& m, const Fas
   return reach;
 }
 
+// The same fill split in two so that a wave can do memory-independent work (the projections) between issuing the
+// gathers of the first 256 footprint pixels and parking them in LDS; footprints > 256 px finish through a second round.
+struct TileRegs {
+  float dv[4];
+  u32 cv[4];
+};
+__device__ __forceinline__ void tile_issue(const Cam& c, const Fast& f, const int4 bb, const int lane, TileRegs& tr) {
+  const int npx = bb.z * bb.w;
+  if (npx <= 0) return;
+  const float inv_w = 1.0f / (float) bb.z;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int p = min(lane + 64 * j, npx - 1);
+    const int r = (int) (((float) p + 0.5f) * inv_w);
+    const int cc = p - r * bb.z;
+    const u32 g = (u32) (__mul24(bb.y + r, c.cols) + bb.x + cc);
+    tr.dv[j] = f.depth_clean[g];
+    tr.cv[j] = f.rgbx[g];
+  }
+}
+__device__ __forceinline__ float tile_commit(const Cam& c, const Map& m, const Fast& f, const int4 bb, const int lane, uint2* tile,
+                                             const TileRegs& tr) {
+  const int npx = bb.z * bb.w;
+  float reach = 0.f;
+  if (npx <= 0) return reach;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int p = lane + 64 * j;
+    if (p < npx) tile[p] = make_uint2(__float_as_uint(tr.dv[j]), tr.cv[j]);
+    reach = __uint_as_float(umax_(__float_as_uint(reach), __float_as_uint(pixel_reach(c, m, tr.dv[j]))));
+  }
+  if (npx > 256) {
+    const float inv_w = 1.0f / (float) bb.z;
+#pragma unroll 1
+    for (int p0 = 256 + lane; p0 < npx; p0 += 128) {
+      float dv[2];
+      u32 cv[2];
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        const int p = min(p0 + 64 * j, npx - 1);
+        const int r = (int) (((float) p + 0.5f) * inv_w);
+        const int cc = p - r * bb.z;
+        const u32 g = (u32) (__mul24(bb.y + r, c.cols) + bb.x + cc);
+        dv[j] = f.depth_clean[g];
+        cv[j] = f.rgbx[g];
+      }
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        const int p = p0 + 64 * j;
+        if (p < npx) tile[p] = make_uint2(__float_as_uint(dv[j]), cv[j]);
+        reach = __uint_as_float(umax_(__float_as_uint(reach), __float_as_uint(pixel_reach(c, m, dv[j]))));
+      }
+    }
+  }
+  return reach;
+}
+
 // branch-free lookups: all NB x 4 ds_read_b64 are issued back to back; pixels outside the footprint (or blocks
 // without a tile) take ONE wave-uniform fallback branch with direct gathers.
 template <int NB>

@@ -98,165 +98,179 @@ __device__ __forceinline__ void append_classified(const Tab& t, const Lists& L, 
   }
 }
 
-template <bool PROFILE>
-__global__ __launch_bounds__(256) void k_front(const Cam c, const Map m, const Tab t, const Fast f, const Lists L,
-                                               const float* __restrict__ depth, const uint8_t* __restrict__ rgb, const int tiles_x,
-                                               const int n_tiles, const u32 stamp, const int parity, const int gc_on,
-                                               const float trunc_threshold) {
-  constexpr int NT = 256;
-  __shared__ u64 set[kRayCap];
-  __shared__ u64 list[kRayCap];
-  __shared__ u32 s_count, s_inserted;
-  const int tid = threadIdx.x;
-  const int cs = CTR_SET0 + 4 * parity;
+// LDS of the allocation / sweep roles
+struct FrontShared {
+  u64 set[kRayCap];
+  u64 list[kRayCap];
+  u32 count, inserted;
+  int nvis, nfree, nkeep, bv, bf;
+};
 
-  const int n_sweep = (int) gridDim.x - n_tiles;  // the sweep workgroups come FIRST in the grid so that they start first
-  MRH_TSF(0);
-  if ((int) blockIdx.x >= n_sweep) {
-    const int tile_id = (int) blockIdx.x - n_sweep;
-    // ------------------------------------------------------------------ allocation for one pixel tile
-    for (int i = tid; i < kRayCap; i += NT) set[i] = kKeyEmpty;
-    if (tid == 0) { s_count = 0; s_inserted = 0; }
-    __syncthreads();
-    MRH_TSF(1);
-    const int ty = tile_id / tiles_x, tx = tile_id - ty * tiles_x;
-    const int row = ty * kRayTile + (tid >> 4), col = tx * kRayTile + (tid & 15);
-    if (row < c.rows && col < c.cols) {
-      const size_t pix = (size_t) row * c.cols + col;
-      float d = depth[pix];
-      if (d <= c.min_depth || d > c.max_depth) d = 0.f;  // camera.cu:13-18
-      f.depth_clean[pix] = d;
-      const uint8_t* px = rgb + pix * 3;
-      f.rgbx[pix] = (u32) px[0] | ((u32) px[1] << 8) | ((u32) px[2] << 16);
-      walk_ray(c, m, t, row, col, d, [&](const i3 cur, const u64 key) {
-        u32 s = (u32) __mul24(cur.z, 5851) + (u32) __mul24(cur.y, 73) + (u32) cur.x;
-        s = (s ^ (s >> 7)) & (kRayCap - 1);
-#pragma unroll 1
-        for (int p = 0; p < kSetProbe; p++) {
-          const u64 old = atomicCAS(&set[s], kKeyEmpty, key);
-          if (old == kKeyEmpty) { list[atomicAdd(&s_count, 1u)] = key; return; }
-          if (old == key) return;
-          s = (s + 1) & (kRayCap - 1);
-        }
-        // LDS set saturated (far, sparse rays): insert directly; the new block is listed below like any other
-        if (!block_in_frustum_approx(c, m.vs, cur)) return;
-        const int slot = hash_insert(t, key);
-        if (slot == -2) atomicOr((u32*) &t.ctr[CTR_ERROR], ERR_TABLE);
-        if (slot < 0) return;
-        const int idx = atomicSub(&t.ctr[CTR_HEAP_FINE], 1);
-        if (idx < 0) {
-          atomicAdd(&t.ctr[CTR_HEAP_FINE], 1);
-          atomicExch(&t.keys[slot], kKeyTomb);
-          atomicOr((u32*) &t.ctr[CTR_ERROR], ERR_POOL);
-          return;
-        }
-        const u32 H = t.heap_fine[idx];
-        t.vals[slot] = H;
-        t.desc_fine[H] = make_int4(cur.x, cur.y, cur.z, desc_w(stamp));
-        f.summary[H] = make_uint2(0x7F7FFFFFu, 0u);
-        if ((int) H >= __hip_atomic_load(&t.ctr[CTR_HWM_FINE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&t.ctr[CTR_HWM_FINE], (int) H + 1);
-        const int li = atomicAdd(&t.ctr[cs + 0], 1);  // unclassified, no footprint (see below)
-        L.vis[li] = make_int4(cur.x, cur.y, cur.z, (int) H);
-        L.bbox[li] = make_int4(0, 0, 0, 0);
-        if (PROFILE) atomicAdd(&t.prof[PROF_INSERTED], 1ull);
-      });
-    }
-    MRH_TSF(2);
-    __syncthreads();
-    MRH_TSF(3);
-    const int n = (int) s_count;
-    u32 my_inserted = 0;
-#pragma unroll 1
-    for (int base = 0; base < n; base += NT) {
-      const int i = base + tid;
-      const bool active = i < n;
-      const u64 key = active ? list[i] : kKeyEmpty;
-      const i3 b = active ? unpack_key(key) : mki3(0, 0, 0);
-      bool won = false;
-      int slot = -1;
-      // probe first: ~95 % of a tile's blocks already exist, and for those neither the 8-corner frustum test nor
-      // the insert protocol is needed
-      if (active && hash_find(t, key) < 0 && block_in_frustum_approx(c, m.vs, b)) {
-        slot = hash_insert(t, key);
-        if (slot == -2) atomicOr((u32*) &t.ctr[CTR_ERROR], ERR_TABLE);
-        won = slot >= 0;
-      }
-      // wave-aggregated pop of the fine free list (alloc_commit2 with a stamped descriptor)
-      const u64 ballot = __ballot(won);
-      int cls = 0;
-      int4 ent = make_int4(0, 0, 0, 0), bb = make_int4(0, 0, 0, 0);
-      if (ballot) {
-        const int leader = __ffsll((long long) ballot) - 1;
-        int hb = 0;
-        if ((int) lane_id() == leader) hb = atomicSub(&t.ctr[CTR_HEAP_FINE], __popcll(ballot));
-        hb = __shfl(hb, leader);
-        if (won) {
-          const int idx = hb - __popcll(ballot & lanemask_lt());
-          if (idx < 0) {
-            atomicAdd(&t.ctr[CTR_HEAP_FINE], 1);
-            atomicExch(&t.keys[slot], kKeyTomb);
-            atomicOr((u32*) &t.ctr[CTR_ERROR], ERR_POOL);
-          } else {
-            const u32 H = t.heap_fine[idx];
-            t.vals[slot] = H;
-            t.desc_fine[H] = make_int4(b.x, b.y, b.z, desc_w(stamp));
-            f.summary[H] = make_uint2(0x7F7FFFFFu, 0u);
-            if ((int) H >= __hip_atomic_load(&t.ctr[CTR_HWM_FINE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&t.ctr[CTR_HWM_FINE], (int) H + 1);
-            // a new block goes on the visible list unclassified and without a pixel footprint (k_back then gathers
-            // its pixels directly): a few hundred blocks per frame, not worth 8 serial corner projections on the
-            // allocation workgroup's critical path.  If no voxel of it lands in the image it stays at weight 0 and
-            // k_back collects it, exactly what GC does with it in the reference.
-            cls = 1;
-            ent = make_int4(b.x, b.y, b.z, (int) H);
-            if (PROFILE) my_inserted++;
-          }
-        }
-        append_classified(t, L, cs, cls, false, ent, bb);
-      }
-    }
-    MRH_TSF(4);
-#ifdef MRH_TRACE
-    if (tid == 0) f.trace[(kTraceFront + blockIdx.x) * 8 + 7] = (u64) n;
-#endif
-    if (PROFILE) {
-      if (my_inserted) atomicAdd(&s_inserted, my_inserted);
-      __syncthreads();
-      if (tid == 0 && s_inserted) atomicAdd(&t.prof[PROF_INSERTED], (u64) s_inserted);
-    }
-    return;
+// stamped pop + descriptor of a block this lane just won in the table; returns the block index or -1 (pool exhausted)
+__device__ __forceinline__ int commit_block(const Tab& t, const Fast& f, const int slot, const int heap_idx, const i3 b, const u32 stamp,
+                                            const int hwm_at_start) {
+  if (heap_idx < 0) {
+    atomicAdd(&t.ctr[CTR_HEAP_FINE], 1);
+    atomicExch(&t.keys[slot], kKeyTomb);
+    atomicOr((u32*) &t.ctr[CTR_ERROR], ERR_POOL);
+    return -1;
   }
+  const u32 H = t.heap_fine[heap_idx];
+  t.vals[slot] = H;
+  t.desc_fine[H] = make_int4(b.x, b.y, b.z, desc_w(stamp));
+  f.summary[H] = make_uint2(0x7F7FFFFFu, 0u);
+  // the high-water mark only grows: below its value at launch nothing is to do, above it the max is fire-and-forget
+  if ((int) H >= hwm_at_start) atomicMax(&t.ctr[CTR_HWM_FINE], (int) H + 1);
+  return (int) H;
+}
 
-  // -------------------------------------------------------------------- sweep of the pre-existing descriptors
-  // Same-address atomics retire at roughly one per 7-10 ns on this chip, so a sweep that appends per 32-block batch
-  // (~3 atomics x 1250 batches per frame) is bound by exactly that.  Each sweep workgroup therefore owns one
-  // contiguous chunk of descriptors, stages its results in LDS (aliasing the key set / list of the allocation half)
-  // and publishes them with three atomics per workgroup.
+// Allocation for one 16x16 pixel tile (allocBlocksKernel vds.cu:758-857 for these pixels).
+// Also writes the cleaned depth / packed colour of its pixels (calculateCloudKernel's validity rule, camera.cu:13-18).
+template <bool PROFILE>
+__device__ __forceinline__ void front_tile(const Cam& c, const Map& m, const Tab& t, const Fast& f, const Lists& L,
+                                           const float* __restrict__ depth, const uint8_t* __restrict__ rgb, const int tiles_x,
+                                           const int tile_id, const u32 stamp, const int cs, FrontShared& sh) {
+  constexpr int NT = 256;
+  const int tid = threadIdx.x;
+  const int hwm0 = t.ctr[CTR_HWM_FINE];  // scalar load, before any store of this launch
+  for (int i = tid; i < kRayCap; i += NT) sh.set[i] = kKeyEmpty;
+  if (tid == 0) { sh.count = 0; sh.inserted = 0; }
+  __syncthreads();
+  MRH_TSF(1);
+  // a new block is listed without a pixel footprint (k_back / k_post derive it): a few hundred blocks per frame, not
+  // worth 8 serial corner projections on the allocation workgroup's critical path.  If no voxel of it lands in the
+  // image it stays at weight 0 and is collected, exactly what GC does with it in the reference.
+  auto list_new = [&](const int4 ent) {  // single lane
+    const int li = atomicAdd(&t.ctr[cs + 0], 1);
+    L.vis[li] = ent;
+    L.bbox[li] = make_int4(0, 0, 0, 0);
+  };
+  const int ty = tile_id / tiles_x, tx = tile_id - ty * tiles_x;
+  const int row = ty * kRayTile + (tid >> 4), col = tx * kRayTile + (tid & 15);
+  if (row < c.rows && col < c.cols) {
+    const size_t pix = (size_t) row * c.cols + col;
+    float d = depth[pix];
+    if (d <= c.min_depth || d > c.max_depth) d = 0.f;  // camera.cu:13-18
+    f.depth_clean[pix] = d;
+    const uint8_t* px = rgb + pix * 3;
+    f.rgbx[pix] = (u32) px[0] | ((u32) px[1] << 8) | ((u32) px[2] << 16);
+    walk_ray(c, m, t, row, col, d, [&](const i3 cur, const u64 key) {
+      u32 s = (u32) __mul24(cur.z, 5851) + (u32) __mul24(cur.y, 73) + (u32) cur.x;
+      s = (s ^ (s >> 7)) & (kRayCap - 1);
+#pragma unroll 1
+      for (int p = 0; p < kSetProbe; p++) {
+        const u64 old = atomicCAS(&sh.set[s], kKeyEmpty, key);
+        if (old == kKeyEmpty) { sh.list[atomicAdd(&sh.count, 1u)] = key; return; }
+        if (old == key) return;
+        s = (s + 1) & (kRayCap - 1);
+      }
+      // LDS set saturated (far, sparse rays): insert directly
+      if (!block_in_frustum_approx(c, m.vs, cur)) return;
+      const int slot = hash_insert(t, key);
+      if (slot == -2) atomicOr((u32*) &t.ctr[CTR_ERROR], ERR_TABLE);
+      if (slot < 0) return;
+      const int H = commit_block(t, f, slot, atomicSub(&t.ctr[CTR_HEAP_FINE], 1), cur, stamp, hwm0);
+      if (H < 0) return;
+      list_new(make_int4(cur.x, cur.y, cur.z, H));
+      if (PROFILE) atomicAdd(&t.prof[PROF_INSERTED], 1ull);
+    });
+  }
+  MRH_TSF(2);
+  __syncthreads();
+  MRH_TSF(3);
+  const int n = (int) sh.count;
+  u32 my_inserted = 0;
+#pragma unroll 1
+  for (int base = 0; base < n; base += NT) {
+    const int i = base + tid;
+    const bool active = i < n;
+    const u64 key = active ? sh.list[i] : kKeyEmpty;
+    const i3 b = active ? unpack_key(key) : mki3(0, 0, 0);
+    bool won = false;
+    int slot = -1;
+    // probe first: ~95 % of a tile's blocks already exist, and for those neither the 8-corner frustum test nor
+    // the insert protocol is needed
+    int claim;
+    u64 claim_val;
+    if (active && hash_find_claim(t, key, claim, claim_val) < 0 && block_in_frustum_approx(c, m.vs, b)) {
+      slot = hash_insert_at(t, key, claim, claim_val);
+      if (slot == -2) atomicOr((u32*) &t.ctr[CTR_ERROR], ERR_TABLE);
+      won = slot >= 0;
+    }
+    // wave-aggregated pop of the fine free list and append to the list
+    const u64 ballot = __ballot(won);
+    if (ballot) {
+      const int leader = __ffsll((long long) ballot) - 1;
+      int hb = 0;
+      if ((int) lane_id() == leader) hb = atomicSub(&t.ctr[CTR_HEAP_FINE], __popcll(ballot));
+      hb = __shfl(hb, leader);
+      // the pop decides who got a block (index >= 0); the list append is then issued together with the read of the
+      // popped stack entries, so the two round trips overlap
+      const int hidx = hb - __popcll(ballot & lanemask_lt());
+      const u64 ok = __ballot(won && hidx >= 0);
+      int lb = 0;
+      if (ok && (int) lane_id() == __ffsll((long long) ok) - 1) lb = atomicAdd(&t.ctr[cs + 0], __popcll(ok));
+      int H = -1;
+      if (won) H = commit_block(t, f, slot, hidx, b, stamp, hwm0);
+      if (ok) {
+        const int lead2 = __ffsll((long long) ok) - 1;
+        lb = __shfl(lb, lead2);
+        if (H >= 0) {
+          const int idx = lb + __popcll(ok & lanemask_lt());
+          const int4 ent = make_int4(b.x, b.y, b.z, H);
+          L.vis[idx] = ent;
+          L.bbox[idx] = make_int4(0, 0, 0, 0);  // k_back derives footprint and zmin itself
+          if (PROFILE) my_inserted++;
+        }
+      }
+    }
+  }
+  MRH_TSF(4);
+#ifdef MRH_TRACE
+  if (tid == 0) f.trace[(kTraceFront + blockIdx.x) * 8 + 7] = (u64) n;
+#endif
+  if (PROFILE) {
+    if (my_inserted) atomicAdd(&sh.inserted, my_inserted);
+    __syncthreads();
+    if (tid == 0 && sh.inserted) atomicAdd(&t.prof[PROF_INSERTED], (u64) sh.inserted);
+  }
+}
+
+// Sweep of the block descriptors that existed before this frame, chunk `sw` of `n_sweep`
+// (flatAndReduceHashTableKernel vds.cu:406-434 + the exact-image cull).
+// Same-address atomics retire at roughly one per 7-10 ns on this chip, so a sweep that appends per 32-block batch
+// (~3 atomics x 1250 batches per frame) is bound by exactly that.  Each sweep workgroup therefore owns one
+// contiguous chunk of descriptors, stages its results in LDS (aliasing the key set / list of the allocation role)
+// and publishes them with three atomics per workgroup.
+__device__ __forceinline__ void front_sweep(const Cam& c, const Map& m, const Tab& t, const Fast& f, const Lists& L, const u32 stamp,
+                                            const int cs, const int gc_on, const float trunc_threshold, const int sw, const int n_sweep,
+                                            FrontShared& sh) {
+  constexpr int NT = 256;
+  const int tid = threadIdx.x;
   const int hwm = t.ctr[CTR_HWM_FINE];
-  const int sw = (int) blockIdx.x;
   const int chunk = (((hwm + n_sweep - 1) / n_sweep) + 63) & ~63;
   const int lo = sw * chunk, hi = min(hwm, lo + chunk);
-  int4* st_vis = (int4*) list;   // 256 x {entry, bbox}
-  int4* st_free = (int4*) set;   // 512 entries
+  int4* st_vis = (int4*) sh.list;   // 256 x {entry, bbox}
+  int4* st_free = (int4*) sh.set;   // 512 entries
   constexpr int kStVis = kRayCap * 8 / 32, kStFree = kRayCap * 8 / 16;
-  __shared__ int s_nvis, s_nfree, s_nkeep, s_bv, s_bf;
-  if (tid == 0) { s_nvis = 0; s_nfree = 0; s_nkeep = 0; }
+  if (tid == 0) { sh.nvis = 0; sh.nfree = 0; sh.nkeep = 0; }
   __syncthreads();
   auto flush = [&]() {  // all threads of the workgroup
     __syncthreads();
     if (tid == 0) {
-      s_bv = s_nvis ? atomicAdd(&t.ctr[cs + 0], s_nvis) : 0;
-      s_bf = s_nfree ? atomicAdd(&t.ctr[cs + 2], s_nfree) : 0;
+      sh.bv = sh.nvis ? atomicAdd(&t.ctr[cs + 0], sh.nvis) : 0;
+      sh.bf = sh.nfree ? atomicAdd(&t.ctr[cs + 2], sh.nfree) : 0;
     }
     __syncthreads();
-    for (int i = tid; i < s_nvis; i += NT) {
+    for (int i = tid; i < sh.nvis; i += NT) {
       const int4 pk = st_vis[2 * i + 1];  // {col0, row0, w | h << 16, bits(zmin)}
-      L.vis[s_bv + i] = st_vis[2 * i];
-      L.bbox[s_bv + i] = make_int4(pk.x, pk.y, pk.z & 0xFFFF, (int) ((u32) pk.z >> 16));
-      L.zmin[s_bv + i] = __int_as_float(pk.w);
+      L.vis[sh.bv + i] = st_vis[2 * i];
+      L.bbox[sh.bv + i] = make_int4(pk.x, pk.y, pk.z & 0xFFFF, (int) ((u32) pk.z >> 16));
+      L.zmin[sh.bv + i] = __int_as_float(pk.w);
     }
-    for (int i = tid; i < s_nfree; i += NT) L.cfree[s_bf + i] = st_free[i];
+    for (int i = tid; i < sh.nfree; i += NT) L.cfree[sh.bf + i] = st_free[i];
     __syncthreads();
-    if (tid == 0) { s_nvis = 0; s_nfree = 0; }
+    if (tid == 0) { sh.nvis = 0; sh.nfree = 0; }
     __syncthreads();
   };
   const int grp = tid >> 2;      // block within the 64-block batch
@@ -309,7 +323,7 @@ __global__ __launch_bounds__(256) void k_front(const Cam c, const Map m, const T
           const int bw = c1 - c0 + 1, bh = r1 - r0 + 1;
           if (bw > 0 && bh > 0 && bw * bh <= kTileMaxPx) bb = make_int4(c0, r0, bw | (bh << 16), __float_as_int(zmin));
         }
-        const int k2 = atomicAdd(&s_nvis, 1);
+        const int k2 = atomicAdd(&sh.nvis, 1);
         st_vis[2 * k2] = e;
         st_vis[2 * k2 + 1] = bb;
       } else {
@@ -317,20 +331,33 @@ __global__ __launch_bounds__(256) void k_front(const Cam c, const Map m, const T
         if (gc_on) {  // culled: untouched by this frame, so the stored summary already decides (vds.cu:1708-1711)
           collect = (__uint_as_float(sm.x) >= trunc_threshold) || (sm.y == 0u);
         }
-        if (collect) st_free[atomicAdd(&s_nfree, 1)] = e;
-        else atomicAdd(&s_nkeep, 1);
+        if (collect) st_free[atomicAdd(&sh.nfree, 1)] = e;
+        else atomicAdd(&sh.nkeep, 1);
       }
     }
     // the staging areas hold at least 4 / 8 more batches than one iteration can add: flush only when nearly full
     __syncthreads();
-    if (s_nvis > kStVis - 64 || s_nfree > kStFree - 64) flush();
+    if (sh.nvis > kStVis - 64 || sh.nfree > kStFree - 64) flush();
   }
   flush();
-  if (tid == 0 && s_nkeep) atomicAdd(&t.ctr[cs + 1], s_nkeep);
+  if (tid == 0 && sh.nkeep) atomicAdd(&t.ctr[cs + 1], sh.nkeep);
   MRH_TSF(4);
 #ifdef MRH_TRACE
   if (tid == 0) f.trace[(kTraceFront + blockIdx.x) * 8 + 7] = (u64) (hi - lo) | (1ull << 63);
 #endif
+}
+
+template <bool PROFILE>
+__global__ __launch_bounds__(256) void k_front(const Cam c, const Map m, const Tab t, const Fast f, const Lists L,
+                                               const float* __restrict__ depth, const uint8_t* __restrict__ rgb, const int tiles_x,
+                                               const int n_tiles, const u32 stamp, const int parity, const int gc_on,
+                                               const float trunc_threshold) {
+  __shared__ FrontShared sh;
+  const int cs = CTR_SET0 + 4 * parity;
+  const int n_sweep = (int) gridDim.x - n_tiles;  // the sweep workgroups come FIRST in the grid so that they start first
+  MRH_TSF(0);
+  if ((int) blockIdx.x >= n_sweep) front_tile<PROFILE>(c, m, t, f, L, depth, rgb, tiles_x, (int) blockIdx.x - n_sweep, stamp, cs, sh);
+  else front_sweep(c, m, t, f, L, stamp, cs, gc_on, trunc_threshold, (int) blockIdx.x, n_sweep, sh);
 }
 
 // pixel footprint of a block computed by the wave that is about to integrate it (lanes 0..7 take one corner each):
@@ -362,32 +389,37 @@ __device__ __forceinline__ int4 wave_bbox(const Cam& c, const float vs, const in
   return make_int4(__shfl(bb.x, 0), __shfl(bb.y, 0), __shfl(bb.z, 0), __shfl(bb.w, 0));
 }
 
-// K2: integrate + summary + GC of the visible list (k_fused's body), then the culled-free list; zeroes the other list set
+// A visible-list record through the scalar unit: the entry index is wave-uniform, the lists were written by an earlier
+// launch, and a scalar-cache hit returns in a fraction of a vector load's round trip — this load heads every wave's
+// dependency chain (entry -> voxel-plane addresses -> HBM).
+typedef int v4i_ __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void load_entry_scalar(const Lists& L, const int e, int4& ent, int4& bb, float& zmin) {
+  v4i_ a, b;
+  int z;
+  const u32 off16 = (u32) e * 16u, off4 = (u32) e * 4u;
+  asm volatile("s_load_dwordx4 %0, %3, %6\n\ts_load_dwordx4 %1, %4, %6\n\ts_load_dword %2, %5, %7\n\ts_waitcnt lgkmcnt(0)"
+               : "=&s"(a), "=&s"(b), "=&s"(z)
+               : "s"(L.vis), "s"(L.bbox), "s"(L.zmin), "s"(off16), "s"(off4)
+               : "memory");
+  ent = make_int4(a.x, a.y, a.z, a.w);
+  bb = make_int4(b.x, b.y, b.z, b.w);
+  zmin = __int_as_float(z);
+}
+
+// Integration of a list of blocks, one wave per block (integrateDepthMapKernel vds.cu:1095-1181 + GC summary + GC
+// decision, vds.cu:1674-1713); wave `gw` of `nw` takes entries gw, gw + nw, ...
+//   FREE  false: no GC here (starve frames decide after the weights changed); true: free on the spot (tombstone the
+//         key, push the free list, zero the 6 KiB)
 template <bool FREE, bool PROFILE>
-__global__ __launch_bounds__(256) void k_back(const Cam c, const Map m, const Tab t, const Fast f, const Lists L, const int parity,
-                                              const float trunc_threshold, const int stagger) {
-  extern __shared__ __attribute__((aligned(16))) uint2 s_tile[];
-  (void) stagger;  // (a delayed start of every other workgroup was measured: it only lengthens the launch)
-  const int cs = CTR_SET0 + 4 * parity;
-  const int nvis = t.ctr[cs + 0];
-  const int ncfree = FREE ? t.ctr[cs + 2] : 0;
-  const int lane = threadIdx.x & 63;
-  const int wpw = blockDim.x >> 6;
-  const int gw = blockIdx.x * wpw + (threadIdx.x >> 6);
-  const int nw = gridDim.x * wpw;
-  if (gw == 0 && lane < 4) t.ctr[CTR_SET0 + 4 * (parity ^ 1) + lane] = 0;  // next frame's k_front appends there
-  if (gw == 0 && lane == 0) {  // stats mirror for the host (M = visible + culled)
-    t.ctr[CTR_COMPACT] = nvis;
-    t.ctr[CTR_CULLED] = t.ctr[cs + 1] + t.ctr[cs + 2];
-    t.ctr[CTR_FREED_EARLY] = 0;
-  }
+__device__ __forceinline__ void back_range(const Cam& c, const Map& m, const Tab& t, const Fast& f, const Lists& L,
+                                           const float trunc_threshold, const int n, const int gw, const int nw, const int lane,
+                                           uint2* tile) {
   const float r_half_vs = rcp_refined(m.vs / 2);
-  uint2* tile = &s_tile[(threadIdx.x >> 6) * kTileMaxPx];
-  for (int e = gw; e < nvis; e += nw) {
+  for (int e = __builtin_amdgcn_readfirstlane(gw); e < n; e += nw) {
     MRH_TS(0);
-    const int4 ent = L.vis[e];
-    int4 bb = L.bbox[e];
-    float zmin = L.zmin[e];
+    int4 ent, bb;
+    float zmin;
+    load_entry_scalar(L, e, ent, bb, zmin);
     const u32 H = (u32) ent.w;
     float4* ps = (float4*) (t.pool + (size_t) H * kFineBytes);
     float4* pq = ps + 128;
@@ -401,7 +433,11 @@ __global__ __launch_bounds__(256) void k_back(const Cam c, const Map m, const Ta
     float d[2][4];
     u32 cpx[2][4];
     MRH_TS(1);
-    const float reach = tile_fill(c, m, f, bb, lane, tile);
+    TileRegs tr;
+    tile_issue(c, f, bb, lane, tr);  // footprint gathers in flight behind the voxel planes ...
+#pragma unroll
+    for (int b = 0; b < 2; b++) P[b] = project4(c, m, ent, lane + 64 * b);  // ... while the projections (entry-only) run
+    const float reach = tile_commit(c, m, f, bb, lane, tile, tr);
     // Early out (exact): camera-frame z is monotone in each voxel coordinate under fp32 rounding, so every voxel of
     // the block has pc.z >= zmin (the smallest corner value); every in-image voxel projects into the footprint
     // (convexity, +-1 px slack).  If d + trunc(d) + 1e-4 <= zmin for every valid footprint pixel, then
@@ -418,53 +454,51 @@ __global__ __launch_bounds__(256) void k_back(const Cam c, const Map m, const Ta
       mn = __uint_as_float(sm.x);
       mx = sm.y;
     } else {
-    MRH_TS(2);
+      MRH_TS(2);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      MRH_TS(3);
+      tile_lookup<2>(f, c.cols, bb, tile, P, d, cpx);
+      __builtin_amdgcn_wave_barrier();
+      MRH_TS(4);
+      u32 mnb = 0x7F7FFFFFu;  // bits of min |sdf| over weighted voxels: |x| >= 0, so unsigned order == float order, and
+      mx = 0;                 // NaN / inf patterns sort above FLT_MAX exactly as fminf ignores them
 #pragma unroll
-    for (int b = 0; b < 2; b++) P[b] = project4(c, m, ent, lane + 64 * b);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    MRH_TS(3);
-    tile_lookup<2>(f, c.cols, bb, tile, P, d, cpx);
-    __builtin_amdgcn_wave_barrier();
-    MRH_TS(4);
-    u32 mnb = 0x7F7FFFFFu;  // bits of min |sdf| over weighted voxels: |x| >= 0, so unsigned order == float order, and
-    mx = 0;                 // NaN / inf patterns sort above FLT_MAX exactly as fminf ignores them
-#pragma unroll
-    for (int b = 0; b < 2; b++) {
-      const int q = lane + 64 * b;
-      float s[4] = {S[b].x, S[b].y, S[b].z, S[b].w};
-      u32 w[4] = {W[b].x, W[b].y, W[b].z, W[b].w};
-      float ss[4] = {0.f, 0.f, 0.f, 0.f};
-      const u32 mask = update_mask4(c, m, P[b], d[b]);
+      for (int b = 0; b < 2; b++) {
+        const int q = lane + 64 * b;
+        float s[4] = {S[b].x, S[b].y, S[b].z, S[b].w};
+        u32 w[4] = {W[b].x, W[b].y, W[b].z, W[b].w};
+        float ss[4] = {0.f, 0.f, 0.f, 0.f};
+        const u32 mask = update_mask4(c, m, P[b], d[b]);
 #ifdef MRH_TRACE
-      trace_upd += __popc(mask);
+        trace_upd += __popc(mask);
 #endif
-      blend4(m, P[b], mask, d[b], cpx[b], r_half_vs, s, w, ss);
-      if (mask) {
-        ps[q] = make_float4(s[0], s[1], s[2], s[3]);
-        pw[q] = make_uint4(w[0], w[1], w[2], w[3]);
-        if (mask == 0xF) {
-          pq[q] = make_float4(ss[0], ss[1], ss[2], ss[3]);
-        } else {
-          float* pqs = (float*) (pq + q);
+        blend4(m, P[b], mask, d[b], cpx[b], r_half_vs, s, w, ss);
+        if (mask) {
+          ps[q] = make_float4(s[0], s[1], s[2], s[3]);
+          pw[q] = make_uint4(w[0], w[1], w[2], w[3]);
+          if (mask == 0xF) {
+            pq[q] = make_float4(ss[0], ss[1], ss[2], ss[3]);
+          } else {
+            float* pqs = (float*) (pq + q);
 #pragma unroll
-          for (int k = 0; k < 4; k++)
-            if (mask & (1u << k)) pqs[k] = ss[k];
+            for (int k = 0; k < 4; k++)
+              if (mask & (1u << k)) pqs[k] = ss[k];
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const u32 wk = w[k] >> 24;
+          const u32 ab = __float_as_uint(s[k]) & 0x7FFFFFFFu;
+          mnb = umin_(mnb, wk != 0 ? ab : 0xFFFFFFFFu);
+          mx = umax_(mx, wk);
         }
       }
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const u32 wk = w[k] >> 24;
-        const u32 ab = __float_as_uint(s[k]) & 0x7FFFFFFFu;
-        mnb = umin_(mnb, wk != 0 ? ab : 0xFFFFFFFFu);
-        mx = umax_(mx, wk);
-      }
-    }
-    mn = __uint_as_float(wave_min_u32(mnb));
-    mx = wave_max_u32(mx);
-    MRH_TS(5);
-    if (lane == 0) f.summary[H] = make_uint2(__float_as_uint(mn), mx);
+      mn = __uint_as_float(wave_min_u32(mnb));
+      mx = wave_max_u32(mx);
+      MRH_TS(5);
+      if (lane == 0) f.summary[H] = make_uint2(__float_as_uint(mn), mx);
     }
     if (FREE && (mn >= trunc_threshold || mx == 0)) {
       wave_free_block(t, ent, lane);
@@ -476,12 +510,47 @@ __global__ __launch_bounds__(256) void k_back(const Cam c, const Map m, const Ta
     if (lane == 0) { u32 hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); f.trace[(size_t) e * 8 + 7] = hw | ((u64) trace_upd << 32) | ((u64) ((bb.z * bb.w) & 0x7FFF) << 48) | ((u64) (skip ? 1 : 0) << 63); }
 #endif
   }
-  if (FREE) {
-    for (int e = gw; e < ncfree; e += nw) {
-      wave_free_block(t, L.cfree[e], lane);
-      if (PROFILE && lane == 0) atomicAdd(&t.prof[PROF_FREED], 1ull);
-    }
+}
+
+// frees entries [0, n) of the culled-free (+ deferred-free) list, one wave per block
+template <bool PROFILE>
+__device__ __forceinline__ void free_range(const Tab& t, const Lists& L, const int n, const int gw, const int nw, const int lane) {
+  for (int e = gw; e < n; e += nw) {
+    wave_free_block(t, L.cfree[e], lane);
+    if (PROFILE && lane == 0) atomicAdd(&t.prof[PROF_FREED], 1ull);
   }
+}
+
+// end of a frame: the other parity's counters are zeroed for the next frame's appends; stats mirror for the host
+__device__ __forceinline__ void frame_epilogue(const Tab& t, const int parity, const int n_integrated, const int n_culled, const int lane) {
+  if (lane < 4) t.ctr[CTR_SET0 + 4 * (parity ^ 1) + lane] = 0;
+  if (lane == 0) {
+    t.ctr[CTR_COMPACT] = n_integrated;  // M = visible + culled
+    t.ctr[CTR_CULLED] = n_culled;
+    t.ctr[CTR_FREED_EARLY] = 0;
+  }
+}
+
+// ---- two-launch path: K2 = integrate + summary + GC of the visible list, then the culled-free list -------------
+template <bool FREE, bool PROFILE>
+__global__ __launch_bounds__(256) void k_back(const Cam c, const Map m, const Tab t, const Fast f, const Lists L, const int parity,
+                                              const float trunc_threshold, const int stagger) {
+  extern __shared__ __attribute__((aligned(16))) uint2 s_tile[];
+  (void) stagger;  // (a delayed start of every other workgroup was measured: it only lengthens the launch)
+  const int cs = CTR_SET0 + 4 * parity;
+  const int lane = threadIdx.x & 63;
+  const int wpw = blockDim.x >> 6;
+  const int gw = blockIdx.x * wpw + (threadIdx.x >> 6);
+  const int nw = gridDim.x * wpw;
+  // the counters are read (scalar loads) BEFORE wave 0 stores to the counter array: a load after those stores would
+  // have to be a vector load with a full memory round trip at the head of every wave
+  const int nvis = t.ctr[cs + 0];
+  const int ncfree = FREE ? t.ctr[cs + 2] : 0;
+  const int nkept = t.ctr[cs + 1];
+  if (gw == 0) frame_epilogue(t, parity, nvis, nkept + t.ctr[cs + 2], lane);
+  uint2* tile = &s_tile[(threadIdx.x >> 6) * kTileMaxPx];
+  back_range<FREE, PROFILE>(c, m, t, f, L, trunc_threshold, nvis, gw, nw, lane, tile);
+  if (FREE) free_range<PROFILE>(t, L, ncfree, gw, nw, lane);
 }
 
 // starve frames: GC after the weights changed — visible list by refreshed summary, plus the culled-free list
