@@ -504,6 +504,17 @@ int mrh_create(const mrh_params* p, mrh_ctx** out) {
   m.shard_rank = c->p.shard_rank;
   m.shard_count = c->p.shard_count;
   m.shard_chunk_log2 = (p->shard_chunk_log2 > 0 && p->shard_chunk_log2 < 16) ? p->shard_chunk_log2 : 3;
+  {  // where is voxel -> block an arithmetic shift?  (mrh_device.h: world_to_block_fast)
+    const u32 init = 1u << 23;
+    u32 first_bad = 0;
+    if (hipMemcpy(c->d_misc, &init, sizeof init, hipMemcpyHostToDevice) != hipSuccess) first_bad = 1;
+    k_block_shift_limit<<<(1 << 23) / 256, 256, 0, c->stream>>>(m.vs, c->d_misc);
+    if (hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(&first_bad, c->d_misc, sizeof first_bad, hipMemcpyDeviceToHost) != hipSuccess) first_bad = 1;
+    int lim = 1;
+    while ((u32) (lim << 1) <= first_bad && lim < (1 << 22)) lim <<= 1;  // largest power of two <= first mismatch
+    m.block_shift_limit = first_bad <= 1 ? 0 : lim;
+    if (getenv("MRH_DEBUG")) fprintf(stderr, "[mrhash_hip] voxel->block is a shift for |v| < %d (first mismatch at %u, voxel size %g)\n", m.block_shift_limit, first_bad, (double) m.vs);
+  }
 
   if (const char* g = getenv("MRH_FUSED_GRID")) {  // tuning knob: workgroups (x4 waves) of the fused integrate kernel
     const int v = atoi(g);

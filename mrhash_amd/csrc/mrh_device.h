@@ -71,6 +71,7 @@ struct Map {
   int weight_max;     // as u8 (vds.cu:1102)
   int min_weight_threshold;
   int shard_rank, shard_count, shard_chunk_log2;
+  int block_shift_limit;  // for |voxel coordinate| < this, voxel_to_block(v) == v >> 3 (checked exhaustively at mrh_create)
 };
 
 // Open-address table + pools.  Layout in HBM:
@@ -260,6 +261,23 @@ __device__ __forceinline__ i3 world_to_block_r(const GridRcp& g, f3 pt) {
   b.y = f2i_hw((pw.y >= 0) ? floorf(div_rr(pw.y + epsilon, g.mbs, g.r_mbs)) : ceilf(div_rr(pw.y - epsilon, g.mbs, g.r_mbs)));
   b.z = f2i_hw((pw.z >= 0) ? floorf(div_rr(pw.z + epsilon, g.mbs, g.r_mbs)) : ceilf(div_rr(pw.z - epsilon, g.mbs, g.r_mbs)));
   return b;
+}
+
+// world_to_block_r with the voxel -> block half as an arithmetic shift wherever that is KNOWN to equal the reference's
+// float detour (vhu.cuh:75-103: voxel -> world -> +-1e-5 -> / (8 * vs) -> floor / ceil): mrh_create evaluates the
+// float form for every voxel coordinate and records the first |v| at which it leaves floor(v / 8)
+// (k_block_shift_limit); beyond that bound (hundreds of metres from the origin) the float form is used.
+__device__ __forceinline__ i3 world_to_block_fast(const GridRcp& g, f3 pt, const int limit) {
+  const float epsilon = 1e-5;
+  const f3 p = mk3(div_rr(pt.x, g.vs, g.r_vs), div_rr(pt.y, g.vs, g.r_vs), div_rr(pt.z, g.vs, g.r_vs));
+  f3 a = mk3(p.x + (float) signi(p.x) * 0.5f, p.y + (float) signi(p.y) * 0.5f, p.z + (float) signi(p.z) * 0.5f);
+  a.x = (a.x >= 0) ? floorf(a.x + epsilon) : ceilf(a.x - epsilon);
+  a.y = (a.y >= 0) ? floorf(a.y + epsilon) : ceilf(a.y - epsilon);
+  a.z = (a.z >= 0) ? floorf(a.z + epsilon) : ceilf(a.z - epsilon);
+  const i3 v = mki3(f2i_hw(a.x), f2i_hw(a.y), f2i_hw(a.z));
+  const int ax = v.x < 0 ? -v.x : v.x, ay = v.y < 0 ? -v.y : v.y, az = v.z < 0 ? -v.z : v.z;
+  if ((u32) (ax | ay | az) < (u32) limit) return mki3(v.x >> 3, v.y >> 3, v.z >> 3);  // (a | b | c) < 2^k bound, limit is a power of two
+  return voxel_to_block(v, g.vs);
 }
 
 // vhu.cuh:184-187

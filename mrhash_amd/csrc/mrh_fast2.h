@@ -154,26 +154,40 @@ __device__ __forceinline__ void front_tile(const Cam& c, const Map& m, const Tab
     f.depth_clean[pix] = d;
     const uint8_t* px = rgb + pix * 3;
     f.rgbx[pix] = (u32) px[0] | ((u32) px[1] << 8) | ((u32) px[2] << 16);
-    walk_ray(c, m, t, row, col, d, [&](const i3 cur, const u64 key) {
-      u32 s = (u32) __mul24(cur.z, 5851) + (u32) __mul24(cur.y, 73) + (u32) cur.x;
-      s = (s ^ (s >> 7)) & (kRayCap - 1);
+    // hot path: keys into the LDS set; anything rare (set saturated by far, sparse rays; keys out of range) is left to
+    // the literal walk below, outside the loop every lane runs
+    const RayState ray = ray_setup(c, m, row, col, d);
+    bool slow = false;
+    if (ray.valid) {
+      if (!ray_keys_in_range(ray)) {
+        slow = true;
+      } else {
+        slow = !walk_ray_lean(m, ray, [&](const i3 cur, const u64 key) {
+          u32 s = (u32) __mul24(cur.z, 5851) + (u32) __mul24(cur.y, 73) + (u32) cur.x;
+          s = (s ^ (s >> 7)) & (kRayCap - 1);
 #pragma unroll 1
-      for (int p = 0; p < kSetProbe; p++) {
-        const u64 old = atomicCAS(&sh.set[s], kKeyEmpty, key);
-        if (old == kKeyEmpty) { sh.list[atomicAdd(&sh.count, 1u)] = key; return; }
-        if (old == key) return;
-        s = (s + 1) & (kRayCap - 1);
+          for (int p = 0; p < kSetProbe; p++) {
+            const u64 old = atomicCAS(&sh.set[s], kKeyEmpty, key);
+            if (old == kKeyEmpty) { sh.list[atomicAdd(&sh.count, 1u)] = key; return true; }
+            if (old == key) return true;
+            s = (s + 1) & (kRayCap - 1);
+          }
+          return false;
+        });
       }
-      // LDS set saturated (far, sparse rays): insert directly
-      if (!block_in_frustum_approx(c, m.vs, cur)) return;
-      const int slot = hash_insert(t, key);
-      if (slot == -2) atomicOr((u32*) &t.ctr[CTR_ERROR], ERR_TABLE);
-      if (slot < 0) return;
-      const int H = commit_block(t, f, slot, atomicSub(&t.ctr[CTR_HEAP_FINE], 1), cur, stamp, hwm0);
-      if (H < 0) return;
-      list_new(make_int4(cur.x, cur.y, cur.z, H));
-      if (PROFILE) atomicAdd(&t.prof[PROF_INSERTED], 1ull);
-    });
+    }
+    if (slow) {
+      walk_ray(c, m, t, row, col, d, [&](const i3 cur, const u64 key) {  // direct insert of every block of this ray
+        if (!block_in_frustum_approx(c, m.vs, cur)) return;
+        const int slot = hash_insert(t, key);
+        if (slot == -2) atomicOr((u32*) &t.ctr[CTR_ERROR], ERR_TABLE);
+        if (slot < 0) return;
+        const int H = commit_block(t, f, slot, atomicSub(&t.ctr[CTR_HEAP_FINE], 1), cur, stamp, hwm0);
+        if (H < 0) return;
+        list_new(make_int4(cur.x, cur.y, cur.z, H));
+        if (PROFILE) atomicAdd(&t.prof[PROF_INSERTED], 1ull);
+      });
+    }
   }
   MRH_TSF(2);
   __syncthreads();
@@ -227,7 +241,14 @@ __device__ __forceinline__ void front_tile(const Cam& c, const Map& m, const Tab
   }
   MRH_TSF(4);
 #ifdef MRH_TRACE
-  if (tid == 0) f.trace[(kTraceFront + blockIdx.x) * 8 + 7] = (u64) n;
+  if (tid == 0) {
+    u32 hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    u32 xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    f.trace[(kTraceFront + blockIdx.x) * 8 + 7] = (u64) n;
+    f.trace[(kTraceFront + blockIdx.x) * 8 + 5] = (u64) hw | ((u64) xcc << 32);
+  }
 #endif
   if (PROFILE) {
     if (my_inserted) atomicAdd(&sh.inserted, my_inserted);

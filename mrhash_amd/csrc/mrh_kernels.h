@@ -730,6 +730,16 @@ __device__ __forceinline__ u32 st_rand(u64& s) {
   s = s * 6364136223846793005ull + 1442695040888963407ull;
   return (u32) (s >> 33) ^ (u32) (s >> 11);
 }
+// exhaustive check behind Map::block_shift_limit: smallest |v| in [0, 2^23) whose float voxel -> block conversion
+// (either sign) differs from the arithmetic shift; out[0] must be initialised to 2^23
+__global__ __launch_bounds__(256) void k_block_shift_limit(const float vs, u32* __restrict__ out) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= (1 << 23)) return;
+  const i3 bp = voxel_to_block(mki3(v, v, v), vs);
+  const i3 bn = voxel_to_block(mki3(-v, -v, -v), vs);
+  if (bp.x != (v >> 3) || bn.x != ((-v) >> 3)) atomicMin(out, (u32) v);
+}
+
 __global__ __launch_bounds__(256) void k_selftest_division(const u64 seed, const u32 iters, u64* __restrict__ mismatches) {
   u64 st = seed * 0x9E3779B97F4A7C15ull + (u64) (blockIdx.x * 256 + threadIdx.x) * 0xD1B54A32D192ED03ull + 1;
   u32 bad = 0;

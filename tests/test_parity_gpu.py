@@ -126,6 +126,26 @@ def test_moving_camera_rotated_poses(hip, oracle):
     pu.compare_meshes(a, b)
 
 
+@pytest.mark.parametrize("offset", [(0.0, 0.0, 0.0), (163.0, -162.5, 81.0), (420.0, -310.0, 150.0)], ids=["origin", "shift-limit-edge", "far"])
+def test_far_from_origin(hip, oracle, offset):
+    """The allocation kernel converts voxel -> block with an arithmetic shift where mrh_create proved it equal to the
+    reference's float detour (vhu.cuh:75-103) and with the float form beyond that bound: the same walk, translated
+    to both sides of the bound, must give the oracle's map."""
+    K = synth.Intrinsics(160.0, 160.0, 79.5, 59.5, 120, 160)
+    params = dict(synth.REPLICA_PARAMS, virtual_voxel_size=0.02, sdf_truncation=0.08)
+    a, b = _pair(hip, oracle, K, params, 65536)
+    scene = synth.scannet_room()
+    for t, q in synth.walk_poses(4, seed=5):
+        f = synth.render(scene, K, t, q, depth_scaling=5000.0)
+        f.t = (f.t + np.asarray(offset, np.float32)).astype(np.float32)
+        pu.feed(a, f)
+        pu.feed(b, f)
+    a.sync()
+    r = pu.compare_maps(a, b)
+    assert r["blocks"] > 300
+    pu.compare_meshes(a, b)
+
+
 def test_variance_adaptive_multires(hip, oracle):
     params = dict(synth.CFG1_PARAMS, sdf_var_threshold=0.5, n_frames_invalidate_voxels=3)
     a, b = _pair(hip, oracle, synth.CFG1, params, 16384)

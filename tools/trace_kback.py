@@ -40,6 +40,16 @@ if len(fr):
     for i, nm in enumerate(["start", "lds init done", "rays done (thread 0)", "all rays done", "probe/insert done"]):
         print(f"  tile  {nm:22s} p10 {np.percentile(tl[:, i], 10):6.2f} p50 {np.percentile(tl[:, i], 50):6.2f} p90 {np.percentile(tl[:, i], 90):6.2f} max {tl[:, i].max():6.2f}")
     print("  tile  distinct keys per tile: mean", (fr[~issweep, 7]).astype(np.int64).mean(), "max", (fr[~issweep, 7]).astype(np.int64).max())
+    # placement: workgroups per CU (XCC id, SE id, CU id from HW_ID) vs finish time
+    hwid = fr[~issweep, 5]
+    xcc = (hwid >> np.uint64(32)) & np.uint64(0xF)
+    cu = (hwid >> np.uint64(8)) & np.uint64(0xF); sh_ = (hwid >> np.uint64(12)) & np.uint64(1); se = (hwid >> np.uint64(13)) & np.uint64(0x7)
+    cuid = (xcc.astype(np.int64) << 12) | (se.astype(np.int64) << 8) | (sh_.astype(np.int64) << 4) | cu.astype(np.int64)
+    uniq, inv, cnt = np.unique(cuid, return_inverse=True, return_counts=True)
+    print("  tile  distinct CUs", len(uniq), "tile workgroups per CU: min", cnt.min(), "max", cnt.max(), "hist", np.bincount(cnt))
+    for k in np.unique(cnt):
+        sel = cnt[inv] == k
+        print(f"        CUs with {k} tile wgs: rays done mean {tl[sel, 3].mean():6.2f}  end mean {tl[sel, 4].mean():6.2f} max {tl[sel, 4].max():6.2f}")
     sw = fr[issweep]
     if len(sw):
         S0 = (sw[:, 0].astype(np.int64) - t0) / 100.0; S4 = (sw[:, 4].astype(np.int64) - t0) / 100.0
