@@ -22,6 +22,7 @@
 #include "mrh_fast.h"
 #include "mrh_pipe.h"
 #include "mrh_fast2.h"
+#include "mrh_mesh.h"
 
 using namespace mrh;
 
@@ -73,6 +74,7 @@ struct mrh_ctx {
   int overlap = 0;        // MRH_OVERLAP=1: rays of frame f+1 on a second stream (mrh_pipe.h; host-bound, off by default)
   int merged = 1;         // MRH_MERGED=0: three-launch path (k_alloc2 / k_compact2 / k_fused) instead of k_front / k_back
   int4* d_cfree = nullptr;
+  int mesh_on_host = 0;      // MRH_MESH_HOST=1: mesh post-process with the host restatement instead of mrh_mesh.h
   float* d_zmin = nullptr;   // per visible-list entry (Lists::zmin)
   uint64_t fast_frames = 0;  // fast-path frames issued: parity selects the list-counter set
   int frame_parity = 0;
@@ -316,6 +318,82 @@ void process_triangles(mrh_ctx* c) {
   }
 }
 
+// MeshExtractor::processTriangles on the device (mrh_mesh.h): fills V / C / F from a triangle soup in device memory.
+// MRH_MESH_HOST=1 keeps the host restatement above (same arrays; tests compare the two).
+int process_triangles_device(mrh_ctx* c, const mrh_triangle* d_tris, const size_t nt) {
+  c->V.clear(); c->C.clear(); c->F.clear();
+  if (nt == 0) return MRH_OK;
+  if (nt * 3 >= 0xFFFFFFF0ull) return fail(c, MRH_ERR_CAPACITY, "mesh post-process: %zu triangles exceed 32-bit vertex indices", nt);
+  hipStream_t s = c->stream;
+  const u32 n = (u32) (nt * 3), ntr = (u32) nt;
+  const double eps = (double) c->p.vertices_merging_threshold;
+  const double inv_eps = eps != 0.0 ? 1.0 / eps : 0.0;
+  const size_t tmp_bytes = mesh_sort_tmp_bytes(n);
+  MeshScratch m;
+  m.bytes = (size_t) n * (4 * 13 + 8 * 2) + tmp_bytes + 64 * 256;
+  HIP_TRY(c, hipMalloc(&m.base, m.bytes));
+  u32* kx = m.take<u32>(n);      u64* kyz = m.take<u64>(n);     u32* idx0 = m.take<u32>(n);   u32* never = m.take<u32>(n);
+  u64* lo_s = m.take<u64>(n);    u32* mid = m.take<u32>(n);     u32* order = m.take<u32>(n);  u32* hi_g = m.take<u32>(n);
+  u32* hi_s = m.take<u32>(n);    u32* headpos = m.take<u32>(n); u32* rep = m.take<u32>(n);    u32* first = m.take<u32>(n);
+  u32* vid = m.take<u32>(n);     u32* corner = m.take<u32>(n);  u32* hscan = m.take<u32>(n);
+  void* tmp = m.take<char>(tmp_bytes);
+  size_t tb = tmp_bytes;
+  const u32 gv = (n + 255) / 256, gf = (ntr + 255) / 256;
+  const float* soup = (const float*) d_tris;
+  int rc = MRH_OK;
+  double *dV = nullptr, *dC = nullptr;
+  int* dF = nullptr;
+#define MESH_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { rc = fail(c, MRH_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(e_)); goto done; } } while (0)
+  {
+    // ---- vertices
+    k_mesh_vertex_keys<<<gv, 256, 0, s>>>(soup, n, eps, inv_eps, kx, kyz, idx0, never);
+    MESH_TRY(mesh_sort96(tmp, tb, kx, kyz, idx0, mid, order, lo_s, hi_g, hi_s, n, s));
+    k_mesh_heads<<<gv, 256, 0, s>>>(kx, kyz, never, order, n, headpos);
+    MESH_TRY(rocprim::inclusive_scan(tmp, tb, headpos, hscan, n, rocprim::maximum<u32>(), s));
+    k_mesh_rep<<<gv, 256, 0, s>>>(order, hscan, n, rep, first);
+    MESH_TRY(rocprim::exclusive_scan(tmp, tb, first, vid, 0u, n, rocprim::plus<u32>(), s));
+    u32 last_vid = 0, last_first = 0;
+    MESH_TRY(hipMemcpyAsync(&last_vid, vid + (n - 1), sizeof(u32), hipMemcpyDeviceToHost, s));
+    MESH_TRY(hipMemcpyAsync(&last_first, first + (n - 1), sizeof(u32), hipMemcpyDeviceToHost, s));
+    MESH_TRY(hipStreamSynchronize(s));
+    const size_t nv = (size_t) last_vid + last_first;
+    MESH_TRY(hipMalloc((void**) &dV, nv * 3 * sizeof(double)));
+    MESH_TRY(hipMalloc((void**) &dC, nv * 3 * sizeof(double)));
+    k_mesh_emit_vertices<<<gv, 256, 0, s>>>(soup, rep, first, vid, n, dV, dC, corner);
+    // ---- faces (the vertex buffers are reused: nt < n)
+    u32* ka = kx; u64* kbc = kyz; u32* fidx = idx0; u32* degenerate = never; u32* keep = rep; u32* fpos = vid;
+    k_mesh_face_keys<<<gf, 256, 0, s>>>(corner, ntr, ka, kbc, fidx, degenerate);
+    MESH_TRY(mesh_sort96(tmp, tb, ka, kbc, fidx, mid, order, lo_s, hi_g, hi_s, ntr, s));
+    k_mesh_heads<<<gf, 256, 0, s>>>(ka, kbc, nullptr, order, ntr, headpos);
+    MESH_TRY(rocprim::inclusive_scan(tmp, tb, headpos, hscan, ntr, rocprim::maximum<u32>(), s));
+    k_mesh_face_keep<<<gf, 256, 0, s>>>(order, hscan, degenerate, ntr, keep);
+    MESH_TRY(rocprim::exclusive_scan(tmp, tb, keep, fpos, 0u, ntr, rocprim::plus<u32>(), s));
+    u32 last_pos = 0, last_keep = 0;
+    MESH_TRY(hipMemcpyAsync(&last_pos, fpos + (ntr - 1), sizeof(u32), hipMemcpyDeviceToHost, s));
+    MESH_TRY(hipMemcpyAsync(&last_keep, keep + (ntr - 1), sizeof(u32), hipMemcpyDeviceToHost, s));
+    MESH_TRY(hipStreamSynchronize(s));
+    const size_t nf = (size_t) last_pos + last_keep;
+    if (nf) {
+      MESH_TRY(hipMalloc((void**) &dF, nf * 3 * sizeof(int)));
+      k_mesh_emit_faces<<<gf, 256, 0, s>>>(corner, keep, fpos, ntr, dF);
+    }
+    c->V.resize(nv * 3); c->C.resize(nv * 3); c->F.resize(nf * 3);
+    MESH_TRY(hipMemcpyAsync(c->V.data(), dV, nv * 3 * sizeof(double), hipMemcpyDeviceToHost, s));
+    MESH_TRY(hipMemcpyAsync(c->C.data(), dC, nv * 3 * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (nf) MESH_TRY(hipMemcpyAsync(c->F.data(), dF, nf * 3 * sizeof(int), hipMemcpyDeviceToHost, s));
+    MESH_TRY(hipStreamSynchronize(s));
+    MESH_TRY(hipGetLastError());
+  }
+done:
+#undef MESH_TRY
+  if (dV) (void) hipFree(dV);
+  if (dC) (void) hipFree(dC);
+  if (dF) (void) hipFree(dF);
+  (void) hipFree(m.base);
+  return rc;
+}
+
+
 
 // stream the frame inputs are consumed on: the ray kernel's stream in the overlapped fast path, else the map stream
 hipStream_t in_stream(mrh_ctx* c) { return (!c->tab.multi_res && c->overlap) ? c->stream_in : c->stream; }
@@ -526,6 +604,7 @@ int mrh_create(const mrh_params* p, mrh_ctx** out) {
   if (const char* g = getenv("MRH_FUSED_PIPE")) c->fused_pipe = atoi(g) ? 1 : 0;
   if (const char* g = getenv("MRH_OVERLAP")) c->overlap = atoi(g) ? 1 : 0;
   if (const char* g = getenv("MRH_MERGED")) c->merged = atoi(g) ? 1 : 0;
+  if (const char* g = getenv("MRH_MESH_HOST")) c->mesh_on_host = atoi(g) ? 1 : 0;
   if (c->overlap) c->merged = 0;
   if (const char* g = getenv("MRH_GC_INLINE")) c->gc_inline_enabled = atoi(g) ? 1 : 0;
   if (const char* g = getenv("MRH_ALLOC_TILE")) c->alloc_tile = atoi(g) == 8 ? 8 : 16;
@@ -910,6 +989,7 @@ int mrh_extract_triangles(mrh_ctx* c, const mrh_triangle** out_tris, uint64_t* o
   c->tri_blocks.clear();
   c->tri_counts.clear();
   c->last_triangles = 0;
+  bool processed = false;
   if (n > 0) {
     // canonical order: sort the block list by position (packed-key order == (x,y,z) order)
     std::vector<int4> list((size_t) n);
@@ -946,15 +1026,18 @@ int mrh_extract_triangles(mrh_ctx* c, const mrh_triangle** out_tris, uint64_t* o
       k_mc<true><<<grid, 512, 0, s>>>(c->map, c->tab, c->tab.compact, n, d_counts, d_offsets, d_tris, total);
       c->tris.resize(total);
       HIP_TRY(c, hipMemcpyAsync(c->tris.data(), d_tris, total * sizeof(mrh_triangle), hipMemcpyDeviceToHost, s));
+      int prc = MRH_OK;
+      if (!c->mesh_on_host) { prc = process_triangles_device(c, d_tris, total); processed = true; }
       HIP_TRY(c, hipStreamSynchronize(s));
       HIP_TRY(c, hipFree(d_tris));
+      if (prc) { (void) hipFree(d_counts); (void) hipFree(d_offsets); return prc; }
     }
     HIP_TRY(c, hipFree(d_counts));
     HIP_TRY(c, hipFree(d_offsets));
     HIP_TRY(c, hipGetLastError());
   }
   c->last_triangles = c->tris.size();
-  process_triangles(c);
+  if (!processed) process_triangles(c);
   *out_tris = c->tris.empty() ? nullptr : c->tris.data();
   *out_n = c->tris.size();
   return MRH_OK;
@@ -1051,8 +1134,15 @@ int mrh_process_triangles(mrh_ctx* c, const mrh_triangle* triangles, uint64_t n)
   if (!c || (n && !triangles)) return MRH_ERR_INVALID_ARG;
   c->tris.assign(triangles, triangles + n);
   c->last_triangles = n;
-  process_triangles(c);
-  return MRH_OK;
+  if (c->mesh_on_host || n == 0) { process_triangles(c); return MRH_OK; }
+  int rc = ensure_ready(c, "mrh_process_triangles");
+  if (rc) return rc;
+  mrh_triangle* d_tris = nullptr;
+  HIP_TRY(c, hipMalloc((void**) &d_tris, n * sizeof(mrh_triangle)));
+  hipError_t e = hipMemcpyAsync(d_tris, triangles, n * sizeof(mrh_triangle), hipMemcpyHostToDevice, c->stream);
+  rc = e == hipSuccess ? process_triangles_device(c, d_tris, n) : fail(c, MRH_ERR_DEVICE, "mrh_process_triangles: upload failed: %s", hipGetErrorString(e));
+  (void) hipFree(d_tris);
+  return rc;
 }
 
 int mrh_selftest_division(mrh_ctx* c, uint64_t samples, uint64_t seed, uint64_t* out_mismatches) {

@@ -146,6 +146,37 @@ def test_far_from_origin(hip, oracle, offset):
     pu.compare_meshes(a, b)
 
 
+@pytest.mark.parametrize("eps", [0.0, 0.013], ids=["exact-merge", "eps-cells"])
+def test_mesh_postprocess_device_equals_host_and_oracle(hip, oracle, monkeypatch, eps):
+    """MeshExtractor::processTriangles runs on the device (mrh_mesh.h: stable sorts + scans); the host restatement
+    (MRH_MESH_HOST=1) and the oracle must give the same V / F / C, element for element, in both merge modes."""
+    K = synth.Intrinsics(160.0, 160.0, 79.5, 59.5, 120, 160)
+    params = dict(synth.REPLICA_PARAMS, virtual_voxel_size=0.02, sdf_truncation=0.08, vertices_merging_threshold=eps,
+                  min_weight_threshold=1)
+    dev = pu.make_engine(hip, K, params, 65536)
+    orc = pu.make_engine(oracle, K, params, 65536)
+    monkeypatch.setenv("MRH_MESH_HOST", "1")
+    host = pu.make_engine(hip, K, params, 65536)
+    scene = synth.scannet_room()
+    for t, q in synth.walk_poses(3, seed=11):
+        f = synth.render(scene, K, t, q, depth_scaling=5000.0)
+        for e in (dev, orc, host):
+            pu.feed(e, f)
+    out = []
+    for e in (dev, host, orc):
+        tris = e.extract_triangles()
+        V, F, C = e.extract_mesh()
+        out.append((tris, V, F, C))
+    assert out[0][0].shape[0] > 5000
+    for other in out[1:]:
+        assert out[0][0].tobytes() == other[0].tobytes()
+        for a, b in zip(out[0][1:], other[1:]):
+            assert a.shape == b.shape and a.tobytes() == b.tobytes()
+    assert out[0][1].shape[0] < out[0][0].shape[0] * 3  # something merged
+    for e in (dev, orc, host):
+        e.close()
+
+
 def test_variance_adaptive_multires(hip, oracle):
     params = dict(synth.CFG1_PARAMS, sdf_var_threshold=0.5, n_frames_invalidate_voxels=3)
     a, b = _pair(hip, oracle, synth.CFG1, params, 16384)
