@@ -74,6 +74,10 @@ struct mrh_ctx {
   int overlap = 0;        // MRH_OVERLAP=1: rays of frame f+1 on a second stream (mrh_pipe.h; host-bound, off by default)
   int merged = 1;         // MRH_MERGED=0: three-launch path (k_alloc2 / k_compact2 / k_fused) instead of k_front / k_back
   int4* d_cfree = nullptr;
+  int mr_fused = 1;          // MRH_MR_FUSED=0: multi-resolution maps always through the general kernels (mrh_kernels.h)
+  bool mr_next_general = true;    // the next multi-resolution frame must take the general path (frame 0 / after a starve frame / after an import)
+  bool mr_summaries_valid = false;  // fast.summary / summary_c describe every live block (the general kernels do not maintain them)
+  bool frame_fused_mr = false;
   int mesh_on_host = 0;      // MRH_MESH_HOST=1: mesh post-process with the host restatement instead of mrh_mesh.h
   float* d_zmin = nullptr;   // per visible-list entry (Lists::zmin)
   uint64_t fast_frames = 0;  // fast-path frames issued: parity selects the list-counter set
@@ -82,6 +86,7 @@ struct mrh_ctx {
   u64* d_cnt_partials = nullptr;
   int fused_grid = 2048;  // x 4 waves
   int stagger = 0;        // MRH_STAGGER: start delay (x ~3.4 us) of odd workgroups of k_back
+  int sweep_wgs_mr = 1024; // the same for multi-resolution maps (9x the descriptors); MRH_SWEEP_WGS_MR
   int sweep_wgs = 128;    // descriptor-sweep workgroups appended to the allocation launch (k_front)
   int fused_nb = 2;       // voxel batches per wave: 2 = block per wave, 1 = half block per wave
   int fused_pipe = 0;     // 1 = software-pipelined variant (k_fused_pipe)
@@ -152,7 +157,7 @@ void free_all(mrh_ctx* c) {
   F(c->tab.keys); F(c->tab.vals); F(c->tab.heap_fine); F(c->tab.heap_coarse); F(c->tab.desc_fine); F(c->tab.desc_coarse);
   F(c->tab.pool); F(c->tab.compact); F(c->tab.ctr); F(c->tab.prof);
   F(c->d_depth_own); F(c->d_rgb_own); F(c->d_decision); F(c->d_zbuf); F(c->d_realloc); F(c->d_reint); F(c->d_flag);
-  F(c->d_upd_partials); F(c->d_misc); F(c->d_cfree); F(c->d_zmin); F(c->fast.summary); F(c->fast.bbox); F(c->d_cnt_partials);
+  F(c->d_upd_partials); F(c->d_misc); F(c->d_cfree); F(c->d_zmin); F(c->fast.summary); F(c->fast.summary_c); F(c->fast.bbox); F(c->d_cnt_partials);
   for (auto& e : c->ev_pool) { (void) hipEventDestroy(e.a); (void) hipEventDestroy(e.b); }
   for (auto& e : c->ev_pending) { (void) hipEventDestroy(e.a); (void) hipEventDestroy(e.b); }
   if (c->stream) (void) hipStreamDestroy(c->stream);
@@ -163,6 +168,8 @@ int init_buffers(mrh_ctx* c) {
   hipStream_t s = c->stream;
   if (c->stream_in) HIP_TRY(c, hipStreamSynchronize(c->stream_in));
   c->frames_enqueued = 0;
+  c->mr_next_general = true;
+  c->mr_summaries_valid = false;
   c->fast_frames = 0;
   const Tab& t = c->tab;
   k_init_table<<<1024, 256, 0, s>>>(t.keys, c->slots);
@@ -445,7 +452,7 @@ int frame_tail(mrh_ctx* c, bool starved, int max_num_frames) {
       } else if (c->profile) k_free2<true><<<256, 256, 0, s>>>(t, c->fast, thr);
       else k_free2<false><<<256, 256, 0, s>>>(t, c->fast, thr);
     }
-  } else if (max_num_frames > 0) {
+  } else if (max_num_frames > 0 && !c->frame_fused_mr) {
     k_gc_identify<<<c->integrate_grid, 512, 0, s>>>(t, thr, c->d_decision);
     if (c->profile) k_gc_free<true><<<256, 256, 0, s>>>(t, c->d_decision);
     else k_gc_free<false><<<256, 256, 0, s>>>(t, c->d_decision);
@@ -561,13 +568,15 @@ int mrh_create(const mrh_params* p, mrh_ctx** out) {
   memset(&c->fast, 0, sizeof c->fast);
   CREATE_TRY(hipMalloc((void**) &c->fast.summary, c->num_blocks * sizeof(uint2)));
   c->fast.compact_cap = (u32) c->num_blocks;
-  CREATE_TRY(hipMalloc((void**) &c->fast.bbox, c->num_blocks * sizeof(int4)));
+  const size_t list_cap = c->num_blocks * (t.multi_res ? 9 : 1);  // visible / free lists may hold coarse units, too
+  CREATE_TRY(hipMalloc((void**) &c->fast.bbox, list_cap * sizeof(int4)));
+  if (t.multi_res) CREATE_TRY(hipMalloc((void**) &c->fast.summary_c, c->num_blocks * 8 * sizeof(uint2)));
 #ifdef MRH_TRACE
   CREATE_TRY(hipMalloc((void**) &c->fast.trace, c->num_blocks * 8 * sizeof(u64)));
   CREATE_TRY(hipMemset(c->fast.trace, 0, c->num_blocks * 8 * sizeof(u64)));
 #endif
-  CREATE_TRY(hipMalloc((void**) &c->d_cfree, c->num_blocks * sizeof(int4)));
-  CREATE_TRY(hipMalloc((void**) &c->d_zmin, c->num_blocks * sizeof(float)));
+  CREATE_TRY(hipMalloc((void**) &c->d_cfree, list_cap * sizeof(int4)));
+  CREATE_TRY(hipMalloc((void**) &c->d_zmin, list_cap * sizeof(float)));
 #undef CREATE_TRY
 
   Map& m = c->map;
@@ -605,6 +614,8 @@ int mrh_create(const mrh_params* p, mrh_ctx** out) {
   if (const char* g = getenv("MRH_OVERLAP")) c->overlap = atoi(g) ? 1 : 0;
   if (const char* g = getenv("MRH_MERGED")) c->merged = atoi(g) ? 1 : 0;
   if (const char* g = getenv("MRH_MESH_HOST")) c->mesh_on_host = atoi(g) ? 1 : 0;
+  if (const char* g = getenv("MRH_MR_FUSED")) c->mr_fused = atoi(g) ? 1 : 0;
+  if (const char* g = getenv("MRH_SWEEP_WGS_MR")) { const int v = atoi(g); if (v > 0 && v <= 4096) c->sweep_wgs_mr = v; }
   if (c->overlap) c->merged = 0;
   if (const char* g = getenv("MRH_GC_INLINE")) c->gc_inline_enabled = atoi(g) ? 1 : 0;
   if (const char* g = getenv("MRH_ALLOC_TILE")) c->alloc_tile = atoi(g) == 8 ? 8 : 16;
@@ -753,8 +764,20 @@ int mrh_integrate(mrh_ctx* c, int n_frames_invalidate) {
   const Tab& t = c->tab;
   const Map& m = c->map;
 
-  if (!t.multi_res) {
-    // ---- single-resolution fast path: alloc -> compact+cull -> fused integrate/summary -> free (mrh_fast.h)
+  // Multi-resolution maps take the same two launches when that is exact: the fused kernel checks the variance of a
+  // fine block right after updating it, which covers every block the reference's checkVarSDF can newly decide on —
+  // EXCEPT blocks that changed without being checked (frame 0 is never checked, voxel_data_structures.cpp:99; the starve
+  // step decrements weights after the check; imported blocks) and are then outside the image on the next frame.  Those
+  // frames, and the starve frames themselves, go through the general kernels.
+  const bool starve_now = max_num_frames > 0 && c->frames > 0 && c->frames % (uint64_t) max_num_frames == 0;
+  c->frame_fused_mr = t.multi_res && c->mr_fused && c->merged && !c->profile && max_num_frames > 0 && !starve_now && !c->mr_next_general &&
+                      c->frames >= 2;
+  if (t.multi_res && !c->frame_fused_mr) {
+    c->mr_summaries_valid = false;
+    c->mr_next_general = starve_now || c->frames == 0;
+  }
+  if (!t.multi_res || c->frame_fused_mr) {
+    // ---- fast path: alloc + sweep -> fused integrate / summary / GC (mrh_fast2.h)
     const size_t npix = (size_t) k.rows * k.cols;
     const int tiles_x = (k.cols + kRayTile - 1) / kRayTile, tiles_y = (k.rows + kRayTile - 1) / kRayTile;
     if (c->fast_npix < npix) {
@@ -788,10 +811,24 @@ int mrh_integrate(mrh_ctx* c, int n_frames_invalidate) {
       const float gc_thr = m.trunc + m.trunc_scale * k.max_depth;  // getTruncation(camera.maxDepth(), ...), vds.cu:1720
       const Lists L = {t.compact, c->fast.bbox, c->d_cfree, c->d_zmin, (u32) c->num_blocks};
       const int n_tiles = tiles_x * tiles_y;
+      if (c->frame_fused_mr) {
+        if (!c->mr_summaries_valid) {
+          k_summarize_all<<<2048, 256, 0, s>>>(t, f);
+          c->mr_summaries_valid = true;
+        }
+        c->frame_gc_inline = true;
+        k_refill_decide<<<1, 64, 0, s>>>(t, c->low_blocks_to_allocate, c->d_flag);  // vds.cu:885-891
+        k_refill<<<(c->low_blocks_to_allocate + 255) / 256, 256, 0, s>>>(t, c->low_blocks_to_allocate, c->d_flag);
+        k_front<false, true><<<n_tiles + c->sweep_wgs_mr, 256, 0, s>>>(k, m, t, f, L, c->d_depth, c->d_rgb, tiles_x, n_tiles, stamp, parity, 1, gc_thr);
+        const size_t lds = (size_t) 4 * kTileMaxPx * sizeof(uint2);
+        k_back<true, false, true><<<c->fused_grid, 256, lds, s>>>(k, m, t, f, L, parity, gc_thr, 0, c->d_depth, c->d_rgb, (u32*) c->d_reint);
+        k_mr_tail<<<1, 256, 0, s>>>(t, (const u32*) c->d_reint);
+        return starve_and_tail(c, max_num_frames);
+      }
       const bool starve = max_num_frames > 0 && c->frames > 0 && c->frames % (uint64_t) max_num_frames == 0;
       c->frame_gc_inline = max_num_frames > 0 && !starve;
-      if (c->profile) k_front<true><<<n_tiles + c->sweep_wgs, 256, 0, s>>>(k, m, t, f, L, c->d_depth, c->d_rgb, tiles_x, n_tiles, stamp, parity, max_num_frames > 0 ? 1 : 0, gc_thr);
-      else k_front<false><<<n_tiles + c->sweep_wgs, 256, 0, s>>>(k, m, t, f, L, c->d_depth, c->d_rgb, tiles_x, n_tiles, stamp, parity, max_num_frames > 0 ? 1 : 0, gc_thr);
+      if (c->profile) k_front<true, false><<<n_tiles + c->sweep_wgs, 256, 0, s>>>(k, m, t, f, L, c->d_depth, c->d_rgb, tiles_x, n_tiles, stamp, parity, max_num_frames > 0 ? 1 : 0, gc_thr);
+      else k_front<false, false><<<n_tiles + c->sweep_wgs, 256, 0, s>>>(k, m, t, f, L, c->d_depth, c->d_rgb, tiles_x, n_tiles, stamp, parity, max_num_frames > 0 ? 1 : 0, gc_thr);
       const int wg = c->fused_wg;
       const size_t lds = (size_t) (wg / 64) * kTileMaxPx * sizeof(uint2);
       EvPair ev;
@@ -802,9 +839,9 @@ int mrh_integrate(mrh_ctx* c, int n_frames_invalidate) {
         else { HIP_TRY(c, hipEventCreate(&ev.a)); HIP_TRY(c, hipEventCreate(&ev.b)); }
         HIP_TRY(c, hipEventRecord(ev.a, s));
       }
-      if (c->frame_gc_inline && c->profile) k_back<true, true><<<c->fused_grid, wg, lds, s>>>(k, m, t, f, L, parity, gc_thr, c->stagger);
-      else if (c->frame_gc_inline) k_back<true, false><<<c->fused_grid, wg, lds, s>>>(k, m, t, f, L, parity, gc_thr, c->stagger);
-      else k_back<false, false><<<c->fused_grid, wg, lds, s>>>(k, m, t, f, L, parity, gc_thr, c->stagger);
+      if (c->frame_gc_inline && c->profile) k_back<true, true, false><<<c->fused_grid, wg, lds, s>>>(k, m, t, f, L, parity, gc_thr, c->stagger, nullptr, nullptr, nullptr);
+      else if (c->frame_gc_inline) k_back<true, false, false><<<c->fused_grid, wg, lds, s>>>(k, m, t, f, L, parity, gc_thr, c->stagger, nullptr, nullptr, nullptr);
+      else k_back<false, false, false><<<c->fused_grid, wg, lds, s>>>(k, m, t, f, L, parity, gc_thr, c->stagger, nullptr, nullptr, nullptr);
       if (c->profile) {
         HIP_TRY(c, hipEventRecord(ev.b, s));
         c->ev_pending.push_back(ev);
@@ -1102,6 +1139,8 @@ int mrh_import_blocks(mrh_ctx* c, const mrh_block_desc* descs, const mrh_voxel* 
   if (rc) return rc;
   if (n == 0) return MRH_OK;
   if (!descs || !voxels) return fail(c, MRH_ERR_INVALID_ARG, "mrh_import_blocks: null argument");
+  c->mr_next_general = true;  // imported payload has not been through a variance check
+  c->mr_summaries_valid = false;
   const uint64_t chunk = 8192;
   int4* d_descs = nullptr;
   char* d_vox = nullptr;

@@ -31,6 +31,7 @@ struct Fast {
   uint2* summary;      // [cap_blocks] {bits of min |sdf| over weighted voxels (FLT_MAX if none), max weight}
   u32 compact_cap;     // entries in Tab::compact
   int4* bbox;          // [compact_cap] per VISIBLE compact entry: pixel footprint {col0, row0, w, h}; w == 0: none
+  uint2* summary_c;    // [8 * cap_blocks] the same summary per COARSE unit (multi-resolution maps only)
 #ifdef MRH_TRACE
   u64* trace;          // [compact_cap * 8] per-block phase timestamps of the last k_back launch (tuning builds only)
 #endif

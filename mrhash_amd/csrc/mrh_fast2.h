@@ -263,14 +263,13 @@ __device__ __forceinline__ void front_tile(const Cam& c, const Map& m, const Tab
 // (~3 atomics x 1250 batches per frame) is bound by exactly that.  Each sweep workgroup therefore owns one
 // contiguous chunk of descriptors, stages its results in LDS (aliasing the key set / list of the allocation role)
 // and publishes them with three atomics per workgroup.
+template <bool MULTI>
 __device__ __forceinline__ void front_sweep(const Cam& c, const Map& m, const Tab& t, const Fast& f, const Lists& L, const u32 stamp,
                                             const int cs, const int gc_on, const float trunc_threshold, const int sw, const int n_sweep,
                                             FrontShared& sh) {
   constexpr int NT = 256;
   const int tid = threadIdx.x;
   const int hwm = t.ctr[CTR_HWM_FINE];
-  const int chunk = (((hwm + n_sweep - 1) / n_sweep) + 63) & ~63;
-  const int lo = sw * chunk, hi = min(hwm, lo + chunk);
   int4* st_vis = (int4*) sh.list;   // 256 x {entry, bbox}
   int4* st_free = (int4*) sh.set;   // 512 entries
   constexpr int kStVis = kRayCap * 8 / 32, kStFree = kRayCap * 8 / 16;
@@ -296,79 +295,88 @@ __device__ __forceinline__ void front_sweep(const Cam& c, const Map& m, const Ta
   };
   const int grp = tid >> 2;      // block within the 64-block batch
   const int sub = tid & 3;       // this lane evaluates corners sub and sub + 4
+  // one pass over descs[0, total): fine blocks (valbit 0, index = block index) or coarse units (MULTI)
+  auto sweep_range = [&](const int4* __restrict__ descs, const uint2* __restrict__ sums, const int total, const u32 valbit) {
+  const int chunk = (((total + n_sweep - 1) / n_sweep) + 63) & ~63;
+  const int lo = sw * chunk, hi = min(total, lo + chunk);
   int4 d_next = make_int4(0, 0, 0, 0);
   uint2 sm_next = make_uint2(0, 0);
-  if (lo + grp < hi) { d_next = t.desc_fine[lo + grp]; sm_next = f.summary[lo + grp]; }
+  if (lo + grp < hi) { d_next = descs[lo + grp]; sm_next = sums[lo + grp]; }
   for (int base = lo; base < hi; base += 64) {
     const int i = base + grp;
     const int4 d = d_next;
     const uint2 sm = sm_next;
-    if (i + 64 < hi) { d_next = t.desc_fine[i + 64]; sm_next = f.summary[i + 64]; }  // next batch in flight during this one
+    if (i + 64 < hi) { d_next = descs[i + 64]; sm_next = sums[i + 64]; }  // next batch in flight during this one
     // live and not inserted by this very launch (those are handled by their inserter)
     const bool live = i < hi && (d.w & 1) && ((u32) d.w >> 1) != stamp;
-    int any_approx = 0;
-    float zmin = kFltMax, zmax = -kFltMax, umin = kFltMax, umax = -kFltMax, vmin = kFltMax, vmax = -kFltMax;
+    if (__ballot(live) != 0) {  // wave-uniform: nothing live among this wave's 16 descriptors (common in the sparse coarse range)
+      int any_approx = 0;
+      float zmin = kFltMax, zmax = -kFltMax, umin = kFltMax, umax = -kFltMax, vmin = kFltMax, vmax = -kFltMax;
 #pragma unroll
-    for (int h = 0; h < 2; h++) {
-      const int corner = sub + 4 * h;
-      const i3 v = mki3(d.x * kBlockSide + ((corner & 4) ? 7 : 0), d.y * kBlockSide + ((corner & 2) ? 7 : 0), d.z * kBlockSide + ((corner & 1) ? 7 : 0));
-      const f3 pc = se3_apply(c.Ri, c.ti, voxel_to_world(m.vs, v));
-      int r, cc;
-      any_approx |= project_point<true>(c, pc, r, cc) ? 1 : 0;
-      zmin = fminf(zmin, pc.z); zmax = fmaxf(zmax, pc.z);
-      if (pc.z >= 0.05f) {
-        const float u = c.fx * pc.x / pc.z + c.cx;
-        const float w = c.fy * pc.y / pc.z + c.cy;
-        umin = fminf(umin, u); umax = fmaxf(umax, u);
-        vmin = fminf(vmin, w); vmax = fmaxf(vmax, w);
+      for (int h = 0; h < 2; h++) {
+        const int corner = sub + 4 * h;
+        const i3 v = mki3(d.x * kBlockSide + ((corner & 4) ? 7 : 0), d.y * kBlockSide + ((corner & 2) ? 7 : 0), d.z * kBlockSide + ((corner & 1) ? 7 : 0));
+        const f3 pc = se3_apply(c.Ri, c.ti, voxel_to_world(m.vs, v));
+        int r, cc;
+        any_approx |= project_point<true>(c, pc, r, cc) ? 1 : 0;
+        zmin = fminf(zmin, pc.z); zmax = fmaxf(zmax, pc.z);
+        if (pc.z >= 0.05f) {
+          const float u = c.fx * pc.x / pc.z + c.cx;
+          const float w = c.fy * pc.y / pc.z + c.cy;
+          umin = fminf(umin, u); umax = fmaxf(umax, u);
+          vmin = fminf(vmin, w); vmax = fmaxf(vmax, w);
+        }
       }
-    }
 #pragma unroll
-    for (int off = 1; off < 4; off <<= 1) {
-      any_approx |= __shfl_xor(any_approx, off);
-      zmin = fminf(zmin, __shfl_xor(zmin, off)); zmax = fmaxf(zmax, __shfl_xor(zmax, off));
-      umin = fminf(umin, __shfl_xor(umin, off)); umax = fmaxf(umax, __shfl_xor(umax, off));
-      vmin = fminf(vmin, __shfl_xor(vmin, off)); vmax = fmaxf(vmax, __shfl_xor(vmax, off));
-    }
-    if (sub == 0 && live && any_approx) {
-      bool cull = (zmax <= c.min_depth - 1e-3f) || (zmin > c.max_depth + 1e-3f);
-      if (!cull && zmin >= 0.05f) cull = umax < -3.f || umin > (float) c.cols + 1.f || vmax < -3.f || vmin > (float) c.rows + 1.f;
-      const int4 e = make_int4(d.x, d.y, d.z, i);
-      if (!cull) {
-        int4 bb = make_int4(0, 0, 0, 0);
-        if (zmin >= 0.05f) {
-          int c0 = f2i_hw(floorf(umin + 0.5f)) - 1, c1 = f2i_hw(floorf(umax + 0.5f)) + 1;
-          int r0 = f2i_hw(floorf(vmin + 0.5f)) - 1, r1 = f2i_hw(floorf(vmax + 0.5f)) + 1;
-          c0 = c0 < 0 ? 0 : c0; r0 = r0 < 0 ? 0 : r0;
-          c1 = c1 > c.cols - 1 ? c.cols - 1 : c1; r1 = r1 > c.rows - 1 ? c.rows - 1 : r1;
-          const int bw = c1 - c0 + 1, bh = r1 - r0 + 1;
-          if (bw > 0 && bh > 0 && bw * bh <= kTileMaxPx) bb = make_int4(c0, r0, bw | (bh << 16), __float_as_int(zmin));
+      for (int off = 1; off < 4; off <<= 1) {
+        any_approx |= __shfl_xor(any_approx, off);
+        zmin = fminf(zmin, __shfl_xor(zmin, off)); zmax = fmaxf(zmax, __shfl_xor(zmax, off));
+        umin = fminf(umin, __shfl_xor(umin, off)); umax = fmaxf(umax, __shfl_xor(umax, off));
+        vmin = fminf(vmin, __shfl_xor(vmin, off)); vmax = fmaxf(vmax, __shfl_xor(vmax, off));
+      }
+      if (sub == 0 && live && any_approx) {
+        bool cull = (zmax <= c.min_depth - 1e-3f) || (zmin > c.max_depth + 1e-3f);
+        if (!cull && zmin >= 0.05f) cull = umax < -3.f || umin > (float) c.cols + 1.f || vmax < -3.f || vmin > (float) c.rows + 1.f;
+        const int4 e = make_int4(d.x, d.y, d.z, (int) ((u32) i | valbit));
+        if (!cull) {
+          int4 bb = make_int4(0, 0, 0, 0);
+          if (zmin >= 0.05f) {
+            int c0 = f2i_hw(floorf(umin + 0.5f)) - 1, c1 = f2i_hw(floorf(umax + 0.5f)) + 1;
+            int r0 = f2i_hw(floorf(vmin + 0.5f)) - 1, r1 = f2i_hw(floorf(vmax + 0.5f)) + 1;
+            c0 = c0 < 0 ? 0 : c0; r0 = r0 < 0 ? 0 : r0;
+            c1 = c1 > c.cols - 1 ? c.cols - 1 : c1; r1 = r1 > c.rows - 1 ? c.rows - 1 : r1;
+            const int bw = c1 - c0 + 1, bh = r1 - r0 + 1;
+            if (bw > 0 && bh > 0 && bw * bh <= kTileMaxPx) bb = make_int4(c0, r0, bw | (bh << 16), __float_as_int(zmin));
+          }
+          const int k2 = atomicAdd(&sh.nvis, 1);
+          st_vis[2 * k2] = e;
+          st_vis[2 * k2 + 1] = bb;
+        } else {
+          bool collect = false;
+          if (gc_on) {  // culled: untouched by this frame, so the stored summary already decides (vds.cu:1708-1711)
+            collect = (__uint_as_float(sm.x) >= trunc_threshold) || (sm.y == 0u);
+          }
+          if (collect) st_free[atomicAdd(&sh.nfree, 1)] = e;
+          else atomicAdd(&sh.nkeep, 1);
         }
-        const int k2 = atomicAdd(&sh.nvis, 1);
-        st_vis[2 * k2] = e;
-        st_vis[2 * k2 + 1] = bb;
-      } else {
-        bool collect = false;
-        if (gc_on) {  // culled: untouched by this frame, so the stored summary already decides (vds.cu:1708-1711)
-          collect = (__uint_as_float(sm.x) >= trunc_threshold) || (sm.y == 0u);
-        }
-        if (collect) st_free[atomicAdd(&sh.nfree, 1)] = e;
-        else atomicAdd(&sh.nkeep, 1);
       }
     }
     // the staging areas hold at least 4 / 8 more batches than one iteration can add: flush only when nearly full
     __syncthreads();
     if (sh.nvis > kStVis - 64 || sh.nfree > kStFree - 64) flush();
   }
+  };
+  sweep_range(t.desc_fine, f.summary, hwm, 0u);
+  if (MULTI) sweep_range(t.desc_coarse, f.summary_c, 8 * hwm, kValCoarseBit);
   flush();
   if (tid == 0 && sh.nkeep) atomicAdd(&t.ctr[cs + 1], sh.nkeep);
   MRH_TSF(4);
 #ifdef MRH_TRACE
-  if (tid == 0) f.trace[(kTraceFront + blockIdx.x) * 8 + 7] = (u64) (hi - lo) | (1ull << 63);
+  if (tid == 0) f.trace[(kTraceFront + blockIdx.x) * 8 + 7] = (u64) (hwm / n_sweep) | (1ull << 63);
 #endif
 }
 
-template <bool PROFILE>
+template <bool PROFILE, bool MULTI>
 __global__ __launch_bounds__(256) void k_front(const Cam c, const Map m, const Tab t, const Fast f, const Lists L,
                                                const float* __restrict__ depth, const uint8_t* __restrict__ rgb, const int tiles_x,
                                                const int n_tiles, const u32 stamp, const int parity, const int gc_on,
@@ -378,7 +386,7 @@ __global__ __launch_bounds__(256) void k_front(const Cam c, const Map m, const T
   const int n_sweep = (int) gridDim.x - n_tiles;  // the sweep workgroups come FIRST in the grid so that they start first
   MRH_TSF(0);
   if ((int) blockIdx.x >= n_sweep) front_tile<PROFILE>(c, m, t, f, L, depth, rgb, tiles_x, (int) blockIdx.x - n_sweep, stamp, cs, sh);
-  else front_sweep(c, m, t, f, L, stamp, cs, gc_on, trunc_threshold, (int) blockIdx.x, n_sweep, sh);
+  else front_sweep<MULTI>(c, m, t, f, L, stamp, cs, gc_on, trunc_threshold, (int) blockIdx.x, n_sweep, sh);
 }
 
 // pixel footprint of a block computed by the wave that is about to integrate it (lanes 0..7 take one corner each):
@@ -427,20 +435,107 @@ __device__ __forceinline__ void load_entry_scalar(const Lists& L, const int e, i
   zmin = __int_as_float(z);
 }
 
+// ---- multi-resolution maps (sdf_var_threshold > 0): coarse units on the fused path ---------------------------
+// A coarse unit u = 8 H + k lives in fine slot H at byte k * 768 as f32[64] | f32[64] | u32[64] (mrh_device.h).
+// Freeing one pushes the coarse free list, which the SAME launch pops when it coarsens fine blocks, and a stack
+// cannot take pushes and pops concurrently: the unit goes on the deferred list, k_mr_tail pushes it after the launch.
+__device__ __forceinline__ void wave_free_coarse(const Tab& t, const int4 ent, const int lane, u32* __restrict__ deferred) {
+  const u32 u = (u32) ent.w & ~kValCoarseBit;
+  if (lane == 0) {
+    u64 key;
+    pack_key(mki3(ent.x, ent.y, ent.z), key);
+    hash_erase(t, key);
+    t.desc_coarse[u].w = 0;
+    deferred[atomicAdd(&t.ctr[CTR_NREINT], 1)] = u;
+  }
+  u32* p = (u32*) (t.pool + (size_t) (u >> 3) * kFineBytes + (size_t) (u & 7) * kCoarseBytes);
+#pragma unroll
+  for (int k = 0; k < kCoarseBytes / 4 / kWave; k++) p[k * kWave + lane] = 0u;
+}
+__device__ __forceinline__ void wave_free_any(const Tab& t, const int4 ent, const int lane, u32* __restrict__ deferred) {
+  if ((u32) ent.w & kValCoarseBit) wave_free_coarse(t, ent, lane, deferred);
+  else wave_free_block(t, ent, lane);
+}
+
+// integrateDepthMapKernel on a coarse unit (64 voxels at twice the spacing, vds.cu:1114-1118), lane = voxel, then the
+// GC summary of the unit.  first_n < 64 restates reintegrateDepthMapKernel's launch shape (voxels 0..31 only, no
+// variance term: D2 in the oracle header).  Returns the GC decision (wave-uniform).
+template <bool VARIANCE>
+__device__ __forceinline__ bool coarse_block(const Cam& c, const Map& m, const Tab& t, const Fast& f, const float* __restrict__ depth,
+                                             const uint8_t* __restrict__ rgb, const int4 ent, const int lane, const int first_n,
+                                             const float trunc_threshold) {
+  const u32 val = (u32) ent.w;
+  const u32 u = val & ~kValCoarseBit;
+  const VoxPtr vp = vox_ptr(t, val);
+  const int v = lane;
+  float sd = vp.sdf[v], sq = vp.sumsq[v];
+  u32 rw = vp.rgbw[v];
+  if (v < first_n) {
+    const i3 pi = mki3(ent.x * kBlockSide + 2 * (v & 3), ent.y * kBlockSide + 2 * ((v >> 2) & 3), ent.z * kBlockSide + 2 * (v >> 4));
+    if (integrate_voxel<VARIANCE>(c, m, depth, rgb, pi, &sd, &sq, &rw)) { vp.sdf[v] = sd; vp.sumsq[v] = sq; vp.rgbw[v] = rw; }
+  }
+  const u32 wk = rw >> 24;
+  const float mn = __uint_as_float(wave_min_u32(umin_(0x7F7FFFFFu, wk != 0 ? (__float_as_uint(sd) & 0x7FFFFFFFu) : 0xFFFFFFFFu)));
+  const u32 mx = wave_max_u32(wk);
+  if (lane == 0) f.summary_c[u] = make_uint2(__float_as_uint(mn), mx);
+  return mn >= trunc_threshold || mx == 0;
+}
+
+// checkVarSDFKernel's decision for one fine block (vds.cu:1857-1939), from the block's (sum_squared, weight) pairs
+// parked in LDS: thread `lane` sums its 2x2x2 sub-cube in the kernel's dz, dy, dx order, then the kernel's 64-thread
+// shfl_down tree — the same association order, so the same float, so the same decision.
+__device__ __forceinline__ bool variance_says_coarsen(const Map& m, const uint2* __restrict__ sv, const int lane) {
+  float local_sum_sq = 0.f, local_weight = 0.f;
+  const int gx = (lane % 4) * 2, gy = ((lane / 4) % 4) * 2, gz = (lane / 16) * 2;
+#pragma unroll
+  for (int dz = 0; dz < 2; ++dz)
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx) {
+        const uint2 e = sv[(gz + dz) * 64 + (gy + dy) * 8 + (gx + dx)];
+        const u32 w = e.y >> 24;
+        if (w > 0) { local_sum_sq += __uint_as_float(e.x); local_weight += (float) w; }
+      }
+  for (int stride = 32; stride > 0; stride >>= 1) {
+    const float os = __shfl_down(local_sum_sq, stride);
+    const float ow = __shfl_down(local_weight, stride);
+    if (lane < stride) { local_sum_sq += os; local_weight += ow; }
+  }
+  int coarsen = 0;
+  if (lane == 0 && !(local_weight < 2)) {
+    const double avg_var = (double) (local_sum_sq / (local_weight - 1));
+    if ((local_weight - 1) > 1e-6f && avg_var > 0.f && avg_var < (double) m.var_threshold) coarsen = 1;
+  }
+  return __shfl(coarsen, 0) != 0;
+}
+
 // Integration of a list of blocks, one wave per block (integrateDepthMapKernel vds.cu:1095-1181 + GC summary + GC
 // decision, vds.cu:1674-1713); wave `gw` of `nw` takes entries gw, gw + nw, ...
 //   FREE  false: no GC here (starve frames decide after the weights changed); true: free on the spot (tombstone the
 //         key, push the free list, zero the 6 KiB)
-template <bool FREE, bool PROFILE>
+//   MULTI multi-resolution map: entries may be coarse units; a fine block is variance-checked right after its update
+//         and, if the reference would coarsen it, converted on the spot (checkVarSDF -> reallocBlocks ->
+//         reintegrateDepthMap, vds.cu:1857-2107): same table slot, new coarse unit, fine slot zeroed and released
+template <bool FREE, bool PROFILE, bool MULTI>
 __device__ __forceinline__ void back_range(const Cam& c, const Map& m, const Tab& t, const Fast& f, const Lists& L,
                                            const float trunc_threshold, const int n, const int gw, const int nw, const int lane,
-                                           uint2* tile) {
+                                           uint2* tile, const float* __restrict__ depth_raw, const uint8_t* __restrict__ rgb_raw,
+                                           u32* __restrict__ deferred) {
   const float r_half_vs = rcp_refined(m.vs / 2);
   for (int e = __builtin_amdgcn_readfirstlane(gw); e < n; e += nw) {
     MRH_TS(0);
     int4 ent, bb;
     float zmin;
     load_entry_scalar(L, e, ent, bb, zmin);
+    if (MULTI && ((u32) ent.w & kValCoarseBit)) {
+      const bool collect = coarse_block<true>(c, m, t, f, depth_raw, rgb_raw, ent, lane, kCoarseVoxels, trunc_threshold);
+      if (FREE && collect) {
+        wave_free_coarse(t, ent, lane, deferred);
+        if (PROFILE && lane == 0) atomicAdd(&t.prof[PROF_FREED], 1ull);
+      }
+      continue;
+    }
     const u32 H = (u32) ent.w;
     float4* ps = (float4*) (t.pool + (size_t) H * kFineBytes);
     float4* pq = ps + 128;
@@ -449,6 +544,11 @@ __device__ __forceinline__ void back_range(const Cam& c, const Map& m, const Tab
     uint4 W[2];
 #pragma unroll
     for (int b = 0; b < 2; b++) { S[b] = ps[lane + 64 * b]; W[b] = pw[lane + 64 * b]; }
+    float4 Q[2];  // MULTI: the variance check needs sum_squared of the voxels this frame does not update, too
+    if (MULTI) {
+#pragma unroll
+      for (int b = 0; b < 2; b++) Q[b] = pq[lane + 64 * b];
+    }
     if (bb.z == 0) bb = wave_bbox(c, m.vs, ent, lane, zmin);  // listed without a footprint (inserted this frame)
     Proj4 P[2];
     float d[2][4];
@@ -491,11 +591,16 @@ __device__ __forceinline__ void back_range(const Cam& c, const Map& m, const Tab
         float s[4] = {S[b].x, S[b].y, S[b].z, S[b].w};
         u32 w[4] = {W[b].x, W[b].y, W[b].z, W[b].w};
         float ss[4] = {0.f, 0.f, 0.f, 0.f};
+        if (MULTI) { ss[0] = Q[b].x; ss[1] = Q[b].y; ss[2] = Q[b].z; ss[3] = Q[b].w; }
         const u32 mask = update_mask4(c, m, P[b], d[b]);
 #ifdef MRH_TRACE
         trace_upd += __popc(mask);
 #endif
         blend4(m, P[b], mask, d[b], cpx[b], r_half_vs, s, w, ss);
+        if (MULTI) {  // (sum_squared, rgbw) of this lane's voxels q * 4 + k for the variance check below
+          W[b] = make_uint4(w[0], w[1], w[2], w[3]);
+          Q[b] = make_float4(ss[0], ss[1], ss[2], ss[3]);
+        }
         if (mask) {
           ps[q] = make_float4(s[0], s[1], s[2], s[3]);
           pw[q] = make_uint4(w[0], w[1], w[2], w[3]);
@@ -519,6 +624,60 @@ __device__ __forceinline__ void back_range(const Cam& c, const Map& m, const Tab
       mn = __uint_as_float(wave_min_u32(mnb));
       mx = wave_max_u32(mx);
       MRH_TS(5);
+      if (MULTI) {
+        __builtin_amdgcn_wave_barrier();  // every lane is done with the pixel tile: its LDS now holds the (sum_sq, rgbw) pairs
+        uint2* sv = tile;
+#pragma unroll
+        for (int b = 0; b < 2; b++) {
+          const int q = lane + 64 * b;
+          sv[q * 4 + 0] = make_uint2(__float_as_uint(Q[b].x), W[b].x);
+          sv[q * 4 + 1] = make_uint2(__float_as_uint(Q[b].y), W[b].y);
+          sv[q * 4 + 2] = make_uint2(__float_as_uint(Q[b].z), W[b].z);
+          sv[q * 4 + 3] = make_uint2(__float_as_uint(Q[b].w), W[b].w);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const bool coarsen = variance_says_coarsen(m, sv, lane);
+        __builtin_amdgcn_wave_barrier();
+        if (coarsen) {
+          // the block keeps its table slot; its payload moves to a coarse unit, the fine slot is zeroed and released
+          int uval = -1;
+          if (lane == 0) {
+            u64 key;
+            pack_key(mki3(ent.x, ent.y, ent.z), key);
+            const int slot = hash_find(t, key);
+            const int idx = atomicSub(&t.ctr[CTR_HEAP_COARSE], 1);
+            if (idx < 0 || slot < 0) {
+              atomicAdd(&t.ctr[CTR_HEAP_COARSE], 1);
+              if (slot >= 0) t.keys[slot] = kKeyTomb;
+              atomicOr((u32*) &t.ctr[CTR_ERROR], ERR_POOL);
+            } else {
+              const u32 u = t.heap_coarse[idx];
+              t.vals[slot] = u | kValCoarseBit;
+              t.desc_coarse[u] = make_int4(ent.x, ent.y, ent.z, 1);
+              uval = (int) u;
+            }
+            const int fi = atomicAdd(&t.ctr[CTR_HEAP_FINE], 1);
+            t.heap_fine[fi + 1] = H;  // vds.cu:53-57
+            t.desc_fine[H].w = 0;
+          }
+          uint4* pz = (uint4*) (t.pool + (size_t) H * kFineBytes);
+          const uint4 z = make_uint4(0, 0, 0, 0);
+#pragma unroll
+          for (int k = 0; k < kFineBytes / 16 / kWave; k++) pz[k * kWave + lane] = z;
+          uval = __shfl(uval, 0);
+          if (uval >= 0) {
+            const int4 ce = make_int4(ent.x, ent.y, ent.z, (int) ((u32) uval | kValCoarseBit));
+            const bool collect = coarse_block<false>(c, m, t, f, depth_raw, rgb_raw, ce, lane, 32, trunc_threshold);
+            if (FREE && collect) {
+              wave_free_coarse(t, ce, lane, deferred);
+              if (PROFILE && lane == 0) atomicAdd(&t.prof[PROF_FREED], 1ull);
+            }
+          }
+          continue;
+        }
+      }
       if (lane == 0) f.summary[H] = make_uint2(__float_as_uint(mn), mx);
     }
     if (FREE && (mn >= trunc_threshold || mx == 0)) {
@@ -534,10 +693,12 @@ __device__ __forceinline__ void back_range(const Cam& c, const Map& m, const Tab
 }
 
 // frees entries [0, n) of the culled-free (+ deferred-free) list, one wave per block
-template <bool PROFILE>
-__device__ __forceinline__ void free_range(const Tab& t, const Lists& L, const int n, const int gw, const int nw, const int lane) {
+template <bool PROFILE, bool MULTI>
+__device__ __forceinline__ void free_range(const Tab& t, const Lists& L, const int n, const int gw, const int nw, const int lane,
+                                           u32* __restrict__ deferred) {
   for (int e = gw; e < n; e += nw) {
-    wave_free_block(t, L.cfree[e], lane);
+    if (MULTI) wave_free_any(t, L.cfree[e], lane, deferred);
+    else wave_free_block(t, L.cfree[e], lane);
     if (PROFILE && lane == 0) atomicAdd(&t.prof[PROF_FREED], 1ull);
   }
 }
@@ -553,9 +714,10 @@ __device__ __forceinline__ void frame_epilogue(const Tab& t, const int parity, c
 }
 
 // ---- two-launch path: K2 = integrate + summary + GC of the visible list, then the culled-free list -------------
-template <bool FREE, bool PROFILE>
+template <bool FREE, bool PROFILE, bool MULTI>
 __global__ __launch_bounds__(256) void k_back(const Cam c, const Map m, const Tab t, const Fast f, const Lists L, const int parity,
-                                              const float trunc_threshold, const int stagger) {
+                                              const float trunc_threshold, const int stagger, const float* __restrict__ depth_raw,
+                                              const uint8_t* __restrict__ rgb_raw, u32* __restrict__ deferred) {
   extern __shared__ __attribute__((aligned(16))) uint2 s_tile[];
   (void) stagger;  // (a delayed start of every other workgroup was measured: it only lengthens the launch)
   const int cs = CTR_SET0 + 4 * parity;
@@ -570,8 +732,44 @@ __global__ __launch_bounds__(256) void k_back(const Cam c, const Map m, const Ta
   const int nkept = t.ctr[cs + 1];
   if (gw == 0) frame_epilogue(t, parity, nvis, nkept + t.ctr[cs + 2], lane);
   uint2* tile = &s_tile[(threadIdx.x >> 6) * kTileMaxPx];
-  back_range<FREE, PROFILE>(c, m, t, f, L, trunc_threshold, nvis, gw, nw, lane, tile);
-  if (FREE) free_range<PROFILE>(t, L, ncfree, gw, nw, lane);
+  back_range<FREE, PROFILE, MULTI>(c, m, t, f, L, trunc_threshold, nvis, gw, nw, lane, tile, depth_raw, rgb_raw, deferred);
+  if (FREE) free_range<PROFILE, MULTI>(t, L, ncfree, gw, nw, lane, deferred);
+}
+
+// after a multi-resolution k_back: the coarse units freed during the launch go onto the coarse free list
+__global__ __launch_bounds__(256) void k_mr_tail(const Tab t, const u32* __restrict__ deferred) {
+  const int n = t.ctr[CTR_NREINT];
+  __shared__ int s_base;
+  if (n == 0) return;
+  if (threadIdx.x == 0) s_base = atomicAdd(&t.ctr[CTR_HEAP_COARSE], n);
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += 256) t.heap_coarse[s_base + 1 + i] = deferred[i];
+  __syncthreads();
+  if (threadIdx.x == 0) t.ctr[CTR_NREINT] = 0;
+}
+
+// GC summaries of every live block and coarse unit from their payload (one wave each): run once when the fused
+// multi-resolution path takes over from frames that went through the general kernels (mrh_kernels.h)
+__global__ __launch_bounds__(256) void k_summarize_all(const Tab t, const Fast f) {
+  const int hwm = t.ctr[CTR_HWM_FINE];
+  const int lane = threadIdx.x & 63;
+  const int gw = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
+  for (int i = gw; i < 9 * hwm; i += nw) {
+    const bool coarse = i >= hwm;
+    const u32 idx = coarse ? (u32) (i - hwm) : (u32) i;
+    const int4 d = coarse ? t.desc_coarse[idx] : t.desc_fine[idx];
+    if (!(d.w & 1)) continue;
+    const VoxPtr vp = vox_ptr(t, coarse ? (idx | kValCoarseBit) : idx);
+    u32 mnb = 0x7F7FFFFFu, mx = 0;
+    for (int v = lane; v < (coarse ? kCoarseVoxels : 512); v += 64) {
+      const u32 wk = vp.rgbw[v] >> 24;
+      mnb = umin_(mnb, wk != 0 ? (__float_as_uint(vp.sdf[v]) & 0x7FFFFFFFu) : 0xFFFFFFFFu);
+      mx = umax_(mx, wk);
+    }
+    mnb = wave_min_u32(mnb);
+    mx = wave_max_u32(mx);
+    if (lane == 0) (coarse ? f.summary_c : f.summary)[idx] = make_uint2(mnb, mx);
+  }
 }
 
 // starve frames: GC after the weights changed — visible list by refreshed summary, plus the culled-free list

@@ -472,7 +472,10 @@ __global__ __launch_bounds__(512) void k_starve(const Cam c, const Map m, const 
 
 // decides on the device whether the coarse free list needs a refill (vds.cu:885-891 reads it on the host)
 __global__ void k_refill_decide(const Tab t, const int low_blocks_to_allocate, int* __restrict__ flag) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) *flag = (t.ctr[CTR_HEAP_COARSE] + 1 < low_blocks_to_allocate) ? 1 : 0;
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    *flag = (t.ctr[CTR_HEAP_COARSE] + 1 < low_blocks_to_allocate) ? 1 : 0;
+    t.ctr[CTR_NREINT] = 0;  // reintegrate list (general path) / deferred coarse frees (fused path) of this frame
+  }
 }
 // one thread per fine block converted: pops H from the fine list, pushes 8H+7 .. 8H (vds.cu:860-871)
 __global__ __launch_bounds__(256) void k_refill(const Tab t, const int low_blocks_to_allocate, const int* __restrict__ flag) {

@@ -196,6 +196,34 @@ def test_variance_adaptive_multires(hip, oracle):
     pu.compare_meshes(a, b)
 
 
+@pytest.mark.parametrize("fused", ["1", "0"], ids=["fused", "general"])
+def test_multires_fused_path_long_run(hip, oracle, monkeypatch, fused):
+    """Multi-resolution frames take the fused two-launch path (inline variance check, in-place coarsening, coarse
+    units integrated and collected by the same kernel) except frame 0, starve frames and the frame after each:
+    12 moving-camera frames with GC every frame and starve every 5th cross every transition; occupancy, free-list
+    counts, payload and mesh must match the oracle after every frame."""
+    monkeypatch.setenv("MRH_MR_FUSED", fused)
+    K = synth.Intrinsics(160.0, 160.0, 79.5, 59.5, 120, 160)
+    params = dict(synth.REPLICA_PARAMS, virtual_voxel_size=0.02, sdf_truncation=0.08, sdf_var_threshold=0.02,
+                  n_frames_invalidate_voxels=5)
+    a, b = _pair(hip, oracle, K, params, 32768)
+    scene = synth.scannet_room()
+    rng = np.random.default_rng(3)
+    saw_coarse = False
+    for i, (t, q) in enumerate(synth.walk_poses(12, seed=9)):
+        f = synth.render(scene, K, t, q, depth_scaling=5000.0, noise_sigma=0.003, rng=rng)
+        pu.feed(a, f)
+        pu.feed(b, f)
+        sa, sb = a.stats(), b.stats()
+        assert (sa.occupied_fine, sa.occupied_coarse, sa.free_fine, sa.free_coarse) == (sb.occupied_fine, sb.occupied_coarse, sb.free_fine, sb.free_coarse), f"frame {i}"
+        saw_coarse |= sa.occupied_coarse > 0
+    assert saw_coarse
+    a.sync()
+    r = pu.compare_maps(a, b)
+    assert r["blocks"] > 300
+    pu.compare_meshes(a, b)
+
+
 def test_multires_noisy_stream(hip, oracle):
     # the project page's sigma values (0.001 .. 0.01) on a noisy plane: mixed fine/coarse map + mesh
     params = dict(synth.CFG1_PARAMS, sdf_var_threshold=0.01, n_frames_invalidate_voxels=0)
