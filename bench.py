@@ -68,20 +68,27 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (torch.cuda.is_available() is False)")
-    torch.cuda.set_device(local_rank)
+    # MRH_BENCH_DEVICE / MRH_BENCH_BACKEND exist so that the multi-rank code path can be exercised on a 1-GPU box
+    # (two ranks sharing device 0 over gloo); the driver's runs use one GPU per rank over RCCL.
+    device_index = int(os.environ.get("MRH_BENCH_DEVICE", local_rank))
+    backend = os.environ.get("MRH_BENCH_BACKEND", "nccl")
+    torch.cuda.set_device(device_index)
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
 
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend=backend)
 
     from mrhash_amd import capi, synth
 
     hip = capi.load_hip()  # no fallback: raises if the HIP library is missing
     Kc = synth.REPLICA_640
-    params = capi.Params(num_sdf_blocks=args.blocks, device_id=local_rank, **synth.REPLICA_PARAMS)
+    params = capi.Params(num_sdf_blocks=args.blocks, device_id=device_index, **synth.REPLICA_PARAMS)
 
     # ---- synthetic stream: this rank's segment, uploaded to HBM before timing ------------------------------
     total = W + K
@@ -120,7 +127,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     st = eng.stats()

@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <array>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -1019,6 +1020,9 @@ int mrh_extract_triangles(mrh_ctx* c, const mrh_triangle** out_tris, uint64_t* o
   if (rc) return rc;
   if (!out_tris || !out_n) return MRH_ERR_INVALID_ARG;
   hipStream_t s = c->stream;
+  const bool dbg = getenv("MRH_DEBUG") != nullptr;
+  auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double t0 = now(), t1 = t0, t2 = t0, t3 = t0, t4 = t0, t5 = t0;
   int n = 0;
   rc = compact_all(c, &n);
   if (rc) return rc;
@@ -1037,6 +1041,7 @@ int mrh_extract_triangles(mrh_ctx* c, const mrh_triangle** out_tris, uint64_t* o
       return a.z < b.z;
     });
     HIP_TRY(c, hipMemcpy(c->tab.compact, list.data(), (size_t) n * sizeof(int4), hipMemcpyHostToDevice));
+    t1 = now();
     u32* d_counts = nullptr;
     u64* d_offsets = nullptr;
     HIP_TRY(c, hipMalloc((void**) &d_counts, (size_t) n * sizeof(u32)));
@@ -1046,6 +1051,7 @@ int mrh_extract_triangles(mrh_ctx* c, const mrh_triangle** out_tris, uint64_t* o
     std::vector<u32> counts((size_t) n);
     HIP_TRY(c, hipMemcpyAsync(counts.data(), d_counts, (size_t) n * sizeof(u32), hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
+    t2 = now();
     std::vector<u64> offsets((size_t) n);
     u64 total = 0;
     for (int i = 0; i < n; i++) { offsets[i] = total; total += counts[i]; }
@@ -1061,8 +1067,10 @@ int mrh_extract_triangles(mrh_ctx* c, const mrh_triangle** out_tris, uint64_t* o
       HIP_TRY(c, hipMalloc((void**) &d_tris, total * sizeof(mrh_triangle)));
       HIP_TRY(c, hipMemcpyAsync(d_offsets, offsets.data(), (size_t) n * sizeof(u64), hipMemcpyHostToDevice, s));
       k_mc<true><<<grid, 512, 0, s>>>(c->map, c->tab, c->tab.compact, n, d_counts, d_offsets, d_tris, total);
+      if (dbg) { HIP_TRY(c, hipStreamSynchronize(s)); t3 = now(); }
       c->tris.resize(total);
       HIP_TRY(c, hipMemcpyAsync(c->tris.data(), d_tris, total * sizeof(mrh_triangle), hipMemcpyDeviceToHost, s));
+      if (dbg) { HIP_TRY(c, hipStreamSynchronize(s)); t4 = now(); }
       int prc = MRH_OK;
       if (!c->mesh_on_host) { prc = process_triangles_device(c, d_tris, total); processed = true; }
       HIP_TRY(c, hipStreamSynchronize(s));
@@ -1075,6 +1083,9 @@ int mrh_extract_triangles(mrh_ctx* c, const mrh_triangle** out_tris, uint64_t* o
   }
   c->last_triangles = c->tris.size();
   if (!processed) process_triangles(c);
+  t5 = now();
+  if (dbg) fprintf(stderr, "[mrhash_hip] extract: %d blocks, %zu triangles | list+sort %.2f ms, count %.2f, emit %.2f, soup D2H %.2f, post-process + V/F/C D2H %.2f, total %.2f\n",
+                   n, c->tris.size(), t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4, t5 - t0);
   *out_tris = c->tris.empty() ? nullptr : c->tris.data();
   *out_n = c->tris.size();
   return MRH_OK;
