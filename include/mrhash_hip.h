@@ -196,6 +196,20 @@ int mrh_integrate(mrh_ctx* ctx, int n_frames_invalidate);
 int mrh_exchange_buffer(mrh_ctx* ctx, void** out_ptr, uint64_t* out_count_int64, int* out_is_device_memory);
 int mrh_integrate_resume(mrh_ctx* ctx);
 
+/* ---- LiDAR scans (BASELINE.json configs[4]) --------------------------------------------------
+ * Replaces GeoWrapper::setPointCloud (geowrapper.cpp:323-372, pybind/pygeowrapper.cpp:66-76: the point matrix is
+ * copied) and VoxelContainer::integrate(point_cloud, normals, weights, camera, max_num_frames)
+ * (voxel_data_structures.cpp:112-135) = allocBlocks3D (vds.cu:925-1092) + integrate3D (vds.cu:1215-1410).
+ * xyz: n points, sensor frame, float32 [n][3]; the pose is the one given to mrh_set_pose, the integration distance
+ * the max_depth given to mrh_set_camera (either camera model; no image is involved).
+ * Scope = the shipped LiDAR configurations (vbr / maicity / newer_college .cfg): projective SDF without normals,
+ * n_frames_invalidate_voxels = 0 and sdf_var_threshold = 0 — anything else returns MRH_ERR_UNSUPPORTED.
+ * The reference updates a voxel with a non-atomic read-modify-write per point (a race between the points of a
+ * scan); here every voxel receives its updates in ascending point index (oracle header, D6). */
+int mrh_upload_points(mrh_ctx* ctx, const float* xyz, uint64_t n);
+int mrh_set_points_device(mrh_ctx* ctx, const float* d_xyz, uint64_t n); /* zero-copy: device pointer, valid until the next integrate returns */
+int mrh_integrate_points(mrh_ctx* ctx, int n_frames_invalidate);
+
 /* Blocks until every enqueued frame has executed; surfaces sticky device error flags as
  * MRH_ERR_CAPACITY / MRH_ERR_OUT_OF_RANGE. */
 int mrh_sync(mrh_ctx* ctx);

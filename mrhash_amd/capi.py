@@ -96,6 +96,7 @@ assert TRI_DTYPE.itemsize == 24
 ABI_SYMBOLS = (
     "mrh_create mrh_destroy mrh_reset mrh_last_error mrh_set_camera mrh_set_pose mrh_upload_depth "
     "mrh_upload_rgb mrh_set_depth_device mrh_set_rgb_device mrh_integrate mrh_integrate_resume mrh_exchange_buffer mrh_sync "
+    "mrh_upload_points mrh_set_points_device mrh_integrate_points "
     "mrh_extract_triangles mrh_extract_mesh mrh_get_stats mrh_set_profile mrh_dump_blocks "
     "mrh_get_voxel mrh_import_blocks mrh_get_triangle_blocks mrh_process_triangles mrh_selftest_division mrh_version"
 ).split()
@@ -121,6 +122,9 @@ def _declare(lib: C.CDLL) -> C.CDLL:
     lib.mrh_set_depth_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
     lib.mrh_set_rgb_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
     lib.mrh_integrate.argtypes = [C.c_void_p, C.c_int]
+    lib.mrh_upload_points.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+    lib.mrh_set_points_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+    lib.mrh_integrate_points.argtypes = [C.c_void_p, C.c_int]
     lib.mrh_integrate_resume.argtypes = [C.c_void_p]
     lib.mrh_exchange_buffer.argtypes = [C.c_void_p, P(C.c_void_p), P(C.c_uint64), P(C.c_int)]
     lib.mrh_sync.argtypes = [C.c_void_p]
@@ -158,6 +162,9 @@ def load_hip() -> C.CDLL:
     """The product library. Raises (never falls back) when it has not been built."""
     global _hip_lib
     if _hip_lib is None:
+        from ._runtime import torch_first
+
+        torch_first()  # see _runtime.py: torch's HIP runtime has to initialise before this library's
         _hip_lib = load_library(HIP_LIB_PATH)
     return _hip_lib
 
@@ -265,6 +272,19 @@ class Engine:
         self._check(self.lib.mrh_set_rgb_device(self._ctx, ptr, rows, cols))
 
     # -- hot path ------------------------------------------------------------------------------
+    def upload_points(self, xyz: np.ndarray):
+        """GeoWrapper.setPointCloud: float32 [N, 3] points in the sensor frame (copied)."""
+        if xyz.ndim != 2 or xyz.shape[1] != 3:
+            raise RuntimeError("GeoWrapper::setPointCloud|input should be a 2D numpy array with 3 columns")
+        a = np.ascontiguousarray(xyz, dtype=np.float32)
+        self._check(self.lib.mrh_upload_points(self._ctx, a.ctypes.data, a.shape[0]))
+
+    def set_points_device(self, ptr: int, n: int):
+        self._check(self.lib.mrh_set_points_device(self._ctx, ptr, n))
+
+    def integrate_points(self, n_frames_invalidate: int = -1):
+        self._check(self.lib.mrh_integrate_points(self._ctx, n_frames_invalidate))
+
     def integrate(self, n_frames_invalidate: int = -1) -> bool:
         """Enqueues one frame.  Returns True when a sharded context stopped for a min-reduction over ranks
         (MRH_PENDING_EXCHANGE): reduce `exchange_buffer()` and call `integrate_resume()` until it returns False

@@ -96,8 +96,6 @@ void GeoWrapper::setPointCloud(const float* pts, size_t n, const float* normals_
 }
 
 void GeoWrapper::compute() {
-  if (!point_cloud_.empty())
-    throw std::runtime_error("GeoWrapper::compute | LiDAR point-cloud integration (integrate3D) is outside this library's scope (SURVEY.md §8f-2)");
   const float R[9] = {pose_[0], pose_[1], pose_[2], pose_[4], pose_[5], pose_[6], pose_[8], pose_[9], pose_[10]};
   const float t[3] = {pose_[3], pose_[7], pose_[11]};
   check(mrh_set_pose(ctx_, R, t), "compute");
@@ -105,6 +103,13 @@ void GeoWrapper::compute() {
     check(mrh_upload_depth(ctx_, depth_.data(), (int) depth_rows_, (int) depth_cols_), "compute");
     check(mrh_upload_rgb(ctx_, rgb_.data(), (int) rgb_rows_, (int) rgb_cols_), "compute");
     check(mrh_integrate(ctx_, n_frames_invalidate_voxels_), "compute");
+  }
+  if (!point_cloud_.empty()) {  // geowrapper.cpp:146-147: VoxelContainer::integrate(point_cloud, eigenvectors, weights, ...)
+    if (!normals_.empty())
+      throw std::runtime_error("GeoWrapper::compute | normal-direction SDF (point cloud with normals) is outside this library's scope; "
+                               "pass the points only (projective SDF), as the reference's LiDAR runners do");
+    check(mrh_upload_points(ctx_, point_cloud_.data(), point_cloud_.size() / 3), "compute");
+    check(mrh_integrate_points(ctx_, n_frames_invalidate_voxels_), "compute");
   }
 }
 

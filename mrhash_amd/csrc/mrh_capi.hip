@@ -24,6 +24,7 @@
 #include "mrh_pipe.h"
 #include "mrh_fast2.h"
 #include "mrh_mesh.h"
+#include "mrh_lidar.h"
 
 using namespace mrh;
 
@@ -75,6 +76,13 @@ struct mrh_ctx {
   int overlap = 0;        // MRH_OVERLAP=1: rays of frame f+1 on a second stream (mrh_pipe.h; host-bound, off by default)
   int merged = 1;         // MRH_MERGED=0: three-launch path (k_alloc2 / k_compact2 / k_fused) instead of k_front / k_back
   int4* d_cfree = nullptr;
+  // LiDAR scan of the current frame (mrh_lidar.h)
+  float* d_points = nullptr;        // owned copy (mrh_upload_points) ...
+  const float* d_points_cur = nullptr;  // ... or the caller's device pointer (mrh_set_points_device)
+  uint64_t points_cap = 0, num_points = 0;
+  u32* d_pt_counts = nullptr; u32* d_pt_offsets = nullptr; uint64_t pt_cap = 0;
+  u64* d_rec_keys[2] = {nullptr, nullptr}; float* d_rec_vals[2] = {nullptr, nullptr}; uint64_t rec_cap = 0;
+  void* d_sort_tmp = nullptr; size_t sort_tmp_bytes = 0;
   int mr_fused = 1;          // MRH_MR_FUSED=0: multi-resolution maps always through the general kernels (mrh_kernels.h)
   bool mr_next_general = true;    // the next multi-resolution frame must take the general path (frame 0 / after a starve frame / after an import)
   bool mr_summaries_valid = false;  // fast.summary / summary_c describe every live block (the general kernels do not maintain them)
@@ -158,7 +166,7 @@ void free_all(mrh_ctx* c) {
   F(c->tab.keys); F(c->tab.vals); F(c->tab.heap_fine); F(c->tab.heap_coarse); F(c->tab.desc_fine); F(c->tab.desc_coarse);
   F(c->tab.pool); F(c->tab.compact); F(c->tab.ctr); F(c->tab.prof);
   F(c->d_depth_own); F(c->d_rgb_own); F(c->d_decision); F(c->d_zbuf); F(c->d_realloc); F(c->d_reint); F(c->d_flag);
-  F(c->d_upd_partials); F(c->d_misc); F(c->d_cfree); F(c->d_zmin); F(c->fast.summary); F(c->fast.summary_c); F(c->fast.bbox); F(c->d_cnt_partials);
+  F(c->d_upd_partials); F(c->d_misc); F(c->d_cfree); F(c->d_zmin); F(c->d_points); F(c->d_pt_counts); F(c->d_pt_offsets); F(c->d_rec_keys[0]); F(c->d_rec_keys[1]); F(c->d_rec_vals[0]); F(c->d_rec_vals[1]); F(c->d_sort_tmp); F(c->fast.summary); F(c->fast.summary_c); F(c->fast.bbox); F(c->d_cnt_partials);
   for (auto& e : c->ev_pool) { (void) hipEventDestroy(e.a); (void) hipEventDestroy(e.b); }
   for (auto& e : c->ev_pending) { (void) hipEventDestroy(e.a); (void) hipEventDestroy(e.b); }
   if (c->stream) (void) hipStreamDestroy(c->stream);
@@ -924,6 +932,122 @@ int mrh_integrate(mrh_ctx* c, int n_frames_invalidate) {
   }
 
   return starve_and_tail(c, max_num_frames);
+}
+
+int mrh_upload_points(mrh_ctx* c, const float* xyz, uint64_t n) {
+  int rc = ensure_ready(c, "mrh_upload_points");
+  if (rc) return rc;
+  if (n && !xyz) return fail(c, MRH_ERR_INVALID_ARG, "mrh_upload_points: null argument");
+  if (n > c->points_cap) {
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->d_points) HIP_TRY(c, hipFree(c->d_points));
+    c->d_points = nullptr;
+    HIP_TRY(c, hipMalloc((void**) &c->d_points, n * 3 * sizeof(float)));
+    c->points_cap = n;
+  }
+  if (n) HIP_TRY(c, hipMemcpyAsync(c->d_points, xyz, n * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));  // the caller's buffer is free on return (GeoWrapper::setPointCloud copies)
+  c->d_points_cur = c->d_points;
+  c->num_points = n;
+  return MRH_OK;
+}
+
+int mrh_set_points_device(mrh_ctx* c, const float* d_xyz, uint64_t n) {
+  int rc = ensure_ready(c, "mrh_set_points_device");
+  if (rc) return rc;
+  if (n && !d_xyz) return fail(c, MRH_ERR_INVALID_ARG, "mrh_set_points_device: null argument");
+  c->d_points_cur = d_xyz;
+  c->num_points = n;
+  return MRH_OK;
+}
+
+// VoxelContainer::integrate(point_cloud, ...) voxel_data_structures.cpp:112-135 (mrh_lidar.h)
+int mrh_integrate_points(mrh_ctx* c, int n_frames_invalidate) {
+  int rc = ensure_ready(c, "mrh_integrate_points");
+  if (rc) return rc;
+  if (c->pending) return fail(c, MRH_ERR_STATE, "mrh_integrate_points: an exchange is pending (call mrh_integrate_resume)");
+  if (!c->has_camera) return fail(c, MRH_ERR_STATE, "mrh_integrate_points: set_camera has not been called");
+  const int max_num_frames = n_frames_invalidate < 0 ? c->p.n_frames_invalidate_voxels : n_frames_invalidate;
+  if (max_num_frames > 0) return fail(c, MRH_ERR_UNSUPPORTED, "mrh_integrate_points: garbage collection on LiDAR scans (spherical projection) is outside this round's scope");
+  if (c->tab.multi_res) return fail(c, MRH_ERR_UNSUPPORTED, "mrh_integrate_points: variance-adaptive resolution on LiDAR scans (reintegrate3D) is outside this round's scope");
+  if (!c->p.projective_sdf) return fail(c, MRH_ERR_UNSUPPORTED, "mrh_integrate_points: normal-direction SDF needs normals, which this boundary does not carry");
+  const uint64_t n = c->num_points;
+  if (n >= (1ull << 24)) return fail(c, MRH_ERR_CAPACITY, "mrh_integrate_points: %llu points in one scan (limit 2^24 - 1)", (unsigned long long) n);
+  hipStream_t s = c->stream;
+  const Cam& k = c->cam;
+  const Map& m = c->map;
+  const Tab& t = c->tab;
+  if (n > 0) {
+    const u32 np = (u32) n, grid = (np + 255) / 256;
+    const float* pts = c->d_points_cur;
+    const u32 stamp = (u32) ((c->frames + 1) & 0x3FFFFFFFu);
+    k_alloc3d<<<grid, 256, 0, s>>>(k, m, t, c->fast, pts, np, stamp);
+    if (n > c->pt_cap) {
+      HIP_TRY(c, hipStreamSynchronize(s));
+      if (c->d_pt_counts) HIP_TRY(c, hipFree(c->d_pt_counts));
+      if (c->d_pt_offsets) HIP_TRY(c, hipFree(c->d_pt_offsets));
+      c->d_pt_counts = c->d_pt_offsets = nullptr;
+      HIP_TRY(c, hipMalloc((void**) &c->d_pt_counts, n * sizeof(u32)));
+      HIP_TRY(c, hipMalloc((void**) &c->d_pt_offsets, n * sizeof(u32)));
+      c->pt_cap = n;
+    }
+    k_points_walk<false><<<grid, 256, 0, s>>>(k, m, t, pts, np, c->d_pt_counts, nullptr, nullptr, nullptr, 0);
+    size_t need = 0;
+    HIP_TRY(c, rocprim::exclusive_scan(nullptr, need, c->d_pt_counts, c->d_pt_offsets, 0u, n, rocprim::plus<u32>(), s));
+    auto ensure_tmp = [&](size_t bytes) -> int {
+      if (bytes <= c->sort_tmp_bytes) return MRH_OK;
+      HIP_TRY(c, hipStreamSynchronize(s));
+      if (c->d_sort_tmp) HIP_TRY(c, hipFree(c->d_sort_tmp));
+      c->d_sort_tmp = nullptr;
+      HIP_TRY(c, hipMalloc(&c->d_sort_tmp, bytes));
+      c->sort_tmp_bytes = bytes;
+      return MRH_OK;
+    };
+    rc = ensure_tmp(need);
+    if (rc) return rc;
+    size_t tb = c->sort_tmp_bytes;
+    HIP_TRY(c, rocprim::exclusive_scan(c->d_sort_tmp, tb, c->d_pt_counts, c->d_pt_offsets, 0u, n, rocprim::plus<u32>(), s));
+    u32 last_off = 0, last_cnt = 0;
+    int hwm = 0;
+    HIP_TRY(c, hipMemcpyAsync(&hwm, &t.ctr[CTR_HWM_FINE], sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(&last_off, c->d_pt_offsets + (n - 1), sizeof(u32), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(&last_cnt, c->d_pt_counts + (n - 1), sizeof(u32), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    const uint64_t n_rec = (uint64_t) last_off + last_cnt;
+    if (n_rec >= 0xFFFFFFF0ull) return fail(c, MRH_ERR_CAPACITY, "mrh_integrate_points: %llu voxel updates in one scan", (unsigned long long) n_rec);
+    if (n_rec > 0) {
+      if (n_rec > c->rec_cap) {
+        for (int b = 0; b < 2; b++) {
+          if (c->d_rec_keys[b]) HIP_TRY(c, hipFree(c->d_rec_keys[b]));
+          if (c->d_rec_vals[b]) HIP_TRY(c, hipFree(c->d_rec_vals[b]));
+          c->d_rec_keys[b] = nullptr; c->d_rec_vals[b] = nullptr;
+        }
+        const uint64_t cap = n_rec + n_rec / 4;
+        for (int b = 0; b < 2; b++) {
+          HIP_TRY(c, hipMalloc((void**) &c->d_rec_keys[b], cap * sizeof(u64)));
+          HIP_TRY(c, hipMalloc((void**) &c->d_rec_vals[b], cap * sizeof(float)));
+        }
+        c->rec_cap = cap;
+      }
+      // sort key = voxel id above the point index; only the bits that can be set take part in the radix passes
+      auto bits_for = [](uint64_t max_value) { int b = 1; while (b < 63 && (max_value >> b)) b++; return b; };
+      const int pbits = bits_for(n - 1);
+      const int end_bit = pbits + bits_for((uint64_t) (hwm > 0 ? hwm : 1) * 512 - 1);
+      k_points_walk<true><<<grid, 256, 0, s>>>(k, m, t, pts, np, nullptr, c->d_pt_offsets, c->d_rec_keys[0], c->d_rec_vals[0], pbits);
+      need = 0;
+      HIP_TRY(c, rocprim::radix_sort_pairs(nullptr, need, c->d_rec_keys[0], c->d_rec_keys[1], c->d_rec_vals[0], c->d_rec_vals[1], n_rec, 0, end_bit, s));
+      rc = ensure_tmp(need);
+      if (rc) return rc;
+      tb = c->sort_tmp_bytes;
+      HIP_TRY(c, rocprim::radix_sort_pairs(c->d_sort_tmp, tb, c->d_rec_keys[0], c->d_rec_keys[1], c->d_rec_vals[0], c->d_rec_vals[1], n_rec, 0, end_bit, s));
+      k_points_apply<<<(u32) ((n_rec + 255) / 256), 256, 0, s>>>(m, t, c->d_rec_keys[1], c->d_rec_vals[1], (u32) n_rec, pbits);
+    }
+    // the GC summaries (used by later depth frames for blocks outside the image) follow the payload
+    k_summarize_all<<<1024, 256, 0, s>>>(t, c->fast);
+  }
+  c->frames++;
+  HIP_TRY(c, hipGetLastError());
+  return MRH_OK;
 }
 
 int mrh_integrate_resume(mrh_ctx* c) {

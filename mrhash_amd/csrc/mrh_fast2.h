@@ -754,7 +754,7 @@ __global__ __launch_bounds__(256) void k_summarize_all(const Tab t, const Fast f
   const int hwm = t.ctr[CTR_HWM_FINE];
   const int lane = threadIdx.x & 63;
   const int gw = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
-  for (int i = gw; i < 9 * hwm; i += nw) {
+  for (int i = gw; i < (t.multi_res ? 9 : 1) * hwm; i += nw) {
     const bool coarse = i >= hwm;
     const u32 idx = coarse ? (u32) (i - hwm) : (u32) i;
     const int4 d = coarse ? t.desc_coarse[idx] : t.desc_fine[idx];

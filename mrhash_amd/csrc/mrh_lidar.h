@@ -1,0 +1,230 @@
+// mrh_lidar.h — LiDAR scans: VoxelContainer::integrate(point_cloud, normals, weights, camera, max_num_frames)
+// (voxel_data_structures.cpp:112-135) for the shipped LiDAR configurations (projective SDF, no normals, no GC, single
+// resolution; include/mrhash_hip.h states the scope).
+//
+//   k_alloc3d        allocBlocks3DKernel vds.cu:925-1033 + the host retry loop :1036-1092.  256 points per workgroup:
+//                    block-level DDA over the segment range -+ truncation along the beam, keys de-duplicated in an LDS
+//                    set, then one probe per distinct key and the lock-free insert of mrh_fast2.h (no mutex, no retry).
+//   k_points_walk    integrate3DKernel vds.cu:1215-1379, split in two so that the result does not depend on a race:
+//                    the reference updates a voxel with a non-atomic read-modify-write per point.  Here a point's
+//                    VOXEL-level DDA only produces (voxel, point, clamped sdf) records — counted, prefix-summed and
+//                    written at exact offsets, no atomics — the records are sorted by (voxel, point index)
+//                    (rocPRIM radix sort on a 55-bit key) and
+//   k_points_apply   one lane per voxel folds its records in ascending point index (combineVoxel, vhu.cuh:167-181, and
+//                    the variance term) — the oracle's sequential order (D6), with plain coalesced loads and stores.
+#pragma once
+
+#include <rocprim/rocprim.hpp>
+
+#include "mrh_fast2.h"
+
+namespace mrh {
+
+__device__ __forceinline__ float norm3(const f3 p) { return sqrtf((p.x * p.x + p.y * p.y) + p.z * p.z); }  // norm3df restated
+__device__ __forceinline__ f3 normalize3(const f3 p) {
+  const float inv = 1.0f / sqrtf((p.x * p.x + p.y * p.y) + p.z * p.z);
+  return mk3(p.x * inv, p.y * inv, p.z * inv);
+}
+__device__ __forceinline__ i3 voxel_to_block_fast(const Map& m, const i3 v) {
+  const int ax = v.x < 0 ? -v.x : v.x, ay = v.y < 0 ? -v.y : v.y, az = v.z < 0 ? -v.z : v.z;
+  if ((u32) (ax | ay | az) < (u32) m.block_shift_limit) return mki3(v.x >> 3, v.y >> 3, v.z >> 3);
+  return voxel_to_block(v, m.vs);
+}
+
+__global__ __launch_bounds__(256) void k_alloc3d(const Cam c, const Map m, const Tab t, const Fast f, const float* __restrict__ pts,
+                                                 const u32 n, const u32 stamp) {
+  __shared__ FrontShared sh;
+  constexpr int NT = 256;
+  const int tid = threadIdx.x;
+  const int hwm0 = t.ctr[CTR_HWM_FINE];
+  for (int i = tid; i < kRayCap; i += NT) sh.set[i] = kKeyEmpty;
+  if (tid == 0) sh.count = 0;
+  __syncthreads();
+  auto insert_direct = [&](const i3 cur, const u64 key) {
+    const int slot = hash_insert(t, key);
+    if (slot == -2) atomicOr((u32*) &t.ctr[CTR_ERROR], ERR_TABLE);
+    if (slot < 0) return;
+    (void) commit_block(t, f, slot, atomicSub(&t.ctr[CTR_HEAP_FINE], 1), cur, stamp, hwm0);
+  };
+  const u32 i = blockIdx.x * NT + tid;
+  if (i < n) {
+    const f3 pcam = mk3(pts[3 * (size_t) i], pts[3 * (size_t) i + 1], pts[3 * (size_t) i + 2]);
+    const float range = norm3(pcam);
+    const float tr = get_truncation(range, m.trunc, m.trunc_scale);
+    const float dmin = fminf(c.max_int_dist, range - tr), dmax = fminf(c.max_int_dist, range + tr);
+    if (range != 0.f && !(dmin >= dmax)) {
+      const f3 dir = normalize3(pcam);
+      const float a = dmin - range, b = dmax - range;
+      const f3 pw_min = se3_apply(c.R, c.t, mk3(pcam.x + dir.x * a, pcam.y + dir.y * a, pcam.z + dir.z * a));
+      const f3 pw_max = se3_apply(c.R, c.t, mk3(pcam.x + dir.x * b, pcam.y + dir.y * b, pcam.z + dir.z * b));
+      const RayState ray = ray_from_segment(m, pw_min, pw_max);
+      bool slow = !ray_keys_in_range(ray);
+      if (!slow) {
+        slow = !walk_ray_lean(m, ray, [&](const i3 cur, const u64 key) {
+          u32 s = (u32) __mul24(cur.z, 5851) + (u32) __mul24(cur.y, 73) + (u32) cur.x;
+          s = (s ^ (s >> 7)) & (kRayCap - 1);
+#pragma unroll 1
+          for (int p = 0; p < kSetProbe; p++) {
+            const u64 old = atomicCAS(&sh.set[s], kKeyEmpty, key);
+            if (old == kKeyEmpty) { sh.list[atomicAdd(&sh.count, 1u)] = key; return true; }
+            if (old == key) return true;
+            s = (s + 1) & (kRayCap - 1);
+          }
+          return false;
+        });
+      }
+      if (slow) {  // LDS set saturated or keys out of range: the literal walk with direct inserts
+        RayState r = ray;
+#pragma unroll 1
+        for (u32 iter = 0; iter < kMaxDdaIter; iter++) {
+          u64 key;
+          if (!pack_key(r.cur, key)) atomicOr((u32*) &t.ctr[CTR_ERROR], ERR_RANGE);
+          else if (owns_block(m, r.cur)) insert_direct(r.cur, key);
+          const bool ax = r.t_max.x < r.t_max.y && r.t_max.x < r.t_max.z;
+          const bool az = !ax && (r.t_max.z < r.t_max.y);
+          const bool ay = !ax && !az;
+          r.cur.x += ax ? r.step.x : 0; r.cur.y += ay ? r.step.y : 0; r.cur.z += az ? r.step.z : 0;
+          if ((ax && r.cur.x == r.bound.x) || (ay && r.cur.y == r.bound.y) || (az && r.cur.z == r.bound.z)) break;
+          r.t_max.x = ax ? r.t_max.x + r.t_delta.x : r.t_max.x;
+          r.t_max.y = ay ? r.t_max.y + r.t_delta.y : r.t_max.y;
+          r.t_max.z = az ? r.t_max.z + r.t_delta.z : r.t_max.z;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const int nk = (int) sh.count;
+#pragma unroll 1
+  for (int base = 0; base < nk; base += NT) {
+    const int j = base + tid;
+    const bool active = j < nk;
+    const u64 key = active ? sh.list[j] : kKeyEmpty;
+    const i3 b = active ? unpack_key(key) : mki3(0, 0, 0);
+    bool won = false;
+    int slot = -1, claim;
+    u64 claim_val;
+    if (active && hash_find_claim(t, key, claim, claim_val) < 0) {  // no frustum test on this path (vds.cu:1010)
+      slot = hash_insert_at(t, key, claim, claim_val);
+      if (slot == -2) atomicOr((u32*) &t.ctr[CTR_ERROR], ERR_TABLE);
+      won = slot >= 0;
+    }
+    const u64 ballot = __ballot(won);
+    if (ballot) {
+      const int leader = __ffsll((long long) ballot) - 1;
+      int hb = 0;
+      if ((int) lane_id() == leader) hb = atomicSub(&t.ctr[CTR_HEAP_FINE], __popcll(ballot));
+      hb = __shfl(hb, leader);
+      if (won) (void) commit_block(t, f, slot, hb - __popcll(ballot & lanemask_lt()), b, stamp, hwm0);
+    }
+  }
+}
+
+// One record per (point, traversed voxel of an allocated block) up to the first voxel with sdf <= -truncation.
+// EMIT = false: counts[i] = number of records of point i.  EMIT = true: records written at offsets[i]...
+//   key = (block index * 512 + voxel index) << pbits | point index     value = the clamped sdf
+// (pbits = bits needed for the point index: the sort then only has to look at pbits + bits(live voxels) key bits)
+template <bool EMIT>
+__global__ __launch_bounds__(256) void k_points_walk(const Cam c, const Map m, const Tab t, const float* __restrict__ pts, const u32 n,
+                                                     u32* __restrict__ counts, const u32* __restrict__ offsets, u64* __restrict__ keys,
+                                                     float* __restrict__ vals, const int pbits) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u32 cnt = 0;
+  const u32 out = EMIT ? offsets[i] : 0u;
+  const f3 pcam = mk3(pts[3 * (size_t) i], pts[3 * (size_t) i + 1], pts[3 * (size_t) i + 2]);
+  const float range = norm3(pcam);
+  const float tr = get_truncation(range, m.trunc, m.trunc_scale);
+  const float dmin = fminf(c.max_int_dist, range - tr), dmax = fminf(c.max_int_dist, range + tr);
+  if (!((double) range < 1e-6 || range > c.max_int_dist) && !(dmin >= dmax)) {
+    const f3 dir0 = normalize3(pcam);
+    const f3 pw_min = se3_apply(c.R, c.t, mk3(pcam.x - dir0.x * tr, pcam.y - dir0.y * tr, pcam.z - dir0.z * tr));
+    const f3 pw_max = se3_apply(c.R, c.t, mk3(pcam.x + dir0.x * tr, pcam.y + dir0.y * tr, pcam.z + dir0.z * tr));
+    // voxel-level DDA (vds.cu:1257-1296)
+    const f3 dir = normalize3(mk3(pw_max.x - pw_min.x, pw_max.y - pw_min.y, pw_max.z - pw_min.z));
+    i3 cur = world_to_voxel(m.vs, pw_min);
+    const i3 end = world_to_voxel(m.vs, pw_max);
+    const f3 step = mk3((float) signi(dir.x), (float) signi(dir.y), (float) signi(dir.z));
+    const i3 istep = mki3(signi(dir.x), signi(dir.y), signi(dir.z));
+    const i3 nb = mki3(cur.x + f2i(clampf(step.x, 0.0f, 1.f)), cur.y + f2i(clampf(step.y, 0.0f, 1.f)), cur.z + f2i(clampf(step.z, 0.0f, 1.f)));
+    const f3 bw = voxel_to_world(m.vs, nb);
+    const f3 boundary = mk3(bw.x - 0.5f * m.vs, bw.y - 0.5f * m.vs, bw.z - 0.5f * m.vs);
+    f3 t_max = mk3((boundary.x - pw_min.x) / dir.x, (boundary.y - pw_min.y) / dir.y, (boundary.z - pw_min.z) / dir.z);
+    f3 t_delta = mk3((step.x * m.vs) / dir.x, (step.y * m.vs) / dir.y, (step.z * m.vs) / dir.z);
+    const i3 bound = mki3(f2i((float) end.x + step.x), f2i((float) end.y + step.y), f2i((float) end.z + step.z));
+    const bool gx = (fabsf(dir.x) < kFloatEps) || (fabsf(boundary.x - dir.x) < kFloatEps);
+    const bool gy = (fabsf(dir.y) < kFloatEps) || (fabsf(boundary.y - dir.y) < kFloatEps);
+    const bool gz = (fabsf(dir.z) < kFloatEps) || (fabsf(boundary.z - dir.z) < kFloatEps);
+    t_max.x = gx ? kFltMax : t_max.x; t_delta.x = gx ? kFltMax : t_delta.x;
+    t_max.y = gy ? kFltMax : t_max.y; t_delta.y = gy ? kFltMax : t_delta.y;
+    t_max.z = gz ? kFltMax : t_max.z; t_delta.z = gz ? kFltMax : t_delta.z;
+#pragma unroll 1
+    for (u32 iter = 0; iter < kMaxDdaIter; iter++) {
+      const i3 block = voxel_to_block_fast(m, cur);
+      u64 bkey;
+      int slot = -1;
+      if (pack_key(block, bkey)) slot = hash_find(t, bkey);
+      if (slot >= 0) {
+        const f3 pc = se3_apply(c.Ri, c.ti, voxel_to_world(m.vs, cur));
+        float sdf = range - norm3(pc);
+        if (sdf <= -tr) break;
+        if (sdf >= 0.f) sdf = fminf(tr, sdf);
+        else sdf = fmaxf(-tr, sdf);
+        if (EMIT) {
+          const u32 H = t.vals[slot];
+          keys[out + cnt] = ((u64) (H * 512u + voxel_local_index(cur, 0)) << pbits) | (u64) i;
+          vals[out + cnt] = sdf;
+        }
+        cnt++;
+      }
+      const bool ax = t_max.x < t_max.y && t_max.x < t_max.z;
+      const bool az = !ax && (t_max.z < t_max.y);
+      const bool ay = !ax && !az;
+      cur.x += ax ? istep.x : 0; cur.y += ay ? istep.y : 0; cur.z += az ? istep.z : 0;
+      if ((ax && cur.x == bound.x) || (ay && cur.y == bound.y) || (az && cur.z == bound.z)) break;
+      t_max.x = ax ? t_max.x + t_delta.x : t_max.x;
+      t_max.y = ay ? t_max.y + t_delta.y : t_max.y;
+      t_max.z = az ? t_max.z + t_delta.z : t_max.z;
+    }
+  }
+  if (!EMIT) counts[i] = cnt;
+}
+
+// sorted records: the lane at the head of a voxel's run folds the run into the voxel, in order
+__global__ __launch_bounds__(256) void k_points_apply(const Map m, const Tab t, const u64* __restrict__ keys, const float* __restrict__ vals,
+                                                      const u32 n_rec, const int pbits) {
+  const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n_rec) return;
+  const u64 vid = keys[j] >> pbits;
+  if (j > 0 && (keys[j - 1] >> pbits) == vid) return;
+  const u32 H = (u32) (vid >> 9), li = (u32) (vid & 511u);
+  char* base = t.pool + (size_t) H * kFineBytes;
+  float* p_sdf = (float*) base + li;
+  float* p_ss = (float*) (base + 2048) + li;
+  u32* p_rgbw = (u32*) (base + 4096) + li;
+  float s0 = *p_sdf, ss = *p_ss;
+  u32 rgbw = *p_rgbw;
+  const u32 w1 = (u32) (m.weight_sample & 0xFF), wmax = (u32) (m.weight_max & 0xFF);
+  const float half_vs = m.vs / 2;
+  for (u32 k = j; k < n_rec && (keys[k] >> pbits) == vid; k++) {
+    const float sdf = vals[k];
+    const u32 w0 = rgbw >> 24;
+    const float curr_mean = w0 > 0 ? s0 : 0.f;
+    const float delta = (sdf - curr_mean) / half_vs;
+    // combineVoxel with curr = {sdf, weight_update, rgb (0, 0, 0)} (vhu.cuh:167-181)
+    const u32 r0 = rgbw & 0xFF, g0 = (rgbw >> 8) & 0xFF, b0 = (rgbw >> 16) & 0xFF;
+    const u32 rn = (u32) f2i((0.5f * (float) r0 + 0.5f * 0.f) + 0.5f) & 0xFF;
+    const u32 gn = (u32) f2i((0.5f * (float) g0 + 0.5f * 0.f) + 0.5f) & 0xFF;
+    const u32 bn = (u32) f2i((0.5f * (float) b0 + 0.5f * 0.f) + 0.5f) & 0xFF;
+    const float sn = (s0 * (float) w0 + sdf * (float) w1) / (float) (int) (w0 + w1);
+    const u32 wn = (w0 + w1) < wmax ? (w0 + w1) : wmax;
+    const float delta2 = (sdf - sn) / half_vs;
+    s0 = sn;
+    ss = 0.f + delta * delta2;
+    rgbw = rn | (gn << 8) | (bn << 16) | (wn << 24);
+  }
+  *p_sdf = s0;
+  *p_ss = ss;
+  *p_rgbw = rgbw;
+}
+
+}  // namespace mrh

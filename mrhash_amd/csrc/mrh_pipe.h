@@ -81,15 +81,9 @@ struct RayState {
   f3 t_max, t_delta;
   bool valid;
 };
-__device__ __forceinline__ RayState ray_setup(const Cam& c, const Map& m, const int row, const int col, const float d) {
+// block-level DDA state for the world-space segment pw_min -> pw_max (vds.cu:782-827; allocBlocks3DKernel :966-1005)
+__device__ __forceinline__ RayState ray_from_segment(const Map& m, const f3 pw_min, const f3 pw_max) {
   RayState r;
-  r.valid = false;
-  const float tr = get_truncation(d, m.trunc, m.trunc_scale);
-  const float dmin = fminf(c.max_int_dist, d - tr);
-  const float dmax = fminf(c.max_int_dist, d + tr);
-  if ((d == 0.f) || (dmin >= dmax)) return r;
-  const f3 pw_min = se3_apply(c.R, c.t, inverse_projection(c, (u32) row, (u32) col, dmin));
-  const f3 pw_max = se3_apply(c.R, c.t, inverse_projection(c, (u32) row, (u32) col, dmax));
   const f3 dd = mk3(pw_max.x - pw_min.x, pw_max.y - pw_min.y, pw_max.z - pw_min.z);
   const float inv_len = 1.0f / sqrtf(dd.x * dd.x + dd.y * dd.y + dd.z * dd.z);  // normalize, cuda_math.cuh:1075-1078
   const f3 dir = mk3(dd.x * inv_len, dd.y * inv_len, dd.z * inv_len);
@@ -115,6 +109,17 @@ __device__ __forceinline__ RayState ray_setup(const Cam& c, const Map& m, const 
   r.t_max.z = gz ? kFltMax : r.t_max.z; r.t_delta.z = gz ? kFltMax : r.t_delta.z;
   r.valid = true;
   return r;
+}
+__device__ __forceinline__ RayState ray_setup(const Cam& c, const Map& m, const int row, const int col, const float d) {
+  RayState r;
+  r.valid = false;
+  const float tr = get_truncation(d, m.trunc, m.trunc_scale);
+  const float dmin = fminf(c.max_int_dist, d - tr);
+  const float dmax = fminf(c.max_int_dist, d + tr);
+  if ((d == 0.f) || (dmin >= dmax)) return r;
+  const f3 pw_min = se3_apply(c.R, c.t, inverse_projection(c, (u32) row, (u32) col, dmin));
+  const f3 pw_max = se3_apply(c.R, c.t, inverse_projection(c, (u32) row, (u32) col, dmax));
+  return ray_from_segment(m, pw_min, pw_max);
 }
 // true if every block key of the walk is representable (pack_key cannot fail inside the loop)
 __device__ __forceinline__ bool ray_keys_in_range(const RayState& r) {

@@ -4,6 +4,7 @@
 // this image; pybind11 returns numpy arrays where the reference returns Eigen matrices.
 #include <pybind11/numpy.h>
 #include <pybind11/pybind11.h>
+#include <vector>
 #include <pybind11/stl.h>
 
 #include "geowrapper.h"
@@ -79,9 +80,18 @@ PYBIND11_MODULE(pygeowrapper, m) {
       g.setDepthImage(a.data(), (size_t) a.shape(0), (size_t) a.shape(1));
     })
     .def("setPointCloud", [](GeoWrapper& g, py::array_t<float, py::array::c_style | py::array::forcecast> pts, bool compute_normals) {
+      // geowrapper.cpp:323-372: [N, 3] points in the sensor frame (the runners pass points[:, :3]); copied
       if (pts.ndim() != 2) throw std::runtime_error("GeoWrapper::setPointCloud|input should be a 2D numpy array");
+      if (pts.shape(1) < 3) throw std::runtime_error("GeoWrapper::setPointCloud|input should have at least 3 columns (x, y, z)");
       if (compute_normals) throw std::runtime_error("GeoWrapper::setPointCloud|normal estimation (MAD tree) is outside this library's scope");
-      g.setPointCloud(pts.data(), (size_t) pts.shape(0), nullptr);
+      if (pts.shape(1) == 3) {
+        g.setPointCloud(pts.data(), (size_t) pts.shape(0), nullptr);
+      } else {
+        std::vector<float> xyz((size_t) pts.shape(0) * 3);
+        auto r = pts.unchecked<2>();
+        for (py::ssize_t i = 0; i < pts.shape(0); i++) { xyz[3 * i] = r(i, 0); xyz[3 * i + 1] = r(i, 1); xyz[3 * i + 2] = r(i, 2); }
+        g.setPointCloud(xyz.data(), (size_t) pts.shape(0), nullptr);
+      }
     }, py::arg("input_point_cloud"), py::arg("compute_normals") = false)
     .def("setPointCloud", [](GeoWrapper& g, py::array_t<float, py::array::c_style | py::array::forcecast> pts,
                              py::array_t<float, py::array::c_style | py::array::forcecast> normals) {

@@ -90,7 +90,10 @@ class Scene:
 
     def cast(self, K: Intrinsics, R: np.ndarray, t: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
         """depth [rows, cols] float64 (ray parameter == camera z) and hit points [rows, cols, 3]."""
-        d_cam = pixel_rays(K)
+        return self.cast_dirs(pixel_rays(K), R, t)
+
+    def cast_dirs(self, d_cam: np.ndarray, R: np.ndarray, t: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+        """Ray parameter of the first hit along sensor-frame directions d_cam [..., 3] and the hit points (world)."""
         d = d_cam @ np.asarray(R, dtype=np.float64).T
         o = np.asarray(t, dtype=np.float64)
         with np.errstate(divide="ignore", invalid="ignore"):
@@ -190,6 +193,68 @@ def scannet_room() -> Scene:
         sx, sz, sy = rng.uniform(0.3, 0.9), rng.uniform(0.3, 0.9), rng.uniform(0.4, 1.2)
         furn.append(Box((cx - sx, 1.5 - sy, cz - sz), (cx + sx, 1.5, cz + sz)))  # standing on the floor (y down)
     return Scene(Box((-4.0, -1.5, -3.0), (4.0, 1.5, 3.0)), furn, seed=1)
+
+
+def street_canyon() -> Scene:
+    """BASELINE configs[4] stand-in ("VBR"): a 100 m street between box buildings, sensor frame x forward / z up."""
+    rng = np.random.default_rng(4)
+    furn = []
+    for side in (-1.0, 1.0):
+        x = -48.0
+        while x < 46.0:
+            w, d, h = rng.uniform(6, 14), rng.uniform(4, 9), rng.uniform(5, 18)
+            y0 = side * rng.uniform(6.0, 9.0)
+            furn.append(Box((x, min(y0, y0 + side * d), -1.8), (x + w, max(y0, y0 + side * d), -1.8 + h)))
+            x += w + rng.uniform(1.0, 5.0)
+    for _ in range(10):  # parked cars / kiosks on the road side
+        cx, cy = rng.uniform(-40, 40), rng.choice([-1.0, 1.0]) * rng.uniform(3.0, 5.0)
+        furn.append(Box((cx - 2.2, cy - 0.9, -1.8), (cx + 2.2, cy + 0.9, -0.3)))
+    return Scene(Box((-50.0, -30.0, -1.8), (50.0, 30.0, 40.0)), furn, seed=4)
+
+
+def lidar_dirs(rows: int, cols: int, el_deg: Tuple[float, float] = (-22.5, 22.5)) -> np.ndarray:
+    """Unit directions of a spinning LiDAR, [rows * cols, 3], azimuth fastest (layout of test_projections.cu:146-158)."""
+    az = (np.arange(cols, dtype=np.float64) + 0.5) / cols * 2.0 * np.pi - np.pi
+    el = np.deg2rad(np.linspace(el_deg[0], el_deg[1], rows))
+    ce, se = np.cos(el)[:, None], np.sin(el)[:, None]
+    d = np.stack([ce * np.cos(az)[None, :], ce * np.sin(az)[None, :], np.broadcast_to(se, (rows, cols))], axis=-1)
+    return d.reshape(-1, 3)
+
+
+def lidar_scan(scene: Scene, t: np.ndarray, q: np.ndarray, rows: int = 32, cols: int = 512, noise_sigma: float = 0.0,
+               rng: Optional[np.random.Generator] = None, max_range: float = 120.0, dropout: float = 0.0) -> np.ndarray:
+    """One scan as float32 [N, 3] points in the SENSOR frame (what GeoWrapper.setPointCloud receives); missing returns
+    are (0, 0, 0), as the reference's matrix initialisation leaves them (vds.cu:1234)."""
+    R = quat_to_rot(q)
+    d = lidar_dirs(rows, cols)
+    rng_len, _ = scene.cast_dirs(d, R, t)
+    if noise_sigma > 0:
+        rng_len = rng_len + (rng or np.random.default_rng(0)).normal(0.0, noise_sigma, size=rng_len.shape)
+    pts = d * rng_len[:, None]
+    bad = ~np.isfinite(rng_len) | (rng_len > max_range) | (rng_len <= 0)
+    if dropout > 0:
+        bad |= (rng or np.random.default_rng(0)).random(rng_len.shape) < dropout
+    pts[bad] = 0.0
+    return pts.astype(np.float32)
+
+
+VBR_PARAMS = dict(  # mrhash/configurations/vbr.cfg
+    sdf_truncation=0.40, sdf_truncation_scale=0.0, integration_weight_sample=1, virtual_voxel_size=0.20,
+    n_frames_invalidate_voxels=0, voxel_extents_scale=1, marching_cubes_threshold=1.5, min_weight_threshold=50,
+    min_depth=0.2, max_depth=100.0, sdf_var_threshold=0.0, vertices_merging_threshold=0.0, projective_sdf=True,
+)
+
+
+def drive_poses(n: int, step: float = 0.5) -> List[Tuple[np.ndarray, np.ndarray]]:
+    """Sensor moving along the street (+x), slight weave and yaw, z up (identity = x forward)."""
+    out = []
+    for i in range(n):
+        x = -30.0 + step * i
+        y = 0.8 * np.sin(0.07 * i)
+        yaw = 0.05 * np.sin(0.11 * i)
+        q = np.array([0.0, 0.0, np.sin(yaw / 2), np.cos(yaw / 2)], dtype=np.float32)
+        out.append((np.array([x, y, 0.0], dtype=np.float32), q))
+    return out
 
 
 def orbit_poses(n: int, radius: float = 1.0, yaw_step_deg: float = 1.8) -> List[Tuple[np.ndarray, np.ndarray]]:

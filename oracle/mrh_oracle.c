@@ -100,6 +100,8 @@ struct mrh_ctx {
   float* depth;
   uint8_t* rgb;
   int depth_rows, depth_cols, rgb_rows, rgb_cols;
+  float* points;       /* sensor-frame xyz of the current scan (GeoWrapper::setPointCloud, geowrapper.cpp:276-298) */
+  uint64_t num_points;
   f3* cloud;
   /* container: voxel_data_structures.cuh:63-100 */
   unsigned num_sdf_blocks, hash_num_buckets, total_size, low_blocks_to_allocate;
@@ -1298,7 +1300,7 @@ int mrh_destroy(mrh_ctx* c) {
   if (!c) return MRH_OK;
   free(c->table); free(c->compact); free(c->decision); free(c->mutex); free(c->heap_high); free(c->heap_low);
   free(c->blocks); free(c->realloc_pos); free(c->realloc_res); free(c->reintegrate); free(c->depth_buff);
-  free(c->depth); free(c->rgb); free(c->cloud); free(c->tris); free(c->tri_blocks); free(c->tri_counts); free(c->V); free(c->C); free(c->F);
+  free(c->depth); free(c->rgb); free(c->points); free(c->cloud); free(c->tris); free(c->tri_blocks); free(c->tri_counts); free(c->V); free(c->C); free(c->F);
   free(c);
   return MRH_OK;
 }
@@ -1354,6 +1356,173 @@ int mrh_upload_rgb(mrh_ctx* c, const uint8_t* rgb, int rows, int cols) {
 
 int mrh_set_depth_device(mrh_ctx* c, const float* d, int rows, int cols) { return mrh_upload_depth(c, d, rows, cols); }
 int mrh_set_rgb_device(mrh_ctx* c, const uint8_t* d, int rows, int cols) { return mrh_upload_rgb(c, d, rows, cols); }
+
+/* ---- LiDAR point-cloud integration: allocBlocks3DKernel vds.cu:925-1033, integrate3DKernel
+ * vds.cu:1215-1379, VoxelContainer::integrate(point_cloud, ...) voxel_data_structures.cpp:112-135 ------------------
+ * Scope: the shipped LiDAR configurations (vbr / maicity / newer_college .cfg: projective_sdf = true, no normals,
+ * n_frames_invalidate_voxels = 0, sdf_var_threshold = 0).  norm3df(x, y, z) is restated as sqrtf((x*x + y*y) + z*z)
+ * and normalize() as a multiplication by 1 / sqrtf(dot) (the arithmetic spec of this header).
+ * D6 (canonicalisation): integrate3DKernel updates a voxel with a non-atomic read-modify-write per point, so points
+ * of one scan that traverse the same voxel race in the reference.  Canonical result: every voxel receives its
+ * updates in ascending point index, each point's walk run to completion — i.e. this sequential loop. */
+static inline float norm3(f3 p) { return sqrtf((p.x * p.x + p.y * p.y) + p.z * p.z); }
+static inline f3 normalize3(f3 p) {
+  const float inv = 1.0f / sqrtf((p.x * p.x + p.y * p.y) + p.z * p.z);
+  return mk3(p.x * inv, p.y * inv, p.z * inv);
+}
+
+/* the DDA set-up shared by both kernels (vds.cu:966-1005 / :1257-1296); unit = voxels per step (8 for blocks, 1 for voxels) */
+typedef struct { i3 cur, bound; f3 step, t_max, t_delta; } dda3;
+static dda3 dda_setup(const mrh_ctx* c, f3 pw_min, f3 pw_max, int blocks) {
+  const float vs = c->p.virtual_voxel_size;
+  const float ext = (float) c->p.voxel_extents_scale;
+  dda3 r;
+  const f3 dir = normalize3(mk3(pw_max.x - pw_min.x, pw_max.y - pw_min.y, pw_max.z - pw_min.z));
+  i3 end;
+  if (blocks) { r.cur = world_to_block(vs, ext, pw_min); end = world_to_block(vs, ext, pw_max); }
+  else { r.cur = world_to_voxel(vs, pw_min); end = world_to_voxel(vs, pw_max); }
+  r.step = mk3((float) signi(dir.x), (float) signi(dir.y), (float) signi(dir.z));
+  const i3 nb = {r.cur.x + f2i(clampf(r.step.x, 0.0f, 1.f)), r.cur.y + f2i(clampf(r.step.y, 0.0f, 1.f)), r.cur.z + f2i(clampf(r.step.z, 0.0f, 1.f))};
+  const f3 bw = voxel_to_world(vs, blocks ? block_to_voxel(nb) : nb);
+  const f3 boundary = mk3(bw.x - 0.5f * vs, bw.y - 0.5f * vs, bw.z - 0.5f * vs);
+  const float unit = blocks ? (float) SDF_BLOCK_SIZE : 1.0f;
+  r.t_max = mk3((boundary.x - pw_min.x) / dir.x, (boundary.y - pw_min.y) / dir.y, (boundary.z - pw_min.z) / dir.z);
+  if (blocks) r.t_delta = mk3((r.step.x * unit * vs) / dir.x, (r.step.y * unit * vs) / dir.y, (r.step.z * unit * vs) / dir.z);
+  else r.t_delta = mk3((r.step.x * vs) / dir.x, (r.step.y * vs) / dir.y, (r.step.z * vs) / dir.z);
+  r.bound.x = f2i((float) end.x + r.step.x); r.bound.y = f2i((float) end.y + r.step.y); r.bound.z = f2i((float) end.z + r.step.z);
+  if (fabsf(dir.x) < FLOAT_EPSILON) { r.t_max.x = FLT_MAX; r.t_delta.x = FLT_MAX; }
+  if (fabsf(boundary.x - dir.x) < FLOAT_EPSILON) { r.t_max.x = FLT_MAX; r.t_delta.x = FLT_MAX; }
+  if (fabsf(dir.y) < FLOAT_EPSILON) { r.t_max.y = FLT_MAX; r.t_delta.y = FLT_MAX; }
+  if (fabsf(boundary.y - dir.y) < FLOAT_EPSILON) { r.t_max.y = FLT_MAX; r.t_delta.y = FLT_MAX; }
+  if (fabsf(dir.z) < FLOAT_EPSILON) { r.t_max.z = FLT_MAX; r.t_delta.z = FLT_MAX; }
+  if (fabsf(boundary.z - dir.z) < FLOAT_EPSILON) { r.t_max.z = FLT_MAX; r.t_delta.z = FLT_MAX; }
+  return r;
+}
+/* one traversal step; returns 0 when the walk ends */
+static inline int dda_step(dda3* r) {
+  if (r->t_max.x < r->t_max.y && r->t_max.x < r->t_max.z) {
+    r->cur.x = f2i((float) r->cur.x + r->step.x);
+    if (r->cur.x == r->bound.x) return 0;
+    r->t_max.x += r->t_delta.x;
+  } else if (r->t_max.z < r->t_max.y) {
+    r->cur.z = f2i((float) r->cur.z + r->step.z);
+    if (r->cur.z == r->bound.z) return 0;
+    r->t_max.z += r->t_delta.z;
+  } else {
+    r->cur.y = f2i((float) r->cur.y + r->step.y);
+    if (r->cur.y == r->bound.y) return 0;
+    r->t_max.y += r->t_delta.y;
+  }
+  return 1;
+}
+
+/* allocBlocks3DKernel for one point (vds.cu:925-1033), projective branch */
+static void alloc_point(mrh_ctx* c, uint64_t i) {
+  const f3 pcam = mk3(c->points[3 * i], c->points[3 * i + 1], c->points[3 * i + 2]);
+  const float range = norm3(pcam);
+  if (range == 0.f) return;
+  const f3 cam_dir = normalize3(pcam);
+  const float t = get_truncation(range, c->p.sdf_truncation, c->p.sdf_truncation_scale);
+  const float min_depth = fminf(c->max_integration_distance, range - t);
+  const float max_depth = fminf(c->max_integration_distance, range + t);
+  if (min_depth >= max_depth) return;
+  const float a = min_depth - range, b = max_depth - range;
+  const f3 pcam_min = mk3(pcam.x + cam_dir.x * a, pcam.y + cam_dir.y * a, pcam.z + cam_dir.z * a);
+  const f3 pcam_max = mk3(pcam.x + cam_dir.x * b, pcam.y + cam_dir.y * b, pcam.z + cam_dir.z * b);
+  dda3 r = dda_setup(c, se3_apply(c->R, c->t, pcam_min), se3_apply(c->R, c->t, pcam_max), 1);
+  for (unsigned iter = 0; iter < MAX_DDA_ITERATION_COUNT; iter++) {
+    if (owns_block(c, r.cur)) (void) alloc_block(c, r.cur, 0, 0);
+    if (!dda_step(&r)) return;
+  }
+}
+/* allocBlocks3D host loop (same retry shape as allocBlocks, vds.cu:1036-1092) */
+static void alloc_blocks_3d(mrh_ctx* c) {
+  int prev_free = heap_high_free(c) + heap_low_free(c);
+  reset_mutex(c);
+  for (uint64_t i = 0; i < c->num_points; i++) alloc_point(c, i);
+  for (;;) {
+    reset_mutex(c);
+    for (uint64_t i = 0; i < c->num_points; i++) alloc_point(c, i);
+    const int cur_free = heap_high_free(c) + heap_low_free(c);
+    if (prev_free == cur_free) break;
+    prev_free = cur_free;
+  }
+}
+
+/* integrate3DKernel for one point (vds.cu:1215-1379), projective branch, resolution-0 entries */
+static void integrate_point(mrh_ctx* c, uint64_t i) {
+  const float vs = c->p.virtual_voxel_size;
+  const float ext = (float) c->p.voxel_extents_scale;
+  const f3 pcam = mk3(c->points[3 * i], c->points[3 * i + 1], c->points[3 * i + 2]);
+  const float range = norm3(pcam);
+  if (range < 1e-6 || range > c->max_integration_distance) return;
+  const f3 cam_dir = normalize3(pcam);
+  const float truncation = get_truncation(range, c->p.sdf_truncation, c->p.sdf_truncation_scale);
+  const float min_depth = fminf(c->max_integration_distance, range - truncation);
+  const float max_depth = fminf(c->max_integration_distance, range + truncation);
+  if (min_depth >= max_depth) return;
+  const f3 pcam_min = mk3(pcam.x - cam_dir.x * truncation, pcam.y - cam_dir.y * truncation, pcam.z - cam_dir.z * truncation);
+  const f3 pcam_max = mk3(pcam.x + cam_dir.x * truncation, pcam.y + cam_dir.y * truncation, pcam.z + cam_dir.z * truncation);
+  dda3 r = dda_setup(c, se3_apply(c->R, c->t, pcam_min), se3_apply(c->R, c->t, pcam_max), 0);
+  const uint8_t w1 = (uint8_t) (float) (uint8_t) c->p.integration_weight_sample;  /* weight_update = integration_weight_sample (uchar -> float -> uchar) */
+  for (unsigned iter = 0; iter < MAX_DDA_ITERATION_COUNT; iter++) {
+    const i3 block = voxel_to_block(r.cur, vs, ext);
+    const HashEntry entry = get_hash_entry(c, block);
+    if (entry.ptr != FREE_ENTRY) {
+      const f3 voxel_pos = voxel_to_world(vs, r.cur);   /* scale 1: voxel_pos_aprox == id_current_voxel */
+      const f3 pc = se3_apply(c->Ri, c->ti, voxel_pos);
+      float sdf = range - norm3(pc);
+      if (sdf <= -truncation) break;
+      if (sdf >= 0.f) sdf = fminf(truncation, sdf);
+      else sdf = fmaxf(-truncation, sdf);
+      Voxel* dst = &c->blocks[(size_t) entry.ptr + voxel_to_block_index(r.cur, SDF_BLOCK_SIZE)];
+      float curr_mean = 0.f;
+      if (dst->weight > 0) curr_mean = dst->sdf;
+      const float delta = (sdf - curr_mean) / (vs / 2);
+      Voxel m;   /* combineVoxel(stored, curr = {sdf, weight_update, rgb 0}), vhu.cuh:167-181 */
+      m.sum_squared = 0.f;
+      m.rgb[0] = (uint8_t) f2i((0.5f * (float) dst->rgb[0] + 0.5f * 0.f) + 0.5f);
+      m.rgb[1] = (uint8_t) f2i((0.5f * (float) dst->rgb[1] + 0.5f * 0.f) + 0.5f);
+      m.rgb[2] = (uint8_t) f2i((0.5f * (float) dst->rgb[2] + 0.5f * 0.f) + 0.5f);
+      m.sdf = (dst->sdf * (float) dst->weight + sdf * (float) w1) / (float) ((int) dst->weight + (int) w1);
+      {
+        const int wsum = (int) dst->weight + (int) w1;
+        const int wmax = (int) (uint8_t) c->p.integration_weight_max;
+        m.weight = (uint8_t) (wsum < wmax ? wsum : wmax);
+      }
+      *dst = m;
+      const float delta2 = (sdf - dst->sdf) / (vs / 2);
+      dst->sum_squared = dst->sum_squared + delta * delta2;
+      c->total_updated++;
+    }
+    if (!dda_step(&r)) return;
+  }
+}
+
+int mrh_upload_points(mrh_ctx* c, const float* xyz, uint64_t n) {
+  if (!c || (n && !xyz)) return fail(c, MRH_ERR_INVALID_ARG, "mrh_upload_points: bad argument");
+  free(c->points);
+  c->points = n ? (float*) malloc((size_t) n * 3 * sizeof(float)) : NULL;
+  if (n) memcpy(c->points, xyz, (size_t) n * 3 * sizeof(float));
+  c->num_points = n;
+  return MRH_OK;
+}
+int mrh_set_points_device(mrh_ctx* c, const float* xyz, uint64_t n) { return mrh_upload_points(c, xyz, n); }
+
+/* VoxelContainer::integrate(point_cloud, normals, weights, camera, max_num_frames), voxel_data_structures.cpp:112-135 */
+int mrh_integrate_points(mrh_ctx* c, int n_frames_invalidate) {
+  if (!c) return MRH_ERR_INVALID_ARG;
+  if (!c->has_camera) return fail(c, MRH_ERR_STATE, "mrh_integrate_points: set_camera has not been called");
+  const int max_num_frames = n_frames_invalidate < 0 ? c->p.n_frames_invalidate_voxels : n_frames_invalidate;
+  if (max_num_frames > 0) return fail(c, MRH_ERR_UNSUPPORTED, "mrh_integrate_points: garbage collection on LiDAR scans (spherical projection) is outside this round's scope");
+  if (c->p.sdf_var_threshold > 0.f) return fail(c, MRH_ERR_UNSUPPORTED, "mrh_integrate_points: variance-adaptive resolution on LiDAR scans (reintegrate3D) is outside this round's scope");
+  if (!c->p.projective_sdf) return fail(c, MRH_ERR_UNSUPPORTED, "mrh_integrate_points: normal-direction SDF needs normals, which this boundary does not carry");
+  c->last_inserted = c->last_freed = 0;
+  alloc_blocks_3d(c);
+  for (uint64_t i = 0; i < c->num_points; i++) integrate_point(c, i);
+  c->frames++;
+  return MRH_OK;
+}
 
 /* voxel_data_structures.cpp:90-110 VoxelContainer::integrate (+ camera.cu:21-26) */
 int mrh_integrate(mrh_ctx* c, int n_frames_invalidate) {

@@ -108,3 +108,33 @@ def test_serialize_outputs(geowrapper_cls, tmp_path):
     assert np.array_equal(g.getVertices(), h.getVertices()) and np.array_equal(g.getFaces(), h.getFaces())
     with pytest.raises(RuntimeError):
         h.deserializeGrid(str(tmp_path / "hash.ply"))
+
+
+def test_lidar_runner_call_sequence_matches_oracle(geowrapper_cls, oracle, tmp_path):
+    """The reference's LiDAR runners (apps/kitti_runner.py:95-106, rosbag_runner.py:115-126): spherical camera,
+    setCurrPose, setPointCloud(points[:, :3], False), compute(); then extractMesh — against the oracle's point path."""
+    p = dict(synth.VBR_PARAMS, min_weight_threshold=1)
+    g = geowrapper_cls(sdf_truncation=p["sdf_truncation"], sdf_truncation_scale=0.0, integration_weight_sample=1,
+                       virtual_voxel_size=p["virtual_voxel_size"], n_frames_invalidate_voxels=0, voxel_extents_scale=1,
+                       viewer_active=False, marching_cubes_threshold=1.5, min_weight_threshold=1, min_depth=0.2,
+                       max_depth=100.0, projective_sdf=True)
+    g.setCamera(1.0, 1.0, 0.0, 0.0, 1, 1, 0.2, 100.0, 1)
+    from mrhash_amd import capi
+
+    b = capi.Engine(oracle, capi.Params(num_sdf_blocks=32768, **p))
+    b.set_camera(1.0, 1.0, 0.0, 0.0, 1, 1, 0.2, 100.0, model=1)
+    scene = synth.street_canyon()
+    for t, q in synth.drive_poses(3, step=2.0):
+        pts = synth.lidar_scan(scene, t, q, rows=16, cols=256)
+        with_intensity = np.concatenate([pts, np.ones((len(pts), 1), np.float32)], axis=1)  # x y z i, as read from a bag
+        g.setCurrPose(t, q)
+        g.setPointCloud(with_intensity[:, :3], False)
+        g.compute()
+        b.set_pose(synth.quat_to_rot(q), t)
+        b.upload_points(pts)
+        b.integrate_points()
+    g.extractMesh(str(tmp_path / "lidar.ply"))
+    b.extract_triangles()
+    Vb, Fb, Cb = b.extract_mesh()
+    assert len(Fb) > 500
+    assert np.array_equal(g.getVertices(), Vb) and np.array_equal(g.getFaces(), Fb)
