@@ -39,7 +39,7 @@ def pmc_traffic_bytes():
     try:
         lines = open(PMC_SUMMARY).read().splitlines()
         for i, l in enumerate(lines):
-            if l.startswith("mrh::k_back<true, false>") or l.startswith("mrh::k_fused<true"):
+            if l.startswith("mrh::k_back<true, false"):
                 kv = dict(tok.split("=") for tok in lines[i + 1].split())
                 return (2.0 * float(kv["FETCH_SIZE"]) + float(kv["WRITE_SIZE"])) * 1024.0
     except Exception:

@@ -65,16 +65,8 @@ struct mrh_ctx {
   u32* d_misc = nullptr;  // 4 words for k_get_voxel
   Fast fast;              // single-resolution fast path buffers (depth_clean / rgbx point at the current frame's pair)
   size_t fast_npix = 0;
-  // allocation overlap (mrh_pipe.h): rays of frame f+1 are marched on stream_in while frame f integrates on stream
-  hipStream_t stream_in = nullptr;
-  static constexpr int kBufs = 3;  // input-side buffer sets: the ray kernel may run up to two frames ahead of the map
-  hipEvent_t ev_rays[kBufs] = {}, ev_done[kBufs] = {};
-  float* dc_buf[kBufs] = {};
-  u32* rgbx_buf[kBufs] = {};
-  u64* tile_keys[kBufs] = {};
-  u32* tile_count[kBufs] = {};
-  int overlap = 0;        // MRH_OVERLAP=1: rays of frame f+1 on a second stream (mrh_pipe.h; host-bound, off by default)
-  int merged = 1;         // MRH_MERGED=0: three-launch path (k_alloc2 / k_compact2 / k_fused) instead of k_front / k_back
+  float* dc_buf = nullptr;   // cleaned depth / packed colour of the current frame (written by k_front)
+  u32* rgbx_buf = nullptr;
   int4* d_cfree = nullptr;
   // LiDAR scan of the current frame (mrh_lidar.h)
   float* d_points = nullptr;        // owned copy (mrh_upload_points) ...
@@ -91,17 +83,10 @@ struct mrh_ctx {
   float* d_zmin = nullptr;   // per visible-list entry (Lists::zmin)
   uint64_t fast_frames = 0;  // fast-path frames issued: parity selects the list-counter set
   int frame_parity = 0;
-  uint64_t frames_enqueued = 0;  // fast-path frames whose rays were issued (parity selects the buffer pair)
   u64* d_cnt_partials = nullptr;
   int fused_grid = 2048;  // x 4 waves
-  int stagger = 0;        // MRH_STAGGER: start delay (x ~3.4 us) of odd workgroups of k_back
   int sweep_wgs_mr = 1024; // the same for multi-resolution maps (9x the descriptors); MRH_SWEEP_WGS_MR
   int sweep_wgs = 128;    // descriptor-sweep workgroups appended to the allocation launch (k_front)
-  int fused_nb = 2;       // voxel batches per wave: 2 = block per wave, 1 = half block per wave
-  int fused_pipe = 0;     // 1 = software-pipelined variant (k_fused_pipe)
-  int fused_wg = 256;     // threads per workgroup of k_fused (64 / 128 / 256)
-  int alloc_tile = 16;    // pixel tile side of k_alloc2 (8 or 16)
-  int gc_inline_enabled = 1;  // MRH_GC_INLINE=0 keeps the separate k_free2 launch
   bool frame_gc_inline = false;
   int integrate_grid = 1024;
   int low_blocks_to_allocate = 0;
@@ -154,15 +139,9 @@ uint64_t next_pow2(uint64_t v) {
 void free_all(mrh_ctx* c) {
   if (!c) return;
   (void) hipSetDevice(c->device);
-  if (c->stream_in) (void) hipStreamSynchronize(c->stream_in);
   if (c->stream) (void) hipStreamSynchronize(c->stream);
   auto F = [](void* p) { if (p) (void) hipFree(p); };
-  for (int i = 0; i < mrh_ctx::kBufs; i++) {
-    F(c->dc_buf[i]); F(c->rgbx_buf[i]); F(c->tile_keys[i]); F(c->tile_count[i]);
-    if (c->ev_rays[i]) (void) hipEventDestroy(c->ev_rays[i]);
-    if (c->ev_done[i]) (void) hipEventDestroy(c->ev_done[i]);
-  }
-  if (c->stream_in) (void) hipStreamDestroy(c->stream_in);
+  F(c->dc_buf); F(c->rgbx_buf);
   F(c->tab.keys); F(c->tab.vals); F(c->tab.heap_fine); F(c->tab.heap_coarse); F(c->tab.desc_fine); F(c->tab.desc_coarse);
   F(c->tab.pool); F(c->tab.compact); F(c->tab.ctr); F(c->tab.prof);
   F(c->d_depth_own); F(c->d_rgb_own); F(c->d_decision); F(c->d_zbuf); F(c->d_realloc); F(c->d_reint); F(c->d_flag);
@@ -175,8 +154,6 @@ void free_all(mrh_ctx* c) {
 // (re)initialises every device structure to the empty map (voxel_data_structures.cpp:58-87 + ctor counters)
 int init_buffers(mrh_ctx* c) {
   hipStream_t s = c->stream;
-  if (c->stream_in) HIP_TRY(c, hipStreamSynchronize(c->stream_in));
-  c->frames_enqueued = 0;
   c->mr_next_general = true;
   c->mr_summaries_valid = false;
   c->fast_frames = 0;
@@ -244,34 +221,6 @@ int compact_all(mrh_ctx* c, int* out_n) {
   HIP_TRY(c, hipGetLastError());
   *out_n = n;
   return MRH_OK;
-}
-
-// free_inline: the frame's GC runs inside k_compact2 (culled blocks) and k_fused (visible blocks): only when GC is on,
-// the frame does not starve (starve changes weights after the integrate pass) and a whole block is owned by one wave
-bool gc_inline(const mrh_ctx* c, int max_num_frames) {
-  const bool starve = max_num_frames > 0 && c->frames > 0 && c->frames % (uint64_t) max_num_frames == 0;
-  return max_num_frames > 0 && !starve && c->fused_nb == 2 && !c->fused_pipe && c->gc_inline_enabled;
-}
-
-void launch_fused(mrh_ctx* c, bool free_inline) {
-  const int g = c->fused_grid;
-  hipStream_t s = c->stream;
-  const float thr = c->map.trunc + c->map.trunc_scale * c->cam.max_depth;
-  if (free_inline) {
-    const int wg = c->fused_wg;
-    const size_t lds = (size_t) (wg / 64) * kTileMaxPx * sizeof(uint2);
-    k_fused<true, 2, true><<<g, wg, lds, s>>>(c->cam, c->map, c->tab, c->fast, thr);
-    return;
-  }
-  if (c->fused_pipe) {
-    if (c->fused_nb == 1) k_fused_pipe<1><<<g, 256, 0, s>>>(c->cam, c->map, c->tab, c->fast);
-    else k_fused_pipe<2><<<g, 256, 0, s>>>(c->cam, c->map, c->tab, c->fast);
-  } else {
-    const int wg = c->fused_wg;
-    const size_t lds = (size_t) (wg / 64) * kTileMaxPx * sizeof(uint2);
-    if (c->fused_nb == 1) k_fused<true, 1, false><<<g, wg, lds, s>>>(c->cam, c->map, c->tab, c->fast, thr);
-    else k_fused<true, 2, false><<<g, wg, lds, s>>>(c->cam, c->map, c->tab, c->fast, thr);
-  }
 }
 
 struct KeyHash3 {
@@ -411,9 +360,6 @@ done:
 
 
 
-// stream the frame inputs are consumed on: the ray kernel's stream in the overlapped fast path, else the map stream
-hipStream_t in_stream(mrh_ctx* c) { return (!c->tab.multi_res && c->overlap) ? c->stream_in : c->stream; }
-
 int ensure_zbuf(mrh_ctx* c, size_t npix) {
   if (c->zbuf_n < npix) {
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -453,21 +399,16 @@ int frame_tail(mrh_ctx* c, bool starved, int max_num_frames) {
   const Tab& t = c->tab;
   const float thr = m.trunc + m.trunc_scale * k.max_depth;  // getTruncation(camera.maxDepth(), ...), vds.cu:1720
   if (!t.multi_res) {
-    if (starved) k_fused<false, 2, false><<<c->fused_grid, 256, 16, s>>>(k, m, t, c->fast, thr);  // weights changed: refresh the summaries
+    if (starved) k_summarize_all<<<1024, 256, 0, s>>>(t, c->fast);  // weights changed: the GC summaries follow the payload
     if (max_num_frames > 0 && !c->frame_gc_inline) {
-      if (c->merged) {
-        const Lists L = {t.compact, c->fast.bbox, c->d_cfree, c->d_zmin, (u32) c->num_blocks};
-        k_free_lists<<<256, 256, 0, s>>>(t, c->fast, L, c->frame_parity, thr);
-      } else if (c->profile) k_free2<true><<<256, 256, 0, s>>>(t, c->fast, thr);
-      else k_free2<false><<<256, 256, 0, s>>>(t, c->fast, thr);
+      const Lists L = {t.compact, c->fast.bbox, c->d_cfree, c->d_zmin, (u32) c->num_blocks};
+      k_free_lists<<<256, 256, 0, s>>>(t, c->fast, L, c->frame_parity, thr);
     }
   } else if (max_num_frames > 0 && !c->frame_fused_mr) {
     k_gc_identify<<<c->integrate_grid, 512, 0, s>>>(t, thr, c->d_decision);
     if (c->profile) k_gc_free<true><<<256, 256, 0, s>>>(t, c->d_decision);
     else k_gc_free<false><<<256, 256, 0, s>>>(t, c->d_decision);
   }
-  if (!t.multi_res && c->overlap && c->frames_enqueued > 0)
-    HIP_TRY(c, hipEventRecord(c->ev_done[(c->frames_enqueued - 1) % mrh_ctx::kBufs], s));  // this frame's image/key buffers are free again
   c->frames++;
   HIP_TRY(c, hipGetLastError());
   return MRH_OK;
@@ -533,11 +474,6 @@ int mrh_create(const mrh_params* p, mrh_ctx** out) {
   } while (0)
   CREATE_TRY(hipSetDevice(c->device));
   CREATE_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-  CREATE_TRY(hipStreamCreateWithFlags(&c->stream_in, hipStreamNonBlocking));
-  for (int i = 0; i < mrh_ctx::kBufs; i++) {
-    CREATE_TRY(hipEventCreateWithFlags(&c->ev_rays[i], hipEventDisableTiming));
-    CREATE_TRY(hipEventCreateWithFlags(&c->ev_done[i], hipEventDisableTiming));
-  }
 
   // capacities: geowrapper.cpp:37-54 when not given explicitly
   size_t free_b = 0, total_b = 0;
@@ -616,19 +552,10 @@ int mrh_create(const mrh_params* p, mrh_ctx** out) {
     const int v = atoi(g);
     if (v > 0 && v <= 32768) c->fused_grid = v;
   }
-  if (const char* g = getenv("MRH_STAGGER")) { const int v = atoi(g); if (v >= 0 && v <= 16) c->stagger = v; }
   if (const char* g = getenv("MRH_SWEEP_WGS")) { const int v = atoi(g); if (v > 0 && v <= 4096) c->sweep_wgs = v; }
-  if (const char* g = getenv("MRH_FUSED_NB")) c->fused_nb = atoi(g) == 1 ? 1 : 2;
-  if (const char* g = getenv("MRH_FUSED_PIPE")) c->fused_pipe = atoi(g) ? 1 : 0;
-  if (const char* g = getenv("MRH_OVERLAP")) c->overlap = atoi(g) ? 1 : 0;
-  if (const char* g = getenv("MRH_MERGED")) c->merged = atoi(g) ? 1 : 0;
   if (const char* g = getenv("MRH_MESH_HOST")) c->mesh_on_host = atoi(g) ? 1 : 0;
   if (const char* g = getenv("MRH_MR_FUSED")) c->mr_fused = atoi(g) ? 1 : 0;
   if (const char* g = getenv("MRH_SWEEP_WGS_MR")) { const int v = atoi(g); if (v > 0 && v <= 4096) c->sweep_wgs_mr = v; }
-  if (c->overlap) c->merged = 0;
-  if (const char* g = getenv("MRH_GC_INLINE")) c->gc_inline_enabled = atoi(g) ? 1 : 0;
-  if (const char* g = getenv("MRH_ALLOC_TILE")) c->alloc_tile = atoi(g) == 8 ? 8 : 16;
-  if (const char* g = getenv("MRH_FUSED_WG")) { const int v = atoi(g); if (v == 64 || v == 128 || v == 256) c->fused_wg = v; }
   int rc = init_buffers(c);
   if (rc != MRH_OK) {
     g_create_err = c->err;
@@ -713,14 +640,13 @@ int mrh_upload_depth(mrh_ctx* c, const float* depth, int rows, int cols) {
   if (!depth || rows <= 0 || cols <= 0) return fail(c, MRH_ERR_INVALID_ARG, "mrh_upload_depth: bad argument");
   const size_t bytes = (size_t) rows * cols * sizeof(float);
   if (bytes > c->depth_cap) {
-    HIP_TRY(c, hipStreamSynchronize(c->stream_in));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (c->d_depth_own) HIP_TRY(c, hipFree(c->d_depth_own));
     c->d_depth_own = nullptr;
     HIP_TRY(c, hipMalloc((void**) &c->d_depth_own, bytes));
     c->depth_cap = bytes;
   }
-  HIP_TRY(c, hipMemcpyAsync(c->d_depth_own, depth, bytes, hipMemcpyHostToDevice, in_stream(c)));
+  HIP_TRY(c, hipMemcpyAsync(c->d_depth_own, depth, bytes, hipMemcpyHostToDevice, c->stream));
   c->d_depth = c->d_depth_own;
   c->depth_rows = rows; c->depth_cols = cols;
   return MRH_OK;
@@ -732,14 +658,13 @@ int mrh_upload_rgb(mrh_ctx* c, const uint8_t* rgb, int rows, int cols) {
   if (!rgb || rows <= 0 || cols <= 0) return fail(c, MRH_ERR_INVALID_ARG, "mrh_upload_rgb: bad argument");
   const size_t bytes = (size_t) rows * cols * 3;
   if (bytes > c->rgb_cap) {
-    HIP_TRY(c, hipStreamSynchronize(c->stream_in));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (c->d_rgb_own) HIP_TRY(c, hipFree(c->d_rgb_own));
     c->d_rgb_own = nullptr;
     HIP_TRY(c, hipMalloc((void**) &c->d_rgb_own, bytes));
     c->rgb_cap = bytes;
   }
-  HIP_TRY(c, hipMemcpyAsync(c->d_rgb_own, rgb, bytes, hipMemcpyHostToDevice, in_stream(c)));
+  HIP_TRY(c, hipMemcpyAsync(c->d_rgb_own, rgb, bytes, hipMemcpyHostToDevice, c->stream));
   c->d_rgb = c->d_rgb_own;
   c->rgb_rows = rows; c->rgb_cols = cols;
   return MRH_OK;
@@ -779,7 +704,7 @@ int mrh_integrate(mrh_ctx* c, int n_frames_invalidate) {
   // step decrements weights after the check; imported blocks) and are then outside the image on the next frame.  Those
   // frames, and the starve frames themselves, go through the general kernels.
   const bool starve_now = max_num_frames > 0 && c->frames > 0 && c->frames % (uint64_t) max_num_frames == 0;
-  c->frame_fused_mr = t.multi_res && c->mr_fused && c->merged && !c->profile && max_num_frames > 0 && !starve_now && !c->mr_next_general &&
+  c->frame_fused_mr = t.multi_res && c->mr_fused && !c->profile && max_num_frames > 0 && !starve_now && !c->mr_next_general &&
                       c->frames >= 2;
   if (t.multi_res && !c->frame_fused_mr) {
     c->mr_summaries_valid = false;
@@ -790,109 +715,56 @@ int mrh_integrate(mrh_ctx* c, int n_frames_invalidate) {
     const size_t npix = (size_t) k.rows * k.cols;
     const int tiles_x = (k.cols + kRayTile - 1) / kRayTile, tiles_y = (k.rows + kRayTile - 1) / kRayTile;
     if (c->fast_npix < npix) {
-      HIP_TRY(c, hipStreamSynchronize(c->stream_in));
       HIP_TRY(c, hipStreamSynchronize(s));
-      for (int i = 0; i < mrh_ctx::kBufs; i++) {
-        if (c->dc_buf[i]) HIP_TRY(c, hipFree(c->dc_buf[i]));
-        if (c->rgbx_buf[i]) HIP_TRY(c, hipFree(c->rgbx_buf[i]));
-        if (c->tile_keys[i]) HIP_TRY(c, hipFree(c->tile_keys[i]));
-        if (c->tile_count[i]) HIP_TRY(c, hipFree(c->tile_count[i]));
-        c->dc_buf[i] = nullptr; c->rgbx_buf[i] = nullptr; c->tile_keys[i] = nullptr; c->tile_count[i] = nullptr;
-        HIP_TRY(c, hipMalloc((void**) &c->dc_buf[i], npix * sizeof(float)));
-        HIP_TRY(c, hipMalloc((void**) &c->rgbx_buf[i], npix * sizeof(u32)));
-        HIP_TRY(c, hipMalloc((void**) &c->tile_keys[i], (size_t) tiles_x * tiles_y * kRayCap * sizeof(u64)));
-        HIP_TRY(c, hipMalloc((void**) &c->tile_count[i], (size_t) tiles_x * tiles_y * sizeof(u32)));
-      }
+      if (c->dc_buf) HIP_TRY(c, hipFree(c->dc_buf));
+      if (c->rgbx_buf) HIP_TRY(c, hipFree(c->rgbx_buf));
+      c->dc_buf = nullptr; c->rgbx_buf = nullptr;
+      HIP_TRY(c, hipMalloc((void**) &c->dc_buf, npix * sizeof(float)));
+      HIP_TRY(c, hipMalloc((void**) &c->rgbx_buf, npix * sizeof(u32)));
       c->fast_npix = npix;
     }
-    // buffer pair of this frame: the previous frame's pair may still be read by its integrate kernel
-    const int buf = (int) (c->frames_enqueued % mrh_ctx::kBufs);
-    c->fast.depth_clean = c->dc_buf[buf];
-    c->fast.rgbx = c->rgbx_buf[buf];
+    c->fast.depth_clean = c->dc_buf;
+    c->fast.rgbx = c->rgbx_buf;
     const Fast& f = c->fast;
-    if (c->merged) {
-      // ---- two launches per frame (mrh_fast2.h)
-      const int parity = (int) (c->fast_frames & 1);
-      c->frame_parity = parity;
-      c->fast_frames++;
-      c->frames_enqueued++;
-      const u32 stamp = (u32) ((c->frames + 1) & 0x3FFFFFFFu);
-      const float gc_thr = m.trunc + m.trunc_scale * k.max_depth;  // getTruncation(camera.maxDepth(), ...), vds.cu:1720
-      const Lists L = {t.compact, c->fast.bbox, c->d_cfree, c->d_zmin, (u32) c->num_blocks};
-      const int n_tiles = tiles_x * tiles_y;
-      if (c->frame_fused_mr) {
-        if (!c->mr_summaries_valid) {
-          k_summarize_all<<<2048, 256, 0, s>>>(t, f);
-          c->mr_summaries_valid = true;
-        }
-        c->frame_gc_inline = true;
-        k_refill_decide<<<1, 64, 0, s>>>(t, c->low_blocks_to_allocate, c->d_flag);  // vds.cu:885-891
-        k_refill<<<(c->low_blocks_to_allocate + 255) / 256, 256, 0, s>>>(t, c->low_blocks_to_allocate, c->d_flag);
-        k_front<false, true><<<n_tiles + c->sweep_wgs_mr, 256, 0, s>>>(k, m, t, f, L, c->d_depth, c->d_rgb, tiles_x, n_tiles, stamp, parity, 1, gc_thr);
-        const size_t lds = (size_t) 4 * kTileMaxPx * sizeof(uint2);
-        k_back<true, false, true><<<c->fused_grid, 256, lds, s>>>(k, m, t, f, L, parity, gc_thr, 0, c->d_depth, c->d_rgb, (u32*) c->d_reint);
-        k_mr_tail<<<1, 256, 0, s>>>(t, (const u32*) c->d_reint);
-        return starve_and_tail(c, max_num_frames);
+    const int parity = (int) (c->fast_frames & 1);
+    c->frame_parity = parity;
+    c->fast_frames++;
+    const u32 stamp = (u32) ((c->frames + 1) & 0x3FFFFFFFu);
+    const float gc_thr = m.trunc + m.trunc_scale * k.max_depth;  // getTruncation(camera.maxDepth(), ...), vds.cu:1720
+    const Lists L = {t.compact, c->fast.bbox, c->d_cfree, c->d_zmin, (u32) c->num_blocks};
+    const int n_tiles = tiles_x * tiles_y;
+    const size_t lds = (size_t) 4 * kTileMaxPx * sizeof(uint2);
+    if (c->frame_fused_mr) {
+      if (!c->mr_summaries_valid) {
+        k_summarize_all<<<2048, 256, 0, s>>>(t, f);
+        c->mr_summaries_valid = true;
       }
-      const bool starve = max_num_frames > 0 && c->frames > 0 && c->frames % (uint64_t) max_num_frames == 0;
-      c->frame_gc_inline = max_num_frames > 0 && !starve;
-      if (c->profile) k_front<true, false><<<n_tiles + c->sweep_wgs, 256, 0, s>>>(k, m, t, f, L, c->d_depth, c->d_rgb, tiles_x, n_tiles, stamp, parity, max_num_frames > 0 ? 1 : 0, gc_thr);
-      else k_front<false, false><<<n_tiles + c->sweep_wgs, 256, 0, s>>>(k, m, t, f, L, c->d_depth, c->d_rgb, tiles_x, n_tiles, stamp, parity, max_num_frames > 0 ? 1 : 0, gc_thr);
-      const int wg = c->fused_wg;
-      const size_t lds = (size_t) (wg / 64) * kTileMaxPx * sizeof(uint2);
-      EvPair ev;
-      if (c->profile) {
-        k_count_updates<<<c->fused_grid, 256, 0, s>>>(k, m, t, f, c->d_cnt_partials, CTR_SET0 + 4 * parity);
-        if (!c->ev_pool.empty()) { ev = c->ev_pool.back(); c->ev_pool.pop_back(); }
-        else if (c->ev_pending.size() >= 4096) { HIP_TRY(c, hipStreamSynchronize(s)); rc = drain_events(c); if (rc) return rc; ev = c->ev_pool.back(); c->ev_pool.pop_back(); }
-        else { HIP_TRY(c, hipEventCreate(&ev.a)); HIP_TRY(c, hipEventCreate(&ev.b)); }
-        HIP_TRY(c, hipEventRecord(ev.a, s));
-      }
-      if (c->frame_gc_inline && c->profile) k_back<true, true, false><<<c->fused_grid, wg, lds, s>>>(k, m, t, f, L, parity, gc_thr, c->stagger, nullptr, nullptr, nullptr);
-      else if (c->frame_gc_inline) k_back<true, false, false><<<c->fused_grid, wg, lds, s>>>(k, m, t, f, L, parity, gc_thr, c->stagger, nullptr, nullptr, nullptr);
-      else k_back<false, false, false><<<c->fused_grid, wg, lds, s>>>(k, m, t, f, L, parity, gc_thr, c->stagger, nullptr, nullptr, nullptr);
-      if (c->profile) {
-        HIP_TRY(c, hipEventRecord(ev.b, s));
-        c->ev_pending.push_back(ev);
-      }
+      c->frame_gc_inline = true;
+      k_refill_decide<<<1, 64, 0, s>>>(t, c->low_blocks_to_allocate, c->d_flag);  // vds.cu:885-891
+      k_refill<<<(c->low_blocks_to_allocate + 255) / 256, 256, 0, s>>>(t, c->low_blocks_to_allocate, c->d_flag);
+      k_front<false, true><<<n_tiles + c->sweep_wgs_mr, 256, 0, s>>>(k, m, t, f, L, c->d_depth, c->d_rgb, tiles_x, n_tiles, stamp, parity, 1, gc_thr);
+      k_back<true, false, true><<<c->fused_grid, 256, lds, s>>>(k, m, t, f, L, parity, gc_thr, c->d_depth, c->d_rgb, (u32*) c->d_reint);
+      k_mr_tail<<<1, 256, 0, s>>>(t, (const u32*) c->d_reint);
       return starve_and_tail(c, max_num_frames);
     }
-    if (c->overlap) {
-      hipStream_t sin = c->stream_in;
-      if (c->frames_enqueued >= (uint64_t) mrh_ctx::kBufs) HIP_TRY(c, hipStreamWaitEvent(sin, c->ev_done[buf], 0));  // frame f-3 released this set
-      k_rays<<<dim3(tiles_x, tiles_y), dim3(kRayTile, kRayTile), 0, sin>>>(k, m, t, c->d_depth, c->d_rgb, c->dc_buf[buf], c->rgbx_buf[buf],
-                                                                          c->tile_keys[buf], c->tile_count[buf]);
-      HIP_TRY(c, hipEventRecord(c->ev_rays[buf], sin));
-      HIP_TRY(c, hipStreamWaitEvent(s, c->ev_rays[buf], 0));
-      if (c->profile) k_insert<true><<<tiles_x * tiles_y, 64, 0, s>>>(k, m, t, f, c->tile_keys[buf], c->tile_count[buf], tiles_x);
-      else k_insert<false><<<tiles_x * tiles_y, 64, 0, s>>>(k, m, t, f, c->tile_keys[buf], c->tile_count[buf], tiles_x);
-    } else if (c->alloc_tile == 8) {
-      const dim3 tiles2((k.cols + 7) / 8, (k.rows + 7) / 8);
-      if (c->profile) k_alloc2<true, 8><<<tiles2, dim3(8, 8), 0, s>>>(k, m, t, f, c->d_depth, c->d_rgb);
-      else k_alloc2<false, 8><<<tiles2, dim3(8, 8), 0, s>>>(k, m, t, f, c->d_depth, c->d_rgb);
-    } else {
-      const dim3 tiles2((k.cols + 15) / 16, (k.rows + 15) / 16);
-      if (c->profile) k_alloc2<true, 16><<<tiles2, dim3(16, 16), 0, s>>>(k, m, t, f, c->d_depth, c->d_rgb);
-      else k_alloc2<false, 16><<<tiles2, dim3(16, 16), 0, s>>>(k, m, t, f, c->d_depth, c->d_rgb);
-    }
-    c->frames_enqueued++;
-    c->frame_gc_inline = gc_inline(c, max_num_frames);
-    const float gc_thr = m.trunc + m.trunc_scale * k.max_depth;
-    if (c->frame_gc_inline) k_compact2<false, true><<<1024, 512, 0, s>>>(k, m, t, f, gc_thr);
-    else if (c->fused_nb == 1) k_compact2<true, false><<<1024, 512, 0, s>>>(k, m, t, f, gc_thr);
-    else k_compact2<false, false><<<1024, 512, 0, s>>>(k, m, t, f, gc_thr);
+    // GC runs inside k_back unless this is a starve frame (the starve step changes weights after the integrate pass)
+    c->frame_gc_inline = max_num_frames > 0 && !starve_now;
+    if (c->profile) k_front<true, false><<<n_tiles + c->sweep_wgs, 256, 0, s>>>(k, m, t, f, L, c->d_depth, c->d_rgb, tiles_x, n_tiles, stamp, parity, max_num_frames > 0 ? 1 : 0, gc_thr);
+    else k_front<false, false><<<n_tiles + c->sweep_wgs, 256, 0, s>>>(k, m, t, f, L, c->d_depth, c->d_rgb, tiles_x, n_tiles, stamp, parity, max_num_frames > 0 ? 1 : 0, gc_thr);
+    EvPair ev;
     if (c->profile) {
-      k_count_updates<<<c->fused_grid, 256, 0, s>>>(k, m, t, f, c->d_cnt_partials, -1);
-      EvPair ev;
+      k_count_updates<<<c->fused_grid, 256, 0, s>>>(k, m, t, f, c->d_cnt_partials, CTR_SET0 + 4 * parity);
       if (!c->ev_pool.empty()) { ev = c->ev_pool.back(); c->ev_pool.pop_back(); }
       else if (c->ev_pending.size() >= 4096) { HIP_TRY(c, hipStreamSynchronize(s)); rc = drain_events(c); if (rc) return rc; ev = c->ev_pool.back(); c->ev_pool.pop_back(); }
       else { HIP_TRY(c, hipEventCreate(&ev.a)); HIP_TRY(c, hipEventCreate(&ev.b)); }
       HIP_TRY(c, hipEventRecord(ev.a, s));
-      launch_fused(c, c->frame_gc_inline);
+    }
+    if (c->frame_gc_inline && c->profile) k_back<true, true, false><<<c->fused_grid, 256, lds, s>>>(k, m, t, f, L, parity, gc_thr, nullptr, nullptr, nullptr);
+    else if (c->frame_gc_inline) k_back<true, false, false><<<c->fused_grid, 256, lds, s>>>(k, m, t, f, L, parity, gc_thr, nullptr, nullptr, nullptr);
+    else k_back<false, false, false><<<c->fused_grid, 256, lds, s>>>(k, m, t, f, L, parity, gc_thr, nullptr, nullptr, nullptr);
+    if (c->profile) {
       HIP_TRY(c, hipEventRecord(ev.b, s));
       c->ev_pending.push_back(ev);
-    } else {
-      launch_fused(c, c->frame_gc_inline);
     }
     return starve_and_tail(c, max_num_frames);
   }

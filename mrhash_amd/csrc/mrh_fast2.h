@@ -716,10 +716,9 @@ __device__ __forceinline__ void frame_epilogue(const Tab& t, const int parity, c
 // ---- two-launch path: K2 = integrate + summary + GC of the visible list, then the culled-free list -------------
 template <bool FREE, bool PROFILE, bool MULTI>
 __global__ __launch_bounds__(256) void k_back(const Cam c, const Map m, const Tab t, const Fast f, const Lists L, const int parity,
-                                              const float trunc_threshold, const int stagger, const float* __restrict__ depth_raw,
+                                              const float trunc_threshold, const float* __restrict__ depth_raw,
                                               const uint8_t* __restrict__ rgb_raw, u32* __restrict__ deferred) {
   extern __shared__ __attribute__((aligned(16))) uint2 s_tile[];
-  (void) stagger;  // (a delayed start of every other workgroup was measured: it only lengthens the launch)
   const int cs = CTR_SET0 + 4 * parity;
   const int lane = threadIdx.x & 63;
   const int wpw = blockDim.x >> 6;

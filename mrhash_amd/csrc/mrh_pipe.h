@@ -1,13 +1,6 @@
-// mrh_pipe.h — block allocation split in two so that its ray-marching half can run AHEAD of the map updates.
-//
-//   k_rays    (input stream)  per pixel: cleaned depth + packed colour, DDA along the truncation segment, block keys
-//                             de-duplicated per 16x16 tile in LDS, the tile's distinct keys written to a per-tile list
-//                             in HBM.  Reads only the images and the pose: it does not touch the map, so the rays of
-//                             frame f+1 are marched on a second HIP stream while frame f is still being integrated.
-//   k_insert  (map stream)    one wave per tile: frustum test + lock-free insert of the listed keys (the part of
-//                             allocation that needs the table as frame f-1 left it).
-//
-// Same arithmetic and same inserted set as k_alloc2 (mrh_fast.h); reference: allocBlocksKernel vds.cu:758-857.
+// mrh_pipe.h — the pixel-ray walk of block allocation (allocBlocksKernel vds.cu:758-857): the literal walk
+// (walk_ray) and the lean one the allocation workgroups run (ray_setup / walk_ray_lean); mrh_fast2.h and mrh_lidar.h
+// build their kernels on them.
 #pragma once
 
 #include "mrh_fast.h"
@@ -16,7 +9,6 @@ namespace mrh {
 
 constexpr int kRayTile = 16;
 constexpr int kRayCap = kRayTile * kRayTile * 4;  // keys per tile list / LDS set (1024)
-constexpr u32 kTileOverflow = 0xFFFFFFFFu;        // tile_count value: LDS set saturated, k_insert re-walks the rays
 
 // Amanatides-Woo walk over the blocks of one pixel's segment [d - t, d + t] (vds.cu:771-853); visit(block, key) is
 // called for every traversed block this shard owns.  `d` is the cleaned depth (0 = invalid pixel).
@@ -145,106 +137,6 @@ __device__ __forceinline__ bool walk_ray_lean(const Map& m, RayState r, V&& visi
     r.t_max.z = az ? r.t_max.z + r.t_delta.z : r.t_max.z;
   }
   return true;
-}
-
-__global__ __launch_bounds__(kRayTile * kRayTile) void k_rays(const Cam c, const Map m, const Tab t, const float* __restrict__ depth,
-                                                              const uint8_t* __restrict__ rgb, float* __restrict__ depth_clean,
-                                                              u32* __restrict__ rgbx, u64* __restrict__ tile_keys, u32* __restrict__ tile_count) {
-  constexpr int NT = kRayTile * kRayTile;
-  __shared__ u64 set[kRayCap];
-  __shared__ u64 list[kRayCap];
-  __shared__ u32 s_count, s_overflow;
-  const int tid = threadIdx.y * kRayTile + threadIdx.x;
-  for (int i = tid; i < kRayCap; i += NT) set[i] = kKeyEmpty;
-  if (tid == 0) { s_count = 0; s_overflow = 0; }
-  __syncthreads();
-  const int row = blockIdx.y * kRayTile + threadIdx.y;
-  const int col = blockIdx.x * kRayTile + threadIdx.x;
-  float d = 0.f;
-  if (row < c.rows && col < c.cols) {
-    const size_t pix = (size_t) row * c.cols + col;
-    d = depth[pix];
-    if (d <= c.min_depth || d > c.max_depth) d = 0.f;  // camera.cu:13-18
-    depth_clean[pix] = d;
-    const uint8_t* px = rgb + pix * 3;
-    rgbx[pix] = (u32) px[0] | ((u32) px[1] << 8) | ((u32) px[2] << 16);
-    walk_ray(c, m, t, row, col, d, [&](const i3 cur, const u64 key) {
-      u32 s = (u32) __mul24(cur.z, 5851) + (u32) __mul24(cur.y, 73) + (u32) cur.x;  // cheap tile-local mix
-      s = (s ^ (s >> 7)) & (kRayCap - 1);
-#pragma unroll 1
-      for (int p = 0; p < kSetProbe; p++) {
-        const u64 old = atomicCAS(&set[s], kKeyEmpty, key);
-        if (old == kKeyEmpty) { list[atomicAdd(&s_count, 1u)] = key; return; }  // first sighting in this tile
-        if (old == key) return;
-        s = (s + 1) & (kRayCap - 1);
-      }
-      s_overflow = 1;  // far, sparse rays: more distinct blocks than the set holds
-    });
-  }
-  __syncthreads();
-  const int tile = blockIdx.y * gridDim.x + blockIdx.x;
-  const u32 n = s_count;
-  for (u32 i = tid; i < n; i += NT) tile_keys[(size_t) tile * kRayCap + i] = list[i];
-  if (tid == 0) tile_count[tile] = s_overflow ? kTileOverflow : n;
-}
-
-// un-aggregated insert of one block (used by the rare overflow path)
-template <bool PROFILE>
-__device__ __forceinline__ void insert_direct(const Cam& c, const Map& m, const Tab& t, const Fast& f, const i3 b, const u64 key) {
-  if (!block_in_frustum_approx(c, m.vs, b)) return;
-  const int slot = hash_insert(t, key);
-  if (slot == -2) atomicOr((u32*) &t.ctr[CTR_ERROR], ERR_TABLE);
-  if (slot < 0) return;
-  const int idx = atomicSub(&t.ctr[CTR_HEAP_FINE], 1);
-  if (idx < 0) {
-    atomicAdd(&t.ctr[CTR_HEAP_FINE], 1);
-    atomicExch(&t.keys[slot], kKeyTomb);
-    atomicOr((u32*) &t.ctr[CTR_ERROR], ERR_POOL);
-    return;
-  }
-  const u32 H = t.heap_fine[idx];
-  t.vals[slot] = H;
-  t.desc_fine[H] = make_int4(b.x, b.y, b.z, 1);
-  f.summary[H] = make_uint2(0x7F7FFFFFu, 0u);
-  if ((int) H >= __hip_atomic_load(&t.ctr[CTR_HWM_FINE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&t.ctr[CTR_HWM_FINE], (int) H + 1);
-  if (PROFILE) atomicAdd(&t.prof[PROF_INSERTED], 1ull);
-}
-
-template <bool PROFILE>
-__global__ __launch_bounds__(64) void k_insert(const Cam c, const Map m, const Tab t, const Fast f, const u64* __restrict__ tile_keys,
-                                               const u32* __restrict__ tile_count, const int tiles_x) {
-  const int tile = blockIdx.x;
-  const int lane = threadIdx.x;
-  if (tile == 0 && lane == 0) { t.ctr[CTR_COMPACT] = 0; t.ctr[CTR_CULLED] = 0; t.ctr[CTR_FREED_EARLY] = 0; }
-  const u32 n = tile_count[tile];
-  if (n == kTileOverflow) {
-    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
-    for (int p = lane; p < kRayTile * kRayTile; p += 64) {
-      const int row = ty * kRayTile + (p >> 4), col = tx * kRayTile + (p & 15);
-      if (row < c.rows && col < c.cols)
-        walk_ray(c, m, t, row, col, f.depth_clean[(size_t) row * c.cols + col],
-                 [&](const i3 cur, const u64 key) { insert_direct<PROFILE>(c, m, t, f, cur, key); });
-    }
-    return;
-  }
-  u32 inserted = 0;
-#pragma unroll 1
-  for (u32 base = 0; base < n; base += 64) {
-    const u32 i = base + lane;
-    const bool active = i < n;
-    const u64 key = active ? tile_keys[(size_t) tile * kRayCap + i] : kKeyEmpty;
-    const i3 b = active ? unpack_key(key) : mki3(0, 0, 0);
-    bool won = false;
-    int slot = -1;
-    if (active && block_in_frustum_approx(c, m.vs, b)) {
-      slot = hash_insert(t, key);
-      if (slot == -2) atomicOr((u32*) &t.ctr[CTR_ERROR], ERR_TABLE);
-      won = slot >= 0;
-    }
-    alloc_commit2(t, f, won, slot, b);
-    if (PROFILE) inserted += __popcll(__ballot(won));
-  }
-  if (PROFILE && lane == 0 && inserted) atomicAdd(&t.prof[PROF_INSERTED], (u64) inserted);
 }
 
 }  // namespace mrh

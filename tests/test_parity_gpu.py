@@ -365,14 +365,9 @@ def test_multires_640x480(hip, oracle):
     assert saw_coarse
 
 
-@pytest.mark.parametrize("env", [{}, {"MRH_MERGED": "0"}, {"MRH_MERGED": "0", "MRH_FUSED_NB": "1"},
-                                 {"MRH_MERGED": "0", "MRH_GC_INLINE": "0"}, {"MRH_OVERLAP": "1"}, {"MRH_MERGED": "0", "MRH_FUSED_PIPE": "1"}],
-                         ids=["two-launch", "three-launch", "half-block-waves", "separate-free", "overlapped-rays", "pipelined"])
-def test_fast_path_variants_agree_with_oracle(hip, oracle, monkeypatch, env):
-    """Every tuning variant of the single-resolution path (selected through environment knobs read at mrh_create)
-    must produce the same map: GC each frame, starve on frames 2 and 4, 640x480."""
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
+def test_gc_and_starve_at_full_resolution(hip, oracle):
+    """640x480, GC every frame, starve on frames 2 and 4: the frames where GC is decided inside k_back, the starve
+    frames (k_back without GC -> k_starve -> k_summarize_all -> k_free_lists) and the hand-over between them."""
     params = dict(synth.REPLICA_PARAMS, n_frames_invalidate_voxels=2)
     a, b = _pair(hip, oracle, synth.REPLICA_640, params, 131072)
     for f in synth.replica_stream(5):
@@ -380,7 +375,7 @@ def test_fast_path_variants_agree_with_oracle(hip, oracle, monkeypatch, env):
         pu.feed(b, f)
     a.sync()
     r = pu.compare_maps(a, b)
-    assert r["sdf_bit_exact"]
+    assert r["blocks"] > 5000 and r["sdf_bit_exact"]
 
 
 def test_golden_fixtures(hip):
