@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Generates tests/golden/cfg1_golden.json from the CPU oracle (the reference cannot be built or run here, and
+"""Generates tests/golden/cfg1_golden.json and tests/golden/lidar_golden.json from the CPU oracle (the reference cannot be built or run here, and
 its own tests store no golden values for this path — SURVEY.md §8c).  The fixture holds, per case, the
 parameters, a description of the synthetic frames, summary counts and SHA-256 of the canonical buffers:
 sorted occupancy list, position-keyed voxel payload, canonical triangle buffer and face index buffer."""
@@ -22,8 +22,42 @@ CASES = {
 }
 
 
+LIDAR_CASES = {
+    # scans are rebuilt by parity_utils.lidar_scans_from_spec: street-canyon scene, drive poses, points rounded to 1 mm
+    "street_3scans": dict(params=dict(synth.VBR_PARAMS, min_weight_threshold=1), max_depth=100.0,
+                          scans=dict(rows=16, cols=256, n=3, step=2.0)),
+    "street_clipped_2scans": dict(params=dict(synth.VBR_PARAMS, min_weight_threshold=1, virtual_voxel_size=0.25, sdf_truncation=0.5),
+                                  max_depth=30.0, scans=dict(rows=8, cols=512, n=2, step=4.0)),
+}
+
+
+def summarize(e):
+    d, v = e.dump_blocks()
+    t = e.extract_triangles()
+    V, F, C = e.extract_mesh()
+    return dict(blocks=int(len(d)), coarse_blocks=int((d["resolution"] == 1).sum()), weighted_voxels=int((v["weight"] > 0).sum()),
+                triangles=int(t.shape[0]), vertices=int(V.shape[0]), faces=int(F.shape[0]),
+                sha256_occupancy=hashlib.sha256(d.tobytes()).hexdigest(), sha256_payload=hashlib.sha256(v.tobytes()).hexdigest(),
+                sha256_triangles=hashlib.sha256(t.tobytes()).hexdigest(), sha256_faces=hashlib.sha256(F.tobytes()).hexdigest())
+
+
+def main_lidar(orc):
+    out = {"generator": "tests/golden/make_golden.py (oracle/mrh_oracle.c)", "cases": {}}
+    for name, case in LIDAR_CASES.items():
+        e = pu.make_lidar_engine(orc, case["params"], case["max_depth"], 32768)
+        for t, q, pts in pu.lidar_scans_from_spec(case["scans"]):
+            e.set_pose(synth.quat_to_rot(q), t)
+            e.upload_points(pts)
+            e.integrate_points()
+        out["cases"][name] = dict(params=case["params"], max_depth=case["max_depth"], scans=case["scans"], **summarize(e))
+        print(name, {k: out["cases"][name][k] for k in ("blocks", "weighted_voxels", "triangles", "faces")})
+        e.close()
+    json.dump(out, open(os.path.join(HERE, "lidar_golden.json"), "w"), indent=1, sort_keys=True)
+
+
 def main():
     orc = pu.oracle_lib()
+    main_lidar(orc)
     out = {"generator": "tests/golden/make_golden.py (oracle/mrh_oracle.c)", "cases": {}}
     for name, case in CASES.items():
         e = pu.make_engine(orc, synth.CFG1, case["params"], 16384)

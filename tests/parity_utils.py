@@ -108,3 +108,20 @@ def frame_from_spec(spec: dict) -> synth.Frame:
     if spec["kind"] == "sphere":
         return synth.cfg1_sphere(radius=spec.get("radius", 0.5), zc=spec["zc"])
     raise ValueError(spec)
+
+
+def make_lidar_engine(lib, params: dict, max_depth: float, num_sdf_blocks: int = 32768) -> capi.Engine:
+    """Engine for point-cloud integration: any camera, only max_depth (the integration distance) matters."""
+    e = capi.Engine(lib, capi.Params(num_sdf_blocks=num_sdf_blocks, **params))
+    e.set_camera(1.0, 1.0, 0.0, 0.0, 1, 1, params["min_depth"], max_depth, model=1)
+    return e
+
+
+def lidar_scans_from_spec(spec: dict):
+    """(t, q, points) of the golden LiDAR cases: street-canyon scene, drive poses; points are rounded to 1 mm so that
+    the fixture does not depend on the last bits of the host's trigonometric functions."""
+    scene = synth.street_canyon()
+    for t, q in synth.drive_poses(spec["n"], step=spec["step"]):
+        pts = synth.lidar_scan(scene, t, q, rows=spec["rows"], cols=spec["cols"])
+        pts = (np.round(pts.astype(np.float64) * 1000.0) / 1000.0).astype(np.float32)
+        yield t, q, pts

@@ -378,24 +378,18 @@ def test_gc_and_starve_at_full_resolution(hip, oracle):
     assert r["blocks"] > 5000 and r["sdf_bit_exact"]
 
 
-def test_golden_fixtures(hip):
-    """Committed fixtures (generated by tests/golden/make_golden.py from the oracle): canonical buffers
-    of cfg1 hashed with SHA-256 plus summary counts."""
-    g = json.load(open(os.path.join(GOLDEN, "cfg1_golden.json")))
+@pytest.mark.parametrize("fixture", ["cfg1_golden.json", "lidar_golden.json"])
+def test_golden_fixtures(hip, fixture):
+    """Committed fixtures (generated by tests/golden/make_golden.py from the oracle): canonical buffers hashed with
+    SHA-256 plus summary counts, RGB-D (cfg1) and LiDAR cases."""
+    import test_golden_cpu as tg
+
+    g = json.load(open(os.path.join(GOLDEN, fixture)))
+    runner = tg.run_rgbd if fixture.startswith("cfg1") else tg.run_lidar
     for name, case in g["cases"].items():
-        e = pu.make_engine(hip, synth.CFG1, case["params"], 16384)
-        for spec in case["frames"]:
-            pu.feed(e, pu.frame_from_spec(spec))
+        e = runner(hip, case)
         e.sync()
-        d, v = e.dump_blocks()
-        assert len(d) == case["blocks"], name
-        assert hashlib.sha256(d.tobytes()).hexdigest() == case["sha256_occupancy"], name
-        assert hashlib.sha256(v.tobytes()).hexdigest() == case["sha256_payload"], name
-        t = e.extract_triangles()
-        V, F, C = e.extract_mesh()
-        assert t.shape[0] == case["triangles"], name
-        assert hashlib.sha256(F.tobytes()).hexdigest() == case["sha256_faces"], name
-        assert hashlib.sha256(t.tobytes()).hexdigest() == case["sha256_triangles"], name
+        tg.check(e, case, name)
         e.close()
 
 
