@@ -1042,8 +1042,10 @@ int mrh_extract_triangles(mrh_ctx* c, const mrh_triangle** out_tris, uint64_t* o
     u64* d_offsets = nullptr;
     HIP_TRY(c, hipMalloc((void**) &d_counts, (size_t) n * sizeof(u32)));
     HIP_TRY(c, hipMalloc((void**) &d_offsets, (size_t) n * sizeof(u64)));
+    uint8_t* d_per_voxel = nullptr;  // triangles per voxel from the count pass: the emit pass skips the empty ones
+    HIP_TRY(c, hipMalloc((void**) &d_per_voxel, (size_t) n * 512));
     const int grid = n < 4096 ? n : 4096;
-    k_mc<false><<<grid, 512, 0, s>>>(c->map, c->tab, c->tab.compact, n, d_counts, nullptr, nullptr, 0);
+    k_mc<false><<<grid, 512, 0, s>>>(c->map, c->tab, c->tab.compact, n, d_counts, nullptr, nullptr, 0, d_per_voxel);
     std::vector<u32> counts((size_t) n);
     HIP_TRY(c, hipMemcpyAsync(counts.data(), d_counts, (size_t) n * sizeof(u32), hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
@@ -1055,14 +1057,14 @@ int mrh_extract_triangles(mrh_ctx* c, const mrh_triangle** out_tris, uint64_t* o
     c->tri_blocks.resize((size_t) n);
     for (int i = 0; i < n; i++) c->tri_blocks[i] = {list[i].x, list[i].y, list[i].z, (list[i].w & (int) kValCoarseBit) ? 1 : 0};
     if (total > c->max_triangles) {
-      (void) hipFree(d_counts); (void) hipFree(d_offsets);
+      (void) hipFree(d_counts); (void) hipFree(d_offsets); (void) hipFree(d_per_voxel);
       return fail(c, MRH_ERR_CAPACITY, "triangle buffer full: %llu triangles > max_triangles %llu", (unsigned long long) total, (unsigned long long) c->max_triangles);
     }
     if (total > 0) {
       mrh_triangle* d_tris = nullptr;
       HIP_TRY(c, hipMalloc((void**) &d_tris, total * sizeof(mrh_triangle)));
       HIP_TRY(c, hipMemcpyAsync(d_offsets, offsets.data(), (size_t) n * sizeof(u64), hipMemcpyHostToDevice, s));
-      k_mc<true><<<grid, 512, 0, s>>>(c->map, c->tab, c->tab.compact, n, d_counts, d_offsets, d_tris, total);
+      k_mc<true><<<grid, 512, 0, s>>>(c->map, c->tab, c->tab.compact, n, d_counts, d_offsets, d_tris, total, d_per_voxel);
       if (dbg) { HIP_TRY(c, hipStreamSynchronize(s)); t3 = now(); }
       c->tris.resize(total);
       HIP_TRY(c, hipMemcpyAsync(c->tris.data(), d_tris, total * sizeof(mrh_triangle), hipMemcpyDeviceToHost, s));
@@ -1071,10 +1073,11 @@ int mrh_extract_triangles(mrh_ctx* c, const mrh_triangle** out_tris, uint64_t* o
       if (!c->mesh_on_host) { prc = process_triangles_device(c, d_tris, total); processed = true; }
       HIP_TRY(c, hipStreamSynchronize(s));
       HIP_TRY(c, hipFree(d_tris));
-      if (prc) { (void) hipFree(d_counts); (void) hipFree(d_offsets); return prc; }
+      if (prc) { (void) hipFree(d_counts); (void) hipFree(d_offsets); (void) hipFree(d_per_voxel); return prc; }
     }
     HIP_TRY(c, hipFree(d_counts));
     HIP_TRY(c, hipFree(d_offsets));
+    HIP_TRY(c, hipFree(d_per_voxel));
     HIP_TRY(c, hipGetLastError());
   }
   c->last_triangles = c->tris.size();

@@ -22,15 +22,40 @@ struct VoxSample {
   bool found;
 };
 
+// The 27 blocks around the block a workgroup is extracting, resolved ONCE per workgroup (table value, or kNbAbsent):
+// on a single-resolution map every sample of marching cubes falls into this neighbourhood, so a lookup is a shift, a
+// subtraction and one LDS read instead of the float voxel->block detour, a 64-bit hash and a dependent probe of the
+// global table per sample (72 samples per voxel that reaches all eight corners).
+constexpr u32 kNbAbsent = 0xFFFFFFFFu;
+struct Neigh {
+  const u32* vals;  // LDS [27], index (dz + 1) * 9 + (dy + 1) * 3 + (dx + 1); nullptr: no table (multi-resolution maps)
+  i3 base;          // block position of the workgroup's block
+  int shift_limit;  // Map::block_shift_limit
+};
+
 // vds.cu:163-205 getVoxel(int3[, block_res]); coarse blocks are read with the writers' dense index
-__device__ __forceinline__ VoxSample get_voxel_i(const Map& m, const Tab& t, i3 v) {
+__device__ __forceinline__ VoxSample get_voxel_i(const Map& m, const Tab& t, const Neigh& nb, i3 v) {
   VoxSample r;
   r.sdf = 0.f; r.rgbw = 0; r.res = 0; r.found = false;
-  u64 key;
-  if (!pack_key(voxel_to_block(v, m.vs), key)) return r;
-  const int s = hash_find(t, key);
-  if (s < 0) return r;
-  const u32 val = t.vals[s];
+  u32 val = kNbAbsent;
+  bool resolved = false;
+  if (nb.vals) {
+    const int ax = v.x < 0 ? -v.x : v.x, ay = v.y < 0 ? -v.y : v.y, az = v.z < 0 ? -v.z : v.z;
+    if ((u32) (ax | ay | az) < (u32) nb.shift_limit) {  // voxel -> block is the shift here (mrh_device.h)
+      const int dx = (v.x >> 3) - nb.base.x, dy = (v.y >> 3) - nb.base.y, dz = (v.z >> 3) - nb.base.z;
+      if ((u32) (dx + 1) < 3u && (u32) (dy + 1) < 3u && (u32) (dz + 1) < 3u) {
+        val = nb.vals[(dz + 1) * 9 + (dy + 1) * 3 + (dx + 1)];
+        resolved = true;
+      }
+    }
+  }
+  if (!resolved) {
+    u64 key;
+    if (!pack_key(voxel_to_block(v, m.vs), key)) return r;
+    const int s = hash_find(t, key);
+    if (s >= 0) val = t.vals[s];
+  }
+  if (val == kNbAbsent) return r;
   r.res = (val & kValCoarseBit) ? 1 : 0;
   r.found = true;
   const VoxPtr vp = vox_ptr(t, val);
@@ -39,7 +64,7 @@ __device__ __forceinline__ VoxSample get_voxel_i(const Map& m, const Tab& t, i3 
   r.rgbw = vp.rgbw[li];
   return r;
 }
-__device__ __forceinline__ VoxSample get_voxel_f(const Map& m, const Tab& t, f3 pos) { return get_voxel_i(m, t, world_to_voxel(m.vs, pos)); }
+__device__ __forceinline__ VoxSample get_voxel_f(const Map& m, const Tab& t, const Neigh& nb, f3 pos) { return get_voxel_i(m, t, nb, world_to_voxel(m.vs, pos)); }
 
 // vds.cu:236-240 getVoxelSize(float3).  With a single resolution every block (and every miss) answers vs.
 __device__ __forceinline__ float get_voxel_size_f(const Map& m, const Tab& t, f3 pos) {
@@ -54,7 +79,7 @@ __device__ __forceinline__ float get_voxel_size_f(const Map& m, const Tab& t, f3
 }
 
 // vds.cu:260-338
-__device__ __forceinline__ bool trilinear(const Map& m, const Tab& t, f3 pos, float& dist) {
+__device__ __forceinline__ bool trilinear(const Map& m, const Tab& t, const Neigh& nb, f3 pos, float& dist) {
   const float voxel_size = get_voxel_size_f(m, t, pos);
   const f3 pos_dual = mk3(pos.x - voxel_size * 0.5f, pos.y - voxel_size * 0.5f, pos.z - voxel_size * 0.5f);
   int base_resolution = 0;
@@ -67,7 +92,7 @@ __device__ __forceinline__ bool trilinear(const Map& m, const Tab& t, f3 pos, fl
   }
   dist = 0.f;
   float pos_sdf = 0.f;
-  if (t.multi_res) pos_sdf = get_voxel_f(m, t, pos_dual).sdf;  // only consumed on resolution jumps
+  if (t.multi_res) pos_sdf = get_voxel_f(m, t, nb, pos_dual).sdf;  // only consumed on resolution jumps
   const float x0 = pos_dual.x, y0 = pos_dual.y, z0 = pos_dual.z;
   float x1 = x0, y1 = y0, z1 = z0;
   float sdf[8];
@@ -75,12 +100,12 @@ __device__ __forceinline__ bool trilinear(const Map& m, const Tab& t, f3 pos, fl
   for (int i = 0; i < 8; ++i) {
     const int dx = i & 1, dy = (i >> 1) & 1, dz = (i >> 2) & 1;
     const f3 vp = mk3(pos_dual.x + (float) dx * voxel_size, pos_dual.y + (float) dy * voxel_size, pos_dual.z + (float) dz * voxel_size);
-    const VoxSample v = get_voxel_f(m, t, vp);
+    const VoxSample v = get_voxel_f(m, t, nb, vp);
     if ((v.rgbw >> 24) == 0) return false;
     if (v.res > base_resolution) {
       const float nvs = voxel_size * 2;
       const f3 np = mk3(pos.x - nvs * 0.5f + (float) dx * nvs, pos.y - nvs * 0.5f + (float) dy * nvs, pos.z - nvs * 0.5f + (float) dz * nvs);
-      const float np_sdf = get_voxel_f(m, t, np).sdf;
+      const float np_sdf = get_voxel_f(m, t, nb, np).sdf;
       const float alpha = 0.5f;
       sdf[i] = (1 - alpha) * pos_sdf + alpha * np_sdf;
     } else {
@@ -133,7 +158,7 @@ __device__ __forceinline__ mrh_vertex vertex_interp(f3 p1, f3 p2, float d1, floa
 
 // marching_cubes.cu:72-261 for one voxel.  Returns the triangle count; with EMIT writes them to out[0..n).
 template <bool EMIT>
-__device__ __forceinline__ int mc_voxel(const Map& m, const Tab& t, f3 pf, mrh_triangle* out) {
+__device__ __forceinline__ int mc_voxel(const Map& m, const Tab& t, const Neigh& nb, f3 pf, mrh_triangle* out) {
   const float vvs = get_voxel_size_f(m, t, pf);
   const float P = vvs * 0.5f;
   const float M = -P;
@@ -161,8 +186,8 @@ __device__ __forceinline__ int mc_voxel(const Map& m, const Tab& t, f3 pf, mrh_t
 #pragma unroll
   for (int k = 0; k < 8; k++) {
     p[k] = mk3(pf.x + ((k & 1) ? sP.x : sM.x), pf.y + ((k & 2) ? sP.y : sM.y), pf.z + ((k & 4) ? sP.z : sM.z));
-    const bool valid = trilinear(m, t, p[k], dist[k]);
-    const VoxSample v = get_voxel_f(m, t, p[k]);
+    const bool valid = trilinear(m, t, nb, p[k], dist[k]);
+    const VoxSample v = get_voxel_f(m, t, nb, p[k]);
     col[k] = v.rgbw;
     if (!valid) {
       if ((int) (v.rgbw >> 24) < m.min_weight_threshold) return 0;
@@ -200,28 +225,47 @@ __device__ __forceinline__ int mc_voxel(const Map& m, const Tab& t, f3 pf, mrh_t
   return ntri;
 }
 
-// Workgroup per block of the sorted list, lane = voxel.  EMIT = false: counts[e] = triangles of block e.
-// EMIT = true: triangles written at offsets[e] + (exclusive prefix over voxel index).
+// Workgroup per block of the sorted list, lane = voxel.  EMIT = false: counts[e] = triangles of block e and
+// per_voxel[e * 512 + v] = triangles of voxel v.  EMIT = true: triangles written at offsets[e] + (exclusive prefix over
+// voxel index); voxels the count pass found empty (the vast majority) are not evaluated a second time.
 template <bool EMIT>
 __global__ __launch_bounds__(512) void k_mc(const Map m, const Tab t, const int4* __restrict__ sorted, const int n,
                                             u32* __restrict__ counts, const u64* __restrict__ offsets,
-                                            mrh_triangle* __restrict__ out, const u64 max_tris) {
+                                            mrh_triangle* __restrict__ out, const u64 max_tris, uint8_t* __restrict__ per_voxel) {
   __shared__ u32 s_wave[8];
+  __shared__ u32 s_nb[27];
   const int v = threadIdx.x;
   const int wave = v >> 6;
   for (int e = blockIdx.x; e < n; e += gridDim.x) {
     const int4 ent = sorted[e];
     const u32 val = (u32) ent.w;
     const bool coarse = (val & kValCoarseBit) != 0;
+    Neigh nb;
+    nb.vals = nullptr;
+    nb.base = mki3(ent.x, ent.y, ent.z);
+    nb.shift_limit = m.block_shift_limit;
+    if (!t.multi_res) {  // single resolution: resolve the 27 surrounding blocks once
+      if (v < 27) {
+        const i3 b = mki3(ent.x + (v % 3) - 1, ent.y + ((v / 3) % 3) - 1, ent.z + (v / 9) - 1);
+        u64 key;
+        int slot = -1;
+        if (pack_key(b, key)) slot = hash_find(t, key);
+        s_nb[v] = slot >= 0 ? t.vals[slot] : kNbAbsent;
+      }
+      __syncthreads();
+      nb.vals = s_nb;
+    }
     int ntri = 0;
     mrh_triangle tris[5];
+    const bool skip = EMIT && per_voxel[(size_t) e * 512 + v] == 0;
     // sharded maps: halo blocks imported from other ranks are read by the lookups but emit nothing themselves
-    if ((!coarse || v < kCoarseVoxels) && owns_block(m, mki3(ent.x, ent.y, ent.z))) {
+    if (!skip && (!coarse || v < kCoarseVoxels) && owns_block(m, mki3(ent.x, ent.y, ent.z))) {
       i3 pi;
       if (!coarse) pi = mki3(ent.x * kBlockSide + (v & 7), ent.y * kBlockSide + ((v >> 3) & 7), ent.z * kBlockSide + (v >> 6));
       else pi = mki3(ent.x * kBlockSide + 2 * (v & 3), ent.y * kBlockSide + 2 * ((v >> 2) & 3), ent.z * kBlockSide + 2 * (v >> 4));
-      ntri = mc_voxel<EMIT>(m, t, voxel_to_world(m.vs, pi), tris);
+      ntri = mc_voxel<EMIT>(m, t, nb, voxel_to_world(m.vs, pi), tris);
     }
+    if (!EMIT) per_voxel[(size_t) e * 512 + v] = (uint8_t) ntri;
     // block-wide exclusive scan of ntri in voxel-index order: wave scan + 8 wave totals through LDS
     u32 incl = (u32) ntri;
     for (int off = 1; off < 64; off <<= 1) {
