@@ -38,6 +38,10 @@
  *       frame coarsens nothing, vds.cu:2040-2043 + :2091-2093, which can write out of bounds).
  *   D4  vertex merge with epsilon == 0 compares the three doubles bitwise (the reference
  *       hashes the bytes and compares with ==; they differ only for -0.0 / NaN).
+ *   D6  LiDAR scans (integrate3DKernel, vds.cu:1215-1379): the reference updates a voxel with a
+ *       non-atomic read-modify-write per point, so the points of one scan that cross the same voxel
+ *       race.  Canonical: every voxel receives its updates in ascending point index (the sequential
+ *       loop of mrh_integrate_points).  norm3df(x, y, z) is restated as sqrtf((x*x + y*y) + z*z).
  */
 #include <float.h>
 #include <limits.h>
