@@ -233,9 +233,24 @@ int mrh_extract_mesh(mrh_ctx* ctx, const double** out_vertices, uint64_t* out_nv
  * current_occupied_blocks_ (voxel_data_structures.cpp:148-161, vds.cu:447). Blocks. */
 int mrh_get_stats(mrh_ctx* ctx, mrh_stats* out);
 
+/* The two scalar read-backs of the per-frame streaming test (geowrapper.cpp:137: getHeapHighFreeCount() <=
+ * stream_threshold * num_sdf_blocks) without the full statistics pass.  Blocks. */
+int mrh_get_free_blocks(mrh_ctx* ctx, int64_t* out_free_fine, int64_t* out_free_coarse);
+
 /* 1 = bracket the integrate kernel with HIP events and count updated voxels / inserted /
  * freed blocks on the device (used by bench.py for the roofline figures); 0 = off. */
 int mrh_set_profile(mrh_ctx* ctx, int enabled);
+
+/* Streamer, device half: Streamer::streamOutToHostPass0 / streamAllOut (streamer.cpp:168-205,
+ * :232-281; integrateFromGlobalHashPass1/2Kernel streamer.cu:11-160).  Every live block whose origin
+ * (block position * 8 * voxel size) lies at distance >= radius from `center` is copied out — descs[i] and 512
+ * reference-layout voxels at voxels[i*512 ...] (coarse blocks use the first 64), ordered by block position — and
+ * removed from the device map (entry deleted, slot zeroed and returned to its free list).  radius < 0: every block
+ * (streamAllOut).  With descs == NULL nothing is removed and only the count of blocks that WOULD leave is returned.
+ * The host keeps the blocks (GeoWrapper's chunk grid) and brings them back with mrh_import_blocks
+ * (Streamer::streamInToGPU, streamer.cpp:358-378). */
+int mrh_stream_out(mrh_ctx* ctx, const float center[3], float radius, mrh_block_desc* descs, mrh_voxel* voxels,
+                   uint64_t capacity, uint64_t* out_n);
 
 /* Copies every live block out: descs[i] and 512 reference-layout voxels at
  * voxels[i*512 .. i*512+511] (coarse blocks use the first 64).  With descs == NULL only the

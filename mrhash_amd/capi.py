@@ -96,7 +96,7 @@ assert TRI_DTYPE.itemsize == 24
 ABI_SYMBOLS = (
     "mrh_create mrh_destroy mrh_reset mrh_last_error mrh_set_camera mrh_set_pose mrh_upload_depth "
     "mrh_upload_rgb mrh_set_depth_device mrh_set_rgb_device mrh_integrate mrh_integrate_resume mrh_exchange_buffer mrh_sync "
-    "mrh_upload_points mrh_set_points_device mrh_integrate_points "
+    "mrh_upload_points mrh_set_points_device mrh_integrate_points mrh_stream_out mrh_get_free_blocks "
     "mrh_extract_triangles mrh_extract_mesh mrh_get_stats mrh_set_profile mrh_dump_blocks "
     "mrh_get_voxel mrh_import_blocks mrh_get_triangle_blocks mrh_process_triangles mrh_selftest_division mrh_version"
 ).split()
@@ -125,6 +125,8 @@ def _declare(lib: C.CDLL) -> C.CDLL:
     lib.mrh_upload_points.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
     lib.mrh_set_points_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
     lib.mrh_integrate_points.argtypes = [C.c_void_p, C.c_int]
+    lib.mrh_get_free_blocks.argtypes = [C.c_void_p, P(C.c_int64), P(C.c_int64)]
+    lib.mrh_stream_out.argtypes = [C.c_void_p, P(C.c_float), C.c_float, C.c_void_p, C.c_void_p, C.c_uint64, P(C.c_uint64)]
     lib.mrh_integrate_resume.argtypes = [C.c_void_p]
     lib.mrh_exchange_buffer.argtypes = [C.c_void_p, P(C.c_void_p), P(C.c_uint64), P(C.c_int)]
     lib.mrh_sync.argtypes = [C.c_void_p]
@@ -346,6 +348,23 @@ class Engine:
             return np.frombuffer((C.c_char * sz).from_address(p.value), dtype=dt).reshape(n, 3).copy()
 
         return arr(pv, nv.value, np.float64), arr(pf, nf.value, np.int32), arr(pc, nv.value, np.float64)
+
+    def free_blocks(self) -> Tuple[int, int]:
+        a, b = C.c_int64(), C.c_int64()
+        self._check(self.lib.mrh_get_free_blocks(self._ctx, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def stream_out(self, center, radius: float) -> Tuple[np.ndarray, np.ndarray]:
+        """Streamer device half: blocks at distance >= radius from `center` (radius < 0: all) are copied out, ordered by
+        block position, and removed from the device map.  Returns (descs, voxels[n, 512])."""
+        cen = (C.c_float * 3)(*[float(v) for v in center])
+        n = C.c_uint64()
+        self._check(self.lib.mrh_stream_out(self._ctx, cen, radius, None, None, 0, C.byref(n)))
+        descs = np.zeros(n.value, dtype=DESC_DTYPE)
+        vox = np.zeros((n.value, 512), dtype=VOXEL_DTYPE)
+        if n.value:
+            self._check(self.lib.mrh_stream_out(self._ctx, cen, radius, descs.ctypes.data, vox.ctypes.data, n.value, C.byref(n)))
+        return descs, vox
 
     def dump_blocks(self) -> Tuple[np.ndarray, np.ndarray]:
         """Canonical dump: (descs sorted by (x,y,z), voxels[n,512]) in the reference Voxel layout."""

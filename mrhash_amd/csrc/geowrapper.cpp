@@ -3,6 +3,8 @@
 // print-and-exit (cuda_utils.cuh:9-17) are raised as std::runtime_error instead.
 #include "geowrapper.h"
 
+#include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
@@ -46,6 +48,7 @@ GeoWrapper::GeoWrapper(float sdf_truncation, float sdf_truncation_scale, int int
   // MRHASH_NUM_SDF_BLOCKS / MRHASH_DEVICE override
   if (const char* e = std::getenv("MRHASH_NUM_SDF_BLOCKS")) p.num_sdf_blocks = std::strtoull(e, nullptr, 10);
   if (const char* e = std::getenv("MRHASH_DEVICE")) p.device_id = std::atoi(e);
+  if (const char* e = std::getenv("MRHASH_STREAM")) streaming_enabled_ = std::atoi(e) != 0;
   p.shard_count = 1;
   int rc = mrh_create(&p, &ctx_);
   if (rc != MRH_OK) throw std::runtime_error(std::string("GeoWrapper::GeoWrapper | ") + mrh_last_error(nullptr));
@@ -75,6 +78,18 @@ void GeoWrapper::setCurrPose(const std::array<float, 3>& t, const std::array<flo
 
 void GeoWrapper::setCamera(float fx, float fy, float cx, float cy, int rows, int cols, float min_depth, float max_depth, int camera_model) {
   check(mrh_set_camera(ctx_, fx, fy, cx, cy, rows, cols, min_depth, max_depth, camera_model), "setCamera");
+  max_depth_ = max_depth;
+  // Streaming radius.  The reference uses max_depth itself (geowrapper.cpp:138), which is the z-range of a pinhole frame,
+  // not its reach: a voxel at z = max_depth in an image corner is farther from the camera centre than that, so blocks
+  // still inside the frustum can be paged out and then re-created empty.  Here the radius is the true reach of a frame:
+  // (max_depth + truncation) along the most oblique pixel ray, plus one block diagonal.
+  const float trunc = sdf_truncation_ + sdf_truncation_scale_ * max_depth;
+  float sec = 1.f;
+  if (camera_model == MRH_CAMERA_PINHOLE && fx > 0.f && fy > 0.f) {
+    const float ux = std::max(cx + 0.5f, (float) cols - cx) / fx, uy = std::max(cy + 0.5f, (float) rows - cy) / fy;
+    sec = std::sqrt(1.f + ux * ux + uy * uy);
+  }
+  reach_ = (max_depth + trunc) * sec + 8.f * virtual_voxel_size_ * std::sqrt(3.f);
 }
 
 void GeoWrapper::setDepthImage(const float* data, size_t rows, size_t cols) {
@@ -95,7 +110,89 @@ void GeoWrapper::setPointCloud(const float* pts, size_t n, const float* normals_
   else normals_.clear();
 }
 
+// ---- streamer, host side: chunk grid (streamer.cuh:251-352, streamer.cpp:214-247, :292-331) ---------------------------
+namespace {
+constexpr float kStreamThreshold = 0.15f;  // params.h:28 stream_threshold
+}
+
+std::array<int, 3> GeoWrapper::worldToChunks(const std::array<float, 3>& pw) const {
+  std::array<int, 3> c;
+  const float ext = (float) voxel_extents_scale_;  // chunk edge in metres (geowrapper.cpp:56)
+  for (int a = 0; a < 3; a++) {
+    const float p = pw[a] / ext;
+    const float s = (float) ((0.f < p) - (p < 0.f));
+    c[a] = (int) (p + s * 0.5f);
+  }
+  return c;
+}
+
+float GeoWrapper::chunkRadius() const {
+  const float ext = (float) voxel_extents_scale_;
+  return std::sqrt(3.f * ext * ext) / 2.0f;  // voxel_extents_.norm() / 2 (streamer.cuh:315-317)
+}
+
+// any part of the chunk within `radius` of `center`?  (The reference's isChunkInSphere, streamer.cuh:345-352, asks for
+// the WHOLE chunk to be inside, which leaves blocks the next frame can touch on the host; see stream().)
+bool GeoWrapper::chunkTouchesSphere(const std::array<int, 3>& chunk, const std::array<float, 3>& center, float radius) const {
+  const float ext = (float) voxel_extents_scale_;
+  const float dx = chunk[0] * ext - center[0], dy = chunk[1] * ext - center[1], dz = chunk[2] * ext - center[2];
+  return std::sqrt(dx * dx + dy * dy + dz * dz) <= radius + chunkRadius();
+}
+
+void GeoWrapper::streamOutToGrid(const std::array<float, 3>& center, float radius) {
+  uint64_t n = 0;
+  check(mrh_stream_out(ctx_, center.data(), radius, nullptr, nullptr, 0, &n), "stream");
+  if (n == 0) return;
+  std::vector<mrh_block_desc> descs(n);
+  std::vector<mrh_voxel> vox(n * 512);
+  check(mrh_stream_out(ctx_, center.data(), radius, descs.data(), vox.data(), n, &n), "stream");
+  const float bs = 8.f * virtual_voxel_size_;
+  for (uint64_t k = 0; k < n; k++) {  // Streamer::integrateInChunkGrid
+    const std::array<float, 3> pw = {(float) descs[k].x * bs, (float) descs[k].y * bs, (float) descs[k].z * bs};
+    HostBlock b;
+    b.desc = descs[k];
+    b.voxels.assign(vox.begin() + k * 512, vox.begin() + (k + 1) * 512);
+    grid_[worldToChunks(pw)].push_back(std::move(b));
+  }
+}
+
+void GeoWrapper::streamInFromGrid(const std::array<float, 3>* center, float radius) {
+  std::vector<mrh_block_desc> descs;
+  std::vector<mrh_voxel> vox;
+  for (auto it = grid_.begin(); it != grid_.end();) {
+    if (center && !chunkTouchesSphere(it->first, *center, radius)) { ++it; continue; }
+    for (const HostBlock& b : it->second) {
+      descs.push_back(b.desc);
+      vox.insert(vox.end(), b.voxels.begin(), b.voxels.end());
+    }
+    it = grid_.erase(it);  // "it lives on the device from now"
+  }
+  if (!descs.empty()) check(mrh_import_blocks(ctx_, descs.data(), vox.data(), descs.size()), "stream");
+}
+
+// Streamer::stream (streamer.cpp:333-354) with the two radii chosen so that paging is TRANSPARENT — a block is either on
+// the device or in the host grid, and everything a frame can touch is on the device:
+//   in : every chunk that touches the sphere of the frame's reach comes back (also called every frame by compute());
+//   out: blocks farther than reach + 2 chunk radii leave — none of them lies in a chunk the next stream-in would take.
+void GeoWrapper::stream(const std::array<float, 3>& camera_position, float radius) {
+  streamOutToGrid(camera_position, radius + 2.f * chunkRadius() + 1e-3f);
+  streamInFromGrid(&camera_position, radius);
+}
+
+size_t GeoWrapper::hostGridBlocks() const {
+  size_t n = 0;
+  for (const auto& kv : grid_) n += kv.second.size();
+  return n;
+}
+
 void GeoWrapper::compute() {
+  if (streaming_enabled_) {
+    const std::array<float, 3> cam = {pose_[3], pose_[7], pose_[11]};
+    if (!grid_.empty()) streamInFromGrid(&cam, reach_);  // host-only test unless a paged-out chunk is within reach
+    int64_t free_fine = 0;
+    check(mrh_get_free_blocks(ctx_, &free_fine, nullptr), "compute");  // geowrapper.cpp:137-138
+    if ((float) free_fine <= kStreamThreshold * (float) num_sdf_blocks_) stream(cam, reach_);
+  }
   const float R[9] = {pose_[0], pose_[1], pose_[2], pose_[4], pose_[5], pose_[6], pose_[8], pose_[9], pose_[10]};
   const float t[3] = {pose_[3], pose_[7], pose_[11]};
   check(mrh_set_pose(ctx_, R, t), "compute");
@@ -114,6 +211,7 @@ void GeoWrapper::compute() {
 }
 
 void GeoWrapper::extractMesh(const std::string& filename) {
+  streamInFromGrid(nullptr, 0.f);  // blocks the streamer paged out take part in the mesh (geowrapper.cpp:162-188 walks the grid)
   const mrh_triangle* tris = nullptr;
   uint64_t nt = 0;
   std::cout << "GeoWrapper::extractMesh | extracting..." << std::endl;
@@ -147,14 +245,16 @@ void GeoWrapper::extractMesh(const std::string& filename) {
 }
 
 void GeoWrapper::streamAllOut() {
-  // The reference pages every block to the host chunk grid here (streamer.cpp:250-281).  Host paging is
-  // outside this round's scope; the map stays resident in HBM, so this only drains the stream.
+  // The reference pages every block to the host chunk grid here (streamer.cpp:250-281) because its marching cubes
+  // then walks the grid chunk by chunk.  With 288 GB of HBM the whole map is extracted in one pass instead
+  // (extractMesh brings back whatever the streamer paged out), so this only drains the stream.
   check(mrh_sync(ctx_), "streamAllOut");
 }
 
 void GeoWrapper::clearBuffers() {
   std::cout << "clearing buffers..." << std::endl;
   check(mrh_reset(ctx_), "clearBuffers");
+  grid_.clear();  // Streamer::clearGrid (geowrapper.cpp:555)
 }
 
 void GeoWrapper::serializeData(const std::string& filename_hash, const std::string& filename_voxel) {
@@ -209,12 +309,18 @@ void GeoWrapper::serializeGrid(const std::string& filename) {
   check(mrh_dump_blocks(ctx_, descs.data(), vox.data(), n, &n), "serializeGrid");
   std::ofstream o(filename, std::ios::binary);
   if (!o.is_open()) throw std::runtime_error("GeoWrapper::serializeGrid | cannot open " + filename);
+  const uint64_t total = n + hostGridBlocks();  // device-resident blocks, then the streamer's host chunk grid
   o.write("MRHGRID1", 8);
-  o.write((const char*) &n, 8);
+  o.write((const char*) &total, 8);
   for (uint64_t k = 0; k < n; ++k) {
     o.write((const char*) &descs[k], sizeof(mrh_block_desc));
     o.write((const char*) &vox[k * 512], 512 * sizeof(mrh_voxel));
   }
+  for (const auto& kv : grid_)
+    for (const HostBlock& b : kv.second) {
+      o.write((const char*) &b.desc, sizeof(mrh_block_desc));
+      o.write((const char*) b.voxels.data(), 512 * sizeof(mrh_voxel));
+    }
 }
 
 void GeoWrapper::deserializeGrid(const std::string& filename) {

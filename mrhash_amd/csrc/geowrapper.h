@@ -5,6 +5,7 @@
 #pragma once
 
 #include <array>
+#include <map>
 #include <cstdint>
 #include <string>
 #include <vector>
@@ -70,6 +71,10 @@ public:
   const std::vector<double>& colors() const { return C_; }
 
   void streamAllOut();
+  // Streamer::stream (streamer.cpp:333-354): blocks farther than `radius` from `camera_position` leave the device for the
+  // host chunk grid, chunks inside the sphere come back.  compute() calls it when the pool runs low (geowrapper.cpp:137-138).
+  void stream(const std::array<float, 3>& camera_position, float radius);
+  size_t hostGridBlocks() const;  // blocks currently held by the host chunk grid
   void clearBuffers();
   void serializeData(const std::string& filename_hash, const std::string& filename_voxel);
   void serializeGrid(const std::string& filename);
@@ -81,6 +86,20 @@ public:
 
 private:
   void check(int rc, const char* what);
+  // host side of the streamer (streamer.cuh:40-80, :251-352): chunk grid of streamed-out blocks
+  struct HostBlock {
+    mrh_block_desc desc;
+    std::vector<mrh_voxel> voxels;  // 512, reference layout
+  };
+  std::array<int, 3> worldToChunks(const std::array<float, 3>& pw) const;
+  float chunkRadius() const;
+  bool chunkTouchesSphere(const std::array<int, 3>& chunk, const std::array<float, 3>& center, float radius) const;
+  void streamOutToGrid(const std::array<float, 3>& center, float radius);
+  void streamInFromGrid(const std::array<float, 3>* center, float radius);  // center == nullptr: everything
+  std::map<std::array<int, 3>, std::vector<HostBlock>> grid_;
+  bool streaming_enabled_ = true;  // MRHASH_STREAM=0 turns the per-frame test off
+  float max_depth_ = 0.f;
+  float reach_ = 0.f;  // farthest distance from the camera centre at which a frame can touch a block (set by setCamera)
 
   int hash_num_buckets_ = 0, num_sdf_blocks_ = 0, hash_bucket_size_ = 10;
   float sdf_truncation_, sdf_truncation_scale_;

@@ -961,6 +961,17 @@ int mrh_sync(mrh_ctx* c) {
   return check_device_flags(c, flags);
 }
 
+int mrh_get_free_blocks(mrh_ctx* c, int64_t* out_free_fine, int64_t* out_free_coarse) {
+  int rc = ensure_ready(c, "mrh_get_free_blocks");
+  if (rc) return rc;
+  int h[2] = {0, 0};  // CTR_HEAP_FINE, CTR_HEAP_COARSE are adjacent: stack tops, free count = top + 1
+  HIP_TRY(c, hipMemcpyAsync(h, &c->tab.ctr[CTR_HEAP_FINE], 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (out_free_fine) *out_free_fine = (int64_t) h[0] + 1;
+  if (out_free_coarse) *out_free_coarse = (int64_t) h[1] + 1;
+  return MRH_OK;
+}
+
 int mrh_set_profile(mrh_ctx* c, int enabled) {
   if (!c) return MRH_ERR_INVALID_ARG;
   c->profile = enabled ? 1 : 0;
@@ -1097,6 +1108,66 @@ int mrh_extract_mesh(mrh_ctx* c, const double** v, uint64_t* nv, const int32_t**
   *f = c->F.empty() ? nullptr : c->F.data();
   *nf = c->F.size() / 3;
   *col = c->C.empty() ? nullptr : c->C.data();
+  return MRH_OK;
+}
+
+// Streamer, device half (streamer.cu:11-160): select by distance from the camera, copy out, free.
+int mrh_stream_out(mrh_ctx* c, const float center[3], float radius, mrh_block_desc* descs, mrh_voxel* voxels, uint64_t capacity,
+                   uint64_t* out_n) {
+  int rc = ensure_ready(c, "mrh_stream_out");
+  if (rc) return rc;
+  if (!out_n || !center) return MRH_ERR_INVALID_ARG;
+  if (c->pending) return fail(c, MRH_ERR_STATE, "mrh_stream_out: an exchange is pending (call mrh_integrate_resume)");
+  int n = 0;
+  rc = compact_all(c, &n);
+  if (rc) return rc;
+  *out_n = 0;
+  if (n == 0) return MRH_OK;
+  // the selection is a handful of flops per live block: done on the host copy of the list, which is needed for the
+  // canonical (position) order anyway
+  std::vector<int4> list((size_t) n);
+  HIP_TRY(c, hipMemcpy(list.data(), c->tab.compact, (size_t) n * sizeof(int4), hipMemcpyDeviceToHost));
+  const float vs = c->map.vs;
+  std::vector<int4> sel;
+  sel.reserve((size_t) n);
+  for (const int4& e : list) {
+    const float px = (float) (e.x * kBlockSide) * vs, py = (float) (e.y * kBlockSide) * vs, pz = (float) (e.z * kBlockSide) * vs;
+    const float dx = px - center[0], dy = py - center[1], dz = pz - center[2];
+    const float d = sqrtf((dx * dx + dy * dy) + dz * dz);
+    if (radius >= 0.f && !(d >= radius)) continue;
+    sel.push_back(e);
+  }
+  *out_n = sel.size();
+  if (!descs || sel.empty()) return MRH_OK;
+  if (sel.size() > capacity) return fail(c, MRH_ERR_CAPACITY, "mrh_stream_out: capacity %llu < %zu blocks to stream out", (unsigned long long) capacity, sel.size());
+  std::sort(sel.begin(), sel.end(), [](const int4& a, const int4& b) {
+    if (a.x != b.x) return a.x < b.x;
+    if (a.y != b.y) return a.y < b.y;
+    return a.z < b.z;
+  });
+  const int ns = (int) sel.size();
+  HIP_TRY(c, hipMemcpy(c->tab.compact, sel.data(), (size_t) ns * sizeof(int4), hipMemcpyHostToDevice));
+  const int chunk = 8192;
+  int4* d_descs = nullptr;
+  char* d_vox = nullptr;
+  HIP_TRY(c, hipMalloc((void**) &d_descs, (size_t) chunk * sizeof(int4)));
+  HIP_TRY(c, hipMalloc((void**) &d_vox, (size_t) chunk * kFineBytes));
+  for (int first = 0; first < ns; first += chunk) {
+    const int cnt = (ns - first) < chunk ? (ns - first) : chunk;
+    k_dump<<<cnt < 2048 ? cnt : 2048, 512, 0, c->stream>>>(c->tab, first, cnt, d_descs, d_vox);
+    HIP_TRY(c, hipMemcpyAsync(&descs[first], d_descs, (size_t) cnt * sizeof(int4), hipMemcpyDeviceToHost, c->stream));
+    if (voxels) HIP_TRY(c, hipMemcpyAsync(&voxels[(size_t) first * 512], d_vox, (size_t) cnt * kFineBytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+  }
+  HIP_TRY(c, hipFree(d_descs));
+  HIP_TRY(c, hipFree(d_vox));
+  // free: garbageCollectFree's kernel over the selected list with every decision set
+  const int ctr_n = ns;
+  HIP_TRY(c, hipMemcpyAsync(&c->tab.ctr[CTR_COMPACT], &ctr_n, sizeof(int), hipMemcpyHostToDevice, c->stream));
+  k_fill_u32<<<256, 256, 0, c->stream>>>(c->d_decision, (size_t) ns, 1u);
+  k_gc_free<false><<<256, 256, 0, c->stream>>>(c->tab, c->d_decision);
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipGetLastError());
   return MRH_OK;
 }
 

@@ -589,6 +589,9 @@ __global__ __launch_bounds__(256) void k_fill_u64(u64* p, const size_t n, const 
   for (size_t i = (size_t) blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t) gridDim.x * 256) p[i] = v;
 }
 // heap[i] = N - 1 - i (voxel_data_structures.cpp:60-66)
+__global__ __launch_bounds__(256) void k_fill_u32(u32* p, const size_t n, const u32 v) {
+  for (size_t i = (size_t) blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t) gridDim.x * 256) p[i] = v;
+}
 __global__ __launch_bounds__(256) void k_init_heap(u32* heap, const u32 n) {
   for (size_t i = (size_t) blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t) gridDim.x * 256) heap[i] = n - 1 - (u32) i;
 }

@@ -119,6 +119,12 @@ PYBIND11_MODULE(pygeowrapper, m) {
     .def("GSSavePointCloud", &GeoWrapper::GSSavePointCloud)
     .def("GSFinalOpt", &GeoWrapper::GSFinalOpt)
     .def("streamAllOut", &GeoWrapper::streamAllOut)
+    // not part of the reference binding: lets tests drive and observe the streamer directly
+    .def("_stream", [](GeoWrapper& g, py::array_t<float, py::array::c_style | py::array::forcecast> pos, float radius) {
+      if (pos.size() != 3) throw std::runtime_error("GeoWrapper::_stream|expected a 3-vector");
+      g.stream({pos.data()[0], pos.data()[1], pos.data()[2]}, radius);
+    })
+    .def("_hostGridBlocks", &GeoWrapper::hostGridBlocks)
     .def("clearBuffers", &GeoWrapper::clearBuffers)
     .def("serializeData", &GeoWrapper::serializeData, py::arg("filename_hash") = "./data/hash_points.ply",
          py::arg("filename_voxel") = "./data/voxel_points.ply")

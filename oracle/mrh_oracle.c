@@ -1647,6 +1647,58 @@ int mrh_dump_blocks(mrh_ctx* c, mrh_block_desc* descs, mrh_voxel* voxels, uint64
   return MRH_OK;
 }
 
+/* streamer.cu:11-60 integrateFromGlobalHashPass1Kernel (RESOLVE_COLLISION branch: entries are unlinked with
+ * deleteHashEntryElement) + Pass2 (payload copy, slot cleared); canonical output order = block position */
+static int cmp_desc_pos(const void* a, const void* b) {
+  const mrh_block_desc* x = (const mrh_block_desc*) a;
+  const mrh_block_desc* y = (const mrh_block_desc*) b;
+  if (x->x != y->x) return x->x < y->x ? -1 : 1;
+  if (x->y != y->y) return x->y < y->y ? -1 : 1;
+  if (x->z != y->z) return x->z < y->z ? -1 : 1;
+  return 0;
+}
+int mrh_stream_out(mrh_ctx* c, const float center[3], float radius, mrh_block_desc* descs, mrh_voxel* voxels, uint64_t capacity, uint64_t* out_n) {
+  if (!c || !out_n || !center) return MRH_ERR_INVALID_ARG;
+  const float vs = c->p.virtual_voxel_size;
+  uint64_t n = 0;
+  for (unsigned i = 0; i < c->total_size; i++) {
+    const HashEntry* e = &c->table[i];
+    if (e->ptr == FREE_ENTRY) continue;
+    const f3 pw = voxel_to_world(vs, block_to_voxel(e->pos));
+    const float dx = pw.x - center[0], dy = pw.y - center[1], dz = pw.z - center[2];
+    const float d = sqrtf((dx * dx + dy * dy) + dz * dz);
+    if (radius >= 0.f && !(d >= radius)) continue;
+    if (descs) {
+      if (n >= capacity) return fail(c, MRH_ERR_CAPACITY, "mrh_stream_out: capacity too small");
+      descs[n].x = e->pos.x; descs[n].y = e->pos.y; descs[n].z = e->pos.z; descs[n].resolution = e->resolution;
+    }
+    n++;
+  }
+  *out_n = n;
+  if (!descs) return MRH_OK;
+  qsort(descs, (size_t) n, sizeof(mrh_block_desc), cmp_desc_pos);
+  for (uint64_t k = 0; k < n; k++) {
+    const i3 pos = {descs[k].x, descs[k].y, descs[k].z};
+    const HashEntry e = get_hash_entry(c, pos);
+    const int nv = num_voxels_of(e.resolution);
+    if (voxels) {
+      memset(&voxels[k * 512], 0, 512 * sizeof(mrh_voxel));
+      memcpy(&voxels[k * 512], &c->blocks[(size_t) e.ptr], (size_t) nv * sizeof(mrh_voxel));
+    }
+    reset_mutex(c);  /* canonical: every qualifying block leaves (the reference's kernel can lose a bucket race and leave one for the next pass) */
+    if (delete_hash_entry_element(c, pos))
+      for (int i = 0; i < nv; ++i) delete_voxel(&c->blocks[(size_t) e.ptr + i]);
+  }
+  return MRH_OK;
+}
+
+int mrh_get_free_blocks(mrh_ctx* c, int64_t* out_free_fine, int64_t* out_free_coarse) {
+  if (!c) return MRH_ERR_INVALID_ARG;
+  if (out_free_fine) *out_free_fine = heap_high_free(c);
+  if (out_free_coarse) *out_free_coarse = heap_low_free(c);
+  return MRH_OK;
+}
+
 int mrh_get_voxel(mrh_ctx* c, int32_t vx, int32_t vy, int32_t vz, mrh_voxel* out, int* found) {
   if (!c || !out) return MRH_ERR_INVALID_ARG;
   i3 v = {vx, vy, vz};

@@ -138,3 +138,45 @@ def test_lidar_runner_call_sequence_matches_oracle(geowrapper_cls, oracle, tmp_p
     Vb, Fb, Cb = b.extract_mesh()
     assert len(Fb) > 500
     assert np.array_equal(g.getVertices(), Vb) and np.array_equal(g.getFaces(), Fb)
+
+
+def test_streamer_pages_far_blocks_out_and_back(monkeypatch, tmp_path):
+    """Streamer: with a pool too small for the whole walk, compute() pages blocks farther than max_depth
+    from the camera out to the host chunk grid (free blocks <= 15 % of the pool, geowrapper.cpp:137-138) and back in
+    when the camera returns; extractMesh sees the whole map.  Paging is transparent: the mesh equals the one of a run
+    whose pool holds everything."""
+    from mrhash_amd import synth as sy
+
+    K = sy.Intrinsics(160.0, 160.0, 79.5, 59.5, 120, 160)
+    kw = dict(sdf_truncation=0.08, sdf_truncation_scale=0.0, integration_weight_sample=1, virtual_voxel_size=0.02,
+              n_frames_invalidate_voxels=1000, voxel_extents_scale=1, viewer_active=False, marching_cubes_threshold=1.5,
+              min_weight_threshold=1, min_depth=0.01, max_depth=2.0)
+    scene = sy.Scene(sy.Box((-0.6, -0.6, -9.0), (0.6, 0.6, 9.0)), seed=3)  # a corridor: walk along z, then come back
+    zs = list(np.arange(-6.0, 6.01, 0.25)) + list(np.arange(5.75, -6.01, -0.25))
+    poses = [(np.array([0.0, 0.0, z], np.float32), np.array([0, 0, 0, 1], np.float32)) for z in zs]
+    frames = [sy.render(scene, K, t, q, depth_scaling=5000.0) for t, q in poses]
+
+    def run(blocks):
+        monkeypatch.setenv("MRHASH_NUM_SDF_BLOCKS", str(blocks))
+        from mrhash.src.pygeowrapper import GeoWrapper
+
+        g = GeoWrapper(**kw)
+        g.setCamera(K.fx, K.fy, K.cx, K.cy, K.rows, K.cols, 0.01, 2.0, 0)
+        peak = 0
+        for f in frames:
+            g.setCurrPose(f.t, f.q)
+            g.setDepthImage(f.depth)
+            g.setRGBImage(f.rgb)
+            g.compute()
+            peak = max(peak, g._hostGridBlocks())
+        g.streamAllOut()
+        g.extractMesh(str(tmp_path / f"m{blocks}.ply"))
+        print('pool', blocks, 'peak host-grid blocks', peak)
+        return g.getVertices(), g.getFaces(), peak, g._hostGridBlocks()
+
+    Vb, Fb, peak_big, _ = run(65536)
+    Vs, Fs, peak_small, left = run(int(os.environ.get('MRH_TEST_SMALL_POOL', '3072')))
+    assert peak_big == 0 and peak_small > 300  # the small pool really paged
+    assert left == 0  # extractMesh brought everything back
+    assert len(Fb) > 5000
+    assert np.array_equal(Vb, Vs) and np.array_equal(Fb, Fs)

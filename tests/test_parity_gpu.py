@@ -365,6 +365,35 @@ def test_multires_640x480(hip, oracle):
     assert saw_coarse
 
 
+def test_stream_out_and_import_match_oracle(hip, oracle):
+    """Streamer device half (mrh_stream_out / mrh_import_blocks): the same blocks leave, in position order, with the
+    same payload; what stays is the same map; importing them back restores the original; fusion continues identically."""
+    import test_streamer as ts
+
+    a, b = ts.build(hip, 4), ts.build(oracle, 4)
+    a.sync()
+    da, va = a.stream_out((0.3, 0.0, -0.2), 2.2)
+    db, vb = b.stream_out((0.3, 0.0, -0.2), 2.2)
+    assert len(da) > 100 and da.tobytes() == db.tobytes() and va.tobytes() == vb.tobytes()
+    r = pu.compare_maps(a, b)
+    assert r["blocks"] > 10
+    sa, sb = a.stats(), b.stats()
+    assert (sa.occupied_fine, sa.free_fine) == (sb.occupied_fine, sb.free_fine)
+    a.import_blocks(da, va)
+    b.import_blocks(db, vb)
+    K = synth.Intrinsics(160.0, 160.0, 79.5, 59.5, 120, 160)
+    scene = synth.scannet_room()
+    for t, q in synth.walk_poses(6, seed=7)[4:]:
+        f = synth.render(scene, K, t, q, depth_scaling=5000.0)
+        pu.feed(a, f)
+        pu.feed(b, f)
+    a.sync()
+    pu.compare_maps(a, b)
+    pu.compare_meshes(a, b)
+    n_all, _ = a.stream_out((0, 0, 0), -1.0)
+    assert a.stats().occupied_fine == 0 and len(n_all) == len(b.stream_out((0, 0, 0), -1.0)[0])
+
+
 def test_gc_and_starve_at_full_resolution(hip, oracle):
     """640x480, GC every frame, starve on frames 2 and 4: the frames where GC is decided inside k_back, the starve
     frames (k_back without GC -> k_starve -> k_summarize_all -> k_free_lists) and the hand-over between them."""
