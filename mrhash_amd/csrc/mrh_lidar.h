@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256) void k_points_walk(const Cam c, const Map m, c
         else sdf = fmaxf(-tr, sdf);
         if (EMIT) {
           const u32 H = t.vals[slot];
-          keys[out + cnt] = ((u64) (H * 512u + voxel_local_index(cur, 0)) << pbits) | (u64) i;
+          keys[out + cnt] = (((u64) H * 512u + voxel_local_index(cur, 0)) << pbits) | (u64) i;  // 64-bit: pools beyond 2^23 blocks
           vals[out + cnt] = sdf;
         }
         cnt++;

@@ -447,3 +447,23 @@ def test_full_size_properties(hip):
     d3, v3 = e2.dump_blocks()
     assert np.array_equal(d, d3) and np.array_equal(v.view(np.uint8), v3.view(np.uint8))
     e.close(); e2.close()
+
+
+def test_default_capacity_rule_sizes_the_pool_to_hbm(hip):
+    """num_sdf_blocks = 0 applies the reference's sizing rule (geowrapper.cpp:37-54) to the free HBM of the device:
+    tens of millions of blocks on a 288 GB part.  The map built in such a pool equals the one built in a small pool
+    (block indices and byte offsets are 64-bit clean)."""
+    K = synth.CFG1
+    big = capi.Engine(hip, capi.Params(num_sdf_blocks=0, **synth.CFG1_PARAMS))
+    small = pu.make_engine(hip, K, synth.CFG1_PARAMS, 16384)
+    big.set_camera(K.fx, K.fy, K.cx, K.cy, K.rows, K.cols, 0.01, 30.0)
+    st = big.stats()
+    assert st.num_sdf_blocks > 4_000_000 and st.free_fine == st.num_sdf_blocks
+    for f in (synth.cfg1_sphere(), synth.cfg1_sphere(zc=1.51)):
+        pu.feed(big, f)
+        pu.feed(small, f)
+    big.sync()
+    pu.compare_maps(big, small)
+    pu.compare_meshes(big, small)
+    big.close()
+    small.close()
