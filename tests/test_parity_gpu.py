@@ -467,3 +467,37 @@ def test_default_capacity_rule_sizes_the_pool_to_hbm(hip):
     pu.compare_meshes(big, small)
     big.close()
     small.close()
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5])
+def test_randomised_parameters_and_shapes(hip, oracle, seed):
+    """Parameter / shape fuzz: odd image sizes (partial allocation tiles, clamped footprints), off-centre anisotropic
+    intrinsics, range-dependent truncation (sdf_truncation_scale > 0), weight sample / weight max other than 1 / 255,
+    depth limits that cut the scene, GC with a starve period — fast path (single resolution) and fused / general
+    multi-resolution path, always against the oracle."""
+    rng = np.random.default_rng(100 + seed)
+    rows, cols = int(rng.integers(90, 200)), int(rng.integers(100, 260))
+    f = float(rng.uniform(0.7, 1.3)) * cols
+    K = synth.Intrinsics(f, f * float(rng.uniform(0.85, 1.15)), cols * float(rng.uniform(0.35, 0.65)), rows * float(rng.uniform(0.35, 0.65)), rows, cols)
+    vs = float(rng.choice([0.015, 0.02, 0.03]))
+    params = dict(
+        sdf_truncation=float(rng.uniform(3.0, 5.0)) * vs, sdf_truncation_scale=float(rng.choice([0.0, 0.01, 0.03])),
+        integration_weight_sample=int(rng.integers(1, 6)), integration_weight_max=int(rng.integers(12, 256)),
+        virtual_voxel_size=vs, n_frames_invalidate_voxels=int(rng.choice([0, 1000, 3])), voxel_extents_scale=1,
+        marching_cubes_threshold=1.5, min_weight_threshold=int(rng.integers(1, 4)),
+        sdf_var_threshold=float(rng.choice([0.0, 0.0, 0.02])), vertices_merging_threshold=0.0,
+        min_depth=float(rng.choice([0.01, 0.8])), max_depth=float(rng.choice([30.0, 3.2])),
+    )
+    a, b = _pair(hip, oracle, K, params, 65536)
+    scene = synth.scannet_room()
+    noise = np.random.default_rng(seed)
+    for t, q in synth.walk_poses(7, seed=20 + seed):
+        fr = synth.render(scene, K, t, q, depth_scaling=5000.0, noise_sigma=0.002 if params["sdf_var_threshold"] > 0 else 0.0, rng=noise)
+        pu.feed(a, fr)
+        pu.feed(b, fr)
+    a.sync()
+    sa, sb = a.stats(), b.stats()
+    assert (sa.occupied_fine, sa.occupied_coarse, sa.free_fine, sa.free_coarse) == (sb.occupied_fine, sb.occupied_coarse, sb.free_fine, sb.free_coarse), params
+    r = pu.compare_maps(a, b)
+    assert r["blocks"] > 50, params
+    pu.compare_meshes(a, b)
