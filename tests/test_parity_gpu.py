@@ -501,3 +501,20 @@ def test_randomised_parameters_and_shapes(hip, oracle, seed):
     r = pu.compare_maps(a, b)
     assert r["blocks"] > 50, params
     pu.compare_meshes(a, b)
+
+
+def test_plain_c_program_drives_the_abi(hip, tmp_path):
+    """examples/c_abi_smoke.c: a C11 program with nothing but include/mrhash_hip.h and -lmrhash_hip reproduces the
+    counts of the golden plane case."""
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "c_abi_smoke")
+    libdir = os.path.join(root, "mrhash_amd", "csrc")
+    subprocess.run(["gcc", "-std=c11", "-Wall", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "c_abi_smoke.c"), "-o", exe,
+                    "-L" + libdir, "-lmrhash_hip", "-Wl,-rpath," + libdir, "-lm"], check=True)
+    out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout.split()
+    got = dict(zip(out[-12::2], map(int, out[-11::2])))
+    case = json.load(open(os.path.join(GOLDEN, "cfg1_golden.json")))["cases"]["plane_1frame"]
+    assert (got["blocks"], got["weighted_voxels"], got["triangles"], got["faces"]) == (case["blocks"], case["weighted_voxels"], case["triangles"], case["faces"])
+    assert got["free_fine"] == 16384 - case["blocks"]
