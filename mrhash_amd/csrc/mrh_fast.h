@@ -12,7 +12,7 @@
 namespace mrh {
 
 constexpr int CTR_CULLED = 12;  // number of culled compact entries (stored from the back of Tab::compact)
-constexpr int CTR_FREED_EARLY = 13;  // culled blocks freed inside k_compact2 this frame (counted into M)
+constexpr int CTR_FREED_EARLY = 13;  // (kept zero: culled blocks are freed by k_back from the CULLED-FREE list)
 constexpr float kFltMax = 3.402823466e+38f;
 constexpr int kTileMaxPx = 576;  // LDS depth+colour tile per wave: 576 px x 8 B = 4.5 KiB (24 x 24 px: blocks beyond ~1.2 m)
 

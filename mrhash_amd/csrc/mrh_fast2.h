@@ -1,16 +1,16 @@
-// mrh_fast2.h — the single-resolution fast path as TWO launches per frame.
+// mrh_fast2.h — the fast path: TWO launches per frame (single-resolution and, with MULTI, multi-resolution maps).
 //
-//   k_front   workgroups [0, n_tiles):      block allocation for one 16x16 pixel tile (rays -> LDS key set -> lock-free
-//                                           insert); a newly inserted block is classified and listed by its inserter
-//             workgroups [n_tiles, grid):   sweep of the block descriptors that existed before this frame:
-//                                           approx-frustum predicate + exact-image cull -> VISIBLE list (+ pixel
-//                                           footprint) or, for culled blocks whose stored summary says "collect",
-//                                           the CULLED-FREE list
-//             The two halves never touch the same block (descriptors carry the frame stamp of their insertion), the
-//             allocation half only POPS the free list and nothing is freed in this launch, so both halves run
-//             concurrently: the latency-bound sweep hides completely under the ray marching.
-//   k_back    one wave per visible block:   depth->TSDF integration + GC summary + GC decision + free (k_fused);
-//             then the same waves free the CULLED-FREE list.  This launch only PUSHES the free list.
+//   k_front   workgroups [0, S):            sweep of the block descriptors that existed before this frame (they come first
+//                                           in the grid so that they start first): approx-frustum predicate + exact-image
+//                                           cull -> VISIBLE list (+ pixel footprint, nearest corner z) or, for culled
+//                                           blocks whose stored summary says "collect", the CULLED-FREE list
+//             workgroups [S, S + tiles):    block allocation for one 16x16 pixel tile (rays -> LDS key set -> one probe
+//                                           per distinct key -> lock-free insert); a new block is listed by its inserter
+//             The two roles never touch the same block (descriptors carry the frame stamp of their insertion), the
+//             allocation role only POPS the free list and nothing is freed in this launch, so they run concurrently:
+//             the latency-bound sweep hides under the ray marching.
+//   k_back    one wave per visible block:   depth->TSDF integration + GC summary + GC decision + free;
+//             then the same waves free the CULLED-FREE list.  This launch only PUSHES the fine free list.
 //
 // List counters are double-buffered by frame parity: k_front(f) appends to set f&1, k_back(f) reads it and zeroes
 // set (f+1)&1 for the next frame, so no reset launch or memset is needed.
@@ -35,68 +35,6 @@ struct Lists {
 };
 
 __device__ __forceinline__ int desc_w(u32 stamp) { return (int) (1u | (stamp << 1)); }
-
-// serial 8-corner classification (used by the inserter of a new block; the sweep does it with 8 lanes per block).
-// Returns 0 = outside the approx frustum, 1 = visible candidate (bb filled), 2 = culled.  See k_compact2 for the argument.
-__device__ __forceinline__ int classify_block_serial(const Cam& c, const float vs, const i3 b, int4& bb) {
-  bool any_approx = false;
-  float zmin = kFltMax, zmax = -kFltMax, umin = kFltMax, umax = -kFltMax, vmin = kFltMax, vmax = -kFltMax;
-#pragma unroll 1
-  for (int i = 0; i < 8; i++) {
-    const i3 v = mki3(b.x * kBlockSide + ((i & 4) ? 7 : 0), b.y * kBlockSide + ((i & 2) ? 7 : 0), b.z * kBlockSide + ((i & 1) ? 7 : 0));
-    const f3 pc = se3_apply(c.Ri, c.ti, voxel_to_world(vs, v));
-    int r, cc;
-    any_approx |= project_point<true>(c, pc, r, cc);
-    zmin = fminf(zmin, pc.z);
-    zmax = fmaxf(zmax, pc.z);
-    if (pc.z >= 0.05f) {
-      const float u = c.fx * pc.x / pc.z + c.cx;
-      const float w = c.fy * pc.y / pc.z + c.cy;
-      umin = fminf(umin, u); umax = fmaxf(umax, u);
-      vmin = fminf(vmin, w); vmax = fmaxf(vmax, w);
-    }
-  }
-  bb = make_int4(0, 0, 0, 0);
-  if (!any_approx) return 0;
-  bool cull = (zmax <= c.min_depth - 1e-3f) || (zmin > c.max_depth + 1e-3f);
-  if (!cull && zmin >= 0.05f) cull = umax < -3.f || umin > (float) c.cols + 1.f || vmax < -3.f || vmin > (float) c.rows + 1.f;
-  if (cull) return 2;
-  if (zmin >= 0.05f) {
-    int c0 = f2i_hw(floorf(umin + 0.5f)) - 1, c1 = f2i_hw(floorf(umax + 0.5f)) + 1;
-    int r0 = f2i_hw(floorf(vmin + 0.5f)) - 1, r1 = f2i_hw(floorf(vmax + 0.5f)) + 1;
-    c0 = c0 < 0 ? 0 : c0; r0 = r0 < 0 ? 0 : r0;
-    c1 = c1 > c.cols - 1 ? c.cols - 1 : c1; r1 = r1 > c.rows - 1 ? c.rows - 1 : r1;
-    const int bw = c1 - c0 + 1, bh = r1 - r0 + 1;
-    if (bw > 0 && bh > 0 && bw * bh <= kTileMaxPx) bb = make_int4(c0, r0, bw, bh);
-  }
-  return 1;
-}
-
-// wave-aggregated append of classified blocks to the lists of set `cs` (ctr index base)
-__device__ __forceinline__ void append_classified(const Tab& t, const Lists& L, const int cs, const int cls, const bool collect,
-                                                  const int4 ent, const int4 bb) {
-  const bool is_vis = cls == 1, is_keep = cls == 2 && !collect, is_free = cls == 2 && collect;
-  const u64 bv = __ballot(is_vis), bk = __ballot(is_keep), bf = __ballot(is_free);
-  if (bv) {
-    const int leader = __ffsll((long long) bv) - 1;
-    int base = 0;
-    if ((int) lane_id() == leader) base = atomicAdd(&t.ctr[cs + 0], __popcll(bv));
-    base = __shfl(base, leader);
-    if (is_vis) {
-      const int idx = base + __popcll(bv & lanemask_lt());
-      L.vis[idx] = ent;
-      L.bbox[idx] = bb;  // {0,0,0,0}: k_back derives footprint and zmin itself
-    }
-  }
-  if (bk && (int) lane_id() == __ffsll((long long) bk) - 1) atomicAdd(&t.ctr[cs + 1], __popcll(bk));
-  if (bf) {
-    const int leader = __ffsll((long long) bf) - 1;
-    int base = 0;
-    if ((int) lane_id() == leader) base = atomicAdd(&t.ctr[cs + 2], __popcll(bf));
-    base = __shfl(base, leader);
-    if (is_free) L.cfree[base + __popcll(bf & lanemask_lt())] = ent;
-  }
-}
 
 // LDS of the allocation / sweep roles
 struct FrontShared {
