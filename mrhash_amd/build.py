@@ -8,6 +8,7 @@ denormals preserved.
 """
 from __future__ import annotations
 
+import glob
 import os
 import shutil
 import subprocess
@@ -40,8 +41,7 @@ def hipcc() -> str:
 
 
 def build_hip(force: bool = False, verbose: bool = True) -> str:
-    srcs = [os.path.join(CSRC, f) for f in ("mrh_capi.hip", "mrh_kernels.h", "mrh_device.h", "mrh_mc.h", "mrh_fast.h", "mrh_pipe.h", "mrh_fast2.h")]
-    srcs += [os.path.join(ROOT, "include", f) for f in ("mrhash_hip.h", "mrh_mc_tables.h")]
+    srcs = sorted(glob.glob(os.path.join(CSRC, "mrh_*.h")) + glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(ROOT, "include", "*.h")))
     if not force and _newer(HIP_LIB, srcs):
         return HIP_LIB
     cmd = [hipcc()] + [f for f in HIPCC_FLAGS if f] + ["-o", HIP_LIB, os.path.join(CSRC, "mrh_capi.hip")]
