@@ -130,6 +130,18 @@ int fail(mrh_ctx* c, int code, const char* fmt, ...) {
     if (e__ != hipSuccess) return fail(ctx, MRH_ERR_DEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
   } while (0)
 
+// device scratch that is released on every path out of a function (error returns included)
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  ~DevBuf() { if (p) (void) hipFree(p); }
+  hipError_t alloc(size_t n) { return hipMalloc((void**) &p, n * sizeof(T)); }
+  operator T*() const { return p; }
+};
+
 uint64_t next_pow2(uint64_t v) {
   uint64_t r = 1;
   while (r < v) r <<= 1;
@@ -1049,12 +1061,12 @@ int mrh_extract_triangles(mrh_ctx* c, const mrh_triangle** out_tris, uint64_t* o
     });
     HIP_TRY(c, hipMemcpy(c->tab.compact, list.data(), (size_t) n * sizeof(int4), hipMemcpyHostToDevice));
     t1 = now();
-    u32* d_counts = nullptr;
-    u64* d_offsets = nullptr;
-    HIP_TRY(c, hipMalloc((void**) &d_counts, (size_t) n * sizeof(u32)));
-    HIP_TRY(c, hipMalloc((void**) &d_offsets, (size_t) n * sizeof(u64)));
-    uint8_t* d_per_voxel = nullptr;  // triangles per voxel from the count pass: the emit pass skips the empty ones
-    HIP_TRY(c, hipMalloc((void**) &d_per_voxel, (size_t) n * 512));
+    DevBuf<u32> d_counts;
+    DevBuf<u64> d_offsets;
+    DevBuf<uint8_t> d_per_voxel;  // triangles per voxel from the count pass: the emit pass skips the empty ones
+    HIP_TRY(c, d_counts.alloc((size_t) n));
+    HIP_TRY(c, d_offsets.alloc((size_t) n));
+    HIP_TRY(c, d_per_voxel.alloc((size_t) n * 512));
     const int grid = n < 4096 ? n : 4096;
     k_mc<false><<<grid, 512, 0, s>>>(c->map, c->tab, c->tab.compact, n, d_counts, nullptr, nullptr, 0, d_per_voxel);
     std::vector<u32> counts((size_t) n);
@@ -1068,12 +1080,11 @@ int mrh_extract_triangles(mrh_ctx* c, const mrh_triangle** out_tris, uint64_t* o
     c->tri_blocks.resize((size_t) n);
     for (int i = 0; i < n; i++) c->tri_blocks[i] = {list[i].x, list[i].y, list[i].z, (list[i].w & (int) kValCoarseBit) ? 1 : 0};
     if (total > c->max_triangles) {
-      (void) hipFree(d_counts); (void) hipFree(d_offsets); (void) hipFree(d_per_voxel);
       return fail(c, MRH_ERR_CAPACITY, "triangle buffer full: %llu triangles > max_triangles %llu", (unsigned long long) total, (unsigned long long) c->max_triangles);
     }
     if (total > 0) {
-      mrh_triangle* d_tris = nullptr;
-      HIP_TRY(c, hipMalloc((void**) &d_tris, total * sizeof(mrh_triangle)));
+      DevBuf<mrh_triangle> d_tris;
+      HIP_TRY(c, d_tris.alloc(total));
       HIP_TRY(c, hipMemcpyAsync(d_offsets, offsets.data(), (size_t) n * sizeof(u64), hipMemcpyHostToDevice, s));
       k_mc<true><<<grid, 512, 0, s>>>(c->map, c->tab, c->tab.compact, n, d_counts, d_offsets, d_tris, total, d_per_voxel);
       if (dbg) { HIP_TRY(c, hipStreamSynchronize(s)); t3 = now(); }
@@ -1083,12 +1094,8 @@ int mrh_extract_triangles(mrh_ctx* c, const mrh_triangle** out_tris, uint64_t* o
       int prc = MRH_OK;
       if (!c->mesh_on_host) { prc = process_triangles_device(c, d_tris, total); processed = true; }
       HIP_TRY(c, hipStreamSynchronize(s));
-      HIP_TRY(c, hipFree(d_tris));
-      if (prc) { (void) hipFree(d_counts); (void) hipFree(d_offsets); (void) hipFree(d_per_voxel); return prc; }
+      if (prc) return prc;
     }
-    HIP_TRY(c, hipFree(d_counts));
-    HIP_TRY(c, hipFree(d_offsets));
-    HIP_TRY(c, hipFree(d_per_voxel));
     HIP_TRY(c, hipGetLastError());
   }
   c->last_triangles = c->tris.size();
@@ -1148,10 +1155,10 @@ int mrh_stream_out(mrh_ctx* c, const float center[3], float radius, mrh_block_de
   const int ns = (int) sel.size();
   HIP_TRY(c, hipMemcpy(c->tab.compact, sel.data(), (size_t) ns * sizeof(int4), hipMemcpyHostToDevice));
   const int chunk = 8192;
-  int4* d_descs = nullptr;
-  char* d_vox = nullptr;
-  HIP_TRY(c, hipMalloc((void**) &d_descs, (size_t) chunk * sizeof(int4)));
-  HIP_TRY(c, hipMalloc((void**) &d_vox, (size_t) chunk * kFineBytes));
+  DevBuf<int4> d_descs;
+  DevBuf<char> d_vox;
+  HIP_TRY(c, d_descs.alloc((size_t) chunk));
+  HIP_TRY(c, d_vox.alloc((size_t) chunk * kFineBytes));
   for (int first = 0; first < ns; first += chunk) {
     const int cnt = (ns - first) < chunk ? (ns - first) : chunk;
     k_dump<<<cnt < 2048 ? cnt : 2048, 512, 0, c->stream>>>(c->tab, first, cnt, d_descs, d_vox);
@@ -1159,8 +1166,6 @@ int mrh_stream_out(mrh_ctx* c, const float center[3], float radius, mrh_block_de
     if (voxels) HIP_TRY(c, hipMemcpyAsync(&voxels[(size_t) first * 512], d_vox, (size_t) cnt * kFineBytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
   }
-  HIP_TRY(c, hipFree(d_descs));
-  HIP_TRY(c, hipFree(d_vox));
   // free: garbageCollectFree's kernel over the selected list with every decision set
   const int ctr_n = ns;
   HIP_TRY(c, hipMemcpyAsync(&c->tab.ctr[CTR_COMPACT], &ctr_n, sizeof(int), hipMemcpyHostToDevice, c->stream));
@@ -1182,10 +1187,10 @@ int mrh_dump_blocks(mrh_ctx* c, mrh_block_desc* descs, mrh_voxel* voxels, uint64
   if (!descs) return MRH_OK;
   if ((uint64_t) n > capacity) return fail(c, MRH_ERR_CAPACITY, "mrh_dump_blocks: capacity %llu < %d live blocks", (unsigned long long) capacity, n);
   const int chunk = 8192;  // 48 MiB of voxels per round trip
-  int4* d_descs = nullptr;
-  char* d_vox = nullptr;
-  HIP_TRY(c, hipMalloc((void**) &d_descs, (size_t) chunk * sizeof(int4)));
-  HIP_TRY(c, hipMalloc((void**) &d_vox, (size_t) chunk * kFineBytes));
+  DevBuf<int4> d_descs;
+  DevBuf<char> d_vox;
+  HIP_TRY(c, d_descs.alloc((size_t) chunk));
+  HIP_TRY(c, d_vox.alloc((size_t) chunk * kFineBytes));
   for (int first = 0; first < n; first += chunk) {
     const int cnt = (n - first) < chunk ? (n - first) : chunk;
     k_dump<<<cnt < 2048 ? cnt : 2048, 512, 0, c->stream>>>(c->tab, first, cnt, d_descs, d_vox);
@@ -1193,8 +1198,6 @@ int mrh_dump_blocks(mrh_ctx* c, mrh_block_desc* descs, mrh_voxel* voxels, uint64
     if (voxels) HIP_TRY(c, hipMemcpyAsync(&voxels[(size_t) first * 512], d_vox, (size_t) cnt * kFineBytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
   }
-  HIP_TRY(c, hipFree(d_descs));
-  HIP_TRY(c, hipFree(d_vox));
   HIP_TRY(c, hipGetLastError());
   return MRH_OK;
 }
@@ -1223,10 +1226,10 @@ int mrh_import_blocks(mrh_ctx* c, const mrh_block_desc* descs, const mrh_voxel* 
   c->mr_next_general = true;  // imported payload has not been through a variance check
   c->mr_summaries_valid = false;
   const uint64_t chunk = 8192;
-  int4* d_descs = nullptr;
-  char* d_vox = nullptr;
-  HIP_TRY(c, hipMalloc((void**) &d_descs, chunk * sizeof(int4)));
-  HIP_TRY(c, hipMalloc((void**) &d_vox, chunk * (size_t) kFineBytes));
+  DevBuf<int4> d_descs;
+  DevBuf<char> d_vox;
+  HIP_TRY(c, d_descs.alloc(chunk));
+  HIP_TRY(c, d_vox.alloc(chunk * (size_t) kFineBytes));
   for (uint64_t first = 0; first < n; first += chunk) {
     const uint64_t cnt = (n - first) < chunk ? (n - first) : chunk;
     HIP_TRY(c, hipMemcpyAsync(d_descs, &descs[first], cnt * sizeof(int4), hipMemcpyHostToDevice, c->stream));
@@ -1234,8 +1237,6 @@ int mrh_import_blocks(mrh_ctx* c, const mrh_block_desc* descs, const mrh_voxel* 
     k_import<<<(int) (cnt < 2048 ? cnt : 2048), 512, 0, c->stream>>>(c->tab, c->fast.summary, (int) cnt, d_descs, d_vox);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
   }
-  HIP_TRY(c, hipFree(d_descs));
-  HIP_TRY(c, hipFree(d_vox));
   HIP_TRY(c, hipGetLastError());
   u32 flags = 0;
   HIP_TRY(c, hipMemcpy(&flags, &c->tab.ctr[CTR_ERROR], sizeof(u32), hipMemcpyDeviceToHost));
@@ -1257,20 +1258,18 @@ int mrh_process_triangles(mrh_ctx* c, const mrh_triangle* triangles, uint64_t n)
   if (c->mesh_on_host || n == 0) { process_triangles(c); return MRH_OK; }
   int rc = ensure_ready(c, "mrh_process_triangles");
   if (rc) return rc;
-  mrh_triangle* d_tris = nullptr;
-  HIP_TRY(c, hipMalloc((void**) &d_tris, n * sizeof(mrh_triangle)));
-  hipError_t e = hipMemcpyAsync(d_tris, triangles, n * sizeof(mrh_triangle), hipMemcpyHostToDevice, c->stream);
-  rc = e == hipSuccess ? process_triangles_device(c, d_tris, n) : fail(c, MRH_ERR_DEVICE, "mrh_process_triangles: upload failed: %s", hipGetErrorString(e));
-  (void) hipFree(d_tris);
-  return rc;
+  DevBuf<mrh_triangle> d_tris;
+  HIP_TRY(c, d_tris.alloc(n));
+  HIP_TRY(c, hipMemcpyAsync(d_tris, triangles, n * sizeof(mrh_triangle), hipMemcpyHostToDevice, c->stream));
+  return process_triangles_device(c, d_tris, n);
 }
 
 int mrh_selftest_division(mrh_ctx* c, uint64_t samples, uint64_t seed, uint64_t* out_mismatches) {
   int rc = ensure_ready(c, "mrh_selftest_division");
   if (rc) return rc;
   if (!out_mismatches) return MRH_ERR_INVALID_ARG;
-  u64* d = nullptr;
-  HIP_TRY(c, hipMalloc((void**) &d, sizeof(u64)));
+  DevBuf<u64> d;
+  HIP_TRY(c, d.alloc(1));
   HIP_TRY(c, hipMemsetAsync(d, 0, sizeof(u64), c->stream));
   const u32 threads = 1024 * 256;
   const u32 iters = (u32) ((samples + threads - 1) / threads);
@@ -1278,7 +1277,6 @@ int mrh_selftest_division(mrh_ctx* c, uint64_t samples, uint64_t seed, uint64_t*
   u64 h = 0;
   HIP_TRY(c, hipMemcpyAsync(&h, d, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
-  HIP_TRY(c, hipFree(d));
   *out_mismatches = h;
   return MRH_OK;
 }
