@@ -210,6 +210,36 @@ int mrh_upload_points(mrh_ctx* ctx, const float* xyz, uint64_t n);
 int mrh_set_points_device(mrh_ctx* ctx, const float* d_xyz, uint64_t n); /* zero-copy: device pointer, valid until the next integrate returns */
 int mrh_integrate_points(mrh_ctx* ctx, int n_frames_invalidate);
 
+/* ---- 3DGS splat seeds (BASELINE.json configs[4]) ----------------------------------------------
+ * Replaces the initialisation half of GaussianContainer::runGS (gaussian_data_structures.cpp:170-186):
+ * extractNodesQTree = CUDAQTree::subdivide (gaussian_data_structures.cpp:58-70, src/gs/quad_tree.cu:6-222) — a
+ * quad-tree over the CURRENT colour image, a node is a leaf when its luma-weighted colour MSE x (rows*cols / 9e7)
+ * is <= qtree_thresh or a half of it would be <= qtree_min_pixel_size pixels wide/high — and checkNodes =
+ * processNodesKernel (gaussian_data_structures.cu:5-84): a leaf whose centre pixel has depth >= min_depth and whose
+ * back-projected centre falls into a voxel of weight exactly 1 (surface seen for the first time) yields one seed
+ * {world position, scale = depth * |half extent| / fx, colour of the centre pixel}.  Call after mrh_integrate of the
+ * same frame (the images and pose of that frame are still the current ones).  Pinhole camera only.
+ * The reference appends leaves and seeds through atomic counters (a race order); canonical order here: leaves by
+ * tree level, then by position in the tree (children in the order the reference writes them: top-left, bottom-left,
+ * top-right, bottom-right); seeds in leaf order.  The optimiser / rasteriser (src/gs) stay out of scope: the seeds
+ * are what GaussianModel::Add_gaussians (src/gs/gaussian.cu:147) is handed.
+ * Buffers are owned by ctx until the next call.  Blocks.  Images above 2^22 pixels or trees above the reference's
+ * 1 000 000-leaf capacity (params.h:20-23) return MRH_ERR_CAPACITY. */
+typedef struct mrh_splat_seed {
+  float p[3];      /* gs::Point, world frame (gaussian_utils.cuh:112-116)  */
+  float scale;     /* d_scales_                                             */
+  uint8_t rgb[3];  /* gs::Color (gaussian_utils.cuh:118-122)               */
+  uint8_t pad;
+} mrh_splat_seed;  /* 20 bytes */
+
+typedef struct mrh_qtree_leaf {
+  int32_t x0, y0, width, height; /* gs::CUDANode (quad_tree.cuh:10-50) without the racy id */
+} mrh_qtree_leaf;
+
+int mrh_splat_seeds(mrh_ctx* ctx, float qtree_thresh, int qtree_min_pixel_size, const mrh_splat_seed** out_seeds, uint64_t* out_n);
+/* The leaves of the last mrh_splat_seeds call (CUDAQTree::getAllNodes, quad_tree.cuh:88-93).  Test / debug helper. */
+int mrh_get_qtree_leaves(mrh_ctx* ctx, const mrh_qtree_leaf** out_leaves, uint64_t* out_n);
+
 /* Blocks until every enqueued frame has executed; surfaces sticky device error flags as
  * MRH_ERR_CAPACITY / MRH_ERR_OUT_OF_RANGE. */
 int mrh_sync(mrh_ctx* ctx);

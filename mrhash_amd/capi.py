@@ -90,6 +90,8 @@ VOXEL_DTYPE = np.dtype(
 assert VOXEL_DTYPE.itemsize == 12
 DESC_DTYPE = np.dtype([("x", "<i4"), ("y", "<i4"), ("z", "<i4"), ("resolution", "<i4")])
 TRI_DTYPE = np.dtype([("p", "<f4", (3,)), ("c", "<f4", (3,))])  # one vertex; a triangle is 3 of them
+SEED_DTYPE = np.dtype([("p", "<f4", (3,)), ("scale", "<f4"), ("rgb", "u1", (3,)), ("pad", "u1")])  # mrh_splat_seed, 20 bytes
+LEAF_DTYPE = np.dtype([("x0", "<i4"), ("y0", "<i4"), ("width", "<i4"), ("height", "<i4")])  # mrh_qtree_leaf
 assert TRI_DTYPE.itemsize == 24
 
 # every symbol include/mrhash_hip.h declares
@@ -97,6 +99,7 @@ ABI_SYMBOLS = (
     "mrh_create mrh_destroy mrh_reset mrh_last_error mrh_set_camera mrh_set_pose mrh_upload_depth "
     "mrh_upload_rgb mrh_set_depth_device mrh_set_rgb_device mrh_integrate mrh_integrate_resume mrh_exchange_buffer mrh_sync "
     "mrh_upload_points mrh_set_points_device mrh_integrate_points mrh_stream_out mrh_get_free_blocks "
+    "mrh_splat_seeds mrh_get_qtree_leaves "
     "mrh_extract_triangles mrh_extract_mesh mrh_get_stats mrh_set_profile mrh_dump_blocks "
     "mrh_get_voxel mrh_import_blocks mrh_get_triangle_blocks mrh_process_triangles mrh_selftest_division mrh_version"
 ).split()
@@ -127,6 +130,8 @@ def _declare(lib: C.CDLL) -> C.CDLL:
     lib.mrh_integrate_points.argtypes = [C.c_void_p, C.c_int]
     lib.mrh_get_free_blocks.argtypes = [C.c_void_p, P(C.c_int64), P(C.c_int64)]
     lib.mrh_stream_out.argtypes = [C.c_void_p, P(C.c_float), C.c_float, C.c_void_p, C.c_void_p, C.c_uint64, P(C.c_uint64)]
+    lib.mrh_splat_seeds.argtypes = [C.c_void_p, C.c_float, C.c_int, P(C.c_void_p), P(C.c_uint64)]
+    lib.mrh_get_qtree_leaves.argtypes = [C.c_void_p, P(C.c_void_p), P(C.c_uint64)]
     lib.mrh_integrate_resume.argtypes = [C.c_void_p]
     lib.mrh_exchange_buffer.argtypes = [C.c_void_p, P(C.c_void_p), P(C.c_uint64), P(C.c_int)]
     lib.mrh_sync.argtypes = [C.c_void_p]
@@ -353,6 +358,23 @@ class Engine:
         a, b = C.c_int64(), C.c_int64()
         self._check(self.lib.mrh_get_free_blocks(self._ctx, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def splat_seeds(self, qtree_thresh: float = 0.1, qtree_min_pixel_size: int = 1) -> np.ndarray:
+        """3DGS splat seeds of the current frame (call after integrate()): quad-tree over the colour image, one seed
+        per leaf whose centre lands in a voxel of weight 1.  Returns a SEED_DTYPE array in canonical (leaf) order."""
+        ptr, n = C.c_void_p(), C.c_uint64()
+        self._check(self.lib.mrh_splat_seeds(self._ctx, qtree_thresh, qtree_min_pixel_size, C.byref(ptr), C.byref(n)))
+        if n.value == 0:
+            return np.zeros(0, SEED_DTYPE)
+        return np.frombuffer((C.c_char * (n.value * 20)).from_address(ptr.value), dtype=SEED_DTYPE).copy()
+
+    def qtree_leaves(self) -> np.ndarray:
+        """Leaves of the quad-tree of the last splat_seeds() call, canonical order (LEAF_DTYPE)."""
+        ptr, n = C.c_void_p(), C.c_uint64()
+        self._check(self.lib.mrh_get_qtree_leaves(self._ctx, C.byref(ptr), C.byref(n)))
+        if n.value == 0:
+            return np.zeros(0, LEAF_DTYPE)
+        return np.frombuffer((C.c_char * (n.value * 16)).from_address(ptr.value), dtype=LEAF_DTYPE).copy()
 
     def stream_out(self, center, radius: float) -> Tuple[np.ndarray, np.ndarray]:
         """Streamer device half: blocks at distance >= radius from `center` (radius < 0: all) are copied out, ordered by

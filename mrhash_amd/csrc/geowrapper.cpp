@@ -24,9 +24,26 @@ GeoWrapper::GeoWrapper(float sdf_truncation, float sdf_truncation_scale, int int
     : sdf_truncation_(sdf_truncation), sdf_truncation_scale_(sdf_truncation_scale), integration_weight_sample_(integration_weight_sample),
       virtual_voxel_size_(virtual_voxel_size), n_frames_invalidate_voxels_(n_frames_invalidate_voxels), voxel_extents_scale_(voxel_extents_scale),
       min_weight_threshold_(min_weight_threshold), sdf_var_threshold_(sdf_var_threshold), vertices_merging_threshold_(vertices_merging_threshold) {
-  if (!gs_optimization_param_path.empty())
-    std::cerr << "GeoWrapper::GeoWrapper | Gaussian-splatting optimisation is outside this library's scope; '" << gs_optimization_param_path
-              << "' is ignored" << std::endl;
+  if (!gs_optimization_param_path.empty()) {
+    // geowrapper.cpp:74-78 builds a GaussianContainer from this file.  Here only its initialisation half exists (the
+    // per-frame splat seeds, mrh_splat_seeds); the optimiser / rasteriser stay out of scope, so of the JSON only the two
+    // quad-tree keys are read (src/gs/gaussian.cu:49-50; defaults gaussian.cuh:28-29).
+    std::ifstream js(gs_optimization_param_path);
+    if (!js.is_open()) throw std::runtime_error("GeoWrapper::GeoWrapper | cannot open " + gs_optimization_param_path);
+    const std::string text((std::istreambuf_iterator<char>(js)), std::istreambuf_iterator<char>());
+    auto number_after = [&](const char* key, double fallback) {
+      const size_t k = text.find(std::string("\"") + key + "\"");
+      if (k == std::string::npos) return fallback;
+      const size_t colon = text.find(':', k);
+      if (colon == std::string::npos) return fallback;
+      return std::strtod(text.c_str() + colon + 1, nullptr);
+    };
+    qtree_thresh_ = (float) number_after("qtree_thresh", 0.1);
+    qtree_min_pixel_size_ = (int) number_after("qtree_min_pixel_size", 1.0);
+    gs_enabled_ = true;
+    std::cerr << "GeoWrapper::GeoWrapper | splat seeds only (quad-tree threshold " << qtree_thresh_ << ", min pixel size " << qtree_min_pixel_size_
+              << "); Gaussian-splatting optimisation is outside this library's scope" << std::endl;
+  }
   mrh_params p;
   std::memset(&p, 0, sizeof p);
   p.abi_version = MRH_ABI_VERSION;
@@ -200,6 +217,12 @@ void GeoWrapper::compute() {
     check(mrh_upload_depth(ctx_, depth_.data(), (int) depth_rows_, (int) depth_cols_), "compute");
     check(mrh_upload_rgb(ctx_, rgb_.data(), (int) rgb_rows_, (int) rgb_cols_), "compute");
     check(mrh_integrate(ctx_, n_frames_invalidate_voxels_), "compute");
+    if (gs_enabled_) {  // geowrapper.cpp:142-143 runGS -> extractNodesQTree + checkNodes; Add_gaussians keeps what they emit
+      const mrh_splat_seed* seeds = nullptr;
+      uint64_t n = 0;
+      check(mrh_splat_seeds(ctx_, qtree_thresh_, qtree_min_pixel_size_, &seeds, &n), "compute");
+      seeds_.insert(seeds_.end(), seeds, seeds + n);
+    }
   }
   if (!point_cloud_.empty()) {  // geowrapper.cpp:146-147: VoxelContainer::integrate(point_cloud, eigenvectors, weights, ...)
     if (!normals_.empty())
@@ -343,10 +366,27 @@ void GeoWrapper::deserializeGrid(const std::string& filename) {
   check(mrh_import_blocks(ctx_, descs.data(), vox.data(), n), "deserializeGrid");
 }
 
-void GeoWrapper::GSSavePointCloud(const std::string& /*folder*/) {
-  std::cerr << "GeoWrapper::GSSavePointCloud | GS container not initialized" << std::endl;  // geowrapper.cpp:233-236
+void GeoWrapper::GSSavePointCloud(const std::string& folder) {
+  if (!gs_enabled_) {
+    std::cerr << "GeoWrapper::GSSavePointCloud | GS container not initialized" << std::endl;  // geowrapper.cpp:233-236
+    return;
+  }
+  // the reference writes the optimised model (GaussianModel::Save_ply, src/gs/gaussian.cu:260-282) to
+  // <folder>/point_cloud.ply; here the same file holds the seeds the model is initialised from
+  const std::string mk = "mkdir -p '" + folder + "'";
+  if (std::system(mk.c_str()) != 0) throw std::runtime_error("GeoWrapper::GSSavePointCloud | cannot create " + folder);
+  std::ofstream ply(folder + "/point_cloud.ply");
+  if (!ply.is_open()) throw std::runtime_error("GeoWrapper::GSSavePointCloud | cannot write " + folder + "/point_cloud.ply");
+  ply << "ply\nformat ascii 1.0\nelement vertex " << seeds_.size()
+      << "\nproperty float x\nproperty float y\nproperty float z\nproperty float scale\n"
+         "property uchar red\nproperty uchar green\nproperty uchar blue\nend_header\n";
+  for (const mrh_splat_seed& s : seeds_)
+    ply << s.p[0] << " " << s.p[1] << " " << s.p[2] << " " << s.scale << " " << (int) s.rgb[0] << " " << (int) s.rgb[1] << " " << (int) s.rgb[2] << "\n";
+  std::cout << "GeoWrapper::GSSavePointCloud | written " << seeds_.size() << " splat seeds to " << folder << std::endl;
 }
 
-void GeoWrapper::GSFinalOpt() {}  // geowrapper.cpp:241-244: no-op without a GS container
+void GeoWrapper::GSFinalOpt() {  // geowrapper.cpp:241-244: no-op without a GS container
+  if (gs_enabled_) throw std::runtime_error("GeoWrapper::GSFinalOpt | Gaussian-splatting optimisation is outside this library's scope");
+}
 
 }  // namespace pygeowrapper

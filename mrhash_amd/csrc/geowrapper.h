@@ -81,6 +81,7 @@ public:
   void deserializeGrid(const std::string& filename);
   void GSSavePointCloud(const std::string& folder);
   void GSFinalOpt();
+  const std::vector<mrh_splat_seed>& splatSeeds() const { return seeds_; }  // accumulated over compute() calls
 
   mrh_ctx* ctx() { return ctx_; }
 
@@ -119,6 +120,11 @@ private:
   std::vector<float> point_cloud_, normals_;
   std::vector<double> V_, C_;
   std::vector<int32_t> F_;
+  // 3DGS initialisation: on when a gs_optimization_param_path was given
+  bool gs_enabled_ = false;
+  float qtree_thresh_ = 0.1f;
+  int qtree_min_pixel_size_ = 1;
+  std::vector<mrh_splat_seed> seeds_;
   mrh_ctx* ctx_ = nullptr;
 };
 

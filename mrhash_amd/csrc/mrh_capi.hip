@@ -25,6 +25,7 @@
 #include "mrh_fast2.h"
 #include "mrh_mesh.h"
 #include "mrh_lidar.h"
+#include "mrh_splat.h"
 
 using namespace mrh;
 
@@ -75,6 +76,16 @@ struct mrh_ctx {
   u32* d_pt_counts = nullptr; u32* d_pt_offsets = nullptr; uint64_t pt_cap = 0;
   u64* d_rec_keys[2] = {nullptr, nullptr}; float* d_rec_vals[2] = {nullptr, nullptr}; uint64_t rec_cap = 0;
   void* d_sort_tmp = nullptr; size_t sort_tmp_bytes = 0;
+  // 3DGS splat seeds (mrh_splat.h): sized for one (image shape, min pixel size)
+  QTree qt = {0, 0, 0, 0, 0};
+  QSum* d_qt_sums = nullptr; u32* d_qt_flags = nullptr; u32* d_qt_unc = nullptr; u64* d_qt_marks = nullptr; u64* d_qt_pos = nullptr;
+  mrh_splat_seed* d_qt_parked = nullptr; mrh_splat_seed* d_qt_seeds = nullptr; mrh_qtree_leaf* d_qt_leaves = nullptr;
+  u64* d_qt_misc = nullptr;  // [0] totals (leaves | seeds << 32), [1] uncertain-node counter (low word)
+  void* d_qt_tmp = nullptr; size_t qt_tmp_bytes = 0;
+  int qt_literal = 0;        // MRH_QTREE_LITERAL=1: every node error through the reference's summation order (cross-check)
+  uint32_t qt_last_literal = 0;
+  std::vector<mrh_splat_seed> seeds;
+  std::vector<mrh_qtree_leaf> qt_leaves;
   int mr_fused = 1;          // MRH_MR_FUSED=0: multi-resolution maps always through the general kernels (mrh_kernels.h)
   bool mr_next_general = true;    // the next multi-resolution frame must take the general path (frame 0 / after a starve frame / after an import)
   bool mr_summaries_valid = false;  // fast.summary / summary_c describe every live block (the general kernels do not maintain them)
@@ -158,6 +169,7 @@ void free_all(mrh_ctx* c) {
   F(c->tab.pool); F(c->tab.compact); F(c->tab.ctr); F(c->tab.prof);
   F(c->d_depth_own); F(c->d_rgb_own); F(c->d_decision); F(c->d_zbuf); F(c->d_realloc); F(c->d_reint); F(c->d_flag);
   F(c->d_upd_partials); F(c->d_misc); F(c->d_cfree); F(c->d_zmin); F(c->d_points); F(c->d_pt_counts); F(c->d_pt_offsets); F(c->d_rec_keys[0]); F(c->d_rec_keys[1]); F(c->d_rec_vals[0]); F(c->d_rec_vals[1]); F(c->d_sort_tmp); F(c->fast.summary); F(c->fast.summary_c); F(c->fast.bbox); F(c->d_cnt_partials);
+  F(c->d_qt_sums); F(c->d_qt_flags); F(c->d_qt_unc); F(c->d_qt_marks); F(c->d_qt_pos); F(c->d_qt_parked); F(c->d_qt_seeds); F(c->d_qt_leaves); F(c->d_qt_misc); F(c->d_qt_tmp);
   for (auto& e : c->ev_pool) { (void) hipEventDestroy(e.a); (void) hipEventDestroy(e.b); }
   for (auto& e : c->ev_pending) { (void) hipEventDestroy(e.a); (void) hipEventDestroy(e.b); }
   if (c->stream) (void) hipStreamDestroy(c->stream);
@@ -566,6 +578,7 @@ int mrh_create(const mrh_params* p, mrh_ctx** out) {
   }
   if (const char* g = getenv("MRH_SWEEP_WGS")) { const int v = atoi(g); if (v > 0 && v <= 4096) c->sweep_wgs = v; }
   if (const char* g = getenv("MRH_MESH_HOST")) c->mesh_on_host = atoi(g) ? 1 : 0;
+  if (const char* g = getenv("MRH_QTREE_LITERAL")) c->qt_literal = atoi(g) ? 1 : 0;
   if (const char* g = getenv("MRH_MR_FUSED")) c->mr_fused = atoi(g) ? 1 : 0;
   if (const char* g = getenv("MRH_SWEEP_WGS_MR")) { const int v = atoi(g); if (v > 0 && v <= 4096) c->sweep_wgs_mr = v; }
   int rc = init_buffers(c);
@@ -971,6 +984,92 @@ int mrh_sync(mrh_ctx* c) {
   rc = drain_events(c);
   if (rc) return rc;
   return check_device_flags(c, flags);
+}
+
+// GaussianContainer::extractNodesQTree + checkNodes (gaussian_data_structures.cpp:58-70, .cu:58-84), see mrh_splat.h
+int mrh_splat_seeds(mrh_ctx* c, float qtree_thresh, int qtree_min_pixel_size, const mrh_splat_seed** out, uint64_t* out_n) {
+  int rc = ensure_ready(c, "mrh_splat_seeds");
+  if (rc) return rc;
+  if (!out || !out_n) return fail(c, MRH_ERR_INVALID_ARG, "mrh_splat_seeds: null argument");
+  if (c->pending) return fail(c, MRH_ERR_STATE, "mrh_splat_seeds: an exchange is pending (call mrh_integrate_resume)");
+  if (!c->has_camera) return fail(c, MRH_ERR_STATE, "mrh_splat_seeds: set_camera has not been called");
+  if (c->spherical) return fail(c, MRH_ERR_UNSUPPORTED, "mrh_splat_seeds: pinhole camera only");
+  if (qtree_min_pixel_size < 0 || qtree_thresh != qtree_thresh) return fail(c, MRH_ERR_INVALID_ARG, "mrh_splat_seeds: bad quad-tree parameter");
+  if (!c->d_depth || !c->d_rgb) return fail(c, MRH_ERR_STATE, "mrh_splat_seeds: no depth / colour image");
+  const Cam& k = c->cam;
+  if (c->depth_rows != k.rows || c->depth_cols != k.cols || c->rgb_rows != k.rows || c->rgb_cols != k.cols)
+    return fail(c, MRH_ERR_INVALID_ARG, "mrh_splat_seeds: image shape differs from the camera");
+  if ((uint64_t) k.rows * (uint64_t) k.cols > (1ull << 22)) return fail(c, MRH_ERR_CAPACITY, "mrh_splat_seeds: image above 2^22 pixels");
+  hipStream_t s = c->stream;
+  // depth of the potential tree: the first level whose largest rectangle (the bottom-right chain of ceil halves) can
+  // no longer split (quad_tree.cu:126-141)
+  QTree qt = {k.cols, k.rows, 0, qtree_min_pixel_size, 0};
+  for (int w = k.cols, h = k.rows; qt.D < kQtMaxDepth && !(w / 2 <= qt.min_px || h / 2 <= qt.min_px); qt.D++) { w -= w / 2; h -= h / 2; }
+  qt.total = qt_level_offset(qt.D + 1);
+  if (qt.total != c->qt.total || !c->d_qt_sums) {
+    HIP_TRY(c, hipStreamSynchronize(s));
+    auto F = [](auto*& p) { if (p) (void) hipFree(p); p = nullptr; };
+    F(c->d_qt_sums); F(c->d_qt_flags); F(c->d_qt_unc); F(c->d_qt_marks); F(c->d_qt_pos); F(c->d_qt_parked); F(c->d_qt_seeds); F(c->d_qt_leaves); F(c->d_qt_misc);
+    const size_t n = qt.total;
+    HIP_TRY(c, hipMalloc((void**) &c->d_qt_sums, n * sizeof(QSum)));
+    HIP_TRY(c, hipMalloc((void**) &c->d_qt_flags, n * sizeof(u32)));
+    HIP_TRY(c, hipMalloc((void**) &c->d_qt_unc, n * sizeof(u32)));
+    HIP_TRY(c, hipMalloc((void**) &c->d_qt_marks, n * sizeof(u64)));
+    HIP_TRY(c, hipMalloc((void**) &c->d_qt_pos, n * sizeof(u64)));
+    HIP_TRY(c, hipMalloc((void**) &c->d_qt_parked, n * sizeof(mrh_splat_seed)));
+    HIP_TRY(c, hipMalloc((void**) &c->d_qt_seeds, n * sizeof(mrh_splat_seed)));
+    HIP_TRY(c, hipMalloc((void**) &c->d_qt_leaves, n * sizeof(mrh_qtree_leaf)));
+    HIP_TRY(c, hipMalloc((void**) &c->d_qt_misc, 2 * sizeof(u64)));
+    size_t need = 0;
+    HIP_TRY(c, rocprim::exclusive_scan(nullptr, need, c->d_qt_marks, c->d_qt_pos, (u64) 0, n, rocprim::plus<u64>(), s));
+    if (need > c->qt_tmp_bytes) {
+      F(c->d_qt_tmp);
+      HIP_TRY(c, hipMalloc(&c->d_qt_tmp, need));
+      c->qt_tmp_bytes = need;
+    }
+  }
+  c->qt = qt;
+  const u32 grid = (qt.total + 255) / 256;
+  u32* unc_count = (u32*) (c->d_qt_misc + 1);
+  HIP_TRY(c, hipMemsetAsync(c->d_qt_misc, 0, 2 * sizeof(u64), s));
+  // exact statistics of every potential node, four tree levels per launch
+  int L = qt.D, T = L < 4 ? L : 4;
+  k_qt_sums_bottom<<<1u << (2 * (L - T)), 256, 0, s>>>(qt, c->d_rgb, c->d_qt_sums, T);
+  for (L -= T; L > 0; L -= T) {
+    T = L < 4 ? L : 4;
+    k_qt_sums_up<<<1u << (2 * (L - T)), 256, 0, s>>>(qt, c->d_qt_sums, L, T);
+  }
+  k_qt_decide<<<grid, 256, 0, s>>>(qt, qtree_thresh, c->d_qt_sums, c->qt_literal, c->d_qt_flags, c->d_qt_unc, unc_count);
+  k_qt_literal<<<512, 256, 0, s>>>(qt, c->d_rgb, qtree_thresh, c->d_qt_unc, unc_count, c->d_qt_flags);
+  k_qt_emit<<<grid, 256, 0, s>>>(qt, c->cam, c->map, c->tab, c->d_depth, c->d_rgb, c->d_qt_flags, c->d_qt_marks, c->d_qt_parked);
+  size_t tb = c->qt_tmp_bytes;
+  HIP_TRY(c, rocprim::exclusive_scan(c->d_qt_tmp, tb, c->d_qt_marks, c->d_qt_pos, (u64) 0, (size_t) qt.total, rocprim::plus<u64>(), s));
+  k_qt_scatter<<<grid, 256, 0, s>>>(qt, c->d_qt_marks, c->d_qt_pos, c->d_qt_parked, c->d_qt_leaves, c->d_qt_seeds, c->d_qt_misc);
+  u64 h_misc[2] = {0, 0};
+  HIP_TRY(c, hipMemcpyAsync(h_misc, c->d_qt_misc, sizeof h_misc, hipMemcpyDeviceToHost, s));
+  HIP_TRY(c, hipStreamSynchronize(s));
+  const uint64_t n_leaves = h_misc[0] & 0xFFFFFFFFull, n_seeds = h_misc[0] >> 32;
+  c->qt_last_literal = (uint32_t) h_misc[1];
+  if (n_leaves > 1000000ull) return fail(c, MRH_ERR_CAPACITY, "mrh_splat_seeds: %llu leaves, above the reference's capacity of 1000000 (params.h:20-23)", (unsigned long long) n_leaves);
+  c->qt_leaves.resize(n_leaves);
+  c->seeds.resize(n_seeds);
+  if (n_leaves) HIP_TRY(c, hipMemcpyAsync(c->qt_leaves.data(), c->d_qt_leaves, n_leaves * sizeof(mrh_qtree_leaf), hipMemcpyDeviceToHost, s));
+  if (n_seeds) HIP_TRY(c, hipMemcpyAsync(c->seeds.data(), c->d_qt_seeds, n_seeds * sizeof(mrh_splat_seed), hipMemcpyDeviceToHost, s));
+  HIP_TRY(c, hipStreamSynchronize(s));
+  if (getenv("MRH_DEBUG")) {
+    fprintf(stderr, "[mrh] splat seeds: %u potential nodes, %u literal evaluations, %llu leaves, %llu seeds\n", qt.total,
+            c->qt_last_literal, (unsigned long long) n_leaves, (unsigned long long) n_seeds);
+  }
+  *out = c->seeds.data();
+  *out_n = n_seeds;
+  return MRH_OK;
+}
+
+int mrh_get_qtree_leaves(mrh_ctx* c, const mrh_qtree_leaf** out, uint64_t* out_n) {
+  if (!c || !out || !out_n) return MRH_ERR_INVALID_ARG;
+  *out = c->qt_leaves.data();
+  *out_n = c->qt_leaves.size();
+  return MRH_OK;
 }
 
 int mrh_get_free_blocks(mrh_ctx* c, int64_t* out_free_fine, int64_t* out_free_coarse) {

@@ -125,6 +125,17 @@ PYBIND11_MODULE(pygeowrapper, m) {
       g.stream({pos.data()[0], pos.data()[1], pos.data()[2]}, radius);
     })
     .def("_hostGridBlocks", &GeoWrapper::hostGridBlocks)
+    // splat seeds accumulated so far (what the reference hands to GaussianModel::Add_gaussians): (xyz, scale, rgb)
+    .def("_splatSeeds", [](const GeoWrapper& g) {
+      const auto& seeds = g.splatSeeds();
+      std::vector<float> xyz(seeds.size() * 3), scale(seeds.size());
+      std::vector<uint8_t> rgb(seeds.size() * 3);
+      for (size_t i = 0; i < seeds.size(); i++) {
+        for (int k = 0; k < 3; k++) { xyz[3 * i + k] = seeds[i].p[k]; rgb[3 * i + k] = seeds[i].rgb[k]; }
+        scale[i] = seeds[i].scale;
+      }
+      return py::make_tuple(to_array<float>(xyz, 3), to_array<float>(scale, 1), to_array<uint8_t>(rgb, 3));
+    })
     .def("clearBuffers", &GeoWrapper::clearBuffers)
     .def("serializeData", &GeoWrapper::serializeData, py::arg("filename_hash") = "./data/hash_points.ply",
          py::arg("filename_voxel") = "./data/voxel_points.ply")

@@ -313,3 +313,22 @@ CFG1_PARAMS = dict(
     n_frames_invalidate_voxels=0, voxel_extents_scale=1, marching_cubes_threshold=1.5, min_weight_threshold=5,
     sdf_var_threshold=0.0, vertices_merging_threshold=0.0, min_depth=0.01, max_depth=30.0,
 )
+
+
+def textured_image(rows: int, cols: int, seed: int = 0) -> np.ndarray:
+    """uint8 [rows, cols, 3] with flat areas, soft gradients, sharp edges and a noisy patch: a colour quad-tree over
+    it has leaves on every level (used for the 3DGS splat-seed cases)."""
+    rng = np.random.default_rng(seed)
+    y, x = np.mgrid[0:rows, 0:cols].astype(np.float64)
+    img = np.zeros((rows, cols, 3), np.float64)
+    img[..., 0] = 90 + 60 * np.sin(x / max(cols, 1) * 3.1) * np.cos(y / max(rows, 1) * 2.3)
+    img[..., 1] = 120 + 0.08 * x
+    img[..., 2] = 60 + 0.1 * y
+    for _ in range(6):  # flat rectangles with hard edges
+        r0, c0 = int(rng.integers(0, rows)), int(rng.integers(0, cols))
+        h, w = int(rng.integers(1, max(rows // 3, 2))), int(rng.integers(1, max(cols // 3, 2)))
+        img[r0:r0 + h, c0:c0 + w] = rng.integers(0, 256, 3)
+    r0, c0 = rows // 5, cols // 2
+    h, w = max(rows // 4, 1), max(cols // 4, 1)
+    img[r0:r0 + h, c0:c0 + w] += rng.normal(0, 25, (min(h, rows - r0), min(w, cols - c0), 3))
+    return np.clip(np.rint(img), 0, 255).astype(np.uint8)

@@ -42,6 +42,11 @@
  *       non-atomic read-modify-write per point, so the points of one scan that cross the same voxel
  *       race.  Canonical: every voxel receives its updates in ascending point index (the sequential
  *       loop of mrh_integrate_points).  norm3df(x, y, z) is restated as sqrtf((x*x + y*y) + z*z).
+ *   D7  3DGS splat seeds (subdivideKernel quad_tree.cu:91-166, processNodesKernel
+ *       gaussian_data_structures.cu:5-56): the reference appends leaves, child nodes and seeds through
+ *       atomic counters.  Canonical: leaves by tree level, inside a level in tree order (children in the
+ *       order the reference writes them); seeds in leaf order.  Node errors keep the reference's
+ *       summation order exactly (256 strided partial sums, then the halving tree of computeError).
  */
 #include <float.h>
 #include <limits.h>
@@ -137,6 +142,11 @@ struct mrh_ctx {
   double* C;
   int32_t* F;
   uint64_t nv, nf;
+  /* 3DGS splat seeds */
+  mrh_qtree_leaf* qt_leaves;
+  uint64_t n_qt_leaves;
+  mrh_splat_seed* seeds;
+  uint64_t n_seeds;
   /* stats */
   int profile;
   uint64_t last_updated, last_inserted, last_freed, total_updated, total_compact;
@@ -1305,6 +1315,7 @@ int mrh_destroy(mrh_ctx* c) {
   free(c->table); free(c->compact); free(c->decision); free(c->mutex); free(c->heap_high); free(c->heap_low);
   free(c->blocks); free(c->realloc_pos); free(c->realloc_res); free(c->reintegrate); free(c->depth_buff);
   free(c->depth); free(c->rgb); free(c->points); free(c->cloud); free(c->tris); free(c->tri_blocks); free(c->tri_counts); free(c->V); free(c->C); free(c->F);
+  free(c->qt_leaves); free(c->seeds);
   free(c);
   return MRH_OK;
 }
@@ -1696,6 +1707,128 @@ int mrh_get_free_blocks(mrh_ctx* c, int64_t* out_free_fine, int64_t* out_free_co
   if (!c) return MRH_ERR_INVALID_ARG;
   if (out_free_fine) *out_free_fine = heap_high_free(c);
   if (out_free_coarse) *out_free_coarse = heap_low_free(c);
+  return MRH_OK;
+}
+
+/* ---- 3DGS splat seeds: src/gs/quad_tree.cu:6-222, gaussian_data_structures.cu:5-84 ------------------------ */
+
+#define QT_THREADS 256          /* params.h:18 n_threads_subdivide: the block size fixes the summation order */
+#define QT_MAX_NODES 1000000u   /* params.h:20-23 max_num_qtree_nodes == qtree_leaves_capacity */
+
+/* CUDANode::computeError, quad_tree.cu:6-89: thread t sums the pixels t, t + 256, ... of the node (row-major inside
+ * the node), the 256 partial sums are folded by a halving tree; the same again for the squared deviations. */
+static void qt_tree_fold(float s[3][QT_THREADS]) {
+  for (int stride = QT_THREADS / 2; stride > 0; stride >>= 1)
+    for (int t = 0; t < stride; t++)
+      for (int k = 0; k < 3; k++) s[k][t] += s[k][t + stride];
+}
+
+static float qtree_node_error(const mrh_ctx* c, mrh_qtree_leaf n) {
+  float s[3][QT_THREADS];
+  const int count = n.width * n.height;
+  const size_t cols = (size_t) c->rgb_cols;
+  for (int t = 0; t < QT_THREADS; t++) {
+    float r_sum = 0.f, g_sum = 0.f, b_sum = 0.f;
+    for (int idx = t; idx < count; idx += QT_THREADS) {
+      const int x = n.x0 + idx % n.width, y = n.y0 + idx / n.width;
+      const uint8_t* pix = c->rgb + ((size_t) y * cols + (size_t) x) * 3;
+      r_sum += (float) pix[0]; g_sum += (float) pix[1]; b_sum += (float) pix[2];
+    }
+    s[0][t] = r_sum; s[1][t] = g_sum; s[2][t] = b_sum;
+  }
+  qt_tree_fold(s);
+  const float r_mean = s[0][0] / count, g_mean = s[1][0] / count, b_mean = s[2][0] / count;
+  for (int t = 0; t < QT_THREADS; t++) {
+    float r_mse = 0.f, g_mse = 0.f, b_mse = 0.f;
+    for (int idx = t; idx < count; idx += QT_THREADS) {
+      const int x = n.x0 + idx % n.width, y = n.y0 + idx / n.width;
+      const uint8_t* pix = c->rgb + ((size_t) y * cols + (size_t) x) * 3;
+      const float r_diff = (float) pix[0] - r_mean, g_diff = (float) pix[1] - g_mean, b_diff = (float) pix[2] - b_mean;
+      r_mse += r_diff * r_diff; g_mse += g_diff * g_diff; b_mse += b_diff * b_diff;
+    }
+    s[0][t] = r_mse; s[1][t] = g_mse; s[2][t] = b_mse;
+  }
+  qt_tree_fold(s);
+  const float r_fin = s[0][0] / count, g_fin = s[1][0] / count, b_fin = s[2][0] / count;
+  const float error = r_fin * 0.2989f + g_fin * 0.5870f + b_fin * 0.1140f;
+  return error * (c->rgb_cols * c->rgb_rows) / 90000000.0f;
+}
+
+/* CUDAQTree::subdivide + subdivideKernel, quad_tree.cu:91-222, level by level (D7 order). */
+static int qtree_subdivide(mrh_ctx* c, float threshold, int min_pixel_size) {
+  const size_t npix = (size_t) c->rgb_rows * c->rgb_cols;
+  mrh_qtree_leaf* in = (mrh_qtree_leaf*) malloc(npix * sizeof *in);
+  mrh_qtree_leaf* out = (mrh_qtree_leaf*) malloc(npix * sizeof *out);
+  free(c->qt_leaves);
+  c->qt_leaves = (mrh_qtree_leaf*) malloc(npix * sizeof *c->qt_leaves); /* leaves tile the image: never more than pixels */
+  c->n_qt_leaves = 0;
+  size_t n_in = 1;
+  in[0].x0 = 0; in[0].y0 = 0; in[0].width = c->rgb_cols; in[0].height = c->rgb_rows;
+  int rc = MRH_OK;
+  while (n_in > 0) {
+    size_t n_out = 0;
+    for (size_t i = 0; i < n_in; i++) {
+      const mrh_qtree_leaf node = in[i];
+      const float err = qtree_node_error(c, node);
+      const int w1 = node.width / 2, w2 = node.width - w1, h1 = node.height / 2, h2 = node.height - h1;
+      if (err <= threshold || w1 <= min_pixel_size || h1 <= min_pixel_size) { c->qt_leaves[c->n_qt_leaves++] = node; continue; }
+      const mrh_qtree_leaf k0 = {node.x0, node.y0, w1, h1}, k1 = {node.x0, node.y0 + h1, w1, h2};
+      const mrh_qtree_leaf k2 = {node.x0 + w1, node.y0, w2, h1}, k3 = {node.x0 + w1, node.y0 + h1, w2, h2};
+      out[n_out++] = k0; out[n_out++] = k1; out[n_out++] = k2; out[n_out++] = k3;
+    }
+    if (n_out > QT_MAX_NODES) { rc = MRH_ERR_CAPACITY; break; }
+    mrh_qtree_leaf* tmp = in; in = out; out = tmp;
+    n_in = n_out;
+  }
+  free(in); free(out);
+  if (rc == MRH_OK && c->n_qt_leaves > QT_MAX_NODES) rc = MRH_ERR_CAPACITY;
+  return rc;
+}
+
+/* processNodesKernel, gaussian_data_structures.cu:5-56 */
+static void process_nodes(mrh_ctx* c) {
+  free(c->seeds);
+  c->seeds = (mrh_splat_seed*) malloc((c->n_qt_leaves ? c->n_qt_leaves : 1) * sizeof *c->seeds);
+  c->n_seeds = 0;
+  for (uint64_t i = 0; i < c->n_qt_leaves; i++) {
+    const mrh_qtree_leaf node = c->qt_leaves[i];
+    const float p2x = (float) node.x0 + 0.5f * (float) node.width, p2y = (float) node.y0 + 0.5f * (float) node.height;
+    const int px = f2i(p2x + 0.5f), py = f2i(p2y + 0.5f);
+    if (px < 0 || py < 0 || px >= (int) c->cols || py >= (int) c->rows) continue;
+    const float depth_value = c->depth[(size_t) py * c->depth_cols + px];
+    if (depth_value < c->min_depth) continue;
+    const f3 center = se3_apply(c->R, c->t, inverse_projection(c, (unsigned) py, (unsigned) px, depth_value));
+    if (get_voxel_f(c, center, NULL).weight != 1) continue;
+    const float half_w = 0.5f * (float) node.width, half_h = 0.5f * (float) node.height;
+    const float scale = (depth_value * sqrtf(half_w * half_w + half_h * half_h)) / c->fx;
+    if (scale <= 0.0f) continue; /* as written: a NaN scale passes */
+    mrh_splat_seed* s = &c->seeds[c->n_seeds++];
+    s->p[0] = center.x; s->p[1] = center.y; s->p[2] = center.z;
+    s->scale = scale;
+    const uint8_t* rgb = c->rgb + ((size_t) py * c->rgb_cols + px) * 3;
+    s->rgb[0] = rgb[0]; s->rgb[1] = rgb[1]; s->rgb[2] = rgb[2]; s->pad = 0;
+  }
+}
+
+int mrh_splat_seeds(mrh_ctx* c, float qtree_thresh, int qtree_min_pixel_size, const mrh_splat_seed** out, uint64_t* out_n) {
+  if (!c || !out || !out_n) return fail(c, MRH_ERR_INVALID_ARG, "mrh_splat_seeds: null argument");
+  if (!c->has_camera) return fail(c, MRH_ERR_STATE, "mrh_splat_seeds: set_camera has not been called");
+  if (c->model != MRH_CAMERA_PINHOLE) return fail(c, MRH_ERR_UNSUPPORTED, "mrh_splat_seeds: pinhole camera only");
+  if (qtree_min_pixel_size < 0 || qtree_thresh != qtree_thresh) return fail(c, MRH_ERR_INVALID_ARG, "mrh_splat_seeds: bad quad-tree parameter");
+  if (!c->depth || !c->rgb) return fail(c, MRH_ERR_STATE, "mrh_splat_seeds: no depth / colour image");
+  if (c->depth_rows != (int) c->rows || c->depth_cols != (int) c->cols || c->rgb_rows != (int) c->rows || c->rgb_cols != (int) c->cols)
+    return fail(c, MRH_ERR_INVALID_ARG, "mrh_splat_seeds: image shape differs from the camera");
+  if ((uint64_t) c->rows * c->cols > (1ull << 22)) return fail(c, MRH_ERR_CAPACITY, "mrh_splat_seeds: image above 2^22 pixels");
+  const int rc = qtree_subdivide(c, qtree_thresh, qtree_min_pixel_size);
+  if (rc) return fail(c, rc, "mrh_splat_seeds: quad-tree above the reference's node capacity");
+  process_nodes(c);
+  *out = c->seeds; *out_n = c->n_seeds;
+  return MRH_OK;
+}
+
+int mrh_get_qtree_leaves(mrh_ctx* c, const mrh_qtree_leaf** out, uint64_t* out_n) {
+  if (!c || !out || !out_n) return MRH_ERR_INVALID_ARG;
+  *out = c->qt_leaves; *out_n = c->n_qt_leaves;
   return MRH_OK;
 }
 

@@ -22,6 +22,8 @@ CASES = {
 }
 
 
+SPLAT = (0.0025, 1)  # quad-tree threshold / min pixel size of the splat-seed hashes (128x128 image: 0.1 * 128^2 / 640x480 ~ 0.005)
+
 LIDAR_CASES = {
     # scans are rebuilt by parity_utils.lidar_scans_from_spec: street-canyon scene, drive poses, points rounded to 1 mm
     "street_3scans": dict(params=dict(synth.VBR_PARAMS, min_weight_threshold=1), max_depth=100.0,
@@ -66,7 +68,11 @@ def main():
         d, v = e.dump_blocks()
         t = e.extract_triangles()
         V, F, C = e.extract_mesh()
+        seeds = e.splat_seeds(*SPLAT)  # 3DGS splat seeds of the last frame
+        leaves = e.qtree_leaves()
         out["cases"][name] = dict(
+            splat=dict(qtree_thresh=SPLAT[0], qtree_min_pixel_size=SPLAT[1], leaves=int(len(leaves)), seeds=int(len(seeds)),
+                       sha256_leaves=hashlib.sha256(leaves.tobytes()).hexdigest(), sha256_seeds=hashlib.sha256(seeds.tobytes()).hexdigest()),
             params=case["params"], frames=case["frames"], blocks=int(len(d)), coarse_blocks=int((d["resolution"] == 1).sum()),
             weighted_voxels=int((v["weight"] > 0).sum()), triangles=int(t.shape[0]), vertices=int(V.shape[0]), faces=int(F.shape[0]),
             sha256_occupancy=hashlib.sha256(d.tobytes()).hexdigest(), sha256_payload=hashlib.sha256(v.tobytes()).hexdigest(),

@@ -180,3 +180,34 @@ def test_streamer_pages_far_blocks_out_and_back(monkeypatch, tmp_path):
     assert left == 0  # extractMesh brought everything back
     assert len(Fb) > 5000
     assert np.array_equal(Vb, Vs) and np.array_equal(Fb, Fs)
+
+
+def test_gs_runner_sequence_accumulates_splat_seeds(geowrapper_cls, oracle, tmp_path):
+    """apps/rgbd_gs_runner.py: the constructor gets configurations/params.json, every compute() seeds splats from the
+    frame's quad-tree (geowrapper.cpp:142-143), GSSavePointCloud writes them; the optimiser itself is out of scope."""
+    js = tmp_path / "params.json"
+    js.write_text('{\n  "kf_thresh": 2000,\n  "qtree_thresh": 0.002,\n  "qtree_min_pixel_size": 1,\n  "kf_iters": 10\n}\n')
+    g = _make(geowrapper_cls, gs_optimization_param_path=str(js), n_frames_invalidate_voxels=0)
+    K = synth.CFG1
+    g.setCamera(K.fx, K.fy, K.cx, K.cy, K.rows, K.cols, 0.01, 30.0, 0)
+    b = pu.make_engine(oracle, K, dict(synth.CFG1_PARAMS), 32768)
+    want = []
+    for f in [synth.cfg1_sphere(), synth.cfg1_sphere(zc=1.56), synth.cfg1_plane(z=1.0)]:
+        g.setCurrPose(f.t, f.q)
+        g.setDepthImage(f.depth)
+        g.setRGBImage(f.rgb)
+        g.compute()
+        pu.feed(b, f)
+        want.append(b.splat_seeds(0.002, 1))
+    want = np.concatenate(want)
+    xyz, scale, rgb = g._splatSeeds()
+    assert len(want) > 100 and xyz.shape == (len(want), 3)
+    assert np.array_equal(xyz, want["p"]) and np.array_equal(scale[:, 0], want["scale"]) and np.array_equal(rgb, want["rgb"])
+    out = tmp_path / "gs_out"
+    g.GSSavePointCloud(str(out))
+    txt = (out / "point_cloud.ply").read_text().splitlines()
+    assert txt[2] == f"element vertex {len(want)}" and len(txt) == txt.index("end_header") + 1 + len(want)
+    with pytest.raises(RuntimeError):
+        g.GSFinalOpt()
+    with pytest.raises(RuntimeError):
+        _make(geowrapper_cls, gs_optimization_param_path=str(tmp_path / "missing.json"))

@@ -23,6 +23,13 @@ def check(e, case, name):
     assert (t.shape[0], V.shape[0], F.shape[0]) == (case["triangles"], case["vertices"], case["faces"]), name
     assert hashlib.sha256(t.tobytes()).hexdigest() == case["sha256_triangles"], name
     assert hashlib.sha256(F.tobytes()).hexdigest() == case["sha256_faces"], name
+    if "splat" in case:  # 3DGS splat seeds of the last frame
+        sp = case["splat"]
+        seeds = e.splat_seeds(sp["qtree_thresh"], sp["qtree_min_pixel_size"])
+        leaves = e.qtree_leaves()
+        assert (len(leaves), len(seeds)) == (sp["leaves"], sp["seeds"]), name
+        assert hashlib.sha256(leaves.tobytes()).hexdigest() == sp["sha256_leaves"], name
+        assert hashlib.sha256(seeds.tobytes()).hexdigest() == sp["sha256_seeds"], name
 
 
 def run_rgbd(lib, case):
