@@ -247,7 +247,9 @@ int mrh_sync(mrh_ctx* ctx);
 /* Replaces MeshExtractor::extractMesh = flatAndReduceHashTable() + extractIsoSurface
  * (mesh_extractor.cpp:95-98, marching_cubes.cu:264-305): marching cubes over every live
  * block.  Triangles come back in canonical order (block position ascending in (x,y,z), then
- * voxel index, then triangle number); the buffer is owned by ctx until the next extraction. */
+ * voxel index, then triangle number); the buffer is owned by ctx until the next extraction.
+ * out_triangles may be NULL: the triangle soup then stays on the device (72 bytes per triangle that never cross the
+ * link) and only *out_n and the mesh behind mrh_extract_mesh are produced — what GeoWrapper::extractMesh needs. */
 int mrh_extract_triangles(mrh_ctx* ctx, const mrh_triangle** out_triangles, uint64_t* out_n);
 
 /* Replaces MeshExtractor::processTriangles (mesh_extractor.cpp:9-76) applied to the triangles

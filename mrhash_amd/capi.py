@@ -330,10 +330,14 @@ class Engine:
         return s
 
     # -- outputs -------------------------------------------------------------------------------
-    def extract_triangles(self) -> np.ndarray:
-        """[T, 3] structured array of vertices (p[3], c[3]) in canonical triangle order."""
+    def extract_triangles(self, soup: bool = True):
+        """[T, 3] structured array of vertices (p[3], c[3]) in canonical triangle order.  soup=False: marching cubes and
+        the mesh post-process run, the triangle soup stays on the device and only the triangle count is returned."""
         ptr = C.c_void_p()
         n = C.c_uint64()
+        if not soup:
+            self._check(self.lib.mrh_extract_triangles(self._ctx, None, C.byref(n)))
+            return int(n.value)
         self._check(self.lib.mrh_extract_triangles(self._ctx, C.byref(ptr), C.byref(n)))
         if n.value == 0:
             return np.zeros((0, 3), dtype=TRI_DTYPE)

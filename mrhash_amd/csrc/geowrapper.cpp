@@ -235,10 +235,9 @@ void GeoWrapper::compute() {
 
 void GeoWrapper::extractMesh(const std::string& filename) {
   streamInFromGrid(nullptr, 0.f);  // blocks the streamer paged out take part in the mesh (geowrapper.cpp:162-188 walks the grid)
-  const mrh_triangle* tris = nullptr;
   uint64_t nt = 0;
   std::cout << "GeoWrapper::extractMesh | extracting..." << std::endl;
-  check(mrh_extract_triangles(ctx_, &tris, &nt), "extractMesh");
+  check(mrh_extract_triangles(ctx_, nullptr, &nt), "extractMesh");  // the soup itself stays on the device
   std::cout << "MarchingCubesExtractor::extractIsoSurface | triangles extracted: " << nt << std::endl;
   const double *v = nullptr, *c = nullptr;
   const int32_t* f = nullptr;

@@ -4,6 +4,7 @@
 // stream with no host round trip, and only synchronises in the calls that hand data back.
 // There is NO CPU fallback in this file: without a HIP device mrh_create fails with MRH_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
+#include <sys/mman.h>
 
 #include <algorithm>
 #include <array>
@@ -35,6 +36,42 @@ thread_local std::string g_create_err;
 
 struct EvPair {
   hipEvent_t a, b;
+};
+
+// Host result buffer of the blocking calls (triangle soup, V / F / C): grow-only, never zero-filled, 2 MiB-aligned
+// and advised to transparent huge pages.  A device-to-host copy into resident pages runs at link speed on this
+// platform (tools/micro/d2h_paths.hip: 128 MB in 2.4 ms) — what costs is the first touch of fresh 4 KiB pages (+8 ms) and
+// the zero fill of std::vector::resize, so the pages are kept across calls and faulted in as huge pages.
+template <typename T>
+struct HostVec {
+  T* p = nullptr;
+  size_t n = 0, cap = 0;
+  HostVec() = default;
+  HostVec(const HostVec&) = delete;
+  HostVec& operator=(const HostVec&) = delete;
+  ~HostVec() { std::free(p); }
+  T* data() { return p; }
+  const T* data() const { return p; }
+  size_t size() const { return n; }
+  bool empty() const { return n == 0; }
+  void clear() { n = 0; }
+  const T& operator[](size_t i) const { return p[i]; }
+  // contents are NOT preserved when the buffer grows
+  void resize_discard(size_t count) {
+    if (count > cap) {
+      std::free(p);
+      const size_t bytes = ((count * sizeof(T) + (2u << 20) - 1) >> 21) << 21;
+      p = (T*) std::aligned_alloc(2u << 20, bytes);
+      if (!p) throw std::bad_alloc();
+      (void) madvise(p, bytes, MADV_HUGEPAGE);
+      cap = bytes / sizeof(T);
+    }
+    n = count;
+  }
+  void assign(const T* a, const T* b) {
+    resize_discard((size_t) (b - a));
+    if (n) memcpy(p, a, n * sizeof(T));
+  }
 };
 
 }  // namespace
@@ -106,11 +143,11 @@ struct mrh_ctx {
   int pending = 0;           // sharded starve frames: 1 after pass 0, 2 after pass 1
   int pending_max_frames = 0;
   // mesh (host)
-  std::vector<mrh_triangle> tris;
+  HostVec<mrh_triangle> tris;   // host copy of the soup: only when the caller of mrh_extract_triangles asks for it
   std::vector<mrh_block_desc> tri_blocks;
   std::vector<uint32_t> tri_counts;
-  std::vector<double> V, C;
-  std::vector<int32_t> F;
+  HostVec<double> V, C;
+  HostVec<int32_t> F;
   // profiling
   int profile = 0;
   std::vector<EvPair> ev_pool;
@@ -271,6 +308,8 @@ void process_triangles(mrh_ctx* c) {
   const size_t nt = c->tris.size();
   c->V.clear(); c->C.clear(); c->F.clear();
   if (nt == 0) return;
+  std::vector<double> V, C;
+  std::vector<int32_t> F;
   const double eps = (double) c->p.vertices_merging_threshold;
   const double inv_eps = eps != 0.0 ? 1.0 / eps : 0.0;
   std::unordered_map<std::array<uint64_t, 3>, int32_t, KeyHash3> vmap;
@@ -290,10 +329,10 @@ void process_triangles(mrh_ctx* c) {
       int32_t idx;
       if (it != vmap.end()) idx = it->second;
       else {
-        idx = (int32_t) (c->V.size() / 3);
+        idx = (int32_t) (V.size() / 3);
         if (!has_nan) vmap.emplace(key, idx);
-        c->V.insert(c->V.end(), {p[0], p[1], p[2]});
-        c->C.insert(c->C.end(), {(double) v.c[0], (double) v.c[1], (double) v.c[2]});
+        V.insert(V.end(), {p[0], p[1], p[2]});
+        C.insert(C.end(), {(double) v.c[0], (double) v.c[1], (double) v.c[2]});
       }
       faces[i * 3 + k] = idx;
     }
@@ -303,8 +342,11 @@ void process_triangles(mrh_ctx* c) {
     const std::array<int32_t, 3> f = {faces[i * 3], faces[i * 3 + 1], faces[i * 3 + 2]};
     if (f[0] == f[1] || f[0] == f[2] || f[1] == f[2]) continue;
     if (!seen.emplace(f, 1).second) continue;
-    c->F.insert(c->F.end(), {f[0], f[1], f[2]});
+    F.insert(F.end(), {f[0], f[1], f[2]});
   }
+  c->V.assign(V.data(), V.data() + V.size());
+  c->C.assign(C.data(), C.data() + C.size());
+  c->F.assign(F.data(), F.data() + F.size());
 }
 
 // MeshExtractor::processTriangles on the device (mrh_mesh.h): fills V / C / F from a triangle soup in device memory.
@@ -366,7 +408,7 @@ int process_triangles_device(mrh_ctx* c, const mrh_triangle* d_tris, const size_
       MESH_TRY(hipMalloc((void**) &dF, nf * 3 * sizeof(int)));
       k_mesh_emit_faces<<<gf, 256, 0, s>>>(corner, keep, fpos, ntr, dF);
     }
-    c->V.resize(nv * 3); c->C.resize(nv * 3); c->F.resize(nf * 3);
+    c->V.resize_discard(nv * 3); c->C.resize_discard(nv * 3); c->F.resize_discard(nf * 3);
     MESH_TRY(hipMemcpyAsync(c->V.data(), dV, nv * 3 * sizeof(double), hipMemcpyDeviceToHost, s));
     MESH_TRY(hipMemcpyAsync(c->C.data(), dC, nv * 3 * sizeof(double), hipMemcpyDeviceToHost, s));
     if (nf) MESH_TRY(hipMemcpyAsync(c->F.data(), dF, nf * 3 * sizeof(int), hipMemcpyDeviceToHost, s));
@@ -1136,7 +1178,11 @@ int mrh_get_stats(mrh_ctx* c, mrh_stats* out) {
 int mrh_extract_triangles(mrh_ctx* c, const mrh_triangle** out_tris, uint64_t* out_n) {
   int rc = ensure_ready(c, "mrh_extract_triangles");
   if (rc) return rc;
-  if (!out_tris || !out_n) return MRH_ERR_INVALID_ARG;
+  if (!out_n) return MRH_ERR_INVALID_ARG;
+  // out_tris == NULL: the caller only wants the mesh (mrh_extract_mesh) — the soup stays on the device.  The host
+  // restatement of the post-process (MRH_MESH_HOST=1) reads the host copy, so it keeps it.
+  const bool want_soup = out_tris != nullptr || c->mesh_on_host;
+  uint64_t n_tris = 0;
   hipStream_t s = c->stream;
   const bool dbg = getenv("MRH_DEBUG") != nullptr;
   auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -1187,23 +1233,26 @@ int mrh_extract_triangles(mrh_ctx* c, const mrh_triangle** out_tris, uint64_t* o
       HIP_TRY(c, hipMemcpyAsync(d_offsets, offsets.data(), (size_t) n * sizeof(u64), hipMemcpyHostToDevice, s));
       k_mc<true><<<grid, 512, 0, s>>>(c->map, c->tab, c->tab.compact, n, d_counts, d_offsets, d_tris, total, d_per_voxel);
       if (dbg) { HIP_TRY(c, hipStreamSynchronize(s)); t3 = now(); }
-      c->tris.resize(total);
-      HIP_TRY(c, hipMemcpyAsync(c->tris.data(), d_tris, total * sizeof(mrh_triangle), hipMemcpyDeviceToHost, s));
+      if (want_soup) {
+        c->tris.resize_discard(total);
+        HIP_TRY(c, hipMemcpyAsync(c->tris.data(), d_tris, total * sizeof(mrh_triangle), hipMemcpyDeviceToHost, s));
+      }
       if (dbg) { HIP_TRY(c, hipStreamSynchronize(s)); t4 = now(); }
       int prc = MRH_OK;
       if (!c->mesh_on_host) { prc = process_triangles_device(c, d_tris, total); processed = true; }
       HIP_TRY(c, hipStreamSynchronize(s));
       if (prc) return prc;
+      n_tris = total;
     }
     HIP_TRY(c, hipGetLastError());
   }
-  c->last_triangles = c->tris.size();
+  c->last_triangles = n_tris;
   if (!processed) process_triangles(c);
   t5 = now();
-  if (dbg) fprintf(stderr, "[mrhash_hip] extract: %d blocks, %zu triangles | list+sort %.2f ms, count %.2f, emit %.2f, soup D2H %.2f, post-process + V/F/C D2H %.2f, total %.2f\n",
-                   n, c->tris.size(), t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4, t5 - t0);
-  *out_tris = c->tris.empty() ? nullptr : c->tris.data();
-  *out_n = c->tris.size();
+  if (dbg) fprintf(stderr, "[mrhash_hip] extract: %d blocks, %llu triangles | list+sort %.2f ms, count %.2f, emit %.2f, soup D2H %.2f, post-process + V/F/C D2H %.2f, total %.2f\n",
+                   n, (unsigned long long) n_tris, t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4, t5 - t0);
+  if (out_tris) *out_tris = c->tris.empty() ? nullptr : c->tris.data();
+  *out_n = n_tris;
   return MRH_OK;
 }
 

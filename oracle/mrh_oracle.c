@@ -1601,10 +1601,10 @@ int mrh_sync(mrh_ctx* c) {
 }
 
 int mrh_extract_triangles(mrh_ctx* c, const mrh_triangle** out, uint64_t* out_n) {
-  if (!c || !out || !out_n) return MRH_ERR_INVALID_ARG;
+  if (!c || !out_n) return MRH_ERR_INVALID_ARG; /* out == NULL: count + mesh only (include/mrhash_hip.h) */
   extract_iso_surface(c);
   process_triangles(c);
-  *out = c->tris;
+  if (out) *out = c->tris;
   *out_n = c->ntris;
   return (c->error_flags & 8u) ? fail(c, MRH_ERR_CAPACITY, "triangle buffer full") : MRH_OK;
 }

@@ -173,6 +173,11 @@ def test_mesh_postprocess_device_equals_host_and_oracle(hip, oracle, monkeypatch
         for a, b in zip(out[0][1:], other[1:]):
             assert a.shape == b.shape and a.tobytes() == b.tobytes()
     assert out[0][1].shape[0] < out[0][0].shape[0] * 3  # something merged
+    # the same mesh when the triangle soup stays on the device (out_triangles == NULL: what GeoWrapper.extractMesh does)
+    for e in (dev, host, orc):
+        assert e.extract_triangles(soup=False) == out[0][0].shape[0]
+        for a, b in zip(out[0][1:], e.extract_mesh()):
+            assert a.tobytes() == b.tobytes()
     for e in (dev, orc, host):
         e.close()
 

@@ -35,4 +35,6 @@ for label, v in (("single-res", 0.0), ("multi-res", var)):
     print(f"{label}: extract_triangles {1e3 * (t1 - t0):7.2f} ms ({tris.shape[0]} triangles)   get V,F,C {1e3 * (t2 - t1):7.2f} ms  V {V.shape[0]} F {F.shape[0]}")
     t0 = time.perf_counter(); tris = e.extract_triangles(); t1 = time.perf_counter()
     print(f"{label}: extract_triangles again {1e3 * (t1 - t0):7.2f} ms")
+    t0 = time.perf_counter(); nt = e.extract_triangles(soup=False); t1 = time.perf_counter()
+    print(f"{label}: extract without the soup read-back (GeoWrapper.extractMesh) {1e3 * (t1 - t0):7.2f} ms ({nt} triangles)")
     e.close()
