@@ -28,33 +28,32 @@ struct VoxSample {
 // global table per sample (72 samples per voxel that reaches all eight corners).
 constexpr u32 kNbAbsent = 0xFFFFFFFFu;
 struct Neigh {
-  const u32* vals;  // LDS [27], index (dz + 1) * 9 + (dy + 1) * 3 + (dx + 1); nullptr: no table (multi-resolution maps)
+  const u32* vals;  // LDS [27], index (dz + 1) * 9 + (dy + 1) * 3 + (dx + 1); nullptr: no table (lookups outside k_mc)
   i3 base;          // block position of the workgroup's block
   int shift_limit;  // Map::block_shift_limit
 };
+
+// table value of a block (kNbAbsent: not allocated): the workgroup's 27-block neighbourhood answers from LDS, anything
+// else through the hash table
+__device__ __forceinline__ u32 block_val(const Tab& t, const Neigh& nb, const i3 b) {
+  if (nb.vals) {
+    const int dx = b.x - nb.base.x, dy = b.y - nb.base.y, dz = b.z - nb.base.z;
+    if ((u32) (dx + 1) < 3u && (u32) (dy + 1) < 3u && (u32) (dz + 1) < 3u) return nb.vals[(dz + 1) * 9 + (dy + 1) * 3 + (dx + 1)];
+  }
+  u64 key;
+  if (!pack_key(b, key)) return kNbAbsent;
+  const int s = hash_find(t, key);
+  return s >= 0 ? t.vals[s] : kNbAbsent;
+}
 
 // vds.cu:163-205 getVoxel(int3[, block_res]); coarse blocks are read with the writers' dense index
 __device__ __forceinline__ VoxSample get_voxel_i(const Map& m, const Tab& t, const Neigh& nb, i3 v) {
   VoxSample r;
   r.sdf = 0.f; r.rgbw = 0; r.res = 0; r.found = false;
-  u32 val = kNbAbsent;
-  bool resolved = false;
-  if (nb.vals) {
-    const int ax = v.x < 0 ? -v.x : v.x, ay = v.y < 0 ? -v.y : v.y, az = v.z < 0 ? -v.z : v.z;
-    if ((u32) (ax | ay | az) < (u32) nb.shift_limit) {  // voxel -> block is the shift here (mrh_device.h)
-      const int dx = (v.x >> 3) - nb.base.x, dy = (v.y >> 3) - nb.base.y, dz = (v.z >> 3) - nb.base.z;
-      if ((u32) (dx + 1) < 3u && (u32) (dy + 1) < 3u && (u32) (dz + 1) < 3u) {
-        val = nb.vals[(dz + 1) * 9 + (dy + 1) * 3 + (dx + 1)];
-        resolved = true;
-      }
-    }
-  }
-  if (!resolved) {
-    u64 key;
-    if (!pack_key(voxel_to_block(v, m.vs), key)) return r;
-    const int s = hash_find(t, key);
-    if (s >= 0) val = t.vals[s];
-  }
+  const int ax = v.x < 0 ? -v.x : v.x, ay = v.y < 0 ? -v.y : v.y, az = v.z < 0 ? -v.z : v.z;
+  // voxel -> block is the shift below the limit (mrh_device.h)
+  const i3 b = (u32) (ax | ay | az) < (u32) nb.shift_limit ? mki3(v.x >> 3, v.y >> 3, v.z >> 3) : voxel_to_block(v, m.vs);
+  const u32 val = block_val(t, nb, b);
   if (val == kNbAbsent) return r;
   r.res = (val & kValCoarseBit) ? 1 : 0;
   r.found = true;
@@ -67,28 +66,21 @@ __device__ __forceinline__ VoxSample get_voxel_i(const Map& m, const Tab& t, con
 __device__ __forceinline__ VoxSample get_voxel_f(const Map& m, const Tab& t, const Neigh& nb, f3 pos) { return get_voxel_i(m, t, nb, world_to_voxel(m.vs, pos)); }
 
 // vds.cu:236-240 getVoxelSize(float3).  With a single resolution every block (and every miss) answers vs.
-__device__ __forceinline__ float get_voxel_size_f(const Map& m, const Tab& t, f3 pos) {
+__device__ __forceinline__ float get_voxel_size_f(const Map& m, const Tab& t, const Neigh& nb, f3 pos) {
   if (!t.multi_res) return m.vs * (float) (1 << 0);
-  u64 key;
-  int res = 0;
-  if (pack_key(world_to_block(m.vs, pos), key)) {
-    const int s = hash_find(t, key);
-    if (s >= 0) res = (t.vals[s] & kValCoarseBit) ? 1 : 0;
-  }
+  const u32 val = block_val(t, nb, world_to_block(m.vs, pos));
+  const int res = (val != kNbAbsent && (val & kValCoarseBit)) ? 1 : 0;
   return m.vs * (float) (1 << res);
 }
 
 // vds.cu:260-338
 __device__ __forceinline__ bool trilinear(const Map& m, const Tab& t, const Neigh& nb, f3 pos, float& dist) {
-  const float voxel_size = get_voxel_size_f(m, t, pos);
+  const float voxel_size = get_voxel_size_f(m, t, nb, pos);
   const f3 pos_dual = mk3(pos.x - voxel_size * 0.5f, pos.y - voxel_size * 0.5f, pos.z - voxel_size * 0.5f);
   int base_resolution = 0;
   if (t.multi_res) {
-    u64 key;
-    if (pack_key(world_to_block(voxel_size, pos), key)) {  // note: voxel_size, not vs (vds.cu:264)
-      const int s = hash_find(t, key);
-      if (s >= 0) base_resolution = (t.vals[s] & kValCoarseBit) ? 1 : 0;
-    }
+    const u32 val = block_val(t, nb, world_to_block(voxel_size, pos));  // note: voxel_size, not vs (vds.cu:264)
+    if (val != kNbAbsent) base_resolution = (val & kValCoarseBit) ? 1 : 0;
   }
   dist = 0.f;
   float pos_sdf = 0.f;
@@ -159,7 +151,7 @@ __device__ __forceinline__ mrh_vertex vertex_interp(f3 p1, f3 p2, float d1, floa
 // marching_cubes.cu:72-261 for one voxel.  Returns the triangle count; with EMIT writes them to out[0..n).
 template <bool EMIT>
 __device__ __forceinline__ int mc_voxel(const Map& m, const Tab& t, const Neigh& nb, f3 pf, mrh_triangle* out) {
-  const float vvs = get_voxel_size_f(m, t, pf);
+  const float vvs = get_voxel_size_f(m, t, nb, pf);
   const float P = vvs * 0.5f;
   const float M = -P;
   f3 sP = mk3(P * 1.f, P * 1.f, P * 1.f);
@@ -167,17 +159,17 @@ __device__ __forceinline__ int mc_voxel(const Map& m, const Tab& t, const Neigh&
   if (t.multi_res) {
     // marching_cubes.cu:7-69 checkVertexVoxels
     float vs;
-    vs = get_voxel_size_f(m, t, mk3(pf.x + sP.x, pf.y + 0.0f, pf.z + 0.0f));
+    vs = get_voxel_size_f(m, t, nb, mk3(pf.x + sP.x, pf.y + 0.0f, pf.z + 0.0f));
     if (vs > 0 && vs < 1 && vs != vvs) sP.x *= 0.499f;
-    vs = get_voxel_size_f(m, t, mk3(pf.x + sM.x, pf.y + 0.0f, pf.z + 0.0f));
+    vs = get_voxel_size_f(m, t, nb, mk3(pf.x + sM.x, pf.y + 0.0f, pf.z + 0.0f));
     if (vs > 0 && vs < 1 && vs != vvs) sM.x *= 0.499f;
-    vs = get_voxel_size_f(m, t, mk3(pf.x + 0.0f, pf.y + sP.y, pf.z + 0.0f));
+    vs = get_voxel_size_f(m, t, nb, mk3(pf.x + 0.0f, pf.y + sP.y, pf.z + 0.0f));
     if (vs > 0 && vs < 1 && vs != vvs) sP.y *= 0.499f;
-    vs = get_voxel_size_f(m, t, mk3(pf.x + 0.0f, pf.y + sM.y, pf.z + 0.0f));
+    vs = get_voxel_size_f(m, t, nb, mk3(pf.x + 0.0f, pf.y + sM.y, pf.z + 0.0f));
     if (vs > 0 && vs < 1 && vs != vvs) sM.y *= 0.499f;
-    vs = get_voxel_size_f(m, t, mk3(pf.x + 0.0f, pf.y + 0.0f, pf.z + sP.z));
+    vs = get_voxel_size_f(m, t, nb, mk3(pf.x + 0.0f, pf.y + 0.0f, pf.z + sP.z));
     if (vs > 0 && vs < 1 && vs != vvs) sP.z *= 0.499f;
-    vs = get_voxel_size_f(m, t, mk3(pf.x + 0.0f, pf.y + 0.0f, pf.z + sM.z));
+    vs = get_voxel_size_f(m, t, nb, mk3(pf.x + 0.0f, pf.y + 0.0f, pf.z + sM.z));
     if (vs > 0 && vs < 1 && vs != vvs) sM.z *= 0.499f;
   }
   f3 p[8];
@@ -244,7 +236,7 @@ __global__ __launch_bounds__(512) void k_mc(const Map m, const Tab t, const int4
     nb.vals = nullptr;
     nb.base = mki3(ent.x, ent.y, ent.z);
     nb.shift_limit = m.block_shift_limit;
-    if (!t.multi_res) {  // single resolution: resolve the 27 surrounding blocks once
+    {  // resolve the 27 surrounding blocks once
       if (v < 27) {
         const i3 b = mki3(ent.x + (v % 3) - 1, ent.y + ((v / 3) % 3) - 1, ent.z + (v / 9) - 1);
         u64 key;
