@@ -171,8 +171,12 @@ int mrh_upload_depth(mrh_ctx* ctx, const float* depth, int rows, int cols);
 /* Replaces rgb_img_.toDevice() (geowrapper.cpp:126): host uint8 [rows, cols, 3]. */
 int mrh_upload_rgb(mrh_ctx* ctx, const uint8_t* rgb, int rows, int cols);
 
-/* Zero-copy variants: the images already live in HBM (e.g. a resident frame queue). The
- * pointers are used by the next mrh_integrate and must stay valid until it has executed. */
+/* Both uploads return as soon as the image sits in pinned staging memory (the caller's buffer is free again); the
+ * host-to-device copy runs on a second stream into one of three device slots per image kind, so the copy of frame N+1
+ * overlaps the kernels of frame N.  mrh_integrate / mrh_splat_seeds order themselves after the newest upload.
+ *
+ * Zero-copy variants: the images already live in HBM (e.g. a resident frame queue). The
+ * pointers are used by the next mrh_integrate (and mrh_splat_seeds) and must stay valid until it has executed. */
 int mrh_set_depth_device(mrh_ctx* ctx, const float* d_depth, int rows, int cols);
 int mrh_set_rgb_device(mrh_ctx* ctx, const uint8_t* d_rgb, int rows, int cols);
 
@@ -268,6 +272,13 @@ int mrh_get_stats(mrh_ctx* ctx, mrh_stats* out);
 /* The two scalar read-backs of the per-frame streaming test (geowrapper.cpp:137: getHeapHighFreeCount() <=
  * stream_threshold * num_sdf_blocks) without the full statistics pass.  Blocks. */
 int mrh_get_free_blocks(mrh_ctx* ctx, int64_t* out_free_fine, int64_t* out_free_coarse);
+
+/* The same two numbers WITHOUT waiting for the device: from the first call on, every frame ends with a two-word copy
+ * of the free-list levels into pinned host memory; the call returns the newest report that has arrived and how many
+ * frames it is behind (0 = the last enqueued frame has already finished).  The very first call, and a call with no
+ * report in flight, answer through mrh_get_free_blocks.  Lets a host keep the reference's per-frame paging test
+ * (geowrapper.cpp:137) without serialising upload and compute on it. */
+int mrh_peek_free_blocks(mrh_ctx* ctx, int64_t* out_free_fine, int64_t* out_free_coarse, uint64_t* out_frames_behind);
 
 /* 1 = bracket the integrate kernel with HIP events and count updated voxels / inserted /
  * freed blocks on the device (used by bench.py for the roofline figures); 0 = off. */

@@ -99,7 +99,7 @@ ABI_SYMBOLS = (
     "mrh_create mrh_destroy mrh_reset mrh_last_error mrh_set_camera mrh_set_pose mrh_upload_depth "
     "mrh_upload_rgb mrh_set_depth_device mrh_set_rgb_device mrh_integrate mrh_integrate_resume mrh_exchange_buffer mrh_sync "
     "mrh_upload_points mrh_set_points_device mrh_integrate_points mrh_stream_out mrh_get_free_blocks "
-    "mrh_splat_seeds mrh_get_qtree_leaves "
+    "mrh_splat_seeds mrh_get_qtree_leaves mrh_peek_free_blocks "
     "mrh_extract_triangles mrh_extract_mesh mrh_get_stats mrh_set_profile mrh_dump_blocks "
     "mrh_get_voxel mrh_import_blocks mrh_get_triangle_blocks mrh_process_triangles mrh_selftest_division mrh_version"
 ).split()
@@ -129,6 +129,7 @@ def _declare(lib: C.CDLL) -> C.CDLL:
     lib.mrh_set_points_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
     lib.mrh_integrate_points.argtypes = [C.c_void_p, C.c_int]
     lib.mrh_get_free_blocks.argtypes = [C.c_void_p, P(C.c_int64), P(C.c_int64)]
+    lib.mrh_peek_free_blocks.argtypes = [C.c_void_p, P(C.c_int64), P(C.c_int64), P(C.c_uint64)]
     lib.mrh_stream_out.argtypes = [C.c_void_p, P(C.c_float), C.c_float, C.c_void_p, C.c_void_p, C.c_uint64, P(C.c_uint64)]
     lib.mrh_splat_seeds.argtypes = [C.c_void_p, C.c_float, C.c_int, P(C.c_void_p), P(C.c_uint64)]
     lib.mrh_get_qtree_leaves.argtypes = [C.c_void_p, P(C.c_void_p), P(C.c_uint64)]
@@ -379,6 +380,12 @@ class Engine:
         if n.value == 0:
             return np.zeros(0, LEAF_DTYPE)
         return np.frombuffer((C.c_char * (n.value * 16)).from_address(ptr.value), dtype=LEAF_DTYPE).copy()
+
+    def peek_free_blocks(self) -> Tuple[int, int, int]:
+        """(free fine, free coarse, frames behind) without waiting for the device (mrh_peek_free_blocks)."""
+        a, b, n = C.c_int64(), C.c_int64(), C.c_uint64()
+        self._check(self.lib.mrh_peek_free_blocks(self._ctx, C.byref(a), C.byref(b), C.byref(n)))
+        return a.value, b.value, n.value
 
     def stream_out(self, center, radius: float) -> Tuple[np.ndarray, np.ndarray]:
         """Streamer device half: blocks at distance >= radius from `center` (radius < 0: all) are copied out, ordered by

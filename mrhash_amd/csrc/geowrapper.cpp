@@ -109,16 +109,18 @@ void GeoWrapper::setCamera(float fx, float fy, float cx, float cy, int rows, int
   reach_ = (max_depth + trunc) * sec + 8.f * virtual_voxel_size_ * std::sqrt(3.f);
 }
 
+// The reference copies the image into its own host buffer here and uploads it in compute() (geowrapper.cpp:300-321,
+// :125-126).  Here the setter's copy IS the upload: mrh_upload_* copies into pinned staging (the numpy array is free on
+// return, as with the reference) and starts the host-to-device copy on a second stream right away, under the previous
+// frame's kernels; compute() only enqueues the frame.
 void GeoWrapper::setDepthImage(const float* data, size_t rows, size_t cols) {
-  depth_.assign(data, data + rows * cols);
-  depth_rows_ = rows;
-  depth_cols_ = cols;
+  check(mrh_upload_depth(ctx_, data, (int) rows, (int) cols), "setDepthImage");
+  have_depth_ = true;
 }
 
 void GeoWrapper::setRGBImage(const uint8_t* data, size_t rows, size_t cols) {
-  rgb_.assign(data, data + rows * cols * 3);
-  rgb_rows_ = rows;
-  rgb_cols_ = cols;
+  check(mrh_upload_rgb(ctx_, data, (int) rows, (int) cols), "setRGBImage");
+  have_rgb_ = true;
 }
 
 void GeoWrapper::setPointCloud(const float* pts, size_t n, const float* normals_or_null) {
@@ -206,16 +208,16 @@ void GeoWrapper::compute() {
   if (streaming_enabled_) {
     const std::array<float, 3> cam = {pose_[3], pose_[7], pose_[11]};
     if (!grid_.empty()) streamInFromGrid(&cam, reach_);  // host-only test unless a paged-out chunk is within reach
+    // geowrapper.cpp:137-138 reads the free count back every frame; here it is the newest level the device has reported
+    // (a frame or two old, no stall): paging is transparent in this library, so the trigger frame does not matter
     int64_t free_fine = 0;
-    check(mrh_get_free_blocks(ctx_, &free_fine, nullptr), "compute");  // geowrapper.cpp:137-138
+    check(mrh_peek_free_blocks(ctx_, &free_fine, nullptr, nullptr), "compute");
     if ((float) free_fine <= kStreamThreshold * (float) num_sdf_blocks_) stream(cam, reach_);
   }
   const float R[9] = {pose_[0], pose_[1], pose_[2], pose_[4], pose_[5], pose_[6], pose_[8], pose_[9], pose_[10]};
   const float t[3] = {pose_[3], pose_[7], pose_[11]};
   check(mrh_set_pose(ctx_, R, t), "compute");
-  if (!depth_.empty() && !rgb_.empty()) {  // geowrapper.cpp:140
-    check(mrh_upload_depth(ctx_, depth_.data(), (int) depth_rows_, (int) depth_cols_), "compute");
-    check(mrh_upload_rgb(ctx_, rgb_.data(), (int) rgb_rows_, (int) rgb_cols_), "compute");
+  if (have_depth_ && have_rgb_) {  // geowrapper.cpp:140
     check(mrh_integrate(ctx_, n_frames_invalidate_voxels_), "compute");
     if (gs_enabled_) {  // geowrapper.cpp:142-143 runGS -> extractNodesQTree + checkNodes; Add_gaussians keeps what they emit
       const mrh_splat_seed* seeds = nullptr;

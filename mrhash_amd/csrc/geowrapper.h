@@ -114,7 +114,7 @@ private:
   float sdf_var_threshold_, vertices_merging_threshold_;
   std::array<float, 16> pose_;
   std::array<float, 16> camera_in_lidar_;
-  std::vector<float> depth_;
+  bool have_depth_ = false, have_rgb_ = false;  // the images themselves live in the library (pinned staging + device slots)
   std::vector<uint8_t> rgb_;
   size_t depth_rows_ = 0, depth_cols_ = 0, rgb_rows_ = 0, rgb_cols_ = 0;
   std::vector<float> point_cloud_, normals_;

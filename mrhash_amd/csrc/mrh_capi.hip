@@ -38,6 +38,19 @@ struct EvPair {
   hipEvent_t a, b;
 };
 
+struct UpSlot {
+  void* h = nullptr;            // pinned staging
+  void* d = nullptr;            // device image
+  size_t cap = 0;
+  hipEvent_t copied = nullptr;  // H2D out of `h` done (copy stream)
+  bool copied_rec = false;
+  uint64_t last_seq = 0;        // newest frame_done mark of a frame that read `d` (0: none)
+};
+struct UpRing {
+  UpSlot s[3];
+  int cur = -1;                 // slot holding the current image; -1: none, or a caller's device pointer
+};
+
 // Host result buffer of the blocking calls (triangle soup, V / F / C): grow-only, never zero-filled, 2 MiB-aligned
 // and advised to transparent huge pages.  A device-to-host copy into resident pages runs at link speed on this
 // platform (tools/micro/d2h_paths.hip: 128 MB in 2.4 ms) — what costs is the first touch of fresh 4 KiB pages (+8 ms) and
@@ -85,10 +98,18 @@ struct mrh_ctx {
   Tab tab;
   bool has_camera = false;
   bool spherical = false;
-  // images
-  float* d_depth_own = nullptr;
-  uint8_t* d_rgb_own = nullptr;
-  size_t depth_cap = 0, rgb_cap = 0;
+  // images.  Host uploads (mrh_upload_depth / _rgb) go through a ring of three slots per image kind — pinned staging +
+  // device buffer — on a second stream, so the copy of frame N+1 overlaps the kernels of frame N; the frame's kernels
+  // wait for the newest copy event, a slot is rewritten only after the last frame that read it (frame_done event).
+  UpRing up_depth, up_rgb;
+  hipStream_t copy_stream = nullptr;
+  hipEvent_t last_copy = nullptr;      // newest copy event the main stream has not waited for yet
+  hipEvent_t frame_done[8] = {};       // recorded on the main stream after every frame that read ring slots / when peeks are on
+  uint64_t frame_seq = 1;
+  // pool level for the host without a read-back stall (mrh_peek_free_blocks): a 2-int D2H per frame into pinned memory
+  int* h_peek = nullptr;               // [8][2], pinned
+  uint64_t peek_seq[8] = {};
+  bool peek_enabled = false;
   const float* d_depth = nullptr;
   const uint8_t* d_rgb = nullptr;
   int depth_rows = 0, depth_cols = 0, rgb_rows = 0, rgb_cols = 0;
@@ -204,7 +225,16 @@ void free_all(mrh_ctx* c) {
   F(c->dc_buf); F(c->rgbx_buf);
   F(c->tab.keys); F(c->tab.vals); F(c->tab.heap_fine); F(c->tab.heap_coarse); F(c->tab.desc_fine); F(c->tab.desc_coarse);
   F(c->tab.pool); F(c->tab.compact); F(c->tab.ctr); F(c->tab.prof);
-  F(c->d_depth_own); F(c->d_rgb_own); F(c->d_decision); F(c->d_zbuf); F(c->d_realloc); F(c->d_reint); F(c->d_flag);
+  for (UpRing* r : {&c->up_depth, &c->up_rgb})
+    for (UpSlot& u : r->s) {
+      if (u.h) (void) hipHostFree(u.h);
+      F(u.d);
+      if (u.copied) (void) hipEventDestroy(u.copied);
+    }
+  for (hipEvent_t e : c->frame_done) if (e) (void) hipEventDestroy(e);
+  if (c->h_peek) (void) hipHostFree(c->h_peek);
+  if (c->copy_stream) { (void) hipStreamSynchronize(c->copy_stream); (void) hipStreamDestroy(c->copy_stream); }
+  F(c->d_decision); F(c->d_zbuf); F(c->d_realloc); F(c->d_reint); F(c->d_flag);
   F(c->d_upd_partials); F(c->d_misc); F(c->d_cfree); F(c->d_zmin); F(c->d_points); F(c->d_pt_counts); F(c->d_pt_offsets); F(c->d_rec_keys[0]); F(c->d_rec_keys[1]); F(c->d_rec_vals[0]); F(c->d_rec_vals[1]); F(c->d_sort_tmp); F(c->fast.summary); F(c->fast.summary_c); F(c->fast.bbox); F(c->d_cnt_partials);
   F(c->d_qt_sums); F(c->d_qt_flags); F(c->d_qt_unc); F(c->d_qt_marks); F(c->d_qt_pos); F(c->d_qt_parked); F(c->d_qt_seeds); F(c->d_qt_leaves); F(c->d_qt_misc); F(c->d_qt_tmp);
   for (auto& e : c->ev_pool) { (void) hipEventDestroy(e.a); (void) hipEventDestroy(e.b); }
@@ -701,20 +731,76 @@ int mrh_set_pose(mrh_ctx* c, const float R[9], const float t[3]) {
   return MRH_OK;
 }
 
+namespace {
+
+// one host image into the next slot of its ring: wait until the slot is free, copy into pinned staging (the caller's
+// buffer is free on return), enqueue the H2D on the copy stream
+int upload_image(mrh_ctx* c, UpRing& ring, const void* src, const size_t bytes, const void** out_dev) {
+  if (!c->copy_stream) {
+    HIP_TRY(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    for (hipEvent_t& e : c->frame_done) HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
+  const int next = (ring.cur + 1) % 3;
+  UpSlot& u = ring.s[next];
+  if (u.last_seq) HIP_TRY(c, hipEventSynchronize(c->frame_done[u.last_seq % 8]));  // this mark or a later one of the same stream
+  if (u.copied_rec) HIP_TRY(c, hipEventSynchronize(u.copied));
+  if (bytes > u.cap) {
+    if (u.h) HIP_TRY(c, hipHostFree(u.h));
+    if (u.d) HIP_TRY(c, hipFree(u.d));
+    u.h = u.d = nullptr; u.cap = 0;
+    HIP_TRY(c, hipHostMalloc(&u.h, bytes, hipHostMallocDefault));
+    HIP_TRY(c, hipMalloc(&u.d, bytes));
+    u.cap = bytes;
+    if (!u.copied) HIP_TRY(c, hipEventCreateWithFlags(&u.copied, hipEventDisableTiming));
+  }
+  memcpy(u.h, src, bytes);
+  HIP_TRY(c, hipMemcpyAsync(u.d, u.h, bytes, hipMemcpyHostToDevice, c->copy_stream));
+  HIP_TRY(c, hipEventRecord(u.copied, c->copy_stream));
+  u.copied_rec = true;
+  u.last_seq = 0;
+  c->last_copy = u.copied;  // copies are ordered on one stream: the newest event covers the earlier ones
+  ring.cur = next;
+  *out_dev = u.d;
+  return MRH_OK;
+}
+
+// before kernels that read the images: the main stream waits for the newest upload
+int wait_inputs(mrh_ctx* c) {
+  if (c->last_copy) {
+    HIP_TRY(c, hipStreamWaitEvent(c->stream, c->last_copy, 0));
+    c->last_copy = nullptr;
+  }
+  return MRH_OK;
+}
+
+// after the kernels of a frame (or of a seeding call) are enqueued: mark the ring slots they read, report the pool level
+int mark_frame(mrh_ctx* c) {
+  UpSlot* used[2] = {nullptr, nullptr};
+  if (c->up_depth.cur >= 0 && c->d_depth == c->up_depth.s[c->up_depth.cur].d) used[0] = &c->up_depth.s[c->up_depth.cur];
+  if (c->up_rgb.cur >= 0 && c->d_rgb == c->up_rgb.s[c->up_rgb.cur].d) used[1] = &c->up_rgb.s[c->up_rgb.cur];
+  if (!used[0] && !used[1] && !c->peek_enabled) return MRH_OK;
+  const uint64_t seq = c->frame_seq++;
+  if (c->peek_enabled) {
+    HIP_TRY(c, hipMemcpyAsync(c->h_peek + 2 * (seq % 8), &c->tab.ctr[CTR_HEAP_FINE], 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    c->peek_seq[seq % 8] = seq;
+  }
+  if (!c->frame_done[0])
+    for (hipEvent_t& e : c->frame_done) HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  HIP_TRY(c, hipEventRecord(c->frame_done[seq % 8], c->stream));
+  for (UpSlot* u : used) if (u) u->last_seq = seq;
+  return MRH_OK;
+}
+
+}  // namespace
+
 int mrh_upload_depth(mrh_ctx* c, const float* depth, int rows, int cols) {
   int rc = ensure_ready(c, "mrh_upload_depth");
   if (rc) return rc;
   if (!depth || rows <= 0 || cols <= 0) return fail(c, MRH_ERR_INVALID_ARG, "mrh_upload_depth: bad argument");
-  const size_t bytes = (size_t) rows * cols * sizeof(float);
-  if (bytes > c->depth_cap) {
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (c->d_depth_own) HIP_TRY(c, hipFree(c->d_depth_own));
-    c->d_depth_own = nullptr;
-    HIP_TRY(c, hipMalloc((void**) &c->d_depth_own, bytes));
-    c->depth_cap = bytes;
-  }
-  HIP_TRY(c, hipMemcpyAsync(c->d_depth_own, depth, bytes, hipMemcpyHostToDevice, c->stream));
-  c->d_depth = c->d_depth_own;
+  const void* dev = nullptr;
+  rc = upload_image(c, c->up_depth, depth, (size_t) rows * cols * sizeof(float), &dev);
+  if (rc) return rc;
+  c->d_depth = (const float*) dev;
   c->depth_rows = rows; c->depth_cols = cols;
   return MRH_OK;
 }
@@ -723,16 +809,10 @@ int mrh_upload_rgb(mrh_ctx* c, const uint8_t* rgb, int rows, int cols) {
   int rc = ensure_ready(c, "mrh_upload_rgb");
   if (rc) return rc;
   if (!rgb || rows <= 0 || cols <= 0) return fail(c, MRH_ERR_INVALID_ARG, "mrh_upload_rgb: bad argument");
-  const size_t bytes = (size_t) rows * cols * 3;
-  if (bytes > c->rgb_cap) {
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (c->d_rgb_own) HIP_TRY(c, hipFree(c->d_rgb_own));
-    c->d_rgb_own = nullptr;
-    HIP_TRY(c, hipMalloc((void**) &c->d_rgb_own, bytes));
-    c->rgb_cap = bytes;
-  }
-  HIP_TRY(c, hipMemcpyAsync(c->d_rgb_own, rgb, bytes, hipMemcpyHostToDevice, c->stream));
-  c->d_rgb = c->d_rgb_own;
+  const void* dev = nullptr;
+  rc = upload_image(c, c->up_rgb, rgb, (size_t) rows * cols * 3, &dev);
+  if (rc) return rc;
+  c->d_rgb = (const uint8_t*) dev;
   c->rgb_rows = rows; c->rgb_cols = cols;
   return MRH_OK;
 }
@@ -740,19 +820,33 @@ int mrh_upload_rgb(mrh_ctx* c, const uint8_t* rgb, int rows, int cols) {
 int mrh_set_depth_device(mrh_ctx* c, const float* d_depth, int rows, int cols) {
   if (!c || !d_depth || rows <= 0 || cols <= 0) return fail(c, MRH_ERR_INVALID_ARG, "mrh_set_depth_device: bad argument");
   c->d_depth = d_depth; c->depth_rows = rows; c->depth_cols = cols;
+  c->up_depth.cur = -1;
   return MRH_OK;
 }
 
 int mrh_set_rgb_device(mrh_ctx* c, const uint8_t* d_rgb, int rows, int cols) {
   if (!c || !d_rgb || rows <= 0 || cols <= 0) return fail(c, MRH_ERR_INVALID_ARG, "mrh_set_rgb_device: bad argument");
   c->d_rgb = d_rgb; c->rgb_rows = rows; c->rgb_cols = cols;
+  c->up_rgb.cur = -1;
   return MRH_OK;
 }
 
 // voxel_data_structures.cpp:90-110 VoxelContainer::integrate, as one sync-free kernel chain
+static int integrate_frame(mrh_ctx* c, int n_frames_invalidate);
+
 int mrh_integrate(mrh_ctx* c, int n_frames_invalidate) {
   int rc = ensure_ready(c, "mrh_integrate");
   if (rc) return rc;
+  rc = wait_inputs(c);
+  if (rc) return rc;
+  rc = integrate_frame(c, n_frames_invalidate);
+  if (rc < 0) return rc;
+  const int mrc = mark_frame(c);
+  return mrc ? mrc : rc;
+}
+
+static int integrate_frame(mrh_ctx* c, int n_frames_invalidate) {
+  int rc = MRH_OK;
   if (c->pending) return fail(c, MRH_ERR_STATE, "mrh_integrate: an exchange is pending (call mrh_integrate_resume)");
   if (!c->has_camera) return fail(c, MRH_ERR_STATE, "mrh_integrate: set_camera has not been called");
   if (c->spherical) return fail(c, MRH_ERR_UNSUPPORTED, "mrh_integrate: spherical (LiDAR) camera model is outside this round's scope");
@@ -986,7 +1080,7 @@ int mrh_integrate_points(mrh_ctx* c, int n_frames_invalidate) {
   }
   c->frames++;
   HIP_TRY(c, hipGetLastError());
-  return MRH_OK;
+  return c->peek_enabled ? mark_frame(c) : MRH_OK;  // pool-level report for mrh_peek_free_blocks
 }
 
 int mrh_integrate_resume(mrh_ctx* c) {
@@ -1001,7 +1095,10 @@ int mrh_integrate_resume(mrh_ctx* c) {
   if (c->pending == 2) {
     launch_starve(c, 2);
     c->pending = 0;
-    return frame_tail(c, true, c->pending_max_frames);
+    rc = frame_tail(c, true, c->pending_max_frames);
+    if (rc < 0) return rc;
+    const int mrc = mark_frame(c);  // the tail's kernels read the frame's images too
+    return mrc ? mrc : rc;
   }
   return fail(c, MRH_ERR_STATE, "mrh_integrate_resume: no exchange is pending");
 }
@@ -1071,6 +1168,8 @@ int mrh_splat_seeds(mrh_ctx* c, float qtree_thresh, int qtree_min_pixel_size, co
     }
   }
   c->qt = qt;
+  rc = wait_inputs(c);
+  if (rc) return rc;
   const u32 grid = (qt.total + 255) / 256;
   u32* unc_count = (u32*) (c->d_qt_misc + 1);
   HIP_TRY(c, hipMemsetAsync(c->d_qt_misc, 0, 2 * sizeof(u64), s));
@@ -1087,6 +1186,8 @@ int mrh_splat_seeds(mrh_ctx* c, float qtree_thresh, int qtree_min_pixel_size, co
   size_t tb = c->qt_tmp_bytes;
   HIP_TRY(c, rocprim::exclusive_scan(c->d_qt_tmp, tb, c->d_qt_marks, c->d_qt_pos, (u64) 0, (size_t) qt.total, rocprim::plus<u64>(), s));
   k_qt_scatter<<<grid, 256, 0, s>>>(qt, c->d_qt_marks, c->d_qt_pos, c->d_qt_parked, c->d_qt_leaves, c->d_qt_seeds, c->d_qt_misc);
+  rc = mark_frame(c);
+  if (rc) return rc;
   u64 h_misc[2] = {0, 0};
   HIP_TRY(c, hipMemcpyAsync(h_misc, c->d_qt_misc, sizeof h_misc, hipMemcpyDeviceToHost, s));
   HIP_TRY(c, hipStreamSynchronize(s));
@@ -1123,6 +1224,29 @@ int mrh_get_free_blocks(mrh_ctx* c, int64_t* out_free_fine, int64_t* out_free_co
   if (out_free_fine) *out_free_fine = (int64_t) h[0] + 1;
   if (out_free_coarse) *out_free_coarse = (int64_t) h[1] + 1;
   return MRH_OK;
+}
+
+int mrh_peek_free_blocks(mrh_ctx* c, int64_t* out_free_fine, int64_t* out_free_coarse, uint64_t* out_frames_behind) {
+  int rc = ensure_ready(c, "mrh_peek_free_blocks");
+  if (rc) return rc;
+  if (!c->peek_enabled) {  // first call: reports start with the next frame; answer this one the blocking way
+    HIP_TRY(c, hipHostMalloc((void**) &c->h_peek, 16 * sizeof(int), hipHostMallocDefault));
+    c->peek_enabled = true;
+  }
+  for (uint64_t back = 1; back <= 8 && back < c->frame_seq; back++) {
+    const uint64_t seq = c->frame_seq - back;
+    if (c->peek_seq[seq % 8] != seq) continue;
+    const hipError_t q = hipEventQuery(c->frame_done[seq % 8]);
+    if (q == hipErrorNotReady) continue;
+    if (q != hipSuccess) return fail(c, MRH_ERR_DEVICE, "mrh_peek_free_blocks: %s", hipGetErrorString(q));
+    if (c->peek_seq[seq % 8] != seq) continue;
+    if (out_free_fine) *out_free_fine = (int64_t) c->h_peek[2 * (seq % 8)] + 1;
+    if (out_free_coarse) *out_free_coarse = (int64_t) c->h_peek[2 * (seq % 8) + 1] + 1;
+    if (out_frames_behind) *out_frames_behind = back - 1;
+    return MRH_OK;
+  }
+  if (out_frames_behind) *out_frames_behind = 0;
+  return mrh_get_free_blocks(c, out_free_fine, out_free_coarse);
 }
 
 int mrh_set_profile(mrh_ctx* c, int enabled) {

@@ -1832,6 +1832,11 @@ int mrh_get_qtree_leaves(mrh_ctx* c, const mrh_qtree_leaf** out, uint64_t* out_n
   return MRH_OK;
 }
 
+int mrh_peek_free_blocks(mrh_ctx* c, int64_t* out_free_fine, int64_t* out_free_coarse, uint64_t* out_frames_behind) {
+  if (out_frames_behind) *out_frames_behind = 0; /* the oracle is synchronous */
+  return mrh_get_free_blocks(c, out_free_fine, out_free_coarse);
+}
+
 int mrh_get_voxel(mrh_ctx* c, int32_t vx, int32_t vy, int32_t vz, mrh_voxel* out, int* found) {
   if (!c || !out) return MRH_ERR_INVALID_ARG;
   i3 v = {vx, vy, vz};
