@@ -523,3 +523,39 @@ def test_plain_c_program_drives_the_abi(hip, tmp_path):
     case = json.load(open(os.path.join(GOLDEN, "cfg1_golden.json")))["cases"]["plane_1frame"]
     assert (got["blocks"], got["weighted_voxels"], got["triangles"], got["faces"]) == (case["blocks"], case["weighted_voxels"], case["triangles"], case["faces"])
     assert got["free_fine"] == 16384 - case["blocks"]
+
+
+def test_upload_ring_semantics(hip, oracle):
+    """Host uploads go through three-slot rings on a copy stream: an image uploaded once stays current over several
+    frames, an upload that is overwritten before any frame used it is harmless, caller-owned device pointers and uploads
+    mix, and a burst of frames without any synchronisation reuses slots only after the frame that read them."""
+    K = synth.CFG1
+    a = pu.make_engine(hip, K, synth.CFG1_PARAMS, 16384)
+    b = pu.make_engine(oracle, K, synth.CFG1_PARAMS, 16384)
+    f0, f1, f2 = synth.cfg1_sphere(), synth.cfg1_sphere(zc=1.52), synth.cfg1_plane(z=1.1)
+    rng = np.random.default_rng(3)
+    junk = rng.integers(0, 256, f0.rgb.shape, dtype=np.uint8)
+    for e in (a, b):
+        e.set_pose(f0.R, f0.t)
+        e.upload_depth(f0.depth); e.upload_rgb(f0.rgb); assert not e.integrate()
+        e.upload_depth(f1.depth); assert not e.integrate()          # colour image of f0 stays current
+        e.upload_rgb(junk); e.upload_rgb(f2.rgb); e.upload_rgb(junk); e.upload_rgb(f2.rgb)  # ring wraps before any frame
+        e.upload_depth(f2.depth); assert not e.integrate()
+        assert not e.integrate()                                     # the same images again
+    pu.compare_maps(a, b)
+    # burst: 24 frames back to back, alternating images, no sync in between
+    seq = [f0, f1, f2] * 8
+    for f in seq:
+        pu.feed(a, f)
+    for f in seq:
+        pu.feed(b, f)
+    pu.compare_maps(a, b)
+    # pool level without a stall: after a sync the newest report is the exact level
+    a.peek_free_blocks()
+    pu.feed(a, f0); pu.feed(b, f0)
+    a.sync()
+    fine, coarse, behind = a.peek_free_blocks()
+    assert behind == 0 and (fine, coarse) == a.free_blocks() == b.free_blocks()
+    pu.compare_maps(a, b)
+    a.close()
+    b.close()
