@@ -70,7 +70,7 @@ def build_pybind(force: bool = False, verbose: bool = True) -> str:
     if not force and _newer(out, srcs):
         return out
     cmd = [
-        "g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fvisibility=hidden",
+        "g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-ffp-contract=off", "-fvisibility=hidden",
         "-I", pybind11.get_include(), "-I", sysconfig.get_paths()["include"], "-I", os.path.join(ROOT, "include"),
         os.path.join(CSRC, "geowrapper.cpp"), os.path.join(CSRC, "pygeowrapper.cpp"),
         "-o", out, "-L", CSRC, "-lmrhash_hip", "-Wl,-rpath,$ORIGIN/csrc",

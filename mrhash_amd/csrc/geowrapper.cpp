@@ -9,7 +9,10 @@
 #include <cstring>
 #include <fstream>
 #include <iostream>
+#include <charconv>
+#include <memory>
 #include <stdexcept>
+#include <thread>
 
 namespace pygeowrapper {
 
@@ -249,8 +252,11 @@ void GeoWrapper::extractMesh(const std::string& filename) {
   C_.assign(c, c + nv * 3);
   F_.assign(f, f + nf * 3);
 
-  // ASCII PLY, same header and value formatting as geowrapper.cpp:194-227
-  std::ofstream ply(filename);
+  // ASCII PLY, same header and value formatting as geowrapper.cpp:194-227.  The reference streams every number through
+  // an ofstream (`<<` on a double is printf's %g with precision 6); std::to_chars(general, 6) is defined to produce the
+  // same characters, so the rows are formatted in parallel chunks and written in order: byte-identical file, a
+  // fraction of the 0.9 s the iostream loop takes for a million triangles.
+  std::ofstream ply(filename, std::ios::binary);
   if (!ply.is_open()) {
     std::cerr << "GeoWrapper::extractMesh | Failed to open file for writing: " << filename << std::endl;
     return;
@@ -258,12 +264,43 @@ void GeoWrapper::extractMesh(const std::string& filename) {
   ply << "ply\nformat ascii 1.0\nelement vertex " << nv << "\nproperty float x\nproperty float y\nproperty float z\n"
       << "property uchar red\nproperty uchar green\nproperty uchar blue\nelement face " << nf
       << "\nproperty list uchar int vertex_indices\nend_header\n";
-  for (uint64_t i = 0; i < nv; ++i) {
-    const unsigned char col[3] = {(unsigned char) (C_[i * 3]), (unsigned char) (C_[i * 3 + 1]), (unsigned char) (C_[i * 3 + 2])};
-    ply << V_[i * 3] << " " << V_[i * 3 + 1] << " " << V_[i * 3 + 2] << " " << static_cast<int>(col[0]) << " " << static_cast<int>(col[1]) << " "
-        << static_cast<int>(col[2]) << "\n";
+  const unsigned n_workers = (unsigned) std::min<uint64_t>(std::max(1u, std::min(32u, std::thread::hardware_concurrency())), (nv + nf) / 65536 + 1);
+  struct Chunk { std::unique_ptr<char[]> buf; size_t len = 0; };
+  std::vector<Chunk> chunks(2 * (size_t) n_workers);
+  auto format_chunk = [&](unsigned k) {
+    auto put_d = [](char* p, double v) { return std::to_chars(p, p + 32, v, std::chars_format::general, 6).ptr; };
+    auto put_i = [](char* p, int v) { return std::to_chars(p, p + 16, v).ptr; };
+    {
+      const uint64_t lo = nv * k / n_workers, hi = nv * (k + 1) / n_workers;
+      Chunk& c = chunks[k];
+      c.buf.reset(new char[(hi - lo) * 64 + 1]);  // 3 x <= 13 chars + 3 x <= 3 chars + separators
+      char* p = c.buf.get();
+      for (uint64_t i = lo; i < hi; ++i) {
+        for (int a = 0; a < 3; a++) { p = put_d(p, V_[i * 3 + a]); *p++ = ' '; }
+        for (int a = 0; a < 3; a++) { p = put_i(p, (int) (unsigned char) (C_[i * 3 + a])); *p++ = a == 2 ? '\n' : ' '; }
+      }
+      c.len = (size_t) (p - c.buf.get());
+    }
+    {
+      const uint64_t lo = nf * k / n_workers, hi = nf * (k + 1) / n_workers;
+      Chunk& c = chunks[n_workers + k];
+      c.buf.reset(new char[(hi - lo) * 40 + 1]);  // "3" + 3 x (space + <= 11 chars) + newline
+      char* p = c.buf.get();
+      for (uint64_t i = lo; i < hi; ++i) {
+        *p++ = '3';
+        for (int a = 0; a < 3; a++) { *p++ = ' '; p = put_i(p, F_[i * 3 + a]); }
+        *p++ = '\n';
+      }
+      c.len = (size_t) (p - c.buf.get());
+    }
+  };
+  if (n_workers == 1) format_chunk(0);
+  else {
+    std::vector<std::thread> workers;
+    for (unsigned k = 0; k < n_workers; k++) workers.emplace_back(format_chunk, k);
+    for (std::thread& w : workers) w.join();
   }
-  for (uint64_t i = 0; i < nf; ++i) ply << "3 " << F_[i * 3] << " " << F_[i * 3 + 1] << " " << F_[i * 3 + 2] << "\n";
+  for (const Chunk& c : chunks) ply.write(c.buf.get(), (std::streamsize) c.len);
   ply.close();
   std::cout << "GeoWrapper::extractMesh | written " << nv << " vertices and " << nf << " faces to " << filename << std::endl;
 }

@@ -58,6 +58,10 @@ def test_runner_call_sequence_matches_oracle(geowrapper_cls, oracle, tmp_path):
     first = txt[hdr_end + 1].split()
     assert len(first) == 6 and abs(float(first[0]) - V[0, 0]) < 1e-4
     assert txt[hdr_end + 1 + len(V)].split() == ["3"] + [str(int(x)) for x in F[0]]
+    # every row as the reference's ofstream prints it: doubles through %g (precision 6), colours as (unsigned char) ints
+    want = ["%g %g %g %d %d %d" % (v[0], v[1], v[2], int(c[0]) & 255, int(c[1]) & 255, int(c[2]) & 255) for v, c in zip(V, C)]
+    want += ["3 %d %d %d" % tuple(f) for f in F]
+    assert txt[hdr_end + 1:] == want
     P = g.getCurrPose()
     assert P.shape == (4, 4) and np.allclose(P[:3, :3], frames[-1].R) and np.allclose(P[:3, 3], frames[-1].t)
 

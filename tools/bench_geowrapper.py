@@ -41,3 +41,7 @@ dt = time.perf_counter() - t0
 m = n - 20
 print(f"GeoWrapper: {m / dt:.0f} frames/s ({1e6 * dt / m:.1f} us/frame); setCurrPose {1e6 * parts[0] / m:.1f}  setDepthImage {1e6 * parts[1] / m:.1f}"
       f"  setRGBImage {1e6 * parts[2] / m:.1f}  compute {1e6 * parts[3] / m:.1f} us")
+t0 = time.perf_counter()
+g.extractMesh("/tmp/mrh_bench_mesh.ply")
+dt = time.perf_counter() - t0
+print(f"GeoWrapper.extractMesh: {1e3 * dt:.1f} ms for {len(g.getFaces())} faces ({os.path.getsize('/tmp/mrh_bench_mesh.ply') / 1e6:.1f} MB ASCII PLY)")
