@@ -1062,17 +1062,22 @@ int mrh_integrate_points(mrh_ctx* c, int n_frames_invalidate) {
         }
         c->rec_cap = cap;
       }
-      // sort key = voxel id above the point index; only the bits that can be set take part in the radix passes
+      // sort key = voxel id above the point index.  The records are emitted in (point, step) order and an LSD radix sort is
+      // stable, so sorting on the voxel bits alone already leaves every voxel's run in ascending point index (D6): the
+      // point bits stay in the key for k_points_apply but take no part in the passes
+      // rocPRIM sorts up to 2^20 items with block sort + log2(n / block) merge passes (10 x 2 launches for one scan's
+      // ~650 k records); with ~21 significant bits the onesweep radix path is 1 histogram + 3 passes
+      using LidarSortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 0>;
       auto bits_for = [](uint64_t max_value) { int b = 1; while (b < 63 && (max_value >> b)) b++; return b; };
       const int pbits = bits_for(n - 1);
       const int end_bit = pbits + bits_for((uint64_t) (hwm > 0 ? hwm : 1) * 512 - 1);
       k_points_walk<true><<<grid, 256, 0, s>>>(k, m, t, pts, np, nullptr, c->d_pt_offsets, c->d_rec_keys[0], c->d_rec_vals[0], pbits);
       need = 0;
-      HIP_TRY(c, rocprim::radix_sort_pairs(nullptr, need, c->d_rec_keys[0], c->d_rec_keys[1], c->d_rec_vals[0], c->d_rec_vals[1], n_rec, 0, end_bit, s));
+      HIP_TRY(c, rocprim::radix_sort_pairs<LidarSortConfig>(nullptr, need, c->d_rec_keys[0], c->d_rec_keys[1], c->d_rec_vals[0], c->d_rec_vals[1], n_rec, pbits, end_bit, s));
       rc = ensure_tmp(need);
       if (rc) return rc;
       tb = c->sort_tmp_bytes;
-      HIP_TRY(c, rocprim::radix_sort_pairs(c->d_sort_tmp, tb, c->d_rec_keys[0], c->d_rec_keys[1], c->d_rec_vals[0], c->d_rec_vals[1], n_rec, 0, end_bit, s));
+      HIP_TRY(c, rocprim::radix_sort_pairs<LidarSortConfig>(c->d_sort_tmp, tb, c->d_rec_keys[0], c->d_rec_keys[1], c->d_rec_vals[0], c->d_rec_vals[1], n_rec, pbits, end_bit, s));
       k_points_apply<<<(u32) ((n_rec + 255) / 256), 256, 0, s>>>(m, t, c->d_rec_keys[1], c->d_rec_vals[1], (u32) n_rec, pbits);
     }
     // the GC summaries (used by later depth frames for blocks outside the image) follow the payload
