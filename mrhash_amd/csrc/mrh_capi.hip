@@ -220,6 +220,7 @@ uint64_t next_pow2(uint64_t v) {
 void free_all(mrh_ctx* c) {
   if (!c) return;
   (void) hipSetDevice(c->device);
+  if (c->copy_stream) { (void) hipStreamSynchronize(c->copy_stream); (void) hipStreamDestroy(c->copy_stream); }
   if (c->stream) (void) hipStreamSynchronize(c->stream);
   auto F = [](void* p) { if (p) (void) hipFree(p); };
   F(c->dc_buf); F(c->rgbx_buf);
@@ -233,7 +234,6 @@ void free_all(mrh_ctx* c) {
     }
   for (hipEvent_t e : c->frame_done) if (e) (void) hipEventDestroy(e);
   if (c->h_peek) (void) hipHostFree(c->h_peek);
-  if (c->copy_stream) { (void) hipStreamSynchronize(c->copy_stream); (void) hipStreamDestroy(c->copy_stream); }
   F(c->d_decision); F(c->d_zbuf); F(c->d_realloc); F(c->d_reint); F(c->d_flag);
   F(c->d_upd_partials); F(c->d_misc); F(c->d_cfree); F(c->d_zmin); F(c->d_points); F(c->d_pt_counts); F(c->d_pt_offsets); F(c->d_rec_keys[0]); F(c->d_rec_keys[1]); F(c->d_rec_vals[0]); F(c->d_rec_vals[1]); F(c->d_sort_tmp); F(c->fast.summary); F(c->fast.summary_c); F(c->fast.bbox); F(c->d_cnt_partials);
   F(c->d_qt_sums); F(c->d_qt_flags); F(c->d_qt_unc); F(c->d_qt_marks); F(c->d_qt_pos); F(c->d_qt_parked); F(c->d_qt_seeds); F(c->d_qt_leaves); F(c->d_qt_misc); F(c->d_qt_tmp);
