@@ -505,7 +505,14 @@ def test_randomised_parameters_and_shapes(hip, oracle, seed):
     assert (sa.occupied_fine, sa.occupied_coarse, sa.free_fine, sa.free_coarse) == (sb.occupied_fine, sb.occupied_coarse, sb.free_fine, sb.free_coarse), params
     r = pu.compare_maps(a, b)
     assert r["blocks"] > 50, params
+    # 3DGS splat seeds of the last frame on the same map (random quad-tree parameters)
+    thr, min_px = float(rng.choice([0.0, 1e-4, 2e-3, 0.05])), int(rng.integers(0, 4))
+    sa_, sb_ = a.splat_seeds(thr, min_px), b.splat_seeds(thr, min_px)
+    assert np.array_equal(a.qtree_leaves(), b.qtree_leaves()), (params, thr, min_px)
+    assert sa_.tobytes() == sb_.tobytes(), (params, thr, min_px)
     pu.compare_meshes(a, b)
+    a.close()
+    b.close()
 
 
 def test_plain_c_program_drives_the_abi(hip, tmp_path):
