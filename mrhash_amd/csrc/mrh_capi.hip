@@ -148,6 +148,7 @@ struct mrh_ctx {
   bool mr_next_general = true;    // the next multi-resolution frame must take the general path (frame 0 / after a starve frame / after an import)
   bool mr_summaries_valid = false;  // fast.summary / summary_c describe every live block (the general kernels do not maintain them)
   bool frame_fused_mr = false;
+  bool refill_flag_valid = false;  // d_flag holds the refill test for the next fused frame (taken by k_mr_tail)
   int mesh_on_host = 0;      // MRH_MESH_HOST=1: mesh post-process with the host restatement instead of mrh_mesh.h
   float* d_zmin = nullptr;   // per visible-list entry (Lists::zmin)
   uint64_t fast_frames = 0;  // fast-path frames issued: parity selects the list-counter set
@@ -246,6 +247,7 @@ void free_all(mrh_ctx* c) {
 int init_buffers(mrh_ctx* c) {
   hipStream_t s = c->stream;
   c->mr_next_general = true;
+  c->refill_flag_valid = false;
   c->mr_summaries_valid = false;
   c->fast_frames = 0;
   const Tab& t = c->tab;
@@ -870,6 +872,7 @@ static int integrate_frame(mrh_ctx* c, int n_frames_invalidate) {
   if (t.multi_res && !c->frame_fused_mr) {
     c->mr_summaries_valid = false;
     c->mr_next_general = starve_now || c->frames == 0;
+    c->refill_flag_valid = false;
   }
   if (!t.multi_res || c->frame_fused_mr) {
     // ---- fast path: alloc + sweep -> fused integrate / summary / GC (mrh_fast2.h)
@@ -901,17 +904,22 @@ static int integrate_frame(mrh_ctx* c, int n_frames_invalidate) {
         c->mr_summaries_valid = true;
       }
       c->frame_gc_inline = true;
-      k_refill_decide<<<1, 64, 0, s>>>(t, c->low_blocks_to_allocate, c->d_flag);  // vds.cu:885-891
-      k_refill<<<(c->low_blocks_to_allocate + 255) / 256, 256, 0, s>>>(t, c->low_blocks_to_allocate, c->d_flag);
-      k_front<false, true><<<n_tiles + c->sweep_wgs_mr, 256, 0, s>>>(k, m, t, f, L, c->d_depth, c->d_rgb, tiles_x, n_tiles, stamp, parity, 1, gc_thr);
+      // the coarse-list refill (vds.cu:885-891) rides in k_front; its test was taken by the previous frame's k_mr_tail
+      // unless something else touched the coarse list since (general frames, import, stream-out, reset)
+      if (!c->refill_flag_valid) k_refill_decide<<<1, 64, 0, s>>>(t, c->low_blocks_to_allocate, c->d_flag);
+      const int n_refill = (c->low_blocks_to_allocate + 255) / 256;
+      k_front<false, true><<<n_tiles + c->sweep_wgs_mr + n_refill, 256, 0, s>>>(k, m, t, f, L, c->d_depth, c->d_rgb, tiles_x, n_tiles, stamp, parity, 1, gc_thr,
+                                                                                   n_refill, c->low_blocks_to_allocate, c->d_flag);
       k_back<true, false, true><<<c->fused_grid, 256, lds, s>>>(k, m, t, f, L, parity, gc_thr, c->d_depth, c->d_rgb, (u32*) c->d_reint);
-      k_mr_tail<<<1, 256, 0, s>>>(t, (const u32*) c->d_reint);
-      return starve_and_tail(c, max_num_frames);
+      k_mr_tail<<<1, 256, 0, s>>>(t, (const u32*) c->d_reint, c->low_blocks_to_allocate, c->d_flag);
+      rc = starve_and_tail(c, max_num_frames);
+      c->refill_flag_valid = rc == MRH_OK;
+      return rc;
     }
     // GC runs inside k_back unless this is a starve frame (the starve step changes weights after the integrate pass)
     c->frame_gc_inline = max_num_frames > 0 && !starve_now;
-    if (c->profile) k_front<true, false><<<n_tiles + c->sweep_wgs, 256, 0, s>>>(k, m, t, f, L, c->d_depth, c->d_rgb, tiles_x, n_tiles, stamp, parity, max_num_frames > 0 ? 1 : 0, gc_thr);
-    else k_front<false, false><<<n_tiles + c->sweep_wgs, 256, 0, s>>>(k, m, t, f, L, c->d_depth, c->d_rgb, tiles_x, n_tiles, stamp, parity, max_num_frames > 0 ? 1 : 0, gc_thr);
+    if (c->profile) k_front<true, false><<<n_tiles + c->sweep_wgs, 256, 0, s>>>(k, m, t, f, L, c->d_depth, c->d_rgb, tiles_x, n_tiles, stamp, parity, max_num_frames > 0 ? 1 : 0, gc_thr, 0, 0, nullptr);
+    else k_front<false, false><<<n_tiles + c->sweep_wgs, 256, 0, s>>>(k, m, t, f, L, c->d_depth, c->d_rgb, tiles_x, n_tiles, stamp, parity, max_num_frames > 0 ? 1 : 0, gc_thr, 0, 0, nullptr);
     EvPair ev;
     if (c->profile) {
       k_count_updates<<<c->fused_grid, 256, 0, s>>>(k, m, t, f, c->d_cnt_partials, CTR_SET0 + 4 * parity);
@@ -1402,6 +1410,7 @@ int mrh_stream_out(mrh_ctx* c, const float center[3], float radius, mrh_block_de
   if (rc) return rc;
   if (!out_n || !center) return MRH_ERR_INVALID_ARG;
   if (c->pending) return fail(c, MRH_ERR_STATE, "mrh_stream_out: an exchange is pending (call mrh_integrate_resume)");
+  c->refill_flag_valid = false;  // freed coarse units change the level the next frame's refill test must see
   int n = 0;
   rc = compact_all(c, &n);
   if (rc) return rc;
@@ -1501,6 +1510,7 @@ int mrh_import_blocks(mrh_ctx* c, const mrh_block_desc* descs, const mrh_voxel* 
   if (n == 0) return MRH_OK;
   if (!descs || !voxels) return fail(c, MRH_ERR_INVALID_ARG, "mrh_import_blocks: null argument");
   c->mr_next_general = true;  // imported payload has not been through a variance check
+  c->refill_flag_valid = false;
   c->mr_summaries_valid = false;
   const uint64_t chunk = 8192;
   DevBuf<int4> d_descs;

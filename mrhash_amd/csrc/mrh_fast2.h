@@ -314,16 +314,35 @@ __device__ __forceinline__ void front_sweep(const Cam& c, const Map& m, const Ta
 #endif
 }
 
+// allocateMemoryLow (vds.cu:860-871, host test :885-891) as extra workgroups of k_front: when the coarse free list has
+// run low (flag, decided by the previous launch in the stream), each thread turns one fine slot into eight coarse units.
+// Safe beside the allocation workgroups: both only POP the fine list (which slot a block gets is not observable), and
+// nothing in k_front pops the coarse list.
+__device__ __forceinline__ void front_refill(const Tab& t, const int low_blocks_to_allocate, const int* __restrict__ flag, const int wg) {
+  if (*flag == 0) return;
+  const int i = wg * 256 + (int) threadIdx.x;
+  if (i >= low_blocks_to_allocate) return;
+  const int addr_high = atomicSub(&t.ctr[CTR_HEAP_FINE], 1);
+  if (addr_high < 0) { atomicAdd(&t.ctr[CTR_HEAP_FINE], 1); atomicOr((u32*) &t.ctr[CTR_ERROR], ERR_POOL); return; }
+  const u32 H = t.heap_fine[addr_high];
+  atomicMax(&t.ctr[CTR_HWM_FINE], (int) H + 1);
+  const int addr_low = atomicAdd(&t.ctr[CTR_HEAP_COARSE], 8);
+  for (int idx = 1; idx <= 8; idx++) t.heap_coarse[addr_low + idx] = H * 8 + 8 - idx;
+}
+
 template <bool PROFILE, bool MULTI>
 __global__ __launch_bounds__(256) void k_front(const Cam c, const Map m, const Tab t, const Fast f, const Lists L,
                                                const float* __restrict__ depth, const uint8_t* __restrict__ rgb, const int tiles_x,
                                                const int n_tiles, const u32 stamp, const int parity, const int gc_on,
-                                               const float trunc_threshold) {
+                                               const float trunc_threshold, const int n_refill, const int low_blocks_to_allocate,
+                                               const int* __restrict__ refill_flag) {
   __shared__ FrontShared sh;
   const int cs = CTR_SET0 + 4 * parity;
-  const int n_sweep = (int) gridDim.x - n_tiles;  // the sweep workgroups come FIRST in the grid so that they start first
+  // grid = [sweep | tiles | refill]: the sweep workgroups come FIRST so that they start first
+  const int n_sweep = (int) gridDim.x - n_tiles - n_refill;
   MRH_TSF(0);
-  if ((int) blockIdx.x >= n_sweep) front_tile<PROFILE>(c, m, t, f, L, depth, rgb, tiles_x, (int) blockIdx.x - n_sweep, stamp, cs, sh);
+  if (MULTI && (int) blockIdx.x >= n_sweep + n_tiles) front_refill(t, low_blocks_to_allocate, refill_flag, (int) blockIdx.x - n_sweep - n_tiles);
+  else if ((int) blockIdx.x >= n_sweep) front_tile<PROFILE>(c, m, t, f, L, depth, rgb, tiles_x, (int) blockIdx.x - n_sweep, stamp, cs, sh);
   else front_sweep<MULTI>(c, m, t, f, L, stamp, cs, gc_on, trunc_threshold, (int) blockIdx.x, n_sweep, sh);
 }
 
@@ -673,16 +692,20 @@ __global__ __launch_bounds__(256) void k_back(const Cam c, const Map m, const Ta
   if (FREE) free_range<PROFILE, MULTI>(t, L, ncfree, gw, nw, lane, deferred);
 }
 
-// after a multi-resolution k_back: the coarse units freed during the launch go onto the coarse free list
-__global__ __launch_bounds__(256) void k_mr_tail(const Tab t, const u32* __restrict__ deferred) {
+// after a multi-resolution k_back: the coarse units freed during the launch go onto the coarse free list, and the
+// refill test of the NEXT frame (vds.cu:885-891: coarse list below low_blocks_to_allocate?) is taken here, on the final
+// level — the next k_front carries the refill itself, so a steady-state frame is three launches
+__global__ __launch_bounds__(256) void k_mr_tail(const Tab t, const u32* __restrict__ deferred, const int low_blocks_to_allocate,
+                                                 int* __restrict__ refill_flag) {
   const int n = t.ctr[CTR_NREINT];
   __shared__ int s_base;
-  if (n == 0) return;
-  if (threadIdx.x == 0) s_base = atomicAdd(&t.ctr[CTR_HEAP_COARSE], n);
+  if (threadIdx.x == 0) s_base = n ? atomicAdd(&t.ctr[CTR_HEAP_COARSE], n) : t.ctr[CTR_HEAP_COARSE];
   __syncthreads();
   for (int i = threadIdx.x; i < n; i += 256) t.heap_coarse[s_base + 1 + i] = deferred[i];
-  __syncthreads();
-  if (threadIdx.x == 0) t.ctr[CTR_NREINT] = 0;
+  if (threadIdx.x == 0) {
+    t.ctr[CTR_NREINT] = 0;
+    *refill_flag = (s_base + n + 1 < low_blocks_to_allocate) ? 1 : 0;
+  }
 }
 
 // GC summaries of every live block and coarse unit from their payload (one wave each): run once when the fused
