@@ -215,3 +215,68 @@ def test_gs_runner_sequence_accumulates_splat_seeds(geowrapper_cls, oracle, tmp_
         g.GSFinalOpt()
     with pytest.raises(RuntimeError):
         _make(geowrapper_cls, gs_optimization_param_path=str(tmp_path / "missing.json"))
+
+
+def test_streamer_single_stream_like_the_reference(monkeypatch, tmp_path):
+    """The reference's own streamer test (tests/test_streamer.cu STREAMER.SingleStream): a circular camera path over a
+    constant-depth image, Streamer::stream(camera position, radius 3 m) before every integrate, a second lap that only
+    streams, then streamAllOut; it passes when fewer than 15 % of the blocks exist twice (host grid + device).  Here the
+    same call sequence must leave NO block twice, and — the geometry lies within the radius — the final mesh must equal
+    the mesh of a run that never streams."""
+    monkeypatch.setenv("MRHASH_NUM_SDF_BLOCKS", "131072")
+    from mrhash.src.pygeowrapper import GeoWrapper
+
+    rows = cols = 150
+    steps, t_step, radius = 40, 1.5, 3.0
+    kw = dict(sdf_truncation=0.02, sdf_truncation_scale=0.01, integration_weight_sample=3, virtual_voxel_size=0.005,
+              n_frames_invalidate_voxels=10, voxel_extents_scale=1, viewer_active=False, marching_cubes_threshold=1.5,
+              min_weight_threshold=0, min_depth=0.0, max_depth=5.0)
+    depth = np.full((rows, cols), 1.0, np.float32)
+    rgb = np.zeros((rows, cols, 3), np.uint8)
+    rgb[..., 0] = 255
+    # makeCameraCircularTrajectory (tests/test_utils.cuh:20-32)
+    a = 2.0 * np.pi / steps
+    step = np.eye(4)
+    step[:3, :3] = [[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]]
+    step[:3, 3] = [t_step, 0, t_step]
+    T, path = np.eye(4), []
+    for k in range(steps + 1):
+        T = T @ step
+        th = (k + 1) * a  # rotation about y by th: (qx, qy, qz, qw) = (0, sin(th/2), 0, cos(th/2))
+        path.append((T[:3, 3].astype(np.float32), np.array([0.0, np.sin(th / 2), 0.0, np.cos(th / 2)], np.float32)))
+
+    def positions(g, name):
+        g.serializeGrid(str(tmp_path / name))
+        raw = np.frombuffer((tmp_path / name).read_bytes(), np.uint8)
+        n = int(raw[8:16].view(np.uint64)[0])
+        rec = raw[16:].reshape(n, 16 + 512 * 12)
+        return np.ascontiguousarray(rec[:, :12]).view(np.int32).reshape(n, 3)
+
+    def run(stream):
+        g = GeoWrapper(**kw)
+        g.setCamera(200.0, 200.0, cols / 2.0, rows / 2.0, rows, cols, 0.0, 5.0, 0)
+        peak = 0
+        for t, q in path:
+            if stream:
+                g._stream(t, radius)
+                peak = max(peak, g._hostGridBlocks())
+            g.setCurrPose(t, q)
+            g.setDepthImage(depth)
+            g.setRGBImage(rgb)
+            g.compute()
+        if stream:
+            pos = positions(g, "lap1.bin")
+            assert len(np.unique(pos, axis=0)) == len(pos), "a block exists twice after the fusing lap"
+            for t, _ in path:  # second lap: stream only
+                g._stream(t, radius)
+            pos2 = positions(g, "lap2.bin")
+            assert len(np.unique(pos2, axis=0)) == len(pos2) == len(pos), "streaming alone changed the set of blocks"
+        g.streamAllOut()
+        g.extractMesh(str(tmp_path / ("s.ply" if stream else "n.ply")))
+        return g.getVertices(), g.getFaces(), peak
+
+    Vn, Fn, _ = run(False)
+    Vs, Fs, peak = run(True)
+    assert peak > 1000, "the path never left the streaming radius"
+    assert len(Fn) > 10000
+    assert np.array_equal(Vn, Vs) and np.array_equal(Fn, Fs)
