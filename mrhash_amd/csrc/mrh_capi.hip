@@ -122,6 +122,7 @@ struct mrh_ctx {
   int* d_flag = nullptr;
   u64* d_upd_partials = nullptr;
   u32* d_misc = nullptr;  // 4 words for k_get_voxel
+  float* d_rcp_w = nullptr;  // Fast::rcp_w
   Fast fast;              // single-resolution fast path buffers (depth_clean / rgbx point at the current frame's pair)
   size_t fast_npix = 0;
   float* dc_buf = nullptr;   // cleaned depth / packed colour of the current frame (written by k_front)
@@ -236,7 +237,7 @@ void free_all(mrh_ctx* c) {
   for (hipEvent_t e : c->frame_done) if (e) (void) hipEventDestroy(e);
   if (c->h_peek) (void) hipHostFree(c->h_peek);
   F(c->d_decision); F(c->d_zbuf); F(c->d_realloc); F(c->d_reint); F(c->d_flag);
-  F(c->d_upd_partials); F(c->d_misc); F(c->d_cfree); F(c->d_zmin); F(c->d_points); F(c->d_pt_counts); F(c->d_pt_offsets); F(c->d_rec_keys[0]); F(c->d_rec_keys[1]); F(c->d_rec_vals[0]); F(c->d_rec_vals[1]); F(c->d_sort_tmp); F(c->fast.summary); F(c->fast.summary_c); F(c->fast.bbox); F(c->d_cnt_partials);
+  F(c->d_upd_partials); F(c->d_misc); F(c->d_rcp_w); F(c->d_cfree); F(c->d_zmin); F(c->d_points); F(c->d_pt_counts); F(c->d_pt_offsets); F(c->d_rec_keys[0]); F(c->d_rec_keys[1]); F(c->d_rec_vals[0]); F(c->d_rec_vals[1]); F(c->d_sort_tmp); F(c->fast.summary); F(c->fast.summary_c); F(c->fast.bbox); F(c->d_cnt_partials);
   F(c->d_qt_sums); F(c->d_qt_flags); F(c->d_qt_unc); F(c->d_qt_marks); F(c->d_qt_pos); F(c->d_qt_parked); F(c->d_qt_seeds); F(c->d_qt_leaves); F(c->d_qt_misc); F(c->d_qt_tmp);
   for (auto& e : c->ev_pool) { (void) hipEventDestroy(e.a); (void) hipEventDestroy(e.b); }
   for (auto& e : c->ev_pending) { (void) hipEventDestroy(e.a); (void) hipEventDestroy(e.b); }
@@ -646,6 +647,39 @@ int mrh_create(const mrh_params* p, mrh_ctx** out) {
     if (getenv("MRH_DEBUG")) fprintf(stderr, "[mrhash_hip] voxel->block is a shift for |v| < %d (first mismatch at %u, voxel size %g)\n", m.block_shift_limit, first_bad, (double) m.vs);
   }
 
+  {  // correctly rounded reciprocals for the short divisions of the running mean (mrh_device.h: div_cr)
+    auto rn_reciprocal = [](float b) {  // fp64 quotient, then the nearest of the three neighbouring floats (b * c is exact in fp64)
+      const float c0 = (float) (1.0 / (double) b);
+      float best = c0;
+      double err = std::fabs(1.0 - (double) c0 * (double) b);
+      for (float t : {std::nextafter(c0, 0.f), std::nextafter(c0, INFINITY)}) {
+        const double e = std::fabs(1.0 - (double) t * (double) b);
+        if (e < err) { err = e; best = t; }
+      }
+      return best;
+    };
+    // weight sums: the kernels use v_rcp_f32 + one Newton step; for the integers 1 .. 510 that must be RN(1 / w)
+    std::vector<float> dev(kRcpWeightEntries, 0.f);
+    bool ok = hipMalloc((void**) &c->d_rcp_w, dev.size() * sizeof(float)) == hipSuccess;
+    if (ok) {
+      k_rcp_weights<<<(kRcpWeightEntries + 255) / 256, 256, 0, c->stream>>>(c->d_rcp_w);
+      ok = hipStreamSynchronize(c->stream) == hipSuccess && hipMemcpy(dev.data(), c->d_rcp_w, dev.size() * sizeof(float), hipMemcpyDeviceToHost) == hipSuccess;
+    }
+    int w_bad = ok ? 0 : 1;
+    for (int w = 1; ok && w <= 510; w++) w_bad += dev[w] != rn_reciprocal((float) w);
+    m.wsum_two_steps = w_bad ? 1 : 0;
+    const float half_vs = m.vs / 2;
+    m.r_half_vs = rn_reciprocal(half_vs);
+    u32 bad = 1;
+    if (hipMemset(c->d_misc, 0, sizeof(u32)) == hipSuccess) {
+      k_check_div_cr<<<4096, 256, 0, c->stream>>>(half_vs, m.r_half_vs, c->d_misc);
+      if (hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(&bad, c->d_misc, sizeof bad, hipMemcpyDeviceToHost) != hipSuccess) bad = 1;
+    }
+    m.half_vs_two_steps = bad ? 1 : 0;
+    if (const char* g = getenv("MRH_SAFE_DIV")) { if (atoi(g)) m.half_vs_two_steps = 1; }  // force the fallback instantiation (tests)
+    if (getenv("MRH_DEBUG")) fprintf(stderr, "[mrhash_hip] division by vs / 2 with one residual step: %u mismatches over the working range -> %s; refined reciprocals of the weight sums: %d not correctly rounded\n", bad, bad ? "two steps" : "one step", w_bad);
+  }
+
   if (const char* g = getenv("MRH_FUSED_GRID")) {  // tuning knob: workgroups (x4 waves) of the fused integrate kernel
     const int v = atoi(g);
     if (v > 0 && v <= 32768) c->fused_grid = v;
@@ -896,6 +930,7 @@ static int integrate_frame(mrh_ctx* c, int n_frames_invalidate) {
     const u32 stamp = (u32) ((c->frames + 1) & 0x3FFFFFFFu);
     const float gc_thr = m.trunc + m.trunc_scale * k.max_depth;  // getTruncation(camera.maxDepth(), ...), vds.cu:1720
     const Lists L = {t.compact, c->fast.bbox, c->d_cfree, c->d_zmin, (u32) c->num_blocks};
+    const bool safe_div = m.half_vs_two_steps || m.wsum_two_steps;  // the short divisions failed their check at mrh_create
     const int n_tiles = tiles_x * tiles_y;
     const size_t lds = (size_t) 4 * kTileMaxPx * sizeof(uint2);
     if (c->frame_fused_mr) {
@@ -910,7 +945,8 @@ static int integrate_frame(mrh_ctx* c, int n_frames_invalidate) {
       const int n_refill = (c->low_blocks_to_allocate + 255) / 256;
       k_front<false, true><<<n_tiles + c->sweep_wgs_mr + n_refill, 256, 0, s>>>(k, m, t, f, L, c->d_depth, c->d_rgb, tiles_x, n_tiles, stamp, parity, 1, gc_thr,
                                                                                    n_refill, c->low_blocks_to_allocate, c->d_flag);
-      k_back<true, false, true><<<c->fused_grid, 256, lds, s>>>(k, m, t, f, L, parity, gc_thr, c->d_depth, c->d_rgb, (u32*) c->d_reint);
+      if (safe_div) k_back<true, false, true, true><<<c->fused_grid, 256, lds, s>>>(k, m, t, f, L, parity, gc_thr, c->d_depth, c->d_rgb, (u32*) c->d_reint);
+      else k_back<true, false, true, false><<<c->fused_grid, 256, lds, s>>>(k, m, t, f, L, parity, gc_thr, c->d_depth, c->d_rgb, (u32*) c->d_reint);
       k_mr_tail<<<1, 256, 0, s>>>(t, (const u32*) c->d_reint, c->low_blocks_to_allocate, c->d_flag);
       rc = starve_and_tail(c, max_num_frames);
       c->refill_flag_valid = rc == MRH_OK;
@@ -928,9 +964,15 @@ static int integrate_frame(mrh_ctx* c, int n_frames_invalidate) {
       else { HIP_TRY(c, hipEventCreate(&ev.a)); HIP_TRY(c, hipEventCreate(&ev.b)); }
       HIP_TRY(c, hipEventRecord(ev.a, s));
     }
-    if (c->frame_gc_inline && c->profile) k_back<true, true, false><<<c->fused_grid, 256, lds, s>>>(k, m, t, f, L, parity, gc_thr, nullptr, nullptr, nullptr);
-    else if (c->frame_gc_inline) k_back<true, false, false><<<c->fused_grid, 256, lds, s>>>(k, m, t, f, L, parity, gc_thr, nullptr, nullptr, nullptr);
-    else k_back<false, false, false><<<c->fused_grid, 256, lds, s>>>(k, m, t, f, L, parity, gc_thr, nullptr, nullptr, nullptr);
+#define MRH_K_BACK(FREE, PROF)                                                                                                          \
+  do {                                                                                                                                   \
+    if (safe_div) k_back<FREE, PROF, false, true><<<c->fused_grid, 256, lds, s>>>(k, m, t, f, L, parity, gc_thr, nullptr, nullptr, nullptr); \
+    else k_back<FREE, PROF, false, false><<<c->fused_grid, 256, lds, s>>>(k, m, t, f, L, parity, gc_thr, nullptr, nullptr, nullptr);         \
+  } while (0)
+    if (c->frame_gc_inline && c->profile) MRH_K_BACK(true, true);
+    else if (c->frame_gc_inline) MRH_K_BACK(true, false);
+    else MRH_K_BACK(false, false);
+#undef MRH_K_BACK
     if (c->profile) {
       HIP_TRY(c, hipEventRecord(ev.b, s));
       c->ev_pending.push_back(ev);

@@ -72,6 +72,9 @@ struct Map {
   int min_weight_threshold;
   int shard_rank, shard_count, shard_chunk_log2;
   int block_shift_limit;  // for |voxel coordinate| < this, voxel_to_block(v) == v >> 3 (checked exhaustively at mrh_create)
+  float r_half_vs;        // RN(1 / (vs / 2)), the correctly rounded reciprocal (fp64 on the host)
+  int half_vs_two_steps;  // 0: div_cr by vs / 2 equals IEEE division for every dividend in the working range (checked exhaustively at mrh_create)
+  int wsum_two_steps;     // 0: rcp_refined(w) IS the correctly rounded reciprocal for every weight sum w = 1 .. 510 (checked at mrh_create)
 };
 
 // Open-address table + pools.  Layout in HBM:
@@ -147,6 +150,27 @@ __device__ __forceinline__ v2f rcp_refined2(v2f b) {
   const v2f e = fma2(-b, r, splat2(1.0f));
   return fma2(e, r, r);
 }
+// Division with a CORRECTLY ROUNDED reciprocal r = RN(1 / b): q = RN(a r) is then within an ulp of a / b and ONE exact
+// residual correction rounds to the IEEE quotient (Markstein).  tools/micro/div_cr_exhaustive.hip checks it against the
+// compiler's correctly rounded division for all 2^32 dividends of every divisor 1 .. 510 (the weight sums) and of ten
+// half-voxel sizes: 0 mismatches for 2^-100 <= |a| <= 2^100 and a == +0 (outside that range an intermediate under- or
+// overflows; the 5-instruction div_rr behaves the same there).  mrh_create repeats the check for the context's voxel size.
+__device__ __forceinline__ v2f div_cr2(v2f a, v2f b, v2f r, const bool two_steps) {
+  v2f q = a * r;
+  v2f e = fma2(-b, q, a);
+  q = fma2(e, r, q);
+  if (two_steps) {  // wave-uniform fallback: a divisor for which the check at mrh_create found a mismatch
+    e = fma2(-b, q, a);
+    q = fma2(e, r, q);
+  }
+  return q;
+}
+__device__ __forceinline__ float div_cr(float a, float b, float r) {
+  const float q = a * r;
+  return fmaf(fmaf(-b, q, a), r, q);
+}
+constexpr int kRcpWeightEntries = 512;  // weight sums w = 1 .. 510 (index w; entry 0 unused)
+
 __device__ __forceinline__ v2f div_rr2(v2f a, v2f b, v2f r) {
   v2f q = a * r;
   v2f e = fma2(-b, q, a);

@@ -132,12 +132,14 @@ __device__ __forceinline__ u32 update_mask4(const Cam& c, const Map& m, const PT
 // running weighted mean, colour blend, weight clamp, variance term (vds.cu:1147-1180, vhu.cuh:167-181), two voxels
 // per instruction where the arithmetic is plain fp32 (mrh_device.h, v2f).  The clamp `sd >= 0 ? min(t, sd) :
 // max(-t, sd)` is one v_med3_f32 (t >= 0 is checked at mrh_create; a NaN sd yields -t on both sides).
-template <typename PT>
+template <bool SAFEDIV, typename PT>
 __device__ __forceinline__ void blend4(const Map& m, const PT& P, const u32 mask, const float (&d)[4], const u32 (&cpx)[4],
-                                       const float r_half_vs, float (&s)[4], u32 (&w)[4], float (&ss)[4]) {
+                                       float (&s)[4], u32 (&w)[4], float (&ss)[4]) {
   const u32 w1 = (u32) (m.weight_sample & 0xFF);
   const u32 wmax = (u32) (m.weight_max & 0xFF);
-  const v2f half_vs = splat2(m.vs / 2), rh = splat2(r_half_vs), w1f = splat2((float) w1);
+  const v2f half_vs = splat2(m.vs / 2), rh = splat2(m.r_half_vs), w1f = splat2((float) w1);
+  // SAFEDIV: a context whose voxel size (or device) failed the checks of mrh_create keeps the second residual step
+  constexpr bool two = SAFEDIV, two_w = SAFEDIV;
 #pragma unroll
   for (int k = 0; k < 4; k += 2) {
     const v2f dd = mk2(d[k], d[k + 1]);
@@ -148,10 +150,11 @@ __device__ __forceinline__ void blend4(const Map& m, const PT& P, const u32 mask
     const u32 old0 = w[k], old1 = w[k + 1];
     const u32 w00 = old0 >> 24, w01 = old1 >> 24;
     const v2f curr_mean = mk2(w00 > 0 ? s0.x : sd.x, w01 > 0 ? s0.y : sd.y);
-    const v2f delta = div_rr2(sd - curr_mean, half_vs, rh);
+    const v2f delta = div_cr2(sd - curr_mean, half_vs, rh, two);
     const v2f wsum = mk2((float) (int) (w00 + w1), (float) (int) (w01 + w1));
-    const v2f sn = div_rr2(s0 * mk2((float) w00, (float) w01) + sd * w1f, wsum, rcp_refined2(wsum));
-    const v2f delta2 = div_rr2(sd - sn, half_vs, rh);
+    // weight sums are integers <= 510: for those, v_rcp_f32 + one Newton step already IS the correctly rounded reciprocal
+    const v2f sn = div_cr2(s0 * mk2((float) w00, (float) w01) + sd * w1f, wsum, rcp_refined2(wsum), two_w);
+    const v2f delta2 = div_cr2(sd - sn, half_vs, rh, two);
     const v2f sq = splat2(0.f) + delta * delta2;
 #pragma unroll
     for (int j = 0; j < 2; j++) {

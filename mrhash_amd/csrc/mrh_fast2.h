@@ -474,12 +474,11 @@ __device__ __forceinline__ bool variance_says_coarsen(const Map& m, const uint2*
 //   MULTI multi-resolution map: entries may be coarse units; a fine block is variance-checked right after its update
 //         and, if the reference would coarsen it, converted on the spot (checkVarSDF -> reallocBlocks ->
 //         reintegrateDepthMap, vds.cu:1857-2107): same table slot, new coarse unit, fine slot zeroed and released
-template <bool FREE, bool PROFILE, bool MULTI>
+template <bool FREE, bool PROFILE, bool MULTI, bool SAFEDIV>
 __device__ __forceinline__ void back_range(const Cam& c, const Map& m, const Tab& t, const Fast& f, const Lists& L,
                                            const float trunc_threshold, const int n, const int gw, const int nw, const int lane,
                                            uint2* tile, const float* __restrict__ depth_raw, const uint8_t* __restrict__ rgb_raw,
                                            u32* __restrict__ deferred) {
-  const float r_half_vs = rcp_refined(m.vs / 2);
   for (int e = __builtin_amdgcn_readfirstlane(gw); e < n; e += nw) {
     MRH_TS(0);
     int4 ent, bb;
@@ -553,7 +552,7 @@ __device__ __forceinline__ void back_range(const Cam& c, const Map& m, const Tab
 #ifdef MRH_TRACE
         trace_upd += __popc(mask);
 #endif
-        blend4(m, P[b], mask, d[b], cpx[b], r_half_vs, s, w, ss);
+        blend4<SAFEDIV>(m, P[b], mask, d[b], cpx[b], s, w, ss);
         if (MULTI) {  // (sum_squared, rgbw) of this lane's voxels q * 4 + k for the variance check below
           W[b] = make_uint4(w[0], w[1], w[2], w[3]);
           Q[b] = make_float4(ss[0], ss[1], ss[2], ss[3]);
@@ -671,7 +670,7 @@ __device__ __forceinline__ void frame_epilogue(const Tab& t, const int parity, c
 }
 
 // ---- two-launch path: K2 = integrate + summary + GC of the visible list, then the culled-free list -------------
-template <bool FREE, bool PROFILE, bool MULTI>
+template <bool FREE, bool PROFILE, bool MULTI, bool SAFEDIV>
 __global__ __launch_bounds__(256) void k_back(const Cam c, const Map m, const Tab t, const Fast f, const Lists L, const int parity,
                                               const float trunc_threshold, const float* __restrict__ depth_raw,
                                               const uint8_t* __restrict__ rgb_raw, u32* __restrict__ deferred) {
@@ -688,7 +687,7 @@ __global__ __launch_bounds__(256) void k_back(const Cam c, const Map m, const Ta
   const int nkept = t.ctr[cs + 1];
   if (gw == 0) frame_epilogue(t, parity, nvis, nkept + t.ctr[cs + 2], lane);
   uint2* tile = &s_tile[(threadIdx.x >> 6) * kTileMaxPx];
-  back_range<FREE, PROFILE, MULTI>(c, m, t, f, L, trunc_threshold, nvis, gw, nw, lane, tile, depth_raw, rgb_raw, deferred);
+  back_range<FREE, PROFILE, MULTI, SAFEDIV>(c, m, t, f, L, trunc_threshold, nvis, gw, nw, lane, tile, depth_raw, rgb_raw, deferred);
   if (FREE) free_range<PROFILE, MULTI>(t, L, ncfree, gw, nw, lane, deferred);
 }
 

@@ -729,6 +729,26 @@ __global__ void k_get_voxel(const Map m, const Tab t, const int vx, const int vy
   out[3] = 1;
 }
 
+// rcp_refined of the weight sums, for the host to compare with the correctly rounded reciprocals (Map::wsum_two_steps)
+__global__ void k_rcp_weights(float* __restrict__ out) {
+  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w < kRcpWeightEntries) out[w] = w ? rcp_refined((float) w) : 0.f;
+}
+
+// Exhaustive check behind Map::half_vs_two_steps: div_cr(a, b, r) against the compiler's correctly rounded a / b for every
+// dividend in the working range 2^-100 <= |a| <= 2^100 (and a == +0); out[0] = number of mismatches.  4096 x 256 threads.
+__global__ __launch_bounds__(256) void k_check_div_cr(const float b, const float r, u32* __restrict__ out) {
+  const u32 tid = blockIdx.x * blockDim.x + threadIdx.x;
+  u32 bad = 0;
+  for (u32 k = 0; k < 4096u; k++) {
+    const u32 bits = tid * 4096u + k;
+    const float a = __uint_as_float(bits), mag = fabsf(a);
+    if (!((mag >= 7.888609e-31f && mag <= 1.2676506e30f) || bits == 0u)) continue;
+    if (__float_as_uint(div_cr(a, b, r)) != __float_as_uint(a / b)) bad++;
+  }
+  if (bad) atomicAdd(out, bad);
+}
+
 // Self-test: div_rr(a, b, rcp_refined(b)) must equal the compiler's correctly rounded a / b bit for bit on the
 // operand domains the fused kernel uses it for (pixel projection, running mean, variance deltas) plus a broad
 // log-uniform domain.  Returns the number of mismatching samples.

@@ -515,6 +515,25 @@ def test_randomised_parameters_and_shapes(hip, oracle, seed):
     b.close()
 
 
+def test_safe_division_fallback_gives_the_same_map(hip, oracle, monkeypatch):
+    """The running mean divides with one residual step after checks at mrh_create (vs / 2 exhaustively over the working
+    range, the weight sums against correctly rounded reciprocals); MRH_SAFE_DIV=1 forces the instantiation a failed check
+    would select (two steps).  Both must reproduce the oracle's IEEE divisions."""
+    K = synth.REPLICA_640
+    monkeypatch.setenv("MRH_SAFE_DIV", "1")
+    safe = pu.make_engine(hip, K, synth.REPLICA_PARAMS, 65536)
+    monkeypatch.delenv("MRH_SAFE_DIV")
+    fast = pu.make_engine(hip, K, synth.REPLICA_PARAMS, 65536)
+    orc = pu.make_engine(oracle, K, synth.REPLICA_PARAMS, 65536)
+    for f in synth.replica_stream(4, noise_sigma=0.002):
+        for e in (safe, fast, orc):
+            pu.feed(e, f)
+    pu.compare_maps(safe, orc)
+    pu.compare_maps(fast, orc)
+    for e in (safe, fast, orc):
+        e.close()
+
+
 def test_plain_c_program_drives_the_abi(hip, tmp_path):
     """examples/c_abi_smoke.c: a C11 program with nothing but include/mrhash_hip.h and -lmrhash_hip reproduces the
     counts of the golden plane case."""
