@@ -4,6 +4,7 @@
 // stream with no host round trip, and only synchronises in the calls that hand data back.
 // There is NO CPU fallback in this file: without a HIP device mrh_create fails with MRH_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <sys/mman.h>
 
 #include <algorithm>
@@ -962,21 +963,23 @@ static int integrate_frame(mrh_ctx* c, int n_frames_invalidate) {
       if (!c->ev_pool.empty()) { ev = c->ev_pool.back(); c->ev_pool.pop_back(); }
       else if (c->ev_pending.size() >= 4096) { HIP_TRY(c, hipStreamSynchronize(s)); rc = drain_events(c); if (rc) return rc; ev = c->ev_pool.back(); c->ev_pool.pop_back(); }
       else { HIP_TRY(c, hipEventCreate(&ev.a)); HIP_TRY(c, hipEventCreate(&ev.b)); }
-      HIP_TRY(c, hipEventRecord(ev.a, s));
     }
-#define MRH_K_BACK(FREE, PROF)                                                                                                          \
+    // Profile mode: the event pair is attached to the launch itself (hipExtLaunchKernelGGL), so it holds the kernel's own
+    // begin / end timestamps — the duration rocprofv3 reports — instead of a hipEventRecord bracket, which adds the
+    // dispatch latency of a dependent launch (~3.5 us here) to every sample.
+#define MRH_K_BACK_V(FREE, PROF, SAFE)                                                                                                   \
   do {                                                                                                                                   \
-    if (safe_div) k_back<FREE, PROF, false, true><<<c->fused_grid, 256, lds, s>>>(k, m, t, f, L, parity, gc_thr, nullptr, nullptr, nullptr); \
-    else k_back<FREE, PROF, false, false><<<c->fused_grid, 256, lds, s>>>(k, m, t, f, L, parity, gc_thr, nullptr, nullptr, nullptr);         \
+    if (c->profile) hipExtLaunchKernelGGL((k_back<FREE, PROF, false, SAFE>), dim3(c->fused_grid), dim3(256), (uint32_t) lds, s, ev.a, ev.b, 0u, k, m, t, f, L,   \
+                                          parity, gc_thr, (const float*) nullptr, (const uint8_t*) nullptr, (u32*) nullptr);              \
+    else k_back<FREE, PROF, false, SAFE><<<c->fused_grid, 256, lds, s>>>(k, m, t, f, L, parity, gc_thr, nullptr, nullptr, nullptr);        \
   } while (0)
+#define MRH_K_BACK(FREE, PROF) do { if (safe_div) MRH_K_BACK_V(FREE, PROF, true); else MRH_K_BACK_V(FREE, PROF, false); } while (0)
     if (c->frame_gc_inline && c->profile) MRH_K_BACK(true, true);
     else if (c->frame_gc_inline) MRH_K_BACK(true, false);
     else MRH_K_BACK(false, false);
 #undef MRH_K_BACK
-    if (c->profile) {
-      HIP_TRY(c, hipEventRecord(ev.b, s));
-      c->ev_pending.push_back(ev);
-    }
+#undef MRH_K_BACK_V
+    if (c->profile) c->ev_pending.push_back(ev);
     return starve_and_tail(c, max_num_frames);
   }
 
