@@ -215,8 +215,8 @@ int mrh_set_points_device(mrh_ctx* ctx, const float* d_xyz, uint64_t n); /* zero
 int mrh_integrate_points(mrh_ctx* ctx, int n_frames_invalidate);
 
 /* ---- 3DGS splat seeds (BASELINE.json configs[4]) ----------------------------------------------
- * Replaces the initialisation half of GaussianContainer::runGS (gaussian_data_structures.cpp:170-186):
- * extractNodesQTree = CUDAQTree::subdivide (gaussian_data_structures.cpp:58-70, src/gs/quad_tree.cu:6-222) — a
+ * Replaces the initialisation half of GaussianContainer::runGS (gaussian_data_structures.cpp:140-157):
+ * extractNodesQTree = CUDAQTree::subdivide (gaussian_data_structures.cpp:48-68, src/gs/quad_tree.cu:6-223) — a
  * quad-tree over the CURRENT colour image, a node is a leaf when its luma-weighted colour MSE x (rows*cols / 9e7)
  * is <= qtree_thresh or a half of it would be <= qtree_min_pixel_size pixels wide/high — and checkNodes =
  * processNodesKernel (gaussian_data_structures.cu:5-84): a leaf whose centre pixel has depth >= min_depth and whose
@@ -241,7 +241,7 @@ typedef struct mrh_qtree_leaf {
 } mrh_qtree_leaf;
 
 int mrh_splat_seeds(mrh_ctx* ctx, float qtree_thresh, int qtree_min_pixel_size, const mrh_splat_seed** out_seeds, uint64_t* out_n);
-/* The leaves of the last mrh_splat_seeds call (CUDAQTree::getAllNodes, quad_tree.cuh:88-93).  Test / debug helper. */
+/* The leaves of the last mrh_splat_seeds call (CUDAQTree::getAllNodes, quad_tree.cuh:82-87).  Test / debug helper. */
 int mrh_get_qtree_leaves(mrh_ctx* ctx, const mrh_qtree_leaf** out_leaves, uint64_t* out_n);
 
 /* Blocks until every enqueued frame has executed; surfaces sticky device error flags as

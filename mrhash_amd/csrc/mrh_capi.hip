@@ -1183,7 +1183,7 @@ int mrh_sync(mrh_ctx* c) {
   return check_device_flags(c, flags);
 }
 
-// GaussianContainer::extractNodesQTree + checkNodes (gaussian_data_structures.cpp:58-70, .cu:58-84), see mrh_splat.h
+// GaussianContainer::extractNodesQTree + checkNodes (gaussian_data_structures.cpp:48-68, .cu:58-84), see mrh_splat.h
 int mrh_splat_seeds(mrh_ctx* c, float qtree_thresh, int qtree_min_pixel_size, const mrh_splat_seed** out, uint64_t* out_n) {
   int rc = ensure_ready(c, "mrh_splat_seeds");
   if (rc) return rc;
@@ -1199,7 +1199,7 @@ int mrh_splat_seeds(mrh_ctx* c, float qtree_thresh, int qtree_min_pixel_size, co
   if ((uint64_t) k.rows * (uint64_t) k.cols > (1ull << 22)) return fail(c, MRH_ERR_CAPACITY, "mrh_splat_seeds: image above 2^22 pixels");
   hipStream_t s = c->stream;
   // depth of the potential tree: the first level whose largest rectangle (the bottom-right chain of ceil halves) can
-  // no longer split (quad_tree.cu:126-141)
+  // no longer split (quad_tree.cu:133-149)
   QTree qt = {k.cols, k.rows, 0, qtree_min_pixel_size, 0};
   for (int w = k.cols, h = k.rows; qt.D < kQtMaxDepth && !(w / 2 <= qt.min_px || h / 2 <= qt.min_px); qt.D++) { w -= w / 2; h -= h / 2; }
   qt.total = qt_level_offset(qt.D + 1);

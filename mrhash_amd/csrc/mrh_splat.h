@@ -1,8 +1,8 @@
 // mrh_splat.h — 3DGS splat seeds: image quad-tree by colour error + one map lookup per leaf.
 //
-// Reference: CUDAQTree::subdivide (src/gs/quad_tree.cu:168-222) runs level by level — one 256-thread block per node
-// sums the node's pixels twice (computeError, :6-89), a second kernel appends leaves / children through atomic
-// counters (:91-166), the host reads the child count back and loops — then processNodesKernel
+// Reference: CUDAQTree::subdivide (src/gs/quad_tree.cu:169-223) runs level by level — one 256-thread block per node
+// sums the node's pixels twice (computeError, :6-90), a second kernel appends leaves / children through atomic
+// counters (:102-167), the host reads the child count back and loops — then processNodesKernel
 // (gaussian_data_structures.cu:5-56) looks the centre voxel of every leaf up.  ~20 dependent launches and host
 // round trips per frame, and the root alone is a 1 200-step serial chain per thread at 640x480.
 //
@@ -46,7 +46,7 @@ struct QTree {
 __host__ __device__ __forceinline__ u32 qt_level_offset(int l) { return ((1u << (2 * l)) - 1u) / 3u; }
 
 // child digits from the root, most significant first: bit 1 = right half (w2), bit 0 = bottom half (h2) — the order
-// subdivideKernel writes its four children in (quad_tree.cu:161-164)
+// subdivideKernel writes its four children in (quad_tree.cu:163-166)
 __device__ __forceinline__ QRect qt_rect(const QTree& q, int level, u32 path) {
   QRect r = {0, 0, q.W, q.H};
   for (int i = level - 1; i >= 0; i--) {
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void k_qt_sums_up(const QTree qt, QSum* __rest
 
 // ---- decision ------------------------------------------------------------------------------------------------
 
-// Error of a node as the reference defines it (quad_tree.cu:80-87), from the exact statistics, in fp64:
+// Error of a node as the reference defines it (quad_tree.cu:83-88), from the exact statistics, in fp64:
 //   mse_c = (n * Q_c - S_c^2) / n^2;  error = (0.2989 mse_r + 0.5870 mse_g + 0.1140 mse_b) * (W * H) / 9e7
 // and a bound on |fp32 value of computeError - exact value|.  With u = 2^-24, K = ceil(n / 256) terms per strided chain:
 //   mean:  8 tree additions + 1 division               |mean~ - mean| <= 9u * 255            < 1.4e-4
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256) void k_qt_decide(const QTree qt, const float t
   const int n = r.w * r.h;
   u32 flag;
   if (n == 0) flag = kQtDead;
-  else if (l == qt.D || r.w / 2 <= qt.min_px || r.h / 2 <= qt.min_px) flag = kQtLeaf;  // leaf whatever the error says (quad_tree.cu:131-141)
+  else if (l == qt.D || r.w / 2 <= qt.min_px || r.h / 2 <= qt.min_px) flag = kQtLeaf;  // leaf whatever the error says (quad_tree.cu:133-149)
   else {
     double err, band;
     qt_exact_error(qt, sums[i], n, err, band);
@@ -229,7 +229,7 @@ __device__ __forceinline__ float qt_error_wave(const uint8_t* __restrict__ rgb, 
   return error * norm / 90000000.0f;
 }
 
-// any node, the whole workgroup of 256 = computeError as written (quad_tree.cu:6-89)
+// any node, the whole workgroup of 256 = computeError as written (quad_tree.cu:6-90)
 __device__ __forceinline__ float qt_error_wg(const uint8_t* __restrict__ rgb, const int cols, const float norm, const QRect n,
                                              float (*sh)[kQtThreads]) {
   const int t = (int) threadIdx.x, count = n.w * n.h;

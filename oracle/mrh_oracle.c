@@ -42,7 +42,7 @@
  *       non-atomic read-modify-write per point, so the points of one scan that cross the same voxel
  *       race.  Canonical: every voxel receives its updates in ascending point index (the sequential
  *       loop of mrh_integrate_points).  norm3df(x, y, z) is restated as sqrtf((x*x + y*y) + z*z).
- *   D7  3DGS splat seeds (subdivideKernel quad_tree.cu:91-166, processNodesKernel
+ *   D7  3DGS splat seeds (subdivideKernel quad_tree.cu:102-167, processNodesKernel
  *       gaussian_data_structures.cu:5-56): the reference appends leaves, child nodes and seeds through
  *       atomic counters.  Canonical: leaves by tree level, inside a level in tree order (children in the
  *       order the reference writes them); seeds in leaf order.  Node errors keep the reference's
@@ -1710,12 +1710,12 @@ int mrh_get_free_blocks(mrh_ctx* c, int64_t* out_free_fine, int64_t* out_free_co
   return MRH_OK;
 }
 
-/* ---- 3DGS splat seeds: src/gs/quad_tree.cu:6-222, gaussian_data_structures.cu:5-84 ------------------------ */
+/* ---- 3DGS splat seeds: src/gs/quad_tree.cu:6-223, gaussian_data_structures.cu:5-84 ------------------------ */
 
 #define QT_THREADS 256          /* params.h:18 n_threads_subdivide: the block size fixes the summation order */
 #define QT_MAX_NODES 1000000u   /* params.h:20-23 max_num_qtree_nodes == qtree_leaves_capacity */
 
-/* CUDANode::computeError, quad_tree.cu:6-89: thread t sums the pixels t, t + 256, ... of the node (row-major inside
+/* CUDANode::computeError, quad_tree.cu:6-90: thread t sums the pixels t, t + 256, ... of the node (row-major inside
  * the node), the 256 partial sums are folded by a halving tree; the same again for the squared deviations. */
 static void qt_tree_fold(float s[3][QT_THREADS]) {
   for (int stride = QT_THREADS / 2; stride > 0; stride >>= 1)
@@ -1754,7 +1754,7 @@ static float qtree_node_error(const mrh_ctx* c, mrh_qtree_leaf n) {
   return error * (c->rgb_cols * c->rgb_rows) / 90000000.0f;
 }
 
-/* CUDAQTree::subdivide + subdivideKernel, quad_tree.cu:91-222, level by level (D7 order). */
+/* CUDAQTree::subdivide + subdivideKernel, quad_tree.cu:102-223, level by level (D7 order). */
 static int qtree_subdivide(mrh_ctx* c, float threshold, int min_pixel_size) {
   const size_t npix = (size_t) c->rgb_rows * c->rgb_cols;
   mrh_qtree_leaf* in = (mrh_qtree_leaf*) malloc(npix * sizeof *in);

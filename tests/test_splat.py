@@ -2,7 +2,7 @@
 
 The reference holds no test for CUDAQTree / processNodesKernel, so this part of the oracle is "parity unpinned"
 against reference output; it is pinned here against an independent numpy restatement of computeError's summation
-order (quad_tree.cu:6-89) and of the subdivision rule (:91-166), and through properties: the leaves tile the image,
+order (quad_tree.cu:6-90) and of the subdivision rule (:102-167), and through properties: the leaves tile the image,
 a uniform image is one leaf, every seed sits in a voxel of weight 1 and carries the centre pixel's colour."""
 import numpy as np
 import pytest
