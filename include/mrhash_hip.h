@@ -61,7 +61,7 @@ typedef struct mrh_params {
   float    sdf_truncation;            /* metres                                                          */
   float    sdf_truncation_scale;      /* truncation grows by scale * depth (vhu.cuh:184-187)             */
   int32_t  integration_weight_sample; /* per-observation weight (passed to kernels as u8, vds.cu:1101)   */
-  int32_t  integration_weight_max;    /* weight clamp, params.h:25 = 255                                 */
+  int32_t  integration_weight_max;    /* weight clamp, params.h:24 = 255                                 */
   float    virtual_voxel_size;        /* metres, finest voxel                                            */
   int32_t  n_frames_invalidate_voxels;/* 0 = no GC; >0 = GC every frame, starve every n-th frame         */
   int32_t  voxel_extents_scale;       /* only 1 is coherent in the reference (vhu.cuh:90-92 vs :138-140) */
@@ -201,7 +201,7 @@ int mrh_exchange_buffer(mrh_ctx* ctx, void** out_ptr, uint64_t* out_count_int64,
 int mrh_integrate_resume(mrh_ctx* ctx);
 
 /* ---- LiDAR scans (BASELINE.json configs[4]) --------------------------------------------------
- * Replaces GeoWrapper::setPointCloud (geowrapper.cpp:323-372, pybind/pygeowrapper.cpp:66-76: the point matrix is
+ * Replaces GeoWrapper::setPointCloud (geowrapper.cpp:345-405, pybind/pygeowrapper.cpp:66-76: the point matrix is
  * copied) and VoxelContainer::integrate(point_cloud, normals, weights, camera, max_num_frames)
  * (voxel_data_structures.cpp:112-135) = allocBlocks3D (vds.cu:925-1092) + integrate3D (vds.cu:1215-1410).
  * xyz: n points, sensor frame, float32 [n][3]; the pose is the one given to mrh_set_pose, the integration distance

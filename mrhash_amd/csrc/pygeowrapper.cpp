@@ -80,7 +80,7 @@ PYBIND11_MODULE(pygeowrapper, m) {
       g.setDepthImage(a.data(), (size_t) a.shape(0), (size_t) a.shape(1));
     })
     .def("setPointCloud", [](GeoWrapper& g, py::array_t<float, py::array::c_style | py::array::forcecast> pts, bool compute_normals) {
-      // geowrapper.cpp:323-372: [N, 3] points in the sensor frame (the runners pass points[:, :3]); copied
+      // geowrapper.cpp:345-405: [N, 3] points in the sensor frame (the runners pass points[:, :3]); copied
       if (pts.ndim() != 2) throw std::runtime_error("GeoWrapper::setPointCloud|input should be a 2D numpy array");
       if (pts.shape(1) < 3) throw std::runtime_error("GeoWrapper::setPointCloud|input should have at least 3 columns (x, y, z)");
       if (compute_normals) throw std::runtime_error("GeoWrapper::setPointCloud|normal estimation (MAD tree) is outside this library's scope");

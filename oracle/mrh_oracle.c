@@ -109,7 +109,7 @@ struct mrh_ctx {
   float* depth;
   uint8_t* rgb;
   int depth_rows, depth_cols, rgb_rows, rgb_cols;
-  float* points;       /* sensor-frame xyz of the current scan (GeoWrapper::setPointCloud, geowrapper.cpp:276-298) */
+  float* points;       /* sensor-frame xyz of the current scan (GeoWrapper::setPointCloud, geowrapper.cpp:345-405) */
   uint64_t num_points;
   f3* cloud;
   /* container: voxel_data_structures.cuh:63-100 */
