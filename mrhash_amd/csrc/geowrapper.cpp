@@ -230,9 +230,10 @@ void GeoWrapper::compute() {
     }
   }
   if (!point_cloud_.empty()) {  // geowrapper.cpp:146-147: VoxelContainer::integrate(point_cloud, eigenvectors, weights, ...)
-    if (!normals_.empty())
-      throw std::runtime_error("GeoWrapper::compute | normal-direction SDF (point cloud with normals) is outside this library's scope; "
-                               "pass the points only (projective SDF), as the reference's LiDAR runners do");
+    // With the projective SDF (every shipped configuration and runner) the reference only normalises the normals and
+    // never uses them (vds.cu:1236, :1245-1251): normals passed along with the points are accepted and ignored.  The
+    // normal-direction SDF itself is rejected by mrh_integrate_points (the reference's own caller-supplied-normals path
+    // indexes the normal array by 3 * point, vds.cu:1229, past the end of what setPointCloud(points, normals) stores).
     check(mrh_upload_points(ctx_, point_cloud_.data(), point_cloud_.size() / 3), "compute");
     check(mrh_integrate_points(ctx_, n_frames_invalidate_voxels_), "compute");
   }

@@ -128,11 +128,14 @@ def test_lidar_runner_call_sequence_matches_oracle(geowrapper_cls, oracle, tmp_p
     b = capi.Engine(oracle, capi.Params(num_sdf_blocks=32768, **p))
     b.set_camera(1.0, 1.0, 0.0, 0.0, 1, 1, 0.2, 100.0, model=1)
     scene = synth.street_canyon()
-    for t, q in synth.drive_poses(3, step=2.0):
+    for k, (t, q) in enumerate(synth.drive_poses(3, step=2.0)):
         pts = synth.lidar_scan(scene, t, q, rows=16, cols=256)
         with_intensity = np.concatenate([pts, np.ones((len(pts), 1), np.float32)], axis=1)  # x y z i, as read from a bag
         g.setCurrPose(t, q)
-        g.setPointCloud(with_intensity[:, :3], False)
+        if k == 1:  # the (points, normals) overload: with the projective SDF the normals are not used
+            g.setPointCloud(with_intensity[:, :3], np.tile(np.array([[0, 0, 1]], np.float32), (len(pts), 1)))
+        else:
+            g.setPointCloud(with_intensity[:, :3], False)
         g.compute()
         b.set_pose(synth.quat_to_rot(q), t)
         b.upload_points(pts)
