@@ -1,10 +1,10 @@
 """One-off soak on the GPU box: the randomised parity tests with many more seeds than the test suite runs.
-usage: python tools/soak.py [first_seed] [n]"""
+usage: python tests/soak.py [first_seed] [n]"""
 import os
 import sys
 import time
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import parity_utils as pu  # noqa: E402
 import test_lidar_gpu as tl  # noqa: E402

@@ -6,16 +6,20 @@ import numpy as np
 
 sys.path.insert(0, ".")
 from mrhash_amd import capi, synth  # noqa: E402
-from tests import parity_utils as pu  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 hip = capi.load_hip()
 K = synth.REPLICA_640
-e = pu.make_engine(hip, K, synth.REPLICA_PARAMS, num_sdf_blocks=262144)
+_p = capi.Params(num_sdf_blocks=262144, **synth.REPLICA_PARAMS)
+e = capi.Engine(hip, _p)
+e.set_camera(K.fx, K.fy, K.cx, K.cy, K.rows, K.cols, _p.min_depth, _p.max_depth)
 frames = list(synth.replica_stream(n))
 ts, counts = [], []
 for f in frames:
-    pu.feed(e, f)
+    e.set_pose(f.R, f.t)
+    e.upload_depth(f.depth)
+    e.upload_rgb(f.rgb)
+    e.integrate()
     e.sync()
     t0 = time.perf_counter()
     s = e.splat_seeds(0.1, 1)
