@@ -124,10 +124,9 @@ struct mrh_ctx {
   u64* d_upd_partials = nullptr;
   u32* d_misc = nullptr;  // 4 words for k_get_voxel
   float* d_rcp_w = nullptr;  // Fast::rcp_w
-  Fast fast;              // single-resolution fast path buffers (depth_clean / rgbx point at the current frame's pair)
+  Fast fast;              // fast path buffers
   size_t fast_npix = 0;
-  float* dc_buf = nullptr;   // cleaned depth / packed colour of the current frame (written by k_front)
-  u32* rgbx_buf = nullptr;
+  uint2* dcx_buf = nullptr;  // {cleaned depth, packed colour} of the current frame (written by k_front)
   int4* d_cfree = nullptr;
   // LiDAR scan of the current frame (mrh_lidar.h)
   float* d_points = nullptr;        // owned copy (mrh_upload_points) ...
@@ -226,7 +225,7 @@ void free_all(mrh_ctx* c) {
   if (c->copy_stream) { (void) hipStreamSynchronize(c->copy_stream); (void) hipStreamDestroy(c->copy_stream); }
   if (c->stream) (void) hipStreamSynchronize(c->stream);
   auto F = [](void* p) { if (p) (void) hipFree(p); };
-  F(c->dc_buf); F(c->rgbx_buf);
+  F(c->dcx_buf);
   F(c->tab.keys); F(c->tab.vals); F(c->tab.heap_fine); F(c->tab.heap_coarse); F(c->tab.desc_fine); F(c->tab.desc_coarse);
   F(c->tab.pool); F(c->tab.compact); F(c->tab.ctr); F(c->tab.prof);
   for (UpRing* r : {&c->up_depth, &c->up_rgb})
@@ -915,15 +914,12 @@ static int integrate_frame(mrh_ctx* c, int n_frames_invalidate) {
     const int tiles_x = (k.cols + kRayTile - 1) / kRayTile, tiles_y = (k.rows + kRayTile - 1) / kRayTile;
     if (c->fast_npix < npix) {
       HIP_TRY(c, hipStreamSynchronize(s));
-      if (c->dc_buf) HIP_TRY(c, hipFree(c->dc_buf));
-      if (c->rgbx_buf) HIP_TRY(c, hipFree(c->rgbx_buf));
-      c->dc_buf = nullptr; c->rgbx_buf = nullptr;
-      HIP_TRY(c, hipMalloc((void**) &c->dc_buf, npix * sizeof(float)));
-      HIP_TRY(c, hipMalloc((void**) &c->rgbx_buf, npix * sizeof(u32)));
+      if (c->dcx_buf) HIP_TRY(c, hipFree(c->dcx_buf));
+      c->dcx_buf = nullptr;
+      HIP_TRY(c, hipMalloc((void**) &c->dcx_buf, npix * sizeof(uint2)));
       c->fast_npix = npix;
     }
-    c->fast.depth_clean = c->dc_buf;
-    c->fast.rgbx = c->rgbx_buf;
+    c->fast.dcx = c->dcx_buf;
     const Fast& f = c->fast;
     const int parity = (int) (c->fast_frames & 1);
     c->frame_parity = parity;

@@ -17,8 +17,8 @@ constexpr float kFltMax = 3.402823466e+38f;
 constexpr int kTileMaxPx = 576;  // LDS depth+colour tile per wave: 576 px x 8 B = 4.5 KiB (24 x 24 px: blocks beyond ~1.2 m)
 
 struct Fast {
-  float* depth_clean;  // [rows*cols] depth if in (min_depth, max_depth] else 0
-  u32* rgbx;           // [rows*cols] r | g << 8 | b << 16
+  uint2* dcx;          // [rows*cols] {bits of the cleaned depth (depth if in (min_depth, max_depth] else 0), r | g << 8 | b << 16}:
+                       // one 8-byte access per pixel, and exactly the element of k_back's LDS footprint tile
   uint2* summary;      // [cap_blocks] {bits of min |sdf| over weighted voxels (FLT_MAX if none), max weight}
   u32 compact_cap;     // entries in Tab::compact
   int4* bbox;          // [compact_cap] per VISIBLE compact entry: pixel footprint {col0, row0, w, h}; w == 0: none
@@ -201,8 +201,9 @@ __device__ __forceinline__ void tile_issue(const Cam& c, const Fast& f, const in
     const int r = (int) (((float) p + 0.5f) * inv_w);
     const int cc = p - r * bb.z;
     const u32 g = (u32) (__mul24(bb.y + r, c.cols) + bb.x + cc);
-    tr.dv[j] = f.depth_clean[g];
-    tr.cv[j] = f.rgbx[g];
+    const uint2 v = f.dcx[g];
+    tr.dv[j] = __uint_as_float(v.x);
+    tr.cv[j] = v.y;
   }
 }
 __device__ __forceinline__ float tile_commit(const Cam& c, const Map& m, const Fast& f, const int4 bb, const int lane, uint2* tile,
@@ -228,8 +229,9 @@ __device__ __forceinline__ float tile_commit(const Cam& c, const Map& m, const F
         const int r = (int) (((float) p + 0.5f) * inv_w);
         const int cc = p - r * bb.z;
         const u32 g = (u32) (__mul24(bb.y + r, c.cols) + bb.x + cc);
-        dv[j] = f.depth_clean[g];
-        cv[j] = f.rgbx[g];
+        const uint2 v = f.dcx[g];
+        dv[j] = __uint_as_float(v.x);
+        cv[j] = v.y;
       }
 #pragma unroll
       for (int j = 0; j < 2; j++) {
@@ -273,8 +275,9 @@ __device__ __forceinline__ void tile_lookup(const Fast& f, const int cols, const
       for (int k = 0; k < 4; k++)
         if ((miss >> (b * 4 + k)) & 1u) {
           const u32 pix = (u32) (__mul24(P[b].row[k], cols) + P[b].col[k]);  // miss implies the voxel is in the image
-          d[b][k] = f.depth_clean[pix];
-          cpx[b][k] = f.rgbx[pix];
+          const uint2 v = f.dcx[pix];
+          d[b][k] = __uint_as_float(v.x);
+          cpx[b][k] = v.y;
         }
   }
 }
@@ -296,7 +299,7 @@ __global__ __launch_bounds__(256) void k_count_updates(const Cam c, const Map m,
       const Proj4 P = project4(c, m, ent, lane + 64 * b);
       float d[4];
 #pragma unroll
-      for (int k = 0; k < 4; k++) d[k] = f.depth_clean[((P.mask >> k) & 1u) ? (u32) (__mul24(P.row[k], c.cols) + P.col[k]) : 0u];
+      for (int k = 0; k < 4; k++) d[k] = __uint_as_float(f.dcx[((P.mask >> k) & 1u) ? (u32) (__mul24(P.row[k], c.cols) + P.col[k]) : 0u].x);
       cnt += __popc(update_mask4(c, m, P, d));
     }
   }

@@ -89,9 +89,8 @@ __device__ __forceinline__ void front_tile(const Cam& c, const Map& m, const Tab
     const size_t pix = (size_t) row * c.cols + col;
     float d = depth[pix];
     if (d <= c.min_depth || d > c.max_depth) d = 0.f;  // camera.cu:13-18
-    f.depth_clean[pix] = d;
     const uint8_t* px = rgb + pix * 3;
-    f.rgbx[pix] = (u32) px[0] | ((u32) px[1] << 8) | ((u32) px[2] << 16);
+    f.dcx[pix] = make_uint2(__float_as_uint(d), (u32) px[0] | ((u32) px[1] << 8) | ((u32) px[2] << 16));
     // hot path: keys into the LDS set; anything rare (set saturated by far, sparse rays; keys out of range) is left to
     // the literal walk below, outside the loop every lane runs
     const RayState ray = ray_setup(c, m, row, col, d);
