@@ -133,6 +133,25 @@ def main():
     st = eng.stats()
     occupied = int(st.occupied_fine)
 
+    # ---- optional pass C: the boundary as the reference uses it (host buffers -> mrh_upload_depth / mrh_upload_rgb each frame).
+    # Runs BEFORE the profiled pass: launches that carry start / stop events switch the queue to profiling mode, which
+    # slows every later dispatch of the process.
+    pcie_fps = None
+    if args.pcie:
+        pe = capi.Engine(hip, params)
+        pe.set_camera(Kc.fx, Kc.fy, Kc.cx, Kc.cy, Kc.rows, Kc.cols, params.min_depth, params.max_depth)
+        for i in range(W):
+            f = frames[i]
+            pe.set_pose(f.R, f.t); pe.upload_depth(f.depth); pe.upload_rgb(f.rgb); pe.integrate()
+        pe.sync()
+        t2 = time.perf_counter()
+        for i in range(W, total):
+            f = frames[i]
+            pe.set_pose(f.R, f.t); pe.upload_depth(f.depth); pe.upload_rgb(f.rgb); pe.integrate()
+        pe.sync()
+        pcie_fps = K / (time.perf_counter() - t2)
+        pe.close()
+
     # ---- pass B: same frames, HIP events around every integrate-kernel launch + device-side U/M counters ---
     eng.reset()
     run(eng, 0, W)
@@ -152,23 +171,6 @@ def main():
     alg_bytes = 24.0 * U + 24.0 * M + img_bytes  # 12 B read + 12 B write per updated voxel
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
     eng.close()
-
-    # ---- optional pass C: the boundary as the reference uses it (host buffers -> mrh_upload_depth / mrh_upload_rgb each frame)
-    pcie_fps = None
-    if args.pcie:
-        eng = capi.Engine(hip, params)
-        eng.set_camera(Kc.fx, Kc.fy, Kc.cx, Kc.cy, Kc.rows, Kc.cols, params.min_depth, params.max_depth)
-        for i in range(W):
-            f = frames[i]
-            eng.set_pose(f.R, f.t); eng.upload_depth(f.depth); eng.upload_rgb(f.rgb); eng.integrate()
-        eng.sync()
-        t2 = time.perf_counter()
-        for i in range(W, total):
-            f = frames[i]
-            eng.set_pose(f.R, f.t); eng.upload_depth(f.depth); eng.upload_rgb(f.rgb); eng.integrate()
-        eng.sync()
-        pcie_fps = K / (time.perf_counter() - t2)
-        eng.close()
 
     # ---- CPU baseline: the oracle on a bounded sample of the same stream (rank 0, N == 1) ------------------
     cpu = None
