@@ -6,6 +6,9 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <sys/mman.h>
+#if !defined(__HIP_DEVICE_COMPILE__)
+#include <immintrin.h>
+#endif
 
 #include <algorithm>
 #include <array>
@@ -769,6 +772,27 @@ int mrh_set_pose(mrh_ctx* c, const float R[9], const float t[3]) {
 
 namespace {
 
+// Host copy into pinned staging with non-temporal stores: the destination is read next by the DMA engine, not by this
+// core, so write-allocating it through the cache only costs bandwidth (tools/micro/staging_copy.hip: 1.2 MB in 28.5 us
+// vs 40.9 us with memcpy, cold pageable source).
+#if !defined(__HIP_DEVICE_COMPILE__)
+__attribute__((target("avx2"))) void copy_streaming_avx2(void* dst, const void* src, size_t n) {
+  const __m256i* s = (const __m256i*) src;
+  __m256i* d = (__m256i*) dst;  // pinned allocations are page-aligned
+  const size_t v = n / 32;
+  for (size_t i = 0; i < v; i++) _mm256_stream_si256(d + i, _mm256_loadu_si256(s + i));
+  _mm_sfence();
+  if (n & 31) memcpy((char*) dst + v * 32, (const char*) src + v * 32, n & 31);
+}
+void copy_to_staging(void* dst, const void* src, size_t n) {
+  static const bool avx2 = __builtin_cpu_supports("avx2");
+  if (avx2 && n >= (64u << 10) && ((uintptr_t) dst & 31) == 0) copy_streaming_avx2(dst, src, n);
+  else memcpy(dst, src, n);
+}
+#else
+void copy_to_staging(void* dst, const void* src, size_t n);
+#endif
+
 // one host image into the next slot of its ring: wait until the slot is free, copy into pinned staging (the caller's
 // buffer is free on return), enqueue the H2D on the copy stream
 int upload_image(mrh_ctx* c, UpRing& ring, const void* src, const size_t bytes, const void** out_dev) {
@@ -789,7 +813,7 @@ int upload_image(mrh_ctx* c, UpRing& ring, const void* src, const size_t bytes, 
     u.cap = bytes;
     if (!u.copied) HIP_TRY(c, hipEventCreateWithFlags(&u.copied, hipEventDisableTiming));
   }
-  memcpy(u.h, src, bytes);
+  copy_to_staging(u.h, src, bytes);
   HIP_TRY(c, hipMemcpyAsync(u.d, u.h, bytes, hipMemcpyHostToDevice, c->copy_stream));
   HIP_TRY(c, hipEventRecord(u.copied, c->copy_stream));
   u.copied_rec = true;
