@@ -43,8 +43,9 @@ def test_param_struct_sizes_match_header():
         #include <stddef.h>
         #include "mrhash_hip.h"
         int main(void) {
-          printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(mrh_params), offsetof(mrh_params, num_sdf_blocks), offsetof(mrh_params, shard_count),
-                 sizeof(mrh_stats), offsetof(mrh_stats, error_flags), sizeof(mrh_voxel), sizeof(mrh_triangle));
+          printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(mrh_params), offsetof(mrh_params, num_sdf_blocks), offsetof(mrh_params, shard_count),
+                 sizeof(mrh_stats), offsetof(mrh_stats, error_flags), sizeof(mrh_voxel), sizeof(mrh_triangle), sizeof(mrh_splat_seed),
+                 offsetof(mrh_splat_seed, rgb), sizeof(mrh_qtree_leaf), sizeof(mrh_block_desc));
           return 0;
         }"""
     )
@@ -56,7 +57,8 @@ def test_param_struct_sizes_match_header():
         out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout.split()
     got = [int(x) for x in out]
     want = [C.sizeof(capi.MrhParams), capi.MrhParams.num_sdf_blocks.offset, capi.MrhParams.shard_count.offset,
-            C.sizeof(capi.MrhStats), capi.MrhStats.error_flags.offset, 12, 72]
+            C.sizeof(capi.MrhStats), capi.MrhStats.error_flags.offset, 12, 72, capi.SEED_DTYPE.itemsize, capi.SEED_DTYPE.fields["rgb"][1],
+            capi.LEAF_DTYPE.itemsize, capi.DESC_DTYPE.itemsize]
     assert got == want
 
 
