@@ -75,7 +75,7 @@ __device__ __forceinline__ void front_tile(const Cam& c, const Map& m, const Tab
   if (tid == 0) { sh.count = 0; sh.inserted = 0; }
   __syncthreads();
   MRH_TSF(1);
-  // a new block is listed without a pixel footprint (k_back / k_post derive it): a few hundred blocks per frame, not
+  // a new block is listed without a pixel footprint (k_back derives it): a few hundred blocks per frame, not
   // worth 8 serial corner projections on the allocation workgroup's critical path.  If no voxel of it lands in the
   // image it stays at weight 0 and is collected, exactly what GC does with it in the reference.
   auto list_new = [&](const int4 ent) {  // single lane
