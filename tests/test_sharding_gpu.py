@@ -48,3 +48,49 @@ def test_two_rank_mesh_equals_single_context_hip(hip, tmp_path):
     assert int(got["n_halo"]) > 0
     assert np.array_equal(got["tris"], t.view(np.uint8))
     assert np.array_equal(got["F"], F) and np.array_equal(got["V"], V)
+
+
+def test_lidar_and_splat_seeds_on_tile_shards_hip(hip):
+    """Tile sharding beyond the RGB-D path: LiDAR scans (allocation inserts owned blocks only, the per-voxel updates find
+    only local blocks) and splat seeds (a seed needs the centre voxel, which exactly one shard holds): the union over the
+    shards equals the single-context result."""
+    from mrhash_amd import capi
+
+    # LiDAR
+    p = dict(synth.VBR_PARAMS, min_weight_threshold=1)
+
+    def lidar_engine(**extra):
+        e = capi.Engine(hip, capi.Params(num_sdf_blocks=32768, **p, **extra))
+        e.set_camera(1.0, 1.0, 0.0, 0.0, 1, 1, 0.2, 100.0, model=1)
+        return e
+
+    single = lidar_engine()
+    shards = [lidar_engine(shard_rank=r, shard_count=2, shard_chunk_log2=1) for r in range(2)]
+    scene = synth.street_canyon()
+    for t, q in synth.drive_poses(2, step=2.0):
+        pts = synth.lidar_scan(scene, t, q, rows=16, cols=256)
+        for e in [single] + shards:
+            e.set_pose(synth.quat_to_rot(q), t)
+            e.upload_points(pts)
+            e.integrate_points()
+    d0, v0 = single.dump_blocks()
+    parts = [s.dump_blocks() for s in shards]
+    assert all(len(pp[0]) > 50 for pp in parts)
+    d = np.concatenate([pp[0] for pp in parts])
+    v = np.concatenate([pp[1] for pp in parts])
+    order = np.lexsort((d["z"], d["y"], d["x"]))
+    assert np.array_equal(d[order], d0) and np.array_equal(v[order].view(np.uint8), v0.view(np.uint8))
+    # splat seeds
+    params = dict(synth.CFG1_PARAMS)
+    single = pu.make_engine(hip, synth.CFG1, params, 16384)
+    shards = [pu.make_engine(hip, synth.CFG1, params, 16384, shard_rank=r, shard_count=2, shard_chunk_log2=1) for r in range(2)]
+    f = synth.cfg1_sphere()
+    for e in [single] + shards:
+        pu.feed(e, f)
+    s0 = single.splat_seeds(0.0025, 1)
+    ss = [e.splat_seeds(0.0025, 1) for e in shards]
+    assert all(len(x) > 0 for x in ss) and sum(len(x) for x in ss) == len(s0) > 100
+    both = np.concatenate(ss)
+    key = lambda a: np.lexsort((a["p"][:, 2], a["p"][:, 1], a["p"][:, 0], a["scale"]))  # noqa: E731
+    assert both[key(both)].tobytes() == s0[key(s0)].tobytes()
+    assert np.array_equal(single.qtree_leaves(), shards[0].qtree_leaves())  # the tree depends on the image only
