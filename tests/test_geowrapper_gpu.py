@@ -147,7 +147,8 @@ def test_lidar_runner_call_sequence_matches_oracle(geowrapper_cls, oracle, tmp_p
     assert np.array_equal(g.getVertices(), Vb) and np.array_equal(g.getFaces(), Fb)
 
 
-def test_streamer_pages_far_blocks_out_and_back(monkeypatch, tmp_path):
+@pytest.mark.parametrize("var_threshold", [0.0, 0.02])
+def test_streamer_pages_far_blocks_out_and_back(monkeypatch, tmp_path, var_threshold):
     """Streamer: with a pool too small for the whole walk, compute() pages blocks farther than max_depth
     from the camera out to the host chunk grid (free blocks <= 15 % of the pool, geowrapper.cpp:137-138) and back in
     when the camera returns; extractMesh sees the whole map.  Paging is transparent: the mesh equals the one of a run
@@ -157,7 +158,7 @@ def test_streamer_pages_far_blocks_out_and_back(monkeypatch, tmp_path):
     K = sy.Intrinsics(160.0, 160.0, 79.5, 59.5, 120, 160)
     kw = dict(sdf_truncation=0.08, sdf_truncation_scale=0.0, integration_weight_sample=1, virtual_voxel_size=0.02,
               n_frames_invalidate_voxels=1000, voxel_extents_scale=1, viewer_active=False, marching_cubes_threshold=1.5,
-              min_weight_threshold=1, min_depth=0.01, max_depth=2.0)
+              min_weight_threshold=1, min_depth=0.01, max_depth=2.0, sdf_var_threshold=var_threshold)
     scene = sy.Scene(sy.Box((-0.6, -0.6, -9.0), (0.6, 0.6, 9.0)), seed=3)  # a corridor: walk along z, then come back
     zs = list(np.arange(-6.0, 6.01, 0.25)) + list(np.arange(5.75, -6.01, -0.25))
     poses = [(np.array([0.0, 0.0, z], np.float32), np.array([0, 0, 0, 1], np.float32)) for z in zs]
