@@ -585,3 +585,34 @@ def test_upload_ring_semantics(hip, oracle):
     pu.compare_maps(a, b)
     a.close()
     b.close()
+
+
+def test_contexts_release_their_device_memory(hip):
+    """Create / use / destroy in a loop (uploads, frames, seeds, extraction — every lazily allocated buffer gets
+    allocated): the free device memory afterwards is what it was before."""
+    import torch
+
+    K = synth.CFG1
+    f = synth.cfg1_sphere()
+
+    def cycle():
+        e = pu.make_engine(hip, K, dict(synth.CFG1_PARAMS, n_frames_invalidate_voxels=2), 32768)
+        for _ in range(3):
+            pu.feed(e, f)
+        e.splat_seeds(0.0025, 1)
+        e.peek_free_blocks()
+        pu.feed(e, f)
+        e.extract_triangles()
+        e.extract_mesh()
+        e.stream_out((0.0, 0.0, 0.0), -1.0)
+        e.close()
+
+    for _ in range(3):  # the first uses pay one-off runtime allocations (code objects, queues, scratch)
+        cycle()
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(25):
+        cycle()
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 32 << 20, f"device memory shrank by {(free0 - free1) >> 20} MiB over 25 create/destroy cycles"
