@@ -501,7 +501,7 @@ int frame_tail(mrh_ctx* c, bool starved, int max_num_frames) {
   const Tab& t = c->tab;
   const float thr = m.trunc + m.trunc_scale * k.max_depth;  // getTruncation(camera.maxDepth(), ...), vds.cu:1720
   if (!t.multi_res) {
-    if (starved) k_summarize_all<<<1024, 256, 0, s>>>(t, c->fast);  // weights changed: the GC summaries follow the payload
+    if (starved) k_summarize_visible<<<1024, 256, 0, s>>>(t, c->fast);  // weights changed: the GC summaries follow the payload
     if (max_num_frames > 0 && !c->frame_gc_inline) {
       const Lists L = {t.compact, c->fast.bbox, c->d_cfree, c->d_zmin, (u32) c->num_blocks};
       k_free_lists<<<256, 256, 0, s>>>(t, c->fast, L, c->frame_parity, thr);

@@ -706,6 +706,28 @@ __global__ __launch_bounds__(256) void k_mr_tail(const Tab t, const u32* __restr
   }
 }
 
+// GC summaries of the blocks on this frame's visible list (single-resolution maps): after the starve step, which only
+// decrements weights of voxels of exactly those blocks (k_starve walks compact[0 .. CTR_COMPACT)) — every other block's
+// summary still describes its payload
+__global__ __launch_bounds__(256) void k_summarize_visible(const Tab t, const Fast f) {
+  const int n = t.ctr[CTR_COMPACT];
+  const int lane = threadIdx.x & 63;
+  const int gw = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
+  for (int e = gw; e < n; e += nw) {
+    const u32 H = (u32) t.compact[e].w;
+    const VoxPtr vp = vox_ptr(t, H);
+    u32 mnb = 0x7F7FFFFFu, mx = 0;
+    for (int v = lane; v < 512; v += 64) {
+      const u32 wk = vp.rgbw[v] >> 24;
+      mnb = umin_(mnb, wk != 0 ? (__float_as_uint(vp.sdf[v]) & 0x7FFFFFFFu) : 0xFFFFFFFFu);
+      mx = umax_(mx, wk);
+    }
+    mnb = wave_min_u32(mnb);
+    mx = wave_max_u32(mx);
+    if (lane == 0) f.summary[H] = make_uint2(mnb, mx);
+  }
+}
+
 // GC summaries of every live block and coarse unit from their payload (one wave each): run once when the fused
 // multi-resolution path takes over from frames that went through the general kernels (mrh_kernels.h)
 __global__ __launch_bounds__(256) void k_summarize_all(const Tab t, const Fast f) {
