@@ -1415,7 +1415,9 @@ int mrh_extract_triangles(mrh_ctx* c, const mrh_triangle** out_tris, uint64_t* o
     HIP_TRY(c, d_offsets.alloc((size_t) n));
     HIP_TRY(c, d_per_voxel.alloc((size_t) n * 512));
     const int grid = n < 4096 ? n : 4096;
-    k_mc<false><<<grid, 512, 0, s>>>(c->map, c->tab, c->tab.compact, n, d_counts, nullptr, nullptr, 0, d_per_voxel);
+    // largest truncation a stored sample can carry (integration clamps to trunc + scale * depth, depth <= the integration distance)
+    const float sdf_bound = c->has_camera && !getenv("MRH_MC_NO_PRESCREEN") ? c->map.trunc + c->map.trunc_scale * c->cam.max_int_dist : 0.f;
+    k_mc<false><<<grid, 512, 0, s>>>(c->map, c->tab, c->tab.compact, n, d_counts, nullptr, nullptr, 0, d_per_voxel, sdf_bound);
     std::vector<u32> counts((size_t) n);
     HIP_TRY(c, hipMemcpyAsync(counts.data(), d_counts, (size_t) n * sizeof(u32), hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
@@ -1433,7 +1435,7 @@ int mrh_extract_triangles(mrh_ctx* c, const mrh_triangle** out_tris, uint64_t* o
       DevBuf<mrh_triangle> d_tris;
       HIP_TRY(c, d_tris.alloc(total));
       HIP_TRY(c, hipMemcpyAsync(d_offsets, offsets.data(), (size_t) n * sizeof(u64), hipMemcpyHostToDevice, s));
-      k_mc<true><<<grid, 512, 0, s>>>(c->map, c->tab, c->tab.compact, n, d_counts, d_offsets, d_tris, total, d_per_voxel);
+      k_mc<true><<<grid, 512, 0, s>>>(c->map, c->tab, c->tab.compact, n, d_counts, d_offsets, d_tris, total, d_per_voxel, 0.f);
       if (dbg) { HIP_TRY(c, hipStreamSynchronize(s)); t3 = now(); }
       if (want_soup) {
         c->tris.resize_discard(total);

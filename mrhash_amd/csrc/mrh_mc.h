@@ -223,9 +223,18 @@ __device__ __forceinline__ int mc_voxel(const Map& m, const Tab& t, const Neigh&
 template <bool EMIT>
 __global__ __launch_bounds__(512) void k_mc(const Map m, const Tab t, const int4* __restrict__ sorted, const int n,
                                             u32* __restrict__ counts, const u64* __restrict__ offsets,
-                                            mrh_triangle* __restrict__ out, const u64 max_tris, uint8_t* __restrict__ per_voxel) {
+                                            mrh_triangle* __restrict__ out, const u64 max_tris, uint8_t* __restrict__ per_voxel,
+                                            const float sdf_bound) {
   __shared__ u32 s_wave[8];
   __shared__ u32 s_nb[27];
+  // Count pass, single-resolution maps: sign class of the 10^3 cells around the block (1: weighted and clearly positive,
+  // 2: weighted and clearly negative, 0: anything else).  Everything marching cubes evaluates for a voxel — the eight
+  // trilinear corner values, or the raw sample a corner falls back to — is built from the 3^3 cells around it, the
+  // trilinear value is a convex combination of them (fp32 evaluation error < 2e-5 x the largest magnitude), so if all 27
+  // are of one class every corner has that sign, the cube index is 0 or 255 and the voxel has no triangle: it is not
+  // evaluated at all.  "Clearly" = 1e-3 x sdf_bound <= |sdf| <= 1.001 x sdf_bound, sdf_bound = the largest truncation a
+  // sample can carry; anything outside (or NaN) is class 0 and takes the full path.
+  __shared__ uint8_t s_cls[1000];
   const int v = threadIdx.x;
   const int wave = v >> 6;
   for (int e = blockIdx.x; e < n; e += gridDim.x) {
@@ -247,6 +256,25 @@ __global__ __launch_bounds__(512) void k_mc(const Map m, const Tab t, const int4
       __syncthreads();
       nb.vals = s_nb;
     }
+    const int amax = max(max(abs(ent.x), abs(ent.y)), abs(ent.z));
+    const bool prescreen = !EMIT && !t.multi_res && sdf_bound > 0.f && (amax + 2) * kBlockSide < m.block_shift_limit;  // uniform
+    if (prescreen) {
+      const float lo = 1e-3f * sdf_bound, hi = 1.001f * sdf_bound;
+      for (int cidx = v; cidx < 1000; cidx += 512) {
+        const int lx = cidx % 10 - 1, ly = (cidx / 10) % 10 - 1, lz = cidx / 100 - 1;  // voxel coordinates relative to the block, -1 .. 8
+        const int bx = lx < 0 ? 0 : (lx > 7 ? 2 : 1), by = ly < 0 ? 0 : (ly > 7 ? 2 : 1), bz = lz < 0 ? 0 : (lz > 7 ? 2 : 1);
+        const u32 nval = s_nb[bz * 9 + by * 3 + bx];
+        uint8_t cls = 0;
+        if (nval != kNbAbsent) {
+          const VoxPtr vp = vox_ptr(t, nval);
+          const u32 li = (u32) ((lz & 7) * 64 + (ly & 7) * 8 + (lx & 7));
+          const float sv = vp.sdf[li];
+          if ((vp.rgbw[li] >> 24) != 0) cls = (sv >= lo && sv <= hi) ? 1 : ((sv <= -lo && sv >= -hi) ? 2 : 0);
+        }
+        s_cls[cidx] = cls;
+      }
+      __syncthreads();
+    }
     int ntri = 0;
     mrh_triangle tris[5];
     const bool skip = EMIT && per_voxel[(size_t) e * 512 + v] == 0;
@@ -255,7 +283,19 @@ __global__ __launch_bounds__(512) void k_mc(const Map m, const Tab t, const int4
       i3 pi;
       if (!coarse) pi = mki3(ent.x * kBlockSide + (v & 7), ent.y * kBlockSide + ((v >> 3) & 7), ent.z * kBlockSide + (v >> 6));
       else pi = mki3(ent.x * kBlockSide + 2 * (v & 3), ent.y * kBlockSide + 2 * ((v >> 2) & 3), ent.z * kBlockSide + 2 * (v >> 4));
-      ntri = mc_voxel<EMIT>(m, t, nb, voxel_to_world(m.vs, pi), tris);
+      bool empty = false;
+      if (prescreen) {
+        u32 acc = 3u;
+        const int x = v & 7, y = (v >> 3) & 7, z = v >> 6;
+#pragma unroll
+        for (int dz = 0; dz < 3; dz++)
+#pragma unroll
+          for (int dy = 0; dy < 3; dy++)
+#pragma unroll
+            for (int dx = 0; dx < 3; dx++) acc &= s_cls[(z + dz) * 100 + (y + dy) * 10 + (x + dx)];
+        empty = acc != 0u;  // all 27 cells positive, or all 27 negative
+      }
+      if (!empty) ntri = mc_voxel<EMIT>(m, t, nb, voxel_to_world(m.vs, pi), tris);
     }
     if (!EMIT) per_voxel[(size_t) e * 512 + v] = (uint8_t) ntri;
     // block-wide exclusive scan of ntri in voxel-index order: wave scan + 8 wave totals through LDS
