@@ -587,6 +587,22 @@ def test_upload_ring_semantics(hip, oracle):
     b.close()
 
 
+def test_marching_cubes_prescreen_changes_nothing(hip, monkeypatch):
+    """The count pass skips voxels whose 27 surrounding cells are all clearly positive or all clearly negative; with
+    the prescreen off (MRH_MC_NO_PRESCREEN=1) every voxel takes the full path: same triangle buffer, byte for byte —
+    also with a range-dependent truncation and with noise that puts samples near zero."""
+    K = synth.REPLICA_640
+    params = dict(synth.REPLICA_PARAMS, sdf_truncation_scale=0.01, min_weight_threshold=1)
+    e = pu.make_engine(hip, K, params, 65536)
+    for f in synth.replica_stream(3, noise_sigma=0.004):
+        pu.feed(e, f)
+    on = e.extract_triangles()
+    monkeypatch.setenv("MRH_MC_NO_PRESCREEN", "1")
+    off = e.extract_triangles()
+    assert on.shape[0] > 20000 and on.tobytes() == off.tobytes()
+    e.close()
+
+
 def test_contexts_release_their_device_memory(hip):
     """Create / use / destroy in a loop (uploads, frames, seeds, extraction — every lazily allocated buffer gets
     allocated): the free device memory afterwards is what it was before."""
