@@ -1398,15 +1398,25 @@ int mrh_extract_triangles(mrh_ctx* c, const mrh_triangle** out_tris, uint64_t* o
   c->last_triangles = 0;
   bool processed = false;
   if (n > 0) {
-    // canonical order: sort the block list by position (packed-key order == (x,y,z) order)
+    // canonical order: sort the block list by position (packed-key order == (x,y,z) order) — on the device; the host
+    // only needs the sorted list for the per-block descriptors it hands out (mrh_get_triangle_blocks)
     std::vector<int4> list((size_t) n);
-    HIP_TRY(c, hipMemcpy(list.data(), c->tab.compact, (size_t) n * sizeof(int4), hipMemcpyDeviceToHost));
-    std::sort(list.begin(), list.end(), [](const int4& a, const int4& b) {
-      if (a.x != b.x) return a.x < b.x;
-      if (a.y != b.y) return a.y < b.y;
-      return a.z < b.z;
-    });
-    HIP_TRY(c, hipMemcpy(c->tab.compact, list.data(), (size_t) n * sizeof(int4), hipMemcpyHostToDevice));
+    {
+      DevBuf<u64> k_in, k_out;
+      DevBuf<int4> sorted;
+      DevBuf<char> tmp;
+      HIP_TRY(c, k_in.alloc((size_t) n));
+      HIP_TRY(c, k_out.alloc((size_t) n));
+      HIP_TRY(c, sorted.alloc((size_t) n));
+      k_list_keys<<<(n + 255) / 256, 256, 0, s>>>(c->tab.compact, n, k_in);
+      size_t bytes = 0;
+      HIP_TRY(c, rocprim::radix_sort_pairs(nullptr, bytes, (u64*) k_in, (u64*) k_out, c->tab.compact, (int4*) sorted, (size_t) n, 0, 63, s));
+      HIP_TRY(c, tmp.alloc(bytes ? bytes : 1));
+      HIP_TRY(c, rocprim::radix_sort_pairs((void*) (char*) tmp, bytes, (u64*) k_in, (u64*) k_out, c->tab.compact, (int4*) sorted, (size_t) n, 0, 63, s));
+      HIP_TRY(c, hipMemcpyAsync(c->tab.compact, (int4*) sorted, (size_t) n * sizeof(int4), hipMemcpyDeviceToDevice, s));
+      HIP_TRY(c, hipMemcpyAsync(list.data(), (int4*) sorted, (size_t) n * sizeof(int4), hipMemcpyDeviceToHost, s));
+      HIP_TRY(c, hipStreamSynchronize(s));
+    }
     t1 = now();
     DevBuf<u32> d_counts;
     DevBuf<u64> d_offsets;

@@ -217,6 +217,15 @@ __device__ __forceinline__ int mc_voxel(const Map& m, const Tab& t, const Neigh&
   return ntri;
 }
 
+// packed keys of a block list: key order == (x, y, z) lexicographic order, the canonical order of the extraction
+__global__ __launch_bounds__(256) void k_list_keys(const int4* __restrict__ list, const int n, u64* __restrict__ keys) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u64 key = ~0ull;  // a listed block always packs (it came out of the table)
+  pack_key(mki3(list[i].x, list[i].y, list[i].z), key);
+  keys[i] = key;
+}
+
 // Workgroup per block of the sorted list, lane = voxel.  EMIT = false: counts[e] = triangles of block e and
 // per_voxel[e * 512 + v] = triangles of voxel v.  EMIT = true: triangles written at offsets[e] + (exclusive prefix over
 // voxel index); voxels the count pass found empty (the vast majority) are not evaluated a second time.
