@@ -236,7 +236,7 @@ __global__ __launch_bounds__(512) void k_mc(const Map m, const Tab t, const int4
                                             const float sdf_bound) {
   __shared__ u32 s_wave[8];
   __shared__ u32 s_nb[27];
-  // Count pass, single-resolution maps: sign class of the 10^3 cells around the block (1: weighted and clearly positive,
+  // Count pass, fine blocks with no coarse neighbour: sign class of the 10^3 cells around the block (1: weighted and clearly positive,
   // 2: weighted and clearly negative, 0: anything else).  Everything marching cubes evaluates for a voxel — the eight
   // trilinear corner values, or the raw sample a corner falls back to — is built from the 3^3 cells around it, the
   // trilinear value is a convex combination of them (fp32 evaluation error < 2e-5 x the largest magnitude), so if all 27
@@ -266,7 +266,12 @@ __global__ __launch_bounds__(512) void k_mc(const Map m, const Tab t, const int4
       nb.vals = s_nb;
     }
     const int amax = max(max(abs(ent.x), abs(ent.y)), abs(ent.z));
-    const bool prescreen = !EMIT && !t.multi_res && sdf_bound > 0.f && (amax + 2) * kBlockSide < m.block_shift_limit;  // uniform
+    bool prescreen = !EMIT && !coarse && sdf_bound > 0.f && (amax + 2) * kBlockSide < m.block_shift_limit;  // uniform
+    if (prescreen && t.multi_res) {  // a fine block whose whole neighbourhood is fine (or absent) is evaluated exactly as on a single-resolution map
+      u32 any_coarse = 0;
+      for (int i = 0; i < 27; i++) any_coarse |= (s_nb[i] != kNbAbsent) ? (s_nb[i] & kValCoarseBit) : 0u;
+      prescreen = any_coarse == 0u;
+    }
     if (prescreen) {
       const float lo = 1e-3f * sdf_bound, hi = 1.001f * sdf_bound;
       for (int cidx = v; cidx < 1000; cidx += 512) {
