@@ -53,7 +53,7 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--blocks", type=int, default=262144, help="SDF block pool capacity (1.6 GB at 262144)")
-    ap.add_argument("--cpu-frames", type=int, default=8, help="frames of the same stream timed on the CPU oracle (rank 0, N=1)")
+    ap.add_argument("--cpu-frames", type=int, default=64, help="frames of the same stream timed on the CPU oracle (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--pcie", action="store_true", help="also time the same frames fed from host memory (mrh_upload_* per frame)")
     args = ap.parse_args()
