@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MRH_ABI_VERSION 1
+#define MRH_ABI_VERSION 2
 
 typedef enum mrh_status {
   MRH_OK                = 0,
@@ -129,9 +129,18 @@ typedef struct mrh_stats {
   float    last_integrate_kernel_ms; /* HIP-event time of the last integrate kernel (profile mode)      */
   float    sum_integrate_kernel_ms;  /* running sum over frames since mrh_set_profile(ctx, 1)           */
   uint64_t n_integrate_kernel;       /* number of launches in that sum                                  */
-  uint32_t error_flags;           /* sticky device-side flags: bit0 pool exhausted, bit1 table full,
-                                     bit2 key out of range, bit3 triangle buffer full                   */
+  uint32_t error_flags;           /* device-side flags raised since create / reset: bit0 pool exhausted,
+                                     bit1 table full, bit2 key out of range, bit3 triangle buffer full   */
   uint32_t reserved;
+  /* open-address table upkeep (no reference counterpart: its buckets return slots to FREE, vds.cu:1727-1824) */
+  uint64_t hash_slots;            /* table capacity                                                     */
+  uint64_t tombstones;            /* erased slots not yet reused or rebuilt away (counted by this call) */
+  uint32_t max_probe_length;      /* longest probe path of a live key, in slots (1 = home slot)         */
+  uint32_t rehash_count;          /* table rebuilds since create / reset                                */
+  /* marching cubes: HIP-event times of the two kernels of the last mrh_extract_triangles (0 if none ran) */
+  float    last_mc_count_ms;
+  float    last_mc_emit_ms;
+  uint64_t last_mc_blocks;        /* blocks (fine + coarse) the last extraction walked                  */
 } mrh_stats;
 
 typedef struct mrh_ctx mrh_ctx;
@@ -244,9 +253,17 @@ int mrh_splat_seeds(mrh_ctx* ctx, float qtree_thresh, int qtree_min_pixel_size, 
 /* The leaves of the last mrh_splat_seeds call (CUDAQTree::getAllNodes, quad_tree.cuh:82-87).  Test / debug helper. */
 int mrh_get_qtree_leaves(mrh_ctx* ctx, const mrh_qtree_leaf** out_leaves, uint64_t* out_n);
 
-/* Blocks until every enqueued frame has executed; surfaces sticky device error flags as
- * MRH_ERR_CAPACITY / MRH_ERR_OUT_OF_RANGE. */
+/* Blocks until every enqueued frame has executed.  Device error flags raised since the last call that reported them
+ * (pool exhausted, table full, key out of range) come back as MRH_ERR_CAPACITY / MRH_ERR_OUT_OF_RANGE ONCE and are
+ * cleared: the frames that raised them skipped the affected blocks (what the reference does after its device printf,
+ * vds.cu:566-569) and the map stays usable.  mrh_get_stats().error_flags keeps the union since create / reset. */
 int mrh_sync(mrh_ctx* ctx);
+
+/* The same flags WITHOUT waiting for the device, for a host loop that never syncs (GeoWrapper::compute): every frame
+ * ends with a small copy of the counters into pinned host memory (the mechanism of mrh_peek_free_blocks); this returns
+ * the flags of the newest report that has arrived and that no earlier peek has returned (0: nothing new).  Does not
+ * clear anything on the device: a later mrh_sync still reports them. */
+int mrh_peek_error_flags(mrh_ctx* ctx, uint32_t* out_new_flags);
 
 /* Replaces MeshExtractor::extractMesh = flatAndReduceHashTable() + extractIsoSurface
  * (mesh_extractor.cpp:95-98, marching_cubes.cu:264-305): marching cubes over every live
@@ -316,6 +333,49 @@ int mrh_get_triangle_blocks(mrh_ctx* ctx, const mrh_block_desc** out_descs, cons
 /* MeshExtractor::processTriangles (mesh_extractor.cpp:9-76) on a caller-supplied triangle buffer; the result is
  * read back with mrh_extract_mesh.  Used by rank 0 on the merged buffer of all shards. */
 int mrh_process_triangles(mrh_ctx* ctx, const mrh_triangle* triangles, uint64_t n);
+
+/* ---- multi-GPU: block exchange between tile-sharded contexts (new design, no reference counterpart) --------------
+ * One process per GPU; the collectives themselves (RCCL all-gather / all-to-all over xGMI) are the host's business
+ * (mrhash_amd/parallel.py), these calls produce and consume the buffers they move — in DEVICE memory, so that nothing
+ * is staged through the host.  A record is one block in the reference layout: */
+typedef struct mrh_block_record {
+  mrh_block_desc desc;
+  mrh_voxel      voxels[512];   /* coarse blocks use the first 64 */
+} mrh_block_record;             /* 6160 bytes */
+
+/* Changes the tile ownership of a context (mrh_params.shard_rank / shard_count / shard_chunk_log2) after creation:
+ * a frame-sharded rank fuses its frames owning everything (count 1), then takes its place in the tile partition for
+ * the merge and the mesh extraction. */
+int mrh_set_sharding(mrh_ctx* ctx, int shard_rank, int shard_count, int shard_chunk_log2);
+
+typedef enum mrh_pack_mode {
+  MRH_PACK_HALO  = 0, /* blocks this rank owns that lie on the surface of their chunk: what a neighbouring chunk's
+                         marching cubes can read (corner samples reach <= 2 voxels into the next block)          */
+  MRH_PACK_OWNER = 1  /* every live block owned by `rank_arg` (frame-sharded sub-maps on their way to the owner) */
+} mrh_pack_mode;
+/* Selects blocks, orders them by position and writes their records into a buffer owned by ctx (valid until the next
+ * pack call).  *out_is_device_memory = 1 for the HIP library.  The map is not modified.  Blocks. */
+int mrh_pack_blocks(mrh_ctx* ctx, int mode, int rank_arg, const mrh_block_record** out_records, uint64_t* out_n,
+                    int* out_is_device_memory);
+
+typedef enum mrh_unpack_mode {
+  MRH_UNPACK_HALO  = 0, /* keep the records of blocks this rank does NOT own that are 26-adjacent to a block position it
+                           owns; they become ordinary readable blocks, remembered as halo (mrh_drop_blocks)     */
+  MRH_UNPACK_MERGE = 1  /* weighted merge into the map, voxel by voxel, with combineVoxel's arithmetic
+                           (vhu.cuh:167-181): sdf = (s0 w0 + s1 w1) / (w0 + w1), weight = min(max, w0 + w1),
+                           colour = u8(0.5 c0 + 0.5 c1 + 0.5); a voxel with weight 0 on one side takes the other
+                           side unchanged; absent blocks are inserted.  Single-resolution maps only.             */
+} mrh_unpack_mode;
+/* `records` is a device pointer iff is_device_memory != 0 (what a RCCL collective leaves behind).  Blocks. */
+int mrh_unpack_blocks(mrh_ctx* ctx, int mode, const mrh_block_record* records, uint64_t n, int is_device_memory,
+                      uint64_t* out_taken);
+
+typedef enum mrh_drop_mode {
+  MRH_DROP_HALO    = 0, /* the blocks MRH_UNPACK_HALO brought in (after the extraction that needed them)  */
+  MRH_DROP_FOREIGN = 1, /* every block this rank does not own                                               */
+  MRH_DROP_ALL     = 2  /* every block (the frame counter and the configuration stay)                       */
+} mrh_drop_mode;
+int mrh_drop_blocks(mrh_ctx* ctx, int mode, uint64_t* out_dropped);
 
 /* Looks one voxel up by integer voxel coordinate = VoxelContainer::getVoxel(int3)
  * (vds.cu:163-176); a miss returns a zero voxel and *out_found = 0. Test helper. */

@@ -18,7 +18,7 @@ import numpy as np
 _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HIP_LIB_PATH = os.path.join(_ROOT, "mrhash_amd", "csrc", "libmrhash_hip.so")
 
-MRH_ABI_VERSION = 1
+MRH_ABI_VERSION = 2
 
 MRH_OK = 0
 MRH_PENDING_EXCHANGE = 1
@@ -81,6 +81,13 @@ class MrhStats(C.Structure):
         ("n_integrate_kernel", C.c_uint64),
         ("error_flags", C.c_uint32),
         ("reserved", C.c_uint32),
+        ("hash_slots", C.c_uint64),
+        ("tombstones", C.c_uint64),
+        ("max_probe_length", C.c_uint32),
+        ("rehash_count", C.c_uint32),
+        ("last_mc_count_ms", C.c_float),
+        ("last_mc_emit_ms", C.c_float),
+        ("last_mc_blocks", C.c_uint64),
     ]
 
 
@@ -89,6 +96,11 @@ VOXEL_DTYPE = np.dtype(
 )
 assert VOXEL_DTYPE.itemsize == 12
 DESC_DTYPE = np.dtype([("x", "<i4"), ("y", "<i4"), ("z", "<i4"), ("resolution", "<i4")])
+RECORD_DTYPE = np.dtype([("desc", DESC_DTYPE), ("voxels", VOXEL_DTYPE, (512,))])  # mrh_block_record
+RECORD_BYTES = 6160
+PACK_HALO, PACK_OWNER = 0, 1
+UNPACK_HALO, UNPACK_MERGE = 0, 1
+DROP_HALO, DROP_FOREIGN, DROP_ALL = 0, 1, 2
 TRI_DTYPE = np.dtype([("p", "<f4", (3,)), ("c", "<f4", (3,))])  # one vertex; a triangle is 3 of them
 SEED_DTYPE = np.dtype([("p", "<f4", (3,)), ("scale", "<f4"), ("rgb", "u1", (3,)), ("pad", "u1")])  # mrh_splat_seed, 20 bytes
 LEAF_DTYPE = np.dtype([("x0", "<i4"), ("y0", "<i4"), ("width", "<i4"), ("height", "<i4")])  # mrh_qtree_leaf
@@ -99,7 +111,8 @@ ABI_SYMBOLS = (
     "mrh_create mrh_destroy mrh_reset mrh_last_error mrh_set_camera mrh_set_pose mrh_upload_depth "
     "mrh_upload_rgb mrh_set_depth_device mrh_set_rgb_device mrh_integrate mrh_integrate_resume mrh_exchange_buffer mrh_sync "
     "mrh_upload_points mrh_set_points_device mrh_integrate_points mrh_stream_out mrh_get_free_blocks "
-    "mrh_splat_seeds mrh_get_qtree_leaves mrh_peek_free_blocks "
+    "mrh_splat_seeds mrh_get_qtree_leaves mrh_peek_free_blocks mrh_peek_error_flags "
+    "mrh_set_sharding mrh_pack_blocks mrh_unpack_blocks mrh_drop_blocks "
     "mrh_extract_triangles mrh_extract_mesh mrh_get_stats mrh_set_profile mrh_dump_blocks "
     "mrh_get_voxel mrh_import_blocks mrh_get_triangle_blocks mrh_process_triangles mrh_selftest_division mrh_version"
 ).split()
@@ -133,6 +146,11 @@ def _declare(lib: C.CDLL) -> C.CDLL:
     lib.mrh_stream_out.argtypes = [C.c_void_p, P(C.c_float), C.c_float, C.c_void_p, C.c_void_p, C.c_uint64, P(C.c_uint64)]
     lib.mrh_splat_seeds.argtypes = [C.c_void_p, C.c_float, C.c_int, P(C.c_void_p), P(C.c_uint64)]
     lib.mrh_get_qtree_leaves.argtypes = [C.c_void_p, P(C.c_void_p), P(C.c_uint64)]
+    lib.mrh_peek_error_flags.argtypes = [C.c_void_p, P(C.c_uint32)]
+    lib.mrh_set_sharding.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+    lib.mrh_pack_blocks.argtypes = [C.c_void_p, C.c_int, C.c_int, P(C.c_void_p), P(C.c_uint64), P(C.c_int)]
+    lib.mrh_unpack_blocks.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64, C.c_int, P(C.c_uint64)]
+    lib.mrh_drop_blocks.argtypes = [C.c_void_p, C.c_int, P(C.c_uint64)]
     lib.mrh_integrate_resume.argtypes = [C.c_void_p]
     lib.mrh_exchange_buffer.argtypes = [C.c_void_p, P(C.c_void_p), P(C.c_uint64), P(C.c_int)]
     lib.mrh_sync.argtypes = [C.c_void_p]
@@ -386,6 +404,32 @@ class Engine:
         a, b, n = C.c_int64(), C.c_int64(), C.c_uint64()
         self._check(self.lib.mrh_peek_free_blocks(self._ctx, C.byref(a), C.byref(b), C.byref(n)))
         return a.value, b.value, n.value
+
+    def peek_error_flags(self) -> int:
+        f = C.c_uint32()
+        self._check(self.lib.mrh_peek_error_flags(self._ctx, C.byref(f)))
+        return int(f.value)
+
+    # -- multi-GPU block exchange ----------------------------------------------------------------
+    def set_sharding(self, rank: int, count: int, chunk_log2: int = 0):
+        self._check(self.lib.mrh_set_sharding(self._ctx, rank, count, chunk_log2))
+        self.params.shard_rank, self.params.shard_count, self.params.shard_chunk_log2 = rank, count, chunk_log2
+
+    def pack_blocks(self, mode: int, rank_arg: int = 0) -> Tuple[int, int, bool]:
+        """(pointer to mrh_block_record[n], n, is_device_memory); the buffer belongs to the context until the next pack."""
+        ptr, n, dev = C.c_void_p(), C.c_uint64(), C.c_int()
+        self._check(self.lib.mrh_pack_blocks(self._ctx, mode, rank_arg, C.byref(ptr), C.byref(n), C.byref(dev)))
+        return int(ptr.value or 0), int(n.value), bool(dev.value)
+
+    def unpack_blocks(self, mode: int, ptr: int, n: int, is_device: bool) -> int:
+        taken = C.c_uint64()
+        self._check(self.lib.mrh_unpack_blocks(self._ctx, mode, ptr, n, 1 if is_device else 0, C.byref(taken)))
+        return int(taken.value)
+
+    def drop_blocks(self, mode: int) -> int:
+        n = C.c_uint64()
+        self._check(self.lib.mrh_drop_blocks(self._ctx, mode, C.byref(n)))
+        return int(n.value)
 
     def stream_out(self, center, radius: float) -> Tuple[np.ndarray, np.ndarray]:
         """Streamer device half: blocks at distance >= radius from `center` (radius < 0: all) are copied out, ordered by

@@ -111,7 +111,7 @@ struct mrh_ctx {
   hipEvent_t frame_done[8] = {};       // recorded on the main stream after every frame that read ring slots / when peeks are on
   uint64_t frame_seq = 1;
   // pool level for the host without a read-back stall (mrh_peek_free_blocks): a 2-int D2H per frame into pinned memory
-  int* h_peek = nullptr;               // [8][2], pinned
+  int* h_peek = nullptr;               // [8][8] pinned: ctr[0 .. 4] = free-list levels ... error flags per report
   uint64_t peek_seq[8] = {};
   bool peek_enabled = false;
   const float* d_depth = nullptr;
@@ -182,6 +182,22 @@ struct mrh_ctx {
   uint64_t n_ms = 0;
   uint64_t prev_total_updated = 0, prev_inserted = 0, prev_freed = 0, total_compact = 0;
   uint64_t last_triangles = 0;
+  // hash-table upkeep (mrh_kernels.h: k_table_census / k_rehash_*)
+  int census_period = 64;          // frames between two censuses; MRH_REHASH_PERIOD
+  int census_force = 0;            // MRH_REHASH_FORCE=1: every census rebuilds (tests)
+  uint64_t frames_since_census = 0;
+  bool table_dirty = false;        // bulk erase / insert since the last census (stream-out, import, drop): census before the next frame
+  // device error flags: `flags_seen` = union of everything taken off the device since create / reset (stats),
+  // `flags_deferred` = taken but not yet returned to the caller by mrh_sync, `flags_peeked` = already returned by a peek
+  u32 flags_seen = 0, flags_deferred = 0, flags_peeked = 0;
+  // multi-GPU block exchange
+  char* d_pack = nullptr; size_t pack_cap = 0;      // mrh_pack_blocks result (records)
+  int4* d_halo = nullptr; size_t halo_cap = 0, halo_upper = 0;  // blocks brought in by MRH_UNPACK_HALO (upper bound of the device count)
+  u32* d_taken = nullptr;
+  // marching cubes timing (mrh_stats)
+  hipEvent_t mc_ev[4] = {};
+  float last_mc_count_ms = 0.f, last_mc_emit_ms = 0.f;
+  uint64_t last_mc_blocks = 0;
   std::string err;
 };
 
@@ -241,6 +257,8 @@ void free_all(mrh_ctx* c) {
   if (c->h_peek) (void) hipHostFree(c->h_peek);
   F(c->d_decision); F(c->d_zbuf); F(c->d_realloc); F(c->d_reint); F(c->d_flag);
   F(c->d_upd_partials); F(c->d_misc); F(c->d_rcp_w); F(c->d_cfree); F(c->d_zmin); F(c->d_points); F(c->d_pt_counts); F(c->d_pt_offsets); F(c->d_rec_keys[0]); F(c->d_rec_keys[1]); F(c->d_rec_vals[0]); F(c->d_rec_vals[1]); F(c->d_sort_tmp); F(c->fast.summary); F(c->fast.summary_c); F(c->fast.bbox); F(c->d_cnt_partials);
+  F(c->d_pack); F(c->d_halo); F(c->d_taken);
+  for (hipEvent_t e : c->mc_ev) if (e) (void) hipEventDestroy(e);
   F(c->d_qt_sums); F(c->d_qt_flags); F(c->d_qt_unc); F(c->d_qt_marks); F(c->d_qt_pos); F(c->d_qt_parked); F(c->d_qt_seeds); F(c->d_qt_leaves); F(c->d_qt_misc); F(c->d_qt_tmp);
   for (auto& e : c->ev_pool) { (void) hipEventDestroy(e.a); (void) hipEventDestroy(e.b); }
   for (auto& e : c->ev_pending) { (void) hipEventDestroy(e.a); (void) hipEventDestroy(e.b); }
@@ -271,6 +289,10 @@ int init_buffers(mrh_ctx* c) {
   HIP_TRY(c, hipMemsetAsync(c->d_cnt_partials, 0, (size_t) 32768 * 4 * sizeof(u64), s));
   HIP_TRY(c, hipStreamSynchronize(s));
   c->frames = 0;
+  c->frames_since_census = 0;
+  c->table_dirty = false;
+  c->flags_seen = c->flags_deferred = c->flags_peeked = 0;
+  c->halo_upper = 0;
   c->prev_total_updated = c->prev_inserted = c->prev_freed = c->total_compact = 0;
   c->sum_ms = c->last_ms = 0.f;
   c->n_ms = 0;
@@ -297,6 +319,36 @@ int check_device_flags(mrh_ctx* c, u32 flags) {
   if (flags & ERR_POOL) return fail(c, MRH_ERR_CAPACITY, "SDF block pool exhausted (num_sdf_blocks = %llu)", (unsigned long long) c->num_blocks);
   if (flags & ERR_TABLE) return fail(c, MRH_ERR_CAPACITY, "hash table probe limit reached (hash_slots = %llu)", (unsigned long long) c->slots);
   if (flags & ERR_TRI) return fail(c, MRH_ERR_CAPACITY, "triangle buffer full (max_triangles = %llu)", (unsigned long long) c->max_triangles);
+  return MRH_OK;
+}
+
+// Device error flags are taken off the device and cleared there in one stream-ordered step (nothing else runs on the
+// stream in between), so a flag is reported for the call that raised it and not for every later one.
+int take_device_flags(mrh_ctx* c, u32* out) {
+  u32 flags = 0;
+  HIP_TRY(c, hipMemcpyAsync(&flags, &c->tab.ctr[CTR_ERROR], sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (flags) HIP_TRY(c, hipMemsetAsync(&c->tab.ctr[CTR_ERROR], 0, sizeof(u32), c->stream));
+  c->flags_seen |= flags;
+  *out = flags;
+  return MRH_OK;
+}
+
+// Table upkeep between two frames (mrh_kernels.h): census of the tombstones every `census_period` frames or after a bulk
+// change, rebuild decided on the device.  Four short launches, no host round trip.
+int maintain_table(mrh_ctx* c, bool force_census) {
+  if (c->pending) return MRH_OK;
+  if (!force_census && !c->table_dirty && c->frames_since_census < (uint64_t) c->census_period) return MRH_OK;
+  hipStream_t s = c->stream;
+  const Tab& t = c->tab;
+  const int grid = (int) std::min<uint64_t>(2048, (c->slots + 255) / 256);
+  k_table_census<<<grid, 256, 0, s>>>(t, (size_t) c->slots);
+  k_rehash_decide<<<1, 1, 0, s>>>(t, (u32) (c->slots / 4), c->census_force);
+  k_rehash_clear<<<grid, 256, 0, s>>>(t, (size_t) c->slots);
+  k_rehash_insert<<<1024, 256, 0, s>>>(t);
+  c->frames_since_census = 0;
+  c->table_dirty = false;
+  HIP_TRY(c, hipGetLastError());
   return MRH_OK;
 }
 
@@ -691,6 +743,8 @@ int mrh_create(const mrh_params* p, mrh_ctx** out) {
   if (const char* g = getenv("MRH_MESH_HOST")) c->mesh_on_host = atoi(g) ? 1 : 0;
   if (const char* g = getenv("MRH_QTREE_LITERAL")) c->qt_literal = atoi(g) ? 1 : 0;
   if (const char* g = getenv("MRH_MR_FUSED")) c->mr_fused = atoi(g) ? 1 : 0;
+  if (const char* g = getenv("MRH_REHASH_PERIOD")) { const int v = atoi(g); if (v > 0) c->census_period = v; }
+  if (const char* g = getenv("MRH_REHASH_FORCE")) c->census_force = atoi(g) ? 1 : 0;
   if (const char* g = getenv("MRH_SWEEP_WGS_MR")) { const int v = atoi(g); if (v > 0 && v <= 4096) c->sweep_wgs_mr = v; }
   int rc = init_buffers(c);
   if (rc != MRH_OK) {
@@ -841,7 +895,7 @@ int mark_frame(mrh_ctx* c) {
   if (!used[0] && !used[1] && !c->peek_enabled) return MRH_OK;
   const uint64_t seq = c->frame_seq++;
   if (c->peek_enabled) {
-    HIP_TRY(c, hipMemcpyAsync(c->h_peek + 2 * (seq % 8), &c->tab.ctr[CTR_HEAP_FINE], 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->h_peek + 8 * (seq % 8), &c->tab.ctr[CTR_HEAP_FINE], 5 * sizeof(int), hipMemcpyDeviceToHost, c->stream));  // ctr[0 .. 4]
     c->peek_seq[seq % 8] = seq;
   }
   if (!c->frame_done[0])
@@ -908,6 +962,7 @@ int mrh_integrate(mrh_ctx* c, int n_frames_invalidate) {
 static int integrate_frame(mrh_ctx* c, int n_frames_invalidate) {
   int rc = MRH_OK;
   if (c->pending) return fail(c, MRH_ERR_STATE, "mrh_integrate: an exchange is pending (call mrh_integrate_resume)");
+  if (c->halo_upper) return fail(c, MRH_ERR_STATE, "mrh_integrate: halo blocks of other shards are present (call mrh_drop_blocks(MRH_DROP_HALO) after the extraction)");
   if (!c->has_camera) return fail(c, MRH_ERR_STATE, "mrh_integrate: set_camera has not been called");
   if (c->spherical) return fail(c, MRH_ERR_UNSUPPORTED, "mrh_integrate: spherical (LiDAR) camera model is outside this round's scope");
   if (!c->d_depth || !c->d_rgb) return fail(c, MRH_ERR_STATE, "mrh_integrate: depth and rgb images are required");
@@ -918,6 +973,9 @@ static int integrate_frame(mrh_ctx* c, int n_frames_invalidate) {
   hipStream_t s = c->stream;
   const Tab& t = c->tab;
   const Map& m = c->map;
+  rc = maintain_table(c, false);
+  if (rc) return rc;
+  c->frames_since_census++;
 
   // Multi-resolution maps take the same two launches when that is exact: the fused kernel checks the variance of a
   // fine block right after updating it, which covers every block the reference's checkVarSDF can newly decide on —
@@ -1072,6 +1130,7 @@ int mrh_integrate_points(mrh_ctx* c, int n_frames_invalidate) {
   int rc = ensure_ready(c, "mrh_integrate_points");
   if (rc) return rc;
   if (c->pending) return fail(c, MRH_ERR_STATE, "mrh_integrate_points: an exchange is pending (call mrh_integrate_resume)");
+  if (c->halo_upper) return fail(c, MRH_ERR_STATE, "mrh_integrate_points: halo blocks of other shards are present (call mrh_drop_blocks(MRH_DROP_HALO) after the extraction)");
   if (!c->has_camera) return fail(c, MRH_ERR_STATE, "mrh_integrate_points: set_camera has not been called");
   const int max_num_frames = n_frames_invalidate < 0 ? c->p.n_frames_invalidate_voxels : n_frames_invalidate;
   if (max_num_frames > 0) return fail(c, MRH_ERR_UNSUPPORTED, "mrh_integrate_points: garbage collection on LiDAR scans (spherical projection) is outside this round's scope");
@@ -1083,6 +1142,9 @@ int mrh_integrate_points(mrh_ctx* c, int n_frames_invalidate) {
   const Cam& k = c->cam;
   const Map& m = c->map;
   const Tab& t = c->tab;
+  rc = maintain_table(c, false);
+  if (rc) return rc;
+  c->frames_since_census++;
   if (n > 0) {
     const u32 np = (u32) n, grid = (np + 255) / 256;
     const float* pts = c->d_points_cur;
@@ -1195,11 +1257,14 @@ int mrh_sync(mrh_ctx* c) {
   int rc = ensure_ready(c, "mrh_sync");
   if (rc) return rc;
   u32 flags = 0;
-  HIP_TRY(c, hipMemcpyAsync(&flags, &c->tab.ctr[CTR_ERROR], sizeof(u32), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  rc = take_device_flags(c, &flags);
+  if (rc) return rc;
   HIP_TRY(c, hipGetLastError());
   rc = drain_events(c);
   if (rc) return rc;
+  flags |= c->flags_deferred;
+  c->flags_deferred = 0;
+  c->flags_peeked = 0;
   return check_device_flags(c, flags);
 }
 
@@ -1226,7 +1291,9 @@ int mrh_splat_seeds(mrh_ctx* c, float qtree_thresh, int qtree_min_pixel_size, co
   if (qt.total != c->qt.total || !c->d_qt_sums) {
     HIP_TRY(c, hipStreamSynchronize(s));
     auto F = [](auto*& p) { if (p) (void) hipFree(p); p = nullptr; };
-    F(c->d_qt_sums); F(c->d_qt_flags); F(c->d_qt_unc); F(c->d_qt_marks); F(c->d_qt_pos); F(c->d_qt_parked); F(c->d_qt_seeds); F(c->d_qt_leaves); F(c->d_qt_misc);
+    F(c->d_pack); F(c->d_halo); F(c->d_taken);
+  for (hipEvent_t e : c->mc_ev) if (e) (void) hipEventDestroy(e);
+  F(c->d_qt_sums); F(c->d_qt_flags); F(c->d_qt_unc); F(c->d_qt_marks); F(c->d_qt_pos); F(c->d_qt_parked); F(c->d_qt_seeds); F(c->d_qt_leaves); F(c->d_qt_misc);
     const size_t n = qt.total;
     HIP_TRY(c, hipMalloc((void**) &c->d_qt_sums, n * sizeof(QSum)));
     HIP_TRY(c, hipMalloc((void**) &c->d_qt_flags, n * sizeof(u32)));
@@ -1308,7 +1375,8 @@ int mrh_peek_free_blocks(mrh_ctx* c, int64_t* out_free_fine, int64_t* out_free_c
   int rc = ensure_ready(c, "mrh_peek_free_blocks");
   if (rc) return rc;
   if (!c->peek_enabled) {  // first call: reports start with the next frame; answer this one the blocking way
-    HIP_TRY(c, hipHostMalloc((void**) &c->h_peek, 16 * sizeof(int), hipHostMallocDefault));
+    HIP_TRY(c, hipHostMalloc((void**) &c->h_peek, 64 * sizeof(int), hipHostMallocDefault));
+    memset(c->h_peek, 0, 64 * sizeof(int));
     c->peek_enabled = true;
   }
   for (uint64_t back = 1; back <= 8 && back < c->frame_seq; back++) {
@@ -1318,13 +1386,38 @@ int mrh_peek_free_blocks(mrh_ctx* c, int64_t* out_free_fine, int64_t* out_free_c
     if (q == hipErrorNotReady) continue;
     if (q != hipSuccess) return fail(c, MRH_ERR_DEVICE, "mrh_peek_free_blocks: %s", hipGetErrorString(q));
     if (c->peek_seq[seq % 8] != seq) continue;
-    if (out_free_fine) *out_free_fine = (int64_t) c->h_peek[2 * (seq % 8)] + 1;
-    if (out_free_coarse) *out_free_coarse = (int64_t) c->h_peek[2 * (seq % 8) + 1] + 1;
+    if (out_free_fine) *out_free_fine = (int64_t) c->h_peek[8 * (seq % 8)] + 1;
+    if (out_free_coarse) *out_free_coarse = (int64_t) c->h_peek[8 * (seq % 8) + 1] + 1;
     if (out_frames_behind) *out_frames_behind = back - 1;
     return MRH_OK;
   }
   if (out_frames_behind) *out_frames_behind = 0;
   return mrh_get_free_blocks(c, out_free_fine, out_free_coarse);
+}
+
+int mrh_peek_error_flags(mrh_ctx* c, uint32_t* out_new_flags) {
+  int rc = ensure_ready(c, "mrh_peek_error_flags");
+  if (rc) return rc;
+  if (!out_new_flags) return MRH_ERR_INVALID_ARG;
+  *out_new_flags = 0;
+  if (!c->peek_enabled) {  // reports start with the next frame
+    HIP_TRY(c, hipHostMalloc((void**) &c->h_peek, 64 * sizeof(int), hipHostMallocDefault));
+    memset(c->h_peek, 0, 64 * sizeof(int));
+    c->peek_enabled = true;
+    return MRH_OK;
+  }
+  for (uint64_t back = 1; back <= 8 && back < c->frame_seq; back++) {
+    const uint64_t seq = c->frame_seq - back;
+    if (c->peek_seq[seq % 8] != seq) continue;
+    const hipError_t q = hipEventQuery(c->frame_done[seq % 8]);
+    if (q == hipErrorNotReady) continue;
+    if (q != hipSuccess) return fail(c, MRH_ERR_DEVICE, "mrh_peek_error_flags: %s", hipGetErrorString(q));
+    const u32 flags = (u32) c->h_peek[8 * (seq % 8) + CTR_ERROR];
+    *out_new_flags = flags & ~c->flags_peeked;
+    c->flags_peeked = flags;  // the device clears its flags only in mrh_sync: what is set now has been reported
+    return MRH_OK;
+  }
+  return MRH_OK;
 }
 
 int mrh_set_profile(mrh_ctx* c, int enabled) {
@@ -1339,7 +1432,9 @@ int mrh_get_stats(mrh_ctx* c, mrh_stats* out) {
   if (!out) return MRH_ERR_INVALID_ARG;
   hipStream_t s = c->stream;
   HIP_TRY(c, hipMemsetAsync(&c->tab.ctr[CTR_LIVE_FINE], 0, 2 * sizeof(int), s));
+  HIP_TRY(c, hipMemsetAsync(&c->tab.ctr[CTR_MAXPROBE], 0, 2 * sizeof(int), s));  // CTR_MAXPROBE, CTR_TOMBS_NOW
   k_count_live<<<256, 256, 0, s>>>(c->tab);
+  k_table_census<<<(int) std::min<uint64_t>(2048, (c->slots + 255) / 256), 256, 0, s>>>(c->tab, (size_t) c->slots);
   int h_ctr[CTR_COUNT];
   u64 h_prof[PROF_COUNT];
   const bool fastp = !c->tab.multi_res;
@@ -1373,7 +1468,15 @@ int mrh_get_stats(mrh_ctx* c, mrh_stats* out) {
   out->last_integrate_kernel_ms = c->last_ms;
   out->sum_integrate_kernel_ms = c->sum_ms;
   out->n_integrate_kernel = c->n_ms;
-  out->error_flags = (u32) h_ctr[CTR_ERROR];
+  out->error_flags = (u32) h_ctr[CTR_ERROR] | c->flags_seen;
+  out->hash_slots = c->slots;
+  out->tombstones = (uint64_t) h_ctr[CTR_TOMBS_NOW];
+  out->max_probe_length = (u32) h_ctr[CTR_MAXPROBE];
+  out->rehash_count = (u32) h_ctr[CTR_NREHASH];
+  out->last_mc_count_ms = c->last_mc_count_ms;
+  out->last_mc_emit_ms = c->last_mc_emit_ms;
+  out->last_mc_blocks = c->last_mc_blocks;
+  HIP_TRY(c, hipMemsetAsync(&c->tab.ctr[CTR_TOMBS_NOW], 0, sizeof(int), s));  // the census accumulator belongs to maintain_table
   return MRH_OK;
 }
 
@@ -1381,6 +1484,7 @@ int mrh_extract_triangles(mrh_ctx* c, const mrh_triangle** out_tris, uint64_t* o
   int rc = ensure_ready(c, "mrh_extract_triangles");
   if (rc) return rc;
   if (!out_n) return MRH_ERR_INVALID_ARG;
+  if (c->pending) return fail(c, MRH_ERR_STATE, "mrh_extract_triangles: an exchange is pending (call mrh_integrate_resume)");
   // out_tris == NULL: the caller only wants the mesh (mrh_extract_mesh) — the soup stays on the device.  The host
   // restatement of the post-process (MRH_MESH_HOST=1) reads the host copy, so it keeps it.
   const bool want_soup = out_tris != nullptr || c->mesh_on_host;
@@ -1534,6 +1638,7 @@ int mrh_stream_out(mrh_ctx* c, const float center[3], float radius, mrh_block_de
   HIP_TRY(c, hipMemcpyAsync(&c->tab.ctr[CTR_COMPACT], &ctr_n, sizeof(int), hipMemcpyHostToDevice, c->stream));
   k_fill_u32<<<256, 256, 0, c->stream>>>(c->d_decision, (size_t) ns, 1u);
   k_gc_free<false><<<256, 256, 0, c->stream>>>(c->tab, c->d_decision);
+  c->table_dirty = true;  // a bulk erase: census (and, if due, rebuild) before the next frame
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   HIP_TRY(c, hipGetLastError());
   return MRH_OK;
@@ -1543,6 +1648,7 @@ int mrh_dump_blocks(mrh_ctx* c, mrh_block_desc* descs, mrh_voxel* voxels, uint64
   int rc = ensure_ready(c, "mrh_dump_blocks");
   if (rc) return rc;
   if (!out_n) return MRH_ERR_INVALID_ARG;
+  if (c->pending) return fail(c, MRH_ERR_STATE, "mrh_dump_blocks: an exchange is pending (call mrh_integrate_resume)");  // the starve passes still need Tab::compact
   int n = 0;
   rc = compact_all(c, &n);
   if (rc) return rc;
@@ -1581,14 +1687,33 @@ int mrh_get_voxel(mrh_ctx* c, int32_t vx, int32_t vy, int32_t vz, mrh_voxel* out
   return MRH_OK;
 }
 
+namespace {
+// flags raised by earlier frames are set aside (mrh_sync reports them) so that a call which checks its own outcome on the
+// device — import, unpack — answers for itself only
+int set_aside_flags(mrh_ctx* c) {
+  u32 flags = 0;
+  int rc = take_device_flags(c, &flags);
+  if (rc) return rc;
+  c->flags_deferred |= flags;
+  return MRH_OK;
+}
+void map_changed_in_bulk(mrh_ctx* c) {
+  c->mr_next_general = true;  // payload that has not been through a variance check
+  c->refill_flag_valid = false;
+  c->mr_summaries_valid = false;
+  c->table_dirty = true;
+}
+}  // namespace
+
 int mrh_import_blocks(mrh_ctx* c, const mrh_block_desc* descs, const mrh_voxel* voxels, uint64_t n) {
   int rc = ensure_ready(c, "mrh_import_blocks");
   if (rc) return rc;
   if (n == 0) return MRH_OK;
   if (!descs || !voxels) return fail(c, MRH_ERR_INVALID_ARG, "mrh_import_blocks: null argument");
-  c->mr_next_general = true;  // imported payload has not been through a variance check
-  c->refill_flag_valid = false;
-  c->mr_summaries_valid = false;
+  if (c->pending) return fail(c, MRH_ERR_STATE, "mrh_import_blocks: an exchange is pending (call mrh_integrate_resume)");
+  rc = set_aside_flags(c);
+  if (rc) return rc;
+  map_changed_in_bulk(c);
   const uint64_t chunk = 8192;
   DevBuf<int4> d_descs;
   DevBuf<char> d_vox;
@@ -1598,13 +1723,161 @@ int mrh_import_blocks(mrh_ctx* c, const mrh_block_desc* descs, const mrh_voxel* 
     const uint64_t cnt = (n - first) < chunk ? (n - first) : chunk;
     HIP_TRY(c, hipMemcpyAsync(d_descs, &descs[first], cnt * sizeof(int4), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(d_vox, &voxels[first * 512], cnt * (size_t) kFineBytes, hipMemcpyHostToDevice, c->stream));
-    k_import<<<(int) (cnt < 2048 ? cnt : 2048), 512, 0, c->stream>>>(c->tab, c->fast.summary, (int) cnt, d_descs, d_vox);
+    k_import<kImportPlain><<<(int) (cnt < 2048 ? cnt : 2048), 512, 0, c->stream>>>(c->map, c->tab, c->fast.summary, (int) cnt, (const char*) (int4*) d_descs, sizeof(int4),
+                                                                                   (const char*) d_vox, (size_t) kFineBytes, nullptr, nullptr);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
   }
   HIP_TRY(c, hipGetLastError());
   u32 flags = 0;
-  HIP_TRY(c, hipMemcpy(&flags, &c->tab.ctr[CTR_ERROR], sizeof(u32), hipMemcpyDeviceToHost));
+  rc = take_device_flags(c, &flags);
+  if (rc) return rc;
   return check_device_flags(c, flags);
+}
+
+// ---- multi-GPU block exchange (include/mrhash_hip.h) -----------------------------------------------------------------
+
+int mrh_set_sharding(mrh_ctx* c, int shard_rank, int shard_count, int shard_chunk_log2) {
+  if (!c) return MRH_ERR_INVALID_ARG;
+  if (shard_count < 1 || shard_rank < 0 || shard_rank >= shard_count) return fail(c, MRH_ERR_INVALID_ARG, "mrh_set_sharding: rank %d of %d", shard_rank, shard_count);
+  if (c->pending) return fail(c, MRH_ERR_STATE, "mrh_set_sharding: an exchange is pending (call mrh_integrate_resume)");
+  c->p.shard_rank = shard_rank; c->p.shard_count = shard_count; c->p.shard_chunk_log2 = shard_chunk_log2;
+  c->map.shard_rank = shard_rank;
+  c->map.shard_count = shard_count;
+  c->map.shard_chunk_log2 = (shard_chunk_log2 > 0 && shard_chunk_log2 < 16) ? shard_chunk_log2 : 3;
+  return MRH_OK;
+}
+
+namespace {
+// live blocks matching a predicate -> Tab::compact[0, n)
+int select_blocks(mrh_ctx* c, int sel_mode, int rank_arg, int* out_n) {
+  hipStream_t s = c->stream;
+  HIP_TRY(c, hipMemsetAsync(&c->tab.ctr[CTR_COMPACT], 0, sizeof(int), s));
+  k_select_blocks<<<512, 256, 0, s>>>(c->map, c->tab, sel_mode, rank_arg);
+  int n = 0;
+  HIP_TRY(c, hipMemcpyAsync(&n, &c->tab.ctr[CTR_COMPACT], sizeof(int), hipMemcpyDeviceToHost, s));
+  HIP_TRY(c, hipStreamSynchronize(s));
+  HIP_TRY(c, hipGetLastError());
+  *out_n = n;
+  return MRH_OK;
+}
+// frees Tab::compact[0, n) (garbageCollectFree's kernel with every decision set)
+int free_compact(mrh_ctx* c, int n) {
+  if (n <= 0) return MRH_OK;
+  hipStream_t s = c->stream;
+  HIP_TRY(c, hipMemcpyAsync(&c->tab.ctr[CTR_COMPACT], &n, sizeof(int), hipMemcpyHostToDevice, s));
+  k_fill_u32<<<256, 256, 0, s>>>(c->d_decision, (size_t) n, 1u);
+  k_gc_free<false><<<256, 256, 0, s>>>(c->tab, c->d_decision);
+  HIP_TRY(c, hipStreamSynchronize(s));
+  HIP_TRY(c, hipGetLastError());
+  map_changed_in_bulk(c);
+  return MRH_OK;
+}
+}  // namespace
+
+int mrh_pack_blocks(mrh_ctx* c, int mode, int rank_arg, const mrh_block_record** out_records, uint64_t* out_n, int* out_is_device_memory) {
+  int rc = ensure_ready(c, "mrh_pack_blocks");
+  if (rc) return rc;
+  if (!out_records || !out_n) return MRH_ERR_INVALID_ARG;
+  if (mode != MRH_PACK_HALO && mode != MRH_PACK_OWNER) return fail(c, MRH_ERR_INVALID_ARG, "mrh_pack_blocks: bad mode %d", mode);
+  if (c->pending) return fail(c, MRH_ERR_STATE, "mrh_pack_blocks: an exchange is pending (call mrh_integrate_resume)");
+  int n = 0;
+  rc = select_blocks(c, mode == MRH_PACK_HALO ? kSelHalo : kSelOwner, rank_arg, &n);
+  if (rc) return rc;
+  if (out_is_device_memory) *out_is_device_memory = 1;
+  *out_n = (uint64_t) n;
+  *out_records = nullptr;
+  if (n == 0) return MRH_OK;
+  const size_t bytes = (size_t) n * sizeof(mrh_block_record);
+  if (bytes > c->pack_cap) {
+    if (c->d_pack) HIP_TRY(c, hipFree(c->d_pack));
+    c->d_pack = nullptr; c->pack_cap = 0;
+    const size_t cap = bytes + bytes / 4;
+    HIP_TRY(c, hipMalloc((void**) &c->d_pack, cap));
+    c->pack_cap = cap;
+  }
+  k_pack_records<<<n < 4096 ? n : 4096, 512, 0, c->stream>>>(c->tab, 0, n, c->d_pack);
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipGetLastError());
+  *out_records = (const mrh_block_record*) c->d_pack;
+  return MRH_OK;
+}
+
+int mrh_unpack_blocks(mrh_ctx* c, int mode, const mrh_block_record* records, uint64_t n, int is_device_memory, uint64_t* out_taken) {
+  int rc = ensure_ready(c, "mrh_unpack_blocks");
+  if (rc) return rc;
+  if (out_taken) *out_taken = 0;
+  if (mode != MRH_UNPACK_HALO && mode != MRH_UNPACK_MERGE) return fail(c, MRH_ERR_INVALID_ARG, "mrh_unpack_blocks: bad mode %d", mode);
+  if (n == 0) return MRH_OK;
+  if (!records) return fail(c, MRH_ERR_INVALID_ARG, "mrh_unpack_blocks: null argument");
+  if (n > 0x7FFFFFFFull) return fail(c, MRH_ERR_CAPACITY, "mrh_unpack_blocks: %llu records in one call", (unsigned long long) n);
+  if (c->pending) return fail(c, MRH_ERR_STATE, "mrh_unpack_blocks: an exchange is pending (call mrh_integrate_resume)");
+  if (mode == MRH_UNPACK_MERGE && c->tab.multi_res) return fail(c, MRH_ERR_UNSUPPORTED, "mrh_unpack_blocks: merging variance-adaptive (multi-resolution) maps is not supported");
+  rc = set_aside_flags(c);
+  if (rc) return rc;
+  hipStream_t s = c->stream;
+  DevBuf<char> staged;
+  const char* d_rec = (const char*) records;
+  if (!is_device_memory) {  // host records (tests over gloo): one staged copy
+    HIP_TRY(c, staged.alloc((size_t) n * sizeof(mrh_block_record)));
+    HIP_TRY(c, hipMemcpyAsync(staged, records, (size_t) n * sizeof(mrh_block_record), hipMemcpyHostToDevice, s));
+    d_rec = staged;
+  }
+  if (!c->d_taken) HIP_TRY(c, hipMalloc((void**) &c->d_taken, sizeof(u32)));
+  HIP_TRY(c, hipMemsetAsync(c->d_taken, 0, sizeof(u32), s));
+  if (mode == MRH_UNPACK_HALO && c->halo_upper + n > c->halo_cap) {  // room for every record of this call on the halo list
+    const size_t cap = (c->halo_upper + n) + (c->halo_upper + n) / 2;
+    int4* grown = nullptr;
+    HIP_TRY(c, hipMalloc((void**) &grown, cap * sizeof(int4)));
+    if (c->d_halo && c->halo_upper) HIP_TRY(c, hipMemcpyAsync(grown, c->d_halo, c->halo_upper * sizeof(int4), hipMemcpyDeviceToDevice, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    if (c->d_halo) HIP_TRY(c, hipFree(c->d_halo));
+    c->d_halo = grown;
+    c->halo_cap = cap;
+  }
+  map_changed_in_bulk(c);
+  const int grid = (int) (n < 4096 ? n : 4096);
+  const size_t stride = sizeof(mrh_block_record);
+  if (mode == MRH_UNPACK_HALO) {
+    k_import<kImportHalo><<<grid, 512, 0, s>>>(c->map, c->tab, c->fast.summary, (int) n, d_rec, stride, d_rec + sizeof(mrh_block_desc), stride, c->d_halo, c->d_taken);
+    c->halo_upper += n;
+  } else {
+    k_import<kImportMerge><<<grid, 512, 0, s>>>(c->map, c->tab, c->fast.summary, (int) n, d_rec, stride, d_rec + sizeof(mrh_block_desc), stride, nullptr, c->d_taken);
+  }
+  u32 taken = 0;
+  HIP_TRY(c, hipMemcpyAsync(&taken, c->d_taken, sizeof(u32), hipMemcpyDeviceToHost, s));
+  HIP_TRY(c, hipStreamSynchronize(s));
+  HIP_TRY(c, hipGetLastError());
+  if (out_taken) *out_taken = taken;
+  u32 flags = 0;
+  rc = take_device_flags(c, &flags);
+  if (rc) return rc;
+  return check_device_flags(c, flags);
+}
+
+int mrh_drop_blocks(mrh_ctx* c, int mode, uint64_t* out_dropped) {
+  int rc = ensure_ready(c, "mrh_drop_blocks");
+  if (rc) return rc;
+  if (out_dropped) *out_dropped = 0;
+  if (c->pending) return fail(c, MRH_ERR_STATE, "mrh_drop_blocks: an exchange is pending (call mrh_integrate_resume)");
+  int n = 0;
+  if (mode == MRH_DROP_HALO) {
+    HIP_TRY(c, hipMemcpyAsync(&n, &c->tab.ctr[CTR_HALO], sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (n > 0) HIP_TRY(c, hipMemcpyAsync(c->tab.compact, c->d_halo, (size_t) n * sizeof(int4), hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(c, hipMemsetAsync(&c->tab.ctr[CTR_HALO], 0, sizeof(int), c->stream));
+    c->halo_upper = 0;
+  } else if (mode == MRH_DROP_FOREIGN || mode == MRH_DROP_ALL) {
+    rc = select_blocks(c, mode == MRH_DROP_FOREIGN ? kSelForeign : kSelAll, 0, &n);
+    if (rc) return rc;
+    HIP_TRY(c, hipMemsetAsync(&c->tab.ctr[CTR_HALO], 0, sizeof(int), c->stream));  // halo blocks are foreign: they go with the rest
+    c->halo_upper = 0;
+  } else {
+    return fail(c, MRH_ERR_INVALID_ARG, "mrh_drop_blocks: bad mode %d", mode);
+  }
+  rc = free_compact(c, n);
+  if (rc) return rc;
+  if (out_dropped) *out_dropped = (uint64_t) n;
+  return MRH_OK;
 }
 
 int mrh_get_triangle_blocks(mrh_ctx* c, const mrh_block_desc** out_descs, const uint32_t** out_counts, uint64_t* out_n) {

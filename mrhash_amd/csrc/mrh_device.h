@@ -31,6 +31,8 @@ constexpr u64 kKeyEmpty = 0xFFFFFFFFFFFFFFFFull;
 constexpr u64 kKeyTomb = 0xFFFFFFFFFFFFFFFEull;
 constexpr int kKeyBias = 1 << 20;        // block coordinates in [-2^20, 2^20)
 constexpr u32 kValCoarseBit = 0x80000000u;
+constexpr u32 kValNone = 0xFFFFFFFFu;    // table value of a key that holds no storage (pool exhausted at insert time): lookups
+                                         // treat it as absent, the next table rebuild (k_rehash_*) drops the key
 
 // device counters (one int array, indices below)
 enum Ctr : int {
@@ -43,10 +45,19 @@ enum Ctr : int {
   CTR_NREINT = 6,
   CTR_LIVE_FINE = 7,
   CTR_LIVE_COARSE = 8,
-  CTR_TOMBS = 9,
+  CTR_TOMBS = 9,         // tombstones found by the last table census (k_table_census)
   CTR_NTRI = 10,
   CTR_DUMP = 11,
-  CTR_COUNT = 32  // slots 16..23: the two list-counter sets of the two-launch fast path (mrh_fast2.h)
+  // 12, 13: CTR_CULLED, CTR_FREED_EARLY (mrh_fast.h)
+  CTR_REHASH = 14,       // decision of the last census: 1 = rebuild the table from the dense descriptors
+  CTR_ORPHANS = 15,      // keys published without storage since the last rebuild (kValNone)
+  // 16..23: the two list-counter sets of the two-launch fast path (mrh_fast2.h)
+  CTR_NREHASH = 24,      // table rebuilds since create / reset
+  CTR_HALO = 25,         // halo blocks imported from other shards (mrh_halo_import), dropped by mrh_halo_drop
+  CTR_MAXPROBE = 26,     // longest probe path of a live key (filled by k_count_live for mrh_get_stats)
+  CTR_TOMBS_NOW = 27,    // census accumulator
+  CTR_PACK = 28,         // blocks selected by k_halo_select / k_owner_select
+  CTR_COUNT = 32
 };
 // 64-bit profile counters
 enum Prof : int { PROF_UPDATED = 0, PROF_INSERTED = 1, PROF_FREED = 2, PROF_COMPACT = 3, PROF_COUNT = 4 };
@@ -472,6 +483,18 @@ __device__ __forceinline__ int hash_insert_at(const Tab& t, u64 key, int claim, 
     if (old == key) return -1;
   }
   return hash_insert(t, key);
+}
+
+// A key was published but the pool had no block for it (the reference prints and skips, vds.cu:566-569).  The slot may
+// not go back to TOMB inside the insert launch — an occupied slot has to stay occupied until the launch ends, or a second
+// inserter of ANOTHER key that already walked past it and a third one that now claims it could both win (a duplicate
+// entry).  So the key stays, marked as holding no storage: every lookup treats kValNone as absent, and the next table
+// rebuild (k_rehash_*, triggered by CTR_ORPHANS) drops it, after which the block can be allocated again.
+__device__ __forceinline__ void publish_without_storage(const Tab& t, const int slot, const int heap_ctr) {
+  atomicAdd(&t.ctr[heap_ctr], 1);  // undo the pop
+  t.vals[slot] = kValNone;
+  atomicAdd(&t.ctr[CTR_ORPHANS], 1);
+  atomicOr((u32*) &t.ctr[CTR_ERROR], ERR_POOL);
 }
 
 }  // namespace mrh

@@ -48,9 +48,7 @@ struct FrontShared {
 __device__ __forceinline__ int commit_block(const Tab& t, const Fast& f, const int slot, const int heap_idx, const i3 b, const u32 stamp,
                                             const int hwm_at_start) {
   if (heap_idx < 0) {
-    atomicAdd(&t.ctr[CTR_HEAP_FINE], 1);
-    atomicExch(&t.keys[slot], kKeyTomb);
-    atomicOr((u32*) &t.ctr[CTR_ERROR], ERR_POOL);
+    publish_without_storage(t, slot, CTR_HEAP_FINE);
     return -1;
   }
   const u32 H = t.heap_fine[heap_idx];

@@ -42,10 +42,7 @@ __device__ __forceinline__ void alloc_commit(const Tab& t, const Map& m, bool wo
   if (!won) return;
   const int idx = base - __popcll(ballot & lanemask_lt());
   if (idx < 0) {
-    // pool exhausted: undo (vds.cu:566-569 prints and skips the block)
-    atomicAdd(&t.ctr[CTR_HEAP_FINE], 1);
-    atomicExch(&t.keys[slot], kKeyTomb);
-    atomicOr((u32*) &t.ctr[CTR_ERROR], ERR_POOL);
+    publish_without_storage(t, slot, CTR_HEAP_FINE);  // pool exhausted (vds.cu:566-569 prints and skips the block)
     return;
   }
   const u32 H = t.heap_fine[idx];
@@ -144,9 +141,7 @@ __global__ __launch_bounds__(256) void k_alloc(const Cam c, const Map m, const T
             if (slot >= 0) {
               const int idx = atomicSub(&t.ctr[CTR_HEAP_FINE], 1);
               if (idx < 0) {
-                atomicAdd(&t.ctr[CTR_HEAP_FINE], 1);
-                atomicExch(&t.keys[slot], kKeyTomb);
-                            atomicOr((u32*) &t.ctr[CTR_ERROR], ERR_POOL);
+                publish_without_storage(t, slot, CTR_HEAP_FINE);
               } else {
                 const u32 H = t.heap_fine[idx];
                 t.vals[slot] = H;
@@ -551,9 +546,7 @@ __global__ __launch_bounds__(256) void k_realloc(const Tab t, const int4* __rest
     if (slot < 0) { if (slot == -2) atomicOr((u32*) &t.ctr[CTR_ERROR], ERR_TABLE); continue; }
     const int idx = atomicSub(&t.ctr[CTR_HEAP_COARSE], 1);
     if (idx < 0) {
-      atomicAdd(&t.ctr[CTR_HEAP_COARSE], 1);
-      atomicExch(&t.keys[slot], kKeyTomb);
-      atomicOr((u32*) &t.ctr[CTR_ERROR], ERR_POOL);
+      publish_without_storage(t, slot, CTR_HEAP_COARSE);
       continue;
     }
     const u32 u = t.heap_coarse[idx];
@@ -601,15 +594,69 @@ __global__ __launch_bounds__(256) void k_count_live(const Tab t) {
   for (int base = blockIdx.x * 256; base < total; base += gridDim.x * 256) {
     const int i = base + threadIdx.x;
     bool lf = false, lc = false;
+    int4 d = make_int4(0, 0, 0, 0);
     if (i < total) {
-      if (i < hwm) lf = (t.desc_fine[i].w & 1) != 0;
-      else lc = (t.desc_coarse[i - hwm].w & 1) != 0;
+      d = i < hwm ? t.desc_fine[i] : t.desc_coarse[i - hwm];
+      if (i < hwm) lf = (d.w & 1) != 0;
+      else lc = (d.w & 1) != 0;
     }
+    // probe-path length of every live key (mrh_stats.max_probe_length)
+    u32 steps = 0;
+    if (lf || lc) {
+      u64 key;
+      pack_key(mki3(d.x, d.y, d.z), key);
+      u32 s = hash_key(key) & t.slot_mask;
+      for (steps = 1; steps < t.max_probe && t.keys[s] != key; steps++) s = (s + 1) & t.slot_mask;
+    }
+    steps = wave_max_u32(steps);
     const u64 bf = __ballot(lf), bc = __ballot(lc);
     if (lane_id() == 0) {
       if (bf) atomicAdd(&t.ctr[CTR_LIVE_FINE], __popcll(bf));
       if (bc) atomicAdd(&t.ctr[CTR_LIVE_COARSE], __popcll(bc));
+      if (steps) atomicMax(&t.ctr[CTR_MAXPROBE], (int) steps);
     }
+  }
+}
+
+// =====================================================================================================
+// table maintenance.  Erasing from an open-address table leaves a tombstone (the reference's buckets return the slot to
+// FREE, vds.cu:1727-1824), and GC frees and re-creates the free-space blocks of the truncation band every frame: without
+// upkeep the never-used slots only get fewer, and a lookup of an absent key — 27 per block in k_mc, one per tile key in
+// k_front — walks ever longer runs.  Every few dozen frames (mrh_capi.hip: maintain_table) a census counts the tombstones;
+// above a quarter of the slots (or when a key was left without storage) the key array is cleared and rebuilt from the dense
+// block descriptors: O(live blocks), between two frames, no host round trip — the decision stays on the device.
+// =====================================================================================================
+__global__ __launch_bounds__(256) void k_table_census(const Tab t, const size_t slots) {
+  u32 n = 0;
+  for (size_t i = (size_t) blockIdx.x * 256 + threadIdx.x; i < slots; i += (size_t) gridDim.x * 256) n += t.keys[i] == kKeyTomb ? 1u : 0u;
+  for (int off = 32; off > 0; off >>= 1) n += __shfl_xor(n, off);
+  if (lane_id() == 0 && n) atomicAdd(&t.ctr[CTR_TOMBS_NOW], (int) n);
+}
+__global__ void k_rehash_decide(const Tab t, const u32 tomb_limit, const int force) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const int tombs = t.ctr[CTR_TOMBS_NOW];
+  t.ctr[CTR_TOMBS_NOW] = 0;
+  const int go = (force || (u32) tombs > tomb_limit || t.ctr[CTR_ORPHANS] > 0) ? 1 : 0;
+  t.ctr[CTR_REHASH] = go;
+  t.ctr[CTR_TOMBS] = go ? 0 : tombs;
+  if (go) { t.ctr[CTR_NREHASH]++; t.ctr[CTR_ORPHANS] = 0; }
+}
+__global__ __launch_bounds__(256) void k_rehash_clear(const Tab t, const size_t slots) {
+  if (t.ctr[CTR_REHASH] == 0) return;
+  for (size_t i = (size_t) blockIdx.x * 256 + threadIdx.x; i < slots; i += (size_t) gridDim.x * 256) t.keys[i] = kKeyEmpty;
+}
+__global__ __launch_bounds__(256) void k_rehash_insert(const Tab t) {
+  if (t.ctr[CTR_REHASH] == 0) return;
+  const int hwm = t.ctr[CTR_HWM_FINE];
+  const int total = t.multi_res ? hwm * 9 : hwm;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const int4 d = i < hwm ? t.desc_fine[i] : t.desc_coarse[i - hwm];
+    if (!(d.w & 1)) continue;
+    u64 key;
+    pack_key(mki3(d.x, d.y, d.z), key);
+    const int slot = hash_insert(t, key);  // distinct keys into a table without tombstones
+    if (slot < 0) { atomicOr((u32*) &t.ctr[CTR_ERROR], ERR_TABLE); continue; }
+    t.vals[slot] = i < hwm ? (u32) i : ((u32) (i - hwm) | kValCoarseBit);
   }
 }
 
@@ -634,37 +681,54 @@ __global__ __launch_bounds__(512) void k_dump(const Tab t, const int first, cons
   }
 }
 
-// reference 12-byte Voxel AoS -> SoA pool, one workgroup per imported block (inverse of k_dump)
-__global__ __launch_bounds__(512) void k_import(const Tab t, uint2* __restrict__ summary, const int n, const int4* __restrict__ descs,
-                                                const char* __restrict__ voxels) {
+// reference 12-byte Voxel AoS -> SoA pool, one workgroup per incoming block (inverse of k_dump).  Block e has its
+// descriptor at descs + e * desc_stride and its 512 voxels at voxels + e * vox_stride (bytes): separate arrays for
+// mrh_import_blocks (16 / 6144), interleaved mrh_block_record for the multi-GPU exchange (6160 / 6160).
+//   MODE 0  import: insert or overwrite
+//   MODE 1  halo:   only blocks of other shards that are 26-adjacent to a block position this shard owns; newly inserted
+//                   ones are remembered in halo_list (mrh_drop_blocks(MRH_DROP_HALO))
+//   MODE 2  merge:  voxel-wise weighted merge into what the map holds (combineVoxel, vhu.cuh:167-181)
+constexpr int kImportPlain = 0, kImportHalo = 1, kImportMerge = 2;
+template <int MODE>
+__global__ __launch_bounds__(512) void k_import(const Map m, const Tab t, uint2* __restrict__ summary, const int n, const char* __restrict__ descs,
+                                                const size_t desc_stride, const char* __restrict__ voxels, const size_t vox_stride,
+                                                int4* __restrict__ halo_list, u32* __restrict__ taken) {
   __shared__ u32 s_val;
   __shared__ float s_min[8];
   __shared__ u32 s_max[8];
   const int v = threadIdx.x;
   for (int e = blockIdx.x; e < n; e += gridDim.x) {
-    const int4 d = descs[e];
+    const int4 d = *(const int4*) (descs + (size_t) e * desc_stride);
     const bool coarse = d.w != 0;
     if (v == 0) {
-      u32 val = 0xFFFFFFFFu;
+      u32 val = kValNone;
       u64 key;
-      if (!pack_key(mki3(d.x, d.y, d.z), key)) {
+      bool wanted = true;
+      if (MODE == kImportHalo) {
+        const i3 b = mki3(d.x, d.y, d.z);
+        wanted = false;
+        if (!owns_block(m, b)) {
+          for (int k = 0; k < 27 && !wanted; k++) wanted = owns_block(m, mki3(b.x + (k % 3) - 1, b.y + ((k / 3) % 3) - 1, b.z + (k / 9) - 1));
+        }
+      }
+      if (!wanted) {
+      } else if (!pack_key(mki3(d.x, d.y, d.z), key)) {
         atomicOr((u32*) &t.ctr[CTR_ERROR], ERR_RANGE);
       } else {
         int slot = hash_find(t, key);
-        if (slot >= 0 && ((t.vals[slot] & kValCoarseBit) != 0) == coarse) {
-          val = t.vals[slot];  // overwrite in place
-        } else if (slot >= 0) {
+        const u32 have = slot >= 0 ? t.vals[slot] : kValNone;
+        if (have != kValNone && ((have & kValCoarseBit) != 0) == coarse) {
+          val = have;  // overwrite / merge in place
+        } else if (have != kValNone) {
           atomicOr((u32*) &t.ctr[CTR_ERROR], ERR_TABLE);  // same position at another resolution: not supported
         } else {
-          slot = hash_insert(t, key);
+          if (slot < 0) slot = hash_insert(t, key);  // (slot >= 0: a key left without storage by an exhausted pool takes the block)
           if (slot < 0) {
             atomicOr((u32*) &t.ctr[CTR_ERROR], ERR_TABLE);
           } else {
             const int idx = atomicSub(&t.ctr[coarse ? CTR_HEAP_COARSE : CTR_HEAP_FINE], 1);
             if (idx < 0) {
-              atomicAdd(&t.ctr[coarse ? CTR_HEAP_COARSE : CTR_HEAP_FINE], 1);
-              atomicExch(&t.keys[slot], kKeyTomb);
-              atomicOr((u32*) &t.ctr[CTR_ERROR], ERR_POOL);
+              publish_without_storage(t, slot, coarse ? CTR_HEAP_COARSE : CTR_HEAP_FINE);
             } else if (coarse) {
               const u32 u = t.heap_coarse[idx];
               val = u | kValCoarseBit;
@@ -677,23 +741,45 @@ __global__ __launch_bounds__(512) void k_import(const Tab t, uint2* __restrict__
               t.desc_fine[H] = make_int4(d.x, d.y, d.z, 1);
               atomicMax(&t.ctr[CTR_HWM_FINE], (int) H + 1);
             }
+            if (MODE == kImportHalo && val != kValNone) halo_list[atomicAdd(&t.ctr[CTR_HALO], 1)] = make_int4(d.x, d.y, d.z, (int) val);
           }
         }
       }
+      if (val != kValNone && taken) atomicAdd(taken, 1u);
       s_val = val;
     }
     __syncthreads();
     const u32 val = s_val;
     float mn = 3.402823466e+38f;
     u32 mx = 0;
-    if (val != 0xFFFFFFFFu && (!coarse || v < kCoarseVoxels)) {
-      const u32* in = (const u32*) (voxels + ((size_t) e * kBlockVoxels + v) * 12);
+    if (val != kValNone && (!coarse || v < kCoarseVoxels)) {
+      const u32* in = (const u32*) (voxels + (size_t) e * vox_stride + (size_t) v * 12);
       const VoxPtr vp = vox_ptr(t, val);
-      const float sdf = __uint_as_float(in[0]);
-      vp.sdf[v] = sdf;
-      vp.sumsq[v] = __uint_as_float(in[1]);
-      vp.rgbw[v] = in[2];
-      mx = in[2] >> 24;
+      float sdf = __uint_as_float(in[0]), ss = __uint_as_float(in[1]);
+      u32 rgbw = in[2];
+      bool store = true;
+      if (MODE == kImportMerge) {
+        const float s0 = vp.sdf[v];
+        const u32 old = vp.rgbw[v];
+        const u32 w0 = old >> 24, w1 = rgbw >> 24;
+        if (w1 == 0) {  // nothing observed on the incoming side
+          store = false;
+          sdf = s0; rgbw = old;
+        } else if (w0 != 0) {
+          const u32 c0x = old & 0x00FFFFFFu, c1x = rgbw & 0x00FFFFFFu;
+          const u32 rgbn = (c0x | c1x) - (((c0x ^ c1x) >> 1) & 0x007F7F7Fu);  // u8(0.5 c0 + 0.5 c1 + 0.5) per channel (mrh_fast.h: blend4)
+          const u32 wmax = (u32) (m.weight_max & 0xFF);
+          const u32 wn = (w0 + w1) < wmax ? (w0 + w1) : wmax;
+          sdf = (s0 * (float) w0 + sdf * (float) w1) / (float) (int) (w0 + w1);
+          rgbw = rgbn | (wn << 24);
+        }
+      }
+      if (store) {
+        vp.sdf[v] = sdf;
+        vp.sumsq[v] = ss;
+        vp.rgbw[v] = rgbw;
+      }
+      mx = rgbw >> 24;
       if (mx != 0) mn = fabsf(sdf);
     }
     for (int off = 32; off > 0; off >>= 1) {
@@ -703,11 +789,81 @@ __global__ __launch_bounds__(512) void k_import(const Tab t, uint2* __restrict__
     }
     if (lane_id() == 0) { s_min[v >> 6] = mn; s_max[v >> 6] = mx; }
     __syncthreads();
-    if (v == 0 && val != 0xFFFFFFFFu && !coarse && summary) {
+    if (v == 0 && val != kValNone && !coarse && summary) {
       for (int i = 1; i < 8; i++) { mn = fminf(mn, s_min[i]); mx = s_max[i] > mx ? s_max[i] : mx; }
       summary[val] = make_uint2(__float_as_uint(mn), mx);  // GC summary of the fast path
     }
     __syncthreads();
+  }
+}
+
+// ---- multi-GPU block exchange (include/mrhash_hip.h: mrh_pack_blocks / mrh_drop_blocks) ---------------------------
+// rank that owns a block: cubes of 2^shard_chunk_log2 blocks, hashed (owns_block is `== shard_rank`)
+__device__ __forceinline__ int owner_rank(const Map& m, const i3 b) {
+  if (m.shard_count <= 1) return 0;
+  const int sh = m.shard_chunk_log2;
+  const u32 cx = (u32) (b.x >> sh), cy = (u32) (b.y >> sh), cz = (u32) (b.z >> sh);
+  const u32 h = (cx * 73856093u) ^ (cy * 19349669u) ^ (cz * 83492791u);
+  return (int) ((h ^ (h >> 15)) % (u32) m.shard_count);
+}
+constexpr int kSelHalo = 0, kSelOwner = 1, kSelForeign = 2, kSelAll = 3;
+// live blocks that satisfy the predicate -> Tab::compact[0 .. CTR_COMPACT) (ballot + popcount prefix, one atomic per wave)
+__global__ __launch_bounds__(256) void k_select_blocks(const Map m, const Tab t, const int mode, const int rank_arg) {
+  const int hwm = t.ctr[CTR_HWM_FINE];
+  const int total = t.multi_res ? hwm * 9 : hwm;
+  for (int base = blockIdx.x * 256; base < total; base += gridDim.x * 256) {
+    const int i = base + threadIdx.x;
+    bool keep = false;
+    int4 d = make_int4(0, 0, 0, 0);
+    u32 val = 0;
+    if (i < total) {
+      if (i < hwm) { d = t.desc_fine[i]; val = (u32) i; }
+      else { const u32 u = (u32) (i - hwm); d = t.desc_coarse[u]; val = u | kValCoarseBit; }
+      if (d.w & 1) {
+        const i3 b = mki3(d.x, d.y, d.z);
+        const int owner = owner_rank(m, b);
+        if (mode == kSelHalo) {
+          const int side = 1 << m.shard_chunk_log2;
+          const int lx = b.x & (side - 1), ly = b.y & (side - 1), lz = b.z & (side - 1);
+          keep = owner == m.shard_rank && (lx == 0 || lx == side - 1 || ly == 0 || ly == side - 1 || lz == 0 || lz == side - 1);
+        } else if (mode == kSelOwner) {
+          keep = owner == rank_arg;
+        } else if (mode == kSelForeign) {
+          keep = owner != m.shard_rank;
+        } else {
+          keep = true;
+        }
+      }
+    }
+    const u64 ballot = __ballot(keep);
+    if (ballot) {
+      const int leader = __ffsll((long long) ballot) - 1;
+      int wbase = 0;
+      if ((int) lane_id() == leader) wbase = atomicAdd(&t.ctr[CTR_COMPACT], __popcll(ballot));
+      wbase = __shfl(wbase, leader);
+      if (keep) t.compact[wbase + __popcll(ballot & lanemask_lt())] = make_int4(d.x, d.y, d.z, (int) val);
+    }
+  }
+}
+// Tab::compact[first .. first + n) -> mrh_block_record[n] (16-byte descriptor + 512 reference-layout voxels, 6160 bytes)
+__global__ __launch_bounds__(512) void k_pack_records(const Tab t, const int first, const int n, char* __restrict__ records) {
+  const int v = threadIdx.x;
+  for (int e = blockIdx.x; e < n; e += gridDim.x) {
+    const int4 ent = t.compact[first + e];
+    const u32 val = (u32) ent.w;
+    const bool coarse = (val & kValCoarseBit) != 0;
+    char* rec = records + (size_t) e * 6160;
+    if (v == 0) *(int4*) rec = make_int4(ent.x, ent.y, ent.z, coarse ? 1 : 0);
+    float sdf = 0.f, ss = 0.f;
+    u32 rgbw = 0;
+    if (!coarse || v < kCoarseVoxels) {
+      const VoxPtr vp = vox_ptr(t, val);
+      sdf = vp.sdf[v]; ss = vp.sumsq[v]; rgbw = vp.rgbw[v];
+    }
+    u32* out = (u32*) (rec + 16 + (size_t) v * 12);
+    out[0] = __float_as_uint(sdf);
+    out[1] = __float_as_uint(ss);
+    out[2] = rgbw;
   }
 }
 
@@ -720,6 +876,7 @@ __global__ void k_get_voxel(const Map m, const Tab t, const int vx, const int vy
   const int s = hash_find(t, key);
   if (s < 0) return;
   const u32 val = t.vals[s];
+  if (val == kValNone) return;
   const int res = (val & kValCoarseBit) ? 1 : 0;
   const VoxPtr vp = vox_ptr(t, val);
   const u32 li = voxel_local_index(v, res);

@@ -163,14 +163,14 @@ __global__ __launch_bounds__(256) void k_points_walk(const Cam c, const Map m, c
       u64 bkey;
       int slot = -1;
       if (pack_key(block, bkey)) slot = hash_find(t, bkey);
-      if (slot >= 0) {
+      const u32 H = slot >= 0 ? t.vals[slot] : kValNone;
+      if (H != kValNone) {
         const f3 pc = se3_apply(c.Ri, c.ti, voxel_to_world(m.vs, cur));
         float sdf = range - norm3(pc);
         if (sdf <= -tr) break;
         if (sdf >= 0.f) sdf = fminf(tr, sdf);
         else sdf = fmaxf(-tr, sdf);
         if (EMIT) {
-          const u32 H = t.vals[slot];
           keys[out + cnt] = (((u64) H * 512u + voxel_local_index(cur, 0)) << pbits) | (u64) i;  // 64-bit: pools beyond 2^23 blocks
           vals[out + cnt] = sdf;
         }

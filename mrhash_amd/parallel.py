@@ -1,18 +1,28 @@
 """Multi-GPU support: one process per GPU, `torch.distributed` (backend "nccl" = RCCL over xGMI on the GPU
 box, "gloo" in the CPU tests).  The reference is single-GPU (no NCCL/MPI/streams anywhere), so this
-is new design:
+is new design.  Two ways to use N GPUs, and how they connect:
 
-* frame sharding (bench.py --gpus N): every rank fuses its own segment of the stream into its own sub-map;
-  no collective in the per-frame loop.
-* tile sharding (`Params.shard_rank/shard_count/shard_chunk_log2`): every rank sees every frame but only inserts
-  the blocks whose chunk it owns, so the union of the tables is bit-identical to the single-GPU map.  The one
-  exchange step is before marching cubes: corner samples reach into neighbouring blocks, so each rank needs the
-  blocks of other ranks that touch its chunks -> all-gather of boundary blocks (`exchange_halo`), then every rank
-  extracts triangles for the blocks it owns and rank 0 merges the buffers into the single-GPU canonical order
-  (`gather_mesh`).
+* tile sharding (`Params.shard_rank/shard_count/shard_chunk_log2`, `Engine.set_sharding`) — the result-identical mode.
+  Every rank sees every frame but only inserts the blocks whose chunk it owns, so the union of the tables is
+  bit-identical to the single-GPU map.  Exchange steps: an element-wise MIN all-reduce of the per-pixel z-buffer on
+  starve frames (`integrate`), and before marching cubes an all-gather of boundary blocks (`exchange_halo`): corner
+  samples reach into neighbouring blocks, so each rank needs the blocks of other ranks that touch its chunks.  Every
+  rank then extracts triangles for the blocks it owns and rank 0 merges the buffers into the single-GPU canonical
+  order (`gather_mesh`).
+* frame sharding (bench.py --gpus N, BASELINE.json configs[3]) — every rank fuses its own segment of the stream into
+  its own sub-map owning everything; no collective in the per-frame loop.  `merge_submaps` then turns the N sub-maps
+  into ONE tile-sharded map: every rank sends each block to the rank that owns its tile (all-to-all), the owner folds
+  the sub-maps with combineVoxel's weighted mean in rank order, and from there on the map is a tile-sharded one
+  (halo exchange, marching cubes, mesh gather as above).
+
+Blocks travel as `mrh_block_record`s (16-byte descriptor + 512 reference-layout voxels) in DEVICE memory: the
+library packs them into a device buffer (`mrh_pack_blocks`), RCCL moves device buffers, the library consumes device
+buffers (`mrh_unpack_blocks`).  Nothing is staged through the host on the nccl path; the gloo path (CPU tests, and
+the single-GPU test box where two ranks share one device) stages through host tensors because gloo needs them.
 """
 from __future__ import annotations
 
+import ctypes
 import os
 from typing import List, Optional, Tuple
 
@@ -21,6 +31,7 @@ import numpy as np
 from . import capi
 
 P0, P1, P2 = 73856093, 19349669, 83492791
+REC = capi.RECORD_BYTES
 
 
 def owner_of_blocks(xyz: np.ndarray, world: int, chunk_log2: int = 3) -> np.ndarray:
@@ -58,42 +69,52 @@ def init_process_group(backend: Optional[str] = None):
     return dist
 
 
-def _all_gather_bytes(dist, payload: bytes, device) -> List[bytes]:
-    """Variable-length all-gather: sizes first, then padded uint8 tensors (one collective each)."""
+class _DeviceArray:
+    """Zero-copy view of device memory for torch.as_tensor (CUDA array interface v2)."""
+
+    def __init__(self, ptr: int, n: int, typestr: str = "<i8"):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False), "version": 2}
+
+
+def _bytes_view(ptr: int, nbytes: int, on_device: bool):
+    """uint8 torch tensor over `nbytes` at `ptr` (device or host memory), no copy."""
     import torch
 
-    world = dist.get_world_size()
-    n = torch.tensor([len(payload)], dtype=torch.int64, device=device)
-    sizes = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
-    dist.all_gather(sizes, n)
-    sizes = [int(s.item()) for s in sizes]
-    mx = max(max(sizes), 1)
-    buf = torch.zeros(mx, dtype=torch.uint8, device=device)
-    if payload:
-        buf[: len(payload)] = torch.frombuffer(bytearray(payload), dtype=torch.uint8).to(device)
-    out = [torch.zeros(mx, dtype=torch.uint8, device=device) for _ in range(world)]
-    dist.all_gather(out, buf)
-    return [bytes(o[:s].cpu().numpy().tobytes()) for o, s in zip(out, sizes)]
+    if nbytes == 0:
+        return torch.empty(0, dtype=torch.uint8, device="cuda" if on_device else "cpu")
+    if on_device:
+        return torch.as_tensor(_DeviceArray(ptr, nbytes, "|u1"), device="cuda")
+    return torch.from_numpy(np.ctypeslib.as_array((ctypes.c_uint8 * nbytes).from_address(ptr)))
 
 
-def _device_for(dist):
+def _comm_device(dist):
     import torch
 
     return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
 
 
-class _DeviceArray:
-    """Zero-copy view of device memory for torch.as_tensor (CUDA array interface v2)."""
+def _all_gather_counts(dist, values: List[int], dev) -> np.ndarray:
+    """[world, len(values)] int64: every rank's `values`."""
+    import torch
 
-    def __init__(self, ptr: int, n: int):
-        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<i8", "data": (ptr, False), "version": 2}
+    world = dist.get_world_size()
+    mine = torch.tensor(values, dtype=torch.int64, device=dev)
+    out = torch.empty(world * len(values), dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(out, mine)
+    return out.cpu().numpy().reshape(world, len(values))
+
+
+def _unpack(engine: capi.Engine, mode: int, buf, first_byte: int, n_records: int) -> int:
+    """Hands records [first_byte, first_byte + n * REC) of a torch uint8 tensor to the library where they lie."""
+    if n_records == 0:
+        return 0
+    return engine.unpack_blocks(mode, buf.data_ptr() + first_byte, n_records, buf.is_cuda)
 
 
 def integrate(engine: capi.Engine, dist=None, n_frames_invalidate: int = -1):
     """One frame on a tile-sharded context.  On starve frames the library stops twice for an element-wise MIN of the
     per-pixel z-buffer over all ranks (the only data-path collective of the fusion loop; every n-th frame, 2.4 MB
     at 640x480): RCCL all-reduce over xGMI on the GPU box, gloo in the CPU tests."""
-    import ctypes
     import torch
 
     pending = engine.integrate(n_frames_invalidate)
@@ -118,7 +139,8 @@ def integrate(engine: capi.Engine, dist=None, n_frames_invalidate: int = -1):
 
 
 def boundary_mask(descs: np.ndarray, chunk_log2: int) -> np.ndarray:
-    """Blocks on the surface of their chunk: the only ones a neighbouring chunk's marching cubes can read."""
+    """Blocks on the surface of their chunk: the only ones a neighbouring chunk's marching cubes can read
+    (host mirror of the MRH_PACK_HALO predicate, used by tests)."""
     side = 1 << chunk_log2
     m = np.zeros(len(descs), dtype=bool)
     for ax in ("x", "y", "z"):
@@ -127,65 +149,129 @@ def boundary_mask(descs: np.ndarray, chunk_log2: int) -> np.ndarray:
     return m
 
 
-def exchange_halo(engine: capi.Engine, dist, chunk_log2: int = 3) -> int:
-    """All-gather of boundary blocks (16-byte desc + 512 x 12-byte voxels each) and import of the ones that are
-    26-adjacent to a chunk this rank owns.  Returns the number of imported halo blocks."""
+def exchange_halo(engine: capi.Engine, dist) -> int:
+    """All-gather of boundary blocks, device to device: the library selects the owned blocks on the surface of their
+    chunk and packs their records into a device buffer (`mrh_pack_blocks(MRH_PACK_HALO)`), one
+    `all_gather_into_tensor` moves them (padded to the largest rank's count), and each rank's segment is consumed where
+    it landed (`mrh_unpack_blocks(MRH_UNPACK_HALO)`: only blocks 26-adjacent to a position this rank owns are kept).
+    Terminal for fusion until `drop_halo`: the library refuses to integrate while halo blocks are present.
+    Returns the number of halo blocks this rank took."""
+    import torch
+
     world, rank = dist.get_world_size(), dist.get_rank()
     if world == 1:
         return 0
-    descs, voxels = engine.dump_blocks()
-    mine = owner_of_blocks(np.stack([descs["x"], descs["y"], descs["z"]], 1), world, chunk_log2) == rank if len(descs) else np.zeros(0, bool)
-    sel = mine & boundary_mask(descs, chunk_log2) if len(descs) else mine
-    payload = descs[sel].tobytes() + voxels[sel].tobytes()
-    header = np.array([int(sel.sum())], dtype=np.int64).tobytes()
-    parts = _all_gather_bytes(dist, header + payload, _device_for(dist))
-    imported = 0
-    for r, blob in enumerate(parts):
-        if r == rank:
-            continue
-        n = int(np.frombuffer(blob[:8], dtype=np.int64)[0])
-        if n == 0:
-            continue
-        d = np.frombuffer(blob[8: 8 + 16 * n], dtype=capi.DESC_DTYPE)
-        v = np.frombuffer(blob[8 + 16 * n: 8 + 16 * n + n * 512 * 12], dtype=capi.VOXEL_DTYPE).reshape(n, 512)
-        xyz = np.stack([d["x"], d["y"], d["z"]], 1).astype(np.int64)
-        need = np.zeros(n, dtype=bool)
-        for dx in (-1, 0, 1):
-            for dy in (-1, 0, 1):
-                for dz in (-1, 0, 1):
-                    if dx == dy == dz == 0:
-                        continue
-                    need |= owner_of_blocks(xyz + np.array([dx, dy, dz]), world, chunk_log2) == rank
-        if need.any():
-            engine.import_blocks(d[need], v[need])
-            imported += int(need.sum())
-    return imported
+    dev = _comm_device(dist)
+    ptr, n, on_device = engine.pack_blocks(capi.PACK_HALO)
+    counts = _all_gather_counts(dist, [n], dev)[:, 0]
+    mx = int(counts.max())
+    if mx == 0:
+        return 0
+    send = torch.zeros(mx * REC, dtype=torch.uint8, device=dev)
+    if n:
+        send[: n * REC].copy_(_bytes_view(ptr, n * REC, on_device))  # device-to-device on the nccl path
+    recv = torch.empty(world * mx * REC, dtype=torch.uint8, device=dev)
+    dist.all_gather_into_tensor(recv, send)
+    if recv.is_cuda:
+        torch.cuda.synchronize()
+    taken = 0
+    for r in range(world):
+        if r != rank:
+            taken += _unpack(engine, capi.UNPACK_HALO, recv, r * mx * REC, int(counts[r]))
+    return taken
+
+
+def drop_halo(engine: capi.Engine) -> int:
+    """Removes the blocks `exchange_halo` brought in (after the extraction that needed them); fusion may continue."""
+    return engine.drop_blocks(capi.DROP_HALO)
+
+
+def merge_submaps(engine: capi.Engine, dist, chunk_log2: int = 3) -> dict:
+    """Frame-sharded sub-maps -> one tile-sharded map.  Every rank packs, per destination, the blocks whose tile that
+    rank owns (`MRH_PACK_OWNER`), one all-to-all moves them (RCCL `all_to_all_single` with per-rank split sizes; gloo
+    has no all-to-all on CPU tensors, so the test path all-gathers and selects), the local map is emptied and the N
+    incoming sub-maps are folded in rank order with combineVoxel's weighted mean (`MRH_UNPACK_MERGE`,
+    vhu.cuh:167-181).  TSDF values and weights of the result equal a single-GPU fusion of all frames up to the
+    rounding of the running mean (while weights stay below the clamp); colours are order-dependent (50/50 blend).
+    Returns {"sent": blocks sent, "received": blocks received, "bytes": payload bytes through the collective}."""
+    import torch
+
+    world, rank = dist.get_world_size(), dist.get_rank()
+    engine.set_sharding(rank, world, chunk_log2)
+    if world == 1:
+        return {"sent": 0, "received": 0, "bytes": 0}
+    dev = _comm_device(dist)
+    parts, out_counts = [], []
+    for dest in range(world):
+        ptr, n, on_device = engine.pack_blocks(capi.PACK_OWNER, dest)
+        out_counts.append(n)
+        t = torch.empty(n * REC, dtype=torch.uint8, device=dev)
+        if n:
+            t.copy_(_bytes_view(ptr, n * REC, on_device))  # the pack buffer is reused by the next pack
+        parts.append(t)
+    counts = _all_gather_counts(dist, out_counts, dev)  # counts[src, dest]
+    in_counts = [int(counts[src, rank]) for src in range(world)]
+    send = torch.cat(parts) if parts else torch.empty(0, dtype=torch.uint8, device=dev)
+    engine.drop_blocks(capi.DROP_ALL)  # the owned blocks come back through the fold, at this rank's position in the order
+    if dist.get_backend() == "nccl":
+        recv = torch.empty(sum(in_counts) * REC, dtype=torch.uint8, device=dev)
+        dist.all_to_all_single(recv, send, output_split_sizes=[c * REC for c in in_counts], input_split_sizes=[c * REC for c in out_counts])
+        torch.cuda.synchronize()
+        offsets = np.concatenate([[0], np.cumsum(in_counts)])[:-1] * REC
+        segments = [(recv, int(offsets[src]), in_counts[src]) for src in range(world)]
+    else:
+        mx = int(counts.sum(axis=1).max())
+        padded = torch.zeros(mx * REC, dtype=torch.uint8, device=dev)
+        padded[: send.numel()].copy_(send)
+        gathered = torch.empty(world * mx * REC, dtype=torch.uint8, device=dev)
+        dist.all_gather_into_tensor(gathered, padded)
+        segments = []
+        for src in range(world):
+            before = int(counts[src, :rank].sum())
+            segments.append((gathered, (src * mx + before) * REC, in_counts[src]))
+    for buf, first, n in segments:  # rank order: the fold is deterministic for a given world size
+        _unpack(engine, capi.UNPACK_MERGE, buf, first, n)
+    sent = int(sum(out_counts)) - out_counts[rank]
+    return {"sent": sent, "received": int(sum(in_counts)) - in_counts[rank], "bytes": sent * REC}
 
 
 def gather_mesh(engine: capi.Engine, dist) -> Optional[Tuple[np.ndarray, np.ndarray, np.ndarray, np.ndarray]]:
     """Every rank extracts the triangles of the blocks it owns; rank 0 merges the per-block runs by block position
-    (the canonical order) and runs the CPU mesh post-process.  Returns (triangles, V, F, C) on rank 0, None elsewhere."""
-    rank = dist.get_rank()
+    (the canonical order) and runs the mesh post-process.  Returns (triangles, V, F, C) on rank 0, None elsewhere."""
+    import torch
+
+    world, rank = dist.get_world_size(), dist.get_rank()
+    dev = _comm_device(dist)
     tris = engine.extract_triangles()
     descs, counts = engine.triangle_blocks()
     keep = counts > 0
-    blob = (np.array([int(keep.sum()), int(tris.shape[0])], dtype=np.int64).tobytes() + descs[keep].tobytes()
-            + counts[keep].tobytes() + tris.tobytes())
-    parts = _all_gather_bytes(dist, blob, _device_for(dist))
+    nb, nt = int(keep.sum()), int(tris.shape[0])
+    blob = np.concatenate([np.frombuffer(descs[keep].tobytes(), np.uint8), np.frombuffer(counts[keep].tobytes(), np.uint8),
+                           np.frombuffer(tris.tobytes(), np.uint8)]) if nb else np.zeros(0, np.uint8)
+    sizes = _all_gather_counts(dist, [nb, nt, len(blob)], dev)
+    mx = max(int(sizes[:, 2].max()), 1)
+    send = torch.zeros(mx, dtype=torch.uint8, device=dev)
+    if len(blob):
+        send[: len(blob)].copy_(torch.from_numpy(blob))
+    recv = torch.empty(world * mx, dtype=torch.uint8, device=dev)
+    dist.all_gather_into_tensor(recv, send)
     if rank != 0:
         return None
-    runs = []  # (x, y, z, triangles of that block)
-    for p in parts:
-        nb, nt = (int(v) for v in np.frombuffer(p[:16], dtype=np.int64))
-        d = np.frombuffer(p[16: 16 + 16 * nb], dtype=capi.DESC_DTYPE)
-        c = np.frombuffer(p[16 + 16 * nb: 16 + 20 * nb], dtype=np.uint32)
-        t = np.frombuffer(p[16 + 20 * nb: 16 + 20 * nb + nt * 72], dtype=capi.TRI_DTYPE).reshape(nt, 3)
-        off = 0
-        for i in range(nb):
-            runs.append((int(d["x"][i]), int(d["y"][i]), int(d["z"][i]), t[off: off + int(c[i])]))
-            off += int(c[i])
-    runs.sort(key=lambda r: r[:3])
-    merged = np.concatenate([r[3] for r in runs]) if runs else np.zeros((0, 3), dtype=capi.TRI_DTYPE)
+    host = recv.cpu().numpy()
+    all_d, all_c, all_t = [], [], []
+    for r in range(world):
+        b, t = int(sizes[r, 0]), int(sizes[r, 1])
+        p = host[r * mx: r * mx + int(sizes[r, 2])]
+        all_d.append(np.frombuffer(p[: 16 * b].tobytes(), dtype=capi.DESC_DTYPE))
+        all_c.append(np.frombuffer(p[16 * b: 20 * b].tobytes(), dtype=np.uint32))
+        all_t.append(np.frombuffer(p[20 * b: 20 * b + t * 72].tobytes(), dtype=capi.TRI_DTYPE).reshape(t, 3))
+    d, c, t = np.concatenate(all_d), np.concatenate(all_c).astype(np.int64), np.concatenate(all_t)
+    # per-block runs ordered by block position (every block is owned by exactly one rank): one gather, no Python loop
+    starts = np.concatenate([[0], np.cumsum(c)])[:-1]
+    order = np.lexsort((d["z"], d["y"], d["x"]))
+    lens = c[order]
+    idx = np.repeat(starts[order] - np.concatenate([[0], np.cumsum(lens)])[:-1], lens) + np.arange(int(lens.sum()))
+    merged = t[idx] if len(idx) else np.zeros((0, 3), dtype=capi.TRI_DTYPE)
     engine.process_triangles(merged)
     V, F, C = engine.extract_mesh()
     return merged, V, F, C

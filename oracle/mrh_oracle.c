@@ -151,6 +151,11 @@ struct mrh_ctx {
   int profile;
   uint64_t last_updated, last_inserted, last_freed, total_updated, total_compact;
   uint32_t error_flags;
+  /* multi-GPU block exchange (test counterpart of the HIP library's device buffers) */
+  mrh_block_record* pack;
+  uint64_t pack_cap;
+  mrh_block_desc* halo;
+  uint64_t n_halo, halo_cap;
   char err[256];
 };
 
@@ -1243,6 +1248,7 @@ const char* mrh_version(void) {
 const char* mrh_last_error(const mrh_ctx* ctx) { return ctx ? ctx->err : g_create_err; }
 
 static void init_buffers(mrh_ctx* c) {
+  c->n_halo = 0;
   /* voxel_data_structures.cpp:58-87 resetBuffers + ctor counters (voxel_data_structures.cuh:88-96) */
   for (unsigned i = 0; i < c->num_sdf_blocks; i++) {
     for (unsigned j = 0; j < 8; j++) c->heap_low[(size_t) i * 8 + j] = c->num_sdf_blocks * 8;
@@ -1315,7 +1321,7 @@ int mrh_destroy(mrh_ctx* c) {
   free(c->table); free(c->compact); free(c->decision); free(c->mutex); free(c->heap_high); free(c->heap_low);
   free(c->blocks); free(c->realloc_pos); free(c->realloc_res); free(c->reintegrate); free(c->depth_buff);
   free(c->depth); free(c->rgb); free(c->points); free(c->cloud); free(c->tris); free(c->tri_blocks); free(c->tri_counts); free(c->V); free(c->C); free(c->F);
-  free(c->qt_leaves); free(c->seeds);
+  free(c->qt_leaves); free(c->seeds); free(c->pack); free(c->halo);
   free(c);
   return MRH_OK;
 }
@@ -1543,6 +1549,7 @@ int mrh_integrate_points(mrh_ctx* c, int n_frames_invalidate) {
 int mrh_integrate(mrh_ctx* c, int n_frames_invalidate) {
   if (!c) return MRH_ERR_INVALID_ARG;
   if (c->pending) return fail(c, MRH_ERR_STATE, "mrh_integrate: an exchange is pending (call mrh_integrate_resume)");
+  if (c->n_halo) return fail(c, MRH_ERR_STATE, "mrh_integrate: halo blocks of other shards are present (call mrh_drop_blocks(MRH_DROP_HALO))");
   if (!c->has_camera) return fail(c, MRH_ERR_STATE, "mrh_integrate: set_camera has not been called");
   if (!c->depth || !c->rgb) return fail(c, MRH_ERR_STATE, "mrh_integrate: depth and rgb images are required");
   if (c->depth_rows != (int) c->rows || c->depth_cols != (int) c->cols || c->rgb_rows != (int) c->rows || c->rgb_cols != (int) c->cols)
@@ -1865,6 +1872,170 @@ int mrh_import_blocks(mrh_ctx* c, const mrh_block_desc* descs, const mrh_voxel* 
     }
     memcpy(&c->blocks[(size_t) e.ptr], &voxels[k * 512], (size_t) num_voxels_of(e.resolution) * sizeof(Voxel));
   }
+  return MRH_OK;
+}
+
+/* ---- multi-GPU block exchange: no reference counterpart (the reference is single-GPU).  Same semantics as the HIP
+ * library (include/mrhash_hip.h), host memory; MRH_UNPACK_MERGE restates combineVoxel (vhu.cuh:167-181). */
+int mrh_peek_error_flags(mrh_ctx* c, uint32_t* out_new_flags) {
+  if (!c || !out_new_flags) return MRH_ERR_INVALID_ARG;
+  *out_new_flags = 0;
+  return MRH_OK;
+}
+
+int mrh_set_sharding(mrh_ctx* c, int shard_rank, int shard_count, int shard_chunk_log2) {
+  if (!c || shard_count < 1 || shard_rank < 0 || shard_rank >= shard_count) return MRH_ERR_INVALID_ARG;
+  c->p.shard_rank = shard_rank; c->p.shard_count = shard_count; c->p.shard_chunk_log2 = shard_chunk_log2;
+  return MRH_OK;
+}
+
+static int owner_rank(const mrh_ctx* c, i3 b) {
+  if (c->p.shard_count <= 1) return 0;
+  const int sh = (c->p.shard_chunk_log2 > 0 && c->p.shard_chunk_log2 < 16) ? c->p.shard_chunk_log2 : 3;
+  const uint32_t cx = (uint32_t) (b.x >> sh), cy = (uint32_t) (b.y >> sh), cz = (uint32_t) (b.z >> sh);
+  const uint32_t h = (cx * P0) ^ (cy * P1) ^ (cz * P2);
+  return (int) ((h ^ (h >> 15)) % (uint32_t) c->p.shard_count);
+}
+
+int mrh_pack_blocks(mrh_ctx* c, int mode, int rank_arg, const mrh_block_record** out_records, uint64_t* out_n, int* out_is_device_memory) {
+  if (!c || !out_records || !out_n) return MRH_ERR_INVALID_ARG;
+  if (out_is_device_memory) *out_is_device_memory = 0;
+  const int sh = (c->p.shard_chunk_log2 > 0 && c->p.shard_chunk_log2 < 16) ? c->p.shard_chunk_log2 : 3;
+  const int side = 1 << sh;
+  uint64_t n = 0;
+  for (int pass = 0; pass < 2; pass++) {
+    if (pass == 1) {
+      if (n > c->pack_cap) {
+        free(c->pack);
+        c->pack = (mrh_block_record*) malloc((size_t) n * sizeof(mrh_block_record));
+        if (!c->pack) { c->pack_cap = 0; return fail(c, MRH_ERR_CAPACITY, "mrh_pack_blocks: out of memory"); }
+        c->pack_cap = n;
+      }
+      n = 0;
+    }
+    for (unsigned i = 0; i < c->total_size; i++) {
+      const HashEntry* e = &c->table[i];
+      if (e->ptr == FREE_ENTRY) continue;
+      const int owner = owner_rank(c, e->pos);
+      int keep;
+      if (mode == MRH_PACK_HALO) {
+        const int lx = e->pos.x & (side - 1), ly = e->pos.y & (side - 1), lz = e->pos.z & (side - 1);
+        keep = owner == c->p.shard_rank && (lx == 0 || lx == side - 1 || ly == 0 || ly == side - 1 || lz == 0 || lz == side - 1);
+      } else if (mode == MRH_PACK_OWNER) {
+        keep = owner == rank_arg;
+      } else {
+        return fail(c, MRH_ERR_INVALID_ARG, "mrh_pack_blocks: bad mode");
+      }
+      if (!keep) continue;
+      if (pass == 1) {
+        mrh_block_record* r = &c->pack[n];
+        r->desc.x = e->pos.x; r->desc.y = e->pos.y; r->desc.z = e->pos.z; r->desc.resolution = e->resolution;
+        memset(r->voxels, 0, sizeof r->voxels);
+        memcpy(r->voxels, &c->blocks[(size_t) e->ptr], (size_t) num_voxels_of(e->resolution) * sizeof(mrh_voxel));
+      }
+      n++;
+    }
+  }
+  *out_n = n;
+  *out_records = n ? c->pack : NULL;
+  return MRH_OK;
+}
+
+int mrh_unpack_blocks(mrh_ctx* c, int mode, const mrh_block_record* records, uint64_t n, int is_device_memory, uint64_t* out_taken) {
+  if (!c || (n && !records)) return MRH_ERR_INVALID_ARG;
+  (void) is_device_memory; /* everything is host memory here */
+  if (mode != MRH_UNPACK_HALO && mode != MRH_UNPACK_MERGE) return fail(c, MRH_ERR_INVALID_ARG, "mrh_unpack_blocks: bad mode");
+  if (mode == MRH_UNPACK_MERGE && c->p.sdf_var_threshold > 0.f) return fail(c, MRH_ERR_UNSUPPORTED, "mrh_unpack_blocks: merging multi-resolution maps is not supported");
+  uint64_t taken = 0;
+  for (uint64_t k = 0; k < n; k++) {
+    const mrh_block_record* r = &records[k];
+    const i3 pos = {r->desc.x, r->desc.y, r->desc.z};
+    if (mode == MRH_UNPACK_HALO) {
+      int wanted = 0;
+      if (!owns_block(c, pos))
+        for (int j = 0; j < 27 && !wanted; j++) {
+          const i3 q = {pos.x + (j % 3) - 1, pos.y + ((j / 3) % 3) - 1, pos.z + (j / 9) - 1};
+          wanted = owns_block(c, q);
+        }
+      if (!wanted) continue;
+    }
+    HashEntry e = get_hash_entry(c, pos);
+    const int fresh = e.ptr == FREE_ENTRY;
+    if (fresh) {
+      int prev_free = heap_high_free(c) + heap_low_free(c);
+      for (;;) { /* allocBlock's retry protocol, vds.cu:901-921 */
+        reset_mutex(c);
+        (void) alloc_block(c, pos, r->desc.resolution, 0);
+        const int cur = heap_high_free(c) + heap_low_free(c);
+        if (cur == prev_free) break;
+        prev_free = cur;
+      }
+      e = get_hash_entry(c, pos);
+      if (e.ptr == FREE_ENTRY) return fail(c, MRH_ERR_CAPACITY, "mrh_unpack_blocks: could not insert block");
+      if (mode == MRH_UNPACK_HALO) {
+        if (c->n_halo == c->halo_cap) {
+          c->halo_cap = c->halo_cap ? 2 * c->halo_cap : 1024;
+          c->halo = (mrh_block_desc*) realloc(c->halo, (size_t) c->halo_cap * sizeof(mrh_block_desc));
+        }
+        c->halo[c->n_halo++] = r->desc;
+      }
+    } else if (e.resolution != r->desc.resolution) {
+      return fail(c, MRH_ERR_CAPACITY, "mrh_unpack_blocks: block exists at another resolution");
+    }
+    const int nv = num_voxels_of(e.resolution);
+    Voxel* dst = &c->blocks[(size_t) e.ptr];
+    if (mode == MRH_UNPACK_HALO) {
+      memcpy(dst, r->voxels, (size_t) nv * sizeof(Voxel));
+    } else {
+      for (int i = 0; i < nv; i++) {
+        const Voxel v0 = dst[i], v1 = r->voxels[i];
+        if (v1.weight == 0) continue;
+        if (v0.weight == 0) { dst[i] = v1; continue; }
+        Voxel out = v1; /* sum_squared: the later sub-map's term */
+        for (int ch = 0; ch < 3; ch++) out.rgb[ch] = (uint8_t) ((0.5f * (float) v0.rgb[ch] + 0.5f * (float) v1.rgb[ch]) + 0.5f);
+        out.sdf = (v0.sdf * (float) v0.weight + v1.sdf * (float) v1.weight) / (float) ((int) v0.weight + (int) v1.weight);
+        const int wsum = (int) v0.weight + (int) v1.weight;
+        const int wmax = c->p.integration_weight_max & 0xFF;
+        out.weight = (uint8_t) (wsum < wmax ? wsum : wmax);
+        dst[i] = out;
+      }
+    }
+    taken++;
+  }
+  if (out_taken) *out_taken = taken;
+  return MRH_OK;
+}
+
+static void drop_position(mrh_ctx* c, i3 pos) {
+  const HashEntry e = get_hash_entry(c, pos);
+  if (e.ptr == FREE_ENTRY) return;
+  const int nv = num_voxels_of(e.resolution);
+  reset_mutex(c);
+  if (delete_hash_entry_element(c, pos))
+    for (int i = 0; i < nv; ++i) delete_voxel(&c->blocks[(size_t) e.ptr + i]);
+}
+
+int mrh_drop_blocks(mrh_ctx* c, int mode, uint64_t* out_dropped) {
+  if (!c) return MRH_ERR_INVALID_ARG;
+  uint64_t n = 0;
+  if (mode == MRH_DROP_HALO) {
+    for (uint64_t k = 0; k < c->n_halo; k++) { const i3 pos = {c->halo[k].x, c->halo[k].y, c->halo[k].z}; drop_position(c, pos); n++; }
+  } else if (mode == MRH_DROP_FOREIGN || mode == MRH_DROP_ALL) {
+    uint64_t cap = 0;
+    for (unsigned i = 0; i < c->total_size; i++) cap += c->table[i].ptr != FREE_ENTRY;
+    i3* list = (i3*) malloc((size_t) (cap ? cap : 1) * sizeof(i3));
+    for (unsigned i = 0; i < c->total_size; i++) {
+      const HashEntry* e = &c->table[i];
+      if (e->ptr == FREE_ENTRY) continue;
+      if (mode == MRH_DROP_ALL || !owns_block(c, e->pos)) list[n++] = e->pos;
+    }
+    for (uint64_t k = 0; k < n; k++) drop_position(c, list[k]);
+    free(list);
+  } else {
+    return fail(c, MRH_ERR_INVALID_ARG, "mrh_drop_blocks: bad mode");
+  }
+  c->n_halo = 0;
+  if (out_dropped) *out_dropped = n;
   return MRH_OK;
 }
 

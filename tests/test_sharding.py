@@ -81,20 +81,61 @@ for f in (synth.cfg1_sphere(), synth.cfg1_sphere(zc=1.51), synth.cfg1_sphere(zc=
     pu.feed(e, f, dist=dist)   # frames 2 and 3... are starve frames: z-buffer MIN all-reduce over the ranks
 e.sync()
 n_own = len(e.dump_blocks()[0])
-n_halo = parallel.exchange_halo(e, dist, chunk_log2=1)
+n_halo = parallel.exchange_halo(e, dist)
+refused = False
+try:
+    e.integrate()           # halo blocks present: fusing on is refused until they are dropped
+except capi.MrhError as ex:
+    refused = ex.code == capi.MRH_ERR_STATE
 res = parallel.gather_mesh(e, dist)
+n_dropped = parallel.drop_halo(e)
+n_after = len(e.dump_blocks()[0])
 if rank == 0:
     tris, V, F, C = res
-    np.savez({out!r}, tris=tris.view(np.uint8), V=V, F=F, C=C, n_own=n_own, n_halo=n_halo)
+    np.savez({out!r}, tris=tris.view(np.uint8), V=V, F=F, C=C, n_own=n_own, n_halo=n_halo, refused=refused, n_dropped=n_dropped, n_after=n_after)
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+# frame-sharded sub-maps (every rank fuses its own frames, owning everything) -> merge_submaps -> one tile-sharded map
+MERGE_WORKER = r"""
+import os, sys, json
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import numpy as np
+import parity_utils as pu
+from mrhash_amd import capi, parallel, synth
+dist = parallel.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+lib = capi.load_hip() if {use_hip} else pu.oracle_lib()
+e = pu.make_engine(lib, synth.CFG1, dict(synth.CFG1_PARAMS), 16384)
+frames = merge_frames()
+for f in frames[rank::world]:
+    pu.feed(e, f)
+e.sync()
+info = parallel.merge_submaps(e, dist, chunk_log2=1)
+d, v = e.dump_blocks()
+owners = parallel.owner_of_blocks(np.stack([d["x"], d["y"], d["z"]], 1), world, 1) if len(d) else np.zeros(0)
+assert np.all(owners == rank), "a rank holds a block it does not own after the merge"
+n_halo = parallel.exchange_halo(e, dist)
+res = parallel.gather_mesh(e, dist)
+parallel.drop_halo(e)
+np.savez({out!r} + f".{{rank}}.npz", d=d, v=v.view(np.uint8), sent=info["sent"], received=info["received"])
+if rank == 0:
+    tris, V, F, C = res
+    np.savez({out!r}, tris=tris.view(np.uint8), V=V, F=F, n_halo=n_halo)
 dist.barrier()
 dist.destroy_process_group()
 """
 
 
-def run_two_ranks(tmp_path, use_hip: bool):
+def merge_frames():
+    return [synth.cfg1_sphere(zc=1.5 + 0.01 * k) for k in range(4)]
+
+
+def run_two_ranks(tmp_path, use_hip: bool, worker: str = None):
     out = str(tmp_path / "rank0.npz")
     script = tmp_path / "worker.py"
-    script.write_text(WORKER.format(root=ROOT, use_hip=use_hip, out=out))
+    script.write_text((worker or WORKER).format(root=ROOT, use_hip=use_hip, out=out))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", OMP_NUM_THREADS="2")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", "29534", str(script)]
@@ -119,3 +160,99 @@ def test_two_rank_gloo_mesh_equals_single_process(oracle, tmp_path):
     assert int(got["n_halo"]) > 0 and int(got["n_own"]) > 0
     assert np.array_equal(got["tris"], t.view(np.uint8)), "merged triangle buffer differs from the single-process one"
     assert np.array_equal(got["F"], F) and np.array_equal(got["V"], V) and np.allclose(got["C"], C)
+    assert bool(got["refused"]) and int(got["n_dropped"]) == int(got["n_halo"]) and int(got["n_after"]) == int(got["n_own"])
+
+
+def check_merged_against_single(lib, tmp_path, got):
+    """The merged tile-sharded map against ONE context that fused all frames.  Occupancy is the same (allocation depends on
+    the depth frames only).  A voxel carries the same weight and — up to the order of the running mean, 1e-5 — the same
+    TSDF value wherever every sub-map held the voxel's block while it fused; a sub-map that allocated the block late (or
+    never) did not record its free-space observations of it, so there the merged weight is LOWER than the single-context
+    one (never higher).  Colours are order-dependent by construction (50/50 blend) and not compared.
+    The fold itself is exact: it equals the host restatement of combineVoxel over the two sub-maps, bit for bit."""
+    frames = merge_frames()
+    single = pu.make_engine(lib, synth.CFG1, dict(synth.CFG1_PARAMS), 16384)
+    for f in frames:
+        pu.feed(single, f)
+    d0, v0 = single.dump_blocks()
+    parts = [np.load(str(tmp_path / "rank0.npz") + f".{r}.npz") for r in range(2)]
+    d = np.concatenate([p["d"] for p in parts])
+    v = np.concatenate([p["v"].view(capi.VOXEL_DTYPE).reshape(-1, 512) for p in parts])
+    order = np.lexsort((d["z"], d["y"], d["x"]))
+    d, v = d[order], v[order]
+    assert np.array_equal(d, d0), "occupancy of the merged map differs from the single-context map"
+    assert np.all(v["weight"] <= v0["weight"])
+    same = (v["weight"] == v0["weight"]) & (v0["weight"] > 0)
+    assert same.sum() > 0.8 * (v0["weight"] > 0).sum()
+    assert float(np.max(np.abs(v["sdf"][same] - v0["sdf"][same]))) <= 1e-5
+    assert all(int(p["sent"]) > 0 and int(p["received"]) > 0 for p in parts)
+    # the fold, restated on the host from the two sub-maps (rank order 0, 1)
+    subs = []
+    for r in range(2):
+        e = pu.make_engine(lib, synth.CFG1, dict(synth.CFG1_PARAMS), 16384)
+        for f in frames[r::2]:
+            pu.feed(e, f)
+        subs.append(e.dump_blocks())
+    acc = {}
+    for ds, vs in subs:
+        for k in range(len(ds)):
+            key = (int(ds["x"][k]), int(ds["y"][k]), int(ds["z"][k]))
+            if key not in acc:
+                acc[key] = vs[k].copy()
+                continue
+            a, b = acc[key], vs[k]
+            w0, w1 = a["weight"].astype(np.int32), b["weight"].astype(np.int32)
+            both, only_b = (w0 > 0) & (w1 > 0), (w0 == 0) & (w1 > 0)
+            out = a.copy()
+            out[only_b] = b[only_b]
+            s = (a["sdf"] * w0.astype(np.float32) + b["sdf"] * w1.astype(np.float32)) / (w0 + w1).astype(np.float32)
+            out["sdf"][both] = s[both]
+            out["sum_squared"][both] = b["sum_squared"][both]
+            out["weight"][both] = np.minimum(255, w0 + w1)[both].astype(np.uint8)
+            rgb = ((a["rgb"].astype(np.uint16) + b["rgb"].astype(np.uint16) + 1) >> 1).astype(np.uint8)
+            out["rgb"][both] = rgb[both]
+            acc[key] = out
+    keys = sorted(acc)
+    want = np.stack([acc[k] for k in keys])
+    assert [tuple(int(d[a][i]) for a in "xyz") for i in range(len(d))] == keys
+    assert np.array_equal(v.view(np.uint8), want.view(np.uint8)), "merge differs from the host restatement of combineVoxel"
+    # mesh of the merged map: rank 0 gathered it; compare with the mesh of a context that imports the merged map
+    ref = pu.make_engine(lib, synth.CFG1, dict(synth.CFG1_PARAMS), 16384)
+    ref.import_blocks(d, v)
+    t = ref.extract_triangles()
+    V, F, C = ref.extract_mesh()
+    assert np.array_equal(got["tris"], t.view(np.uint8)) and np.array_equal(got["F"], F) and np.array_equal(got["V"], V)
+    assert int(got["n_halo"]) > 0
+
+
+def test_frame_sharded_submaps_merge_into_one_tile_sharded_map(oracle, tmp_path):
+    got = run_two_ranks(tmp_path, use_hip=False, worker=MERGE_WORKER.replace("merge_frames()", "[synth.cfg1_sphere(zc=1.5 + 0.01 * k) for k in range(4)]"))
+    check_merged_against_single(oracle, tmp_path, got)
+
+
+def test_pack_unpack_drop_single_process(oracle):
+    """The exchange primitives without a process group: pack by owner, empty the map, fold the records back."""
+    import ctypes
+
+    e = pu.make_engine(oracle, synth.CFG1, dict(synth.CFG1_PARAMS), 16384)
+    pu.feed(e, synth.cfg1_sphere())
+    d0, v0 = e.dump_blocks()
+    e.set_sharding(0, 2, 1)
+    recs = []
+    for dest in range(2):
+        ptr, n, on_dev = e.pack_blocks(capi.PACK_OWNER, dest)
+        assert not on_dev
+        recs.append(np.frombuffer((ctypes.c_char * (n * capi.RECORD_BYTES)).from_address(ptr), dtype=capi.RECORD_DTYPE).copy() if n else np.zeros(0, capi.RECORD_DTYPE))
+    assert len(recs[0]) + len(recs[1]) == len(d0) and min(len(r) for r in recs) > 0
+    ptr, n, _ = e.pack_blocks(capi.PACK_HALO)
+    halo = np.frombuffer((ctypes.c_char * (n * capi.RECORD_BYTES)).from_address(ptr), dtype=capi.RECORD_DTYPE).copy()
+    own0 = recs[0]["desc"]
+    assert np.array_equal(np.sort(halo["desc"], order=["x", "y", "z"]), np.sort(own0[parallel.boundary_mask(own0, 1)], order=["x", "y", "z"]))
+    assert e.drop_blocks(capi.DROP_FOREIGN) == len(recs[1])
+    assert e.drop_blocks(capi.DROP_ALL) == len(recs[0])
+    assert len(e.dump_blocks()[0]) == 0
+    e.set_sharding(0, 1, 0)
+    for r in recs:
+        assert e.unpack_blocks(capi.UNPACK_MERGE, r.ctypes.data, len(r), False) == len(r)
+    d1, v1 = e.dump_blocks()
+    assert np.array_equal(d0, d1) and np.array_equal(v0.view(np.uint8), v1.view(np.uint8))

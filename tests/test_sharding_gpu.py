@@ -5,7 +5,7 @@ import pytest
 
 import parity_utils as pu
 from mrhash_amd import parallel, synth
-from test_sharding import reference_single, run_two_ranks
+from test_sharding import MERGE_WORKER, check_merged_against_single, reference_single, run_two_ranks
 
 pytestmark = pytest.mark.gpu
 
@@ -48,6 +48,68 @@ def test_two_rank_mesh_equals_single_context_hip(hip, tmp_path):
     assert int(got["n_halo"]) > 0
     assert np.array_equal(got["tris"], t.view(np.uint8))
     assert np.array_equal(got["F"], F) and np.array_equal(got["V"], V)
+    assert bool(got["refused"]) and int(got["n_dropped"]) == int(got["n_halo"]) and int(got["n_after"]) == int(got["n_own"])
+
+
+def test_frame_sharded_submaps_merge_into_one_tile_sharded_map_hip(hip, tmp_path):
+    """Two HIP ranks fuse disjoint halves of the stream, merge_submaps folds them into one tile-sharded map (device
+    pack -> collective -> device unpack), halo exchange + mesh gather follow."""
+    got = run_two_ranks(tmp_path, use_hip=True, worker=MERGE_WORKER.replace("merge_frames()", "[synth.cfg1_sphere(zc=1.5 + 0.01 * k) for k in range(4)]"))
+    check_merged_against_single(hip, tmp_path, got)
+
+
+def test_exchange_primitives_match_the_oracle(hip, oracle):
+    """mrh_pack_blocks / mrh_unpack_blocks / mrh_drop_blocks on the device against the oracle's host versions: the same
+    record sets (order aside), the same merged map."""
+    import torch
+
+    a = pu.make_engine(hip, synth.CFG1, dict(synth.CFG1_PARAMS), 16384)
+    b = pu.make_engine(oracle, synth.CFG1, dict(synth.CFG1_PARAMS), 16384)
+    for e in (a, b):
+        pu.feed(e, synth.cfg1_sphere())
+        pu.feed(e, synth.cfg1_sphere(zc=1.52))
+        e.set_sharding(1, 3, 1)
+
+    def records(e, mode, arg=0):
+        import ctypes
+        from mrhash_amd import capi
+
+        ptr, n, on_dev = e.pack_blocks(mode, arg)
+        if n == 0:
+            return np.zeros(0, capi.RECORD_DTYPE)
+        if on_dev:
+            raw = parallel._bytes_view(ptr, n * capi.RECORD_BYTES, True).cpu().numpy()
+        else:
+            raw = np.frombuffer((ctypes.c_char * (n * capi.RECORD_BYTES)).from_address(ptr), dtype=np.uint8).copy()
+        r = raw.view(capi.RECORD_DTYPE)
+        return r[np.lexsort((r["desc"]["z"], r["desc"]["y"], r["desc"]["x"]))]
+
+    from mrhash_amd import capi
+
+    for mode, arg in ((capi.PACK_HALO, 0), (capi.PACK_OWNER, 0), (capi.PACK_OWNER, 1), (capi.PACK_OWNER, 2)):
+        ra, rb = records(a, mode, arg), records(b, mode, arg)
+        assert len(ra) == len(rb) > 0 and ra.tobytes() == rb.tobytes(), (mode, arg)
+    # merge a second sub-map into both, from device memory on the HIP side
+    c = pu.make_engine(oracle, synth.CFG1, dict(synth.CFG1_PARAMS), 16384)
+    pu.feed(c, synth.cfg1_sphere(zc=1.51))
+    c.set_sharding(0, 1, 0)
+    rc_ = records(c, capi.PACK_OWNER, 0)
+    dev = torch.from_numpy(rc_.view(np.uint8).copy()).cuda()
+    assert a.unpack_blocks(capi.UNPACK_MERGE, dev.data_ptr(), len(rc_), True) == len(rc_)
+    assert b.unpack_blocks(capi.UNPACK_MERGE, rc_.ctypes.data, len(rc_), False) == len(rc_)
+    pu.compare_maps(a, b)
+    # halo import keeps exactly the adjacent foreign blocks; drop removes them again
+    for e in (a, b):
+        e.drop_blocks(capi.DROP_FOREIGN)
+    na, nb_ = len(a.dump_blocks()[0]), len(b.dump_blocks()[0])
+    assert na == nb_ > 0
+    ta = a.unpack_blocks(capi.UNPACK_HALO, dev.data_ptr(), len(rc_), True)
+    tb = b.unpack_blocks(capi.UNPACK_HALO, rc_.ctypes.data, len(rc_), False)
+    assert ta == tb > 0
+    pu.compare_maps(a, b)
+    assert a.drop_blocks(capi.DROP_HALO) == b.drop_blocks(capi.DROP_HALO) == ta
+    pu.compare_maps(a, b)
+    assert len(a.dump_blocks()[0]) == na
 
 
 def test_lidar_and_splat_seeds_on_tile_shards_hip(hip):
