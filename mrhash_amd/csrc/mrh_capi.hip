@@ -1528,13 +1528,19 @@ int mrh_extract_triangles(mrh_ctx* c, const mrh_triangle** out_tris, uint64_t* o
     HIP_TRY(c, d_counts.alloc((size_t) n));
     HIP_TRY(c, d_offsets.alloc((size_t) n));
     HIP_TRY(c, d_per_voxel.alloc((size_t) n * 512));
-    const int grid = n < 4096 ? n : 4096;
+    const int grid = n < 8192 ? n : 8192;
     // largest truncation a stored sample can carry (integration clamps to trunc + scale * depth, depth <= the integration distance)
     const float sdf_bound = c->has_camera && !getenv("MRH_MC_NO_PRESCREEN") ? c->map.trunc + c->map.trunc_scale * c->cam.max_int_dist : 0.f;
-    k_mc<false><<<grid, 512, 0, s>>>(c->map, c->tab, c->tab.compact, n, d_counts, nullptr, nullptr, 0, d_per_voxel, sdf_bound);
+    for (hipEvent_t& ev : c->mc_ev)
+      if (!ev) HIP_TRY(c, hipEventCreate(&ev));
+    c->last_mc_count_ms = c->last_mc_emit_ms = 0.f;
+    c->last_mc_blocks = (uint64_t) n;
+    hipExtLaunchKernelGGL((k_mc<false>), dim3(grid), dim3(kMcThreads), 0, s, c->mc_ev[0], c->mc_ev[1], 0u, c->map, c->tab, (const int4*) c->tab.compact, n,
+                          (u32*) d_counts, (const u64*) nullptr, (mrh_triangle*) nullptr, (u64) 0, (uint8_t*) d_per_voxel, sdf_bound);
     std::vector<u32> counts((size_t) n);
     HIP_TRY(c, hipMemcpyAsync(counts.data(), d_counts, (size_t) n * sizeof(u32), hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
+    HIP_TRY(c, hipEventElapsedTime(&c->last_mc_count_ms, c->mc_ev[0], c->mc_ev[1]));
     t2 = now();
     std::vector<u64> offsets((size_t) n);
     u64 total = 0;
@@ -1549,7 +1555,10 @@ int mrh_extract_triangles(mrh_ctx* c, const mrh_triangle** out_tris, uint64_t* o
       DevBuf<mrh_triangle> d_tris;
       HIP_TRY(c, d_tris.alloc(total));
       HIP_TRY(c, hipMemcpyAsync(d_offsets, offsets.data(), (size_t) n * sizeof(u64), hipMemcpyHostToDevice, s));
-      k_mc<true><<<grid, 512, 0, s>>>(c->map, c->tab, c->tab.compact, n, d_counts, d_offsets, d_tris, total, d_per_voxel, 0.f);
+      hipExtLaunchKernelGGL((k_mc<true>), dim3(grid), dim3(kMcThreads), 0, s, c->mc_ev[2], c->mc_ev[3], 0u, c->map, c->tab, (const int4*) c->tab.compact, n,
+                            (u32*) d_counts, (const u64*) d_offsets, (mrh_triangle*) d_tris, (u64) total, (uint8_t*) d_per_voxel, 0.f);
+      HIP_TRY(c, hipEventSynchronize(c->mc_ev[3]));
+      HIP_TRY(c, hipEventElapsedTime(&c->last_mc_emit_ms, c->mc_ev[2], c->mc_ev[3]));
       if (dbg) { HIP_TRY(c, hipStreamSynchronize(s)); t3 = now(); }
       if (want_soup) {
         c->tris.resize_discard(total);

@@ -27,11 +27,30 @@ struct VoxSample {
 // subtraction and one LDS read instead of the float voxel->block detour, a 64-bit hash and a dependent probe of the
 // global table per sample (72 samples per voxel that reaches all eight corners).
 constexpr u32 kNbAbsent = 0xFFFFFFFFu;
+// The voxels marching cubes can sample for a block, staged ONCE per workgroup in LDS: the block's 8^3 fine cells and a
+// rim of kHaloRim cells around it, {sdf, rgbw} per FINE cell (a coarse neighbour's voxel fills the 2^3 fine cells it
+// covers, which is exactly what the reference's read through `local index >> resolution` returns for each of them).
+// Reach: a corner sits <= 1/2 voxel from the sample position; the trilinear stencil adds one voxel of the sampled block's
+// size; on a resolution jump the coarser re-sample (vds.cu:296-309) reaches pos - h + {0, 2h}: at most 3 fine cells
+// from the voxel when the sampled block is coarse, 1 cell on a single-resolution neighbourhood.
+constexpr int kHaloRim = 3;
+constexpr int kHaloSide = 8 + 2 * kHaloRim;                      // 14
+constexpr int kHaloCells = kHaloSide * kHaloSide * kHaloSide;    // 2744
 struct Neigh {
   const u32* vals;  // LDS [27], index (dz + 1) * 9 + (dy + 1) * 3 + (dx + 1); nullptr: no table (lookups outside k_mc)
   i3 base;          // block position of the workgroup's block
   int shift_limit;  // Map::block_shift_limit
+  // LDS halo (nullptr: none); valid for cells within `halo_rim` of the block, under the workgroup's guarantee that
+  // voxel -> block is the arithmetic shift for every voxel it can reach
+  const float* halo_sdf;
+  const u32* halo_rgbw;
+  int halo_rim;
 };
+__device__ __forceinline__ Neigh neigh_none() {
+  Neigh nb;
+  nb.vals = nullptr; nb.base = mki3(0, 0, 0); nb.shift_limit = 0; nb.halo_sdf = nullptr; nb.halo_rgbw = nullptr; nb.halo_rim = 0;
+  return nb;
+}
 
 // table value of a block (kNbAbsent: not allocated): the workgroup's 27-block neighbourhood answers from LDS, anything
 // else through the hash table
@@ -50,6 +69,20 @@ __device__ __forceinline__ u32 block_val(const Tab& t, const Neigh& nb, const i3
 __device__ __forceinline__ VoxSample get_voxel_i(const Map& m, const Tab& t, const Neigh& nb, i3 v) {
   VoxSample r;
   r.sdf = 0.f; r.rgbw = 0; r.res = 0; r.found = false;
+  if (nb.halo_sdf) {
+    const int lx = v.x - nb.base.x * kBlockSide, ly = v.y - nb.base.y * kBlockSide, lz = v.z - nb.base.z * kBlockSide;
+    const int rim = nb.halo_rim;
+    if ((u32) (lx + rim) < (u32) (kBlockSide + 2 * rim) && (u32) (ly + rim) < (u32) (kBlockSide + 2 * rim) && (u32) (lz + rim) < (u32) (kBlockSide + 2 * rim)) {
+      const u32 val = nb.vals[((lz >> 3) + 1) * 9 + ((ly >> 3) + 1) * 3 + ((lx >> 3) + 1)];
+      if (val == kNbAbsent) return r;
+      const int idx = ((lz + kHaloRim) * kHaloSide + (ly + kHaloRim)) * kHaloSide + (lx + kHaloRim);
+      r.res = (val & kValCoarseBit) ? 1 : 0;
+      r.found = true;
+      r.sdf = nb.halo_sdf[idx];
+      r.rgbw = nb.halo_rgbw[idx];
+      return r;
+    }
+  }
   const int ax = v.x < 0 ? -v.x : v.x, ay = v.y < 0 ? -v.y : v.y, az = v.z < 0 ? -v.z : v.z;
   // voxel -> block is the shift below the limit (mrh_device.h)
   const i3 b = (u32) (ax | ay | az) < (u32) nb.shift_limit ? mki3(v.x >> 3, v.y >> 3, v.z >> 3) : voxel_to_block(v, m.vs);
@@ -148,9 +181,9 @@ __device__ __forceinline__ mrh_vertex vertex_interp(f3 p1, f3 p2, float d1, floa
   return v;
 }
 
-// marching_cubes.cu:72-261 for one voxel.  Returns the triangle count; with EMIT writes them to out[0..n).
+// marching_cubes.cu:72-261 for one voxel.  Returns the triangle count; with EMIT writes triangles j < max_out to out[j].
 template <bool EMIT>
-__device__ __forceinline__ int mc_voxel(const Map& m, const Tab& t, const Neigh& nb, f3 pf, mrh_triangle* out) {
+__device__ __forceinline__ int mc_voxel(const Map& m, const Tab& t, const Neigh& nb, f3 pf, mrh_triangle* out, const int max_out = 5) {
   const float vvs = get_voxel_size_f(m, t, nb, pf);
   const float P = vvs * 0.5f;
   const float M = -P;
@@ -207,7 +240,7 @@ __device__ __forceinline__ int mc_voxel(const Map& m, const Tab& t, const Neigh&
   const uint8_t* row = d_mc_tri[cube];
   const int ntri = row[0];
   if (EMIT) {
-    for (int j = 0; j < ntri; j++)
+    for (int j = 0; j < ntri && j < max_out; j++)
       for (int k = 0; k < 3; k++) {
         const int code = row[1 + 3 * j + k];
         const int a = code >> 4, b = code & 0xF;
@@ -226,109 +259,181 @@ __global__ __launch_bounds__(256) void k_list_keys(const int4* __restrict__ list
   keys[i] = key;
 }
 
-// Workgroup per block of the sorted list, lane = voxel.  EMIT = false: counts[e] = triangles of block e and
-// per_voxel[e * 512 + v] = triangles of voxel v.  EMIT = true: triangles written at offsets[e] + (exclusive prefix over
-// voxel index); voxels the count pass found empty (the vast majority) are not evaluated a second time.
+// One workgroup (256 threads) per block of the sorted list.
+//   1. the 27 surrounding blocks are resolved once (table value or absent)                              -> s_nb
+//   2. every voxel marching cubes can sample for this block is staged in LDS ({sdf, rgbw} per fine cell) -> halo
+//   3. COUNT pass: sign class of every staged cell (1: weighted and clearly positive, 2: weighted and clearly negative,
+//      0: anything else) and a separable AND over the (2w + 1)^3 window of each voxel (w = 1 on a single-resolution
+//      neighbourhood, 3 otherwise): everything marching cubes evaluates for a voxel — the eight trilinear corner values,
+//      the coarser re-samples they blend in on a resolution jump, or the raw sample a corner falls back to — is a convex
+//      combination of, or a sample from, cells of that window (fp32 evaluation error < 2e-5 x the largest magnitude), so
+//      if all of them share one class every corner has that sign, the cube index is 0 or 255 and the voxel has no
+//      triangle: it is not evaluated at all.  "Clearly" = 1e-3 x sdf_bound <= |sdf| <= 1.001 x sdf_bound, sdf_bound =
+//      the largest truncation a sample can carry; anything outside (or NaN) is class 0.
+//      EMIT pass: the candidates are the voxels the count pass found non-empty (per_voxel).
+//   4. the candidates are COMPACTED (LDS list) and evaluated densely, one lane each, through the staged cells: a lookup
+//      is the reference's float position -> voxel conversion, a subtraction and two LDS reads — no hash, no global gather
+//   5. block-wide exclusive scan of the per-voxel triangle counts in voxel order: counts[e] (COUNT) / the exact offset
+//      of every voxel's triangles (EMIT) -> canonical (block, voxel, triangle) order, no atomics.
+// Blocks too far from the origin for voxel -> block to be the arithmetic shift skip 2-3 and evaluate every voxel through
+// the neighbour table / the hash (the literal path).
+constexpr int kMcThreads = 256;
 template <bool EMIT>
-__global__ __launch_bounds__(512) void k_mc(const Map m, const Tab t, const int4* __restrict__ sorted, const int n,
-                                            u32* __restrict__ counts, const u64* __restrict__ offsets,
-                                            mrh_triangle* __restrict__ out, const u64 max_tris, uint8_t* __restrict__ per_voxel,
-                                            const float sdf_bound) {
-  __shared__ u32 s_wave[8];
+__global__ __launch_bounds__(kMcThreads) void k_mc(const Map m, const Tab t, const int4* __restrict__ sorted, const int n,
+                                                   u32* __restrict__ counts, const u64* __restrict__ offsets,
+                                                   mrh_triangle* __restrict__ out, const u64 max_tris, uint8_t* __restrict__ per_voxel,
+                                                   const float sdf_bound) {
   __shared__ u32 s_nb[27];
-  // Count pass, fine blocks with no coarse neighbour: sign class of the 10^3 cells around the block (1: weighted and clearly positive,
-  // 2: weighted and clearly negative, 0: anything else).  Everything marching cubes evaluates for a voxel — the eight
-  // trilinear corner values, or the raw sample a corner falls back to — is built from the 3^3 cells around it, the
-  // trilinear value is a convex combination of them (fp32 evaluation error < 2e-5 x the largest magnitude), so if all 27
-  // are of one class every corner has that sign, the cube index is 0 or 255 and the voxel has no triangle: it is not
-  // evaluated at all.  "Clearly" = 1e-3 x sdf_bound <= |sdf| <= 1.001 x sdf_bound, sdf_bound = the largest truncation a
-  // sample can carry; anything outside (or NaN) is class 0 and takes the full path.
-  __shared__ uint8_t s_cls[1000];
-  const int v = threadIdx.x;
-  const int wave = v >> 6;
+  __shared__ float s_sdf[kHaloCells];
+  __shared__ u32 s_rgbw[kHaloCells];
+  __shared__ uint8_t s_cls[2][kHaloCells];
+  __shared__ unsigned short s_cand[512];
+  __shared__ uint8_t s_ntri[512];
+  __shared__ u32 s_wave[kMcThreads / 64];
+  __shared__ u32 s_ncand;
+  const int tid = threadIdx.x;
   for (int e = blockIdx.x; e < n; e += gridDim.x) {
     const int4 ent = sorted[e];
     const u32 val = (u32) ent.w;
     const bool coarse = (val & kValCoarseBit) != 0;
-    Neigh nb;
-    nb.vals = nullptr;
+    const int nvox = coarse ? kCoarseVoxels : kBlockVoxels;
+    Neigh nb = neigh_none();
     nb.base = mki3(ent.x, ent.y, ent.z);
     nb.shift_limit = m.block_shift_limit;
-    {  // resolve the 27 surrounding blocks once
-      if (v < 27) {
-        const i3 b = mki3(ent.x + (v % 3) - 1, ent.y + ((v / 3) % 3) - 1, ent.z + (v / 9) - 1);
-        u64 key;
-        int slot = -1;
-        if (pack_key(b, key)) slot = hash_find(t, key);
-        s_nb[v] = slot >= 0 ? t.vals[slot] : kNbAbsent;
-      }
-      __syncthreads();
-      nb.vals = s_nb;
+    if (tid < 27) {  // resolve the 27 surrounding blocks once
+      const i3 b = mki3(ent.x + (tid % 3) - 1, ent.y + ((tid / 3) % 3) - 1, ent.z + (tid / 9) - 1);
+      u64 key;
+      int slot = -1;
+      if (pack_key(b, key)) slot = hash_find(t, key);
+      s_nb[tid] = slot >= 0 ? t.vals[slot] : kNbAbsent;
     }
+    if (tid == 0) s_ncand = 0;
+    for (int i = tid; i < 512; i += kMcThreads) s_ntri[i] = 0;
+    __syncthreads();
+    nb.vals = s_nb;
+    // sharded maps: halo blocks imported from other ranks are read by the lookups but emit nothing themselves
+    const bool mine = owns_block(m, mki3(ent.x, ent.y, ent.z));  // uniform
     const int amax = max(max(abs(ent.x), abs(ent.y)), abs(ent.z));
-    bool prescreen = !EMIT && !coarse && sdf_bound > 0.f && (amax + 2) * kBlockSide < m.block_shift_limit;  // uniform
-    if (prescreen && t.multi_res) {  // a fine block whose whole neighbourhood is fine (or absent) is evaluated exactly as on a single-resolution map
-      u32 any_coarse = 0;
+    const bool staged = mine && (amax + 3) * kBlockSide < m.block_shift_limit;  // uniform: every reachable voxel converts by shift
+    u32 any_coarse = coarse ? kValCoarseBit : 0u;
+    if (t.multi_res)
       for (int i = 0; i < 27; i++) any_coarse |= (s_nb[i] != kNbAbsent) ? (s_nb[i] & kValCoarseBit) : 0u;
-      prescreen = any_coarse == 0u;
-    }
-    if (prescreen) {
-      const float lo = 1e-3f * sdf_bound, hi = 1.001f * sdf_bound;
-      for (int cidx = v; cidx < 1000; cidx += 512) {
-        const int lx = cidx % 10 - 1, ly = (cidx / 10) % 10 - 1, lz = cidx / 100 - 1;  // voxel coordinates relative to the block, -1 .. 8
-        const int bx = lx < 0 ? 0 : (lx > 7 ? 2 : 1), by = ly < 0 ? 0 : (ly > 7 ? 2 : 1), bz = lz < 0 ? 0 : (lz > 7 ? 2 : 1);
-        const u32 nval = s_nb[bz * 9 + by * 3 + bx];
-        uint8_t cls = 0;
+    const int rim = any_coarse ? kHaloRim : 1;  // uniform
+    if (staged) {
+      const int side = kBlockSide + 2 * rim;
+      for (int c = tid; c < side * side * side; c += kMcThreads) {
+        const int lx = c % side - rim, ly = (c / side) % side - rim, lz = c / (side * side) - rim;  // fine cell relative to the block
+        const u32 nval = s_nb[((lz >> 3) + 1) * 9 + ((ly >> 3) + 1) * 3 + ((lx >> 3) + 1)];
+        float sv = 0.f;
+        u32 rw = 0;
         if (nval != kNbAbsent) {
           const VoxPtr vp = vox_ptr(t, nval);
-          const u32 li = (u32) ((lz & 7) * 64 + (ly & 7) * 8 + (lx & 7));
-          const float sv = vp.sdf[li];
-          if ((vp.rgbw[li] >> 24) != 0) cls = (sv >= lo && sv <= hi) ? 1 : ((sv <= -lo && sv >= -hi) ? 2 : 0);
+          const int fx = lx & 7, fy = ly & 7, fz = lz & 7;
+          const u32 li = (nval & kValCoarseBit) ? (u32) ((fz >> 1) * 16 + (fy >> 1) * 4 + (fx >> 1)) : (u32) (fz * 64 + fy * 8 + fx);
+          sv = vp.sdf[li];
+          rw = vp.rgbw[li];
         }
-        s_cls[cidx] = cls;
+        const int idx = ((lz + kHaloRim) * kHaloSide + (ly + kHaloRim)) * kHaloSide + (lx + kHaloRim);
+        s_sdf[idx] = sv;
+        s_rgbw[idx] = rw;
+        if (!EMIT) {
+          const float lo = 1e-3f * sdf_bound, hi = 1.001f * sdf_bound;
+          uint8_t cls = 0;
+          if ((rw >> 24) != 0) cls = (sv >= lo && sv <= hi) ? 1 : ((sv <= -lo && sv >= -hi) ? 2 : 0);
+          s_cls[0][idx] = cls;
+        }
+      }
+      __syncthreads();
+      nb.halo_sdf = s_sdf;
+      nb.halo_rgbw = s_rgbw;
+      nb.halo_rim = rim;
+    }
+    // ---- candidates
+    if (!mine) {
+      // nothing to evaluate
+    } else if (EMIT) {
+      for (int v = tid; v < nvox; v += kMcThreads)
+        if (per_voxel[(size_t) e * 512 + v] != 0) s_cand[atomicAdd(&s_ncand, 1u)] = (unsigned short) v;
+    } else if (staged && sdf_bound > 0.f) {
+      // separable AND of the sign classes over the window [-w, w]^3 (w = rim): x, then y, then z
+      const int w = rim;
+      for (int c = tid; c < kBlockSide * kHaloSide * kHaloSide; c += kMcThreads) {  // x in 0..7, all staged y, z
+        const int x = c & 7, yz = c >> 3;
+        const int base = yz * kHaloSide + (x + kHaloRim);
+        u32 acc = 3u;
+        for (int d = -w; d <= w; d++) acc &= s_cls[0][base + d];
+        s_cls[1][base] = (uint8_t) acc;
+      }
+      __syncthreads();
+      for (int c = tid; c < kBlockSide * kBlockSide * kHaloSide; c += kMcThreads) {  // x, y in 0..7, all staged z
+        const int x = c & 7, y = (c >> 3) & 7, z = c >> 6;
+        const int base = (z * kHaloSide + (y + kHaloRim)) * kHaloSide + (x + kHaloRim);
+        u32 acc = 3u;
+        for (int d = -w; d <= w; d++) acc &= s_cls[1][base + d * kHaloSide];
+        s_cls[0][base] = (uint8_t) acc;
+      }
+      __syncthreads();
+      for (int v = tid; v < nvox; v += kMcThreads) {
+        int x, y, z;
+        if (!coarse) { x = v & 7; y = (v >> 3) & 7; z = v >> 6; }
+        else { x = 2 * (v & 3); y = 2 * ((v >> 2) & 3); z = 2 * (v >> 4); }
+        const int base = ((z + kHaloRim) * kHaloSide + (y + kHaloRim)) * kHaloSide + (x + kHaloRim);
+        u32 acc = 3u;
+        for (int d = -w; d <= w; d++) acc &= s_cls[0][base + d * kHaloSide * kHaloSide];
+        if (acc == 0u) s_cand[atomicAdd(&s_ncand, 1u)] = (unsigned short) v;  // not all positive and not all negative
+      }
+    } else {
+      for (int v = tid; v < nvox; v += kMcThreads) s_cand[atomicAdd(&s_ncand, 1u)] = (unsigned short) v;
+    }
+    __syncthreads();
+    const int ncand = (int) s_ncand;
+    if (!EMIT) {
+      // ---- dense evaluation of the candidates; per-voxel counts to LDS
+      for (int i = tid; i < ncand; i += kMcThreads) {
+        const int v = s_cand[i];
+        i3 pi;
+        if (!coarse) pi = mki3(ent.x * kBlockSide + (v & 7), ent.y * kBlockSide + ((v >> 3) & 7), ent.z * kBlockSide + (v >> 6));
+        else pi = mki3(ent.x * kBlockSide + 2 * (v & 3), ent.y * kBlockSide + 2 * ((v >> 2) & 3), ent.z * kBlockSide + 2 * (v >> 4));
+        s_ntri[v] = (uint8_t) mc_voxel<false>(m, t, nb, voxel_to_world(m.vs, pi), nullptr);
       }
       __syncthreads();
     }
-    int ntri = 0;
-    mrh_triangle tris[5];
-    const bool skip = EMIT && per_voxel[(size_t) e * 512 + v] == 0;
-    // sharded maps: halo blocks imported from other ranks are read by the lookups but emit nothing themselves
-    if (!skip && (!coarse || v < kCoarseVoxels) && owns_block(m, mki3(ent.x, ent.y, ent.z))) {
-      i3 pi;
-      if (!coarse) pi = mki3(ent.x * kBlockSide + (v & 7), ent.y * kBlockSide + ((v >> 3) & 7), ent.z * kBlockSide + (v >> 6));
-      else pi = mki3(ent.x * kBlockSide + 2 * (v & 3), ent.y * kBlockSide + 2 * ((v >> 2) & 3), ent.z * kBlockSide + 2 * (v >> 4));
-      bool empty = false;
-      if (prescreen) {
-        u32 acc = 3u;
-        const int x = v & 7, y = (v >> 3) & 7, z = v >> 6;
-#pragma unroll
-        for (int dz = 0; dz < 3; dz++)
-#pragma unroll
-          for (int dy = 0; dy < 3; dy++)
-#pragma unroll
-            for (int dx = 0; dx < 3; dx++) acc &= s_cls[(z + dz) * 100 + (y + dy) * 10 + (x + dx)];
-        empty = acc != 0u;  // all 27 cells positive, or all 27 negative
-      }
-      if (!empty) ntri = mc_voxel<EMIT>(m, t, nb, voxel_to_world(m.vs, pi), tris);
+    // ---- block-wide exclusive scan of the per-voxel counts, 2 voxels per thread, in voxel order
+    const int v0 = 2 * tid;
+    u32 c0, c1;
+    if (EMIT) { c0 = per_voxel[(size_t) e * 512 + v0]; c1 = per_voxel[(size_t) e * 512 + v0 + 1]; }
+    else {
+      c0 = s_ntri[v0]; c1 = s_ntri[v0 + 1];
+      *(unsigned short*) (per_voxel + (size_t) e * 512 + v0) = (unsigned short) (c0 | (c1 << 8));
     }
-    if (!EMIT) per_voxel[(size_t) e * 512 + v] = (uint8_t) ntri;
-    // block-wide exclusive scan of ntri in voxel-index order: wave scan + 8 wave totals through LDS
-    u32 incl = (u32) ntri;
+    u32 incl = c0 + c1;
     for (int off = 1; off < 64; off <<= 1) {
       const u32 o = __shfl_up(incl, off);
       if ((int) lane_id() >= off) incl += o;
     }
-    if (lane_id() == 63) s_wave[wave] = incl;
+    if (lane_id() == 63) s_wave[tid >> 6] = incl;
     __syncthreads();
     u32 wave_off = 0, total = 0;
-    for (int i = 0; i < 8; i++) { if (i < wave) wave_off += s_wave[i]; total += s_wave[i]; }
+    for (int i = 0; i < kMcThreads / 64; i++) { if (i < (tid >> 6)) wave_off += s_wave[i]; total += s_wave[i]; }
     if (!EMIT) {
-      if (v == 0) counts[e] = total;
+      if (tid == 0) counts[e] = total;
     } else {
-      const u64 base = offsets[e] + wave_off + (incl - (u32) ntri);
-      for (int j = 0; j < ntri; j++)
-        if (base + j < max_tris) out[base + j] = tris[j];
-        else atomicOr((u32*) &t.ctr[CTR_ERROR], ERR_TRI);
+      // exclusive offsets of this thread's two voxels, parked in LDS for the lanes that evaluate them
+      u32* s_off = (u32*) s_cls;  // 512 x u32 = 2 KiB of the class arrays (unused by the emit pass)
+      const u32 ex0 = wave_off + incl - (c0 + c1);
+      s_off[v0] = ex0;
+      s_off[v0 + 1] = ex0 + c0;
+      __syncthreads();
+      for (int i = tid; i < ncand; i += kMcThreads) {
+        const int v = s_cand[i];
+        i3 pi;
+        if (!coarse) pi = mki3(ent.x * kBlockSide + (v & 7), ent.y * kBlockSide + ((v >> 3) & 7), ent.z * kBlockSide + (v >> 6));
+        else pi = mki3(ent.x * kBlockSide + 2 * (v & 3), ent.y * kBlockSide + 2 * ((v >> 2) & 3), ent.z * kBlockSide + 2 * (v >> 4));
+        const u64 base = offsets[e] + s_off[v];
+        const int room = base >= max_tris ? 0 : (int) (max_tris - base < 5 ? max_tris - base : 5);
+        const int ntri = mc_voxel<true>(m, t, nb, voxel_to_world(m.vs, pi), out + base, room);  // straight to the exact offset
+        if (ntri > room) atomicOr((u32*) &t.ctr[CTR_ERROR], ERR_TRI);
+      }
     }
     __syncthreads();
   }

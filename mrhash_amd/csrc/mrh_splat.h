@@ -314,7 +314,7 @@ __device__ __forceinline__ bool splat_seed_of(const Cam& c, const Map& m, const 
   const float d = depth[(size_t) py * c.cols + px];
   if (d < c.min_depth) return false;
   const f3 center = se3_apply(c.R, c.t, inverse_projection(c, (u32) py, (u32) px, d));
-  const Neigh none = {nullptr, mki3(0, 0, 0), 0};
+  const Neigh none = neigh_none();
   const VoxSample v = get_voxel_f(m, t, none, center);
   if ((v.rgbw >> 24) != 1u) return false;  // a miss reads as weight 0
   const float half_w = 0.5f * (float) n.w, half_h = 0.5f * (float) n.h;

@@ -26,6 +26,14 @@ def corridor_frames(loops):
     return one * loops
 
 
+def one_way_frames(n, step=0.25):
+    """A long trajectory that never comes back: n frames straight down an 800 m corridor.  Every block the streamer pages
+    out behind the camera leaves an erased slot that no later insert of the same key will ever reuse."""
+    scene = synth.Scene(synth.Box((-0.6, -0.6, -20.0), (0.6, 0.6, 820.0)), seed=3)
+    for i in range(n):
+        yield synth.render(scene, K, np.array([0.0, 0.0, step * i], np.float32), np.array([0, 0, 0, 1], np.float32), depth_scaling=5000.0)
+
+
 def engine(lib, **extra):
     e = capi.Engine(lib, capi.Params(num_sdf_blocks=POOL, **{**PARAMS, **extra}))
     e.set_camera(K.fx, K.fy, K.cx, K.cy, K.rows, K.cols, PARAMS["min_depth"], PARAMS["max_depth"])
@@ -37,8 +45,8 @@ class Pager:
     both engines: when fewer than 15 % of the pool are free, blocks farther than `far` from the camera leave; blocks
     within `near` of the camera come back before the frame."""
 
-    def __init__(self, e, near=3.0, far=4.5):
-        self.e, self.near, self.far, self.store, self.paged = e, near, far, {}, 0
+    def __init__(self, e, near=3.0, far=4.5, keep=True):
+        self.e, self.near, self.far, self.store, self.paged, self.keep = e, near, far, {}, 0, keep
 
     def before_frame(self, cam):
         if self.store:
@@ -51,35 +59,41 @@ class Pager:
         free, _ = self.e.free_blocks()
         if free <= 0.15 * POOL:
             d, v = self.e.stream_out(cam, self.far)
-            for i in range(len(d)):
+            for i in range(len(d) if self.keep else 0):
                 self.store[(int(d["x"][i]), int(d["y"][i]), int(d["z"][i]))] = (d[i], v[i])
             self.paged += len(d)
+            self.last = (d, v)
 
 
 def test_three_thousand_frames_of_gc_and_paging_keep_the_table_healthy(hip, oracle):
-    frames = corridor_frames(31)
-    assert len(frames) >= 3000
+    """3 000 frames, 750 m, GC every frame (starve every 1000th), a 3 072-block pool and the streamer paging behind the
+    camera: ~150 k blocks pass through a 16 384-slot table.  No table error, short probe paths, oracle parity of what is
+    resident at the end and of everything that was paged out on the way."""
     a, b = engine(hip), engine(oracle)
-    pa, pb = Pager(a), Pager(b)
+    pa, pb = Pager(a, keep=False), Pager(b, keep=False)
     worst_probe = 0
-    for i, f in enumerate(frames):
+    n = 0
+    for i, f in enumerate(one_way_frames(3000)):
         cam = f.t.astype(np.float64)
         pa.before_frame(cam)
         pb.before_frame(cam)
+        if pa.paged != n:  # a paging event: both sides must have handed out the same blocks
+            n = pa.paged
+            assert pb.paged == n and np.array_equal(pa.last[0], pb.last[0]) and np.array_equal(pa.last[1].view(np.uint8), pb.last[1].view(np.uint8))
         pu.feed(a, f)
         pu.feed(b, f)
-        if i % 500 == 499:
+        if i % 250 == 249:
             a.sync()  # raises on ERR_TABLE / ERR_POOL
             s = a.stats()
             worst_probe = max(worst_probe, int(s.max_probe_length))
             assert s.error_flags == 0
     a.sync()
     s = a.stats()
-    print("frames", len(frames), "rehashes", s.rehash_count, "tombstones", s.tombstones, "slots", s.hash_slots, "max probe", s.max_probe_length,
+    print("frames 3000: rehashes", s.rehash_count, "tombstones", s.tombstones, "slots", s.hash_slots, "max probe", max(worst_probe, s.max_probe_length),
           "paged blocks", pa.paged)
-    assert pa.paged == pb.paged > 1000 and sorted(pa.store) == sorted(pb.store)  # the streamer really paged, identically
-    assert s.rehash_count >= 1, "the churn never triggered a table rebuild: the test does not stress the table"
-    assert s.tombstones <= s.hash_slots // 4 + 64 * 600
+    assert pa.paged == pb.paged > 50000
+    assert s.rehash_count >= 5, "the walk never triggered a table rebuild: the test does not stress the table"
+    assert s.tombstones <= s.hash_slots // 4 + 64 * 100
     assert max(worst_probe, int(s.max_probe_length)) <= 64
     assert s.error_flags == 0
     r = pu.compare_maps(a, b)
@@ -90,17 +104,25 @@ def test_three_thousand_frames_of_gc_and_paging_keep_the_table_healthy(hip, orac
     b.close()
 
 
-def test_without_upkeep_the_same_walk_fills_the_table_with_tombstones(hip, monkeypatch):
+def test_without_upkeep_the_same_walk_wears_the_table_out(hip, monkeypatch):
     """The hazard the rebuild removes, shown on the device alone: with the census switched off, the erased slots of the
-    same walk outnumber a quarter of the table many times over."""
+    same walk fill the table — lookups of absent keys walk ever longer runs and in the end an insert finds no slot."""
     monkeypatch.setenv("MRH_REHASH_PERIOD", "100000000")
-    frames = corridor_frames(8)
-    e = engine(hip, n_frames_invalidate_voxels=1000)
-    for f in frames:
+    e = engine(hip)
+    p = Pager(e, keep=False)
+    failed_at = None
+    tombs = 0
+    for i, f in enumerate(one_way_frames(1500)):
+        p.before_frame(f.t.astype(np.float64))
         pu.feed(e, f)
-    s = e.stats()
-    print("no upkeep:", len(frames), "frames -> tombstones", s.tombstones, "of", s.hash_slots, "slots, max probe", s.max_probe_length)
-    assert s.rehash_count == 0 and s.tombstones > s.hash_slots // 4
+        if i % 100 == 99:
+            st = e.stats()
+            tombs = max(tombs, int(st.tombstones))
+            if st.error_flags & 2:
+                failed_at = i
+                break
+    print("no upkeep: tombstones", tombs, "of", st.hash_slots, "slots; table error at frame", failed_at, "; max probe", st.max_probe_length)
+    assert st.rehash_count == 0 and (failed_at is not None or tombs > st.hash_slots // 2)
     e.close()
 
 

@@ -37,4 +37,9 @@ for label, v in (("single-res", 0.0), ("multi-res", var)):
     print(f"{label}: extract_triangles again {1e3 * (t1 - t0):7.2f} ms")
     t0 = time.perf_counter(); nt = e.extract_triangles(soup=False); t1 = time.perf_counter()
     print(f"{label}: extract without the soup read-back (GeoWrapper.extractMesh) {1e3 * (t1 - t0):7.2f} ms ({nt} triangles)")
+    st = e.stats()
+    mc_ms = st.last_mc_count_ms + st.last_mc_emit_ms
+    alg = 6144.0 * st.occupied_fine + 768.0 * st.occupied_coarse + 72.0 * nt
+    print(f"{label}: k_mc count {st.last_mc_count_ms:.3f} ms + emit {st.last_mc_emit_ms:.3f} ms over {st.last_mc_blocks} blocks; algorithmic bytes "
+          f"{alg / 1e6:.1f} MB -> {alg / (mc_ms * 1e-3) / 1e9 if mc_ms > 0 else 0:.1f} GB/s")
     e.close()
