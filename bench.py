@@ -3,24 +3,44 @@
 fraction of the integrate kernel and the CPU restatement timed beside it.
 
   python bench.py [--gpus N] [--steps K] [--warmup W]
+      N > 1 without WORLD_SIZE in the environment: re-executes itself under torch.distributed.run with N ranks
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[1]): "Replica room0" stand-in — analytic 6x3x4 m box room, orbit trajectory,
-Replica intrinsics rescaled to 640x480, depth quantised to 1/6553.5 m, replica.cfg parameters (1 cm voxels,
-7 cm truncation, GC every frame, starve every 100th).  One step = one frame through the whole
-VoxelContainer::integrate chain (allocate along rays -> frustum compaction -> depth->TSDF integrate -> GC).
-Frames are resident in HBM before the timed region starts (the PCIe-inclusive figure is in DESIGN.md).
+N = 1 — workload BASELINE.json configs[1]: "Replica room0" stand-in — analytic 6x3x4 m box room, orbit trajectory,
+Replica intrinsics rescaled to 640x480, depth quantised to 1/6553.5 m, replica.cfg parameters (1 cm voxels, 7 cm
+truncation, GC every frame, starve every 100th).  One step = one frame through the whole VoxelContainer::integrate
+chain (allocate along rays -> frustum compaction -> depth->TSDF integrate -> GC).  `value` = frames/s with the frames
+resident in HBM before the timed region starts.  Beside it, in the same JSON line:
+  roofline            k_back (integrate + GC) on that workload: algorithmic bytes / HIP-event time of the launch; `traffic`
+                      = HBM bytes per launch from rocprofv3 PMC passes of THIS workload run as sub-processes (null if
+                      rocprofv3 is not available)
+  roofline_hbm        the same kernel on a 2.5x larger room: the per-frame working set exceeds the 256 MiB Infinity Cache
+  mc                  configs[2]: variance-adaptive multi-resolution map of the same stream + marching-cubes extraction,
+                      roofline of the two k_mc launches (6144 B per fine block + 768 B per coarse block + 72 B per triangle)
+  pcie_inclusive_frames_per_s   the drop-in number: host numpy images -> mrh_upload_* every frame (never `value`)
+  cpu_baseline        the oracle on a bounded sample of the same stream
 
-N > 1: frame-sharded, weak scaling — every rank fuses its own K-frame segment of the stream into its own
-sub-map, no data-path collective inside the timed region; value = N*K / max-over-ranks time.
+N > 1 — workload BASELINE.json configs[3]: "ScanNet scene0000" stand-in (furnished 8x3x6 m room, hand-held walk).
+  `value`: FRAME-SHARDED fusion, weak scaling: every rank fuses its own K-frame segment into its own sub-map, no
+           data-path collective inside the timed region; value = N*K / max-over-ranks time.
+  `merge`: the sub-maps are then folded into ONE tile-sharded map (mrhash_amd.parallel.merge_submaps: all-to-all of
+           blocks to their tile owner over RCCL + weighted merge on the device) and the boundary blocks all-gathered
+           (exchange_halo): times and bytes of both steps.
+  `tile_sharded`: the result-identical mode on the same K frames (rank 0's segment, seen by every rank; starve frames
+           run their MIN all-reduce): frames/s = K / max-over-ranks time (strong scaling).
 """
 from __future__ import annotations
 
 import argparse
+import glob
 import json
 import os
+import shutil
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -29,25 +49,18 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01", "bench_pmc_summary.txt")
+MALL_BYTES = 256 << 20
 
 
-def pmc_traffic_bytes():
-    """HBM bytes per launch of the integrate kernel from the committed rocprofv3 PMC passes of this same command
-    (separate --pmc runs for FETCH_SIZE and WRITE_SIZE, tools/profile_bench.sh).  Units are KiB; on gfx950
-    FETCH_SIZE counts a wide coalesced read at half its bytes, so it is doubled (MI355X_MICROARCH.md, HBM)."""
-    try:
-        lines = open(PMC_SUMMARY).read().splitlines()
-        for i, l in enumerate(lines):
-            if l.startswith("mrh::k_back<true, false"):
-                kv = dict(tok.split("=") for tok in lines[i + 1].split())
-                return (2.0 * float(kv["FETCH_SIZE"]) + float(kv["WRITE_SIZE"])) * 1024.0
-    except Exception:
-        pass
-    return None
+def free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
@@ -55,91 +68,178 @@ def main():
     ap.add_argument("--blocks", type=int, default=262144, help="SDF block pool capacity (1.6 GB at 262144)")
     ap.add_argument("--cpu-frames", type=int, default=64, help="frames of the same stream timed on the CPU oracle (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--pcie", action="store_true", help="also time the same frames fed from host memory (mrh_upload_* per frame)")
-    args = ap.parse_args()
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 PMC sub-process passes (roofline.traffic = null)")
+    ap.add_argument("--no-extras", action="store_true", help="N=1: only the headline pass and its roofline (no mc / hbm / pcie legs)")
+    ap.add_argument("--pmc-inner", action="store_true", help=argparse.SUPPRESS)  # the workload alone, under rocprofv3
+    ap.add_argument("--frames-cache", default="", help=argparse.SUPPRESS)
+    return ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    n_gpus = args.gpus
-    K, W = args.steps, args.warmup
 
+# ---- workload helpers --------------------------------------------------------------------------------------------
+
+def render_stream(kind: str, n: int, start: int = 0, cache: str = ""):
+    """[Frame] of the named stand-in stream, frames [start, start + n)."""
+    from mrhash_amd import synth
+
+    if cache and os.path.exists(cache):
+        z = np.load(cache)
+        return [synth.Frame(z["t"][i], z["q"][i], z["R"][i], z["depth"][i], z["rgb"][i]) for i in range(len(z["t"]))]
+    if kind == "replica":
+        scene, K, poses, scaling = synth.replica_room(), synth.REPLICA_640, synth.orbit_poses(start + n)[start:], 6553.5
+    elif kind == "replica_big":  # the same room scaled 2.5x, the orbit with it: 6.25x the surface in view
+        scene = synth.Scene(synth.Box((-7.5, -3.75, -5.0), (7.5, 3.75, 5.0)), seed=0)
+        K, poses, scaling = synth.REPLICA_640, synth.orbit_poses(start + n, radius=2.5)[start:], 6553.5
+    elif kind == "scannet":
+        scene, K, poses, scaling = synth.scannet_room(), synth.SCANNET, synth.walk_poses(start + n, seed=0)[start:], 5000.0
+    else:
+        raise ValueError(kind)
+    frames = [synth.render(scene, K, t, q, depth_scaling=scaling) for t, q in poses]
+    if cache:
+        np.savez(cache, t=np.stack([f.t for f in frames]), q=np.stack([f.q for f in frames]), R=np.stack([f.R for f in frames]),
+                 depth=np.stack([f.depth for f in frames]), rgb=np.stack([f.rgb for f in frames]))
+    return frames
+
+
+class Resident:
+    """A stream uploaded to HBM once; `run` feeds frames [lo, hi) through the zero-copy setters."""
+
+    def __init__(self, frames, K):
+        import torch
+
+        self.frames, self.K = frames, K
+        self.depth = torch.from_numpy(np.stack([f.depth for f in frames])).cuda()
+        self.rgb = torch.from_numpy(np.stack([f.rgb for f in frames])).cuda()
+        torch.cuda.synchronize()
+        self.ds, self.rs = K.rows * K.cols * 4, K.rows * K.cols * 3
+
+    def run(self, engine, lo, hi, integrate=None):
+        K = self.K
+        for i in range(lo, hi):
+            f = self.frames[i]
+            engine.set_pose(f.R, f.t)
+            engine.set_depth_device(self.depth.data_ptr() + i * self.ds, K.rows, K.cols)
+            engine.set_rgb_device(self.rgb.data_ptr() + i * self.rs, K.rows, K.cols)
+            if integrate is None:
+                engine.integrate()
+            else:
+                integrate(engine)
+
+
+def make_engine(hip, params, K):
+    from mrhash_amd import capi
+
+    e = capi.Engine(hip, params)
+    e.set_camera(K.fx, K.fy, K.cx, K.cy, K.rows, K.cols, params.min_depth, params.max_depth)
+    return e
+
+
+def profiled_roofline(eng, res: Resident, W: int, total: int, label: str):
+    """Second pass over the same frames with the event pair attached to every k_back launch and the device-side U / M
+    counters (12 B read + 12 B write per updated voxel, 24 B per compact block, 7 B per pixel)."""
+    eng.reset()
+    res.run(eng, 0, W)
+    eng.sync()
+    eng.set_profile(True)
+    s0 = eng.stats()
+    t1 = time.perf_counter()
+    res.run(eng, W, total)
+    eng.sync()
+    prof_elapsed = time.perf_counter() - t1
+    s1 = eng.stats()
+    eng.set_profile(False)
+    n_k = int(s1.n_integrate_kernel - s0.n_integrate_kernel)
+    k_ms = float(s1.sum_integrate_kernel_ms - s0.sum_integrate_kernel_ms) / max(n_k, 1)
+    U = (int(s1.total_updated_voxels) - int(s0.total_updated_voxels)) / max(n_k, 1)
+    M = (int(s1.total_compact_blocks) - int(s0.total_compact_blocks)) / max(n_k, 1)
+    alg = 24.0 * U + 24.0 * M + 7 * res.K.rows * res.K.cols
+    achieved = alg / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+    touched = (U / 512.0) * 6144.0  # payload of the block-equivalents the launch rewrites
+    return {"bound": "hbm", "kernel": "k_back (depth->TSDF integrate + GC summary + GC decision)", "workload": label,
+            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "algorithmic_bytes_per_launch": alg, "kernel_ms_avg": k_ms, "launches": n_k, "updated_voxels_per_launch": U,
+            "compact_blocks_per_launch": M, "working_set_bytes_per_frame": M * 6144.0 + 7 * res.K.rows * res.K.cols,
+            "rewritten_payload_bytes_per_frame": touched, "exceeds_infinity_cache": bool(M * 6144.0 > MALL_BYTES),
+            "profiled_pass_ms_per_step": prof_elapsed / max(total - W, 1) * 1e3}
+
+
+def pmc_traffic(args, kernel_prefix: str, cache: str):
+    """HBM bytes per launch of `kernel_prefix` from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE: separate runs,
+    no trace flags beside --pmc) of this workload run as a sub-process.  Units are KiB; on gfx950 FETCH_SIZE counts a
+    wide coalesced read at half its bytes, so it is doubled (MI355X_MICROARCH.md, HBM section)."""
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    import csv
+
+    vals = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="mrh_pmc_", dir="/tmp")
+        cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__), "--pmc-inner",
+               "--steps", str(args.steps), "--warmup", str(args.warmup), "--blocks", str(args.blocks), "--frames-cache", cache]
+        try:
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=420)
+        except subprocess.TimeoutExpired:
+            shutil.rmtree(d, ignore_errors=True)
+            return None, f"rocprofv3 --pmc {counter} timed out"
+        tot, n = 0.0, 0
+        for fn in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            for row in csv.DictReader(open(fn)):
+                name = row["Kernel_Name"].replace("void ", "")
+                if name.startswith(kernel_prefix) and row["Counter_Name"] == counter:
+                    tot += float(row["Counter_Value"])
+                    n += 1
+        shutil.rmtree(d, ignore_errors=True)
+        if n == 0:
+            return None, f"rocprofv3 --pmc {counter}: no dispatch of {kernel_prefix} recorded (rc {r.returncode}: {r.stderr[-200:]})"
+        vals[counter] = (tot / n, n)
+    bytes_per_launch = (2.0 * vals["FETCH_SIZE"][0] + vals["WRITE_SIZE"][0]) * 1024.0
+    return bytes_per_launch, (f"measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE sub-process passes of the same workload, "
+                              f"{vals['FETCH_SIZE'][1]} dispatches, 2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction)")
+
+
+# ---- N = 1 ---------------------------------------------------------------------------------------------------------
+
+def bench_single(args):
     import torch
-
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device (torch.cuda.is_available() is False)")
-    # MRH_BENCH_DEVICE / MRH_BENCH_BACKEND exist so that the multi-rank code path can be exercised on a 1-GPU box
-    # (two ranks sharing device 0 over gloo); the driver's runs use one GPU per rank over RCCL.
-    device_index = int(os.environ.get("MRH_BENCH_DEVICE", local_rank))
-    backend = os.environ.get("MRH_BENCH_BACKEND", "nccl")
-    torch.cuda.set_device(device_index)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist_mod
-
-        dist = dist_mod
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device_index))
-        else:
-            dist.init_process_group(backend=backend)
 
     from mrhash_amd import capi, synth
 
+    K, W = args.steps, args.warmup
+    total = W + K
     hip = capi.load_hip()  # no fallback: raises if the HIP library is missing
     Kc = synth.REPLICA_640
-    params = capi.Params(num_sdf_blocks=args.blocks, device_id=device_index, **synth.REPLICA_PARAMS)
+    params = capi.Params(num_sdf_blocks=args.blocks, device_id=0, **synth.REPLICA_PARAMS)
+    cache = args.frames_cache or os.path.join(tempfile.gettempdir(), f"mrh_bench_replica_{total}.npz")
+    frames = render_stream("replica", total, cache=cache)
+    res = Resident(frames, Kc)
 
-    # ---- synthetic stream: this rank's segment, uploaded to HBM before timing ------------------------------
-    total = W + K
-    scene = synth.replica_room()
-    poses = synth.orbit_poses(total * world)[rank * total:(rank + 1) * total]
-    frames = [synth.render(scene, Kc, t, q, depth_scaling=6553.5) for t, q in poses]
-    depth_d = torch.from_numpy(np.stack([f.depth for f in frames])).cuda()
-    rgb_d = torch.from_numpy(np.stack([f.rgb for f in frames])).cuda()
-    torch.cuda.synchronize()
-    dstride = Kc.rows * Kc.cols * 4
-    rstride = Kc.rows * Kc.cols * 3
+    if args.pmc_inner:  # the timed workload alone (under rocprofv3 --pmc)
+        eng = make_engine(hip, params, Kc)
+        res.run(eng, 0, total)
+        eng.sync()
+        eng.close()
+        return
 
-    def run(engine, lo, hi):
-        for i in range(lo, hi):
-            f = frames[i]
-            engine.set_pose(f.R, f.t)
-            engine.set_depth_device(depth_d.data_ptr() + i * dstride, Kc.rows, Kc.cols)
-            engine.set_rgb_device(rgb_d.data_ptr() + i * rstride, Kc.rows, Kc.cols)
-            engine.integrate()
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-
-    # ---- pass A: the timed region (profile hooks off) -----------------------------------------------------
-    eng = capi.Engine(hip, params)
-    eng.set_camera(Kc.fx, Kc.fy, Kc.cx, Kc.cy, Kc.rows, Kc.cols, params.min_depth, params.max_depth)
-    run(eng, 0, W)
+    # ---- pass A: the timed region (profile hooks off)
+    eng = make_engine(hip, params, Kc)
+    res.run(eng, 0, W)
     eng.sync()
     torch.cuda.synchronize()
-    barrier()
     t0 = time.perf_counter()
-    run(eng, W, total)
+    res.run(eng, W, total)
     eng.sync()
     torch.cuda.synchronize()
-    barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
     st = eng.stats()
     occupied = int(st.occupied_fine)
+    table = {"hash_slots": int(st.hash_slots), "tombstones": int(st.tombstones), "max_probe_length": int(st.max_probe_length), "rehash_count": int(st.rehash_count)}
 
-    # ---- optional pass C: the boundary as the reference uses it (host buffers -> mrh_upload_depth / mrh_upload_rgb each frame).
-    # Runs BEFORE the profiled pass: launches that carry start / stop events switch the queue to profiling mode, which
-    # slows every later dispatch of the process.
+    # ---- the boundary as the reference uses it: host buffers -> mrh_upload_depth / mrh_upload_rgb each frame.  Runs BEFORE
+    # any profiled pass: launches that carry start / stop events switch the queue to profiling mode, which slows every
+    # later dispatch of the process.
     pcie_fps = None
-    if args.pcie:
-        pe = capi.Engine(hip, params)
-        pe.set_camera(Kc.fx, Kc.fy, Kc.cx, Kc.cy, Kc.rows, Kc.cols, params.min_depth, params.max_depth)
+    if not args.no_extras:
+        pe = make_engine(hip, params, Kc)
         for i in range(W):
             f = frames[i]
             pe.set_pose(f.R, f.t); pe.upload_depth(f.depth); pe.upload_rgb(f.rgb); pe.integrate()
@@ -152,38 +252,79 @@ def main():
         pcie_fps = K / (time.perf_counter() - t2)
         pe.close()
 
-    # ---- pass B: same frames, HIP events around every integrate-kernel launch + device-side U/M counters ---
-    eng.reset()
-    run(eng, 0, W)
-    eng.sync()
-    eng.set_profile(True)
-    s0 = eng.stats()
-    t1 = time.perf_counter()
-    run(eng, W, total)
-    eng.sync()
-    prof_elapsed = time.perf_counter() - t1
-    s1 = eng.stats()
-    n_k = int(s1.n_integrate_kernel - s0.n_integrate_kernel)
-    k_ms = float(s1.sum_integrate_kernel_ms - s0.sum_integrate_kernel_ms) / max(n_k, 1)
-    U = (int(s1.total_updated_voxels) - int(s0.total_updated_voxels)) / max(n_k, 1)
-    M = (int(s1.total_compact_blocks) - int(s0.total_compact_blocks)) / max(n_k, 1)
-    img_bytes = 7 * Kc.rows * Kc.cols
-    alg_bytes = 24.0 * U + 24.0 * M + img_bytes  # 12 B read + 12 B write per updated voxel
-    achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-    eng.close()
+    # ---- configs[2]: multi-resolution map of the same stream + marching cubes (timed before the profiled passes, too)
+    mc = None
+    if not args.no_extras:
+        mp = capi.Params(num_sdf_blocks=args.blocks, device_id=0, **dict(synth.REPLICA_PARAMS, sdf_var_threshold=0.005))
+        me = make_engine(hip, mp, Kc)
+        res.run(me, 0, W)
+        me.sync()
+        t3 = time.perf_counter()
+        res.run(me, W, total)
+        me.sync()
+        mr_elapsed = time.perf_counter() - t3
+        me.extract_triangles(soup=False)  # warm (allocations, first-touch of the result buffers)
+        t4 = time.perf_counter()
+        ntri = me.extract_triangles(soup=False)
+        extract_ms = (time.perf_counter() - t4) * 1e3
+        ms = me.stats()
+        mc_ms = float(ms.last_mc_count_ms + ms.last_mc_emit_ms)
+        alg_mc = 6144.0 * int(ms.occupied_fine) + 768.0 * int(ms.occupied_coarse) + 72.0 * ntri
+        ach = alg_mc / (mc_ms * 1e-3) / 1e9 if mc_ms > 0 else 0.0
+        mc = {"workload": "replica-room0 stand-in 640x480, sdf_var_threshold 0.005 (configs[2]): multi-resolution fusion, then extraction",
+              "multires_frames_per_s": K / mr_elapsed, "multires_ms_per_step": mr_elapsed / K * 1e3,
+              "fine_blocks": int(ms.occupied_fine), "coarse_blocks": int(ms.occupied_coarse), "triangles": int(ntri),
+              "extract_ms_in_library": extract_ms, "k_mc_count_ms": float(ms.last_mc_count_ms), "k_mc_emit_ms": float(ms.last_mc_emit_ms),
+              "roofline": {"bound": "hbm", "kernel": "k_mc<count> + k_mc<emit>", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": ach / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes": alg_mc,
+                           "note": "6144 B per fine block + 768 B per coarse block read once + 72 B per triangle written; latency / issue-bound, far below the HBM roof"}}
+        me.close()
 
-    # ---- CPU baseline: the oracle on a bounded sample of the same stream (rank 0, N == 1) ------------------
+    # ---- pass B: same frames, HIP events around every integrate-kernel launch + device-side U/M counters
+    roof = profiled_roofline(eng, res, W, total, "configs[1] (value's workload)")
+    eng.close()
+    roof["cache_note"] = "the per-frame working set sits inside the 256 MiB Infinity Cache between frames: see roofline_hbm for the same kernel outside it"
+
+    # ---- the same kernel with a working set above the Infinity Cache
+    roof_hbm = None
+    if not args.no_extras:
+        nb = min(total, 60)
+        wb = min(W, 10)
+        big = render_stream("replica_big", nb)
+        rb = Resident(big, Kc)
+        bp = capi.Params(num_sdf_blocks=max(args.blocks, 786432), device_id=0, **synth.REPLICA_PARAMS)
+        be = make_engine(hip, bp, Kc)
+        rb.run(be, 0, wb)
+        be.sync()
+        t5 = time.perf_counter()
+        rb.run(be, wb, nb)
+        be.sync()
+        big_fps = (nb - wb) / (time.perf_counter() - t5)
+        roof_hbm = profiled_roofline(be, rb, wb, nb, "the same room scaled 2.5x (15 x 7.5 x 10 m, orbit radius 2.5 m): depths 6.5-7.5 m")
+        roof_hbm["frames_per_s"] = big_fps
+        roof_hbm["live_blocks_end"] = int(be.stats().occupied_fine)
+        be.close()
+        del rb
+
+    # ---- HBM traffic of the headline kernel, measured now (sub-processes under rocprofv3)
+    if not args.no_pmc:
+        traffic, note = pmc_traffic(args, "mrh::k_back<true, false", cache)
+        roof["traffic"], roof["traffic_note"] = traffic, note
+    else:
+        roof["traffic_note"] = "--no-pmc"
+
+    # ---- CPU baseline: the oracle on a bounded sample of the same stream
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu and args.cpu_frames > 0:
+    if not args.no_cpu and args.cpu_frames > 0:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import ctypes
+
         import parity_utils as pu
 
         orc = pu.oracle_lib()
         orc.orc_num_threads.restype = ctypes.c_int
         cores = int(orc.orc_num_threads())
-        ce = capi.Engine(orc, capi.Params(num_sdf_blocks=131072, **synth.REPLICA_PARAMS))
-        ce.set_camera(Kc.fx, Kc.fy, Kc.cx, Kc.cy, Kc.rows, Kc.cols, params.min_depth, params.max_depth)
+        ce = make_engine(orc, capi.Params(num_sdf_blocks=131072, **synth.REPLICA_PARAMS), Kc)
         n_cpu = min(args.cpu_frames, total)
         tc = 0.0
         for i in range(n_cpu):
@@ -196,43 +337,171 @@ def main():
             tc += time.perf_counter() - c0
         ce.close()
         cpu = {"value": n_cpu / tc, "unit": "frames/s", "cores": cores, "kind": "port",
-               "sample": f"first {n_cpu} frames of the same 640x480 stream, CPU restatement (oracle/mrh_oracle.c, "
-                         f"gcc -O2 -fopenmp; allocation single-threaded), time of mrh_integrate only"}
+               "sample": f"first {n_cpu} frames of the same 640x480 stream through the test oracle (oracle/mrh_oracle.c, gcc -O2 -fopenmp, "
+                         f"allocation single-threaded: a restatement for checking results, not a tuned CPU implementation), time of mrh_integrate only"}
+
+    out = {
+        "metric": "depth frames/sec integrated (640x480)",
+        "value": K / elapsed, "unit": "frames/s", "n_gpus": 1, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "replica-room0 stand-in 640x480, single-resolution hash TSDF integrate (alloc+compact+integrate+GC per frame, "
+                               "replica.cfg params), frames resident in HBM",
+                   "frames_per_gpu": K, "voxel_size_m": 0.01, "truncation_m": 0.07, "parallelism": "single GPU", "live_blocks_end": occupied,
+                   "hash_table": table},
+        "roofline": roof, "roofline_hbm": roof_hbm, "mc": mc, "cpu_baseline": cpu,
+        "pcie_inclusive_frames_per_s": pcie_fps,
+    }
+    print(json.dumps(out), flush=True)
+
+
+# ---- N > 1 ---------------------------------------------------------------------------------------------------------
+
+def bench_multi(args):
+    import torch
+    import torch.distributed as dist
+
+    from mrhash_amd import capi, parallel, synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    K, W = args.steps, args.warmup
+    total = W + K
+    if world != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: launched with WORLD_SIZE={world}; refusing to report n_gpus = {args.gpus}")
+    # MRH_BENCH_DEVICE / MRH_BENCH_BACKEND exist so that the multi-rank code path can be exercised on a 1-GPU box
+    # (ranks sharing device 0 over gloo); the driver's runs use one GPU per rank over RCCL.
+    device_index = int(os.environ.get("MRH_BENCH_DEVICE", local_rank))
+    backend = os.environ.get("MRH_BENCH_BACKEND", "nccl")
+    torch.cuda.set_device(device_index)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if backend == "nccl":
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device_index))
+    else:
+        dist.init_process_group(backend=backend)
+    if dist.get_world_size() != args.gpus:
+        raise SystemExit(f"bench.py: the process group reports {dist.get_world_size()} ranks, --gpus says {args.gpus}")
+    cdev = "cuda" if backend == "nccl" else "cpu"
+
+    def barrier():
+        torch.cuda.synchronize()
+        dist.barrier()
+
+    def max_over_ranks(x: float) -> float:
+        t = torch.tensor([x], dtype=torch.float64, device=cdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    hip = capi.load_hip()
+    Kc = synth.SCANNET
+    params = capi.Params(num_sdf_blocks=args.blocks, device_id=device_index, **synth.SCANNET_PARAMS)
+    chunk_log2 = 3
+
+    # ---- frame-sharded fusion (value): this rank's own segment of the walk
+    mine = Resident(render_stream("scannet", total, start=rank * total), Kc)
+    eng = make_engine(hip, params, Kc)
+    mine.run(eng, 0, W)
+    eng.sync()
+    barrier()
+    t0 = time.perf_counter()
+    mine.run(eng, W, total)
+    eng.sync()
+    barrier()
+    elapsed = max_over_ranks(time.perf_counter() - t0)
+    sub_blocks = int(eng.stats().occupied_fine)
+
+    # ---- sub-maps -> one tile-sharded map -> halo exchange (what a mesh extraction needs next)
+    barrier()
+    t1 = time.perf_counter()
+    info = parallel.merge_submaps(eng, dist, chunk_log2)
+    barrier()
+    merge_s = max_over_ranks(time.perf_counter() - t1)
+    t2 = time.perf_counter()
+    n_halo = parallel.exchange_halo(eng, dist)
+    barrier()
+    halo_s = max_over_ranks(time.perf_counter() - t2)
+    owned = int(eng.stats().occupied_fine) - n_halo
+    parallel.drop_halo(eng)
+    counts = torch.tensor([sub_blocks, info["sent"], owned, n_halo], dtype=torch.int64, device=cdev)
+    allc = torch.empty(world * 4, dtype=torch.int64, device=cdev)
+    dist.all_gather_into_tensor(allc, counts)
+    allc = allc.cpu().numpy().reshape(world, 4)
+    eng.close()
+
+    # ---- tile-sharded fusion of ONE stream (rank 0's segment) by all ranks
+    shared = mine if rank == 0 else Resident(render_stream("scannet", total, start=0), Kc)
+    tp = capi.Params(num_sdf_blocks=args.blocks, device_id=device_index, shard_rank=rank, shard_count=world, shard_chunk_log2=chunk_log2,
+                     **synth.SCANNET_PARAMS)
+    te = make_engine(hip, tp, Kc)
+    step = lambda e: parallel.integrate(e, dist)  # noqa: E731
+    shared.run(te, 0, W, integrate=step)
+    te.sync()
+    barrier()
+    t3 = time.perf_counter()
+    shared.run(te, W, total, integrate=step)
+    te.sync()
+    barrier()
+    tile_elapsed = max_over_ranks(time.perf_counter() - t3)
+    tile_blocks = int(te.stats().occupied_fine)
+    te.close()
 
     if rank == 0:
+        rec = capi.RECORD_BYTES
         out = {
             "metric": "depth frames/sec integrated (640x480)",
-            "value": n_gpus * K / elapsed if world == n_gpus else world * K / elapsed,
-            "unit": "frames/s",
-            "n_gpus": n_gpus,
-            "steps": K,
-            "warmup": W,
-            "ms_per_step": elapsed / K * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f32",
-            "data": "synthetic",
-            "config": {"workload": "replica-room0 stand-in 640x480, single-resolution hash TSDF integrate "
-                                   "(alloc+compact+integrate+GC per frame, replica.cfg params)",
+            "value": world * K / elapsed, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "scannet-scene0000 stand-in 640x480 (furnished 8x3x6 m room, hand-held walk), single-resolution hash TSDF "
+                                   "integrate (alloc+compact+integrate+GC per frame, scannet.cfg params), frames resident in HBM",
                        "frames_per_gpu": K, "voxel_size_m": 0.01, "truncation_m": 0.07,
-                       "parallelism": "frame-sharded sub-maps, no data-path collective" if world > 1 else "single GPU",
-                       "live_blocks_end": occupied},
-            "roofline": {"bound": "hbm", "kernel": "k_back (depth->TSDF integrate + GC summary + GC decision)", "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic_bytes(),
-                         "traffic_note": "bytes per launch from profiles/r01/bench_pmc_summary.txt (rocprofv3 PMC passes of this "
-                                         "command, 2 x FETCH_SIZE + WRITE_SIZE); the ~85 MB working set stays in the 256 MiB "
-                                         "Infinity Cache between frames",
-                         "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms_avg": k_ms, "launches": n_k,
-                         "updated_voxels_per_launch": U, "compact_blocks_per_launch": M,
-                         "profiled_pass_ms_per_step": prof_elapsed / K * 1e3},
-            "cpu_baseline": cpu,
+                       "parallelism": f"value = FRAME-SHARDED: {world} ranks x {K} own frames into {world} sub-maps, no data-path collective in the timed "
+                                      f"region (backend {backend}); the sub-maps are merged afterwards (see merge)",
+                       "sub_map_blocks_per_rank": [int(v) for v in allc[:, 0]]},
+            "merge": {"what": "sub-maps -> one tile-sharded map: all-to-all of blocks to their tile owner + weighted merge on the device "
+                              "(parallel.merge_submaps), then all-gather of boundary blocks (parallel.exchange_halo)",
+                      "merge_ms": merge_s * 1e3, "halo_exchange_ms": halo_s * 1e3,
+                      "blocks_sent_per_rank": [int(v) for v in allc[:, 1]], "bytes_sent_per_rank": [int(v) * rec for v in allc[:, 1]],
+                      "owned_blocks_after_merge_per_rank": [int(v) for v in allc[:, 2]], "halo_blocks_taken_per_rank": [int(v) for v in allc[:, 3]],
+                      "value_including_merge": world * K / (elapsed + merge_s)},
+            "tile_sharded": {"what": f"the result-identical mode: every rank sees the same {K} frames and fuses only the tiles it owns (union of the "
+                                     f"{world} tables == the single-GPU map); starve frames run their MIN all-reduce; strong scaling",
+                             "frames_per_s": K / tile_elapsed, "ms_per_step": tile_elapsed / K * 1e3, "owned_blocks_rank0": tile_blocks,
+                             "chunk_log2": chunk_log2},
+            "roofline": None, "cpu_baseline": None,
         }
-        if pcie_fps is not None:
-            out["pcie_inclusive_frames_per_s"] = pcie_fps  # never `value`: inputs cross PCIe inside the timed region
         print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
+    barrier()
+    dist.destroy_process_group()
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # launched the single-process way: become N ranks (one per GPU) under torch.distributed.run
+        import torch
+
+        ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        share = os.environ.get("MRH_BENCH_SHARE_DEVICE") == "1"  # test mode: N ranks on device 0
+        if ndev < args.gpus and not share:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: only {ndev} HIP device(s) visible; refusing to report n_gpus = {args.gpus}")
+        env = dict(os.environ)
+        if share:
+            env.setdefault("MRH_BENCH_DEVICE", "0")
+            env.setdefault("MRH_BENCH_BACKEND", "gloo")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd, env=env))
+    import torch
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (torch.cuda.is_available() is False)")
+    if args.gpus > 1:
+        bench_multi(args)
+    else:
+        if int(os.environ.get("WORLD_SIZE", "1")) != 1:
+            raise SystemExit(f"bench.py --gpus 1 launched with WORLD_SIZE={os.environ['WORLD_SIZE']}")
+        torch.cuda.set_device(0)
+        bench_single(args)
 
 
 if __name__ == "__main__":

@@ -337,7 +337,7 @@ int take_device_flags(mrh_ctx* c, u32* out) {
 // Table upkeep between two frames (mrh_kernels.h): census of the tombstones every `census_period` frames or after a bulk
 // change, rebuild decided on the device.  Four short launches, no host round trip.
 int maintain_table(mrh_ctx* c, bool force_census) {
-  if (c->pending) return MRH_OK;
+  if (c->pending || c->census_period < 0) return MRH_OK;
   if (!force_census && !c->table_dirty && c->frames_since_census < (uint64_t) c->census_period) return MRH_OK;
   hipStream_t s = c->stream;
   const Tab& t = c->tab;
@@ -745,6 +745,7 @@ int mrh_create(const mrh_params* p, mrh_ctx** out) {
   if (const char* g = getenv("MRH_MR_FUSED")) c->mr_fused = atoi(g) ? 1 : 0;
   if (const char* g = getenv("MRH_REHASH_PERIOD")) { const int v = atoi(g); if (v > 0) c->census_period = v; }
   if (const char* g = getenv("MRH_REHASH_FORCE")) c->census_force = atoi(g) ? 1 : 0;
+  if (const char* g = getenv("MRH_REHASH_OFF")) { if (atoi(g)) c->census_period = -1; }  // no upkeep at all (tests: shows what it prevents)
   if (const char* g = getenv("MRH_SWEEP_WGS_MR")) { const int v = atoi(g); if (v > 0 && v <= 4096) c->sweep_wgs_mr = v; }
   int rc = init_buffers(c);
   if (rc != MRH_OK) {

@@ -45,10 +45,11 @@ struct Neigh {
   const float* halo_sdf;
   const u32* halo_rgbw;
   int halo_rim;
+  float r_vs;       // rcp_refined(voxel size) for the position -> voxel divisions (0: plain IEEE division)
 };
 __device__ __forceinline__ Neigh neigh_none() {
   Neigh nb;
-  nb.vals = nullptr; nb.base = mki3(0, 0, 0); nb.shift_limit = 0; nb.halo_sdf = nullptr; nb.halo_rgbw = nullptr; nb.halo_rim = 0;
+  nb.vals = nullptr; nb.base = mki3(0, 0, 0); nb.shift_limit = 0; nb.halo_sdf = nullptr; nb.halo_rgbw = nullptr; nb.halo_rim = 0; nb.r_vs = 0.f;
   return nb;
 }
 
@@ -96,12 +97,32 @@ __device__ __forceinline__ VoxSample get_voxel_i(const Map& m, const Tab& t, con
   r.rgbw = vp.rgbw[li];
   return r;
 }
-__device__ __forceinline__ VoxSample get_voxel_f(const Map& m, const Tab& t, const Neigh& nb, f3 pos) { return get_voxel_i(m, t, nb, world_to_voxel(m.vs, pos)); }
+// vhu.cuh:143-151 worldPointToVirtualVoxelPos with the three divisions by the voxel size through one shared refined
+// reciprocal (div_rr is bit-identical to the IEEE divide for these operands, mrh_device.h; a -0 quotient may come out as
+// +0, which both sign(.) and the >= 0 test treat identically)
+__device__ __forceinline__ i3 world_to_voxel_nb(const Neigh& nb, const float vs, const f3 pt) {
+  if (nb.r_vs == 0.f) return world_to_voxel(vs, pt);
+  const f3 p = mk3(div_rr(pt.x, vs, nb.r_vs), div_rr(pt.y, vs, nb.r_vs), div_rr(pt.z, vs, nb.r_vs));
+  const float epsilon = 1e-5;
+  f3 a = mk3(p.x + (float) signi(p.x) * 0.5f, p.y + (float) signi(p.y) * 0.5f, p.z + (float) signi(p.z) * 0.5f);
+  a.x = (a.x >= 0) ? floorf(a.x + epsilon) : ceilf(a.x - epsilon);
+  a.y = (a.y >= 0) ? floorf(a.y + epsilon) : ceilf(a.y - epsilon);
+  a.z = (a.z >= 0) ? floorf(a.z + epsilon) : ceilf(a.z - epsilon);
+  return mki3(f2i_hw(a.x), f2i_hw(a.y), f2i_hw(a.z));
+}
+__device__ __forceinline__ VoxSample get_voxel_f(const Map& m, const Tab& t, const Neigh& nb, f3 pos) { return get_voxel_i(m, t, nb, world_to_voxel_nb(nb, m.vs, pos)); }
 
 // vds.cu:236-240 getVoxelSize(float3).  With a single resolution every block (and every miss) answers vs.
 __device__ __forceinline__ float get_voxel_size_f(const Map& m, const Tab& t, const Neigh& nb, f3 pos) {
   if (!t.multi_res) return m.vs * (float) (1 << 0);
-  const u32 val = block_val(t, nb, world_to_block(m.vs, pos));
+  i3 b;
+  if (nb.halo_sdf) {  // staged workgroup: every voxel it can reach converts to its block by the arithmetic shift
+    const i3 v = world_to_voxel_nb(nb, m.vs, pos);
+    b = mki3(v.x >> 3, v.y >> 3, v.z >> 3);
+  } else {
+    b = world_to_block(m.vs, pos);
+  }
+  const u32 val = block_val(t, nb, b);
   const int res = (val != kNbAbsent && (val & kValCoarseBit)) ? 1 : 0;
   return m.vs * (float) (1 << res);
 }
@@ -250,6 +271,78 @@ __device__ __forceinline__ int mc_voxel(const Map& m, const Tab& t, const Neigh&
   return ntri;
 }
 
+// marching_cubes.cu:72-261 for one voxel by EIGHT adjacent lanes, lane `k` = corner k (bit 0: +x, bit 1: +y, bit 2: +z; the
+// corner numbers of the edge codes), `gb` = first lane of the group.  Each lane evaluates one trilinear corner value and
+// one raw sample; the cube index, the early returns (a corner without a usable value, a jump above the threshold) and the
+// triangle count are formed with ballots and shuffles inside the group — the same pure function of the same 8 corner
+// values as the sequential mc_voxel, so the same result.  With EMIT the up to 15 vertices of the voxel are interpolated
+// by the 8 lanes (two each) and stored straight into out[0 .. min(ntri, room)).  Must be called by all 8 lanes of a group
+// (inactive groups pass active = false and take part in the ballots with neutral values).
+template <bool EMIT>
+__device__ __forceinline__ int mc_group(const Map& m, const Tab& t, const Neigh& nb, const f3 pf, const int k, const int gb, const bool active,
+                                        mrh_triangle* out, const int room) {
+  const float vvs = get_voxel_size_f(m, t, nb, pf);
+  const float P = vvs * 0.5f;
+  const float M = -P;
+  f3 sP = mk3(P * 1.f, P * 1.f, P * 1.f);
+  f3 sM = mk3(M * 1.f, M * 1.f, M * 1.f);
+  if (t.multi_res) {
+    // marching_cubes.cu:7-69 checkVertexVoxels: six independent tests, lane j < 6 takes test j (+x, -x, +y, -y, +z, -z)
+    bool flag = false;
+    if (k < 6) {
+      const float o = (k & 1) ? M : P;
+      const f3 q = mk3(pf.x + ((k >> 1) == 0 ? o : 0.0f), pf.y + ((k >> 1) == 1 ? o : 0.0f), pf.z + ((k >> 1) == 2 ? o : 0.0f));
+      const float vs = get_voxel_size_f(m, t, nb, q);
+      flag = vs > 0 && vs < 1 && vs != vvs;
+    }
+    const u32 flags = (u32) (__ballot(flag) >> gb) & 0x3Fu;
+    if (flags & 1u) sP.x *= 0.499f;
+    if (flags & 2u) sM.x *= 0.499f;
+    if (flags & 4u) sP.y *= 0.499f;
+    if (flags & 8u) sM.y *= 0.499f;
+    if (flags & 16u) sP.z *= 0.499f;
+    if (flags & 32u) sM.z *= 0.499f;
+  }
+  const f3 p = mk3(pf.x + ((k & 1) ? sP.x : sM.x), pf.y + ((k & 2) ? sP.y : sM.y), pf.z + ((k & 4) ? sP.z : sM.z));
+  float dist = 0.f;
+  const bool valid = trilinear(m, t, nb, p, dist);
+  const VoxSample v = get_voxel_f(m, t, nb, p);
+  const u32 col = v.rgbw;
+  bool bad = false;
+  if (!valid) {
+    if ((int) (v.rgbw >> 24) < m.min_weight_threshold) bad = true;
+    else dist = v.sdf;
+  }
+  const u32 badmask = (u32) (__ballot(bad && active) >> gb) & 0xFFu;
+  const u32 cube = (u32) (__ballot(dist < 0.f) >> gb) & 0xFFu;
+  const float thr = m.mc_threshold;
+  bool fail = fabsf(dist) > thr;
+#pragma unroll
+  for (int l = 0; l < 8; l++) {
+    const float dl = __shfl(dist, gb + l);
+    if (dist * dl < 0.f) fail = fail || (fabsf(dist) + fabsf(dl) > thr);
+    else fail = fail || (fabsf(dist - dl) > thr);
+  }
+  const u32 failmask = (u32) (__ballot(fail && active) >> gb) & 0xFFu;
+  const uint8_t* row = d_mc_tri[cube];
+  const int ntri = (!active || badmask || failmask) ? 0 : (int) row[0];
+  if (EMIT) {
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const int sidx = k + 8 * h;  // vertex slot: triangle sidx / 3, corner sidx % 3
+      const bool mine = sidx < 3 * ntri;
+      const int code = mine ? (int) row[1 + sidx] : 0;
+      const int a = code >> 4, b = code & 0xF;
+      const float da = __shfl(dist, gb + a), db = __shfl(dist, gb + b);
+      const u32 ca = (u32) __shfl((int) col, gb + a), cb = (u32) __shfl((int) col, gb + b);
+      const f3 pa = mk3(pf.x + ((a & 1) ? sP.x : sM.x), pf.y + ((a & 2) ? sP.y : sM.y), pf.z + ((a & 4) ? sP.z : sM.z));
+      const f3 pb = mk3(pf.x + ((b & 1) ? sP.x : sM.x), pf.y + ((b & 2) ? sP.y : sM.y), pf.z + ((b & 4) ? sP.z : sM.z));
+      if (mine && sidx / 3 < room) out[sidx / 3].v[sidx % 3] = vertex_interp(pa, pb, da, db, ca, cb);
+    }
+  }
+  return ntri;
+}
+
 // packed keys of a block list: key order == (x, y, z) lexicographic order, the canonical order of the extraction
 __global__ __launch_bounds__(256) void k_list_keys(const int4* __restrict__ list, const int n, u64* __restrict__ keys) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -263,21 +356,24 @@ __global__ __launch_bounds__(256) void k_list_keys(const int4* __restrict__ list
 //   1. the 27 surrounding blocks are resolved once (table value or absent)                              -> s_nb
 //   2. every voxel marching cubes can sample for this block is staged in LDS ({sdf, rgbw} per fine cell) -> halo
 //   3. COUNT pass: sign class of every staged cell (1: weighted and clearly positive, 2: weighted and clearly negative,
-//      0: anything else) and a separable AND over the (2w + 1)^3 window of each voxel (w = 1 on a single-resolution
-//      neighbourhood, 3 otherwise): everything marching cubes evaluates for a voxel — the eight trilinear corner values,
-//      the coarser re-samples they blend in on a resolution jump, or the raw sample a corner falls back to — is a convex
-//      combination of, or a sample from, cells of that window (fp32 evaluation error < 2e-5 x the largest magnitude), so
-//      if all of them share one class every corner has that sign, the cube index is 0 or 255 and the voxel has no
-//      triangle: it is not evaluated at all.  "Clearly" = 1e-3 x sdf_bound <= |sdf| <= 1.001 x sdf_bound, sdf_bound =
-//      the largest truncation a sample can carry; anything outside (or NaN) is class 0.
+//      0: anything else) and an AND over the (2w + 1)^3 window of each voxel: everything marching cubes evaluates for a
+//      voxel — the eight trilinear corner values, the coarser re-samples they blend in on a resolution jump, or the raw
+//      sample a corner falls back to — is a convex combination of, or a sample from, cells of that window (fp32 evaluation
+//      error < 2e-5 x the largest magnitude), so if all of them share one class every corner has that sign, the cube index
+//      is 0 or 255 and the voxel has no triangle: it is not evaluated at all.  w = 1 for a fine voxel whose 3^3 cells lie
+//      in fine (or absent) blocks — every sample then stays inside those cells; w = 3 for a coarse voxel or a fine one
+//      next to a coarse block (Neigh's comment derives the reach).  "Clearly" = 1e-3 x sdf_bound <= |sdf| <= 1.001 x
+//      sdf_bound, sdf_bound = the largest truncation a sample can carry; anything outside (or NaN) is class 0.
 //      EMIT pass: the candidates are the voxels the count pass found non-empty (per_voxel).
-//   4. the candidates are COMPACTED (LDS list) and evaluated densely, one lane each, through the staged cells: a lookup
-//      is the reference's float position -> voxel conversion, a subtraction and two LDS reads — no hash, no global gather
+//   4. the candidates are COMPACTED (LDS list) and evaluated densely, EIGHT lanes per voxel (one per cube corner,
+//      mc_group), through the staged cells: a lookup is the reference's float position -> voxel conversion, a subtraction
+//      and two LDS reads — no hash, no global gather
 //   5. block-wide exclusive scan of the per-voxel triangle counts in voxel order: counts[e] (COUNT) / the exact offset
 //      of every voxel's triangles (EMIT) -> canonical (block, voxel, triangle) order, no atomics.
 // Blocks too far from the origin for voxel -> block to be the arithmetic shift skip 2-3 and evaluate every voxel through
 // the neighbour table / the hash (the literal path).
 constexpr int kMcThreads = 256;
+constexpr int kMcFillIters = (kHaloCells + kMcThreads - 1) / kMcThreads;  // 11
 template <bool EMIT>
 __global__ __launch_bounds__(kMcThreads) void k_mc(const Map m, const Tab t, const int4* __restrict__ sorted, const int n,
                                                    u32* __restrict__ counts, const u64* __restrict__ offsets,
@@ -289,9 +385,11 @@ __global__ __launch_bounds__(kMcThreads) void k_mc(const Map m, const Tab t, con
   __shared__ uint8_t s_cls[2][kHaloCells];
   __shared__ unsigned short s_cand[512];
   __shared__ uint8_t s_ntri[512];
+  __shared__ u32 s_off[512];
   __shared__ u32 s_wave[kMcThreads / 64];
   __shared__ u32 s_ncand;
   const int tid = threadIdx.x;
+  const int lane = tid & 63;
   for (int e = blockIdx.x; e < n; e += gridDim.x) {
     const int4 ent = sorted[e];
     const u32 val = (u32) ent.w;
@@ -300,6 +398,7 @@ __global__ __launch_bounds__(kMcThreads) void k_mc(const Map m, const Tab t, con
     Neigh nb = neigh_none();
     nb.base = mki3(ent.x, ent.y, ent.z);
     nb.shift_limit = m.block_shift_limit;
+    nb.r_vs = rcp_refined(m.vs);
     if (tid < 27) {  // resolve the 27 surrounding blocks once
       const i3 b = mki3(ent.x + (tid % 3) - 1, ent.y + ((tid / 3) % 3) - 1, ent.z + (tid / 9) - 1);
       u64 key;
@@ -315,32 +414,48 @@ __global__ __launch_bounds__(kMcThreads) void k_mc(const Map m, const Tab t, con
     const bool mine = owns_block(m, mki3(ent.x, ent.y, ent.z));  // uniform
     const int amax = max(max(abs(ent.x), abs(ent.y)), abs(ent.z));
     const bool staged = mine && (amax + 3) * kBlockSide < m.block_shift_limit;  // uniform: every reachable voxel converts by shift
-    u32 any_coarse = coarse ? kValCoarseBit : 0u;
+    u32 cmask = 0;  // bit i: neighbour i is a coarse block (uniform)
     if (t.multi_res)
-      for (int i = 0; i < 27; i++) any_coarse |= (s_nb[i] != kNbAbsent) ? (s_nb[i] & kValCoarseBit) : 0u;
-    const int rim = any_coarse ? kHaloRim : 1;  // uniform
+      for (int i = 0; i < 27; i++) cmask |= (s_nb[i] != kNbAbsent && (s_nb[i] & kValCoarseBit)) ? (1u << i) : 0u;
+    // cells to stage around the block: the count pass classifies up to 3 cells out when a coarse block is near, the emit
+    // pass only needs what its few candidates read (anything farther falls back to the neighbour table)
+    const int rim = (EMIT ? coarse : cmask != 0u) ? kHaloRim : 1;  // uniform
     if (staged) {
       const int side = kBlockSide + 2 * rim;
-      for (int c = tid; c < side * side * side; c += kMcThreads) {
-        const int lx = c % side - rim, ly = (c / side) % side - rim, lz = c / (side * side) - rim;  // fine cell relative to the block
-        const u32 nval = s_nb[((lz >> 3) + 1) * 9 + ((ly >> 3) + 1) * 3 + ((lx >> 3) + 1)];
-        float sv = 0.f;
-        u32 rw = 0;
-        if (nval != kNbAbsent) {
-          const VoxPtr vp = vox_ptr(t, nval);
-          const int fx = lx & 7, fy = ly & 7, fz = lz & 7;
-          const u32 li = (nval & kValCoarseBit) ? (u32) ((fz >> 1) * 16 + (fy >> 1) * 4 + (fx >> 1)) : (u32) (fz * 64 + fy * 8 + fx);
-          sv = vp.sdf[li];
-          rw = vp.rgbw[li];
+      const int ncell = side * side * side;
+      float sv[kMcFillIters];
+      u32 rw[kMcFillIters];
+#pragma unroll
+      for (int it = 0; it < kMcFillIters; it++) {  // all gathers of a thread in flight before the first LDS store
+        const int c = tid + it * kMcThreads;
+        sv[it] = 0.f;
+        rw[it] = 0;
+        if (c < ncell) {
+          const int lx = c % side - rim, ly = (c / side) % side - rim, lz = c / (side * side) - rim;  // fine cell relative to the block
+          const u32 nval = s_nb[((lz >> 3) + 1) * 9 + ((ly >> 3) + 1) * 3 + ((lx >> 3) + 1)];
+          if (nval != kNbAbsent) {
+            const VoxPtr vp = vox_ptr(t, nval);
+            const int fx = lx & 7, fy = ly & 7, fz = lz & 7;
+            const u32 li = (nval & kValCoarseBit) ? (u32) ((fz >> 1) * 16 + (fy >> 1) * 4 + (fx >> 1)) : (u32) (fz * 64 + fy * 8 + fx);
+            sv[it] = vp.sdf[li];
+            rw[it] = vp.rgbw[li];
+          }
         }
-        const int idx = ((lz + kHaloRim) * kHaloSide + (ly + kHaloRim)) * kHaloSide + (lx + kHaloRim);
-        s_sdf[idx] = sv;
-        s_rgbw[idx] = rw;
-        if (!EMIT) {
-          const float lo = 1e-3f * sdf_bound, hi = 1.001f * sdf_bound;
-          uint8_t cls = 0;
-          if ((rw >> 24) != 0) cls = (sv >= lo && sv <= hi) ? 1 : ((sv <= -lo && sv >= -hi) ? 2 : 0);
-          s_cls[0][idx] = cls;
+      }
+      const float lo = 1e-3f * sdf_bound, hi = 1.001f * sdf_bound;
+#pragma unroll
+      for (int it = 0; it < kMcFillIters; it++) {
+        const int c = tid + it * kMcThreads;
+        if (c < ncell) {
+          const int lx = c % side - rim, ly = (c / side) % side - rim, lz = c / (side * side) - rim;
+          const int idx = ((lz + kHaloRim) * kHaloSide + (ly + kHaloRim)) * kHaloSide + (lx + kHaloRim);
+          s_sdf[idx] = sv[it];
+          s_rgbw[idx] = rw[it];
+          if (!EMIT) {
+            uint8_t cls = 0;
+            if ((rw[it] >> 24) != 0) cls = (sv[it] >= lo && sv[it] <= hi) ? 1 : ((sv[it] <= -lo && sv[it] >= -hi) ? 2 : 0);
+            s_cls[0][idx] = cls;
+          }
         }
       }
       __syncthreads();
@@ -355,46 +470,100 @@ __global__ __launch_bounds__(kMcThreads) void k_mc(const Map m, const Tab t, con
       for (int v = tid; v < nvox; v += kMcThreads)
         if (per_voxel[(size_t) e * 512 + v] != 0) s_cand[atomicAdd(&s_ncand, 1u)] = (unsigned short) v;
     } else if (staged && sdf_bound > 0.f) {
-      // separable AND of the sign classes over the window [-w, w]^3 (w = rim): x, then y, then z
-      const int w = rim;
-      for (int c = tid; c < kBlockSide * kHaloSide * kHaloSide; c += kMcThreads) {  // x in 0..7, all staged y, z
-        const int x = c & 7, yz = c >> 3;
-        const int base = yz * kHaloSide + (x + kHaloRim);
-        u32 acc = 3u;
-        for (int d = -w; d <= w; d++) acc &= s_cls[0][base + d];
-        s_cls[1][base] = (uint8_t) acc;
+      // per voxel: w = 1 window straight from the classes; does it need the wide one?
+      u32 acc1[2] = {3u, 3u};
+      bool wide[2] = {false, false};
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const int v = tid + h * kMcThreads;
+        if (v < nvox) {
+          if (coarse) {
+            wide[h] = true;
+          } else {
+            const int x = v & 7, y = (v >> 3) & 7, z = v >> 6;
+            const int base = ((z + kHaloRim) * kHaloSide + (y + kHaloRim)) * kHaloSide + (x + kHaloRim);
+            u32 acc = 3u;
+#pragma unroll
+            for (int dz = -1; dz <= 1; dz++)
+#pragma unroll
+              for (int dy = -1; dy <= 1; dy++)
+#pragma unroll
+                for (int dx = -1; dx <= 1; dx++) acc &= s_cls[0][base + (dz * kHaloSide + dy) * kHaloSide + dx];
+            acc1[h] = acc;
+            if (cmask) {  // blocks its 3^3 cells touch: per axis the own block, and the previous / next one at coordinate 0 / 7
+              u32 touched = 0;
+#pragma unroll
+              for (int i = 0; i < 27; i++) {
+                const int bx = i % 3, by = (i / 3) % 3, bz = i / 9;
+                const bool tx = bx == 1 || (bx == 0 && x == 0) || (bx == 2 && x == 7);
+                const bool ty = by == 1 || (by == 0 && y == 0) || (by == 2 && y == 7);
+                const bool tz = bz == 1 || (bz == 0 && z == 0) || (bz == 2 && z == 7);
+                touched |= (tx && ty && tz) ? (1u << i) : 0u;
+              }
+              wide[h] = (touched & cmask) != 0u;
+            }
+          }
+        }
       }
-      __syncthreads();
-      for (int c = tid; c < kBlockSide * kBlockSide * kHaloSide; c += kMcThreads) {  // x, y in 0..7, all staged z
-        const int x = c & 7, y = (c >> 3) & 7, z = c >> 6;
-        const int base = (z * kHaloSide + (y + kHaloRim)) * kHaloSide + (x + kHaloRim);
-        u32 acc = 3u;
-        for (int d = -w; d <= w; d++) acc &= s_cls[1][base + d * kHaloSide];
-        s_cls[0][base] = (uint8_t) acc;
+      if (cmask) {  // uniform: separable AND of the classes over [-3, 3]^3: x, then y, then z
+        __syncthreads();
+        constexpr int w = kHaloRim;
+        for (int c = tid; c < kBlockSide * kHaloSide * kHaloSide; c += kMcThreads) {  // x in 0..7, all staged y, z
+          const int x = c & 7, yz = c >> 3;
+          const int base = yz * kHaloSide + (x + kHaloRim);
+          u32 acc = 3u;
+#pragma unroll
+          for (int d = -w; d <= w; d++) acc &= s_cls[0][base + d];
+          s_cls[1][base] = (uint8_t) acc;
+        }
+        __syncthreads();
+        for (int c = tid; c < kBlockSide * kBlockSide * kHaloSide; c += kMcThreads) {  // x, y in 0..7, all staged z
+          const int x = c & 7, y = (c >> 3) & 7, z = c >> 6;
+          const int base = (z * kHaloSide + (y + kHaloRim)) * kHaloSide + (x + kHaloRim);
+          u32 acc = 3u;
+#pragma unroll
+          for (int d = -w; d <= w; d++) acc &= s_cls[1][base + d * kHaloSide];
+          s_cls[0][base] = (uint8_t) acc;
+        }
+        __syncthreads();
       }
-      __syncthreads();
-      for (int v = tid; v < nvox; v += kMcThreads) {
-        int x, y, z;
-        if (!coarse) { x = v & 7; y = (v >> 3) & 7; z = v >> 6; }
-        else { x = 2 * (v & 3); y = 2 * ((v >> 2) & 3); z = 2 * (v >> 4); }
-        const int base = ((z + kHaloRim) * kHaloSide + (y + kHaloRim)) * kHaloSide + (x + kHaloRim);
-        u32 acc = 3u;
-        for (int d = -w; d <= w; d++) acc &= s_cls[0][base + d * kHaloSide * kHaloSide];
-        if (acc == 0u) s_cand[atomicAdd(&s_ncand, 1u)] = (unsigned short) v;  // not all positive and not all negative
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const int v = tid + h * kMcThreads;
+        if (v < nvox) {
+          u32 acc = acc1[h];
+          if (wide[h]) {
+            int x, y, z;
+            if (!coarse) { x = v & 7; y = (v >> 3) & 7; z = v >> 6; }
+            else { x = 2 * (v & 3); y = 2 * ((v >> 2) & 3); z = 2 * (v >> 4); }
+            const int base = ((z + kHaloRim) * kHaloSide + (y + kHaloRim)) * kHaloSide + (x + kHaloRim);
+            acc = 3u;
+#pragma unroll
+            for (int d = -kHaloRim; d <= kHaloRim; d++) acc &= s_cls[0][base + d * kHaloSide * kHaloSide];
+          }
+          if (acc == 0u) s_cand[atomicAdd(&s_ncand, 1u)] = (unsigned short) v;  // not all positive and not all negative
+        }
       }
     } else {
       for (int v = tid; v < nvox; v += kMcThreads) s_cand[atomicAdd(&s_ncand, 1u)] = (unsigned short) v;
     }
     __syncthreads();
     const int ncand = (int) s_ncand;
+    auto voxel_position = [&](const int v) {
+      i3 pi;
+      if (!coarse) pi = mki3(ent.x * kBlockSide + (v & 7), ent.y * kBlockSide + ((v >> 3) & 7), ent.z * kBlockSide + (v >> 6));
+      else pi = mki3(ent.x * kBlockSide + 2 * (v & 3), ent.y * kBlockSide + 2 * ((v >> 2) & 3), ent.z * kBlockSide + 2 * (v >> 4));
+      return voxel_to_world(m.vs, pi);
+    };
+    const int gb = lane & ~7, corner = lane & 7;
     if (!EMIT) {
-      // ---- dense evaluation of the candidates; per-voxel counts to LDS
-      for (int i = tid; i < ncand; i += kMcThreads) {
-        const int v = s_cand[i];
-        i3 pi;
-        if (!coarse) pi = mki3(ent.x * kBlockSide + (v & 7), ent.y * kBlockSide + ((v >> 3) & 7), ent.z * kBlockSide + (v >> 6));
-        else pi = mki3(ent.x * kBlockSide + 2 * (v & 3), ent.y * kBlockSide + 2 * ((v >> 2) & 3), ent.z * kBlockSide + 2 * (v >> 4));
-        s_ntri[v] = (uint8_t) mc_voxel<false>(m, t, nb, voxel_to_world(m.vs, pi), nullptr);
+      // ---- dense evaluation of the candidates, 8 lanes each; per-voxel counts to LDS
+      for (int base = 0; base < ncand * 8; base += kMcThreads) {
+        const int i = base + tid;
+        const bool active = i < ncand * 8;
+        const int v = s_cand[active ? (i >> 3) : 0];
+        const int ntri = mc_group<false>(m, t, nb, voxel_position(v), corner, gb, active, nullptr, 0);
+        if (active && corner == 0) s_ntri[v] = (uint8_t) ntri;
       }
       __syncthreads();
     }
@@ -409,30 +578,28 @@ __global__ __launch_bounds__(kMcThreads) void k_mc(const Map m, const Tab t, con
     u32 incl = c0 + c1;
     for (int off = 1; off < 64; off <<= 1) {
       const u32 o = __shfl_up(incl, off);
-      if ((int) lane_id() >= off) incl += o;
+      if (lane >= off) incl += o;
     }
-    if (lane_id() == 63) s_wave[tid >> 6] = incl;
+    if (lane == 63) s_wave[tid >> 6] = incl;
     __syncthreads();
     u32 wave_off = 0, total = 0;
     for (int i = 0; i < kMcThreads / 64; i++) { if (i < (tid >> 6)) wave_off += s_wave[i]; total += s_wave[i]; }
     if (!EMIT) {
       if (tid == 0) counts[e] = total;
     } else {
-      // exclusive offsets of this thread's two voxels, parked in LDS for the lanes that evaluate them
-      u32* s_off = (u32*) s_cls;  // 512 x u32 = 2 KiB of the class arrays (unused by the emit pass)
+      // exclusive offsets of this thread's two voxels, parked in LDS for the groups that evaluate them
       const u32 ex0 = wave_off + incl - (c0 + c1);
       s_off[v0] = ex0;
       s_off[v0 + 1] = ex0 + c0;
       __syncthreads();
-      for (int i = tid; i < ncand; i += kMcThreads) {
-        const int v = s_cand[i];
-        i3 pi;
-        if (!coarse) pi = mki3(ent.x * kBlockSide + (v & 7), ent.y * kBlockSide + ((v >> 3) & 7), ent.z * kBlockSide + (v >> 6));
-        else pi = mki3(ent.x * kBlockSide + 2 * (v & 3), ent.y * kBlockSide + 2 * ((v >> 2) & 3), ent.z * kBlockSide + 2 * (v >> 4));
-        const u64 base = offsets[e] + s_off[v];
-        const int room = base >= max_tris ? 0 : (int) (max_tris - base < 5 ? max_tris - base : 5);
-        const int ntri = mc_voxel<true>(m, t, nb, voxel_to_world(m.vs, pi), out + base, room);  // straight to the exact offset
-        if (ntri > room) atomicOr((u32*) &t.ctr[CTR_ERROR], ERR_TRI);
+      for (int base = 0; base < ncand * 8; base += kMcThreads) {
+        const int i = base + tid;
+        const bool active = i < ncand * 8;
+        const int v = s_cand[active ? (i >> 3) : 0];
+        const u64 first = offsets[e] + s_off[v];
+        const int room = first >= max_tris ? 0 : (int) (max_tris - first < 5 ? max_tris - first : 5);
+        const int ntri = mc_group<true>(m, t, nb, voxel_position(v), corner, gb, active, out + first, room);  // straight to the exact offset
+        if (active && corner == 0 && ntri > room) atomicOr((u32*) &t.ctr[CTR_ERROR], ERR_TRI);
       }
     }
     __syncthreads();
