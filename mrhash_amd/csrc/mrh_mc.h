@@ -355,8 +355,8 @@ __global__ __launch_bounds__(256) void k_list_keys(const int4* __restrict__ list
 // One workgroup (256 threads) per block of the sorted list.
 //   1. the 27 surrounding blocks are resolved once (table value or absent)                              -> s_nb
 //   2. every voxel marching cubes can sample for this block is staged in LDS ({sdf, rgbw} per fine cell) -> halo
-//   3. COUNT pass: sign class of every staged cell (1: weighted and clearly positive, 2: weighted and clearly negative,
-//      0: anything else) and an AND over the (2w + 1)^3 window of each voxel: everything marching cubes evaluates for a
+//   3. COUNT pass: class of every staged cell (1: weighted and clearly positive, 2: weighted and clearly negative, 4: never
+//      observed, 0: anything else) and an AND over the (2w + 1)^3 window of each voxel: everything marching cubes evaluates for a
 //      voxel — the eight trilinear corner values, the coarser re-samples they blend in on a resolution jump, or the raw
 //      sample a corner falls back to — is a convex combination of, or a sample from, cells of that window (fp32 evaluation
 //      error < 2e-5 x the largest magnitude), so if all of them share one class every corner has that sign, the cube index
@@ -443,6 +443,10 @@ __global__ __launch_bounds__(kMcThreads) void k_mc(const Map m, const Tab t, con
         }
       }
       const float lo = 1e-3f * sdf_bound, hi = 1.001f * sdf_bound;
+      // third class: a cell without an observation (weight 0, or no block).  If a voxel's whole window is unseen, every
+      // corner's trilinear stencil meets a weight-0 sample (vds.cu:283-284: invalid) and the raw sample it falls back to has
+      // weight 0 < min_weight_threshold (marching_cubes.cu:89-93: return): no triangle.  Needs min_weight_threshold >= 1.
+      const uint8_t unseen = m.min_weight_threshold >= 1 ? 4 : 0;
 #pragma unroll
       for (int it = 0; it < kMcFillIters; it++) {
         const int c = tid + it * kMcThreads;
@@ -452,7 +456,7 @@ __global__ __launch_bounds__(kMcThreads) void k_mc(const Map m, const Tab t, con
           s_sdf[idx] = sv[it];
           s_rgbw[idx] = rw[it];
           if (!EMIT) {
-            uint8_t cls = 0;
+            uint8_t cls = unseen;
             if ((rw[it] >> 24) != 0) cls = (sv[it] >= lo && sv[it] <= hi) ? 1 : ((sv[it] <= -lo && sv[it] >= -hi) ? 2 : 0);
             s_cls[0][idx] = cls;
           }
@@ -471,7 +475,7 @@ __global__ __launch_bounds__(kMcThreads) void k_mc(const Map m, const Tab t, con
         if (per_voxel[(size_t) e * 512 + v] != 0) s_cand[atomicAdd(&s_ncand, 1u)] = (unsigned short) v;
     } else if (staged && sdf_bound > 0.f) {
       // per voxel: w = 1 window straight from the classes; does it need the wide one?
-      u32 acc1[2] = {3u, 3u};
+      u32 acc1[2] = {7u, 7u};
       bool wide[2] = {false, false};
 #pragma unroll
       for (int h = 0; h < 2; h++) {
@@ -482,7 +486,7 @@ __global__ __launch_bounds__(kMcThreads) void k_mc(const Map m, const Tab t, con
           } else {
             const int x = v & 7, y = (v >> 3) & 7, z = v >> 6;
             const int base = ((z + kHaloRim) * kHaloSide + (y + kHaloRim)) * kHaloSide + (x + kHaloRim);
-            u32 acc = 3u;
+            u32 acc = 7u;
 #pragma unroll
             for (int dz = -1; dz <= 1; dz++)
 #pragma unroll
@@ -511,7 +515,7 @@ __global__ __launch_bounds__(kMcThreads) void k_mc(const Map m, const Tab t, con
         for (int c = tid; c < kBlockSide * kHaloSide * kHaloSide; c += kMcThreads) {  // x in 0..7, all staged y, z
           const int x = c & 7, yz = c >> 3;
           const int base = yz * kHaloSide + (x + kHaloRim);
-          u32 acc = 3u;
+          u32 acc = 7u;
 #pragma unroll
           for (int d = -w; d <= w; d++) acc &= s_cls[0][base + d];
           s_cls[1][base] = (uint8_t) acc;
@@ -520,7 +524,7 @@ __global__ __launch_bounds__(kMcThreads) void k_mc(const Map m, const Tab t, con
         for (int c = tid; c < kBlockSide * kBlockSide * kHaloSide; c += kMcThreads) {  // x, y in 0..7, all staged z
           const int x = c & 7, y = (c >> 3) & 7, z = c >> 6;
           const int base = (z * kHaloSide + (y + kHaloRim)) * kHaloSide + (x + kHaloRim);
-          u32 acc = 3u;
+          u32 acc = 7u;
 #pragma unroll
           for (int d = -w; d <= w; d++) acc &= s_cls[1][base + d * kHaloSide];
           s_cls[0][base] = (uint8_t) acc;
@@ -537,11 +541,11 @@ __global__ __launch_bounds__(kMcThreads) void k_mc(const Map m, const Tab t, con
             if (!coarse) { x = v & 7; y = (v >> 3) & 7; z = v >> 6; }
             else { x = 2 * (v & 3); y = 2 * ((v >> 2) & 3); z = 2 * (v >> 4); }
             const int base = ((z + kHaloRim) * kHaloSide + (y + kHaloRim)) * kHaloSide + (x + kHaloRim);
-            acc = 3u;
+            acc = 7u;
 #pragma unroll
             for (int d = -kHaloRim; d <= kHaloRim; d++) acc &= s_cls[0][base + d * kHaloSide * kHaloSide];
           }
-          if (acc == 0u) s_cand[atomicAdd(&s_ncand, 1u)] = (unsigned short) v;  // not all positive and not all negative
+          if (acc == 0u) s_cand[atomicAdd(&s_ncand, 1u)] = (unsigned short) v;  // the window's cells do not share one class
         }
       }
     } else {
