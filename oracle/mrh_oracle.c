@@ -42,6 +42,9 @@
  *       non-atomic read-modify-write per point, so the points of one scan that cross the same voxel
  *       race.  Canonical: every voxel receives its updates in ascending point index (the sequential
  *       loop of mrh_integrate_points).  norm3df(x, y, z) is restated as sqrtf((x*x + y*y) + z*z).
+ *   D8  spherical camera model (camera.cuh:93-101, :147-164, :184-201): sinf / cosf / atan2f / asinf are evaluated by ONE
+ *       plain-fp32 implementation shared with the kernels (include/mrh_softmath.h, within ~2 ulp of the correctly
+ *       rounded values) instead of CUDA's intrinsics, exactly as rsqrtf is restated as 1 / sqrtf.
  *   D7  3DGS splat seeds (subdivideKernel quad_tree.cu:102-167, processNodesKernel
  *       gaussian_data_structures.cu:5-56): the reference appends leaves, child nodes and seeds through
  *       atomic counters.  Canonical: leaves by tree level, inside a level in tree order (children in the
@@ -58,6 +61,7 @@
 
 #include "../include/mrhash_hip.h"
 #include "../include/mrh_mc_tables.h"
+#include "../include/mrh_softmath.h"
 
 /* ---- constants: params.h:4-38 ---------------------------------------------------------- */
 #define LOCK_ENTRY (-1)
@@ -311,7 +315,9 @@ static inline f3 inverse_projection(const mrh_ctx* c, unsigned row, unsigned col
     /* camera.cuh:91-99 */
     const float az = c->ifx * ((float) col - c->cx - 0.5f);
     const float el = c->ify * ((float) row - c->cy - 0.5f);
-    const float s0 = sinf(az), c0 = cosf(az), s1 = sinf(el), c1 = cosf(el);
+    float s0, c0, s1, c1; /* D8: one shared fp32 implementation instead of CUDA's sinf / cosf (include/mrh_softmath.h) */
+    mrh_sincosf(az, &s0, &c0);
+    mrh_sincosf(el, &s1, &c1);
     return mk3(d * (c0 * c1), d * (s0 * c1), d * s1);
   }
 }
@@ -332,8 +338,8 @@ static inline int project_point(const mrh_ctx* c, f3 pc, int approx, int* row_ou
   } else {
     const float range = sqrtf(pc.x * pc.x + pc.y * pc.y + pc.z * pc.z);
     if (range < c->min_depth || range > c->max_depth) return 0;
-    const float px = atan2f(pc.y, pc.x);
-    const float py = asinf(pc.z / range);
+    const float px = mrh_atan2f(pc.y, pc.x); /* D8 */
+    const float py = mrh_asinf(pc.z / range);
     row = f2i((c->fy * py + c->cy) + 0.5f);
     col = f2i((c->fx * px + c->cx) + 0.5f);
   }
@@ -2059,6 +2065,17 @@ int mrh_selftest_division(mrh_ctx* c, uint64_t samples, uint64_t seed, uint64_t*
   (void) c; (void) samples; (void) seed;
   if (out) *out = 0; /* the oracle divides with the C '/' operator: nothing to self-test */
   return MRH_OK;
+}
+
+/* test hook for include/mrh_softmath.h (tests/test_softmath.py): op 0 sin, 1 cos, 2 atan2(a, b), 3 asin */
+float orc_softmath(int op, float a, float b) {
+  float s, c;
+  switch (op) {
+    case 0: mrh_sincosf(a, &s, &c); return s;
+    case 1: mrh_sincosf(a, &s, &c); return c;
+    case 2: return mrh_atan2f(a, b);
+    default: return mrh_asinf(a);
+  }
 }
 
 /* threads the order-independent loops (integrate, GC identify) run on; 1 when built without OpenMP */
