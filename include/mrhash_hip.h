@@ -215,11 +215,19 @@ int mrh_integrate_resume(mrh_ctx* ctx);
  * (voxel_data_structures.cpp:112-135) = allocBlocks3D (vds.cu:925-1092) + integrate3D (vds.cu:1215-1410).
  * xyz: n points, sensor frame, float32 [n][3]; the pose is the one given to mrh_set_pose, the integration distance
  * the max_depth given to mrh_set_camera (either camera model; no image is involved).
- * Scope = the shipped LiDAR configurations (vbr / maicity / newer_college .cfg): projective SDF without normals,
- * n_frames_invalidate_voxels = 0 and sdf_var_threshold = 0 — anything else returns MRH_ERR_UNSUPPORTED.
+ * Covers the projective SDF (every shipped LiDAR configuration) and the normal-direction SDF (mrh_upload_normals),
+ * garbage collection on scans (n_frames_invalidate_voxels > 0: identify + free over every live block each scan; the
+ * starve step every n-th scan projects through the camera given to mrh_set_camera — spherical for a LiDAR) and
+ * variance-adaptive maps (sdf_var_threshold > 0: after coarsening the scan is integrated a second time, as
+ * reintegrate3D does, vds.cu:1561-1580).
  * The reference updates a voxel with a non-atomic read-modify-write per point (a race between the points of a
  * scan); here every voxel receives its updates in ascending point index (oracle header, D6). */
 int mrh_upload_points(mrh_ctx* ctx, const float* xyz, uint64_t n);
+/* One normal per point of the current scan (sensor frame, any length: normalised on the device as vds.cu:1236 does), for
+ * the normal-direction SDF (projective_sdf = 0, vds.cu:1248-1251, :1322-1326).  Replaces the first eigenvector the
+ * reference takes from its MAD-tree (geowrapper.cpp:386-403: three eigenvectors per point, indexed by 3 * point,
+ * vds.cu:1229); estimating normals is the caller's business here.  Copied before the call returns. */
+int mrh_upload_normals(mrh_ctx* ctx, const float* nxyz, uint64_t n);
 int mrh_set_points_device(mrh_ctx* ctx, const float* d_xyz, uint64_t n); /* zero-copy: device pointer, valid until the next integrate returns */
 int mrh_integrate_points(mrh_ctx* ctx, int n_frames_invalidate);
 

@@ -110,7 +110,7 @@ assert TRI_DTYPE.itemsize == 24
 ABI_SYMBOLS = (
     "mrh_create mrh_destroy mrh_reset mrh_last_error mrh_set_camera mrh_set_pose mrh_upload_depth "
     "mrh_upload_rgb mrh_set_depth_device mrh_set_rgb_device mrh_integrate mrh_integrate_resume mrh_exchange_buffer mrh_sync "
-    "mrh_upload_points mrh_set_points_device mrh_integrate_points mrh_stream_out mrh_get_free_blocks "
+    "mrh_upload_points mrh_upload_normals mrh_set_points_device mrh_integrate_points mrh_stream_out mrh_get_free_blocks "
     "mrh_splat_seeds mrh_get_qtree_leaves mrh_peek_free_blocks mrh_peek_error_flags "
     "mrh_set_sharding mrh_pack_blocks mrh_unpack_blocks mrh_drop_blocks "
     "mrh_extract_triangles mrh_extract_mesh mrh_get_stats mrh_set_profile mrh_dump_blocks "
@@ -139,6 +139,7 @@ def _declare(lib: C.CDLL) -> C.CDLL:
     lib.mrh_set_rgb_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
     lib.mrh_integrate.argtypes = [C.c_void_p, C.c_int]
     lib.mrh_upload_points.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+    lib.mrh_upload_normals.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
     lib.mrh_set_points_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
     lib.mrh_integrate_points.argtypes = [C.c_void_p, C.c_int]
     lib.mrh_get_free_blocks.argtypes = [C.c_void_p, P(C.c_int64), P(C.c_int64)]
@@ -305,11 +306,21 @@ class Engine:
         a = np.ascontiguousarray(xyz, dtype=np.float32)
         self._check(self.lib.mrh_upload_points(self._ctx, a.ctypes.data, a.shape[0]))
 
+    def upload_normals(self, nxyz: np.ndarray):
+        """One normal per point of the current scan, float32 [N, 3] (copied): the normal-direction SDF (projective_sdf = False)."""
+        a = np.ascontiguousarray(nxyz, dtype=np.float32).reshape(-1, 3)
+        self._check(self.lib.mrh_upload_normals(self._ctx, a.ctypes.data, a.shape[0]))
+
     def set_points_device(self, ptr: int, n: int):
         self._check(self.lib.mrh_set_points_device(self._ctx, ptr, n))
 
-    def integrate_points(self, n_frames_invalidate: int = -1):
-        self._check(self.lib.mrh_integrate_points(self._ctx, n_frames_invalidate))
+    def integrate_points(self, n_frames_invalidate: int = -1) -> bool:
+        """One scan.  Returns True when a sharded context stopped for the starve z-buffer reduction (see integrate())."""
+        rc = self.lib.mrh_integrate_points(self._ctx, n_frames_invalidate)
+        if rc == MRH_PENDING_EXCHANGE:
+            return True
+        self._check(rc)
+        return False
 
     def integrate(self, n_frames_invalidate: int = -1) -> bool:
         """Enqueues one frame.  Returns True when a sharded context stopped for a min-reduction over ranks

@@ -230,10 +230,11 @@ void GeoWrapper::compute() {
     }
   }
   if (!point_cloud_.empty()) {  // geowrapper.cpp:146-147: VoxelContainer::integrate(point_cloud, eigenvectors, weights, ...)
-    // With the projective SDF (every shipped configuration and runner) the reference only normalises the normals and
-    // never uses them (vds.cu:1236, :1245-1251): normals passed along with the points are accepted and ignored.  The
-    // normal-direction SDF itself is rejected by mrh_integrate_points (the reference's own caller-supplied-normals path
-    // indexes the normal array by 3 * point, vds.cu:1229, past the end of what setPointCloud(points, normals) stores).
+    // Normals passed along with the points (one per point) drive the normal-direction SDF when the wrapper was built with
+    // projective_sdf = false (vds.cu:1248-1251, :1322-1326); with the projective SDF (every shipped configuration and
+    // runner) the reference only normalises them and never uses them (vds.cu:1236), so they are simply not needed.
+    // Estimating normals (the reference's MAD-tree, geowrapper.cpp:377-403) is the caller's business here.
+    if (!normals_.empty()) check(mrh_upload_normals(ctx_, normals_.data(), normals_.size() / 3), "compute");
     check(mrh_upload_points(ctx_, point_cloud_.data(), point_cloud_.size() / 3), "compute");
     check(mrh_integrate_points(ctx_, n_frames_invalidate_voxels_), "compute");
   }

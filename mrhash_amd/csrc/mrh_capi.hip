@@ -132,6 +132,10 @@ struct mrh_ctx {
   uint2* dcx_buf = nullptr;  // {cleaned depth, packed colour} of the current frame (written by k_front)
   int4* d_cfree = nullptr;
   // LiDAR scan of the current frame (mrh_lidar.h)
+  float* d_cloud = nullptr; size_t cloud_n = 0;  // spherical camera: getDepth(cloud) image of the current frame (k_cloud_depth)
+  float* d_normals = nullptr; uint64_t normals_cap = 0, num_normals = 0;  // one normal per point (mrh_upload_normals)
+  bool frame_general = false;       // this frame ran through the general kernels (mrh_kernels.h): GC by k_gc_identify / k_gc_free
+  bool fast_summaries_stale = false;  // single-resolution map: a general frame left Fast::summary behind
   float* d_points = nullptr;        // owned copy (mrh_upload_points) ...
   const float* d_points_cur = nullptr;  // ... or the caller's device pointer (mrh_set_points_device)
   uint64_t points_cap = 0, num_points = 0;
@@ -257,7 +261,7 @@ void free_all(mrh_ctx* c) {
   if (c->h_peek) (void) hipHostFree(c->h_peek);
   F(c->d_decision); F(c->d_zbuf); F(c->d_realloc); F(c->d_reint); F(c->d_flag);
   F(c->d_upd_partials); F(c->d_misc); F(c->d_rcp_w); F(c->d_cfree); F(c->d_zmin); F(c->d_points); F(c->d_pt_counts); F(c->d_pt_offsets); F(c->d_rec_keys[0]); F(c->d_rec_keys[1]); F(c->d_rec_vals[0]); F(c->d_rec_vals[1]); F(c->d_sort_tmp); F(c->fast.summary); F(c->fast.summary_c); F(c->fast.bbox); F(c->d_cnt_partials);
-  F(c->d_pack); F(c->d_halo); F(c->d_taken);
+  F(c->d_pack); F(c->d_halo); F(c->d_taken); F(c->d_cloud); F(c->d_normals);
   for (hipEvent_t e : c->mc_ev) if (e) (void) hipEventDestroy(e);
   F(c->d_qt_sums); F(c->d_qt_flags); F(c->d_qt_unc); F(c->d_qt_marks); F(c->d_qt_pos); F(c->d_qt_parked); F(c->d_qt_seeds); F(c->d_qt_leaves); F(c->d_qt_misc); F(c->d_qt_tmp);
   for (auto& e : c->ev_pool) { (void) hipEventDestroy(e.a); (void) hipEventDestroy(e.b); }
@@ -552,16 +556,19 @@ int frame_tail(mrh_ctx* c, bool starved, int max_num_frames) {
   const Map& m = c->map;
   const Tab& t = c->tab;
   const float thr = m.trunc + m.trunc_scale * k.max_depth;  // getTruncation(camera.maxDepth(), ...), vds.cu:1720
-  if (!t.multi_res) {
+  if (c->frame_general) {  // garbageCollectIdentify + garbageCollectFree over the compact list (vds.cu:1674-1713, :1827-1844)
+    if (max_num_frames > 0) {
+      k_gc_identify<<<c->integrate_grid, 512, 0, s>>>(t, thr, c->d_decision);
+      if (c->profile) k_gc_free<true><<<256, 256, 0, s>>>(t, c->d_decision);
+      else k_gc_free<false><<<256, 256, 0, s>>>(t, c->d_decision);
+    }
+    if (!t.multi_res) c->fast_summaries_stale = true;  // the general kernels do not maintain the fast path's GC summaries
+  } else if (!t.multi_res) {
     if (starved) k_summarize_visible<<<1024, 256, 0, s>>>(t, c->fast);  // weights changed: the GC summaries follow the payload
     if (max_num_frames > 0 && !c->frame_gc_inline) {
       const Lists L = {t.compact, c->fast.bbox, c->d_cfree, c->d_zmin, (u32) c->num_blocks};
       k_free_lists<<<256, 256, 0, s>>>(t, c->fast, L, c->frame_parity, thr);
     }
-  } else if (max_num_frames > 0 && !c->frame_fused_mr) {
-    k_gc_identify<<<c->integrate_grid, 512, 0, s>>>(t, thr, c->d_decision);
-    if (c->profile) k_gc_free<true><<<256, 256, 0, s>>>(t, c->d_decision);
-    else k_gc_free<false><<<256, 256, 0, s>>>(t, c->d_decision);
   }
   c->frames++;
   HIP_TRY(c, hipGetLastError());
@@ -804,6 +811,7 @@ int mrh_set_camera(mrh_ctx* c, float fx, float fy, float cx, float cy, int rows,
   k.min_depth = min_depth; k.max_depth = max_depth;
   k.max_int_dist = max_depth;  // geowrapper.cpp:111 setIntegrationDistance(max_depth)
   c->spherical = model == MRH_CAMERA_SPHERICAL;
+  k.model = c->spherical ? 1 : 0;
   c->has_camera = true;
   return MRH_OK;
 }
@@ -965,7 +973,6 @@ static int integrate_frame(mrh_ctx* c, int n_frames_invalidate) {
   if (c->pending) return fail(c, MRH_ERR_STATE, "mrh_integrate: an exchange is pending (call mrh_integrate_resume)");
   if (c->halo_upper) return fail(c, MRH_ERR_STATE, "mrh_integrate: halo blocks of other shards are present (call mrh_drop_blocks(MRH_DROP_HALO) after the extraction)");
   if (!c->has_camera) return fail(c, MRH_ERR_STATE, "mrh_integrate: set_camera has not been called");
-  if (c->spherical) return fail(c, MRH_ERR_UNSUPPORTED, "mrh_integrate: spherical (LiDAR) camera model is outside this round's scope");
   if (!c->d_depth || !c->d_rgb) return fail(c, MRH_ERR_STATE, "mrh_integrate: depth and rgb images are required");
   const Cam& k = c->cam;
   if (c->depth_rows != k.rows || c->depth_cols != k.cols || c->rgb_rows != k.rows || c->rgb_cols != k.cols)
@@ -985,14 +992,19 @@ static int integrate_frame(mrh_ctx* c, int n_frames_invalidate) {
   // frames, and the starve frames themselves, go through the general kernels.
   const bool starve_now = max_num_frames > 0 && c->frames > 0 && c->frames % (uint64_t) max_num_frames == 0;
   c->frame_fused_mr = t.multi_res && c->mr_fused && !c->profile && max_num_frames > 0 && !starve_now && !c->mr_next_general &&
-                      c->frames >= 2;
+                      c->frames >= 2 && !c->spherical;
+  c->frame_general = c->spherical || (t.multi_res && !c->frame_fused_mr);
   if (t.multi_res && !c->frame_fused_mr) {
     c->mr_summaries_valid = false;
     c->mr_next_general = starve_now || c->frames == 0;
     c->refill_flag_valid = false;
   }
-  if (!t.multi_res || c->frame_fused_mr) {
+  if (!c->frame_general) {
     // ---- fast path: alloc + sweep -> fused integrate / summary / GC (mrh_fast2.h)
+    if (!t.multi_res && c->fast_summaries_stale) {  // a general frame (spherical camera) ran since: rebuild the GC summaries once
+      k_summarize_all<<<2048, 256, 0, s>>>(t, c->fast);
+      c->fast_summaries_stale = false;
+    }
     const size_t npix = (size_t) k.rows * k.cols;
     const int tiles_x = (k.cols + kRayTile - 1) / kRayTile, tiles_y = (k.rows + kRayTile - 1) / kRayTile;
     if (c->fast_npix < npix) {
@@ -1067,9 +1079,24 @@ static int integrate_frame(mrh_ctx* c, int n_frames_invalidate) {
     k_refill_decide<<<1, 64, 0, s>>>(t, c->low_blocks_to_allocate, c->d_flag);
     k_refill<<<(c->low_blocks_to_allocate + 255) / 256, 256, 0, s>>>(t, c->low_blocks_to_allocate, c->d_flag);
   }
+  // the image every kernel below reads as "depth": the raw image (pinhole: cloud z == depth, cleaned on the fly) or, for
+  // the spherical model, getDepth(cloud) computed once per frame
+  const float* depth_img = c->d_depth;
+  if (c->spherical) {
+    const size_t npix = (size_t) k.rows * k.cols;
+    if (c->cloud_n < npix) {
+      HIP_TRY(c, hipStreamSynchronize(s));
+      if (c->d_cloud) HIP_TRY(c, hipFree(c->d_cloud));
+      c->d_cloud = nullptr;
+      HIP_TRY(c, hipMalloc((void**) &c->d_cloud, npix * sizeof(float)));
+      c->cloud_n = npix;
+    }
+    k_cloud_depth<<<(int) ((npix + 255) / 256), 256, 0, s>>>(k, c->d_depth, c->d_cloud);
+    depth_img = c->d_cloud;
+  }
   const dim3 tiles((k.cols + kTile - 1) / kTile, (k.rows + kTile - 1) / kTile);
-  if (c->profile) k_alloc<true><<<tiles, dim3(kTile, kTile), 0, s>>>(k, m, t, c->d_depth);
-  else k_alloc<false><<<tiles, dim3(kTile, kTile), 0, s>>>(k, m, t, c->d_depth);
+  if (c->profile) k_alloc<true><<<tiles, dim3(kTile, kTile), 0, s>>>(k, m, t, depth_img);
+  else k_alloc<false><<<tiles, dim3(kTile, kTile), 0, s>>>(k, m, t, depth_img);
   k_compact<<<512, 256, 0, s>>>(k, m, t, 1);
 
   if (c->profile) {
@@ -1080,11 +1107,11 @@ static int integrate_frame(mrh_ctx* c, int n_frames_invalidate) {
       else { HIP_TRY(c, hipEventCreate(&ev.a)); HIP_TRY(c, hipEventCreate(&ev.b)); }
     }
     HIP_TRY(c, hipEventRecord(ev.a, s));
-    k_integrate<true><<<c->integrate_grid, 512, 0, s>>>(k, m, t, c->d_depth, c->d_rgb, c->d_upd_partials);
+    k_integrate<true><<<c->integrate_grid, 512, 0, s>>>(k, m, t, depth_img, c->d_rgb, c->d_upd_partials);
     HIP_TRY(c, hipEventRecord(ev.b, s));
     c->ev_pending.push_back(ev);
   } else {
-    k_integrate<false><<<c->integrate_grid, 512, 0, s>>>(k, m, t, c->d_depth, c->d_rgb, c->d_upd_partials);
+    k_integrate<false><<<c->integrate_grid, 512, 0, s>>>(k, m, t, depth_img, c->d_rgb, c->d_upd_partials);
   }
 
   if (t.multi_res && c->frames > 0) {
@@ -1093,7 +1120,7 @@ static int integrate_frame(mrh_ctx* c, int n_frames_invalidate) {
     k_check_var<<<2048, 64, 0, s>>>(m, t, c->d_realloc);
     k_realloc<<<64, 256, 0, s>>>(t, c->d_realloc, c->d_reint);
     k_compact<<<512, 256, 0, s>>>(k, m, t, 1);
-    k_reintegrate<<<1024, 64, 0, s>>>(k, m, t, c->d_depth, c->d_rgb, c->d_reint);
+    k_reintegrate<<<1024, 64, 0, s>>>(k, m, t, depth_img, c->d_rgb, c->d_reint);
   }
 
   return starve_and_tail(c, max_num_frames);
@@ -1126,6 +1153,23 @@ int mrh_set_points_device(mrh_ctx* c, const float* d_xyz, uint64_t n) {
   return MRH_OK;
 }
 
+int mrh_upload_normals(mrh_ctx* c, const float* nxyz, uint64_t n) {
+  int rc = ensure_ready(c, "mrh_upload_normals");
+  if (rc) return rc;
+  if (n && !nxyz) return fail(c, MRH_ERR_INVALID_ARG, "mrh_upload_normals: null argument");
+  if (n > c->normals_cap) {
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->d_normals) HIP_TRY(c, hipFree(c->d_normals));
+    c->d_normals = nullptr;
+    HIP_TRY(c, hipMalloc((void**) &c->d_normals, n * 3 * sizeof(float)));
+    c->normals_cap = n;
+  }
+  if (n) HIP_TRY(c, hipMemcpyAsync(c->d_normals, nxyz, n * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));  // the caller's buffer is free on return
+  c->num_normals = n;
+  return MRH_OK;
+}
+
 // VoxelContainer::integrate(point_cloud, ...) voxel_data_structures.cpp:112-135 (mrh_lidar.h)
 int mrh_integrate_points(mrh_ctx* c, int n_frames_invalidate) {
   int rc = ensure_ready(c, "mrh_integrate_points");
@@ -1134,10 +1178,9 @@ int mrh_integrate_points(mrh_ctx* c, int n_frames_invalidate) {
   if (c->halo_upper) return fail(c, MRH_ERR_STATE, "mrh_integrate_points: halo blocks of other shards are present (call mrh_drop_blocks(MRH_DROP_HALO) after the extraction)");
   if (!c->has_camera) return fail(c, MRH_ERR_STATE, "mrh_integrate_points: set_camera has not been called");
   const int max_num_frames = n_frames_invalidate < 0 ? c->p.n_frames_invalidate_voxels : n_frames_invalidate;
-  if (max_num_frames > 0) return fail(c, MRH_ERR_UNSUPPORTED, "mrh_integrate_points: garbage collection on LiDAR scans (spherical projection) is outside this round's scope");
-  if (c->tab.multi_res) return fail(c, MRH_ERR_UNSUPPORTED, "mrh_integrate_points: variance-adaptive resolution on LiDAR scans (reintegrate3D) is outside this round's scope");
-  if (!c->p.projective_sdf) return fail(c, MRH_ERR_UNSUPPORTED, "mrh_integrate_points: normal-direction SDF needs normals, which this boundary does not carry");
   const uint64_t n = c->num_points;
+  if (!c->p.projective_sdf && c->num_normals != n)
+    return fail(c, MRH_ERR_STATE, "mrh_integrate_points: the normal-direction SDF needs one normal per point (mrh_upload_normals)");
   if (n >= (1ull << 24)) return fail(c, MRH_ERR_CAPACITY, "mrh_integrate_points: %llu points in one scan (limit 2^24 - 1)", (unsigned long long) n);
   hipStream_t s = c->stream;
   const Cam& k = c->cam;
@@ -1146,11 +1189,19 @@ int mrh_integrate_points(mrh_ctx* c, int n_frames_invalidate) {
   rc = maintain_table(c, false);
   if (rc) return rc;
   c->frames_since_census++;
+  c->frame_general = true;  // GC (and the starve step) of a scan run through the general kernels on the list of ALL live blocks
+  c->frame_fused_mr = false;
+  if (t.multi_res) { c->mr_summaries_valid = false; c->mr_next_general = true; c->refill_flag_valid = false; }
+  const float* normals = c->p.projective_sdf ? nullptr : c->d_normals;
   if (n > 0) {
     const u32 np = (u32) n, grid = (np + 255) / 256;
     const float* pts = c->d_points_cur;
     const u32 stamp = (u32) ((c->frames + 1) & 0x3FFFFFFFu);
-    k_alloc3d<<<grid, 256, 0, s>>>(k, m, t, c->fast, pts, np, stamp);
+    if (t.multi_res) {  // vds.cu:1048-1054: coarse free-list refill, decided on the device
+      k_refill_decide<<<1, 64, 0, s>>>(t, c->low_blocks_to_allocate, c->d_flag);
+      k_refill<<<(c->low_blocks_to_allocate + 255) / 256, 256, 0, s>>>(t, c->low_blocks_to_allocate, c->d_flag);
+    }
+    k_alloc3d<<<grid, 256, 0, s>>>(k, m, t, c->fast, pts, normals, np, stamp);
     if (n > c->pt_cap) {
       HIP_TRY(c, hipStreamSynchronize(s));
       if (c->d_pt_counts) HIP_TRY(c, hipFree(c->d_pt_counts));
@@ -1160,9 +1211,6 @@ int mrh_integrate_points(mrh_ctx* c, int n_frames_invalidate) {
       HIP_TRY(c, hipMalloc((void**) &c->d_pt_offsets, n * sizeof(u32)));
       c->pt_cap = n;
     }
-    k_points_walk<false><<<grid, 256, 0, s>>>(k, m, t, pts, np, c->d_pt_counts, nullptr, nullptr, nullptr, 0);
-    size_t need = 0;
-    HIP_TRY(c, rocprim::exclusive_scan(nullptr, need, c->d_pt_counts, c->d_pt_offsets, 0u, n, rocprim::plus<u32>(), s));
     auto ensure_tmp = [&](size_t bytes) -> int {
       if (bytes <= c->sort_tmp_bytes) return MRH_OK;
       HIP_TRY(c, hipStreamSynchronize(s));
@@ -1172,19 +1220,24 @@ int mrh_integrate_points(mrh_ctx* c, int n_frames_invalidate) {
       c->sort_tmp_bytes = bytes;
       return MRH_OK;
     };
-    rc = ensure_tmp(need);
-    if (rc) return rc;
-    size_t tb = c->sort_tmp_bytes;
-    HIP_TRY(c, rocprim::exclusive_scan(c->d_sort_tmp, tb, c->d_pt_counts, c->d_pt_offsets, 0u, n, rocprim::plus<u32>(), s));
-    u32 last_off = 0, last_cnt = 0;
-    int hwm = 0;
-    HIP_TRY(c, hipMemcpyAsync(&hwm, &t.ctr[CTR_HWM_FINE], sizeof(int), hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipMemcpyAsync(&last_off, c->d_pt_offsets + (n - 1), sizeof(u32), hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipMemcpyAsync(&last_cnt, c->d_pt_counts + (n - 1), sizeof(u32), hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipStreamSynchronize(s));
-    const uint64_t n_rec = (uint64_t) last_off + last_cnt;
-    if (n_rec >= 0xFFFFFFF0ull) return fail(c, MRH_ERR_CAPACITY, "mrh_integrate_points: %llu voxel updates in one scan", (unsigned long long) n_rec);
-    if (n_rec > 0) {
+    // integrate3D (vds.cu:1215-1410): records of every (point, voxel) -> sorted by voxel, stable in the point index -> folded
+    auto integrate_scan = [&]() -> int {
+      k_points_walk<false><<<grid, 256, 0, s>>>(k, m, t, pts, normals, np, c->d_pt_counts, nullptr, nullptr, nullptr, 0);
+      size_t need = 0;
+      HIP_TRY(c, rocprim::exclusive_scan(nullptr, need, c->d_pt_counts, c->d_pt_offsets, 0u, n, rocprim::plus<u32>(), s));
+      int r = ensure_tmp(need);
+      if (r) return r;
+      size_t tb = c->sort_tmp_bytes;
+      HIP_TRY(c, rocprim::exclusive_scan(c->d_sort_tmp, tb, c->d_pt_counts, c->d_pt_offsets, 0u, n, rocprim::plus<u32>(), s));
+      u32 last_off = 0, last_cnt = 0;
+      int hwm = 0;
+      HIP_TRY(c, hipMemcpyAsync(&hwm, &t.ctr[CTR_HWM_FINE], sizeof(int), hipMemcpyDeviceToHost, s));
+      HIP_TRY(c, hipMemcpyAsync(&last_off, c->d_pt_offsets + (n - 1), sizeof(u32), hipMemcpyDeviceToHost, s));
+      HIP_TRY(c, hipMemcpyAsync(&last_cnt, c->d_pt_counts + (n - 1), sizeof(u32), hipMemcpyDeviceToHost, s));
+      HIP_TRY(c, hipStreamSynchronize(s));
+      const uint64_t n_rec = (uint64_t) last_off + last_cnt;
+      if (n_rec >= 0xFFFFFFF0ull) return fail(c, MRH_ERR_CAPACITY, "mrh_integrate_points: %llu voxel updates in one scan", (unsigned long long) n_rec);
+      if (n_rec == 0) return MRH_OK;
       if (n_rec > c->rec_cap) {
         for (int b = 0; b < 2; b++) {
           if (c->d_rec_keys[b]) HIP_TRY(c, hipFree(c->d_rec_keys[b]));
@@ -1206,22 +1259,43 @@ int mrh_integrate_points(mrh_ctx* c, int n_frames_invalidate) {
       using LidarSortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 0>;
       auto bits_for = [](uint64_t max_value) { int b = 1; while (b < 63 && (max_value >> b)) b++; return b; };
       const int pbits = bits_for(n - 1);
-      const int end_bit = pbits + bits_for((uint64_t) (hwm > 0 ? hwm : 1) * 512 - 1);
-      k_points_walk<true><<<grid, 256, 0, s>>>(k, m, t, pts, np, nullptr, c->d_pt_offsets, c->d_rec_keys[0], c->d_rec_vals[0], pbits);
+      const int end_bit = pbits + (t.multi_res ? 38 : bits_for((uint64_t) (hwm > 0 ? hwm : 1) * 512 - 1));  // coarse flag: bit 37 of the voxel id
+      k_points_walk<true><<<grid, 256, 0, s>>>(k, m, t, pts, normals, np, nullptr, c->d_pt_offsets, c->d_rec_keys[0], c->d_rec_vals[0], pbits);
       need = 0;
       HIP_TRY(c, rocprim::radix_sort_pairs<LidarSortConfig>(nullptr, need, c->d_rec_keys[0], c->d_rec_keys[1], c->d_rec_vals[0], c->d_rec_vals[1], n_rec, pbits, end_bit, s));
-      rc = ensure_tmp(need);
-      if (rc) return rc;
+      r = ensure_tmp(need);
+      if (r) return r;
       tb = c->sort_tmp_bytes;
       HIP_TRY(c, rocprim::radix_sort_pairs<LidarSortConfig>(c->d_sort_tmp, tb, c->d_rec_keys[0], c->d_rec_keys[1], c->d_rec_vals[0], c->d_rec_vals[1], n_rec, pbits, end_bit, s));
       k_points_apply<<<(u32) ((n_rec + 255) / 256), 256, 0, s>>>(m, t, c->d_rec_keys[1], c->d_rec_vals[1], (u32) n_rec, pbits);
+      return MRH_OK;
+    };
+    rc = integrate_scan();
+    if (rc) return rc;
+    if (t.multi_res && c->frames > 0) {
+      // checkVarSDF -> reallocBlocks -> flatAndReduceHashTable() -> reintegrate3D, which launches integrate3DKernel again
+      // (vds.cu:1561-1580): the whole scan a second time, into fine and coarse blocks alike
+      HIP_TRY(c, hipMemsetAsync(&t.ctr[CTR_COMPACT], 0, sizeof(int), s));
+      k_compact<<<512, 256, 0, s>>>(k, m, t, 0);
+      HIP_TRY(c, hipMemsetAsync(&t.ctr[CTR_NREALLOC], 0, 2 * sizeof(int), s));  // NREALLOC, NREINT
+      k_check_var<<<2048, 64, 0, s>>>(m, t, c->d_realloc);
+      k_realloc<<<64, 256, 0, s>>>(t, c->d_realloc, c->d_reint);
+      rc = integrate_scan();
+      if (rc) return rc;
     }
-    // the GC summaries (used by later depth frames for blocks outside the image) follow the payload
-    k_summarize_all<<<1024, 256, 0, s>>>(t, c->fast);
   }
-  c->frames++;
+  if (max_num_frames > 0) {  // flatAndReduceHashTable() without a camera: every live block (voxel_data_structures.cpp:121, :126)
+    HIP_TRY(c, hipMemsetAsync(&t.ctr[CTR_COMPACT], 0, sizeof(int), s));
+    k_compact<<<512, 256, 0, s>>>(k, m, t, 0);
+  }
+  rc = starve_and_tail(c, max_num_frames);  // garbageCollect(camera, max_num_frames); counts the frame
+  if (rc < 0) return rc;
   HIP_TRY(c, hipGetLastError());
-  return c->peek_enabled ? mark_frame(c) : MRH_OK;  // pool-level report for mrh_peek_free_blocks
+  if (c->peek_enabled) {
+    const int mrc = mark_frame(c);  // pool-level report for mrh_peek_free_blocks
+    if (mrc) return mrc;
+  }
+  return rc;
 }
 
 int mrh_integrate_resume(mrh_ctx* c) {
@@ -1292,7 +1366,7 @@ int mrh_splat_seeds(mrh_ctx* c, float qtree_thresh, int qtree_min_pixel_size, co
   if (qt.total != c->qt.total || !c->d_qt_sums) {
     HIP_TRY(c, hipStreamSynchronize(s));
     auto F = [](auto*& p) { if (p) (void) hipFree(p); p = nullptr; };
-    F(c->d_pack); F(c->d_halo); F(c->d_taken);
+    F(c->d_pack); F(c->d_halo); F(c->d_taken); F(c->d_cloud); F(c->d_normals);
   for (hipEvent_t e : c->mc_ev) if (e) (void) hipEventDestroy(e);
   F(c->d_qt_sums); F(c->d_qt_flags); F(c->d_qt_unc); F(c->d_qt_marks); F(c->d_qt_pos); F(c->d_qt_parked); F(c->d_qt_seeds); F(c->d_qt_leaves); F(c->d_qt_misc);
     const size_t n = qt.total;

@@ -13,6 +13,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "../../include/mrh_softmath.h"
+
 namespace mrh {
 
 typedef unsigned long long u64;
@@ -70,6 +72,7 @@ struct Cam {
   float min_depth, max_depth, max_int_dist;
   float R[9], t[3];    // camera in world
   float Ri[9], ti[3];  // world in camera = (R^T, -(R^T t))   cuda_algebra.cuh:137-143
+  int model;           // 0 pinhole, 1 spherical (camera.cuh:9); the two-launch fast path is pinhole-only
 };
 
 struct Map {
@@ -332,14 +335,30 @@ __device__ __forceinline__ u32 voxel_local_index(i3 v, int res) {
 
 // ---- camera (pinhole): camera.cuh:84-203 ----------------------------------------------------------
 
-// camera.cuh:88
+// camera.cuh:88 (pinhole: what the two-launch fast path is specialised for)
 __device__ __forceinline__ f3 inverse_projection(const Cam& c, u32 row, u32 col, float d) {
   return mk3(d * (c.ifx * ((float) col - c.cx - 0.5f)), d * (c.ify * ((float) row - c.cy - 0.5f)), d * 1.f);
+}
+// camera.cuh:84-103, either model (the general kernels).  Spherical: sinf / cosf through the one implementation shared
+// with the oracle (mrh_softmath.h, D8)
+__device__ __forceinline__ f3 inverse_projection_m(const Cam& c, u32 row, u32 col, float d) {
+  if (c.model == 0) return inverse_projection(c, row, col, d);
+  const float az = c.ifx * ((float) col - c.cx - 0.5f);
+  const float el = c.ify * ((float) row - c.cy - 0.5f);
+  float s0, c0, s1, c1;
+  mrh_sincosf(az, &s0, &c0);
+  mrh_sincosf(el, &s1, &c1);
+  return mk3(d * (c0 * c1), d * (s0 * c1), d * s1);
+}
+// camera.cuh:120-129 getDepth
+__device__ __forceinline__ float get_depth(const Cam& c, f3 p) {
+  if (c.model == 0) return p.z;
+  return sqrtf(p.x * p.x + p.y * p.y + p.z * p.z);
 }
 
 // camera.cuh:131-147 (exact image bounds) / :167-182 (bounds enlarged by half the image, APPROX)
 template <bool APPROX>
-__device__ __forceinline__ bool project_point(const Cam& c, f3 pc, int& row, int& col) {
+__device__ __forceinline__ bool project_point(const Cam& c, f3 pc, int& row, int& col) {  // pinhole
   if (pc.z <= c.min_depth || pc.z > c.max_depth) return false;
   row = f2i((c.fy * pc.y / pc.z + c.cy) + 0.5f);
   col = f2i((c.fx * pc.x / pc.z + c.cx) + 0.5f);
@@ -347,9 +366,25 @@ __device__ __forceinline__ bool project_point(const Cam& c, f3 pc, int& row, int
     return row >= -c.row_thr && col >= -c.col_thr && row < (c.rows + c.row_thr) && col < (c.cols + c.col_thr);
   return row >= 0 && col >= 0 && row < c.rows && col < c.cols;
 }
+template <bool APPROX>
+__device__ __forceinline__ bool project_point_m(const Cam& c, f3 pc, int& row, int& col) {  // either model
+  if (c.model == 0) {
+    return project_point<APPROX>(c, pc, row, col);
+  } else {  // camera.cuh:147-164 / :184-201
+    const float range = sqrtf(pc.x * pc.x + pc.y * pc.y + pc.z * pc.z);
+    if (range < c.min_depth || range > c.max_depth) return false;
+    const float px = mrh_atan2f(pc.y, pc.x);
+    const float py = mrh_asinf(pc.z / range);
+    row = f2i((c.fy * py + c.cy) + 0.5f);
+    col = f2i((c.fx * px + c.cx) + 0.5f);
+  }
+  if (APPROX)
+    return row >= -c.row_thr && col >= -c.col_thr && row < (c.rows + c.row_thr) && col < (c.cols + c.col_thr);
+  return row >= 0 && col >= 0 && row < c.rows && col < c.cols;
+}
 
 // vds.cu:66-77 isSDFBlockInCameraFrustumApprox: any of the 8 corner voxels (offsets 0 / 7, params.h:41-49)
-__device__ __forceinline__ bool block_in_frustum_approx(const Cam& c, float vs, i3 b) {
+__device__ __forceinline__ bool block_in_frustum_approx(const Cam& c, float vs, i3 b) {  // pinhole
 #pragma unroll 1
   for (int i = 0; i < 8; i++) {
     // params.h:41-49 order: z toggles fastest, then y, then x
@@ -357,6 +392,16 @@ __device__ __forceinline__ bool block_in_frustum_approx(const Cam& c, float vs, 
     const f3 pc = se3_apply(c.Ri, c.ti, voxel_to_world(vs, v));
     int r, cc;
     if (project_point<true>(c, pc, r, cc)) return true;
+  }
+  return false;
+}
+__device__ __forceinline__ bool block_in_frustum_approx_m(const Cam& c, float vs, i3 b) {  // either model
+#pragma unroll 1
+  for (int i = 0; i < 8; i++) {
+    const i3 v = mki3(b.x * kBlockSide + ((i & 4) ? 7 : 0), b.y * kBlockSide + ((i & 2) ? 7 : 0), b.z * kBlockSide + ((i & 1) ? 7 : 0));
+    const f3 pc = se3_apply(c.Ri, c.ti, voxel_to_world(vs, v));
+    int r, cc;
+    if (project_point_m<true>(c, pc, r, cc)) return true;
   }
   return false;
 }

@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void k_alloc(const Cam c, const Map m, const T
   auto visit_global = [&](i3 b, u64 key, bool active) {
     bool won = false;
     int slot = -1;
-    if (active && block_in_frustum_approx(c, m.vs, b)) {
+    if (active && block_in_frustum_approx_m(c, m.vs, b)) {
       slot = hash_insert(t, key);
       if (slot == -2) atomicOr((u32*) &t.ctr[CTR_ERROR], ERR_TABLE);
       won = slot >= 0;
@@ -84,8 +84,9 @@ __global__ __launch_bounds__(256) void k_alloc(const Cam c, const Map m, const T
   float d = 0.f;
   if (in_img) {
     d = depth[(size_t) row * c.cols + col];
-    // camera.cu:13-18: cloud stays 0 outside (min_depth, max_depth]; pinhole cloud.z == d
-    if (d <= c.min_depth || d > c.max_depth) d = 0.f;
+    // camera.cu:13-18: cloud stays 0 outside (min_depth, max_depth]; pinhole cloud.z == d.  Spherical: `depth` is the
+    // pre-computed getDepth(cloud) image (k_cloud_depth), already 0 where the raw depth is out of range
+    if (c.model == 0 && (d <= c.min_depth || d > c.max_depth)) d = 0.f;
   }
   // vds.cu:771-781
   const float tr = get_truncation(d, m.trunc, m.trunc_scale);
@@ -93,8 +94,8 @@ __global__ __launch_bounds__(256) void k_alloc(const Cam c, const Map m, const T
   const float dmax = fminf(c.max_int_dist, d + tr);
   const bool walk = in_img && !(d == 0.f) && !(dmin >= dmax);
   if (walk) {
-    const f3 pw_min = se3_apply(c.R, c.t, inverse_projection(c, (u32) row, (u32) col, dmin));
-    const f3 pw_max = se3_apply(c.R, c.t, inverse_projection(c, (u32) row, (u32) col, dmax));
+    const f3 pw_min = se3_apply(c.R, c.t, inverse_projection_m(c, (u32) row, (u32) col, dmin));
+    const f3 pw_max = se3_apply(c.R, c.t, inverse_projection_m(c, (u32) row, (u32) col, dmax));
     const f3 dd = mk3(pw_max.x - pw_min.x, pw_max.y - pw_min.y, pw_max.z - pw_min.z);
     const float inv_len = 1.0f / sqrtf(dd.x * dd.x + dd.y * dd.y + dd.z * dd.z);  // normalize, cuda_math.cuh:1075-1078
     const f3 dir = mk3(dd.x * inv_len, dd.y * inv_len, dd.z * inv_len);
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(256) void k_alloc(const Cam c, const Map m, const T
         }
         if (!placed) {
           // set saturated (far, sparse rays): go to the global table directly, un-aggregated
-          if (block_in_frustum_approx(c, m.vs, cur)) {
+          if (block_in_frustum_approx_m(c, m.vs, cur)) {
             const int slot = hash_insert(t, key);
             if (slot == -2) atomicOr((u32*) &t.ctr[CTR_ERROR], ERR_TABLE);
             if (slot >= 0) {
@@ -185,6 +186,17 @@ __global__ __launch_bounds__(256) void k_alloc(const Cam c, const Map m, const T
   }
 }
 
+// spherical camera: getDepth(cloud) per pixel (camera.cu:5-19 + camera.cuh:120-129) = the norm of the back-projected
+// point, 0 where the raw depth is outside (min_depth, max_depth] — what every later kernel of the frame reads as "depth"
+__global__ __launch_bounds__(256) void k_cloud_depth(const Cam c, const float* __restrict__ depth, float* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= c.rows * c.cols) return;
+  const float d = depth[i];
+  float r = 0.f;
+  if (!(d <= c.min_depth || d > c.max_depth)) r = get_depth(c, inverse_projection(c, (u32) (i / c.cols), (u32) (i % c.cols), d));
+  out[i] = r;
+}
+
 // =====================================================================================================
 // K2  frustum compaction of the live blocks   (reference: resetCompactHashTableKernel vds.cu:9-14 +
 //     flatAndReduceHashTableKernel :406-434/:452-480, both O(hash slots) = 2 x 24 B x 10 x buckets per frame)
@@ -203,7 +215,7 @@ __global__ __launch_bounds__(256) void k_compact(const Cam c, const Map m, const
     if (i < total) {
       if (i < hwm) { d = t.desc_fine[i]; val = (u32) i; }
       else { const u32 u = (u32) (i - hwm); d = t.desc_coarse[u]; val = u | kValCoarseBit; }
-      if (d.w & 1) keep = !use_camera || block_in_frustum_approx(c, m.vs, mki3(d.x, d.y, d.z));  // bit 0 = live (upper bits: insertion stamp)
+      if (d.w & 1) keep = !use_camera || block_in_frustum_approx_m(c, m.vs, mki3(d.x, d.y, d.z));  // bit 0 = live (upper bits: insertion stamp)
     }
     const u64 ballot = __ballot(keep);
     if (ballot) {
@@ -239,11 +251,11 @@ __device__ __forceinline__ bool integrate_voxel(const Cam& c, const Map& m, cons
   const f3 pf = voxel_to_world(m.vs, pi);
   const f3 pcam = se3_apply(c.Ri, c.ti, pf);
   int row, col;
-  if (!project_point<false>(c, pcam, row, col)) return false;
+  if (!project_point_m<false>(c, pcam, row, col)) return false;
   float d = depth[(size_t) row * c.cols + col];
-  if (d <= c.min_depth || d > c.max_depth) d = 0.f;  // camera.cu:13-18 (cloud z)
+  if (c.model == 0 && (d <= c.min_depth || d > c.max_depth)) d = 0.f;  // camera.cu:13-18 (cloud z); spherical: see k_cloud_depth
   if (d == 0.f || d > c.max_int_dist) return false;
-  float sdf = d - pcam.z;
+  float sdf = d - get_depth(c, pcam);
   const float truncation = get_truncation(d, m.trunc, m.trunc_scale);
   if (sdf <= -truncation) return false;
   if (sdf >= 0.f) sdf = fminf(truncation, sdf);
@@ -435,10 +447,10 @@ __global__ __launch_bounds__(512) void k_starve(const Cam c, const Map m, const 
     // fine delinearisation for every block, as the reference does (vds.cu:1606-1607)
     const i3 pi = mki3(ent.x * kBlockSide + (v & 7), ent.y * kBlockSide + ((v >> 3) & 7), ent.z * kBlockSide + (v >> 6));
     const f3 pcam = se3_apply(c.Ri, c.ti, voxel_to_world(m.vs, pi));
-    const float dep = pcam.z;
+    const float dep = get_depth(c, pcam);
     if (dep < c.min_depth) continue;
     int row, col;
-    if (!project_point<false>(c, pcam, row, col)) continue;
+    if (!project_point_m<false>(c, pcam, row, col)) continue;
     u64 key;
     pack_key(mki3(ent.x, ent.y, ent.z), key);
     const u64 hi = ((u64) __float_as_uint(dep) << 32) | (key >> 31);                 // top 32 bits of the 72-bit (key63<<9 | v)

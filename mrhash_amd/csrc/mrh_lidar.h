@@ -1,6 +1,7 @@
 // mrh_lidar.h — LiDAR scans: VoxelContainer::integrate(point_cloud, normals, weights, camera, max_num_frames)
-// (voxel_data_structures.cpp:112-135) for the shipped LiDAR configurations (projective SDF, no normals, no GC, single
-// resolution; include/mrhash_hip.h states the scope).
+// (voxel_data_structures.cpp:112-135): projective or normal-direction SDF (one caller-supplied normal per point), fine and
+// coarse blocks (variance-adaptive maps re-integrate the scan after coarsening, vds.cu:1561-1580); garbage collection
+// and the starve step run through the general kernels (mrh_kernels.h) on the list of all live blocks.
 //
 //   k_alloc3d        allocBlocks3DKernel vds.cu:925-1033 + the host retry loop :1036-1092.  256 points per workgroup:
 //                    block-level DDA over the segment range -+ truncation along the beam, keys de-duplicated in an LDS
@@ -31,8 +32,10 @@ __device__ __forceinline__ i3 voxel_to_block_fast(const Map& m, const i3 v) {
   return voxel_to_block(v, m.vs);
 }
 
+constexpr u64 kVidCoarse = 1ull << 37;  // record key: voxel id = fine block index * 512 + local index (< 2^37), this bit = coarse unit
+
 __global__ __launch_bounds__(256) void k_alloc3d(const Cam c, const Map m, const Tab t, const Fast f, const float* __restrict__ pts,
-                                                 const u32 n, const u32 stamp) {
+                                                 const float* __restrict__ normals, const u32 n, const u32 stamp) {
   __shared__ FrontShared sh;
   constexpr int NT = 256;
   const int tid = threadIdx.x;
@@ -53,7 +56,8 @@ __global__ __launch_bounds__(256) void k_alloc3d(const Cam c, const Map m, const
     const float tr = get_truncation(range, m.trunc, m.trunc_scale);
     const float dmin = fminf(c.max_int_dist, range - tr), dmax = fminf(c.max_int_dist, range + tr);
     if (range != 0.f && !(dmin >= dmax)) {
-      const f3 dir = normalize3(pcam);
+      // vds.cu:957-962: along the beam (projective SDF) or along the point's normal
+      const f3 dir = normals ? normalize3(mk3(normals[3 * (size_t) i], normals[3 * (size_t) i + 1], normals[3 * (size_t) i + 2])) : normalize3(pcam);
       const float a = dmin - range, b = dmax - range;
       const f3 pw_min = se3_apply(c.R, c.t, mk3(pcam.x + dir.x * a, pcam.y + dir.y * a, pcam.z + dir.z * a));
       const f3 pw_max = se3_apply(c.R, c.t, mk3(pcam.x + dir.x * b, pcam.y + dir.y * b, pcam.z + dir.z * b));
@@ -121,12 +125,14 @@ __global__ __launch_bounds__(256) void k_alloc3d(const Cam c, const Map m, const
 
 // One record per (point, traversed voxel of an allocated block) up to the first voxel with sdf <= -truncation.
 // EMIT = false: counts[i] = number of records of point i.  EMIT = true: records written at offsets[i]...
-//   key = (block index * 512 + voxel index) << pbits | point index     value = the clamped sdf
-// (pbits = bits needed for the point index: the sort then only has to look at pbits + bits(live voxels) key bits)
+//   key = voxel id << pbits | point index     value = the clamped sdf
+//   voxel id = fine block index * 512 + local index; on a coarse unit u = 8 H + k: H * 512 + k * 64 + local index, | kVidCoarse
+// (pbits = bits needed for the point index: the sort then only has to look at pbits + bits(voxel id) key bits)
 template <bool EMIT>
-__global__ __launch_bounds__(256) void k_points_walk(const Cam c, const Map m, const Tab t, const float* __restrict__ pts, const u32 n,
-                                                     u32* __restrict__ counts, const u32* __restrict__ offsets, u64* __restrict__ keys,
-                                                     float* __restrict__ vals, const int pbits) {
+__global__ __launch_bounds__(256) void k_points_walk(const Cam c, const Map m, const Tab t, const float* __restrict__ pts,
+                                                     const float* __restrict__ normals, const u32 n, u32* __restrict__ counts,
+                                                     const u32* __restrict__ offsets, u64* __restrict__ keys, float* __restrict__ vals,
+                                                     const int pbits) {
   const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   u32 cnt = 0;
@@ -137,8 +143,19 @@ __global__ __launch_bounds__(256) void k_points_walk(const Cam c, const Map m, c
   const float dmin = fminf(c.max_int_dist, range - tr), dmax = fminf(c.max_int_dist, range + tr);
   if (!((double) range < 1e-6 || range > c.max_int_dist) && !(dmin >= dmax)) {
     const f3 dir0 = normalize3(pcam);
-    const f3 pw_min = se3_apply(c.R, c.t, mk3(pcam.x - dir0.x * tr, pcam.y - dir0.y * tr, pcam.z - dir0.z * tr));
-    const f3 pw_max = se3_apply(c.R, c.t, mk3(pcam.x + dir0.x * tr, pcam.y + dir0.y * tr, pcam.z + dir0.z * tr));
+    f3 norm_dir = mk3(0.f, 0.f, 0.f);
+    f3 pc_min, pc_max;
+    if (!normals) {  // projective (vds.cu:1245-1247)
+      pc_min = mk3(pcam.x - dir0.x * tr, pcam.y - dir0.y * tr, pcam.z - dir0.z * tr);
+      pc_max = mk3(pcam.x + dir0.x * tr, pcam.y + dir0.y * tr, pcam.z + dir0.z * tr);
+    } else {         // along the normal (vds.cu:1248-1251)
+      norm_dir = normalize3(mk3(normals[3 * (size_t) i], normals[3 * (size_t) i + 1], normals[3 * (size_t) i + 2]));
+      const float a = dmin - range, b = dmax - range;
+      pc_min = mk3(pcam.x + norm_dir.x * a, pcam.y + norm_dir.y * a, pcam.z + norm_dir.z * a);
+      pc_max = mk3(pcam.x + norm_dir.x * b, pcam.y + norm_dir.y * b, pcam.z + norm_dir.z * b);
+    }
+    const f3 pw_min = se3_apply(c.R, c.t, pc_min);
+    const f3 pw_max = se3_apply(c.R, c.t, pc_max);
     // voxel-level DDA (vds.cu:1257-1296)
     const f3 dir = normalize3(mk3(pw_max.x - pw_min.x, pw_max.y - pw_min.y, pw_max.z - pw_min.z));
     i3 cur = world_to_voxel(m.vs, pw_min);
@@ -163,15 +180,26 @@ __global__ __launch_bounds__(256) void k_points_walk(const Cam c, const Map m, c
       u64 bkey;
       int slot = -1;
       if (pack_key(block, bkey)) slot = hash_find(t, bkey);
-      const u32 H = slot >= 0 ? t.vals[slot] : kValNone;
-      if (H != kValNone) {
-        const f3 pc = se3_apply(c.Ri, c.ti, voxel_to_world(m.vs, cur));
-        float sdf = range - norm3(pc);
+      const u32 val = slot >= 0 ? t.vals[slot] : kValNone;
+      if (val != kValNone) {
+        const int res = (val & kValCoarseBit) ? 1 : 0;
+        const int scale = 1 << res;
+        // vds.cu:1303-1309: the voxel the SDF is measured at — on a coarse block the fine coordinate divided by 2 with C's
+        // truncation toward zero, times the coarse voxel size (kept literally, negative coordinates included)
+        const i3 aprox = mki3(cur.x / scale, cur.y / scale, cur.z / scale);
+        const f3 pc = se3_apply(c.Ri, c.ti, voxel_to_world(m.vs * (float) scale, aprox));
+        float sdf;
+        if (!normals) sdf = range - norm3(pc);
+        else sdf = ((pc.x - pcam.x) * norm_dir.x + (pc.y - pcam.y) * norm_dir.y) + (pc.z - pcam.z) * norm_dir.z;
         if (sdf <= -tr) break;
         if (sdf >= 0.f) sdf = fminf(tr, sdf);
         else sdf = fmaxf(-tr, sdf);
         if (EMIT) {
-          keys[out + cnt] = (((u64) H * 512u + voxel_local_index(cur, 0)) << pbits) | (u64) i;  // 64-bit: pools beyond 2^23 blocks
+          const u32 li = voxel_local_index(cur, res);
+          u64 vid;
+          if (res) { const u32 u = val & ~kValCoarseBit; vid = ((u64) (u >> 3) * 512u + (u64) (u & 7u) * 64u + li) | kVidCoarse; }
+          else vid = (u64) val * 512u + li;
+          keys[out + cnt] = (vid << pbits) | (u64) i;
           vals[out + cnt] = sdf;
         }
         cnt++;
@@ -196,11 +224,19 @@ __global__ __launch_bounds__(256) void k_points_apply(const Map m, const Tab t, 
   if (j >= n_rec) return;
   const u64 vid = keys[j] >> pbits;
   if (j > 0 && (keys[j - 1] >> pbits) == vid) return;
-  const u32 H = (u32) (vid >> 9), li = (u32) (vid & 511u);
+  const u64 id = vid & (kVidCoarse - 1);
+  const u32 H = (u32) (id >> 9);
   char* base = t.pool + (size_t) H * kFineBytes;
-  float* p_sdf = (float*) base + li;
-  float* p_ss = (float*) (base + 2048) + li;
-  u32* p_rgbw = (u32*) (base + 4096) + li;
+  float *p_sdf, *p_ss;
+  u32* p_rgbw;
+  if (vid & kVidCoarse) {
+    const u32 k = (u32) (id >> 6) & 7u, li = (u32) (id & 63u);
+    base += (size_t) k * kCoarseBytes;
+    p_sdf = (float*) base + li; p_ss = (float*) (base + 256) + li; p_rgbw = (u32*) (base + 512) + li;
+  } else {
+    const u32 li = (u32) (id & 511u);
+    p_sdf = (float*) base + li; p_ss = (float*) (base + 2048) + li; p_rgbw = (u32*) (base + 4096) + li;
+  }
   float s0 = *p_sdf, ss = *p_ss;
   u32 rgbw = *p_rgbw;
   const u32 w1 = (u32) (m.weight_sample & 0xFF), wmax = (u32) (m.weight_max & 0xFF);

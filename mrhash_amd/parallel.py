@@ -87,6 +87,13 @@ def _bytes_view(ptr: int, nbytes: int, on_device: bool):
     return torch.from_numpy(np.ctypeslib.as_array((ctypes.c_uint8 * nbytes).from_address(ptr)))
 
 
+def _force_collectives() -> bool:
+    """MRH_FORCE_COLLECTIVES=1: run every collective even in a one-rank group.  A 1-GPU box cannot host two RCCL ranks
+    (RCCL refuses duplicate GPUs), so this is how the nccl branches — device buffers of the library handed to RCCL and
+    back — get executed there (tests/test_sharding_gpu.py)."""
+    return os.environ.get("MRH_FORCE_COLLECTIVES") == "1"
+
+
 def _comm_device(dist):
     import torch
 
@@ -120,7 +127,7 @@ def integrate(engine: capi.Engine, dist=None, n_frames_invalidate: int = -1):
     pending = engine.integrate(n_frames_invalidate)
     while pending:
         ptr, n, on_device = engine.exchange_buffer()
-        if dist is not None and dist.get_world_size() > 1:
+        if dist is not None and (dist.get_world_size() > 1 or _force_collectives()):
             if on_device:
                 t = torch.as_tensor(_DeviceArray(ptr, n), device="cuda")
                 if dist.get_backend() == "nccl":
@@ -159,7 +166,7 @@ def exchange_halo(engine: capi.Engine, dist) -> int:
     import torch
 
     world, rank = dist.get_world_size(), dist.get_rank()
-    if world == 1:
+    if world == 1 and not _force_collectives():
         return 0
     dev = _comm_device(dist)
     ptr, n, on_device = engine.pack_blocks(capi.PACK_HALO)
@@ -198,7 +205,7 @@ def merge_submaps(engine: capi.Engine, dist, chunk_log2: int = 3) -> dict:
 
     world, rank = dist.get_world_size(), dist.get_rank()
     engine.set_sharding(rank, world, chunk_log2)
-    if world == 1:
+    if world == 1 and not _force_collectives():
         return {"sent": 0, "received": 0, "bytes": 0}
     dev = _comm_device(dist)
     parts, out_counts = [], []

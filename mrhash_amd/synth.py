@@ -238,6 +238,33 @@ def lidar_scan(scene: Scene, t: np.ndarray, q: np.ndarray, rows: int = 32, cols:
     return pts.astype(np.float32)
 
 
+def scan_normals(pts: np.ndarray) -> np.ndarray:
+    """A normal per point of a scan, oriented towards the sensor (what the reference's MAD-tree hands out,
+    geowrapper.cpp:386-388): here simply the reversed beam direction tilted by a fixed, point-dependent amount — a
+    deterministic stand-in, not an estimator (estimating normals is the caller's business, include/mrhash_hip.h)."""
+    p = pts.astype(np.float64)
+    r = np.linalg.norm(p, axis=1, keepdims=True)
+    n = -p / np.maximum(r, 1e-9)
+    tilt = np.stack([np.sin(0.7 * p[:, 1]), np.cos(1.3 * p[:, 0]), np.sin(0.9 * p[:, 2] + 0.4)], axis=1) * 0.35
+    n = n + tilt
+    n /= np.maximum(np.linalg.norm(n, axis=1, keepdims=True), 1e-9)
+    n[r[:, 0] == 0] = 0.0
+    return n.astype(np.float32)
+
+
+def spherical_range_image(scene: Scene, t: np.ndarray, q: np.ndarray, cam: dict) -> Tuple[np.ndarray, np.ndarray]:
+    """Range image [rows, cols] float32 + colours for the spherical camera model (camera.cuh:91-99): pixel (row, col) looks
+    along azimuth (col - cx - 0.5) / fx, elevation (row - cy - 0.5) / fy; the value is the range along that ray."""
+    rows, cols = cam["rows"], cam["cols"]
+    az = (np.arange(cols, dtype=np.float64) - cam["cx"] - 0.5) / cam["fx"]
+    el = (np.arange(rows, dtype=np.float64) - cam["cy"] - 0.5) / cam["fy"]
+    ce, se = np.cos(el)[:, None], np.sin(el)[:, None]
+    d = np.stack([ce * np.cos(az)[None, :], ce * np.sin(az)[None, :], np.broadcast_to(se, (rows, cols))], axis=-1)
+    rng_len, pts = scene.cast_dirs(d, quat_to_rot(q), t)
+    rng_len = np.where(np.isfinite(rng_len) & (rng_len > 0), rng_len, 0.0)
+    return rng_len.astype(np.float32), scene.color(pts)
+
+
 VBR_PARAMS = dict(  # mrhash/configurations/vbr.cfg
     sdf_truncation=0.40, sdf_truncation_scale=0.0, integration_weight_sample=1, virtual_voxel_size=0.20,
     n_frames_invalidate_voxels=0, voxel_extents_scale=1, marching_cubes_threshold=1.5, min_weight_threshold=50,

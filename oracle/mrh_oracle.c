@@ -115,6 +115,8 @@ struct mrh_ctx {
   int depth_rows, depth_cols, rgb_rows, rgb_cols;
   float* points;       /* sensor-frame xyz of the current scan (GeoWrapper::setPointCloud, geowrapper.cpp:345-405) */
   uint64_t num_points;
+  float* normals;      /* one normal per point (mrh_upload_normals), NULL: none */
+  uint64_t num_normals;
   f3* cloud;
   /* container: voxel_data_structures.cuh:63-100 */
   unsigned num_sdf_blocks, hash_num_buckets, total_size, low_blocks_to_allocate;
@@ -1326,7 +1328,7 @@ int mrh_destroy(mrh_ctx* c) {
   if (!c) return MRH_OK;
   free(c->table); free(c->compact); free(c->decision); free(c->mutex); free(c->heap_high); free(c->heap_low);
   free(c->blocks); free(c->realloc_pos); free(c->realloc_res); free(c->reintegrate); free(c->depth_buff);
-  free(c->depth); free(c->rgb); free(c->points); free(c->cloud); free(c->tris); free(c->tri_blocks); free(c->tri_counts); free(c->V); free(c->C); free(c->F);
+  free(c->depth); free(c->rgb); free(c->points); free(c->normals); free(c->cloud); free(c->tris); free(c->tri_blocks); free(c->tri_counts); free(c->V); free(c->C); free(c->F);
   free(c->qt_leaves); free(c->seeds); free(c->pack); free(c->halo);
   free(c);
   return MRH_OK;
@@ -1443,12 +1445,14 @@ static inline int dda_step(dda3* r) {
   return 1;
 }
 
-/* allocBlocks3DKernel for one point (vds.cu:925-1033), projective branch */
+/* allocBlocks3DKernel for one point (vds.cu:925-1033).  Normals: one per point (the reference indexes a 3-vectors-per-point
+ * eigenvector array by 3 * point, vds.cu:937; only that first vector, the normal, is used) */
 static void alloc_point(mrh_ctx* c, uint64_t i) {
   const f3 pcam = mk3(c->points[3 * i], c->points[3 * i + 1], c->points[3 * i + 2]);
   const float range = norm3(pcam);
   if (range == 0.f) return;
-  const f3 cam_dir = normalize3(pcam);
+  f3 cam_dir = normalize3(pcam);
+  if (!c->p.projective_sdf) cam_dir = normalize3(mk3(c->normals[3 * i], c->normals[3 * i + 1], c->normals[3 * i + 2]));  /* vds.cu:959-962: norm_dir */
   const float t = get_truncation(range, c->p.sdf_truncation, c->p.sdf_truncation_scale);
   const float min_depth = fminf(c->max_integration_distance, range - t);
   const float max_depth = fminf(c->max_integration_distance, range + t);
@@ -1466,6 +1470,7 @@ static void alloc_point(mrh_ctx* c, uint64_t i) {
 static void alloc_blocks_3d(mrh_ctx* c) {
   int prev_free = heap_high_free(c) + heap_low_free(c);
   reset_mutex(c);
+  if (c->p.sdf_var_threshold > 0.f && heap_low_free(c) < (int) c->low_blocks_to_allocate) allocate_memory_low(c);  /* vds.cu:1048-1054 */
   for (uint64_t i = 0; i < c->num_points; i++) alloc_point(c, i);
   for (;;) {
     reset_mutex(c);
@@ -1476,7 +1481,7 @@ static void alloc_blocks_3d(mrh_ctx* c) {
   }
 }
 
-/* integrate3DKernel for one point (vds.cu:1215-1379), projective branch, resolution-0 entries */
+/* integrate3DKernel for one point (vds.cu:1215-1379): projective or normal-direction SDF, fine and coarse entries */
 static void integrate_point(mrh_ctx* c, uint64_t i) {
   const float vs = c->p.virtual_voxel_size;
   const float ext = (float) c->p.voxel_extents_scale;
@@ -1484,25 +1489,39 @@ static void integrate_point(mrh_ctx* c, uint64_t i) {
   const float range = norm3(pcam);
   if (range < 1e-6 || range > c->max_integration_distance) return;
   const f3 cam_dir = normalize3(pcam);
+  const int projective = c->p.projective_sdf != 0;
+  f3 norm_dir = mk3(0.f, 0.f, 0.f);
+  if (!projective) norm_dir = normalize3(mk3(c->normals[3 * i], c->normals[3 * i + 1], c->normals[3 * i + 2]));
   const float truncation = get_truncation(range, c->p.sdf_truncation, c->p.sdf_truncation_scale);
   const float min_depth = fminf(c->max_integration_distance, range - truncation);
   const float max_depth = fminf(c->max_integration_distance, range + truncation);
   if (min_depth >= max_depth) return;
-  const f3 pcam_min = mk3(pcam.x - cam_dir.x * truncation, pcam.y - cam_dir.y * truncation, pcam.z - cam_dir.z * truncation);
-  const f3 pcam_max = mk3(pcam.x + cam_dir.x * truncation, pcam.y + cam_dir.y * truncation, pcam.z + cam_dir.z * truncation);
+  f3 pcam_min, pcam_max;
+  if (projective) {
+    pcam_min = mk3(pcam.x - cam_dir.x * truncation, pcam.y - cam_dir.y * truncation, pcam.z - cam_dir.z * truncation);
+    pcam_max = mk3(pcam.x + cam_dir.x * truncation, pcam.y + cam_dir.y * truncation, pcam.z + cam_dir.z * truncation);
+  } else {
+    const float a = min_depth - range, b = max_depth - range;
+    pcam_min = mk3(pcam.x + norm_dir.x * a, pcam.y + norm_dir.y * a, pcam.z + norm_dir.z * a);
+    pcam_max = mk3(pcam.x + norm_dir.x * b, pcam.y + norm_dir.y * b, pcam.z + norm_dir.z * b);
+  }
   dda3 r = dda_setup(c, se3_apply(c->R, c->t, pcam_min), se3_apply(c->R, c->t, pcam_max), 0);
   const uint8_t w1 = (uint8_t) (float) (uint8_t) c->p.integration_weight_sample;  /* weight_update = integration_weight_sample (uchar -> float -> uchar) */
   for (unsigned iter = 0; iter < MAX_DDA_ITERATION_COUNT; iter++) {
     const i3 block = voxel_to_block(r.cur, vs, ext);
     const HashEntry entry = get_hash_entry(c, block);
     if (entry.ptr != FREE_ENTRY) {
-      const f3 voxel_pos = voxel_to_world(vs, r.cur);   /* scale 1: voxel_pos_aprox == id_current_voxel */
+      const int scale = 1 << entry.resolution;
+      const i3 aprox = {r.cur.x / scale, r.cur.y / scale, r.cur.z / scale};  /* C division: truncates toward zero (vds.cu:1306-1307) */
+      const f3 voxel_pos = voxel_to_world(vs * (float) scale, aprox);       /* getVoxelSize(entry) = vs * (1 << resolution) */
       const f3 pc = se3_apply(c->Ri, c->ti, voxel_pos);
-      float sdf = range - norm3(pc);
+      float sdf;
+      if (projective) sdf = range - norm3(pc);
+      else sdf = ((pc.x - pcam.x) * norm_dir.x + (pc.y - pcam.y) * norm_dir.y) + (pc.z - pcam.z) * norm_dir.z;  /* dot, cuda_math.cuh */
       if (sdf <= -truncation) break;
       if (sdf >= 0.f) sdf = fminf(truncation, sdf);
       else sdf = fmaxf(-truncation, sdf);
-      Voxel* dst = &c->blocks[(size_t) entry.ptr + voxel_to_block_index(r.cur, SDF_BLOCK_SIZE)];
+      Voxel* dst = &c->blocks[(size_t) entry.ptr + voxel_to_block_index(r.cur, SDF_BLOCK_SIZE / scale)];  /* D1: dense index on coarse blocks */
       float curr_mean = 0.f;
       if (dst->weight > 0) curr_mean = dst->sdf;
       const float delta = (sdf - curr_mean) / (vs / 2);
@@ -1535,18 +1554,44 @@ int mrh_upload_points(mrh_ctx* c, const float* xyz, uint64_t n) {
   return MRH_OK;
 }
 int mrh_set_points_device(mrh_ctx* c, const float* xyz, uint64_t n) { return mrh_upload_points(c, xyz, n); }
+int mrh_upload_normals(mrh_ctx* c, const float* nxyz, uint64_t n) {
+  if (!c || (n && !nxyz)) return fail(c, MRH_ERR_INVALID_ARG, "mrh_upload_normals: bad argument");
+  free(c->normals);
+  c->normals = n ? (float*) malloc((size_t) n * 3 * sizeof(float)) : NULL;
+  if (n) memcpy(c->normals, nxyz, (size_t) n * 3 * sizeof(float));
+  c->num_normals = n;
+  return MRH_OK;
+}
 
 /* VoxelContainer::integrate(point_cloud, normals, weights, camera, max_num_frames), voxel_data_structures.cpp:112-135 */
+static int is_starve_frame(const mrh_ctx* c, int max_num_frames);
+static void gc_tail(mrh_ctx* c);
 int mrh_integrate_points(mrh_ctx* c, int n_frames_invalidate) {
   if (!c) return MRH_ERR_INVALID_ARG;
+  if (c->pending) return fail(c, MRH_ERR_STATE, "mrh_integrate_points: an exchange is pending (call mrh_integrate_resume)");
+  if (c->n_halo) return fail(c, MRH_ERR_STATE, "mrh_integrate_points: halo blocks of other shards are present (call mrh_drop_blocks(MRH_DROP_HALO))");
   if (!c->has_camera) return fail(c, MRH_ERR_STATE, "mrh_integrate_points: set_camera has not been called");
   const int max_num_frames = n_frames_invalidate < 0 ? c->p.n_frames_invalidate_voxels : n_frames_invalidate;
-  if (max_num_frames > 0) return fail(c, MRH_ERR_UNSUPPORTED, "mrh_integrate_points: garbage collection on LiDAR scans (spherical projection) is outside this round's scope");
-  if (c->p.sdf_var_threshold > 0.f) return fail(c, MRH_ERR_UNSUPPORTED, "mrh_integrate_points: variance-adaptive resolution on LiDAR scans (reintegrate3D) is outside this round's scope");
-  if (!c->p.projective_sdf) return fail(c, MRH_ERR_UNSUPPORTED, "mrh_integrate_points: normal-direction SDF needs normals, which this boundary does not carry");
+  if (!c->p.projective_sdf && c->num_normals != c->num_points)
+    return fail(c, MRH_ERR_STATE, "mrh_integrate_points: the normal-direction SDF needs one normal per point (mrh_upload_normals)");
   c->last_inserted = c->last_freed = 0;
   alloc_blocks_3d(c);
+  flat_and_reduce(c, 0);
   for (uint64_t i = 0; i < c->num_points; i++) integrate_point(c, i);
+  if (c->p.sdf_var_threshold > 0.f && c->frames > 0) {
+    check_var_sdf(c);
+    realloc_blocks(c);
+    flat_and_reduce(c, 0);
+    /* reintegrate3D launches integrate3DKernel, not reintegrate3DKernel (vds.cu:1561-1580): the whole scan a second time */
+    for (uint64_t i = 0; i < c->num_points; i++) integrate_point(c, i);
+  }
+  if (is_starve_frame(c, max_num_frames)) {
+    starve_pass(c, 0);
+    if (c->p.shard_count > 1) { c->pending = 1; return MRH_PENDING_EXCHANGE; }
+    starve_pass(c, 1);
+    starve_pass(c, 2);
+  }
+  if (max_num_frames > 0) gc_tail(c);
   c->frames++;
   return MRH_OK;
 }

@@ -127,17 +127,138 @@ def test_update_order_is_the_point_order(oracle):
     assert fold((p0, p1, p2))[1] != fold((p2, p1, p0))[1]  # the order is observable, so it has to be pinned
 
 
-def test_unsupported_modes_say_so(oracle):
-    e = _engine(oracle, dict(n_frames_invalidate_voxels=5))
+def spherical_camera(rows=32, cols=512, el_deg=(-22.5, 22.5)):
+    """Spherical intrinsics that map a rows x cols LiDAR image onto [-pi, pi) x [el0, el1] (test_projections.cu:146-158):
+    col = fx * azimuth + cx, row = fy * elevation + cy."""
+    fx = cols / (2.0 * np.pi)
+    el0, el1 = np.deg2rad(el_deg[0]), np.deg2rad(el_deg[1])
+    fy = (rows - 1) / (el1 - el0)
+    return dict(fx=fx, fy=fy, cx=cols / 2.0, cy=-fy * el0, rows=rows, cols=cols)
+
+
+def _scan_engine(lib, params, cam=None, blocks=65536, max_depth=100.0):
+    p = dict(synth.VBR_PARAMS, **params)
+    e = capi.Engine(lib, capi.Params(num_sdf_blocks=blocks, **p))
+    k = cam or dict(fx=1.0, fy=1.0, cx=0.0, cy=0.0, rows=1, cols=1)
+    e.set_camera(k["fx"], k["fy"], k["cx"], k["cy"], k["rows"], k["cols"], p["min_depth"], max_depth, model=1)
+    return e
+
+
+def drive(e, n=4, rows=16, cols=256, normals=False, step=1.5):
+    scene = synth.street_canyon()
+    for t, q in synth.drive_poses(n, step=step):
+        pts = synth.lidar_scan(scene, t, q, rows=rows, cols=cols)
+        e.set_pose(synth.quat_to_rot(q), t)
+        e.upload_points(pts)
+        if normals:
+            e.upload_normals(synth.scan_normals(pts))
+        e.integrate_points()
+
+
+def test_gc_on_scans_frees_blocks_without_a_surface_and_conserves_the_heap(oracle):
+    """garbageCollect after every scan (voxel_data_structures.cpp:128-129): identify + free over EVERY live block (the
+    scan path compacts without a camera); every 3rd scan the starve step projects through the spherical camera."""
+    cam = spherical_camera(16, 256)
+    keep = _scan_engine(oracle, dict(n_frames_invalidate_voxels=0), cam)
+    gc = _scan_engine(oracle, dict(n_frames_invalidate_voxels=3), cam)
+    drive(keep, 7)
+    drive(gc, 7)
+    sk, sg = keep.stats(), gc.stats()
+    assert sg.occupied_fine < sk.occupied_fine and sg.occupied_fine > 100
+    assert sg.occupied_fine + sg.free_fine == sg.num_sdf_blocks
+    dk, vk = keep.dump_blocks()
+    dg, vg = gc.dump_blocks()
+    assert np.all(np.isin(dg, dk))  # GC only removes
+    # a surviving block holds a weighted voxel inside the truncation band (vds.cu:1708-1711)
+    w = vg["weight"] > 0
+    assert np.all((np.where(w, np.abs(vg["sdf"]), np.inf).min(axis=1) < np.float32(0.4)))
+    # the starve step took weight off the front-most voxel of some pixels: total weight below the no-GC run on common blocks
+    common = np.isin(dk, dg)
+    assert vg["weight"].astype(np.int64).sum() < vk["weight"][common].astype(np.int64).sum()
+    for e in (keep, gc):
+        e.close()
+
+
+def test_normal_direction_sdf_needs_and_uses_the_normals(oracle):
+    e = _scan_engine(oracle, dict(projective_sdf=False))
     _identity(e)
     e.upload_points(np.array([[5.0, 0, 0]], np.float32))
     with pytest.raises(capi.MrhError) as ei:
-        e.integrate_points()
-    assert ei.value.code == capi.MRH_ERR_UNSUPPORTED
+        e.integrate_points()  # no normals given
+    assert ei.value.code == capi.MRH_ERR_STATE
     e.close()
-    e = _engine(oracle, dict(sdf_var_threshold=0.01))
-    _identity(e)
-    e.upload_points(np.array([[5.0, 0, 0]], np.float32))
-    with pytest.raises(capi.MrhError):
-        e.integrate_points()
+    maps = []
+    for flip in (1.0, -1.0):
+        e = _scan_engine(oracle, dict(projective_sdf=False, min_weight_threshold=1))
+        scene = synth.street_canyon()
+        for t, q in synth.drive_poses(2, step=2.0):
+            pts = synth.lidar_scan(scene, t, q, rows=16, cols=256)
+            e.set_pose(synth.quat_to_rot(q), t)
+            e.upload_points(pts)
+            e.upload_normals(flip * synth.scan_normals(pts))
+            e.integrate_points()
+        d, v = e.dump_blocks()
+        assert len(d) > 200 and (v["weight"] > 0).sum() > 1000
+        maps.append((d, v))
+        e.close()
+    # along the normal the SDF is dot(voxel - point, normal) (vds.cu:1322-1326): flipping the normals flips its sign
+    proj = _scan_engine(oracle, dict(min_weight_threshold=1))
+    drive(proj, 2, step=2.0)
+    dp, vp = proj.dump_blocks()
+    assert not (len(dp) == len(maps[0][0]) and np.array_equal(vp["sdf"], maps[0][1]["sdf"]))
+    assert not (len(maps[0][0]) == len(maps[1][0]) and np.array_equal(maps[0][1]["sdf"], maps[1][1]["sdf"]))
+    proj.close()
+
+
+def test_variance_adaptive_scans_coarsen_flat_regions(oracle):
+    """sdf_var_threshold > 0 on scans: checkVarSDF over every live block, coarsened blocks are re-created at 4^3 and the
+    whole scan is integrated a second time (reintegrate3D launches integrate3DKernel, vds.cu:1561-1580)."""
+    e = _scan_engine(oracle, dict(sdf_var_threshold=0.05, min_weight_threshold=1))
+    drive(e, 4, step=0.5)
+    s = e.stats()
+    assert s.occupied_coarse > 20 and s.occupied_fine > 100
+    d, v = e.dump_blocks()
+    coarse = d["resolution"] == 1
+    assert coarse.sum() == s.occupied_coarse
+    assert (v["weight"][coarse][:, :64] > 0).any() and not (v["weight"][coarse][:, 64:] > 0).any()
+    # fine slots + coarse units account for the whole pool: 8 coarse units per converted fine slot
+    assert (s.free_coarse + s.occupied_coarse) % 8 == 0
+    assert s.occupied_fine + s.free_fine + (s.free_coarse + s.occupied_coarse) // 8 == s.num_sdf_blocks
+    e.close()
+
+
+def test_spherical_depth_image_fuses_like_the_same_points_would_project(oracle):
+    """The image path with the spherical camera model (camera.cuh:91-99, :147-164): a range image of the street scene;
+    allocation walks the back-projected rays, integration projects voxels with atan2 / asin (mrh_softmath.h)."""
+    cam = spherical_camera(32, 256)
+    p = dict(synth.VBR_PARAMS, min_weight_threshold=1)
+    e = capi.Engine(oracle, capi.Params(num_sdf_blocks=65536, **p))
+    e.set_camera(cam["fx"], cam["fy"], cam["cx"], cam["cy"], cam["rows"], cam["cols"], p["min_depth"], 60.0, model=1)
+    scene = synth.street_canyon()
+    (t, q), = synth.drive_poses(1)
+    depth, rgb = synth.spherical_range_image(scene, t, q, cam)
+    e.set_pose(synth.quat_to_rot(q), t)
+    e.upload_depth(depth)
+    e.upload_rgb(rgb)
+    e.integrate()
+    d, v = e.dump_blocks()
+    assert len(d) > 500
+    w = v["weight"] > 0
+    assert w.sum() > 20000 and np.abs(v["sdf"][w]).max() <= np.float32(0.4)
+    # known answer: a weighted voxel's sdf is (range image at its pixel) - |voxel in the sensor frame|, clamped
+    R = synth.quat_to_rot(q).astype(np.float64)
+    checked = 0
+    for bi in np.argsort(-w.sum(axis=1))[:5]:
+        for li in np.nonzero(w[bi])[0][:40]:
+            vx = np.array([d["x"][bi] * 8 + li % 8, d["y"][bi] * 8 + (li // 8) % 8, d["z"][bi] * 8 + li // 64]) * 0.2
+            pc = R.T @ (vx - t.astype(np.float64))
+            rng = np.linalg.norm(pc)
+            col = int(cam["fx"] * np.arctan2(pc[1], pc[0]) + cam["cx"] + 0.5)
+            row = int(cam["fy"] * np.arcsin(pc[2] / rng) + cam["cy"] + 0.5)
+            want = np.clip(depth[row, col] - rng, -0.4, 0.4)
+            if abs(cam["fx"] * np.arctan2(pc[1], pc[0]) + cam["cx"] + 0.5 - round(cam["fx"] * np.arctan2(pc[1], pc[0]) + cam["cx"] + 0.5)) < 1e-3:
+                continue  # on a pixel boundary: the ulp-level differences of the soft functions may pick the neighbour
+            assert abs(float(v["sdf"][bi][li]) - want) < 2e-4
+            checked += 1
+    assert checked > 100
     e.close()

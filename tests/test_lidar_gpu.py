@@ -101,15 +101,129 @@ def test_far_from_origin_and_device_pointer(hip, oracle):
     assert r["blocks"] > 300 and r["sdf_bit_exact"]
 
 
-def test_unsupported_modes_say_so(hip):
-    e = capi.Engine(hip, capi.Params(num_sdf_blocks=4096, **dict(synth.VBR_PARAMS, n_frames_invalidate_voxels=3)))
+from test_lidar import spherical_camera  # noqa: E402
+
+
+def _scan_pair(hip, oracle, params, cam=None, blocks=131072, max_depth=100.0):
+    p = dict(synth.VBR_PARAMS, **params)
+    k = cam or dict(fx=1.0, fy=1.0, cx=0.0, cy=0.0, rows=1, cols=1)
+    out = []
+    for lib in (hip, oracle):
+        e = capi.Engine(lib, capi.Params(num_sdf_blocks=blocks, **p))
+        e.set_camera(k["fx"], k["fy"], k["cx"], k["cy"], k["rows"], k["cols"], p["min_depth"], max_depth, model=1)
+        out.append(e)
+    return out
+
+
+def _drive(engines, n, rows, cols, step=1.5, normals=False, noise=0.0, seed=0):
+    scene = synth.street_canyon()
+    rng = np.random.default_rng(seed)
+    for t, q in synth.drive_poses(n, step=step):
+        pts = synth.lidar_scan(scene, t, q, rows=rows, cols=cols, noise_sigma=noise, rng=rng)
+        for e in engines:
+            e.set_pose(synth.quat_to_rot(q), t)
+            e.upload_points(pts)
+            if normals:
+                e.upload_normals(synth.scan_normals(pts))
+            assert not e.integrate_points()
+
+
+def test_full_size_vbr_scans_match_oracle(hip, oracle):
+    """BASELINE configs[4] at its stated size: 128 x 1024 = 131 072 points per scan, vbr.cfg parameters, three scans of a
+    drive; occupancy, payload and mesh against the oracle."""
+    a, b = _scan_pair(hip, oracle, dict(min_weight_threshold=1), blocks=262144)
+    _drive((a, b), 3, 128, 1024, step=2.0, noise=0.02)
+    a.sync()
+    r = pu.compare_maps(a, b)
+    assert r["blocks"] > 8000 and r["sdf_bit_exact"] and r["sumsq_bit_exact"]
+    m = pu.compare_meshes(a, b)
+    assert m["triangles"] > 20000 and m["pos_bit_exact"]
+
+
+def test_gc_and_starve_on_scans_match_oracle(hip, oracle):
+    """garbageCollect on scans (voxel_data_structures.cpp:128-129): identify + free over every live block after each scan,
+    the starve step every 3rd scan through the SPHERICAL camera (atan2 / asin of mrh_softmath.h on both sides)."""
+    cam = spherical_camera(32, 512)
+    a, b = _scan_pair(hip, oracle, dict(n_frames_invalidate_voxels=3, min_weight_threshold=1), cam)
+    _drive((a, b), 8, 32, 512, noise=0.02)
+    a.sync()
+    sa, sb = a.stats(), b.stats()
+    assert (sa.occupied_fine, sa.free_fine) == (sb.occupied_fine, sb.free_fine) and sa.error_flags == 0
+    r = pu.compare_maps(a, b)
+    assert r["blocks"] > 500 and r["sdf_bit_exact"]
+    pu.compare_meshes(a, b)
+    keep = _scan_pair(hip, oracle, dict(min_weight_threshold=1), cam)[0]
+    _drive((keep,), 8, 32, 512, noise=0.02)
+    assert keep.stats().occupied_fine > sa.occupied_fine  # GC really freed blocks
+
+
+def test_normal_direction_sdf_matches_oracle(hip, oracle):
+    a, b = _scan_pair(hip, oracle, dict(projective_sdf=False, min_weight_threshold=1))
+    _drive((a, b), 4, 32, 512, normals=True, noise=0.02)
+    a.sync()
+    r = pu.compare_maps(a, b)
+    assert r["blocks"] > 800 and r["weighted"] > 10000 and r["sdf_bit_exact"] and r["sumsq_bit_exact"]
+    pu.compare_meshes(a, b)
+    e = capi.Engine(hip, capi.Params(num_sdf_blocks=4096, **dict(synth.VBR_PARAMS, projective_sdf=False)))
     e.set_camera(1, 1, 0, 0, 1, 1, 0.2, 100.0, model=1)
     e.set_pose(np.eye(3, dtype=np.float32), np.zeros(3, np.float32))
     e.upload_points(np.array([[5.0, 0, 0]], np.float32))
     with pytest.raises(capi.MrhError) as ei:
-        e.integrate_points()
-    assert ei.value.code == capi.MRH_ERR_UNSUPPORTED
+        e.integrate_points()  # no normals given
+    assert ei.value.code == capi.MRH_ERR_STATE
     e.close()
+
+
+@pytest.mark.parametrize("gc", [0, 4])
+def test_variance_adaptive_scans_match_oracle(hip, oracle, gc):
+    """sdf_var_threshold > 0 on scans: coarsening over all live blocks, then the scan a second time into fine and coarse
+    blocks (reintegrate3D, vds.cu:1561-1580); with and without garbage collection / starve."""
+    cam = spherical_camera(32, 512)
+    a, b = _scan_pair(hip, oracle, dict(sdf_var_threshold=0.05, n_frames_invalidate_voxels=gc, min_weight_threshold=1), cam)
+    _drive((a, b), 6, 32, 512, step=0.5, noise=0.01)
+    a.sync()
+    sa, sb = a.stats(), b.stats()
+    assert sb.occupied_coarse > 50
+    assert (sa.occupied_fine, sa.occupied_coarse, sa.free_fine, sa.free_coarse) == (sb.occupied_fine, sb.occupied_coarse, sb.free_fine, sb.free_coarse)
+    r = pu.compare_maps(a, b)
+    assert r["sdf_bit_exact"] and r["sumsq_bit_exact"]
+    pu.compare_meshes(a, b)
+
+
+@pytest.mark.parametrize("var_threshold", [0.0, 0.05])
+def test_spherical_depth_images_match_oracle(hip, oracle, var_threshold):
+    """The image path under the spherical camera model (camera.cuh:91-99, :147-164, :184-201): range images of the street
+    scene through mrh_integrate — the general kernels with sin / cos / atan2 / asin from mrh_softmath.h — with GC every
+    frame and starve every 3rd."""
+    cam = spherical_camera(64, 512)
+    p = dict(synth.VBR_PARAMS, min_weight_threshold=1, n_frames_invalidate_voxels=3, sdf_var_threshold=var_threshold)
+    engines = []
+    for lib in (hip, oracle):
+        e = capi.Engine(lib, capi.Params(num_sdf_blocks=131072, **p))
+        e.set_camera(cam["fx"], cam["fy"], cam["cx"], cam["cy"], cam["rows"], cam["cols"], p["min_depth"], 60.0, model=1)
+        engines.append(e)
+    scene = synth.street_canyon()
+    for t, q in synth.drive_poses(5, step=1.0):
+        depth, rgb = synth.spherical_range_image(scene, t, q, cam)
+        for e in engines:
+            e.set_pose(synth.quat_to_rot(q), t)
+            e.upload_depth(depth)
+            e.upload_rgb(rgb)
+            assert not e.integrate()
+    a, b = engines
+    a.sync()
+    r = pu.compare_maps(a, b)
+    assert r["blocks"] > 800 and r["weighted"] > 50000 and r["sdf_bit_exact"]
+    pu.compare_meshes(a, b)
+    # a pinhole frame into the same context afterwards takes the fast path again (its GC summaries are rebuilt first)
+    if var_threshold == 0.0:
+        K = synth.CFG1
+        f = synth.cfg1_sphere()
+        for e in engines:
+            e.set_camera(K.fx, K.fy, K.cx, K.cy, K.rows, K.cols, p["min_depth"], 60.0)
+            pu.feed(e, f)
+        a.sync()
+        pu.compare_maps(a, b)
 
 
 @pytest.mark.parametrize("seed", [0, 1, 2, 3])

@@ -58,6 +58,69 @@ def test_frame_sharded_submaps_merge_into_one_tile_sharded_map_hip(hip, tmp_path
     check_merged_against_single(hip, tmp_path, got)
 
 
+NCCL_WORKER = r"""
+import os, sys
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import numpy as np
+import torch
+import parity_utils as pu
+from mrhash_amd import capi, parallel, synth
+os.environ["MRH_FORCE_COLLECTIVES"] = "1"
+dist = parallel.init_process_group("nccl")     # RCCL, one rank: every collective below runs through RCCL on device buffers
+assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
+hip = capi.load_hip()
+params = dict(synth.CFG1_PARAMS, n_frames_invalidate_voxels=2)
+frames = (synth.cfg1_sphere(), synth.cfg1_sphere(zc=1.51), synth.cfg1_sphere(zc=1.5), synth.cfg1_sphere(zc=1.49))
+# (1) a tile-sharded context that owns one of two shards: starve frames stop for the MIN all-reduce of the device z-buffer
+a = pu.make_engine(hip, synth.CFG1, params, 16384, shard_rank=0, shard_count=2, shard_chunk_log2=1)
+b = pu.make_engine(hip, synth.CFG1, params, 16384, shard_rank=0, shard_count=2, shard_chunk_log2=1)
+for f in frames:
+    pu.feed(a, f, dist=dist)            # parallel.integrate: dist.all_reduce(MIN) over RCCL on the library's buffer
+    b.set_pose(f.R, f.t); b.upload_depth(f.depth); b.upload_rgb(f.rgb)
+    pending = b.integrate()
+    while pending:                      # the same frame with the exchange skipped (one shard: MIN over one buffer is the buffer)
+        pending = b.integrate_resume()
+pu.compare_maps(a, b)
+# (2) merge_submaps through all_to_all_single on device tensors: a one-rank fold reproduces the map
+c = pu.make_engine(hip, synth.CFG1, dict(synth.CFG1_PARAMS), 16384)
+for f in frames:
+    pu.feed(c, f)
+d0, v0 = c.dump_blocks()
+info = parallel.merge_submaps(c, dist, chunk_log2=1)
+d1, v1 = c.dump_blocks()
+assert len(d0) > 50 and np.array_equal(d0, d1) and np.array_equal(v0.view(np.uint8), v1.view(np.uint8))
+# (3) exchange_halo through all_gather_into_tensor on device tensors (no other rank: nothing is taken)
+assert parallel.exchange_halo(c, dist) == 0
+res = parallel.gather_mesh(c, dist)
+ref = pu.make_engine(hip, synth.CFG1, dict(synth.CFG1_PARAMS), 16384)
+for f in frames:
+    pu.feed(ref, f)
+t = ref.extract_triangles()
+assert np.array_equal(res[0].view(np.uint8), t.view(np.uint8))
+open({out!r}, "w").write("ok")
+dist.destroy_process_group()
+"""
+
+
+def test_rccl_branches_run_in_a_one_rank_group(hip, tmp_path):
+    """The nccl branches of mrhash_amd.parallel (library device buffers -> RCCL collective -> library) cannot run with two
+    ranks on this one-GPU box (RCCL: "Duplicate GPU detected", profiles/r02/two_ranks_one_device_nccl_outcome.txt), so
+    they run here in a ONE-rank RCCL group with MRH_FORCE_COLLECTIVES=1: all_reduce(MIN) on the starve z-buffer,
+    all_to_all_single + device merge, all_gather_into_tensor of halo records."""
+    import os
+    import subprocess
+    import sys
+
+    from test_sharding import ROOT
+
+    out = str(tmp_path / "ok.txt")
+    script = tmp_path / "nccl_worker.py"
+    script.write_text(NCCL_WORKER.format(root=ROOT, out=out))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and os.path.exists(out), r.stdout[-2000:] + r.stderr[-4000:]
+
+
 def test_exchange_primitives_match_the_oracle(hip, oracle):
     """mrh_pack_blocks / mrh_unpack_blocks / mrh_drop_blocks on the device against the oracle's host versions: the same
     record sets (order aside), the same merged map."""
