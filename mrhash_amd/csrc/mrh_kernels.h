@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256) void k_cloud_depth(const Cam c, const float* _
   if (i >= c.rows * c.cols) return;
   const float d = depth[i];
   float r = 0.f;
-  if (!(d <= c.min_depth || d > c.max_depth)) r = get_depth(c, inverse_projection(c, (u32) (i / c.cols), (u32) (i % c.cols), d));
+  if (!(d <= c.min_depth || d > c.max_depth)) r = get_depth(c, inverse_projection_m(c, (u32) (i / c.cols), (u32) (i % c.cols), d));
   out[i] = r;
 }
 
