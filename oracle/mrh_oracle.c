@@ -1056,8 +1056,9 @@ static void check_vertex_voxels(const mrh_ctx* c, f3 pf, f3* sP, f3* sM) {
   if (vs > 0 && vs < 1 && vs != vvs) sM->z *= 0.499f;
 }
 
-/* marching_cubes.cu:72-261 extractIsoSurfaceAtPosition (positive/negative scaling = 1) */
-static void extract_at_position(mrh_ctx* c, f3 pf) {
+/* marching_cubes.cu:72-261 extractIsoSurfaceAtPosition (positive/negative scaling = 1); the voxel's triangles go to out[0 .. n),
+ * n <= 5 is returned (the caller appends them in canonical order: blocks are evaluated in parallel, appended in sequence) */
+static int extract_at_position(const mrh_ctx* c, f3 pf, mrh_triangle* out) {
   const float isolevel = 0.f;
   const float vvs = get_voxel_size_f(c, pf);
   const float P = vvs * 0.5f;
@@ -1075,7 +1076,7 @@ static void extract_at_position(mrh_ctx* c, f3 pf) {
     const int valid = trilinear(c, p[k], &dist[k]);
     vox[k] = get_voxel_f(c, p[k], NULL);
     if (!valid) {
-      if (vox[k].weight < c->p.min_weight_threshold) return;
+      if (vox[k].weight < c->p.min_weight_threshold) return 0;
       dist[k] = vox[k].sdf;
     }
   }
@@ -1087,13 +1088,13 @@ static void extract_at_position(mrh_ctx* c, f3 pf) {
   for (unsigned k = 0; k < 8; k++)
     for (unsigned l = 0; l < 8; l++) {
       if (dist[k] * dist[l] < 0.f) {
-        if (fabsf(dist[k]) + fabsf(dist[l]) > thr) return;
+        if (fabsf(dist[k]) + fabsf(dist[l]) > thr) return 0;
       } else {
-        if (fabsf(dist[k] - dist[l]) > thr) return;
+        if (fabsf(dist[k] - dist[l]) > thr) return 0;
       }
     }
   for (int k = 0; k < 8; k++)
-    if (fabsf(dist[k]) > thr) return;
+    if (fabsf(dist[k]) > thr) return 0;
 
   const uint8_t* row = MC_TRI[cube_index];
   const int ntri = row[0];
@@ -1104,8 +1105,9 @@ static void extract_at_position(mrh_ctx* c, f3 pf) {
       const int a = code >> 4, b = code & 0xF;
       t.v[k] = vertex_interp(isolevel, p[a], p[b], dist[a], dist[b], vox[a].rgb, vox[b].rgb);
     }
-    push_triangle(c, &t);
+    out[j] = t;
   }
+  return ntri;
 }
 
 /* mesh_extractor.cpp:95-98 + marching_cubes.cu:264-305 */
@@ -1117,22 +1119,39 @@ static void extract_iso_surface(mrh_ctx* c) {
   c->tri_blocks = (mrh_block_desc*) calloc(c->current_occupied ? c->current_occupied : 1, sizeof(mrh_block_desc));
   c->tri_counts = (uint32_t*) calloc(c->current_occupied ? c->current_occupied : 1, sizeof(uint32_t));
   const float vs = c->p.virtual_voxel_size;
-  for (unsigned e = 0; e < c->current_occupied; e++) {
+  const long nblk = (long) c->current_occupied;
+  /* per block: its triangles in voxel order (blocks are independent: evaluated in parallel, appended below in list order) */
+  mrh_triangle** per_block = (mrh_triangle**) calloc(nblk ? (size_t) nblk : 1, sizeof(mrh_triangle*));
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 8)
+#endif
+  for (long e = 0; e < nblk; e++) {
     const HashEntry* entry = &c->compact[e];
     const int scaling = 1 << entry->resolution;
     const unsigned nv = (unsigned) num_voxels_of(entry->resolution);
     const i3 base = block_to_voxel(entry->pos);
-    const uint64_t before = c->ntris;
-    if (owns_block(c, entry->pos)) /* halo blocks of other shards are looked up but emit nothing */
+    uint32_t n = 0;
+    mrh_triangle* buf = NULL;
+    if (owns_block(c, entry->pos)) { /* halo blocks of other shards are looked up but emit nothing */
+      buf = (mrh_triangle*) malloc((size_t) nv * 5 * sizeof(mrh_triangle));
       for (unsigned v = 0; v < nv; v++) {
         const i3 lc = delinearize(v, SDF_BLOCK_SIZE / scaling);
         const i3 pi = {base.x + scaling * lc.x, base.y + scaling * lc.y, base.z + scaling * lc.z};
-        extract_at_position(c, voxel_to_world(vs, pi));
+        n += (uint32_t) extract_at_position(c, voxel_to_world(vs, pi), buf + n);
       }
+    }
+    per_block[e] = buf;
     c->tri_blocks[e].x = entry->pos.x; c->tri_blocks[e].y = entry->pos.y; c->tri_blocks[e].z = entry->pos.z;
     c->tri_blocks[e].resolution = entry->resolution;
-    c->tri_counts[e] = (uint32_t) (c->ntris - before);
+    c->tri_counts[e] = n;
   }
+  for (long e = 0; e < nblk; e++) {
+    uint32_t kept = 0;
+    for (uint32_t j = 0; j < c->tri_counts[e]; j++) kept += (uint32_t) push_triangle(c, &per_block[e][j]);
+    c->tri_counts[e] = kept;
+    free(per_block[e]);
+  }
+  free(per_block);
 }
 
 /* ---- host mesh assembly: mesh_extractor.cpp:9-76, 156-259 --------------------------------- */

@@ -326,6 +326,55 @@ def test_replica_640x480_stream(hip, oracle):
     a.sync()
     r = pu.compare_maps(a, b)
     assert r["blocks"] > 5000 and r["sdf_bit_exact"]
+    m = pu.compare_meshes(a, b)  # marching cubes + mesh post-process at full resolution
+    assert m["triangles"] > 100000 and m["pos_bit_exact"]
+
+
+def test_replica_640x480_crosses_the_starve_period_of_the_shipped_configuration(hip, oracle):
+    """replica.cfg as shipped: GC every frame, starve every 100th.  103 frames of the 640x480 stream, so that frame 100 — the
+    first starve frame of the shipped period, with the table churn and the high-water mark of a hundred frames behind it —
+    runs on both sides; maps compared right after it and at the end, then the mesh."""
+    a, b = _pair(hip, oracle, synth.REPLICA_640, synth.REPLICA_PARAMS, 131072)
+    for i, f in enumerate(synth.replica_stream(103)):
+        pu.feed(a, f)
+        pu.feed(b, f)
+        if i in (99, 100):
+            a.sync()
+            pu.compare_maps(a, b)
+    a.sync()
+    s = a.stats()
+    assert s.frames_integrated == 103 and s.error_flags == 0
+    r = pu.compare_maps(a, b)
+    assert r["blocks"] > 20000 and r["sdf_bit_exact"] and r["sumsq_bit_exact"]
+    m = pu.compare_meshes(a, b)
+    assert m["triangles"] > 500000
+
+
+def test_a_full_reference_table_drops_blocks_the_open_address_table_keeps(hip, oracle):
+    """Deviation D9 (oracle header): the reference inserts a block into its bucket of 10 slots or, when that is full, into
+    an overflow list of at most 7 entries; with both full the block is silently NOT allocated (allocBlock vds.cu:502-624:
+    every failure path just returns).  The open-address table of this library has no such local limit — it keeps every
+    block while the table has a free slot within the probe limit.  Shown with a table that is nearly full (the shipped
+    sizing, 10 slots per pool block, never gets there): the reference's map is a strict subset of this library's, and on
+    the common blocks the payloads agree bit for bit."""
+    params = dict(synth.CFG1_PARAMS)
+    f = synth.cfg1_plane()
+    roomy = pu.make_engine(oracle, synth.CFG1, params, 4096)
+    pu.feed(roomy, f)
+    d_all, v_all = roomy.dump_blocks()
+    assert len(d_all) == 100
+    tight = pu.make_engine(oracle, synth.CFG1, params, 4096, hash_slots=120)  # 12 buckets x 10 slots for 100 blocks
+    pu.feed(tight, f)
+    d_t, v_t = tight.dump_blocks()
+    assert 0 < len(d_t) < 100 and np.all(np.isin(d_t, d_all)), "the reference's table did not overflow: the case does not show the deviation"
+    a = pu.make_engine(hip, synth.CFG1, params, 4096, hash_slots=120)  # rounded up to the library's minimum of 1024 slots
+    pu.feed(a, f)
+    a.sync()
+    d_a, v_a = a.dump_blocks()
+    assert np.array_equal(d_a, d_all) and np.array_equal(v_a.view(np.uint8), v_all.view(np.uint8))
+    common = np.isin(d_all, d_t)
+    assert np.array_equal(v_a[common].view(np.uint8), v_t.view(np.uint8))
+    print(f"reference table of 120 slots kept {len(d_t)} of 100 blocks; open-address table kept 100")
 
 
 def test_scannet_640x480_furnished_walk(hip, oracle):
@@ -368,6 +417,24 @@ def test_multires_640x480(hip, oracle):
     a.sync()
     pu.compare_maps(a, b)
     assert saw_coarse
+    m = pu.compare_meshes(a, b)  # configs[2] end to end: multi-resolution map -> marching cubes across resolution jumps -> mesh
+    assert m["triangles"] > 100000
+
+
+def test_multires_640x480_long_run_and_mesh(hip, oracle):
+    """configs[2] over 24 frames (sigma 0.005, noise-free stream): the fused multi-resolution path, GC every frame and
+    two starve frames (period 10), then the mesh over thousands of coarse and fine blocks."""
+    params = dict(synth.REPLICA_PARAMS, sdf_var_threshold=0.005, n_frames_invalidate_voxels=10)
+    a, b = _pair(hip, oracle, synth.REPLICA_640, params, 131072)
+    for f in synth.replica_stream(24):
+        pu.feed(a, f)
+        pu.feed(b, f)
+    a.sync()
+    sa, sb = a.stats(), b.stats()
+    assert (sa.occupied_fine, sa.occupied_coarse) == (sb.occupied_fine, sb.occupied_coarse) and sb.occupied_coarse > 1000
+    pu.compare_maps(a, b)
+    m = pu.compare_meshes(a, b)
+    assert m["triangles"] > 300000
 
 
 def test_stream_out_and_import_match_oracle(hip, oracle):
