@@ -181,15 +181,19 @@ void GeoWrapper::streamOutToGrid(const std::array<float, 3>& center, float radiu
 void GeoWrapper::streamInFromGrid(const std::array<float, 3>* center, float radius) {
   std::vector<mrh_block_desc> descs;
   std::vector<mrh_voxel> vox;
-  for (auto it = grid_.begin(); it != grid_.end();) {
-    if (center && !chunkTouchesSphere(it->first, *center, radius)) { ++it; continue; }
-    for (const HostBlock& b : it->second) {
+  std::vector<std::array<int, 3>> taken;
+  for (const auto& kv : grid_) {
+    if (center && !chunkTouchesSphere(kv.first, *center, radius)) continue;
+    for (const HostBlock& b : kv.second) {
       descs.push_back(b.desc);
       vox.insert(vox.end(), b.voxels.begin(), b.voxels.end());
     }
-    it = grid_.erase(it);  // "it lives on the device from now"
+    taken.push_back(kv.first);
   }
-  if (!descs.empty()) check(mrh_import_blocks(ctx_, descs.data(), vox.data(), descs.size()), "stream");
+  if (descs.empty()) return;
+  // import first, forget the host copies only once the device holds them: a failed import (pool full) must not lose blocks
+  check(mrh_import_blocks(ctx_, descs.data(), vox.data(), descs.size()), "stream");
+  for (const auto& k : taken) grid_.erase(k);  // "it lives on the device from now"
 }
 
 // Streamer::stream (streamer.cpp:333-354) with the two radii chosen so that paging is TRANSPARENT — a block is either on
@@ -222,6 +226,15 @@ void GeoWrapper::compute() {
   check(mrh_set_pose(ctx_, R, t), "compute");
   if (have_depth_ && have_rgb_) {  // geowrapper.cpp:140
     check(mrh_integrate(ctx_, n_frames_invalidate_voxels_), "compute");
+    // The reference reports an exhausted pool / a full table from the device (printf, vds.cu:566-569) and carries on without
+    // the affected blocks.  Same here, without a stall: the flags of a frame that finished a moment ago arrive with the
+    // pool-level report; each is announced once.
+    uint32_t flags = 0;
+    if (mrh_peek_error_flags(ctx_, &flags) == MRH_OK && flags) {
+      if (flags & 1u) std::cerr << "GeoWrapper::compute | SDF block pool exhausted: blocks of recent frames were skipped" << std::endl;
+      if (flags & 2u) std::cerr << "GeoWrapper::compute | hash table probe limit reached: blocks of recent frames were skipped" << std::endl;
+      if (flags & 4u) std::cerr << "GeoWrapper::compute | block coordinates left the +-2^20 key range" << std::endl;
+    }
     if (gs_enabled_) {  // geowrapper.cpp:142-143 runGS -> extractNodesQTree + checkNodes; Add_gaussians keeps what they emit
       const mrh_splat_seed* seeds = nullptr;
       uint64_t n = 0;

@@ -4,7 +4,7 @@
 #   usage: tools/profile_bench.sh <tag> [bench args...]
 set -u
 TAG=${1:-r01}; shift || true
-ARGS=${@:---steps 100 --warmup 10 --no-cpu}
+ARGS=${@:---steps 100 --warmup 10 --no-cpu --no-pmc}  # bench.py runs its own PMC sub-processes: never nest them under rocprofv3
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_$TAG
