@@ -46,10 +46,11 @@ struct Neigh {
   const u32* halo_rgbw;
   int halo_rim;
   float r_vs;       // rcp_refined(voxel size) for the position -> voxel divisions (0: plain IEEE division)
+  bool stencil_known;  // the trilinear stencil of a corner is the 2^3 cells next to the voxel (trilinear_known below)
 };
 __device__ __forceinline__ Neigh neigh_none() {
   Neigh nb;
-  nb.vals = nullptr; nb.base = mki3(0, 0, 0); nb.shift_limit = 0; nb.halo_sdf = nullptr; nb.halo_rgbw = nullptr; nb.halo_rim = 0; nb.r_vs = 0.f;
+  nb.vals = nullptr; nb.base = mki3(0, 0, 0); nb.shift_limit = 0; nb.halo_sdf = nullptr; nb.halo_rgbw = nullptr; nb.halo_rim = 0; nb.r_vs = 0.f; nb.stencil_known = false;
   return nb;
 }
 
@@ -176,6 +177,59 @@ __device__ __forceinline__ bool trilinear(const Map& m, const Tab& t, const Neig
   return true;
 }
 
+// trilinearInterpolation (vds.cu:260-338) for corner `k` of the voxel at local coordinates (lx, ly, lz) of a staged FINE
+// block whose 27-block neighbourhood holds no coarse block, without converting the eight sample positions to voxels: the
+// samples are pos_dual + {0, 1} * vs per axis with pos_dual = (pf +- vs / 2) - vs / 2, i.e. within a few ulp of the voxel
+// centres k - 1, k (corner on the low side) or k, k + 1 (high side).  worldPointToVirtualVoxelPos rounds p / vs to the
+// nearest integer (ties aside), so an error below 0.49 voxel cannot change the cell: with |voxel coordinate| < 2^18
+// (the workgroup checks it) the accumulated rounding error of those few operations stays below 2^18 * 6 * 2^-24 = 0.1.
+// The arithmetic on the positions (the interpolation weights) is the reference's, so the value is bit-identical; only
+// WHICH cells are read is known beforehand.  The raw sample at the corner itself sits on a half-integer and keeps the
+// literal conversion (get_voxel_f).
+__device__ __forceinline__ bool trilinear_known(const Map& m, const Neigh& nb, const f3 pos, const int k, const int lx, const int ly, const int lz,
+                                                float& dist) {
+  const float voxel_size = m.vs * (float) (1 << 0);
+  const f3 pos_dual = mk3(pos.x - voxel_size * 0.5f, pos.y - voxel_size * 0.5f, pos.z - voxel_size * 0.5f);
+  const int bx = lx - ((k & 1) ? 0 : 1), by = ly - ((k & 2) ? 0 : 1), bz = lz - ((k & 4) ? 0 : 1);
+  const int idx0 = ((bz + kHaloRim) * kHaloSide + (by + kHaloRim)) * kHaloSide + (bx + kHaloRim);
+  dist = 0.f;
+  float sdf[8];
+  u32 wmin = 0xFFFFFFFFu;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int o = idx0 + (i & 1) + ((i >> 1) & 1) * kHaloSide + ((i >> 2) & 1) * kHaloSide * kHaloSide;
+    sdf[i] = nb.halo_sdf[o];
+    wmin = umin_(wmin, nb.halo_rgbw[o] >> 24);
+  }
+  if (wmin == 0u) return false;  // vds.cu:283-284: a sample without weight
+  const float x0 = pos_dual.x, y0 = pos_dual.y, z0 = pos_dual.z;
+  float x1 = x0, y1 = y0, z1 = z0;
+  {  // the running maximum over the eight sample positions (vds.cu:311-316): the dx = dy = dz = 1 sample dominates
+    const float xa = pos_dual.x + 0.f * voxel_size, xb = pos_dual.x + 1.f * voxel_size;
+    const float ya = pos_dual.y + 0.f * voxel_size, yb = pos_dual.y + 1.f * voxel_size;
+    const float za = pos_dual.z + 0.f * voxel_size, zb = pos_dual.z + 1.f * voxel_size;
+    if (xa > x1) x1 = xa;
+    if (xb > x1) x1 = xb;
+    if (ya > y1) y1 = ya;
+    if (yb > y1) y1 = yb;
+    if (za > z1) z1 = za;
+    if (zb > z1) z1 = zb;
+  }
+  const float ddx = (x1 - x0) > 1e-6f ? (pos.x - x0) / (x1 - x0) : 0.5f;
+  const float ddy = (y1 - y0) > 1e-6f ? (pos.y - y0) / (y1 - y0) : 0.5f;
+  const float ddz = (z1 - z0) > 1e-6f ? (pos.z - z0) / (z1 - z0) : 0.5f;
+  const float c0 = sdf[0];
+  const float c1 = (sdf[1] - sdf[0]);
+  const float c2 = (sdf[2] - sdf[0]);
+  const float c3 = (sdf[4] - sdf[0]);
+  const float c4 = (sdf[3] - sdf[2] - sdf[1] + sdf[0]);
+  const float c5 = (sdf[6] - sdf[4] - sdf[2] + sdf[0]);
+  const float c6 = (sdf[5] - sdf[4] - sdf[1] + sdf[0]);
+  const float c7 = (sdf[7] - sdf[6] - sdf[5] - sdf[3] + sdf[1] + sdf[4] + sdf[2] - sdf[0]);
+  dist = c0 + c1 * ddx + c2 * ddy + c3 * ddz + c4 * ddx * ddy + c5 * ddy * ddz + c6 * ddx * ddz + c7 * ddx * ddy * ddz;
+  return true;
+}
+
 // mesh_extractor.cu:6-36
 __device__ __forceinline__ mrh_vertex vertex_interp(f3 p1, f3 p2, float d1, float d2, u32 c1, u32 c2) {
   const float isolevel = 0.f;
@@ -279,8 +333,8 @@ __device__ __forceinline__ int mc_voxel(const Map& m, const Tab& t, const Neigh&
 // by the 8 lanes (two each) and stored straight into out[0 .. min(ntri, room)).  Must be called by all 8 lanes of a group
 // (inactive groups pass active = false and take part in the ballots with neutral values).
 template <bool EMIT>
-__device__ __forceinline__ int mc_group(const Map& m, const Tab& t, const Neigh& nb, const f3 pf, const int k, const int gb, const bool active,
-                                        mrh_triangle* out, const int room) {
+__device__ __forceinline__ int mc_group(const Map& m, const Tab& t, const Neigh& nb, const f3 pf, const int v, const int k, const int gb,
+                                        const bool active, mrh_triangle* out, const int room) {
   const float vvs = get_voxel_size_f(m, t, nb, pf);
   const float P = vvs * 0.5f;
   const float M = -P;
@@ -305,13 +359,13 @@ __device__ __forceinline__ int mc_group(const Map& m, const Tab& t, const Neigh&
   }
   const f3 p = mk3(pf.x + ((k & 1) ? sP.x : sM.x), pf.y + ((k & 2) ? sP.y : sM.y), pf.z + ((k & 4) ? sP.z : sM.z));
   float dist = 0.f;
-  const bool valid = trilinear(m, t, nb, p, dist);
-  const VoxSample v = get_voxel_f(m, t, nb, p);
-  const u32 col = v.rgbw;
+  const bool valid = nb.stencil_known ? trilinear_known(m, nb, p, k, v & 7, (v >> 3) & 7, v >> 6, dist) : trilinear(m, t, nb, p, dist);
+  const VoxSample vs_ = get_voxel_f(m, t, nb, p);
+  const u32 col = vs_.rgbw;
   bool bad = false;
   if (!valid) {
-    if ((int) (v.rgbw >> 24) < m.min_weight_threshold) bad = true;
-    else dist = v.sdf;
+    if ((int) (vs_.rgbw >> 24) < m.min_weight_threshold) bad = true;
+    else dist = vs_.sdf;
   }
   const u32 badmask = (u32) (__ballot(bad && active) >> gb) & 0xFFu;
   const u32 cube = (u32) (__ballot(dist < 0.f) >> gb) & 0xFFu;
@@ -466,6 +520,7 @@ __global__ __launch_bounds__(kMcThreads) void k_mc(const Map m, const Tab t, con
       nb.halo_sdf = s_sdf;
       nb.halo_rgbw = s_rgbw;
       nb.halo_rim = rim;
+      nb.stencil_known = !coarse && cmask == 0u && (amax + 2) * kBlockSide < (1 << 18);
     }
     // ---- candidates
     if (!mine) {
@@ -566,7 +621,7 @@ __global__ __launch_bounds__(kMcThreads) void k_mc(const Map m, const Tab t, con
         const int i = base + tid;
         const bool active = i < ncand * 8;
         const int v = s_cand[active ? (i >> 3) : 0];
-        const int ntri = mc_group<false>(m, t, nb, voxel_position(v), corner, gb, active, nullptr, 0);
+        const int ntri = mc_group<false>(m, t, nb, voxel_position(v), v, corner, gb, active, nullptr, 0);
         if (active && corner == 0) s_ntri[v] = (uint8_t) ntri;
       }
       __syncthreads();
@@ -602,7 +657,7 @@ __global__ __launch_bounds__(kMcThreads) void k_mc(const Map m, const Tab t, con
         const int v = s_cand[active ? (i >> 3) : 0];
         const u64 first = offsets[e] + s_off[v];
         const int room = first >= max_tris ? 0 : (int) (max_tris - first < 5 ? max_tris - first : 5);
-        const int ntri = mc_group<true>(m, t, nb, voxel_position(v), corner, gb, active, out + first, room);  // straight to the exact offset
+        const int ntri = mc_group<true>(m, t, nb, voxel_position(v), v, corner, gb, active, out + first, room);  // straight to the exact offset
         if (active && corner == 0 && ntri > room) atomicOr((u32*) &t.ctr[CTR_ERROR], ERR_TRI);
       }
     }
