@@ -46,11 +46,10 @@ struct Neigh {
   const u32* halo_rgbw;
   int halo_rim;
   float r_vs;       // rcp_refined(voxel size) for the position -> voxel divisions (0: plain IEEE division)
-  bool stencil_known;  // the trilinear stencil of a corner is the 2^3 cells next to the voxel (trilinear_known below)
 };
 __device__ __forceinline__ Neigh neigh_none() {
   Neigh nb;
-  nb.vals = nullptr; nb.base = mki3(0, 0, 0); nb.shift_limit = 0; nb.halo_sdf = nullptr; nb.halo_rgbw = nullptr; nb.halo_rim = 0; nb.r_vs = 0.f; nb.stencil_known = false;
+  nb.vals = nullptr; nb.base = mki3(0, 0, 0); nb.shift_limit = 0; nb.halo_sdf = nullptr; nb.halo_rgbw = nullptr; nb.halo_rim = 0; nb.r_vs = 0.f;
   return nb;
 }
 
@@ -178,7 +177,7 @@ __device__ __forceinline__ bool trilinear(const Map& m, const Tab& t, const Neig
 }
 
 // trilinearInterpolation (vds.cu:260-338) for corner `k` of the voxel at local coordinates (lx, ly, lz) of a staged FINE
-// block whose 27-block neighbourhood holds no coarse block, without converting the eight sample positions to voxels: the
+// block, when the voxel's 3^3 cells lie in fine (or absent) blocks only, without converting the eight sample positions to voxels: the
 // samples are pos_dual + {0, 1} * vs per axis with pos_dual = (pf +- vs / 2) - vs / 2, i.e. within a few ulp of the voxel
 // centres k - 1, k (corner on the low side) or k, k + 1 (high side).  worldPointToVirtualVoxelPos rounds p / vs to the
 // nearest integer (ties aside), so an error below 0.49 voxel cannot change the cell: with |voxel coordinate| < 2^18
@@ -333,8 +332,8 @@ __device__ __forceinline__ int mc_voxel(const Map& m, const Tab& t, const Neigh&
 // by the 8 lanes (two each) and stored straight into out[0 .. min(ntri, room)).  Must be called by all 8 lanes of a group
 // (inactive groups pass active = false and take part in the ballots with neutral values).
 template <bool EMIT>
-__device__ __forceinline__ int mc_group(const Map& m, const Tab& t, const Neigh& nb, const f3 pf, const int v, const int k, const int gb,
-                                        const bool active, mrh_triangle* out, const int room) {
+__device__ __forceinline__ int mc_group(const Map& m, const Tab& t, const Neigh& nb, const f3 pf, const int v, const bool stencil_known,
+                                        const int k, const int gb, const bool active, mrh_triangle* out, const int room) {
   const float vvs = get_voxel_size_f(m, t, nb, pf);
   const float P = vvs * 0.5f;
   const float M = -P;
@@ -359,7 +358,7 @@ __device__ __forceinline__ int mc_group(const Map& m, const Tab& t, const Neigh&
   }
   const f3 p = mk3(pf.x + ((k & 1) ? sP.x : sM.x), pf.y + ((k & 2) ? sP.y : sM.y), pf.z + ((k & 4) ? sP.z : sM.z));
   float dist = 0.f;
-  const bool valid = nb.stencil_known ? trilinear_known(m, nb, p, k, v & 7, (v >> 3) & 7, v >> 6, dist) : trilinear(m, t, nb, p, dist);
+  const bool valid = stencil_known ? trilinear_known(m, nb, p, k, v & 7, (v >> 3) & 7, v >> 6, dist) : trilinear(m, t, nb, p, dist);
   const VoxSample vs_ = get_voxel_f(m, t, nb, p);
   const u32 col = vs_.rgbw;
   bool bad = false;
@@ -426,6 +425,23 @@ __global__ __launch_bounds__(256) void k_list_keys(const int4* __restrict__ list
 //      of every voxel's triangles (EMIT) -> canonical (block, voxel, triangle) order, no atomics.
 // Blocks too far from the origin for voxel -> block to be the arithmetic shift skip 2-3 and evaluate every voxel through
 // the neighbour table / the hash (the literal path).
+// does the 3^3 cell neighbourhood of fine voxel v (local index) touch a coarse block?  cmask: bit i = neighbour block i is
+// coarse.  Per axis the cells lie in the own block, plus the previous / next one at local coordinate 0 / 7.
+__device__ __forceinline__ bool voxel_touches_coarse(const int v, const u32 cmask) {
+  if (cmask == 0u) return false;
+  const int x = v & 7, y = (v >> 3) & 7, z = v >> 6;
+  u32 touched = 0;
+#pragma unroll
+  for (int i = 0; i < 27; i++) {
+    const int bx = i % 3, by = (i / 3) % 3, bz = i / 9;
+    const bool tx = bx == 1 || (bx == 0 && x == 0) || (bx == 2 && x == 7);
+    const bool ty = by == 1 || (by == 0 && y == 0) || (by == 2 && y == 7);
+    const bool tz = bz == 1 || (bz == 0 && z == 0) || (bz == 2 && z == 7);
+    touched |= (tx && ty && tz) ? (1u << i) : 0u;
+  }
+  return (touched & cmask) != 0u;
+}
+
 constexpr int kMcThreads = 256;
 constexpr int kMcFillIters = (kHaloCells + kMcThreads - 1) / kMcThreads;  // 11
 template <bool EMIT>
@@ -520,8 +536,9 @@ __global__ __launch_bounds__(kMcThreads) void k_mc(const Map m, const Tab t, con
       nb.halo_sdf = s_sdf;
       nb.halo_rgbw = s_rgbw;
       nb.halo_rim = rim;
-      nb.stencil_known = !coarse && cmask == 0u && (amax + 2) * kBlockSide < (1 << 18);
     }
+    // a fine voxel whose 3^3 cells lie in fine (or absent) blocks has a known trilinear stencil (trilinear_known)
+    const bool fine_known = staged && !coarse && (amax + 2) * kBlockSide < (1 << 18);  // uniform
     // ---- candidates
     if (!mine) {
       // nothing to evaluate
@@ -549,18 +566,7 @@ __global__ __launch_bounds__(kMcThreads) void k_mc(const Map m, const Tab t, con
 #pragma unroll
                 for (int dx = -1; dx <= 1; dx++) acc &= s_cls[0][base + (dz * kHaloSide + dy) * kHaloSide + dx];
             acc1[h] = acc;
-            if (cmask) {  // blocks its 3^3 cells touch: per axis the own block, and the previous / next one at coordinate 0 / 7
-              u32 touched = 0;
-#pragma unroll
-              for (int i = 0; i < 27; i++) {
-                const int bx = i % 3, by = (i / 3) % 3, bz = i / 9;
-                const bool tx = bx == 1 || (bx == 0 && x == 0) || (bx == 2 && x == 7);
-                const bool ty = by == 1 || (by == 0 && y == 0) || (by == 2 && y == 7);
-                const bool tz = bz == 1 || (bz == 0 && z == 0) || (bz == 2 && z == 7);
-                touched |= (tx && ty && tz) ? (1u << i) : 0u;
-              }
-              wide[h] = (touched & cmask) != 0u;
-            }
+            wide[h] = voxel_touches_coarse(v, cmask);
           }
         }
       }
@@ -621,7 +627,7 @@ __global__ __launch_bounds__(kMcThreads) void k_mc(const Map m, const Tab t, con
         const int i = base + tid;
         const bool active = i < ncand * 8;
         const int v = s_cand[active ? (i >> 3) : 0];
-        const int ntri = mc_group<false>(m, t, nb, voxel_position(v), v, corner, gb, active, nullptr, 0);
+        const int ntri = mc_group<false>(m, t, nb, voxel_position(v), v, fine_known && !voxel_touches_coarse(v, cmask), corner, gb, active, nullptr, 0);
         if (active && corner == 0) s_ntri[v] = (uint8_t) ntri;
       }
       __syncthreads();
@@ -657,7 +663,7 @@ __global__ __launch_bounds__(kMcThreads) void k_mc(const Map m, const Tab t, con
         const int v = s_cand[active ? (i >> 3) : 0];
         const u64 first = offsets[e] + s_off[v];
         const int room = first >= max_tris ? 0 : (int) (max_tris - first < 5 ? max_tris - first : 5);
-        const int ntri = mc_group<true>(m, t, nb, voxel_position(v), v, corner, gb, active, out + first, room);  // straight to the exact offset
+        const int ntri = mc_group<true>(m, t, nb, voxel_position(v), v, fine_known && !voxel_touches_coarse(v, cmask), corner, gb, active, out + first, room);  // straight to the exact offset
         if (active && corner == 0 && ntri > room) atomicOr((u32*) &t.ctr[CTR_ERROR], ERR_TRI);
       }
     }
