@@ -147,6 +147,39 @@ def test_lidar_runner_call_sequence_matches_oracle(geowrapper_cls, oracle, tmp_p
     assert np.array_equal(g.getVertices(), Vb) and np.array_equal(g.getFaces(), Fb)
 
 
+def test_lidar_normal_direction_sdf_and_gc_through_the_wrapper(geowrapper_cls, oracle, tmp_path):
+    """GeoWrapper(projective_sdf=False): setPointCloud(points, normals) + compute() with garbage collection on scans, the
+    spherical intrinsics of the sensor given to setCamera — against the oracle driven through the C ABI."""
+    from mrhash_amd import capi
+    from test_lidar import spherical_camera
+
+    cam = spherical_camera(16, 256)
+    p = dict(synth.VBR_PARAMS, min_weight_threshold=1, projective_sdf=False, n_frames_invalidate_voxels=3)
+    g = geowrapper_cls(sdf_truncation=p["sdf_truncation"], sdf_truncation_scale=0.0, integration_weight_sample=1,
+                       virtual_voxel_size=p["virtual_voxel_size"], n_frames_invalidate_voxels=3, voxel_extents_scale=1,
+                       viewer_active=False, marching_cubes_threshold=1.5, min_weight_threshold=1, min_depth=0.2,
+                       max_depth=100.0, projective_sdf=False)
+    g.setCamera(cam["fx"], cam["fy"], cam["cx"], cam["cy"], cam["rows"], cam["cols"], 0.2, 100.0, 1)
+    b = capi.Engine(oracle, capi.Params(num_sdf_blocks=32768, **p))
+    b.set_camera(cam["fx"], cam["fy"], cam["cx"], cam["cy"], cam["rows"], cam["cols"], 0.2, 100.0, model=1)
+    scene = synth.street_canyon()
+    for t, q in synth.drive_poses(5, step=2.0):
+        pts = synth.lidar_scan(scene, t, q, rows=16, cols=256)
+        nrm = synth.scan_normals(pts)
+        g.setCurrPose(t, q)
+        g.setPointCloud(pts, nrm)
+        g.compute()
+        b.set_pose(synth.quat_to_rot(q), t)
+        b.upload_points(pts)
+        b.upload_normals(nrm)
+        b.integrate_points()
+    g.extractMesh(str(tmp_path / "lidar_n.ply"))
+    b.extract_triangles()
+    Vb, Fb, _ = b.extract_mesh()
+    assert len(Fb) > 200
+    assert np.array_equal(g.getVertices(), Vb) and np.array_equal(g.getFaces(), Fb)
+
+
 @pytest.mark.parametrize("var_threshold", [0.0, 0.02])
 def test_streamer_pages_far_blocks_out_and_back(monkeypatch, tmp_path, var_threshold):
     """Streamer: with a pool too small for the whole walk, compute() pages blocks farther than max_depth
