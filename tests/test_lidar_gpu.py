@@ -190,6 +190,22 @@ def test_variance_adaptive_scans_match_oracle(hip, oracle, gc):
     pu.compare_meshes(a, b)
 
 
+def test_softmath_is_bit_identical_on_device_and_host(tmp_path):
+    """include/mrh_softmath.h compiled for gfx950 and for the host by hipcc with the arithmetic-spec flags: sin, cos, atan2
+    and asin of 2^20 random arguments each, every result the same bits on both sides (tools/micro/softmath_check.hip)."""
+    import os
+    import shutil
+    import subprocess
+
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    src = os.path.join(pu.ROOT, "tools", "micro", "softmath_check.hip")
+    exe = str(tmp_path / "softmath_check")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wno-unused-result",
+                    src, "-o", exe], check=True, capture_output=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "mismatches sin 0 cos 0 atan2 0 asin 0" in r.stdout, r.stdout + r.stderr
+
+
 @pytest.mark.parametrize("var_threshold", [0.0, 0.05])
 def test_spherical_depth_images_match_oracle(hip, oracle, var_threshold):
     """The image path under the spherical camera model (camera.cuh:91-99, :147-164, :184-201): range images of the street
