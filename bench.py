@@ -177,7 +177,7 @@ def pmc_traffic(args, kernel_prefix: str, cache: str):
         cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__), "--pmc-inner",
                "--steps", str(args.steps), "--warmup", str(args.warmup), "--blocks", str(args.blocks), "--frames-cache", cache]
         try:
-            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=420)
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=180)
         except subprocess.TimeoutExpired:
             shutil.rmtree(d, ignore_errors=True)
             return None, f"rocprofv3 --pmc {counter} timed out"
