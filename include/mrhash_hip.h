@@ -338,6 +338,18 @@ int mrh_import_blocks(mrh_ctx* ctx, const mrh_block_desc* descs, const mrh_voxel
  * single-GPU order.  Buffers are owned by ctx until the next extraction. */
 int mrh_get_triangle_blocks(mrh_ctx* ctx, const mrh_block_desc** out_descs, const uint32_t** out_counts, uint64_t* out_n);
 
+/* The triangle soup of the last mrh_extract_triangles / mrh_process_triangle_runs where the library keeps it (device memory
+ * for the HIP library: *out_is_device_memory = 1), valid until the next extraction: what a rank hands to a collective. */
+int mrh_get_triangles_device(mrh_ctx* ctx, const mrh_triangle** out_triangles, uint64_t* out_n, int* out_is_device_memory);
+
+/* Rank 0 of a sharded extraction: per-block runs of triangles from all ranks — descs[i] / counts[i] in host memory (a few
+ * bytes per block), the triangles of run i following those of run i - 1 in `triangles` (device memory iff
+ * is_device_memory, e.g. the output of an all-gather) — are brought into the canonical single-GPU order (block position)
+ * on the device and post-processed (MeshExtractor::processTriangles); results through mrh_extract_mesh,
+ * mrh_get_triangle_blocks and mrh_get_triangles_device. */
+int mrh_process_triangle_runs(mrh_ctx* ctx, const mrh_block_desc* descs, const uint32_t* counts, uint64_t n_blocks,
+                              const mrh_triangle* triangles, uint64_t n_triangles, int is_device_memory);
+
 /* MeshExtractor::processTriangles (mesh_extractor.cpp:9-76) on a caller-supplied triangle buffer; the result is
  * read back with mrh_extract_mesh.  Used by rank 0 on the merged buffer of all shards. */
 int mrh_process_triangles(mrh_ctx* ctx, const mrh_triangle* triangles, uint64_t n);

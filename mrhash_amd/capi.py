@@ -114,7 +114,7 @@ ABI_SYMBOLS = (
     "mrh_splat_seeds mrh_get_qtree_leaves mrh_peek_free_blocks mrh_peek_error_flags "
     "mrh_set_sharding mrh_pack_blocks mrh_unpack_blocks mrh_drop_blocks "
     "mrh_extract_triangles mrh_extract_mesh mrh_get_stats mrh_set_profile mrh_dump_blocks "
-    "mrh_get_voxel mrh_import_blocks mrh_get_triangle_blocks mrh_process_triangles mrh_selftest_division mrh_version"
+    "mrh_get_voxel mrh_import_blocks mrh_get_triangle_blocks mrh_get_triangles_device mrh_process_triangle_runs mrh_process_triangles mrh_selftest_division mrh_version"
 ).split()
 
 
@@ -164,6 +164,8 @@ def _declare(lib: C.CDLL) -> C.CDLL:
     lib.mrh_import_blocks.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
     lib.mrh_get_triangle_blocks.argtypes = [C.c_void_p, P(C.c_void_p), P(C.c_void_p), P(C.c_uint64)]
     lib.mrh_process_triangles.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+    lib.mrh_get_triangles_device.argtypes = [C.c_void_p, P(C.c_void_p), P(C.c_uint64), P(C.c_int)]
+    lib.mrh_process_triangle_runs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_int]
     lib.mrh_selftest_division.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, P(C.c_uint64)]
     lib.mrh_version.argtypes = []
     lib.mrh_version.restype = C.c_char_p
@@ -481,6 +483,19 @@ class Engine:
         d = np.frombuffer((C.c_char * (n.value * 16)).from_address(pd.value), dtype=DESC_DTYPE).copy()
         c = np.frombuffer((C.c_char * (n.value * 4)).from_address(pc.value), dtype=np.uint32).copy()
         return d, c
+
+    def triangles_device(self) -> Tuple[int, int, bool]:
+        """(pointer, number of triangles, is_device_memory) of the soup of the last extraction / run merge, where the library keeps it."""
+        ptr, n, dev = C.c_void_p(), C.c_uint64(), C.c_int()
+        self._check(self.lib.mrh_get_triangles_device(self._ctx, C.byref(ptr), C.byref(n), C.byref(dev)))
+        return int(ptr.value or 0), int(n.value), bool(dev.value)
+
+    def process_triangle_runs(self, descs: np.ndarray, counts: np.ndarray, tris_ptr: int, n_tris: int, is_device: bool):
+        """Per-block triangle runs of all ranks (descs / counts: host arrays; triangles: one buffer, device or host) ->
+        canonical order + mesh post-process (rank 0 of a sharded extraction)."""
+        d = np.ascontiguousarray(descs, dtype=DESC_DTYPE)
+        c = np.ascontiguousarray(counts, dtype=np.uint32)
+        self._check(self.lib.mrh_process_triangle_runs(self._ctx, d.ctypes.data, c.ctypes.data, len(d), tris_ptr, n_tris, 1 if is_device else 0))
 
     def process_triangles(self, tris: np.ndarray):
         t = np.ascontiguousarray(tris, dtype=TRI_DTYPE).reshape(-1, 3)

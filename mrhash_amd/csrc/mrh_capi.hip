@@ -200,6 +200,7 @@ struct mrh_ctx {
   u32 flags_seen = 0, flags_deferred = 0, flags_peeked = 0;
   // multi-GPU block exchange
   char* d_pack = nullptr; size_t pack_cap = 0;      // mrh_pack_blocks result (records)
+  mrh_triangle* d_soup = nullptr; size_t soup_cap = 0, soup_n = 0;  // triangle soup of the last extraction / run merge (mrh_get_triangles_device)
   int4* d_halo = nullptr; size_t halo_cap = 0, halo_upper = 0;  // blocks brought in by MRH_UNPACK_HALO (upper bound of the device count)
   u32* d_taken = nullptr;
   // marching cubes timing (mrh_stats)
@@ -265,7 +266,7 @@ void free_all(mrh_ctx* c) {
   if (c->h_peek) (void) hipHostFree(c->h_peek);
   F(c->d_decision); F(c->d_zbuf); F(c->d_realloc); F(c->d_reint); F(c->d_flag);
   F(c->d_upd_partials); F(c->d_misc); F(c->d_rcp_w); F(c->d_cfree); F(c->d_zmin); F(c->d_points); F(c->d_pt_counts); F(c->d_pt_offsets); F(c->d_rec_keys[0]); F(c->d_rec_keys[1]); F(c->d_rec_vals[0]); F(c->d_rec_vals[1]); F(c->d_sort_tmp); F(c->fast.summary); F(c->fast.summary_c); F(c->fast.bbox); F(c->d_cnt_partials);
-  F(c->d_pack); F(c->d_halo); F(c->d_taken); F(c->d_cloud); F(c->d_normals);
+  F(c->d_pack); F(c->d_halo); F(c->d_taken); F(c->d_cloud); F(c->d_normals); F(c->d_soup);
   for (hipEvent_t e : c->mc_ev) if (e) (void) hipEventDestroy(e);
   F(c->d_qt_sums); F(c->d_qt_flags); F(c->d_qt_unc); F(c->d_qt_marks); F(c->d_qt_pos); F(c->d_qt_parked); F(c->d_qt_seeds); F(c->d_qt_leaves); F(c->d_qt_misc); F(c->d_qt_tmp);
   for (auto& e : c->ev_pool) { (void) hipEventDestroy(e.a); (void) hipEventDestroy(e.b); }
@@ -521,6 +522,19 @@ done:
 }
 
 
+
+// the soup buffer: grow-only, owned by the context, valid until the next extraction
+int ensure_soup(mrh_ctx* c, size_t n) {
+  if (n > c->soup_cap) {
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->d_soup) HIP_TRY(c, hipFree(c->d_soup));
+    c->d_soup = nullptr; c->soup_cap = 0;
+    const size_t cap = n + n / 8;
+    HIP_TRY(c, hipMalloc((void**) &c->d_soup, cap * sizeof(mrh_triangle)));
+    c->soup_cap = cap;
+  }
+  return MRH_OK;
+}
 
 int ensure_zbuf(mrh_ctx* c, size_t npix) {
   if (c->zbuf_n < npix) {
@@ -1449,7 +1463,7 @@ int mrh_splat_seeds(mrh_ctx* c, float qtree_thresh, int qtree_min_pixel_size, co
   if (qt.total != c->qt.total || !c->d_qt_sums) {
     HIP_TRY(c, hipStreamSynchronize(s));
     auto F = [](auto*& p) { if (p) (void) hipFree(p); p = nullptr; };
-    F(c->d_pack); F(c->d_halo); F(c->d_taken); F(c->d_cloud); F(c->d_normals);
+    F(c->d_pack); F(c->d_halo); F(c->d_taken); F(c->d_cloud); F(c->d_normals); F(c->d_soup);
   for (hipEvent_t e : c->mc_ev) if (e) (void) hipEventDestroy(e);
   F(c->d_qt_sums); F(c->d_qt_flags); F(c->d_qt_unc); F(c->d_qt_marks); F(c->d_qt_pos); F(c->d_qt_parked); F(c->d_qt_seeds); F(c->d_qt_leaves); F(c->d_qt_misc);
     const size_t n = qt.total;
@@ -1658,6 +1672,7 @@ int mrh_extract_triangles(mrh_ctx* c, const mrh_triangle** out_tris, uint64_t* o
   c->tri_blocks.clear();
   c->tri_counts.clear();
   c->last_triangles = 0;
+  c->soup_n = 0;
   bool processed = false;
   if (n > 0) {
     // canonical order: sort the block list by position (packed-key order == (x,y,z) order) — on the device; the host
@@ -1710,8 +1725,10 @@ int mrh_extract_triangles(mrh_ctx* c, const mrh_triangle** out_tris, uint64_t* o
       return fail(c, MRH_ERR_CAPACITY, "triangle buffer full: %llu triangles > max_triangles %llu", (unsigned long long) total, (unsigned long long) c->max_triangles);
     }
     if (total > 0) {
-      DevBuf<mrh_triangle> d_tris;
-      HIP_TRY(c, d_tris.alloc(total));
+      rc = ensure_soup(c, (size_t) total);
+      if (rc) return rc;
+      mrh_triangle* d_tris = c->d_soup;
+      c->soup_n = (size_t) total;
       HIP_TRY(c, hipMemcpyAsync(d_offsets, offsets.data(), (size_t) n * sizeof(u64), hipMemcpyHostToDevice, s));
       hipExtLaunchKernelGGL((k_mc<true>), dim3(grid), dim3(kMcThreads), 0, s, c->mc_ev[2], c->mc_ev[3], 0u, c->map, c->tab, (const int4*) c->tab.compact, n,
                             (u32*) d_counts, (const u64*) d_offsets, (mrh_triangle*) d_tris, (u64) total, (uint8_t*) d_per_voxel, 0.f);
@@ -2066,6 +2083,77 @@ int mrh_process_triangles(mrh_ctx* c, const mrh_triangle* triangles, uint64_t n)
   HIP_TRY(c, d_tris.alloc(n));
   HIP_TRY(c, hipMemcpyAsync(d_tris, triangles, n * sizeof(mrh_triangle), hipMemcpyHostToDevice, c->stream));
   return process_triangles_device(c, d_tris, n);
+}
+
+int mrh_get_triangles_device(mrh_ctx* c, const mrh_triangle** out, uint64_t* out_n, int* out_is_device_memory) {
+  if (!c || !out || !out_n) return MRH_ERR_INVALID_ARG;
+  *out = c->soup_n ? c->d_soup : nullptr;
+  *out_n = c->soup_n;
+  if (out_is_device_memory) *out_is_device_memory = 1;
+  return MRH_OK;
+}
+
+int mrh_process_triangle_runs(mrh_ctx* c, const mrh_block_desc* descs, const uint32_t* counts, uint64_t n_blocks, const mrh_triangle* triangles,
+                              uint64_t n_triangles, int is_device_memory) {
+  int rc = ensure_ready(c, "mrh_process_triangle_runs");
+  if (rc) return rc;
+  if ((n_blocks && (!descs || !counts)) || (n_triangles && !triangles)) return fail(c, MRH_ERR_INVALID_ARG, "mrh_process_triangle_runs: null argument");
+  hipStream_t s = c->stream;
+  // runs in input order -> canonical order (block position): a host sort of the few-byte descriptors, a device permutation
+  // of the 72-byte triangles
+  std::vector<uint64_t> src_off(n_blocks);
+  uint64_t total = 0;
+  for (uint64_t i = 0; i < n_blocks; i++) { src_off[i] = total; total += counts[i]; }
+  if (total != n_triangles) return fail(c, MRH_ERR_INVALID_ARG, "mrh_process_triangle_runs: the counts add up to %llu triangles, %llu given", (unsigned long long) total, (unsigned long long) n_triangles);
+  std::vector<uint32_t> order(n_blocks);
+  for (uint64_t i = 0; i < n_blocks; i++) order[i] = (uint32_t) i;
+  std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+    if (descs[a].x != descs[b].x) return descs[a].x < descs[b].x;
+    if (descs[a].y != descs[b].y) return descs[a].y < descs[b].y;
+    return descs[a].z < descs[b].z;
+  });
+  c->tri_blocks.resize(n_blocks);
+  c->tri_counts.resize(n_blocks);
+  std::vector<ulonglong2> runs;  // {source offset, destination offset | count << 40}
+  runs.reserve(n_blocks);
+  uint64_t dst = 0;
+  for (uint64_t k = 0; k < n_blocks; k++) {
+    const uint32_t i = order[k];
+    c->tri_blocks[k] = descs[i];
+    c->tri_counts[k] = counts[i];
+    if (counts[i]) runs.push_back(make_ulonglong2(src_off[i], dst | ((uint64_t) counts[i] << 40)));
+    dst += counts[i];
+  }
+  c->tris.clear();
+  c->last_triangles = n_triangles;
+  c->soup_n = 0;
+  if (n_triangles == 0) { c->V.clear(); c->C.clear(); c->F.clear(); return MRH_OK; }
+  if (n_triangles >= (1ull << 40)) return fail(c, MRH_ERR_CAPACITY, "mrh_process_triangle_runs: too many triangles");
+  rc = ensure_soup(c, (size_t) n_triangles);
+  if (rc) return rc;
+  DevBuf<mrh_triangle> staged;
+  const mrh_triangle* d_in = triangles;
+  if (!is_device_memory) {
+    HIP_TRY(c, staged.alloc(n_triangles));
+    HIP_TRY(c, hipMemcpyAsync(staged, triangles, n_triangles * sizeof(mrh_triangle), hipMemcpyHostToDevice, s));
+    d_in = staged;
+  }
+  DevBuf<ulonglong2> d_runs;
+  HIP_TRY(c, d_runs.alloc(runs.size()));
+  HIP_TRY(c, hipMemcpyAsync(d_runs, runs.data(), runs.size() * sizeof(ulonglong2), hipMemcpyHostToDevice, s));
+  k_permute_runs<<<(int) std::min<size_t>(runs.size(), 8192), 256, 0, s>>>((const ulonglong2*) d_runs, (int) runs.size(), (const uint4*) d_in, (uint4*) c->d_soup);
+  c->soup_n = (size_t) n_triangles;
+  if (c->mesh_on_host) {
+    c->tris.resize_discard(n_triangles);
+    HIP_TRY(c, hipMemcpyAsync(c->tris.data(), c->d_soup, n_triangles * sizeof(mrh_triangle), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    process_triangles(c);
+    return MRH_OK;
+  }
+  rc = process_triangles_device(c, c->d_soup, n_triangles);
+  HIP_TRY(c, hipStreamSynchronize(s));
+  HIP_TRY(c, hipGetLastError());
+  return rc;
 }
 
 int mrh_selftest_division(mrh_ctx* c, uint64_t samples, uint64_t seed, uint64_t* out_mismatches) {

@@ -149,4 +149,16 @@ inline hipError_t mesh_sort96(void* tmp, size_t tmp_bytes, const u32* hi, const 
   return rocprim::radix_sort_pairs(tmp, tmp_bytes, hi_gathered, hi_sorted, order_mid, order_out, n, 0, 32, s);
 }
 
+// per-block triangle runs of several ranks -> one buffer in canonical block order (mrh_process_triangle_runs): run r copies
+// count triangles (72 B = 4.5 x uint4, moved as 9 x 8-byte words) from src to dst
+__global__ __launch_bounds__(256) void k_permute_runs(const ulonglong2* __restrict__ runs, const int n_runs, const uint4* __restrict__ in, uint4* __restrict__ out) {
+  for (int r = blockIdx.x; r < n_runs; r += gridDim.x) {
+    const ulonglong2 run = runs[r];
+    const size_t src = (size_t) run.x, dst = (size_t) (run.y & ((1ull << 40) - 1)), cnt = (size_t) (run.y >> 40);
+    const unsigned long long* a = (const unsigned long long*) in + src * 9;
+    unsigned long long* b = (unsigned long long*) out + dst * 9;
+    for (size_t w = threadIdx.x; w < cnt * 9; w += 256) b[w] = a[w];
+  }
+}
+
 }  // namespace mrh

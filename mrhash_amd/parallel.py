@@ -243,42 +243,63 @@ def merge_submaps(engine: capi.Engine, dist, chunk_log2: int = 3) -> dict:
 
 
 def gather_mesh(engine: capi.Engine, dist) -> Optional[Tuple[np.ndarray, np.ndarray, np.ndarray, np.ndarray]]:
-    """Every rank extracts the triangles of the blocks it owns; rank 0 merges the per-block runs by block position
-    (the canonical order) and runs the mesh post-process.  Returns (triangles, V, F, C) on rank 0, None elsewhere."""
+    """Every rank extracts the triangles of the blocks it owns; rank 0 brings the per-block runs of all ranks into the
+    canonical single-GPU order (block position) and runs the mesh post-process.  The triangles stay where the library keeps
+    them: the soup of the extraction is a device buffer (`mrh_get_triangles_device`), one `all_gather_into_tensor` moves it
+    (padded to the largest rank's count), and `mrh_process_triangle_runs` permutes the runs on the device; only the
+    per-block descriptors and counts (20 bytes a block) travel as host-side metadata.  Returns (triangles, V, F, C) on
+    rank 0, None elsewhere."""
     import torch
 
     world, rank = dist.get_world_size(), dist.get_rank()
     dev = _comm_device(dist)
-    tris = engine.extract_triangles()
+    engine.extract_triangles(soup=False)  # the soup stays in the library's memory
+    ptr, nt, on_device = engine.triangles_device()
     descs, counts = engine.triangle_blocks()
     keep = counts > 0
-    nb, nt = int(keep.sum()), int(tris.shape[0])
-    blob = np.concatenate([np.frombuffer(descs[keep].tobytes(), np.uint8), np.frombuffer(counts[keep].tobytes(), np.uint8),
-                           np.frombuffer(tris.tobytes(), np.uint8)]) if nb else np.zeros(0, np.uint8)
-    sizes = _all_gather_counts(dist, [nb, nt, len(blob)], dev)
-    mx = max(int(sizes[:, 2].max()), 1)
-    send = torch.zeros(mx, dtype=torch.uint8, device=dev)
-    if len(blob):
-        send[: len(blob)].copy_(torch.from_numpy(blob))
-    recv = torch.empty(world * mx, dtype=torch.uint8, device=dev)
+    nb = int(keep.sum())
+    sizes = _all_gather_counts(dist, [nb, nt], dev)
+    max_b, max_t = max(int(sizes[:, 0].max()), 1), max(int(sizes[:, 1].max()), 1)
+    meta = np.zeros(max_b * 20, np.uint8)
+    if nb:
+        meta[: nb * 16] = np.frombuffer(descs[keep].tobytes(), np.uint8)
+        meta[max_b * 16: max_b * 16 + nb * 4] = np.frombuffer(counts[keep].astype(np.uint32).tobytes(), np.uint8)
+    meta_t = torch.from_numpy(meta).to(dev)
+    all_meta = torch.empty(world * max_b * 20, dtype=torch.uint8, device=dev)
+    dist.all_gather_into_tensor(all_meta, meta_t)
+    send = torch.zeros(max_t * 72, dtype=torch.uint8, device=dev)
+    if nt:
+        send[: nt * 72].copy_(_bytes_view(ptr, nt * 72, on_device))  # device-to-device on the nccl path
+    recv = torch.empty(world * max_t * 72, dtype=torch.uint8, device=dev)
     dist.all_gather_into_tensor(recv, send)
     if rank != 0:
         return None
-    host = recv.cpu().numpy()
-    all_d, all_c, all_t = [], [], []
+    if recv.is_cuda:
+        torch.cuda.synchronize()
+    host_meta = all_meta.cpu().numpy()
+    all_d, all_c = [], []
     for r in range(world):
-        b, t = int(sizes[r, 0]), int(sizes[r, 1])
-        p = host[r * mx: r * mx + int(sizes[r, 2])]
-        all_d.append(np.frombuffer(p[: 16 * b].tobytes(), dtype=capi.DESC_DTYPE))
-        all_c.append(np.frombuffer(p[16 * b: 20 * b].tobytes(), dtype=np.uint32))
-        all_t.append(np.frombuffer(p[20 * b: 20 * b + t * 72].tobytes(), dtype=capi.TRI_DTYPE).reshape(t, 3))
-    d, c, t = np.concatenate(all_d), np.concatenate(all_c).astype(np.int64), np.concatenate(all_t)
-    # per-block runs ordered by block position (every block is owned by exactly one rank): one gather, no Python loop
-    starts = np.concatenate([[0], np.cumsum(c)])[:-1]
-    order = np.lexsort((d["z"], d["y"], d["x"]))
-    lens = c[order]
-    idx = np.repeat(starts[order] - np.concatenate([[0], np.cumsum(lens)])[:-1], lens) + np.arange(int(lens.sum()))
-    merged = t[idx] if len(idx) else np.zeros((0, 3), dtype=capi.TRI_DTYPE)
-    engine.process_triangles(merged)
+        b = int(sizes[r, 0])
+        m = host_meta[r * max_b * 20: (r + 1) * max_b * 20]
+        all_d.append(np.frombuffer(m[: 16 * b].tobytes(), dtype=capi.DESC_DTYPE))
+        all_c.append(np.frombuffer(m[max_b * 16: max_b * 16 + 4 * b].tobytes(), dtype=np.uint32))
+    # the ranks' soups, closed up (each segment of `recv` is padded to max_t triangles)
+    total = int(sizes[:, 1].sum())
+    packed = torch.empty(max(total, 1) * 72, dtype=torch.uint8, device=dev)
+    off = 0
+    for r in range(world):
+        t = int(sizes[r, 1])
+        if t:
+            packed[off * 72: (off + t) * 72].copy_(recv[r * max_t * 72: (r * max_t + t) * 72])
+        off += t
+    if packed.is_cuda:
+        torch.cuda.synchronize()
+    engine.process_triangle_runs(np.concatenate(all_d), np.concatenate(all_c), packed.data_ptr(), total, packed.is_cuda)
     V, F, C = engine.extract_mesh()
+    mptr, mn, mdev = engine.triangles_device()
+    if mn:
+        raw = _bytes_view(mptr, mn * 72, mdev)
+        merged = np.frombuffer((raw.cpu() if mdev else raw).numpy().tobytes(), dtype=capi.TRI_DTYPE).reshape(mn, 3)
+    else:
+        merged = np.zeros((0, 3), dtype=capi.TRI_DTYPE)
     return merged, V, F, C

@@ -2115,6 +2115,52 @@ int mrh_get_triangle_blocks(mrh_ctx* c, const mrh_block_desc** d, const uint32_t
   return MRH_OK;
 }
 
+int mrh_get_triangles_device(mrh_ctx* c, const mrh_triangle** out, uint64_t* out_n, int* out_is_device_memory) {
+  if (!c || !out || !out_n) return MRH_ERR_INVALID_ARG;
+  *out = c->ntris ? c->tris : NULL;
+  *out_n = c->ntris;
+  if (out_is_device_memory) *out_is_device_memory = 0;
+  return MRH_OK;
+}
+
+typedef struct { mrh_block_desc d; uint32_t count; uint64_t src; } TriRun;
+static int cmp_run_pos(const void* a, const void* b) {
+  const TriRun* x = (const TriRun*) a;
+  const TriRun* y = (const TriRun*) b;
+  if (x->d.x != y->d.x) return x->d.x < y->d.x ? -1 : 1;
+  if (x->d.y != y->d.y) return x->d.y < y->d.y ? -1 : 1;
+  if (x->d.z != y->d.z) return x->d.z < y->d.z ? -1 : 1;
+  return x->src < y->src ? -1 : (x->src > y->src ? 1 : 0);
+}
+/* rank 0 of a sharded extraction (no reference counterpart): per-block runs -> canonical block order -> processTriangles */
+int mrh_process_triangle_runs(mrh_ctx* c, const mrh_block_desc* descs, const uint32_t* counts, uint64_t n_blocks, const mrh_triangle* tris,
+                              uint64_t n_tris, int is_device_memory) {
+  if (!c || (n_blocks && (!descs || !counts)) || (n_tris && !tris)) return MRH_ERR_INVALID_ARG;
+  (void) is_device_memory;
+  TriRun* runs = (TriRun*) malloc((size_t) (n_blocks ? n_blocks : 1) * sizeof(TriRun));
+  uint64_t total = 0;
+  for (uint64_t i = 0; i < n_blocks; i++) { runs[i].d = descs[i]; runs[i].count = counts[i]; runs[i].src = total; total += counts[i]; }
+  if (total != n_tris) { free(runs); return fail(c, MRH_ERR_INVALID_ARG, "mrh_process_triangle_runs: counts and triangles disagree"); }
+  qsort(runs, (size_t) n_blocks, sizeof(TriRun), cmp_run_pos);
+  mrh_triangle* merged = (mrh_triangle*) malloc((size_t) (n_tris ? n_tris : 1) * sizeof(mrh_triangle));
+  free(c->tri_blocks); free(c->tri_counts);
+  c->tri_blocks = (mrh_block_desc*) calloc(n_blocks ? n_blocks : 1, sizeof(mrh_block_desc));
+  c->tri_counts = (uint32_t*) calloc(n_blocks ? n_blocks : 1, sizeof(uint32_t));
+  c->n_tri_blocks = n_blocks;
+  uint64_t dst = 0;
+  for (uint64_t k = 0; k < n_blocks; k++) {
+    memcpy(merged + dst, tris + runs[k].src, (size_t) runs[k].count * sizeof(mrh_triangle));
+    c->tri_blocks[k] = runs[k].d;
+    c->tri_counts[k] = runs[k].count;
+    dst += runs[k].count;
+  }
+  free(runs);
+  free(c->tris);
+  c->tris = merged; c->ntris = n_tris; c->cap_tris = n_tris ? n_tris : 1;
+  process_triangles(c);
+  return MRH_OK;
+}
+
 int mrh_process_triangles(mrh_ctx* c, const mrh_triangle* tris, uint64_t n) {
   if (!c || (n && !tris)) return MRH_ERR_INVALID_ARG;
   mrh_triangle* copy = (mrh_triangle*) malloc((n ? n : 1) * sizeof(mrh_triangle));

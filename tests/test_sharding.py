@@ -205,7 +205,8 @@ def check_merged_against_single(lib, tmp_path, got):
             both, only_b = (w0 > 0) & (w1 > 0), (w0 == 0) & (w1 > 0)
             out = a.copy()
             out[only_b] = b[only_b]
-            s = (a["sdf"] * w0.astype(np.float32) + b["sdf"] * w1.astype(np.float32)) / (w0 + w1).astype(np.float32)
+            with np.errstate(invalid="ignore", divide="ignore"):
+                s = (a["sdf"] * w0.astype(np.float32) + b["sdf"] * w1.astype(np.float32)) / (w0 + w1).astype(np.float32)
             out["sdf"][both] = s[both]
             out["sum_squared"][both] = b["sum_squared"][both]
             out["weight"][both] = np.minimum(255, w0 + w1)[both].astype(np.uint8)
