@@ -84,14 +84,15 @@ __device__ __forceinline__ RayState ray_from_segment(const Map& m, const f3 pw_m
   const i3 end = world_to_block_fast(grid, pw_max, m.block_shift_limit);
   const f3 step = mk3((float) signi(dir.x), (float) signi(dir.y), (float) signi(dir.z));
   r.step = mki3(signi(dir.x), signi(dir.y), signi(dir.z));
-  const i3 nb = mki3(r.cur.x + f2i(clampf(step.x, 0.0f, 1.f)), r.cur.y + f2i(clampf(step.y, 0.0f, 1.f)), r.cur.z + f2i(clampf(step.z, 0.0f, 1.f)));
+  // int(clamp(step, 0, 1)) is 1 for a positive step and 0 otherwise (step is -1, 0 or +1)
+  const i3 nb = mki3(r.cur.x + (r.step.x > 0 ? 1 : 0), r.cur.y + (r.step.y > 0 ? 1 : 0), r.cur.z + (r.step.z > 0 ? 1 : 0));
   const f3 bw = voxel_to_world(m.vs, mki3(nb.x * kBlockSide, nb.y * kBlockSide, nb.z * kBlockSide));
   const f3 boundary = mk3(bw.x - 0.5f * m.vs, bw.y - 0.5f * m.vs, bw.z - 0.5f * m.vs);
   const f3 rd = mk3(rcp_refined(dir.x), rcp_refined(dir.y), rcp_refined(dir.z));
   r.t_max = mk3(div_rr(boundary.x - pw_min.x, dir.x, rd.x), div_rr(boundary.y - pw_min.y, dir.y, rd.y), div_rr(boundary.z - pw_min.z, dir.z, rd.z));
   r.t_delta = mk3(div_rr(step.x * (float) kBlockSide * m.vs, dir.x, rd.x), div_rr(step.y * (float) kBlockSide * m.vs, dir.y, rd.y),
                   div_rr(step.z * (float) kBlockSide * m.vs, dir.z, rd.z));
-  r.bound = mki3(f2i((float) end.x + step.x), f2i((float) end.y + step.y), f2i((float) end.z + step.z));
+  r.bound = mki3(f2i_hw((float) end.x + step.x), f2i_hw((float) end.y + step.y), f2i_hw((float) end.z + step.z));
   // vds.cu:801-827 (the second test of each pair compares a position with a direction; kept literally)
   const bool gx = (fabsf(dir.x) < kFloatEps) || (fabsf(boundary.x - dir.x) < kFloatEps);
   const bool gy = (fabsf(dir.y) < kFloatEps) || (fabsf(boundary.y - dir.y) < kFloatEps);
@@ -120,14 +121,18 @@ __device__ __forceinline__ bool ray_keys_in_range(const RayState& r) {
 }
 template <typename V>
 __device__ __forceinline__ bool walk_ray_lean(const Map& m, RayState r, V&& visit) {
+  // the packed key follows the walk by addition: one step along an axis changes its 21-bit field by +-1, and every block
+  // between the first one and `bound` is representable (ray_keys_in_range), so no field ever carries into its neighbour
+  u64 key;
+  pack_key(r.cur, key);
+  const u64 dkx = (u64) ((long long) r.step.x * (1ll << 42)), dky = (u64) ((long long) r.step.y * (1ll << 21)), dkz = (u64) (long long) r.step.z;
 #pragma unroll 1
   for (u32 iter = 0; iter < kMaxDdaIter; iter++) {
-    u64 key;
-    pack_key(r.cur, key);
     if (owns_block(m, r.cur) && !visit(r.cur, key)) return false;
     const bool ax = r.t_max.x < r.t_max.y && r.t_max.x < r.t_max.z;
     const bool az = !ax && (r.t_max.z < r.t_max.y);
     const bool ay = !ax && !az;
+    key += ax ? dkx : (ay ? dky : dkz);
     r.cur.x += ax ? r.step.x : 0;
     r.cur.y += ay ? r.step.y : 0;
     r.cur.z += az ? r.step.z : 0;
