@@ -654,6 +654,43 @@ def test_upload_ring_semantics(hip, oracle):
     b.close()
 
 
+def test_two_contexts_on_two_host_threads_share_the_copy_pool(hip, oracle):
+    """The helper threads that share the setters' staging copies are one pool per process: two contexts driven from two
+    host threads upload 640x480 frames concurrently (ctypes releases the GIL inside the calls); both maps must equal the
+    oracle's."""
+    import threading
+
+    streams = [list(synth.replica_stream(6)), list(synth.scannet_stream(6, start=10))]
+    Ks = [synth.REPLICA_640, synth.SCANNET]
+    engines = [pu.make_engine(hip, Ks[i], synth.REPLICA_PARAMS, 65536) for i in range(2)]
+    errors = []
+
+    def drive(i):
+        try:
+            for rep in range(3):  # the same frames three times: more uploads in flight, same final weights x3
+                for f in streams[i]:
+                    pu.feed(engines[i], f)
+            engines[i].sync()
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    th = [threading.Thread(target=drive, args=(i,)) for i in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
+    for i in range(2):
+        b = pu.make_engine(oracle, Ks[i], synth.REPLICA_PARAMS, 65536)
+        for rep in range(3):
+            for f in streams[i]:
+                pu.feed(b, f)
+        r = pu.compare_maps(engines[i], b)
+        assert r["blocks"] > 3000 and r["sdf_bit_exact"]
+        b.close()
+        engines[i].close()
+
+
 def test_marching_cubes_prescreen_changes_nothing(hip, monkeypatch):
     """The count pass skips voxels whose 27 surrounding cells are all clearly positive or all clearly negative; with
     the prescreen off (MRH_MC_NO_PRESCREEN=1) every voxel takes the full path: same triangle buffer, byte for byte —
