@@ -217,82 +217,50 @@ __global__ __launch_bounds__(256) void k_points_walk(const Cam c, const Map m, c
   if (!EMIT) counts[i] = cnt;
 }
 
-// sorted records: the lane at the head of a voxel's run folds the run into the voxel, in ascending point index (D6).
-// Every lane loads ITS record (coalesced); in round r a head takes the sdf of lane + r through a shuffle, so the fold loop
-// is arithmetic only — no dependent global loads.  A run that continues past the end of the wave is finished by its head
-// from memory (the lanes of the next wave that belong to it are not heads and do nothing).
-__device__ __forceinline__ void fold_sample(const Map& m, const float half_vs, const u32 w1, const u32 wmax, const float sdf, float& s0, float& ss,
-                                            u32& rgbw) {
-  const u32 w0 = rgbw >> 24;
-  const float curr_mean = w0 > 0 ? s0 : 0.f;
-  const float delta = (sdf - curr_mean) / half_vs;
-  // combineVoxel with curr = {sdf, weight_update, rgb (0, 0, 0)} (vhu.cuh:167-181)
-  const u32 r0 = rgbw & 0xFF, g0 = (rgbw >> 8) & 0xFF, b0 = (rgbw >> 16) & 0xFF;
-  const u32 rn = (u32) f2i((0.5f * (float) r0 + 0.5f * 0.f) + 0.5f) & 0xFF;
-  const u32 gn = (u32) f2i((0.5f * (float) g0 + 0.5f * 0.f) + 0.5f) & 0xFF;
-  const u32 bn = (u32) f2i((0.5f * (float) b0 + 0.5f * 0.f) + 0.5f) & 0xFF;
-  const float sn = (s0 * (float) w0 + sdf * (float) w1) / (float) (int) (w0 + w1);
-  const u32 wn = (w0 + w1) < wmax ? (w0 + w1) : wmax;
-  const float delta2 = (sdf - sn) / half_vs;
-  s0 = sn;
-  ss = 0.f + delta * delta2;
-  rgbw = rn | (gn << 8) | (bn << 16) | (wn << 24);
-}
-
+// sorted records: the lane at the head of a voxel's run folds the run into the voxel, in order
 __global__ __launch_bounds__(256) void k_points_apply(const Map m, const Tab t, const u64* __restrict__ keys, const float* __restrict__ vals,
                                                       const u32 n_rec, const int pbits) {
-  const u32 j = blockIdx.x * blockDim.x + threadIdx.x;  // grid covers whole waves: every lane takes part in the shuffles
-  const int lane = (int) (threadIdx.x & 63);
-  const bool in = j < n_rec;
-  const u64 vid = in ? (keys[j] >> pbits) : ~0ull;
-  const float val = in ? vals[j] : 0.f;
-  // previous record's voxel: the lane below, or memory at the wave's first lane
-  u64 prev = ((u64) (u32) __shfl_up((int) (vid >> 32), 1) << 32) | (u64) (u32) __shfl_up((int) (u32) vid, 1);
-  if (lane == 0) prev = (in && j > 0) ? (keys[j - 1] >> pbits) : ~0ull - 1;
-  const bool head = in && prev != vid;
-  const u64 heads = __ballot(head);
-  const u64 valid = __ballot(in);
-  // records of this lane's run inside the wave: up to the next head (or the last valid lane)
-  const u64 above = lane == 63 ? 0ull : (heads >> (lane + 1));
-  const int next_head = above ? lane + 1 + (__ffsll((long long) above) - 1) : 64;
-  const int last_valid = valid ? 64 - __clzll((long long) valid) : 0;  // one past the highest valid lane
-  const int run_in_wave = head ? (min(next_head, last_valid) - lane) : 0;
-  int max_run = run_in_wave;
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) max_run = max(max_run, __shfl_xor(max_run, off));
-  float s0 = 0.f, ss = 0.f;
-  u32 rgbw = 0;
-  float *p_sdf = nullptr, *p_ss = nullptr;
-  u32* p_rgbw = nullptr;
-  if (head) {
-    const u64 id = vid & (kVidCoarse - 1);
-    const u32 H = (u32) (id >> 9);
-    char* base = t.pool + (size_t) H * kFineBytes;
-    if (vid & kVidCoarse) {
-      const u32 k = (u32) (id >> 6) & 7u, li = (u32) (id & 63u);
-      base += (size_t) k * kCoarseBytes;
-      p_sdf = (float*) base + li; p_ss = (float*) (base + 256) + li; p_rgbw = (u32*) (base + 512) + li;
-    } else {
-      const u32 li = (u32) (id & 511u);
-      p_sdf = (float*) base + li; p_ss = (float*) (base + 2048) + li; p_rgbw = (u32*) (base + 4096) + li;
-    }
-    s0 = *p_sdf; ss = *p_ss; rgbw = *p_rgbw;
+  const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n_rec) return;
+  const u64 vid = keys[j] >> pbits;
+  if (j > 0 && (keys[j - 1] >> pbits) == vid) return;
+  const u64 id = vid & (kVidCoarse - 1);
+  const u32 H = (u32) (id >> 9);
+  char* base = t.pool + (size_t) H * kFineBytes;
+  float *p_sdf, *p_ss;
+  u32* p_rgbw;
+  if (vid & kVidCoarse) {
+    const u32 k = (u32) (id >> 6) & 7u, li = (u32) (id & 63u);
+    base += (size_t) k * kCoarseBytes;
+    p_sdf = (float*) base + li; p_ss = (float*) (base + 256) + li; p_rgbw = (u32*) (base + 512) + li;
+  } else {
+    const u32 li = (u32) (id & 511u);
+    p_sdf = (float*) base + li; p_ss = (float*) (base + 2048) + li; p_rgbw = (u32*) (base + 4096) + li;
   }
+  float s0 = *p_sdf, ss = *p_ss;
+  u32 rgbw = *p_rgbw;
   const u32 w1 = (u32) (m.weight_sample & 0xFF), wmax = (u32) (m.weight_max & 0xFF);
   const float half_vs = m.vs / 2;
-  for (int r = 0; r < max_run; r++) {  // wave-uniform bound
-    const float v_r = __shfl(val, (lane + r) & 63);
-    if (r < run_in_wave) fold_sample(m, half_vs, w1, wmax, v_r, s0, ss, rgbw);
+  for (u32 k = j; k < n_rec && (keys[k] >> pbits) == vid; k++) {
+    const float sdf = vals[k];
+    const u32 w0 = rgbw >> 24;
+    const float curr_mean = w0 > 0 ? s0 : 0.f;
+    const float delta = (sdf - curr_mean) / half_vs;
+    // combineVoxel with curr = {sdf, weight_update, rgb (0, 0, 0)} (vhu.cuh:167-181)
+    const u32 r0 = rgbw & 0xFF, g0 = (rgbw >> 8) & 0xFF, b0 = (rgbw >> 16) & 0xFF;
+    const u32 rn = (u32) f2i((0.5f * (float) r0 + 0.5f * 0.f) + 0.5f) & 0xFF;
+    const u32 gn = (u32) f2i((0.5f * (float) g0 + 0.5f * 0.f) + 0.5f) & 0xFF;
+    const u32 bn = (u32) f2i((0.5f * (float) b0 + 0.5f * 0.f) + 0.5f) & 0xFF;
+    const float sn = (s0 * (float) w0 + sdf * (float) w1) / (float) (int) (w0 + w1);
+    const u32 wn = (w0 + w1) < wmax ? (w0 + w1) : wmax;
+    const float delta2 = (sdf - sn) / half_vs;
+    s0 = sn;
+    ss = 0.f + delta * delta2;
+    rgbw = rn | (gn << 8) | (bn << 16) | (wn << 24);
   }
-  if (head) {
-    // the run may continue in the next wave(s): finish it from memory
-    if (lane + run_in_wave == 64) {
-      for (u32 k = j + (u32) run_in_wave; k < n_rec && (keys[k] >> pbits) == vid; k++) fold_sample(m, half_vs, w1, wmax, vals[k], s0, ss, rgbw);
-    }
-    *p_sdf = s0;
-    *p_ss = ss;
-    *p_rgbw = rgbw;
-  }
+  *p_sdf = s0;
+  *p_ss = ss;
+  *p_rgbw = rgbw;
 }
 
 }  // namespace mrh
