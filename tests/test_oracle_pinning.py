@@ -199,3 +199,52 @@ def test_projection_roundtrip_and_row_col_convention(oracle):
     px = (C.c_int * 2)()
     pt = (C.c_float * 3)(np.float32((-0.7 - 318.6) / 517.3), 0.0, 1.0)
     assert oracle.orc_project_point(e._ctx, pt, 0, px) == 1 and px[1] == 0
+
+
+def _lidar_engine(oracle, min_depth, max_depth):
+    # tests/test_projections.cu:155-161 / :192-197: K = (-1024 / 2pi, -128 / (pi / 2), 512, 64), 128 x 1024, Spherical
+    fx, fy = np.float32(-1024 / (2 * np.pi)), np.float32(-128 / (np.pi / 2))
+    e = capi.Engine(oracle, capi.Params(num_sdf_blocks=1024, **dict(synth.CFG1_PARAMS, min_depth=min_depth, max_depth=max_depth)))
+    e.set_camera(float(fx), float(fy), 512.0, 64.0, 128, 1024, min_depth, max_depth, model=1)
+    return e
+
+
+def test_inverse_projection_spherical(oracle):
+    """tests/test_projections.cu:143-188 INV_PROJECTION_LIDAR: the range of the back-projected point equals the depth
+    (ASSERT_FLOAT_EQ: within 4 ulp) — with sin / cos from include/mrh_softmath.h instead of CUDA's (deviation D8)."""
+    e = _lidar_engine(oracle, 0.0, 10.0)
+    oracle.orc_inverse_projection.argtypes = [C.c_void_p, C.c_uint, C.c_uint, C.c_float, C.POINTER(C.c_float)]
+    rng = np.random.default_rng(4)
+    out = (C.c_float * 3)()
+    worst = 0.0
+    for _ in range(4000):
+        r, c = int(rng.integers(0, 128)), int(rng.integers(0, 1024))
+        d = np.float32(rng.uniform(0.05, 10.0))
+        oracle.orc_inverse_projection(e._ctx, r, c, d, out)
+        x, y, z = np.float32(out[0]), np.float32(out[1]), np.float32(out[2])
+        rng_len = np.sqrt(np.float32(np.float32(x * x + y * y) + z * z), dtype=np.float32)
+        worst = max(worst, abs(float(rng_len) - float(d)) / float(np.spacing(d)))
+    assert worst <= 4.0, worst
+
+
+def test_projection_roundtrip_spherical(oracle):
+    """tests/test_projections.cu:190-222 PROJECTIONS_LIDAR.Dummy: random points in [-1, 1]^3, project (atan2 / asin), back-
+    project the pixel with the point's range: every coordinate within 2e-2; pimg = (row, col)."""
+    e = _lidar_engine(oracle, 0.2, 50.0)
+    oracle.orc_inverse_projection.argtypes = [C.c_void_p, C.c_uint, C.c_uint, C.c_float, C.POINTER(C.c_float)]
+    oracle.orc_project_point.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_int)]
+    rng = np.random.default_rng(5)
+    n_ok = 0
+    for _ in range(20000):
+        p = rng.uniform(-1.0, 1.0, 3).astype(np.float32)
+        pc = (C.c_float * 3)(*[float(v) for v in p])
+        px = (C.c_int * 2)()
+        if not oracle.orc_project_point(e._ctx, pc, 0, px):
+            continue
+        assert 0 <= px[0] < 128 and 0 <= px[1] < 1024
+        rng_len = np.sqrt(np.float32(np.float32(p[0] * p[0] + p[1] * p[1]) + p[2] * p[2]), dtype=np.float32)
+        q = (C.c_float * 3)()
+        oracle.orc_inverse_projection(e._ctx, px[0], px[1], rng_len, q)
+        assert max(abs(q[i] - p[i]) for i in range(3)) < 2e-2
+        n_ok += 1
+    assert n_ok > 10000
