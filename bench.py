@@ -33,6 +33,7 @@ N > 1 — workload BASELINE.json configs[3]: "ScanNet scene0000" stand-in (furni
 from __future__ import annotations
 
 import argparse
+import gc
 import glob
 import json
 import os
@@ -495,6 +496,11 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (torch.cuda.is_available() is False)")
+    # Python's cyclic collector stays off for the run: a generation-2 pass of an interpreter with torch loaded takes tens
+    # of milliseconds and fires after a fixed number of allocations, i.e. inside whichever timed loop happens to cross it
+    # (seen as a 20x outlier of one leg in tools/bench_tile_shards.py).  Nothing here builds reference cycles that matter.
+    gc.collect()
+    gc.disable()
     if args.gpus > 1:
         bench_multi(args)
     else:

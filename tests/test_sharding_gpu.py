@@ -26,6 +26,35 @@ def test_union_of_tile_shards_equals_single_map_hip(hip):
     assert np.array_equal(d[order], d0) and np.array_equal(v[order].view(np.uint8), v0.view(np.uint8))
 
 
+def _union(shards):
+    parts = [s.dump_blocks() for s in shards]
+    d = np.concatenate([p[0] for p in parts])
+    v = np.concatenate([p[1] for p in parts])
+    order = np.lexsort((d["z"], d["y"], d["x"]))
+    return d[order], v[order]
+
+
+@pytest.mark.parametrize("count,chunk_log2,var", [(8, 3, 0.0), (4, 2, 0.0), (3, 3, 0.005)])
+def test_shards_that_skip_foreign_tiles_still_build_the_single_map_hip(hip, count, chunk_log2, var):
+    """640x480 Replica stand-in on `count` tile shards (the fast path; with `var` the multi-resolution one): a shard skips the
+    ray walk of every 16x16 pixel tile whose rays cannot reach one of its chunks (tile_reaches_owned_chunk).  The union of
+    the shard maps must still be the single-context map, block for block and voxel for voxel, after a few frames of the
+    orbit with garbage collection on — a tile skipped wrongly would show up as a missing block."""
+    params = dict(synth.REPLICA_PARAMS, sdf_var_threshold=var)
+    single = pu.make_engine(hip, synth.REPLICA_640, params, 65536)
+    shards = [pu.make_engine(hip, synth.REPLICA_640, params, 65536, shard_rank=r, shard_count=count, shard_chunk_log2=chunk_log2)
+              for r in range(count)]
+    for f in synth.replica_stream(6):
+        for e in [single] + shards:
+            pu.feed(e, f)
+    d0, v0 = single.dump_blocks()
+    d, v = _union(shards)
+    assert len(d0) > 5000 and np.array_equal(d, d0) and np.array_equal(v.view(np.uint8), v0.view(np.uint8))
+    assert all(s.stats().error_flags == 0 for s in shards)
+    owned = [int(s.stats().occupied_fine + s.stats().occupied_coarse) for s in shards]
+    assert min(owned) > 0 and sum(owned) == len(d0)
+
+
 def test_import_blocks_roundtrip_hip(hip):
     a = pu.make_engine(hip, synth.CFG1, dict(synth.CFG1_PARAMS, n_frames_invalidate_voxels=1000), 8192)  # GC every frame, no starve
     pu.feed(a, synth.cfg1_sphere())
