@@ -181,8 +181,8 @@ int mrh_upload_depth(mrh_ctx* ctx, const float* depth, int rows, int cols);
 int mrh_upload_rgb(mrh_ctx* ctx, const uint8_t* rgb, int rows, int cols);
 
 /* Both uploads return as soon as the image sits in pinned staging memory (the caller's buffer is free again); the
- * host-to-device copy runs on a second stream into one of three device slots per image kind, so the copy of frame N+1
- * overlaps the kernels of frame N.  mrh_integrate / mrh_splat_seeds order themselves after the newest upload.
+ * host-to-device copy runs on a copy stream of its image kind (depth and colour move side by side) into one of three
+ * device slots, so the copies of frame N+1 overlap the kernels of frame N.  mrh_integrate / mrh_splat_seeds order themselves after the newest upload.
  *
  * Zero-copy variants: the images already live in HBM (e.g. a resident frame queue). The
  * pointers are used by the next mrh_integrate (and mrh_splat_seeds) and must stay valid until it has executed. */

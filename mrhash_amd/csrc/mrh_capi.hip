@@ -57,6 +57,8 @@ struct UpSlot {
 struct UpRing {
   UpSlot s[3];
   int cur = -1;                 // slot holding the current image; -1: none, or a caller's device pointer
+  hipStream_t stream = nullptr; // this ring's copy stream
+  hipEvent_t last_copy = nullptr;  // newest copy event of this ring the main stream has not waited for yet
 };
 
 // Host result buffer of the blocking calls (triangle soup, V / F / C): grow-only, never zero-filled, 2 MiB-aligned
@@ -110,8 +112,7 @@ struct mrh_ctx {
   // device buffer — on a second stream, so the copy of frame N+1 overlaps the kernels of frame N; the frame's kernels
   // wait for the newest copy event, a slot is rewritten only after the last frame that read it (frame_done event).
   UpRing up_depth, up_rgb;
-  hipStream_t copy_stream = nullptr;
-  hipEvent_t last_copy = nullptr;      // newest copy event the main stream has not waited for yet
+  bool copy_ready = false;             // copy streams and frame marks exist
   hipEvent_t frame_done[8] = {};       // recorded on the main stream after every frame that read ring slots / when peeks are on
   uint64_t frame_seq = 1;
   // pool level for the host without a read-back stall (mrh_peek_free_blocks): a 2-int D2H per frame into pinned memory
@@ -250,7 +251,8 @@ uint64_t next_pow2(uint64_t v) {
 void free_all(mrh_ctx* c) {
   if (!c) return;
   (void) hipSetDevice(c->device);
-  if (c->copy_stream) { (void) hipStreamSynchronize(c->copy_stream); (void) hipStreamDestroy(c->copy_stream); }
+  for (UpRing* r : {&c->up_depth, &c->up_rgb})
+    if (r->stream) { (void) hipStreamSynchronize(r->stream); (void) hipStreamDestroy(r->stream); }
   if (c->stream) (void) hipStreamSynchronize(c->stream);
   auto F = [](void* p) { if (p) (void) hipFree(p); };
   F(c->dcx_buf);
@@ -956,9 +958,15 @@ void copy_to_staging(void* dst, const void* src, size_t n);
 // one host image into the next slot of its ring: wait until the slot is free, copy into pinned staging (the caller's
 // buffer is free on return), enqueue the H2D on the copy stream
 int upload_image(mrh_ctx* c, UpRing& ring, const void* src, const size_t bytes, const void** out_dev) {
-  if (!c->copy_stream) {
-    HIP_TRY(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+  if (!c->copy_ready) {
+    // One copy stream per image kind: the depth and the colour image of a frame then move through two SDMA engines side by
+    // side (64 us per frame instead of 77 on one stream).  A copy kernel pulling the pinned buffer over PCIe is faster on its
+    // own (48 GB/s against 25-30, tools/micro/h2d_paths.hip) but finds no wave slots while k_back fills every SIMD's
+    // registers, neither with stream priority nor with CU masks (tools/micro/cu_mask_overlap.hip: a masked stream costs the
+    // big kernel 14 %): measured at 73-75 us per frame inside the library, and dropped.
+    for (UpRing* r : {&c->up_depth, &c->up_rgb}) HIP_TRY(c, hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking));
     for (hipEvent_t& e : c->frame_done) HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    c->copy_ready = true;
   }
   const int next = (ring.cur + 1) % 3;
   UpSlot& u = ring.s[next];
@@ -974,11 +982,11 @@ int upload_image(mrh_ctx* c, UpRing& ring, const void* src, const size_t bytes, 
     if (!u.copied) HIP_TRY(c, hipEventCreateWithFlags(&u.copied, hipEventDisableTiming));
   }
   copy_to_staging(u.h, src, bytes);
-  HIP_TRY(c, hipMemcpyAsync(u.d, u.h, bytes, hipMemcpyHostToDevice, c->copy_stream));
-  HIP_TRY(c, hipEventRecord(u.copied, c->copy_stream));
+  HIP_TRY(c, hipMemcpyAsync(u.d, u.h, bytes, hipMemcpyHostToDevice, ring.stream));
+  HIP_TRY(c, hipEventRecord(u.copied, ring.stream));
   u.copied_rec = true;
   u.last_seq = 0;
-  c->last_copy = u.copied;  // copies are ordered on one stream: the newest event covers the earlier ones
+  ring.last_copy = u.copied;  // a ring's copies are ordered on its stream: the newest event covers the earlier ones
   ring.cur = next;
   *out_dev = u.d;
   return MRH_OK;
@@ -986,10 +994,11 @@ int upload_image(mrh_ctx* c, UpRing& ring, const void* src, const size_t bytes, 
 
 // before kernels that read the images: the main stream waits for the newest upload
 int wait_inputs(mrh_ctx* c) {
-  if (c->last_copy) {
-    HIP_TRY(c, hipStreamWaitEvent(c->stream, c->last_copy, 0));
-    c->last_copy = nullptr;
-  }
+  for (UpRing* r : {&c->up_depth, &c->up_rgb})
+    if (r->last_copy) {
+      HIP_TRY(c, hipStreamWaitEvent(c->stream, r->last_copy, 0));
+      r->last_copy = nullptr;
+    }
   return MRH_OK;
 }
 
@@ -1001,7 +1010,8 @@ int mark_frame(mrh_ctx* c) {
   if (!used[0] && !used[1] && !c->peek_enabled) return MRH_OK;
   const uint64_t seq = c->frame_seq++;
   if (c->peek_enabled) {
-    HIP_TRY(c, hipMemcpyAsync(c->h_peek + 8 * (seq % 8), &c->tab.ctr[CTR_HEAP_FINE], 5 * sizeof(int), hipMemcpyDeviceToHost, c->stream));  // ctr[0 .. 4]
+    k_report<<<1, 64, 0, c->stream>>>(&c->tab.ctr[CTR_HEAP_FINE], c->h_peek + 8 * (seq % 8));  // ctr[0 .. 4]
+    HIP_TRY(c, hipGetLastError());
     c->peek_seq[seq % 8] = seq;
   }
   if (!c->frame_done[0])

@@ -590,6 +590,11 @@ __global__ __launch_bounds__(64) void k_reintegrate(const Cam c, const Map m, co
 __global__ __launch_bounds__(256) void k_init_table(u64* keys, const size_t slots) {
   for (size_t i = (size_t) blockIdx.x * 256 + threadIdx.x; i < slots; i += (size_t) gridDim.x * 256) keys[i] = kKeyEmpty;
 }
+// the per-frame report of mrh_peek_free_blocks / mrh_peek_error_flags: ctr[0 .. 4] into a pinned host record (one lane; a
+// 20-byte hipMemcpyAsync would cost the host as much as the two launches of the frame together)
+__global__ void k_report(const int* __restrict__ ctr, int* __restrict__ host_rec) {
+  if (threadIdx.x < 5) host_rec[threadIdx.x] = ctr[threadIdx.x];
+}
 __global__ __launch_bounds__(256) void k_fill_u64(u64* p, const size_t n, const u64 v) {
   for (size_t i = (size_t) blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t) gridDim.x * 256) p[i] = v;
 }
