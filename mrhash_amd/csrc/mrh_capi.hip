@@ -117,6 +117,8 @@ struct mrh_ctx {
   uint64_t frame_seq = 1;
   // pool level for the host without a read-back stall (mrh_peek_free_blocks): a 2-int D2H per frame into pinned memory
   int* h_peek = nullptr;               // [8][8] pinned: ctr[0 .. 4] = free-list levels ... error flags per report
+  u32* h_scan = nullptr;               // pinned {hwm, last offset, last count, sequence}: the mid-scan report of mrh_integrate_points
+  u32 scan_seq = 0;
   uint64_t peek_seq[8] = {};
   bool peek_enabled = false;
   const float* d_depth = nullptr;
@@ -266,6 +268,7 @@ void free_all(mrh_ctx* c) {
     }
   for (hipEvent_t e : c->frame_done) if (e) (void) hipEventDestroy(e);
   if (c->h_peek) (void) hipHostFree(c->h_peek);
+  if (c->h_scan) (void) hipHostFree(c->h_scan);
   F(c->d_decision); F(c->d_zbuf); F(c->d_realloc); F(c->d_reint); F(c->d_flag);
   F(c->d_upd_partials); F(c->d_misc); F(c->d_rcp_w); F(c->d_cfree); F(c->d_zmin); F(c->d_points); F(c->d_pt_counts); F(c->d_pt_offsets); F(c->d_rec_keys[0]); F(c->d_rec_keys[1]); F(c->d_rec_vals[0]); F(c->d_rec_vals[1]); F(c->d_sort_tmp); F(c->fast.summary); F(c->fast.summary_c); F(c->fast.bbox); F(c->d_cnt_partials);
   F(c->d_pack); F(c->d_halo); F(c->d_taken); F(c->d_cloud); F(c->d_normals); F(c->d_soup);
@@ -1336,12 +1339,30 @@ int mrh_integrate_points(mrh_ctx* c, int n_frames_invalidate) {
       if (r) return r;
       size_t tb = c->sort_tmp_bytes;
       HIP_TRY(c, rocprim::exclusive_scan(c->d_sort_tmp, tb, c->d_pt_counts, c->d_pt_offsets, 0u, n, rocprim::plus<u32>(), s));
-      u32 last_off = 0, last_cnt = 0;
-      int hwm = 0;
-      HIP_TRY(c, hipMemcpyAsync(&hwm, &t.ctr[CTR_HWM_FINE], sizeof(int), hipMemcpyDeviceToHost, s));
-      HIP_TRY(c, hipMemcpyAsync(&last_off, c->d_pt_offsets + (n - 1), sizeof(u32), hipMemcpyDeviceToHost, s));
-      HIP_TRY(c, hipMemcpyAsync(&last_cnt, c->d_pt_counts + (n - 1), sizeof(u32), hipMemcpyDeviceToHost, s));
-      HIP_TRY(c, hipStreamSynchronize(s));
+      // the one host round trip of a scan (the record count sizes the sort): a one-lane kernel writes the three numbers and
+      // a sequence mark into pinned memory and the host watches the mark — three small hipMemcpyAsync + a stream
+      // synchronisation cost ~60 us of host and copy-engine latency per scan with the device idle meanwhile
+      if (!c->h_scan) {
+        HIP_TRY(c, hipHostMalloc((void**) &c->h_scan, 4 * sizeof(u32), hipHostMallocDefault));
+        memset(c->h_scan, 0, 4 * sizeof(u32));
+      }
+      const u32 seq = ++c->scan_seq;
+      k_scan_report<<<1, 64, 0, s>>>(t.ctr, c->d_pt_offsets, c->d_pt_counts, np, c->h_scan, seq);
+      HIP_TRY(c, hipGetLastError());
+      {
+        volatile u32* mark = c->h_scan + 3;
+        const auto t0 = std::chrono::steady_clock::now();
+        int spins = 0;
+        while (*mark != seq) {
+          _mm_pause();
+          if ((++spins & 1023) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;  // long scan or a fault
+        }
+        if (*mark != seq) HIP_TRY(c, hipStreamSynchronize(s));  // reports a device error if that is why the mark never came
+        if (*mark != seq) return fail(c, MRH_ERR_DEVICE, "mrh_integrate_points: the scan report did not arrive");
+        std::atomic_thread_fence(std::memory_order_acquire);
+      }
+      const int hwm = (int) c->h_scan[0];
+      const u32 last_off = c->h_scan[1], last_cnt = c->h_scan[2];
       const uint64_t n_rec = (uint64_t) last_off + last_cnt;
       if (n_rec >= 0xFFFFFFF0ull) return fail(c, MRH_ERR_CAPACITY, "mrh_integrate_points: %llu voxel updates in one scan", (unsigned long long) n_rec);
       if (n_rec == 0) return MRH_OK;
