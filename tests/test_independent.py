@@ -62,6 +62,115 @@ def test_allocation_and_integration_match_the_independent_restatement(oracle, sc
     e.close()
 
 
+def _chain_step(cam, params, f, state):
+    """allocate + integrate of one frame on `state` with the independent restatement (GC / variance left to the caller)."""
+    cam.set_pose(f.R, f.t)
+    for k in ind.allocate(cam, params, f.depth) - set(state):
+        state[k] = np.zeros(512, capi.VOXEL_DTYPE)
+    return ind.integrate(cam, params, f.depth, f.rgb, state)
+
+
+def _assert_same_blocks(want: dict, got: dict, what: str):
+    assert set(want) == set(got), f"{what}: occupancy differs ({len(want)} vs {len(got)} blocks)"
+    for k in sorted(want):
+        a, b = want[k], got[k]
+        assert np.array_equal(a["weight"], b["weight"]) and np.array_equal(a["rgb"], b["rgb"]), (what, k)
+        assert np.array_equal(a["sdf"].view(np.uint32), b["sdf"].view(np.uint32)), (what, k)
+        assert np.array_equal(a["sum_squared"].view(np.uint32), b["sum_squared"].view(np.uint32)), (what, k)
+
+
+@pytest.mark.parametrize("starve_period", [1000, 1, 2])
+def test_garbage_collection_and_starve_match_the_independent_restatement(oracle, starve_period):
+    """garbageCollect (voxel_data_structures.cpp:137-145) every frame: starve on frames f > 0 with f % period == 0, then
+    identify + free.  The independent chain — allocate, integrate, starve, decisions — must reproduce the oracle's map
+    after every frame, freed blocks and decremented weights included."""
+    # a truncation band wider than a block (0.25 m against 0.16 m): blocks wholly in front of the surface sit at +t and are collected
+    params = dict(synth.CFG1_PARAMS, sdf_truncation=0.25, integration_weight_sample=2, n_frames_invalidate_voxels=starve_period)
+    K = synth.CFG1
+    e = pu.make_engine(oracle, K, params, 32768)
+    cam = make_cam(K, params)
+    state, freed, starved = {}, 0, 0
+    for i, f in enumerate(rotated_frames() + rotated_frames()[:2]):
+        pu.feed(e, f)
+        d, v = e.dump_blocks()
+        state = _chain_step(cam, params, f, state)
+        if i > 0 and i % starve_period == 0:
+            before = sum(int(b["weight"].astype(np.int64).sum()) for b in state.values())
+            state = ind.starve(cam, params, state)
+            starved += before - sum(int(b["weight"].astype(np.int64).sum()) for b in state.values())
+        drop = ind.gc_decisions(cam, params, state)
+        freed += len(drop)
+        for k in drop:
+            del state[k]
+        _assert_same_blocks(state, as_dict(d, v), f"frame {i}")
+    assert freed > 50 and len(state) > 50
+    assert (starved > 500) == (starve_period < 1000)
+    e.close()
+
+
+def test_variance_adaptive_coarsening_matches_the_independent_restatement(oracle):
+    """checkVarSDF -> reallocBlocks -> reintegrateDepthMap (voxel_data_structures.cpp:99-104) on the second frame: which
+    blocks go coarse, what the fine ones keep and what the fresh coarse blocks hold (voxels 0..31 of the current frame,
+    the reference's launch shape) — predicted from the single-resolution state by the independent restatement."""
+    base = dict(synth.CFG1_PARAMS, integration_weight_sample=2)
+    K = synth.CFG1
+    frames = rotated_frames()[:2]
+    cam = make_cam(K, base)
+    state = {}
+    for f in frames:
+        state = _chain_step(cam, base, f, state)
+    some = 0
+    for thr in (0.002, 0.02, 0.5):
+        params = dict(base, sdf_var_threshold=thr)
+        e = pu.make_engine(oracle, K, params, 32768)
+        for f in frames:
+            pu.feed(e, f)
+        d, v = e.dump_blocks()
+        e.close()
+        coarse_want = ind.check_var(cam, params, state)  # cam still holds the second frame's pose
+        got_coarse = {(int(d["x"][i]), int(d["y"][i]), int(d["z"][i])): v[i] for i in range(len(d)) if d["resolution"][i] == 1}
+        got_fine = {(int(d["x"][i]), int(d["y"][i]), int(d["z"][i])): v[i] for i in range(len(d)) if d["resolution"][i] == 0}
+        assert set(got_coarse) == set(coarse_want), f"threshold {thr}: {len(got_coarse)} coarse blocks, predicted {len(coarse_want)}"
+        _assert_same_blocks({k: b for k, b in state.items() if k not in got_coarse}, got_fine, f"threshold {thr}, fine blocks")
+        for k in coarse_want:
+            want = ind.reintegrate_coarse(cam, params, frames[1].depth, frames[1].rgb, k)
+            got = got_coarse[k][:64]
+            assert np.array_equal(want["weight"], got["weight"]) and np.array_equal(want["rgb"], got["rgb"]), (thr, k)
+            assert np.array_equal(want["sdf"].view(np.uint32), got["sdf"].view(np.uint32)), (thr, k)
+            assert not got["sum_squared"].any()
+        some += len(coarse_want)
+        if thr == 0.5:
+            assert 0 < len(coarse_want) < len(state)
+    assert some > 20
+
+
+def test_lidar_scans_match_the_independent_restatement(oracle):
+    """allocBlocks3DKernel + integrate3DKernel (projective SDF): three 16 x 128 scans of the street scene from a moving
+    sensor, vbr.cfg parameters; occupancy and every voxel (sdf, sum_squared, weight) bit for bit after each scan."""
+    params = dict(synth.VBR_PARAMS)
+    e = pu.make_lidar_engine(oracle, params, 100.0)
+    cam = ind.Camera(1, 1, 0, 0, 1, 1, params["min_depth"], params["max_depth"])
+    scene = synth.street_canyon()
+    state, updated = {}, 0
+    for t, q in synth.drive_poses(3, step=1.5):
+        pts = synth.lidar_scan(scene, t, q, rows=16, cols=128)
+        R = synth.quat_to_rot(q)
+        e.set_pose(R, t)
+        e.upload_points(pts)
+        e.integrate_points()
+        d, v = e.dump_blocks()
+        got = as_dict(d, v)
+        cam.set_pose(R, t)
+        for k in ind.allocate3d(cam, params, pts) - set(state):
+            state[k] = np.zeros(512, capi.VOXEL_DTYPE)
+        new = ind.integrate3d(cam, params, pts, state)
+        updated += sum(int((new[k]["weight"] != state[k]["weight"]).sum()) for k in state)
+        state = new
+        _assert_same_blocks(state, got, "scan")
+    assert len(state) > 300 and updated > 5000
+    e.close()
+
+
 def test_marching_cubes_matches_the_independent_restatement(oracle):
     """extractIsoSurfaceAtPosition + trilinearInterpolation + vertexInterp, voxel by voxel in python, for the blocks of a
     small map that carry most triangles; the triangle table is rebuilt from the reference's own Transvoxel tables when
@@ -112,6 +221,73 @@ def test_marching_cubes_matches_the_independent_restatement(oracle):
         checked += len(got)
     assert checked > 200
     e.close()
+
+
+def _tri_table():
+    table = ind.reference_tri_table(REFERENCE) if os.path.isdir(REFERENCE) else None
+    if table is None:
+        import re
+
+        txt = open(os.path.join(pu.ROOT, "include", "mrh_mc_tables.h")).read()
+        rows = re.findall(r"\{((?:0x[0-9A-Fa-f]{2},?){16})\}", txt)
+        table = [[int(x, 16) for x in r.split(",") if x] for r in rows[:256]]
+    return table
+
+
+def test_marching_cubes_on_a_multiresolution_map_matches_the_independent_restatement(oracle):
+    """The resolution-aware half of the extraction — getVoxelSize, checkVertexVoxels (marching_cubes.cu:7-69), the base
+    resolution lookup and the coarser re-sample of trilinearInterpolation (vds.cu:260-338), coarse blocks read and traversed
+    (extractIsoSurfaceKernel, marching_cubes.cu:264-285) — on a map where coarse and fine blocks touch: the coarse blocks
+    with most triangles and the fine blocks next to a coarse one with most triangles, voxel by voxel."""
+    params = dict(synth.CFG1_PARAMS, integration_weight_sample=2, sdf_var_threshold=0.5, min_weight_threshold=1)
+    K = synth.CFG1
+    e = pu.make_engine(oracle, K, params, 32768)
+    for f in rotated_frames():
+        pu.feed(e, f)
+    d, v = e.dump_blocks()
+    tris = e.extract_triangles()
+    td, tc = e.triangle_blocks()
+    e.close()
+    blocks = {(int(d["x"][i]), int(d["y"][i]), int(d["z"][i])): (int(d["resolution"][i]), v[i][: 512 if d["resolution"][i] == 0 else 64])
+              for i in range(len(d))}
+    coarse = {k for k, (r, _) in blocks.items() if r == 1}
+    assert 5 < len(coarse) < len(blocks) - 5
+    m = ind.MultiMap(params, blocks)
+    table = _tri_table()
+    starts = np.concatenate([[0], np.cumsum(tc.astype(np.int64))]).astype(np.int64)
+    order = np.argsort(-tc.astype(np.int64))
+
+    def next_to_coarse(k):
+        return any((k[0] + a, k[1] + b, k[2] + c) in coarse for a in (-1, 0, 1) for b in (-1, 0, 1) for c in (-1, 0, 1))
+
+    picks, n_c, n_f = [], 0, 0
+    for bi in order:
+        k = (int(td["x"][bi]), int(td["y"][bi]), int(td["z"][bi]))
+        if tc[bi] == 0:
+            break
+        if k in coarse and n_c < 6:
+            picks.append(bi); n_c += 1
+        elif k not in coarse and next_to_coarse(k) and n_f < 2:
+            picks.append(bi); n_f += 1
+    assert n_c >= 3 and n_f == 2
+    checked = 0
+    for bi in picks:
+        k = (int(td["x"][bi]), int(td["y"][bi]), int(td["z"][bi]))
+        res = blocks[k][0]
+        side, sc = (8, 1) if res == 0 else (4, 2)
+        want = tris[starts[bi]: starts[bi + 1]]
+        got = []
+        for li in range(side ** 3):
+            pi = np.array([k[0] * 8 + sc * (li % side), k[1] * 8 + sc * ((li % (side * side)) // side), k[2] * 8 + sc * (li // (side * side))], np.int32)
+            pf = ind.voxel_to_world(m.vs, pi)
+            got.extend(ind.mc_voxel(m, table, (pf[0], pf[1], pf[2])))
+        assert len(got) == len(want) > 0, (k, res, len(got), len(want))
+        gp = np.array([[vert[0] for vert in tri] for tri in got], np.float32)
+        gc = np.array([[vert[1] for vert in tri] for tri in got], np.float32)
+        assert np.array_equal(gp.view(np.uint32), want["p"].view(np.uint32)), (k, res)
+        assert np.array_equal(gc.view(np.uint32), want["c"].view(np.uint32)), (k, res)
+        checked += len(got)
+    assert checked > 100 and m.jumps > 50 and m.shrunk > 10, (checked, m.jumps, m.shrunk)
 
 
 # ---- analytic known answers -------------------------------------------------------------------------------------------
