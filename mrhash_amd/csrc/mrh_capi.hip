@@ -288,7 +288,7 @@ int init_buffers(mrh_ctx* c) {
   c->fast_frames = 0;
   const Tab& t = c->tab;
   k_init_table<<<1024, 256, 0, s>>>(t.keys, c->slots);
-  k_init_heap<<<1024, 256, 0, s>>>(t.heap_fine, (u32) c->num_blocks);
+  k_init_heap<<<1024, 256, 0, s>>>(t.heap_fine, (u32) c->num_blocks, getenv("MRH_DEBUG_HEAP_DESCENDING") ? 1 : 0);
   HIP_TRY(c, hipMemsetAsync(t.vals, 0, c->slots * sizeof(u32), s));
   HIP_TRY(c, hipMemsetAsync(t.desc_fine, 0, c->num_blocks * sizeof(int4), s));
   if (t.multi_res) HIP_TRY(c, hipMemsetAsync(t.desc_coarse, 0, c->num_blocks * 8 * sizeof(int4), s));

@@ -612,8 +612,11 @@ __global__ __launch_bounds__(256) void k_fill_u64(u64* p, const size_t n, const 
 __global__ __launch_bounds__(256) void k_fill_u32(u32* p, const size_t n, const u32 v) {
   for (size_t i = (size_t) blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t) gridDim.x * 256) p[i] = v;
 }
-__global__ __launch_bounds__(256) void k_init_heap(u32* heap, const u32 n) {
-  for (size_t i = (size_t) blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t) gridDim.x * 256) heap[i] = n - 1 - (u32) i;
+// free list of fine block indices, popped from the top: index 0 first (heap[i] = N - 1 - i, vds.cu:33-40) — or, for the
+// addressing test (MRH_DEBUG_HEAP_DESCENDING=1), the HIGHEST index first, so that a small scene lands at the far end of a
+// pool sized to HBM and every byte offset it touches needs more than 32 bits
+__global__ __launch_bounds__(256) void k_init_heap(u32* heap, const u32 n, const int highest_first) {
+  for (size_t i = (size_t) blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t) gridDim.x * 256) heap[i] = highest_first ? (u32) i : n - 1 - (u32) i;
 }
 __global__ __launch_bounds__(256) void k_count_live(const Tab t) {
   const int hwm = t.ctr[CTR_HWM_FINE];

@@ -541,6 +541,50 @@ def test_default_capacity_rule_sizes_the_pool_to_hbm(hip):
     small.close()
 
 
+@pytest.mark.parametrize("kind", ["rgbd_multires", "lidar"])
+def test_far_end_of_an_hbm_sized_pool(hip, monkeypatch, kind):
+    """BASELINE configs[4] names "288 GB HBM hash-table sizing": with the pool sized to the device (tens of millions of blocks,
+    > 100 GB of voxel planes) and the free list handing out its HIGHEST indices first (MRH_DEBUG_HEAP_DESCENDING), a small
+    scene lives at byte offsets far beyond 2^32 in every plane, descriptor and summary array.  The map, the mesh and the
+    scan results must equal those of a small pool filled from index 0."""
+    if kind == "rgbd_multires":
+        K = synth.CFG1
+        params = dict(synth.CFG1_PARAMS, integration_weight_sample=2, sdf_var_threshold=0.5, n_frames_invalidate_voxels=3)
+        small = pu.make_engine(hip, K, params, 16384)
+        monkeypatch.setenv("MRH_DEBUG_HEAP_DESCENDING", "1")
+        big = capi.Engine(hip, capi.Params(num_sdf_blocks=0, **params))
+        monkeypatch.delenv("MRH_DEBUG_HEAP_DESCENDING")
+        big.set_camera(K.fx, K.fy, K.cx, K.cy, K.rows, K.cols, params["min_depth"], params["max_depth"])
+        frames = [synth.cfg1_sphere(), synth.cfg1_sphere(zc=1.51), synth.cfg1_sphere(zc=1.49), synth.cfg1_sphere(zc=1.5), synth.cfg1_sphere(zc=1.52)]
+        for f in frames:
+            pu.feed(big, f)
+            pu.feed(small, f)
+    else:
+        params = dict(synth.VBR_PARAMS, n_frames_invalidate_voxels=2)
+        small = pu.make_lidar_engine(hip, params, 100.0)
+        monkeypatch.setenv("MRH_DEBUG_HEAP_DESCENDING", "1")
+        big = capi.Engine(hip, capi.Params(num_sdf_blocks=0, **params))
+        monkeypatch.delenv("MRH_DEBUG_HEAP_DESCENDING")
+        big.set_camera(1.0, 1.0, 0.0, 0.0, 1, 1, params["min_depth"], 100.0, model=1)
+        scene = synth.street_canyon()
+        for t, q in synth.drive_poses(3, step=1.0):
+            pts = synth.lidar_scan(scene, t, q, rows=32, cols=512)
+            for e in (big, small):
+                e.set_pose(synth.quat_to_rot(q), t)
+                e.upload_points(pts)
+                e.integrate_points()
+    big.sync()
+    st = big.stats()
+    assert st.num_sdf_blocks > 8_000_000 and st.error_flags == 0
+    r = pu.compare_maps(big, small)
+    assert r["blocks"] > 50 and r["sdf_bit_exact"]
+    if kind == "rgbd_multires":
+        assert st.occupied_coarse > 0
+        pu.compare_meshes(big, small)
+    big.close()
+    small.close()
+
+
 @pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5])
 def test_randomised_parameters_and_shapes(hip, oracle, seed):
     """Parameter / shape fuzz: odd image sizes (partial allocation tiles, clamped footprints), off-centre anisotropic
