@@ -132,12 +132,12 @@ def merge_frames():
     return [synth.cfg1_sphere(zc=1.5 + 0.01 * k) for k in range(4)]
 
 
-def run_two_ranks(tmp_path, use_hip: bool, worker: str = None):
+def run_two_ranks(tmp_path, use_hip: bool, worker: str = None, nproc: int = 2):
     out = str(tmp_path / "rank0.npz")
     script = tmp_path / "worker.py"
     script.write_text((worker or WORKER).format(root=ROOT, use_hip=use_hip, out=out))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", OMP_NUM_THREADS="2")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
            "--master-port", "29534", str(script)]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
@@ -163,7 +163,18 @@ def test_two_rank_gloo_mesh_equals_single_process(oracle, tmp_path):
     assert bool(got["refused"]) and int(got["n_dropped"]) == int(got["n_halo"]) and int(got["n_after"]) == int(got["n_own"])
 
 
-def check_merged_against_single(lib, tmp_path, got):
+def test_four_rank_gloo_mesh_equals_single_process(oracle, tmp_path):
+    """The same protocol on FOUR ranks (uneven shards, halo segments of different lengths padded to the longest, four triangle
+    runs interleaved back into the canonical order): what the 8-GPU job does, at a size the CPU oracle handles."""
+    got = run_two_ranks(tmp_path, use_hip=False, nproc=4)
+    t, V, F, C = reference_single(oracle)
+    assert int(got["n_halo"]) > 0 and int(got["n_own"]) > 0
+    assert np.array_equal(got["tris"], t.view(np.uint8)), "merged triangle buffer differs from the single-process one"
+    assert np.array_equal(got["F"], F) and np.array_equal(got["V"], V) and np.allclose(got["C"], C)
+    assert bool(got["refused"]) and int(got["n_dropped"]) == int(got["n_halo"]) and int(got["n_after"]) == int(got["n_own"])
+
+
+def check_merged_against_single(lib, tmp_path, got, world: int = 2):
     """The merged tile-sharded map against ONE context that fused all frames.  Occupancy is the same (allocation depends on
     the depth frames only).  A voxel carries the same weight and — up to the order of the running mean, 1e-5 — the same
     TSDF value wherever every sub-map held the voxel's block while it fused; a sub-map that allocated the block late (or
@@ -175,7 +186,7 @@ def check_merged_against_single(lib, tmp_path, got):
     for f in frames:
         pu.feed(single, f)
     d0, v0 = single.dump_blocks()
-    parts = [np.load(str(tmp_path / "rank0.npz") + f".{r}.npz") for r in range(2)]
+    parts = [np.load(str(tmp_path / "rank0.npz") + f".{r}.npz") for r in range(world)]
     d = np.concatenate([p["d"] for p in parts])
     v = np.concatenate([p["v"].view(capi.VOXEL_DTYPE).reshape(-1, 512) for p in parts])
     order = np.lexsort((d["z"], d["y"], d["x"]))
@@ -183,14 +194,14 @@ def check_merged_against_single(lib, tmp_path, got):
     assert np.array_equal(d, d0), "occupancy of the merged map differs from the single-context map"
     assert np.all(v["weight"] <= v0["weight"])
     same = (v["weight"] == v0["weight"]) & (v0["weight"] > 0)
-    assert same.sum() > 0.8 * (v0["weight"] > 0).sum()
+    assert same.sum() > (0.8 if world == 2 else 0.5) * (v0["weight"] > 0).sum()
     assert float(np.max(np.abs(v["sdf"][same] - v0["sdf"][same]))) <= 1e-5
     assert all(int(p["sent"]) > 0 and int(p["received"]) > 0 for p in parts)
-    # the fold, restated on the host from the two sub-maps (rank order 0, 1)
+    # the fold, restated on the host from the sub-maps in rank order
     subs = []
-    for r in range(2):
+    for r in range(world):
         e = pu.make_engine(lib, synth.CFG1, dict(synth.CFG1_PARAMS), 16384)
-        for f in frames[r::2]:
+        for f in frames[r::world]:
             pu.feed(e, f)
         subs.append(e.dump_blocks())
     acc = {}
@@ -229,6 +240,12 @@ def check_merged_against_single(lib, tmp_path, got):
 def test_frame_sharded_submaps_merge_into_one_tile_sharded_map(oracle, tmp_path):
     got = run_two_ranks(tmp_path, use_hip=False, worker=MERGE_WORKER.replace("merge_frames()", "[synth.cfg1_sphere(zc=1.5 + 0.01 * k) for k in range(4)]"))
     check_merged_against_single(oracle, tmp_path, got)
+
+
+def test_three_rank_merge_of_uneven_submaps(oracle, tmp_path):
+    """Three ranks, four frames (rank 0 fuses two): all-to-all with three different split lists, the fold in rank order."""
+    got = run_two_ranks(tmp_path, use_hip=False, worker=MERGE_WORKER.replace("merge_frames()", "[synth.cfg1_sphere(zc=1.5 + 0.01 * k) for k in range(4)]"), nproc=3)
+    check_merged_against_single(oracle, tmp_path, got, world=3)
 
 
 def test_pack_unpack_drop_single_process(oracle):
