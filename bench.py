@@ -18,6 +18,7 @@ resident in HBM before the timed region starts.  Beside it, in the same JSON lin
   roofline_hbm        the same kernel on a 2.5x larger room: the per-frame working set exceeds the 256 MiB Infinity Cache
   mc                  configs[2]: variance-adaptive multi-resolution map of the same stream + marching-cubes extraction,
                       roofline of the two k_mc launches (6144 B per fine block + 768 B per coarse block + 72 B per triangle)
+  lidar               configs[4], LiDAR half: 128 x 1024-point scans along a street (vbr.cfg parameters): scans/s, points/s
   pcie_inclusive_frames_per_s   the drop-in number: host numpy images -> mrh_upload_* every frame (never `value`)
   cpu_baseline        the oracle on a bounded sample of the same stream
 
@@ -281,6 +282,43 @@ def bench_single(args):
                            "note": "6144 B per fine block + 768 B per coarse block read once + 72 B per triangle written; latency / issue-bound, far below the HBM roof"}}
         me.close()
 
+    # ---- configs[4], LiDAR half: 128 x 1024 scans along a street (vbr.cfg parameters), scans resident in HBM
+    lidar = None
+    if not args.no_extras:
+        n_scans, w_scans = 25, 5
+        lcache = os.path.join(tempfile.gettempdir(), f"mrh_bench_vbr_{n_scans}.npz")
+        poses = synth.drive_poses(n_scans, step=0.5)
+        if os.path.exists(lcache):
+            scans = list(np.load(lcache)["scans"])
+        else:
+            scene = synth.street_canyon()
+            scans = [synth.lidar_scan(scene, t, q, rows=128, cols=1024) for t, q in poses]
+            np.savez(lcache, scans=np.stack(scans))
+        d_scans = [torch.from_numpy(np.ascontiguousarray(sc)).cuda() for sc in scans]
+        le = capi.Engine(hip, capi.Params(num_sdf_blocks=args.blocks, device_id=0, **synth.VBR_PARAMS))
+        le.set_camera(1, 1, 0, 0, 1, 1, 0.2, 100.0, model=1)
+
+        def run_scans(lo, hi):
+            for i in range(lo, hi):
+                t, q = poses[i]
+                le.set_pose(synth.quat_to_rot(q), t)
+                le.set_points_device(d_scans[i].data_ptr(), len(scans[i]))
+                le.integrate_points()
+
+        run_scans(0, w_scans)
+        le.sync()
+        t6 = time.perf_counter()
+        run_scans(w_scans, n_scans)
+        le.sync()
+        dt = time.perf_counter() - t6
+        npts = int(sum(len(sc) for sc in scans[w_scans:]))
+        lidar = {"workload": "VBR stand-in (configs[4], LiDAR half): 128 x 1024 scans along a 100 m street, vbr.cfg parameters (voxel 0.20 m, "
+                             "truncation 0.40 m, projective SDF), scans resident in HBM",
+                 "scans_per_s": (n_scans - w_scans) / dt, "us_per_scan": dt / (n_scans - w_scans) * 1e6, "points_per_s": npts / dt,
+                 "points_per_scan": int(len(scans[0])), "live_blocks_end": int(le.stats().occupied_fine)}
+        le.close()
+        del d_scans
+
     # ---- pass B: same frames, HIP events around every integrate-kernel launch + device-side U/M counters
     roof = profiled_roofline(eng, res, W, total, "configs[1] (value's workload)")
     eng.close()
@@ -350,7 +388,7 @@ def bench_single(args):
                    "frames_per_gpu": K, "voxel_size_m": 0.01, "truncation_m": 0.07, "parallelism": "single GPU", "live_blocks_end": occupied,
                    "hash_table": table},
         "roofline": roof, "roofline_hbm": roof_hbm, "mc": mc, "cpu_baseline": cpu,
-        "pcie_inclusive_frames_per_s": pcie_fps,
+        "lidar": lidar, "pcie_inclusive_frames_per_s": pcie_fps,
     }
     print(json.dumps(out), flush=True)
 
