@@ -73,6 +73,7 @@ def parse_args():
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 PMC sub-process passes (roofline.traffic = null)")
     ap.add_argument("--no-extras", action="store_true", help="N=1: only the headline pass and its roofline (no mc / hbm / pcie legs)")
     ap.add_argument("--pmc-inner", action="store_true", help=argparse.SUPPRESS)  # the workload alone, under rocprofv3
+    ap.add_argument("--pmc-inner-big", action="store_true", help=argparse.SUPPRESS)  # the roofline_hbm workload alone
     ap.add_argument("--frames-cache", default="", help=argparse.SUPPRESS)
     return ap.parse_args()
 
@@ -164,7 +165,7 @@ def profiled_roofline(eng, res: Resident, W: int, total: int, label: str):
             "profiled_pass_ms_per_step": prof_elapsed / max(total - W, 1) * 1e3}
 
 
-def pmc_traffic(args, kernel_prefix: str, cache: str):
+def pmc_traffic(args, kernel_prefix: str, cache: str, inner: str = "--pmc-inner", steps: int = 0, warmup: int = 0):
     """HBM bytes per launch of `kernel_prefix` from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE: separate runs,
     no trace flags beside --pmc) of this workload run as a sub-process.  Units are KiB; on gfx950 FETCH_SIZE counts a
     wide coalesced read at half its bytes, so it is doubled (MI355X_MICROARCH.md, HBM section)."""
@@ -176,21 +177,24 @@ def pmc_traffic(args, kernel_prefix: str, cache: str):
     vals = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="mrh_pmc_", dir="/tmp")
-        cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__), "--pmc-inner",
-               "--steps", str(args.steps), "--warmup", str(args.warmup), "--blocks", str(args.blocks), "--frames-cache", cache]
+        steps, warmup = steps or args.steps, warmup or args.warmup
+        cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__), inner,
+               "--steps", str(steps), "--warmup", str(warmup), "--blocks", str(args.blocks), "--frames-cache", cache]
         try:
             r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=180)
         except subprocess.TimeoutExpired:
             shutil.rmtree(d, ignore_errors=True)
             return None, f"rocprofv3 --pmc {counter} timed out"
-        tot, n = 0.0, 0
+        rows = []
         for fn in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
             for row in csv.DictReader(open(fn)):
                 name = row["Kernel_Name"].replace("void ", "")
                 if name.startswith(kernel_prefix) and row["Counter_Name"] == counter:
-                    tot += float(row["Counter_Value"])
-                    n += 1
+                    rows.append((int(row.get("Dispatch_Id", len(rows))), float(row["Counter_Value"])))
         shutil.rmtree(d, ignore_errors=True)
+        rows.sort()
+        rows = rows[warmup:] if len(rows) > warmup else rows  # the timed frames only (the map still grows during the warm-up)
+        tot, n = sum(v for _, v in rows), len(rows)
         if n == 0:
             return None, f"rocprofv3 --pmc {counter}: no dispatch of {kernel_prefix} recorded (rc {r.returncode}: {r.stderr[-200:]})"
         vals[counter] = (tot / n, n)
@@ -212,6 +216,14 @@ def bench_single(args):
     Kc = synth.REPLICA_640
     params = capi.Params(num_sdf_blocks=args.blocks, device_id=0, **synth.REPLICA_PARAMS)
     cache = args.frames_cache or os.path.join(tempfile.gettempdir(), f"mrh_bench_replica_{total}.npz")
+    if args.pmc_inner_big:  # the roofline_hbm workload alone (under rocprofv3 --pmc)
+        big = render_stream("replica_big", total, cache=cache)
+        rb = Resident(big, Kc)
+        be = make_engine(hip, capi.Params(num_sdf_blocks=max(args.blocks, 786432), device_id=0, **synth.REPLICA_PARAMS), Kc)
+        rb.run(be, 0, total)
+        be.sync()
+        be.close()
+        return
     frames = render_stream("replica", total, cache=cache)
     res = Resident(frames, Kc)
 
@@ -329,7 +341,8 @@ def bench_single(args):
     if not args.no_extras:
         nb = min(total, 60)
         wb = min(W, 10)
-        big = render_stream("replica_big", nb)
+        big_cache = os.path.join(tempfile.gettempdir(), f"mrh_bench_replica_big_{nb}.npz")
+        big = render_stream("replica_big", nb, cache=big_cache)
         rb = Resident(big, Kc)
         bp = capi.Params(num_sdf_blocks=max(args.blocks, 786432), device_id=0, **synth.REPLICA_PARAMS)
         be = make_engine(hip, bp, Kc)
@@ -344,6 +357,8 @@ def bench_single(args):
         roof_hbm["live_blocks_end"] = int(be.stats().occupied_fine)
         be.close()
         del rb
+        if not args.no_pmc:
+            roof_hbm["traffic"], roof_hbm["traffic_note"] = pmc_traffic(args, "mrh::k_back<true, false", big_cache, "--pmc-inner-big", nb - wb, wb)
 
     # ---- HBM traffic of the headline kernel, measured now (sub-processes under rocprofv3)
     if not args.no_pmc:
