@@ -64,12 +64,15 @@ def yaw_quat(angle: float) -> np.ndarray:
     return np.array([0.0, np.sin(angle / 2), 0.0, np.cos(angle / 2)], dtype=np.float32)
 
 
-def pixel_rays(K: Intrinsics) -> np.ndarray:
-    """[rows, cols, 3] float64 camera-frame ray directions with z == 1."""
+def pixel_rays(K: Intrinsics, offset: float = 0.5) -> np.ndarray:
+    """[rows, cols, 3] float64 camera-frame ray directions with z == 1.  `offset` = 0.5 is the reference's back-projection
+    (inverseProjection, camera.cuh:88: pixel (r, c) looks along (c - cx - 0.5, r - cy - 0.5)); its forward projection rounds
+    fx x / z + cx to the nearest pixel (camera.cuh:137-138), i.e. places the same pixel half a pixel further — `offset` = 0
+    renders for THAT convention (tests/test_parity_gpu.py::test_mesh_accuracy_against_the_analytic_room)."""
     c = np.arange(K.cols, dtype=np.float64)[None, :]
     r = np.arange(K.rows, dtype=np.float64)[:, None]
-    x = (c - K.cx - 0.5) / K.fx + 0 * r
-    y = (r - K.cy - 0.5) / K.fy + 0 * c
+    x = (c - K.cx - offset) / K.fx + 0 * r
+    y = (r - K.cy - offset) / K.fy + 0 * c
     return np.stack([x, y, np.ones_like(x)], axis=-1)
 
 
@@ -88,9 +91,9 @@ class Scene:
     checker: float = 0.10  # metres
     seed: int = 0
 
-    def cast(self, K: Intrinsics, R: np.ndarray, t: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    def cast(self, K: Intrinsics, R: np.ndarray, t: np.ndarray, pixel_offset: float = 0.5) -> Tuple[np.ndarray, np.ndarray]:
         """depth [rows, cols] float64 (ray parameter == camera z) and hit points [rows, cols, 3]."""
-        return self.cast_dirs(pixel_rays(K), R, t)
+        return self.cast_dirs(pixel_rays(K, pixel_offset), R, t)
 
     def cast_dirs(self, d_cam: np.ndarray, R: np.ndarray, t: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
         """Ray parameter of the first hit along sensor-frame directions d_cam [..., 3] and the hit points (world)."""
@@ -138,9 +141,9 @@ class Frame:
 
 
 def render(scene: Scene, K: Intrinsics, t: np.ndarray, q: np.ndarray, depth_scaling: Optional[float] = None,
-           noise_sigma: float = 0.0, rng: Optional[np.random.Generator] = None, max_depth: float = 30.0) -> Frame:
+           noise_sigma: float = 0.0, rng: Optional[np.random.Generator] = None, max_depth: float = 30.0, pixel_offset: float = 0.5) -> Frame:
     R = quat_to_rot(q)
-    depth, pts = scene.cast(K, R, t)
+    depth, pts = scene.cast(K, R, t, pixel_offset)
     if noise_sigma > 0:
         depth = depth + (rng or np.random.default_rng(0)).normal(0.0, noise_sigma, size=depth.shape)
     if depth_scaling:
