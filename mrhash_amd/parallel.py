@@ -214,7 +214,9 @@ def merge_submaps(engine: capi.Engine, dist, chunk_log2: int = 3) -> dict:
         out_counts.append(n)
         t = torch.empty(n * REC, dtype=torch.uint8, device=dev)
         if n:
-            t.copy_(_bytes_view(ptr, n * REC, on_device))  # the pack buffer is reused by the next pack
+            t.copy_(_bytes_view(ptr, n * REC, on_device))
+            if t.is_cuda:  # the copy runs on torch's stream, the next pack reuses (or re-allocates) the buffer on the library's
+                torch.cuda.synchronize()
         parts.append(t)
     counts = _all_gather_counts(dist, out_counts, dev)  # counts[src, dest]
     in_counts = [int(counts[src, rank]) for src in range(world)]
