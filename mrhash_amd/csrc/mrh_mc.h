@@ -408,15 +408,22 @@ __global__ __launch_bounds__(256) void k_list_keys(const int4* __restrict__ list
 // One workgroup (256 threads) per block of the sorted list.
 //   1. the 27 surrounding blocks are resolved once (table value or absent)                              -> s_nb
 //   2. every voxel marching cubes can sample for this block is staged in LDS ({sdf, rgbw} per fine cell) -> halo
-//   3. COUNT pass: class of every staged cell (1: weighted and clearly positive, 2: weighted and clearly negative, 4: never
-//      observed, 0: anything else) and an AND over the (2w + 1)^3 window of each voxel: everything marching cubes evaluates for a
-//      voxel — the eight trilinear corner values, the coarser re-samples they blend in on a resolution jump, or the raw
-//      sample a corner falls back to — is a convex combination of, or a sample from, cells of that window (fp32 evaluation
-//      error < 2e-5 x the largest magnitude), so if all of them share one class every corner has that sign, the cube index
-//      is 0 or 255 and the voxel has no triangle: it is not evaluated at all.  w = 1 for a fine voxel whose 3^3 cells lie
-//      in fine (or absent) blocks — every sample then stays inside those cells; w = 3 for a coarse voxel or a fine one
-//      next to a coarse block (Neigh's comment derives the reach).  "Clearly" = 1e-3 x sdf_bound <= |sdf| <= 1.001 x
-//      sdf_bound, sdf_bound = the largest truncation a sample can carry; anything outside (or NaN) is class 0.
+//   3. COUNT pass: class of every staged cell as a one-hot bit (1: weighted and clearly positive, 2: weighted and clearly
+//      negative, 4: never observed, 8: anything else) and an OR over the (2w + 1)^3 window of each voxel: everything marching
+//      cubes evaluates for a voxel — the eight trilinear corner values, the coarser re-samples they blend in on a resolution
+//      jump, or the raw sample a corner falls back to — is a convex combination of, or a sample from, cells of that window
+//      (fp32 evaluation error < 2e-5 x the largest magnitude).
+//        w = 1, a fine voxel whose 3^3 cells lie in fine (or absent) blocks: no re-sample can occur, so a cell without weight
+//        never contributes a VALUE (it invalidates the stencil, and a raw sample below min_weight_threshold ends the voxel
+//        without a triangle).  Without an "anything else" cell and without both signs among the weighted cells every corner
+//        that has a value has the same sign: cube index 0 or 255, no triangle — the voxel is not evaluated.  This also drops
+//        the two shells where the observed band ends (weighted cells of one sign next to unseen ones), five of every six
+//        voxels the one-class rule of the first version let through.
+//        w = 3, a coarse voxel or a fine one next to a coarse block (Neigh's comment derives the reach): a re-sample blends
+//        the sdf of a possibly UNWEIGHTED cell in (vds.cu:268, :296-309), so only a window whose cells all share one class
+//        is skipped.
+//      "Clearly" = 1e-3 x sdf_bound <= |sdf| <= 1.001 x sdf_bound, sdf_bound = the largest truncation a sample can carry;
+//      anything outside (or NaN) is class 8.
 //      EMIT pass: the candidates are the voxels the count pass found non-empty (per_voxel).
 //   4. the candidates are COMPACTED (LDS list) and evaluated densely, EIGHT lanes per voxel (one per cube corner,
 //      mc_group), through the staged cells: a lookup is the reference's float position -> voxel conversion, a subtraction
@@ -445,7 +452,10 @@ __device__ __forceinline__ bool voxel_touches_coarse(const int v, const u32 cmas
 constexpr int kMcThreads = 256;
 constexpr int kMcFillIters = (kHaloCells + kMcThreads - 1) / kMcThreads;  // 11
 template <bool EMIT>
-__global__ __launch_bounds__(kMcThreads) void k_mc(const Map m, const Tab t, const int4* __restrict__ sorted, const int n,
+// 4 waves per SIMD: left alone the allocator takes 147 VGPRs (3 waves); capped at 128 it spills 8-24 bytes and both passes
+// run 10-12 % faster — the staging half of the kernel is a chain of memory round trips and wants the extra workgroup per CU
+// (5 waves / 96 VGPRs: 100 bytes of scratch, no better).
+__global__ __launch_bounds__(kMcThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_mc(const Map m, const Tab t, const int4* __restrict__ sorted, const int n,
                                                    u32* __restrict__ counts, const u64* __restrict__ offsets,
                                                    mrh_triangle* __restrict__ out, const u64 max_tris, uint8_t* __restrict__ per_voxel,
                                                    const float sdf_bound) {
@@ -516,7 +526,7 @@ __global__ __launch_bounds__(kMcThreads) void k_mc(const Map m, const Tab t, con
       // third class: a cell without an observation (weight 0, or no block).  If a voxel's whole window is unseen, every
       // corner's trilinear stencil meets a weight-0 sample (vds.cu:283-284: invalid) and the raw sample it falls back to has
       // weight 0 < min_weight_threshold (marching_cubes.cu:89-93: return): no triangle.  Needs min_weight_threshold >= 1.
-      const uint8_t unseen = m.min_weight_threshold >= 1 ? 4 : 0;
+      const uint8_t unseen = m.min_weight_threshold >= 1 ? 4 : 8;  // 8 = "anything else": always a candidate
 #pragma unroll
       for (int it = 0; it < kMcFillIters; it++) {
         const int c = tid + it * kMcThreads;
@@ -527,7 +537,7 @@ __global__ __launch_bounds__(kMcThreads) void k_mc(const Map m, const Tab t, con
           s_rgbw[idx] = rw[it];
           if (!EMIT) {
             uint8_t cls = unseen;
-            if ((rw[it] >> 24) != 0) cls = (sv[it] >= lo && sv[it] <= hi) ? 1 : ((sv[it] <= -lo && sv[it] >= -hi) ? 2 : 0);
+            if ((rw[it] >> 24) != 0) cls = (sv[it] >= lo && sv[it] <= hi) ? 1 : ((sv[it] <= -lo && sv[it] >= -hi) ? 2 : 8);
             s_cls[0][idx] = cls;
           }
         }
@@ -546,8 +556,8 @@ __global__ __launch_bounds__(kMcThreads) void k_mc(const Map m, const Tab t, con
       for (int v = tid; v < nvox; v += kMcThreads)
         if (per_voxel[(size_t) e * 512 + v] != 0) s_cand[atomicAdd(&s_ncand, 1u)] = (unsigned short) v;
     } else if (staged && sdf_bound > 0.f) {
-      // per voxel: w = 1 window straight from the classes; does it need the wide one?
-      u32 acc1[2] = {7u, 7u};
+      // per voxel: w = 1 window straight from the classes (OR of the one-hot class bits); does it need the wide one?
+      u32 acc1[2] = {0u, 0u};
       bool wide[2] = {false, false};
 #pragma unroll
       for (int h = 0; h < 2; h++) {
@@ -558,36 +568,36 @@ __global__ __launch_bounds__(kMcThreads) void k_mc(const Map m, const Tab t, con
           } else {
             const int x = v & 7, y = (v >> 3) & 7, z = v >> 6;
             const int base = ((z + kHaloRim) * kHaloSide + (y + kHaloRim)) * kHaloSide + (x + kHaloRim);
-            u32 acc = 7u;
+            u32 acc = 0u;
 #pragma unroll
             for (int dz = -1; dz <= 1; dz++)
 #pragma unroll
               for (int dy = -1; dy <= 1; dy++)
 #pragma unroll
-                for (int dx = -1; dx <= 1; dx++) acc &= s_cls[0][base + (dz * kHaloSide + dy) * kHaloSide + dx];
+                for (int dx = -1; dx <= 1; dx++) acc |= s_cls[0][base + (dz * kHaloSide + dy) * kHaloSide + dx];
             acc1[h] = acc;
             wide[h] = voxel_touches_coarse(v, cmask);
           }
         }
       }
-      if (cmask) {  // uniform: separable AND of the classes over [-3, 3]^3: x, then y, then z
+      if (cmask) {  // uniform: separable OR of the class bits over [-3, 3]^3: x, then y, then z
         __syncthreads();
         constexpr int w = kHaloRim;
         for (int c = tid; c < kBlockSide * kHaloSide * kHaloSide; c += kMcThreads) {  // x in 0..7, all staged y, z
           const int x = c & 7, yz = c >> 3;
           const int base = yz * kHaloSide + (x + kHaloRim);
-          u32 acc = 7u;
+          u32 acc = 0u;
 #pragma unroll
-          for (int d = -w; d <= w; d++) acc &= s_cls[0][base + d];
+          for (int d = -w; d <= w; d++) acc |= s_cls[0][base + d];
           s_cls[1][base] = (uint8_t) acc;
         }
         __syncthreads();
         for (int c = tid; c < kBlockSide * kBlockSide * kHaloSide; c += kMcThreads) {  // x, y in 0..7, all staged z
           const int x = c & 7, y = (c >> 3) & 7, z = c >> 6;
           const int base = (z * kHaloSide + (y + kHaloRim)) * kHaloSide + (x + kHaloRim);
-          u32 acc = 7u;
+          u32 acc = 0u;
 #pragma unroll
-          for (int d = -w; d <= w; d++) acc &= s_cls[1][base + d * kHaloSide];
+          for (int d = -w; d <= w; d++) acc |= s_cls[1][base + d * kHaloSide];
           s_cls[0][base] = (uint8_t) acc;
         }
         __syncthreads();
@@ -597,16 +607,24 @@ __global__ __launch_bounds__(kMcThreads) void k_mc(const Map m, const Tab t, con
         const int v = tid + h * kMcThreads;
         if (v < nvox) {
           u32 acc = acc1[h];
+          bool empty;
           if (wide[h]) {
             int x, y, z;
             if (!coarse) { x = v & 7; y = (v >> 3) & 7; z = v >> 6; }
             else { x = 2 * (v & 3); y = 2 * ((v >> 2) & 3); z = 2 * (v >> 4); }
             const int base = ((z + kHaloRim) * kHaloSide + (y + kHaloRim)) * kHaloSide + (x + kHaloRim);
-            acc = 7u;
+            acc = 0u;
 #pragma unroll
-            for (int d = -kHaloRim; d <= kHaloRim; d++) acc &= s_cls[0][base + d * kHaloSide * kHaloSide];
+            for (int d = -kHaloRim; d <= kHaloRim; d++) acc |= s_cls[0][base + d * kHaloSide * kHaloSide];
+            empty = acc == 1u || acc == 2u || acc == 4u;  // the whole window shares one class (re-samples on resolution jumps blend UNWEIGHTED cells in, so nothing weaker holds here)
+          } else {
+            // no resolution jump can occur: every corner value is a convex combination of WEIGHTED cells (a sample without
+            // weight invalidates the stencil, vds.cu:283-284) or a weighted raw sample — or the voxel returns without a
+            // triangle (raw sample below min_weight_threshold).  Unseen cells therefore never contribute a value: without
+            // an "anything else" cell and without BOTH signs in the window every corner that has a value has the same sign.
+            empty = (acc & 8u) == 0u && (acc & 3u) != 3u;
           }
-          if (acc == 0u) s_cand[atomicAdd(&s_ncand, 1u)] = (unsigned short) v;  // the window's cells do not share one class
+          if (!empty) s_cand[atomicAdd(&s_ncand, 1u)] = (unsigned short) v;
         }
       }
     } else {
