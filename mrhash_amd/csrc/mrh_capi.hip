@@ -118,6 +118,10 @@ struct mrh_ctx {
   // pool level for the host without a read-back stall (mrh_peek_free_blocks): a 2-int D2H per frame into pinned memory
   int* h_peek = nullptr;               // [8][8] pinned: ctr[0 .. 4] = free-list levels ... error flags per report
   u32* h_scan = nullptr;               // pinned {hwm, last offset, last count, sequence}: the mid-scan report of mrh_integrate_points
+  // grow-only device scratch of the extraction (0: block list / counts / per-voxel counts, 1: mesh post-process, 2: V / C / F):
+  // a mesh of a million triangles needs ~400 MB of temporaries, and hipMalloc + hipFree of those cost more than the kernels
+  void* arena[3] = {nullptr, nullptr, nullptr};
+  size_t arena_cap[3] = {0, 0, 0};
   u32 scan_seq = 0;
   uint64_t peek_seq[8] = {};
   bool peek_enabled = false;
@@ -269,6 +273,7 @@ void free_all(mrh_ctx* c) {
   for (hipEvent_t e : c->frame_done) if (e) (void) hipEventDestroy(e);
   if (c->h_peek) (void) hipHostFree(c->h_peek);
   if (c->h_scan) (void) hipHostFree(c->h_scan);
+  for (void* a : c->arena) if (a) (void) hipFree(a);
   F(c->d_decision); F(c->d_zbuf); F(c->d_realloc); F(c->d_reint); F(c->d_flag);
   F(c->d_upd_partials); F(c->d_misc); F(c->d_rcp_w); F(c->d_cfree); F(c->d_zmin); F(c->d_points); F(c->d_pt_counts); F(c->d_pt_offsets); F(c->d_rec_keys[0]); F(c->d_rec_keys[1]); F(c->d_rec_vals[0]); F(c->d_rec_vals[1]); F(c->d_sort_tmp); F(c->fast.summary); F(c->fast.summary_c); F(c->fast.bbox); F(c->d_cnt_partials);
   F(c->d_pack); F(c->d_halo); F(c->d_taken); F(c->d_cloud); F(c->d_normals); F(c->d_soup);
@@ -451,6 +456,20 @@ void process_triangles(mrh_ctx* c) {
   c->F.assign(F.data(), F.data() + F.size());
 }
 
+// grow-only scratch `slot` of at least `bytes` (contents undefined); the previous buffer is released only after the stream drained
+int arena_get(mrh_ctx* c, const int slot, const size_t bytes, void** out) {
+  if (bytes > c->arena_cap[slot]) {
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->arena[slot]) HIP_TRY(c, hipFree(c->arena[slot]));
+    c->arena[slot] = nullptr; c->arena_cap[slot] = 0;
+    const size_t cap = bytes + bytes / 4;
+    HIP_TRY(c, hipMalloc(&c->arena[slot], cap));
+    c->arena_cap[slot] = cap;
+  }
+  *out = c->arena[slot];
+  return MRH_OK;
+}
+
 // MeshExtractor::processTriangles on the device (mrh_mesh.h): fills V / C / F from a triangle soup in device memory.
 // MRH_MESH_HOST=1 keeps the host restatement above (same arrays; tests compare the two).
 int process_triangles_device(mrh_ctx* c, const mrh_triangle* d_tris, const size_t nt) {
@@ -464,7 +483,10 @@ int process_triangles_device(mrh_ctx* c, const mrh_triangle* d_tris, const size_
   const size_t tmp_bytes = mesh_sort_tmp_bytes(n);
   MeshScratch m;
   m.bytes = (size_t) n * (4 * 13 + 8 * 2) + tmp_bytes + 64 * 256;
-  HIP_TRY(c, hipMalloc(&m.base, m.bytes));
+  {
+    const int arc = arena_get(c, 1, m.bytes, &m.base);
+    if (arc) return arc;
+  }
   u32* kx = m.take<u32>(n);      u64* kyz = m.take<u64>(n);     u32* idx0 = m.take<u32>(n);   u32* never = m.take<u32>(n);
   u64* lo_s = m.take<u64>(n);    u32* mid = m.take<u32>(n);     u32* order = m.take<u32>(n);  u32* hi_g = m.take<u32>(n);
   u32* hi_s = m.take<u32>(n);    u32* headpos = m.take<u32>(n); u32* rep = m.take<u32>(n);    u32* first = m.take<u32>(n);
@@ -490,8 +512,15 @@ int process_triangles_device(mrh_ctx* c, const mrh_triangle* d_tris, const size_
     MESH_TRY(hipMemcpyAsync(&last_first, first + (n - 1), sizeof(u32), hipMemcpyDeviceToHost, s));
     MESH_TRY(hipStreamSynchronize(s));
     const size_t nv = (size_t) last_vid + last_first;
-    MESH_TRY(hipMalloc((void**) &dV, nv * 3 * sizeof(double)));
-    MESH_TRY(hipMalloc((void**) &dC, nv * 3 * sizeof(double)));
+    {  // V, C and (at most nt) faces share slot 2
+      void* vcf = nullptr;
+      const size_t vbytes = (nv * 3 * sizeof(double) + 255) & ~(size_t) 255;
+      rc = arena_get(c, 2, 2 * vbytes + (size_t) ntr * 3 * sizeof(int), &vcf);
+      if (rc) goto done;
+      dV = (double*) vcf;
+      dC = (double*) ((char*) vcf + vbytes);
+      dF = (int*) ((char*) vcf + 2 * vbytes);
+    }
     k_mesh_emit_vertices<<<gv, 256, 0, s>>>(soup, rep, first, vid, n, dV, dC, corner);
     // ---- faces (the vertex buffers are reused: nt < n)
     u32* ka = kx; u64* kbc = kyz; u32* fidx = idx0; u32* degenerate = never; u32* keep = rep; u32* fpos = vid;
@@ -506,10 +535,7 @@ int process_triangles_device(mrh_ctx* c, const mrh_triangle* d_tris, const size_
     MESH_TRY(hipMemcpyAsync(&last_keep, keep + (ntr - 1), sizeof(u32), hipMemcpyDeviceToHost, s));
     MESH_TRY(hipStreamSynchronize(s));
     const size_t nf = (size_t) last_pos + last_keep;
-    if (nf) {
-      MESH_TRY(hipMalloc((void**) &dF, nf * 3 * sizeof(int)));
-      k_mesh_emit_faces<<<gf, 256, 0, s>>>(corner, keep, fpos, ntr, dF);
-    }
+    if (nf) k_mesh_emit_faces<<<gf, 256, 0, s>>>(corner, keep, fpos, ntr, dF);
     c->V.resize_discard(nv * 3); c->C.resize_discard(nv * 3); c->F.resize_discard(nf * 3);
     MESH_TRY(hipMemcpyAsync(c->V.data(), dV, nv * 3 * sizeof(double), hipMemcpyDeviceToHost, s));
     MESH_TRY(hipMemcpyAsync(c->C.data(), dC, nv * 3 * sizeof(double), hipMemcpyDeviceToHost, s));
@@ -519,10 +545,6 @@ int process_triangles_device(mrh_ctx* c, const mrh_triangle* d_tris, const size_
   }
 done:
 #undef MESH_TRY
-  if (dV) (void) hipFree(dV);
-  if (dC) (void) hipFree(dC);
-  if (dF) (void) hipFree(dF);
-  (void) hipFree(m.base);
   return rc;
 }
 
@@ -1709,29 +1731,32 @@ int mrh_extract_triangles(mrh_ctx* c, const mrh_triangle** out_tris, uint64_t* o
     // canonical order: sort the block list by position (packed-key order == (x,y,z) order) — on the device; the host
     // only needs the sorted list for the per-block descriptors it hands out (mrh_get_triangle_blocks)
     std::vector<int4> list((size_t) n);
+    // temporaries of this call, carved from the grow-only scratch (slot 0)
+    u64 *k_in, *k_out, *d_offsets;
+    int4* sorted;
+    u32* d_counts;
+    uint8_t* d_per_voxel;  // triangles per voxel from the count pass: the emit pass skips the empty ones
+    void* tmp;
+    size_t sort_bytes = 0;
+    HIP_TRY(c, rocprim::radix_sort_pairs(nullptr, sort_bytes, (u64*) nullptr, (u64*) nullptr, (int4*) nullptr, (int4*) nullptr, (size_t) n, 0, 63, s));
     {
-      DevBuf<u64> k_in, k_out;
-      DevBuf<int4> sorted;
-      DevBuf<char> tmp;
-      HIP_TRY(c, k_in.alloc((size_t) n));
-      HIP_TRY(c, k_out.alloc((size_t) n));
-      HIP_TRY(c, sorted.alloc((size_t) n));
+      MeshScratch a;
+      a.bytes = (size_t) n * (8 * 3 + 16 + 4 + 512) + sort_bytes + 16 * 256;
+      rc = arena_get(c, 0, a.bytes, &a.base);
+      if (rc) return rc;
+      k_in = a.take<u64>((size_t) n); k_out = a.take<u64>((size_t) n); d_offsets = a.take<u64>((size_t) n);
+      sorted = a.take<int4>((size_t) n); d_counts = a.take<u32>((size_t) n); d_per_voxel = a.take<uint8_t>((size_t) n * 512);
+      tmp = a.take<char>(sort_bytes ? sort_bytes : 1);
+    }
+    {
       k_list_keys<<<(n + 255) / 256, 256, 0, s>>>(c->tab.compact, n, k_in);
-      size_t bytes = 0;
-      HIP_TRY(c, rocprim::radix_sort_pairs(nullptr, bytes, (u64*) k_in, (u64*) k_out, c->tab.compact, (int4*) sorted, (size_t) n, 0, 63, s));
-      HIP_TRY(c, tmp.alloc(bytes ? bytes : 1));
-      HIP_TRY(c, rocprim::radix_sort_pairs((void*) (char*) tmp, bytes, (u64*) k_in, (u64*) k_out, c->tab.compact, (int4*) sorted, (size_t) n, 0, 63, s));
-      HIP_TRY(c, hipMemcpyAsync(c->tab.compact, (int4*) sorted, (size_t) n * sizeof(int4), hipMemcpyDeviceToDevice, s));
-      HIP_TRY(c, hipMemcpyAsync(list.data(), (int4*) sorted, (size_t) n * sizeof(int4), hipMemcpyDeviceToHost, s));
+      size_t bytes = sort_bytes;
+      HIP_TRY(c, rocprim::radix_sort_pairs(tmp, bytes, k_in, k_out, c->tab.compact, sorted, (size_t) n, 0, 63, s));
+      HIP_TRY(c, hipMemcpyAsync(c->tab.compact, sorted, (size_t) n * sizeof(int4), hipMemcpyDeviceToDevice, s));
+      HIP_TRY(c, hipMemcpyAsync(list.data(), sorted, (size_t) n * sizeof(int4), hipMemcpyDeviceToHost, s));
       HIP_TRY(c, hipStreamSynchronize(s));
     }
     t1 = now();
-    DevBuf<u32> d_counts;
-    DevBuf<u64> d_offsets;
-    DevBuf<uint8_t> d_per_voxel;  // triangles per voxel from the count pass: the emit pass skips the empty ones
-    HIP_TRY(c, d_counts.alloc((size_t) n));
-    HIP_TRY(c, d_offsets.alloc((size_t) n));
-    HIP_TRY(c, d_per_voxel.alloc((size_t) n * 512));
     const int grid = n < 8192 ? n : 8192;
     // largest truncation a stored sample can carry (integration clamps to trunc + scale * depth, depth <= the integration distance)
     const float sdf_bound = c->has_camera && !getenv("MRH_MC_NO_PRESCREEN") ? c->map.trunc + c->map.trunc_scale * c->cam.max_int_dist : 0.f;
