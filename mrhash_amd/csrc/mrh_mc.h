@@ -417,8 +417,8 @@ __global__ __launch_bounds__(256) void k_list_keys(const int4* __restrict__ list
 //        never contributes a VALUE (it invalidates the stencil, and a raw sample below min_weight_threshold ends the voxel
 //        without a triangle).  Without an "anything else" cell and without both signs among the weighted cells every corner
 //        that has a value has the same sign: cube index 0 or 255, no triangle — the voxel is not evaluated.  This also drops
-//        the two shells where the observed band ends (weighted cells of one sign next to unseen ones), five of every six
-//        voxels the one-class rule of the first version let through.
+//        the two shells where the observed band ends (weighted cells of one sign next to unseen ones), which made up most
+//        of what the one-class rule of the first version let through (4.03 M candidates for 1.47 M triangles).
 //        w = 3, a coarse voxel or a fine one next to a coarse block (Neigh's comment derives the reach): a re-sample blends
 //        the sdf of a possibly UNWEIGHTED cell in (vds.cu:268, :296-309), so only a window whose cells all share one class
 //        is skipped.
