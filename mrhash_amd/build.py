@@ -57,6 +57,13 @@ def build_oracle(verbose: bool = True) -> str:
     return os.path.join(ROOT, "oracle", "_build", "libmrh_oracle.so")
 
 
+def build_oracle_ref(verbose: bool = True) -> str:
+    """oracle/_ref: the slice of the reference that builds from its own sources where they lie (oracle/Makefile `ref`):
+    nothing happens when /root/reference is absent (the GPU box uses the prebuilt files).  Test infrastructure only."""
+    subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "ref"], check=True, stdout=None if verbose else subprocess.DEVNULL)
+    return os.path.join(ROOT, "oracle", "_ref")
+
+
 def build_pybind(force: bool = False, verbose: bool = True) -> str:
     import pybind11
 

@@ -15,13 +15,16 @@
  * NO fused multiply-add contraction (-ffp-contract=off), correctly rounded / and sqrt,
  * `rsqrtf(x)` restated as `1.0f / sqrtf(x)`, float->int conversions saturating with NaN -> 0.
  *
- * Parity pinning: the reference cannot be built or run in this environment (no nvcc, no CUDA
- * device, Eigen/nanobind/OpenCV absent) and its tests hold no golden values for integration,
- * variance adaptation, GC or marching cubes.  The oracle is pinned against (a) the invariants
- * the reference's own tests assert (tests/test_hash_utils.cu, test_projections.cu,
- * test_marching_cubes.cpp) and (b) three host-computable known answers captured from
- * voxel_hash_utils.cuh.  For integrate / variance / GC / marching-cubes results
- * the status is therefore "PARITY UNPINNED against reference GPU output".
+ * Parity pinning: the reference as a whole cannot be built or run in this environment (no nvcc, no
+ * CUDA device, Eigen/nanobind/OpenCV absent) and its tests hold no golden values for integration,
+ * variance adaptation, GC or marching cubes.  The oracle is pinned against (a) the slice of the
+ * reference that DOES build from its own sources (oracle/_ref, Makefile target `ref`:
+ * voxel_hash_utils.cuh's host-visible structs, constants and index helpers by g++, params.h's
+ * marching-cubes tables by hipcc; tests/test_oracle_pinning.py, tests/test_parity_gpu.py), (b) the
+ * invariants the reference's own tests assert (tests/test_hash_utils.cu, test_projections.cu,
+ * test_marching_cubes.cpp), (c) a second, independent restatement of every step
+ * (tests/independent.py) and analytic known answers.  For integrate / variance / GC /
+ * marching-cubes RESULTS the status remains "PARITY UNPINNED against reference GPU output".
  *
  * Canonicalisation of race-ordered reference behaviour (documented deviations):
  *   C1  compact-list order = block position ascending in (x,y,z)   (reference: atomicAdd winners,

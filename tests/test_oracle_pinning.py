@@ -248,3 +248,91 @@ def test_projection_roundtrip_spherical(oracle):
         assert max(abs(q[i] - p[i]) for i in range(3)) < 2e-2
         n_ok += 1
     assert n_ok > 10000
+
+
+# ---- oracle/_ref: the slice of the REFERENCE that compiles for the host as it lies (oracle/Makefile `ref`, oracle/ref_vhu_host.cpp) ----
+
+def _ref_host():
+    import os
+
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "libref_vhu_host.so")
+    if not os.path.exists(path):
+        pytest.skip("oracle/_ref/libref_vhu_host.so not built (needs /root/reference: `make -C oracle ref`)")
+    return C.CDLL(path)
+
+
+def test_reference_compiled_struct_layouts_and_constants():
+    """voxel_hash_utils.cuh / params.h of the reference, compiled by g++ from where they lie: the layouts of Voxel, HashEntry,
+    Vertex, Triangle and the constants of the path — against the boundary structs and the numbers this repository uses."""
+    ref = _ref_host()
+    lay = (C.c_int32 * 16)()
+    ref.ref_struct_layout(lay)
+    assert list(lay[:5]) == [12, 0, 4, 8, 11]          # Voxel: sdf, sum_squared, rgb[3], weight (SURVEY.md 8a T1)
+    assert list(lay[5:10]) == [24, 0, 12, 16, 20]      # HashEntry: pos, offset, ptr, resolution (T2)
+    assert list(lay[10:15]) == [24, 12, 72, 24, 48]    # Vertex {p, c}, Triangle {v0, v1, v2} (T3)
+    vd = capi.VOXEL_DTYPE
+    assert vd.itemsize == lay[0] and [vd.fields[k][1] for k in ("sdf", "sum_squared", "rgb", "weight")] == list(lay[1:5])
+    assert capi.TRI_DTYPE.itemsize * 3 == lay[12] or capi.TRI_DTYPE.itemsize == lay[10]
+    v = (C.c_uint8 * 12)()
+    ref.ref_default_voxel(v)
+    assert bytes(v) == bytes(12)
+    e = (C.c_uint8 * 24)()
+    ref.ref_default_hash_entry(e)
+    ent = np.frombuffer(bytes(e), dtype=HASH_ENTRY)[0]
+    assert tuple(ent["pos"]) == (0, 0, 0) and ent["offset"] == 0 and ent["ptr"] == -2 and ent["resolution"] == 0
+    k = (C.c_int64 * 16)()
+    ref.ref_constants(k)
+    assert list(k[:3]) == [73856093, 19349669, 83492791]
+    assert list(k[3:15]) == [8, 512, 3, 10, 7, 255, 1024, 16, -1, -2, 0, 8]
+    ref.ref_float_constant.restype = C.c_double
+    assert ref.ref_float_constant(0) == float(np.float32(1e-6)) and ref.ref_float_constant(1) == float(np.float32(0.15))
+    assert ref.ref_float_constant(2) == 10.0
+
+
+def test_reference_compiled_index_helpers_match_the_oracle(oracle):
+    """linearizeVoxelPos / virtualVoxelPosToSDFBlockIndex / delinearizeVoxelPos / SDFBlockToVirtualVoxelPos /
+    virtualVoxelPosToWorld of the reference, EXECUTED (host build of voxel_hash_utils.cuh), against the oracle's restatement
+    and the independent numpy one: every voxel position of a 61^3 cube around the origin for block sizes 8, 4 and 2."""
+    import independent as ind
+
+    ref = _ref_host()
+    r = np.arange(-30, 31, dtype=np.int32)
+    xyz = np.stack(np.meshgrid(r, r, r, indexing="ij"), -1).reshape(-1, 3).astype(np.int32)
+    xyz = np.ascontiguousarray(xyz)
+    n = len(xyz)
+    oracle.orc_kat_voxel_to_block_index.restype = C.c_uint
+    for bs in (8, 4, 2):
+        out = np.zeros(n, np.uint32)
+        ref.ref_voxel_to_block_index(xyz.ctypes.data_as(C.c_void_p), C.c_int64(n), bs, out.ctypes.data_as(C.c_void_p))
+        # the reference's formula: local coordinate made non-negative, divided by 8 / bs, linearised with stride 8 (vhu.cuh:110-128)
+        loc = (xyz % 8) // (8 // bs)
+        assert np.array_equal(out, (loc[:, 2] * 64 + loc[:, 1] * 8 + loc[:, 0]).astype(np.uint32))
+        step = 7  # the oracle hook is one ctypes call per position: a regular subsample, plus the survey's known answers
+        got = np.array([oracle.orc_kat_voxel_to_block_index(int(x), int(y), int(z), bs) for x, y, z in xyz[::step]], np.uint32)
+        assert np.array_equal(got, out[::step])
+        lin = np.zeros(n, np.uint32)
+        ref.ref_linearize(xyz.ctypes.data_as(C.c_void_p), C.c_int64(n), bs, lin.ctypes.data_as(C.c_void_p))
+        assert np.array_equal(lin, (xyz[:, 2] * bs * bs + xyz[:, 1] * bs + xyz[:, 0]).astype(np.uint32))
+        idx = np.arange(bs ** 3, dtype=np.uint32)
+        de = np.zeros((len(idx), 3), np.uint32)
+        ref.ref_delinearize(idx.ctypes.data_as(C.c_void_p), C.c_int64(len(idx)), bs, de.ctypes.data_as(C.c_void_p))
+        o = (C.c_int * 3)()
+        for i in idx[:: max(1, len(idx) // 64)]:
+            oracle.orc_kat_delinearize(int(i), bs, o)
+            assert tuple(o) == tuple(int(c) for c in de[i])
+        assert np.array_equal(de, np.stack([idx % bs, (idx % (bs * bs)) // bs, idx // (bs * bs)], -1))
+    assert ref_known(ref, (-9, 17, 3), 8) == 207 and ref_known(ref, (-9, 17, 3), 4) == 67  # the survey's captured answers
+    b2v = np.zeros_like(xyz)
+    ref.ref_block_to_voxel(xyz.ctypes.data_as(C.c_void_p), C.c_int64(n), b2v.ctypes.data_as(C.c_void_p))
+    assert np.array_equal(b2v, xyz * 8)
+    for vs in (0.01, 0.02, 0.2, 1e-6):
+        w = np.zeros((n, 3), np.float32)
+        ref.ref_voxel_to_world(C.c_float(vs), xyz.ctypes.data_as(C.c_void_p), C.c_int64(n), w.ctypes.data_as(C.c_void_p))
+        assert np.array_equal(w.view(np.uint32), ind.voxel_to_world(np.float32(vs), xyz).view(np.uint32))
+
+
+def ref_known(ref, v, bs):
+    xyz = np.array([v], np.int32)
+    out = np.zeros(1, np.uint32)
+    ref.ref_voxel_to_block_index(xyz.ctypes.data_as(C.c_void_p), C.c_int64(1), bs, out.ctypes.data_as(C.c_void_p))
+    return int(out[0])

@@ -541,6 +541,38 @@ def test_default_capacity_rule_sizes_the_pool_to_hbm(hip):
     small.close()
 
 
+def test_reference_compiled_tables_equal_the_generated_header():
+    """oracle/_ref/ref_params_dump = the reference's params.h compiled for gfx950 as it lies (its marching-cubes tables are
+    `__device__ const` arrays): the values the reference's own source defines, read back through a kernel, against
+    include/mrh_mc_tables.h (generated by tools/gen_mc_tables.py) and the constants this repository uses."""
+    import json
+    import os
+    import re
+    import subprocess
+
+    exe = os.path.join(pu.ROOT, "oracle", "_ref", "ref_params_dump")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/ref_params_dump not built (needs /root/reference at build time: `make -C oracle ref`)")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    d = json.loads(r.stdout)
+    assert d["p"] == [73856093, 19349669, 83492791] and d["sdf_block_size"] == 8 and d["hash_bucket_size"] == 10 and d["linked_list_size"] == 7
+    assert d["integration_weight_max"] == 255 and d["max_dda_iteration_count"] == 1024 and d["n_threads"] == 16
+    assert np.float32(d["float_epsilon"]) == np.float32(1e-6) and np.float32(d["stream_threshold"]) == np.float32(0.15)  # printed with 9 digits: exact for binary32
+    assert d["vert_offset"] == [c for k in range(8) for c in (7 * ((k >> 2) & 1), 7 * ((k >> 1) & 1), 7 * (k & 1))]
+    cls, data, vert = d["regularCellClass"], d["regularCellData"], d["regularVertexData"]
+    assert len(cls) == 256 and len(data) == 256 and len(vert) == 256 * 12
+    txt = open(os.path.join(pu.ROOT, "include", "mrh_mc_tables.h")).read()
+    rows = re.findall(r"\{((?:0x[0-9A-Fa-f]{2},?){16})\}", txt)
+    mine = [[int(x, 16) for x in row.split(",") if x] for row in rows[:256]]
+    assert len(mine) == 256
+    for cube in range(256):
+        geo = data[cls[cube] * 16]
+        ntri = geo & 0x0F  # RegularCellData::getTriangleCount (params.h:110-112)
+        want = [ntri] + [vert[cube * 12 + data[cls[cube] * 16 + 1 + s]] & 0xFF for s in range(3 * ntri)]
+        assert mine[cube][: 1 + 3 * ntri] == want, cube
+
+
 @pytest.mark.parametrize("var,pixel_offset", [(0.0, 0.0), (0.0, 0.5), (0.005, 0.0)])
 def test_mesh_accuracy_against_the_analytic_room(hip, var, pixel_offset):
     """A check from OUTSIDE the oracle, at BASELINE's full size: 60 frames of the 640x480 Replica stand-in (depth quantised to
