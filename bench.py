@@ -53,6 +53,19 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MALL_BYTES = 256 << 20
 
+_RESULT_FD = None  # the process's original stdout, once main() has pointed fd 1 at stderr
+
+
+def emit(out: dict) -> None:
+    """The ONE JSON line of the run, on the real stdout.  Everything else that lands on fd 1 during the run — gloo's
+    connection banner, anything a runtime library prints — has been pointed at stderr by main(), so the line stands alone."""
+    line = (json.dumps(out) + "\n").encode()
+    if _RESULT_FD is None:
+        sys.stdout.write(line.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_RESULT_FD, line)
+
 
 def free_port() -> int:
     s = socket.socket()
@@ -405,7 +418,7 @@ def bench_single(args):
         "roofline": roof, "roofline_hbm": roof_hbm, "mc": mc, "cpu_baseline": cpu,
         "lidar": lidar, "pcie_inclusive_frames_per_s": pcie_fps,
     }
-    print(json.dumps(out), flush=True)
+    emit(out)
 
 
 # ---- N > 1 ---------------------------------------------------------------------------------------------------------
@@ -482,6 +495,15 @@ def bench_multi(args):
     allc = allc.cpu().numpy().reshape(world, 4)
     eng.close()
 
+    # ---- roofline of the integrate kernel on rank 0's own segment (profiled pass on a second context; the other ranks wait)
+    roof = None
+    if rank == 0:
+        pe = make_engine(hip, params, Kc)
+        roof = profiled_roofline(pe, mine, W, total, f"configs[3], rank 0's segment of the frame-sharded stream ({K} frames)")
+        roof["cache_note"] = "per-frame working set inside the 256 MiB Infinity Cache (see the N = 1 line's roofline_hbm for the kernel outside it)"
+        pe.close()
+    barrier()
+
     # ---- tile-sharded fusion of ONE stream (rank 0's segment) by all ranks
     shared = mine if rank == 0 else Resident(render_stream("scannet", total, start=0), Kc)
     tp = capi.Params(num_sdf_blocks=args.blocks, device_id=device_index, shard_rank=rank, shard_count=world, shard_chunk_log2=chunk_log2,
@@ -521,9 +543,9 @@ def bench_multi(args):
                                      f"{world} tables == the single-GPU map); starve frames run their MIN all-reduce; strong scaling",
                              "frames_per_s": K / tile_elapsed, "ms_per_step": tile_elapsed / K * 1e3, "owned_blocks_rank0": tile_blocks,
                              "chunk_log2": chunk_log2},
-            "roofline": None, "cpu_baseline": None,
+            "roofline": roof, "cpu_baseline": None,
         }
-        print(json.dumps(out), flush=True)
+        emit(out)
     barrier()
     dist.destroy_process_group()
 
@@ -545,6 +567,11 @@ def main():
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
                "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
         raise SystemExit(subprocess.call(cmd, env=env))
+    if not args.pmc_inner and not args.pmc_inner_big:
+        global _RESULT_FD
+        sys.stdout.flush()
+        _RESULT_FD = os.dup(1)
+        os.dup2(2, 1)  # from here on fd 1 is stderr for every library in the process; emit() writes the result line
     import torch
 
     if not torch.cuda.is_available():
