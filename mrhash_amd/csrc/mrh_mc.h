@@ -437,16 +437,14 @@ __global__ __launch_bounds__(256) void k_list_keys(const int4* __restrict__ list
 __device__ __forceinline__ bool voxel_touches_coarse(const int v, const u32 cmask) {
   if (cmask == 0u) return false;
   const int x = v & 7, y = (v >> 3) & 7, z = v >> 6;
-  u32 touched = 0;
-#pragma unroll
-  for (int i = 0; i < 27; i++) {
-    const int bx = i % 3, by = (i / 3) % 3, bz = i / 9;
-    const bool tx = bx == 1 || (bx == 0 && x == 0) || (bx == 2 && x == 7);
-    const bool ty = by == 1 || (by == 0 && y == 0) || (by == 2 && y == 7);
-    const bool tz = bz == 1 || (bz == 0 && z == 0) || (bz == 2 && z == 7);
-    touched |= (tx && ty && tz) ? (1u << i) : 0u;
-  }
-  return (touched & cmask) != 0u;
+  // per axis: which of the three neighbour columns (previous, own, next) the 3 cells fall into; bit i of the product set =
+  // neighbour (bz, by, bx) with i = bz * 9 + by * 3 + bx, the numbering of s_nb / cmask
+  const u32 tx = 2u | (x == 0 ? 1u : 0u) | (x == 7 ? 4u : 0u);
+  const u32 ty = 2u | (y == 0 ? 1u : 0u) | (y == 7 ? 4u : 0u);
+  const u32 tz = 2u | (z == 0 ? 1u : 0u) | (z == 7 ? 4u : 0u);
+  const u32 plane = ((ty & 1u) ? tx : 0u) | (tx << 3) | ((ty & 4u) ? tx << 6 : 0u);
+  const u32 cube = ((tz & 1u) ? plane : 0u) | (plane << 9) | ((tz & 4u) ? plane << 18 : 0u);
+  return (cube & cmask) != 0u;
 }
 
 constexpr int kMcThreads = 256;
@@ -467,7 +465,7 @@ __global__ __launch_bounds__(kMcThreads) __attribute__((amdgpu_waves_per_eu(4, 4
   __shared__ uint8_t s_ntri[512];
   __shared__ u32 s_off[512];
   __shared__ u32 s_wave[kMcThreads / 64];
-  __shared__ u32 s_ncand;
+  __shared__ u32 s_ncand[2];  // [0] candidates with a known stencil (list grows from s_cand[0] up), [1] the others (from s_cand[511] down)
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   for (int e = blockIdx.x; e < n; e += gridDim.x) {
@@ -486,7 +484,7 @@ __global__ __launch_bounds__(kMcThreads) __attribute__((amdgpu_waves_per_eu(4, 4
       if (pack_key(b, key)) slot = hash_find(t, key);
       s_nb[tid] = slot >= 0 ? t.vals[slot] : kNbAbsent;
     }
-    if (tid == 0) s_ncand = 0;
+    if (tid < 2) s_ncand[tid] = 0;
     for (int i = tid; i < 512; i += kMcThreads) s_ntri[i] = 0;
     __syncthreads();
     nb.vals = s_nb;
@@ -549,12 +547,17 @@ __global__ __launch_bounds__(kMcThreads) __attribute__((amdgpu_waves_per_eu(4, 4
     }
     // a fine voxel whose 3^3 cells lie in fine (or absent) blocks has a known trilinear stencil (trilinear_known)
     const bool fine_known = staged && !coarse && (amax + 2) * kBlockSide < (1 << 18);  // uniform
-    // ---- candidates
+    // ---- candidates, in two groups so that a wave evaluates voxels of ONE kind: the known-stencil evaluation is ~10x shorter
+    // than the literal one, and a wave that holds a single literal voxel pays for both
+    auto push = [&](const int v) {
+      if (fine_known && !voxel_touches_coarse(v, cmask)) s_cand[atomicAdd(&s_ncand[0], 1u)] = (unsigned short) v;
+      else s_cand[511u - atomicAdd(&s_ncand[1], 1u)] = (unsigned short) v;
+    };
     if (!mine) {
       // nothing to evaluate
     } else if (EMIT) {
       for (int v = tid; v < nvox; v += kMcThreads)
-        if (per_voxel[(size_t) e * 512 + v] != 0) s_cand[atomicAdd(&s_ncand, 1u)] = (unsigned short) v;
+        if (per_voxel[(size_t) e * 512 + v] != 0) push(v);
     } else if (staged && sdf_bound > 0.f) {
       // per voxel: w = 1 window straight from the classes (OR of the one-hot class bits); does it need the wide one?
       u32 acc1[2] = {0u, 0u};
@@ -624,14 +627,14 @@ __global__ __launch_bounds__(kMcThreads) __attribute__((amdgpu_waves_per_eu(4, 4
             // an "anything else" cell and without BOTH signs in the window every corner that has a value has the same sign.
             empty = (acc & 8u) == 0u && (acc & 3u) != 3u;
           }
-          if (!empty) s_cand[atomicAdd(&s_ncand, 1u)] = (unsigned short) v;
+          if (!empty) push(v);
         }
       }
     } else {
-      for (int v = tid; v < nvox; v += kMcThreads) s_cand[atomicAdd(&s_ncand, 1u)] = (unsigned short) v;
+      for (int v = tid; v < nvox; v += kMcThreads) push(v);
     }
     __syncthreads();
-    const int ncand = (int) s_ncand;
+    const int ncand[2] = {(int) s_ncand[0], (int) s_ncand[1]};
     auto voxel_position = [&](const int v) {
       i3 pi;
       if (!coarse) pi = mki3(ent.x * kBlockSide + (v & 7), ent.y * kBlockSide + ((v >> 3) & 7), ent.z * kBlockSide + (v >> 6));
@@ -641,12 +644,17 @@ __global__ __launch_bounds__(kMcThreads) __attribute__((amdgpu_waves_per_eu(4, 4
     const int gb = lane & ~7, corner = lane & 7;
     if (!EMIT) {
       // ---- dense evaluation of the candidates, 8 lanes each; per-voxel counts to LDS
-      for (int base = 0; base < ncand * 8; base += kMcThreads) {
-        const int i = base + tid;
-        const bool active = i < ncand * 8;
-        const int v = s_cand[active ? (i >> 3) : 0];
-        const int ntri = mc_group<false>(m, t, nb, voxel_position(v), v, fine_known && !voxel_touches_coarse(v, cmask), corner, gb, active, nullptr, 0);
-        if (active && corner == 0) s_ntri[v] = (uint8_t) ntri;
+#pragma unroll 1
+      for (int kind = 0; kind < 2; kind++) {
+#pragma unroll 1
+        for (int base = 0; base < ncand[kind] * 8; base += kMcThreads) {
+          const int i = base + tid;
+          const bool active = i < ncand[kind] * 8;
+          const int ci = active ? (i >> 3) : 0;
+          const int v = s_cand[kind == 0 ? ci : 511 - ci];
+          const int ntri = mc_group<false>(m, t, nb, voxel_position(v), v, kind == 0, corner, gb, active, nullptr, 0);
+          if (active && corner == 0) s_ntri[v] = (uint8_t) ntri;
+        }
       }
       __syncthreads();
     }
@@ -675,14 +683,19 @@ __global__ __launch_bounds__(kMcThreads) __attribute__((amdgpu_waves_per_eu(4, 4
       s_off[v0] = ex0;
       s_off[v0 + 1] = ex0 + c0;
       __syncthreads();
-      for (int base = 0; base < ncand * 8; base += kMcThreads) {
-        const int i = base + tid;
-        const bool active = i < ncand * 8;
-        const int v = s_cand[active ? (i >> 3) : 0];
-        const u64 first = offsets[e] + s_off[v];
-        const int room = first >= max_tris ? 0 : (int) (max_tris - first < 5 ? max_tris - first : 5);
-        const int ntri = mc_group<true>(m, t, nb, voxel_position(v), v, fine_known && !voxel_touches_coarse(v, cmask), corner, gb, active, out + first, room);  // straight to the exact offset
-        if (active && corner == 0 && ntri > room) atomicOr((u32*) &t.ctr[CTR_ERROR], ERR_TRI);
+#pragma unroll 1
+      for (int kind = 0; kind < 2; kind++) {
+#pragma unroll 1
+        for (int base = 0; base < ncand[kind] * 8; base += kMcThreads) {
+          const int i = base + tid;
+          const bool active = i < ncand[kind] * 8;
+          const int ci = active ? (i >> 3) : 0;
+          const int v = s_cand[kind == 0 ? ci : 511 - ci];
+          const u64 first = offsets[e] + s_off[v];
+          const int room = first >= max_tris ? 0 : (int) (max_tris - first < 5 ? max_tris - first : 5);
+          const int ntri = mc_group<true>(m, t, nb, voxel_position(v), v, kind == 0, corner, gb, active, out + first, room);  // straight to the exact offset
+          if (active && corner == 0 && ntri > room) atomicOr((u32*) &t.ctr[CTR_ERROR], ERR_TRI);
+        }
       }
     }
     __syncthreads();
