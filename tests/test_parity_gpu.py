@@ -263,6 +263,28 @@ def test_edge_inputs(hip, oracle):
     pu.compare_meshes(a, b)
 
 
+def test_camera_changes_between_frames(hip, oracle):
+    """Two sensors feeding one map: the camera (resolution and intrinsics) is set anew between frames, larger then smaller
+    again — the per-pixel buffers follow, the map carries on; single- and multi-resolution, GC on."""
+    scene = synth.Scene(synth.Box((-2.0, -1.5, -2.0), (2.0, 1.5, 2.0)), [synth.Box((-0.3, -0.2, 1.0), (0.3, 0.4, 1.4))], seed=3)
+    cams = [synth.CFG1, synth.Intrinsics(210.0, 205.0, 101.3, 74.2, 150, 200), synth.Intrinsics(95.0, 97.0, 47.5, 36.0, 72, 96)]
+    for var in (0.0, 0.5):
+        params = dict(synth.CFG1_PARAMS, integration_weight_sample=2, n_frames_invalidate_voxels=3, sdf_var_threshold=var)
+        a, b = _pair(hip, oracle, cams[0], params)
+        for i in range(7):
+            K = cams[i % 3]
+            f = synth.render(scene, K, np.array([0.05 * i, 0.0, -0.5], np.float32), synth.yaw_quat(0.1 * i - 0.3), depth_scaling=5000.0)
+            for e in (a, b):
+                e.set_camera(K.fx, K.fy, K.cx, K.cy, K.rows, K.cols, params["min_depth"], params["max_depth"])
+                pu.feed(e, f)
+            a.sync()
+            pu.compare_maps(a, b)
+        r = pu.compare_maps(a, b)
+        assert r["blocks"] > 100 and r["sdf_bit_exact"]
+        pu.compare_meshes(a, b)
+        a.close(); b.close()
+
+
 def test_error_behaviour(hip):
     e = capi.Engine(hip, capi.Params(num_sdf_blocks=4096, **synth.CFG1_PARAMS))
     with pytest.raises(capi.MrhError) as ei:
