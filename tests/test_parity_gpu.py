@@ -285,6 +285,35 @@ def test_camera_changes_between_frames(hip, oracle):
         a.close(); b.close()
 
 
+@pytest.mark.parametrize("var", [0.0, 0.5])
+def test_depth_frames_and_point_clouds_interleaved_on_one_map(hip, oracle, var):
+    """GeoWrapper::compute fuses a depth image AND a point cloud when both are set (geowrapper.cpp:140-147).  Alternating the two
+    kinds of input on one map, with garbage collection on, walks the library through every hand-over between its fast path
+    (block summaries, visible lists) and the general kernels the scans use."""
+    K = synth.CFG1
+    params = dict(synth.CFG1_PARAMS, integration_weight_sample=2, n_frames_invalidate_voxels=3, sdf_var_threshold=var, sdf_truncation=0.12)
+    a, b = _pair(hip, oracle, K, params)
+    scene = synth.Scene(synth.Box((-2.0, -1.5, -2.0), (2.0, 1.5, 2.0)), [synth.Box((-0.3, -0.2, 1.0), (0.3, 0.4, 1.4))], seed=3)
+    for i in range(8):
+        t = np.array([0.04 * i, 0.0, -0.5], np.float32)
+        q = synth.yaw_quat(0.08 * i - 0.2)
+        f = synth.render(scene, K, t, q, depth_scaling=5000.0)
+        pts = synth.lidar_scan(scene, t, q, rows=24, cols=96, max_range=10.0)
+        for e in (a, b):
+            if i % 3 != 2:
+                pu.feed(e, f)
+            if i % 2 == 1:
+                e.set_pose(f.R, f.t)
+                e.upload_points(pts)
+                e.integrate_points()
+        a.sync()
+        pu.compare_maps(a, b)
+    r = pu.compare_maps(a, b)
+    assert r["blocks"] > 100 and r["sdf_bit_exact"] and a.stats().error_flags == 0
+    pu.compare_meshes(a, b)
+    a.close(); b.close()
+
+
 def test_error_behaviour(hip):
     e = capi.Engine(hip, capi.Params(num_sdf_blocks=4096, **synth.CFG1_PARAMS))
     with pytest.raises(capi.MrhError) as ei:
