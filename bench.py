@@ -19,6 +19,7 @@ resident in HBM before the timed region starts.  Beside it, in the same JSON lin
   mc                  configs[2]: variance-adaptive multi-resolution map of the same stream + marching-cubes extraction,
                       roofline of the two k_mc launches (6144 B per fine block + 768 B per coarse block + 72 B per triangle)
   lidar               configs[4], LiDAR half: 128 x 1024-point scans along a street (vbr.cfg parameters): scans/s, points/s
+  splat               configs[4], 3DGS half: splat seeds per frame (mrh_splat_seeds after every fused frame)
   pcie_inclusive_frames_per_s   the drop-in number: host numpy images -> mrh_upload_* every frame (never `value`)
   cpu_baseline        the oracle on a bounded sample of the same stream
 
@@ -344,6 +345,30 @@ def bench_single(args):
         le.close()
         del d_scans
 
+    # ---- configs[4], 3DGS half: splat seeds of every frame (quad-tree over the colour image + one map lookup per leaf), the
+    # blocking call GeoWrapper::compute makes after the fusion of a frame when a gs_optimization_param_path is set
+    splat = None
+    if not args.no_extras:
+        se = make_engine(hip, params, Kc)
+        n_seed_frames = min(total, 40)
+        res.run(se, 0, 2)
+        se.sync()
+        t_seed, n_seeds, n_leaves = 0.0, 0, 0
+        t7 = time.perf_counter()
+        for i in range(2, n_seed_frames):
+            res.run(se, i, i + 1)
+            c0 = time.perf_counter()
+            seeds = se.splat_seeds(0.1, 1)  # qtree_thresh, qtree_min_pixel_size of the reference's params.json
+            t_seed += time.perf_counter() - c0
+            n_seeds += len(seeds)
+        se.sync()
+        dt7 = time.perf_counter() - t7
+        nf = n_seed_frames - 2
+        n_leaves = len(se.qtree_leaves()) * nf  # of the last frame (outside the timed loop: a 35 k-row host copy)
+        splat = {"workload": "3DGS splat initialisation (configs[4], second half) on the 640x480 stream: mrh_integrate + mrh_splat_seeds per frame",
+                 "frames_per_s_with_seeding": nf / dt7, "seed_call_us": t_seed / nf * 1e6, "leaves_per_frame": n_leaves / nf, "seeds_per_frame": n_seeds / nf}
+        se.close()
+
     # ---- pass B: same frames, HIP events around every integrate-kernel launch + device-side U/M counters
     roof = profiled_roofline(eng, res, W, total, "configs[1] (value's workload)")
     eng.close()
@@ -416,7 +441,7 @@ def bench_single(args):
                    "frames_per_gpu": K, "voxel_size_m": 0.01, "truncation_m": 0.07, "parallelism": "single GPU", "live_blocks_end": occupied,
                    "hash_table": table},
         "roofline": roof, "roofline_hbm": roof_hbm, "mc": mc, "cpu_baseline": cpu,
-        "lidar": lidar, "pcie_inclusive_frames_per_s": pcie_fps,
+        "lidar": lidar, "splat": splat, "pcie_inclusive_frames_per_s": pcie_fps,
     }
     emit(out)
 

@@ -163,6 +163,8 @@ struct mrh_ctx {
   uint32_t qt_last_literal = 0;
   std::vector<mrh_splat_seed> seeds;
   std::vector<mrh_qtree_leaf> qt_leaves;
+  uint64_t qt_n_leaves = 0;            // leaves of the last mrh_splat_seeds, still on the device (d_qt_leaves) until someone asks
+  bool qt_leaves_on_host = true;
   int mr_fused = 1;          // MRH_MR_FUSED=0: multi-resolution maps always through the general kernels (mrh_kernels.h)
   bool mr_next_general = true;    // the next multi-resolution frame must take the general path (frame 0 / after a starve frame / after an import)
   bool mr_summaries_valid = false;  // fast.summary / summary_c describe every live block (the general kernels do not maintain them)
@@ -1564,9 +1566,11 @@ int mrh_splat_seeds(mrh_ctx* c, float qtree_thresh, int qtree_min_pixel_size, co
   const uint64_t n_leaves = h_misc[0] & 0xFFFFFFFFull, n_seeds = h_misc[0] >> 32;
   c->qt_last_literal = (uint32_t) h_misc[1];
   if (n_leaves > 1000000ull) return fail(c, MRH_ERR_CAPACITY, "mrh_splat_seeds: %llu leaves, above the reference's capacity of 1000000 (params.h:20-23)", (unsigned long long) n_leaves);
-  c->qt_leaves.resize(n_leaves);
+  // the leaves (tens of thousands per frame) stay on the device until mrh_get_qtree_leaves asks: the fusion loop only takes the seeds
+  c->qt_n_leaves = n_leaves;
+  c->qt_leaves_on_host = n_leaves == 0;
+  c->qt_leaves.clear();
   c->seeds.resize(n_seeds);
-  if (n_leaves) HIP_TRY(c, hipMemcpyAsync(c->qt_leaves.data(), c->d_qt_leaves, n_leaves * sizeof(mrh_qtree_leaf), hipMemcpyDeviceToHost, s));
   if (n_seeds) HIP_TRY(c, hipMemcpyAsync(c->seeds.data(), c->d_qt_seeds, n_seeds * sizeof(mrh_splat_seed), hipMemcpyDeviceToHost, s));
   HIP_TRY(c, hipStreamSynchronize(s));
   if (getenv("MRH_DEBUG")) {
@@ -1580,6 +1584,12 @@ int mrh_splat_seeds(mrh_ctx* c, float qtree_thresh, int qtree_min_pixel_size, co
 
 int mrh_get_qtree_leaves(mrh_ctx* c, const mrh_qtree_leaf** out, uint64_t* out_n) {
   if (!c || !out || !out_n) return MRH_ERR_INVALID_ARG;
+  if (!c->qt_leaves_on_host) {
+    c->qt_leaves.resize(c->qt_n_leaves);
+    HIP_TRY(c, hipMemcpyAsync(c->qt_leaves.data(), c->d_qt_leaves, c->qt_n_leaves * sizeof(mrh_qtree_leaf), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->qt_leaves_on_host = true;
+  }
   *out = c->qt_leaves.data();
   *out_n = c->qt_leaves.size();
   return MRH_OK;

@@ -32,7 +32,7 @@ def test_single_gpu_line():
     assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["kernel_ms_avg"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0
-    assert d["roofline_hbm"]["exceeds_infinity_cache"] in (True, False) and d["mc"]["triangles"] > 0 and d["lidar"]["scans_per_s"] > 0
+    assert d["roofline_hbm"]["exceeds_infinity_cache"] in (True, False) and d["mc"]["triangles"] > 0 and d["lidar"]["scans_per_s"] > 0 and d["splat"]["seeds_per_frame"] > 0
     assert d["pcie_inclusive_frames_per_s"] > 0 and "workload" in d["config"]
 
 
