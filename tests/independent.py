@@ -405,19 +405,22 @@ def _dda_walk(cur, bound, step, t_max, t_delta, visit):
             t_max[a] = F(t_max[a] + t_delta[a])
 
 
-def allocate3d(cam: Camera, params: dict, points) -> set:
+def allocate3d(cam: Camera, params: dict, points, normals=None) -> set:
     """Blocks allocBlocks3DKernel inserts for one scan (points in the sensor frame, (0, 0, 0) = no return).  No frustum
-    test on this path."""
+    test on this path.  `normals` (one per point): the segment runs along the normal instead of the beam (vds.cu:957-962)."""
     vs, trunc, scale = F(params["virtual_voxel_size"]), F(params["sdf_truncation"]), F(params["sdf_truncation_scale"])
     p = np.asarray(points, F).reshape(-1, 3)
+    nrm = None if normals is None else np.asarray(normals, F).reshape(-1, 3)
     rng = _norm3(p)
     keep = rng != 0
     p, rng = p[keep], rng[keep]
+    nrm = None if nrm is None else nrm[keep]
     t = (trunc + scale * rng).astype(F)
     lo, hi = np.minimum(cam.max_depth, rng - t), np.minimum(cam.max_depth, rng + t)
     keep = ~(lo >= hi)
     p, rng, lo, hi = p[keep], rng[keep], lo[keep], hi[keep]
-    cdir = _normalize(p)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        cdir = _normalize(p) if nrm is None else _normalize(nrm[keep])
     pw_min = cam.cam_in_world((p + cdir * (lo - rng)[:, None]).astype(F))
     pw_max = cam.cam_in_world((p + cdir * (hi - rng)[:, None]).astype(F))
     cur, bound, step, t_max, t_delta = _dda_setup(vs, pw_min, pw_max, BLOCK)
@@ -427,36 +430,50 @@ def allocate3d(cam: Camera, params: dict, points) -> set:
     return visited
 
 
-def integrate3d(cam: Camera, params: dict, points, blocks: dict) -> dict:
+def integrate3d(cam: Camera, params: dict, points, blocks: dict, normals=None) -> dict:
     """integrate3DKernel for one scan, the points taken in ascending index (the build's canonical order D6 for the
-    reference's racing read-modify-writes).  Projective SDF, fine blocks."""
+    reference's racing read-modify-writes).  Fine blocks; projective SDF, or with `normals` the normal-direction one
+    (segment pcam + n (min_depth - range) .. pcam + n (max_depth - range), sdf = dot(voxel - point, n): vds.cu:1248-1251, :1322-1326)."""
     vs, trunc, scale = F(params["virtual_voxel_size"]), F(params["sdf_truncation"]), F(params["sdf_truncation_scale"])
     w1 = int(params["integration_weight_sample"]) & 0xFF
     wmax = int(params.get("integration_weight_max", 255)) & 0xFF
     half = F(vs / F(2))
     out = {k: v.copy() for k, v in blocks.items()}
     p = np.asarray(points, F).reshape(-1, 3)
+    nrm = None if normals is None else np.asarray(normals, F).reshape(-1, 3)
     rng = _norm3(p)
-    keep = ~((rng < F(1e-6)) | (rng > cam.max_depth))
+    keep = ~((rng.astype(np.float64) < 1e-6) | (rng > cam.max_depth))  # `range < 1e-6` compares in double (vds.cu:1233)
     p, rng = p[keep], rng[keep]
+    nrm = None if nrm is None else nrm[keep]
     t = (trunc + scale * rng).astype(F)
     lo, hi = np.minimum(cam.max_depth, rng - t), np.minimum(cam.max_depth, rng + t)
     keep = ~(lo >= hi)
-    p, rng, t = p[keep], rng[keep], t[keep]
-    cdir = _normalize(p)
-    pw_min = cam.cam_in_world((p - cdir * t[:, None]).astype(F))
-    pw_max = cam.cam_in_world((p + cdir * t[:, None]).astype(F))
+    p, rng, t, lo, hi = p[keep], rng[keep], t[keep], lo[keep], hi[keep]
+    if nrm is None:
+        cdir = _normalize(p)
+        pw_min = cam.cam_in_world((p - cdir * t[:, None]).astype(F))
+        pw_max = cam.cam_in_world((p + cdir * t[:, None]).astype(F))
+        ndir = np.zeros_like(p)
+    else:
+        with np.errstate(divide="ignore", invalid="ignore"):
+            ndir = _normalize(nrm[keep])
+        pw_min = cam.cam_in_world((p + ndir * (lo - rng)[:, None]).astype(F))
+        pw_max = cam.cam_in_world((p + ndir * (hi - rng)[:, None]).astype(F))
     cur, bound, step, t_max, t_delta = _dda_setup(vs, pw_min, pw_max, 1)
     for i in range(len(p)):
-        r_i, t_i = rng[i], t[i]
+        r_i, t_i, p_i, n_i = rng[i], t[i], p[i], ndir[i]
 
-        def visit(v, r_i=r_i, t_i=t_i):
+        def visit(v, r_i=r_i, t_i=t_i, p_i=p_i, n_i=n_i):
             b = tuple(int(c) for c in voxel_to_block(np.array(v, I), vs))
             blk = out.get(b)
             if blk is None:
                 return True
             pc = cam.world_in_cam(voxel_to_world(vs, np.array(v, I)))
-            sdf = F(r_i - _norm3(pc))
+            if nrm is None:
+                sdf = F(r_i - _norm3(pc))
+            else:  # dot(voxel_pos_camera - pcam, norm_dir), cuda_math dot: x*x' + y*y' + z*z' left to right
+                dv = (pc - p_i).astype(F)
+                sdf = F(F(F(dv[0] * n_i[0]) + F(dv[1] * n_i[1])) + F(dv[2] * n_i[2]))
             if sdf <= -t_i:
                 return False  # `break`: the ray is done
             sdf = min(t_i, sdf) if sdf >= 0 else max(F(-t_i), sdf)

@@ -144,10 +144,11 @@ def test_variance_adaptive_coarsening_matches_the_independent_restatement(oracle
     assert some > 20
 
 
-def test_lidar_scans_match_the_independent_restatement(oracle):
-    """allocBlocks3DKernel + integrate3DKernel (projective SDF): three 16 x 128 scans of the street scene from a moving
-    sensor, vbr.cfg parameters; occupancy and every voxel (sdf, sum_squared, weight) bit for bit after each scan."""
-    params = dict(synth.VBR_PARAMS)
+@pytest.mark.parametrize("projective", [True, False], ids=["projective", "along-the-normal"])
+def test_lidar_scans_match_the_independent_restatement(oracle, projective):
+    """allocBlocks3DKernel + integrate3DKernel, projective and normal-direction SDF: three 16 x 128 scans of the street scene
+    from a moving sensor, vbr.cfg parameters; occupancy and every voxel (sdf, sum_squared, weight) bit for bit after each scan."""
+    params = dict(synth.VBR_PARAMS, projective_sdf=projective)
     e = pu.make_lidar_engine(oracle, params, 100.0)
     cam = ind.Camera(1, 1, 0, 0, 1, 1, params["min_depth"], params["max_depth"])
     scene = synth.street_canyon()
@@ -155,15 +156,18 @@ def test_lidar_scans_match_the_independent_restatement(oracle):
     for t, q in synth.drive_poses(3, step=1.5):
         pts = synth.lidar_scan(scene, t, q, rows=16, cols=128)
         R = synth.quat_to_rot(q)
+        nrm = None if projective else synth.scan_normals(pts)
         e.set_pose(R, t)
         e.upload_points(pts)
+        if nrm is not None:
+            e.upload_normals(nrm)
         e.integrate_points()
         d, v = e.dump_blocks()
         got = as_dict(d, v)
         cam.set_pose(R, t)
-        for k in ind.allocate3d(cam, params, pts) - set(state):
+        for k in ind.allocate3d(cam, params, pts, nrm) - set(state):
             state[k] = np.zeros(512, capi.VOXEL_DTYPE)
-        new = ind.integrate3d(cam, params, pts, state)
+        new = ind.integrate3d(cam, params, pts, state, nrm)
         updated += sum(int((new[k]["weight"] != state[k]["weight"]).sum()) for k in state)
         state = new
         _assert_same_blocks(state, got, "scan")
