@@ -244,7 +244,7 @@ def compact_positions(cam: Camera, params: dict, blocks: dict):
     return [k for k, v in zip(keys, vis) if v]
 
 
-def check_var(cam: Camera, params: dict, blocks: dict):
+def check_var(cam: Camera, params: dict, blocks: dict, all_blocks: bool = False):
     """checkVarSDFKernel (vds.cu:1857-1939) over the compact FINE blocks: the positions the kernel hands to reallocBlocks.
     64 threads per block; thread t sums the 2x2x2 cell at (2 (t % 4), 2 ((t / 4) % 4), 2 (t / 16)) in dz, dy, dx order over the
     voxels with weight > 0 (sum_squared and weight, both as float), then the shared-memory tree `s[t] += s[t + stride]` for
@@ -254,7 +254,7 @@ def check_var(cam: Camera, params: dict, blocks: dict):
     out = []
     t = np.arange(64)
     gx, gy, gz = (t % 4) * 2, ((t // 4) % 4) * 2, (t // 16) * 2
-    for key in compact_positions(cam, params, blocks):
+    for key in (sorted(blocks) if all_blocks else compact_positions(cam, params, blocks)):  # flatAndReduceHashTable() without a camera lists every block
         vox = blocks[key]
         ss = np.zeros(64, F)
         ww = np.zeros(64, F)
@@ -483,6 +483,61 @@ def integrate3d(cam: Camera, params: dict, points, blocks: dict, normals=None) -
             delta = F(F(sdf - mean) / half)
             c0 = blk["rgb"][li].astype(F)
             blk["rgb"][li] = _trunc_int(F(0.5) * c0 + F(0.5) * F(0) + F(0.5)).astype(np.uint8)  # the sample carries colour 0
+            s_new = F(F(F(s0 * F(w0)) + F(sdf * F(w1))) / F(w0 + w1))
+            blk["sdf"][li] = s_new
+            blk["weight"][li] = min(wmax, w0 + w1)
+            blk["sum_squared"][li] = F(F(0) + F(delta * F(F(sdf - s_new) / half)))
+            return True
+
+        _dda_walk(cur[i], bound[i], step[i], t_max[i], t_delta[i], visit)
+    return out
+
+
+def integrate3d_multires(cam: Camera, params: dict, points, blocks: dict) -> dict:
+    """integrate3DKernel (projective SDF) on a map with fine AND coarse blocks, blocks = {(x, y, z): (resolution, voxels)}:
+    on a coarse block the SDF is measured at the fine voxel coordinate divided by 2 with C's truncation toward zero, times the
+    coarse voxel size (vds.cu:1303-1309), and the voxel updated is the one the coarse local coordinate names (dense index:
+    deviation D1).  Points in ascending index (D6)."""
+    vs, trunc, scale = F(params["virtual_voxel_size"]), F(params["sdf_truncation"]), F(params["sdf_truncation_scale"])
+    w1 = int(params["integration_weight_sample"]) & 0xFF
+    wmax = int(params.get("integration_weight_max", 255)) & 0xFF
+    half = F(vs / F(2))
+    out = {k: (r, v.copy()) for k, (r, v) in blocks.items()}
+    p = np.asarray(points, F).reshape(-1, 3)
+    rng = _norm3(p)
+    keep = ~((rng.astype(np.float64) < 1e-6) | (rng > cam.max_depth))
+    p, rng = p[keep], rng[keep]
+    t = (trunc + scale * rng).astype(F)
+    lo, hi = np.minimum(cam.max_depth, rng - t), np.minimum(cam.max_depth, rng + t)
+    keep = ~(lo >= hi)
+    p, rng, t = p[keep], rng[keep], t[keep]
+    cdir = _normalize(p)
+    pw_min = cam.cam_in_world((p - cdir * t[:, None]).astype(F))
+    pw_max = cam.cam_in_world((p + cdir * t[:, None]).astype(F))
+    cur, bound, step, t_max, t_delta = _dda_setup(vs, pw_min, pw_max, 1)
+    for i in range(len(p)):
+        r_i, t_i = rng[i], t[i]
+
+        def visit(v, r_i=r_i, t_i=t_i):
+            b = tuple(int(c) for c in voxel_to_block(np.array(v, I), vs))
+            ent = out.get(b)
+            if ent is None:
+                return True
+            res, blk = ent
+            sc = 1 << res
+            aprox = np.array([int(v[0] / sc), int(v[1] / sc), int(v[2] / sc)], I)  # C division: toward zero
+            pc = cam.world_in_cam(voxel_to_world(F(vs * F(sc)), aprox))
+            sdf = F(r_i - _norm3(pc))
+            if sdf <= -t_i:
+                return False
+            sdf = min(t_i, sdf) if sdf >= 0 else max(F(-t_i), sdf)
+            lx, ly, lz = v[0] % 8, v[1] % 8, v[2] % 8
+            li = lz * 64 + ly * 8 + lx if res == 0 else (lz // 2) * 16 + (ly // 2) * 4 + (lx // 2)
+            s0, w0 = F(blk["sdf"][li]), int(blk["weight"][li])
+            mean = s0 if w0 > 0 else F(0)
+            delta = F(F(sdf - mean) / half)
+            c0 = blk["rgb"][li].astype(F)
+            blk["rgb"][li] = _trunc_int(F(0.5) * c0 + F(0.5) * F(0) + F(0.5)).astype(np.uint8)
             s_new = F(F(F(s0 * F(w0)) + F(sdf * F(w1))) / F(w0 + w1))
             blk["sdf"][li] = s_new
             blk["weight"][li] = min(wmax, w0 + w1)

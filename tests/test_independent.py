@@ -175,6 +175,45 @@ def test_lidar_scans_match_the_independent_restatement(oracle, projective):
     e.close()
 
 
+def test_variance_adaptive_lidar_scans_match_the_independent_restatement(oracle):
+    """VoxelContainer::integrate(point_cloud, ...) with sdf_var_threshold > 0 (voxel_data_structures.cpp:112-135): integrate3D,
+    then from the second scan on checkVarSDF over ALL blocks, reallocBlocks, and the scan a second time (reintegrate3D launches
+    integrate3DKernel, vds.cu:1561-1580) into fine and coarse blocks alike."""
+    params = dict(synth.VBR_PARAMS, sdf_var_threshold=2.0, integration_weight_sample=2)
+    e = pu.make_lidar_engine(oracle, params, 100.0)
+    cam = ind.Camera(1, 1, 0, 0, 1, 1, params["min_depth"], params["max_depth"])
+    scene = synth.street_canyon()
+    state, n_coarse = {}, 0
+    for i, (t, q) in enumerate(synth.drive_poses(3, step=1.5)):
+        pts = synth.lidar_scan(scene, t, q, rows=16, cols=128)
+        R = synth.quat_to_rot(q)
+        e.set_pose(R, t)
+        e.upload_points(pts)
+        e.integrate_points()
+        d, v = e.dump_blocks()
+        cam.set_pose(R, t)
+        for k in ind.allocate3d(cam, params, pts) - set(state):
+            state[k] = (0, np.zeros(512, capi.VOXEL_DTYPE))
+        state = ind.integrate3d_multires(cam, params, pts, state)
+        if i > 0:
+            fine = {k: vox for k, (r, vox) in state.items() if r == 0}
+            for k in ind.check_var(cam, params, fine, all_blocks=True):
+                state[k] = (1, np.zeros(64, capi.VOXEL_DTYPE))
+                n_coarse += 1
+            state = ind.integrate3d_multires(cam, params, pts, state)
+        got = {(int(d["x"][j]), int(d["y"][j]), int(d["z"][j])): (int(d["resolution"][j]), v[j]) for j in range(len(d))}
+        assert set(got) == set(state), f"scan {i}: occupancy"
+        for k, (r, vox) in state.items():
+            gr, gv = got[k]
+            assert gr == r, (i, k, gr, r)
+            g = gv[: len(vox)]
+            assert np.array_equal(g["weight"], vox["weight"]) and np.array_equal(g["rgb"], vox["rgb"]), (i, k, r)
+            assert np.array_equal(g["sdf"].view(np.uint32), vox["sdf"].view(np.uint32)), (i, k, r)
+            assert np.array_equal(g["sum_squared"].view(np.uint32), vox["sum_squared"].view(np.uint32)), (i, k, r)
+    assert n_coarse > 10 and len(state) > 300
+    e.close()
+
+
 def test_marching_cubes_matches_the_independent_restatement(oracle):
     """extractIsoSurfaceAtPosition + trilinearInterpolation + vertexInterp, voxel by voxel in python, for the blocks of a
     small map that carry most triangles; the triangle table is rebuilt from the reference's own Transvoxel tables when
