@@ -258,7 +258,8 @@ typedef struct mrh_qtree_leaf {
 } mrh_qtree_leaf;
 
 int mrh_splat_seeds(mrh_ctx* ctx, float qtree_thresh, int qtree_min_pixel_size, const mrh_splat_seed** out_seeds, uint64_t* out_n);
-/* The leaves of the last mrh_splat_seeds call (CUDAQTree::getAllNodes, quad_tree.cuh:82-87).  Test / debug helper. */
+/* The leaves of the last mrh_splat_seeds call (CUDAQTree::getAllNodes, quad_tree.cuh:82-87).  Test / debug helper: the leaves
+ * stay on the device until this is called (blocks for the read-back). */
 int mrh_get_qtree_leaves(mrh_ctx* ctx, const mrh_qtree_leaf** out_leaves, uint64_t* out_n);
 
 /* Blocks until every enqueued frame has executed.  Device error flags raised since the last call that reported them
