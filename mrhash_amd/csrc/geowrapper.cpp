@@ -10,6 +10,7 @@
 #include <fstream>
 #include <iostream>
 #include <charconv>
+#include <chrono>
 #include <memory>
 #include <stdexcept>
 #include <thread>
@@ -254,6 +255,9 @@ void GeoWrapper::compute() {
 }
 
 void GeoWrapper::extractMesh(const std::string& filename) {
+  const bool dbg = std::getenv("MRH_DEBUG") != nullptr;
+  auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t0 = now();
   streamInFromGrid(nullptr, 0.f);  // blocks the streamer paged out take part in the mesh (geowrapper.cpp:162-188 walks the grid)
   uint64_t nt = 0;
   std::cout << "GeoWrapper::extractMesh | extracting..." << std::endl;
@@ -263,9 +267,10 @@ void GeoWrapper::extractMesh(const std::string& filename) {
   const int32_t* f = nullptr;
   uint64_t nv = 0, nf = 0;
   check(mrh_extract_mesh(ctx_, &v, &nv, &f, &nf, &c), "extractMesh");
-  V_.assign(v, v + nv * 3);
-  C_.assign(c, c + nv * 3);
-  F_.assign(f, f + nf * 3);
+  const double t1 = now();
+  mesh_v_ = v; mesh_c_ = c; mesh_f_ = f; mesh_nv_ = nv; mesh_nf_ = nf;
+  mesh_cached_ = false;  // getVertices / getFaces / getColors copy on first use (cacheMesh)
+  const double t2 = now();
 
   // ASCII PLY, same header and value formatting as geowrapper.cpp:194-227.  The reference streams every number through
   // an ofstream (`<<` on a double is printf's %g with precision 6); std::to_chars(general, 6) is defined to produce the
@@ -291,8 +296,8 @@ void GeoWrapper::extractMesh(const std::string& filename) {
       c.buf.reset(new char[(hi - lo) * 64 + 1]);  // 3 x <= 13 chars + 3 x <= 3 chars + separators
       char* p = c.buf.get();
       for (uint64_t i = lo; i < hi; ++i) {
-        for (int a = 0; a < 3; a++) { p = put_d(p, V_[i * 3 + a]); *p++ = ' '; }
-        for (int a = 0; a < 3; a++) { p = put_i(p, (int) (unsigned char) (C_[i * 3 + a])); *p++ = a == 2 ? '\n' : ' '; }
+        for (int a = 0; a < 3; a++) { p = put_d(p, mesh_v_[i * 3 + a]); *p++ = ' '; }
+        for (int a = 0; a < 3; a++) { p = put_i(p, (int) (unsigned char) (mesh_c_[i * 3 + a])); *p++ = a == 2 ? '\n' : ' '; }
       }
       c.len = (size_t) (p - c.buf.get());
     }
@@ -303,7 +308,7 @@ void GeoWrapper::extractMesh(const std::string& filename) {
       char* p = c.buf.get();
       for (uint64_t i = lo; i < hi; ++i) {
         *p++ = '3';
-        for (int a = 0; a < 3; a++) { *p++ = ' '; p = put_i(p, F_[i * 3 + a]); }
+        for (int a = 0; a < 3; a++) { *p++ = ' '; p = put_i(p, mesh_f_[i * 3 + a]); }
         *p++ = '\n';
       }
       c.len = (size_t) (p - c.buf.get());
@@ -315,9 +320,20 @@ void GeoWrapper::extractMesh(const std::string& filename) {
     for (unsigned k = 0; k < n_workers; k++) workers.emplace_back(format_chunk, k);
     for (std::thread& w : workers) w.join();
   }
+  const double t3 = now();
   for (const Chunk& c : chunks) ply.write(c.buf.get(), (std::streamsize) c.len);
   ply.close();
+  if (dbg) std::cerr << "[geowrapper] extractMesh: library " << t1 - t0 << " ms, formatting " << t3 - t2
+                     << ", writing " << now() - t3 << std::endl;
   std::cout << "GeoWrapper::extractMesh | written " << nv << " vertices and " << nf << " faces to " << filename << std::endl;
+}
+
+void GeoWrapper::cacheMesh() const {
+  if (mesh_cached_) return;
+  V_.assign(mesh_v_, mesh_v_ + mesh_nv_ * 3);
+  C_.assign(mesh_c_, mesh_c_ + mesh_nv_ * 3);
+  F_.assign(mesh_f_, mesh_f_ + mesh_nf_ * 3);
+  mesh_cached_ = true;
 }
 
 void GeoWrapper::streamAllOut() {
@@ -329,6 +345,7 @@ void GeoWrapper::streamAllOut() {
 
 void GeoWrapper::clearBuffers() {
   std::cout << "clearing buffers..." << std::endl;
+  cacheMesh();  // the mesh of the last extractMesh outlives the map, as the reference's host matrices do
   check(mrh_reset(ctx_), "clearBuffers");
   grid_.clear();  // Streamer::clearGrid (geowrapper.cpp:555)
 }

@@ -66,9 +66,12 @@ public:
 
   void compute();                                // geowrapper.cpp:118-148
   void extractMesh(const std::string& filename);  // geowrapper.cpp:150-230
-  const std::vector<double>& vertices() const { return V_; }
-  const std::vector<int32_t>& faces() const { return F_; }
-  const std::vector<double>& colors() const { return C_; }
+  // V / F / C of the last extractMesh.  The library keeps them (until the next extraction); the copies the getters hand out are
+  // made on first use — extractMesh itself formats the PLY straight from the library's buffers (83 MB of copies, a third
+  // of the call, when nobody asks for the arrays).
+  const std::vector<double>& vertices() const { cacheMesh(); return V_; }
+  const std::vector<int32_t>& faces() const { cacheMesh(); return F_; }
+  const std::vector<double>& colors() const { cacheMesh(); return C_; }
 
   void streamAllOut();
   // Streamer::stream (streamer.cpp:333-354): blocks farther than `radius` from `camera_position` leave the device for the
@@ -118,8 +121,13 @@ private:
   std::vector<uint8_t> rgb_;
   size_t depth_rows_ = 0, depth_cols_ = 0, rgb_rows_ = 0, rgb_cols_ = 0;
   std::vector<float> point_cloud_, normals_;
-  std::vector<double> V_, C_;
-  std::vector<int32_t> F_;
+  void cacheMesh() const;
+  mutable std::vector<double> V_, C_;
+  mutable std::vector<int32_t> F_;
+  mutable bool mesh_cached_ = true;
+  const double *mesh_v_ = nullptr, *mesh_c_ = nullptr;  // the library's buffers (mrh_extract_mesh)
+  const int32_t* mesh_f_ = nullptr;
+  uint64_t mesh_nv_ = 0, mesh_nf_ = 0;
   // 3DGS initialisation: on when a gs_optimization_param_path was given
   bool gs_enabled_ = false;
   float qtree_thresh_ = 0.1f;
