@@ -3,7 +3,7 @@
 fraction of the integrate kernel and the CPU restatement timed beside it.
 
   python bench.py [--gpus N] [--steps K] [--warmup W]
-      N > 1 without WORLD_SIZE in the environment: re-executes itself under torch.distributed.run with N ranks
+      N > 1 without WORLD_SIZE in the environment: starts N copies of itself, one rank per GPU (RANK / LOCAL_RANK / WORLD_SIZE set)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
 
@@ -26,11 +26,15 @@ resident in HBM before the timed region starts.  Beside it, in the same JSON lin
 N > 1 — workload BASELINE.json configs[3]: "ScanNet scene0000" stand-in (furnished 8x3x6 m room, hand-held walk).
   `value`: FRAME-SHARDED fusion, weak scaling: every rank fuses its own K-frame segment into its own sub-map, no
            data-path collective inside the timed region; value = N*K / max-over-ranks time.
-  `merge`: the sub-maps are then folded into ONE tile-sharded map (mrhash_amd.parallel.merge_submaps: all-to-all of
-           blocks to their tile owner over RCCL + weighted merge on the device) and the boundary blocks all-gathered
-           (exchange_halo): times and bytes of both steps.
+  `merge`: the sub-maps are then folded into ONE tile-sharded map (mrh_comm_merge_submaps: all-to-all of blocks to
+           their tile owner over RCCL + weighted merge on the device) and the boundary blocks exchanged
+           (mrh_comm_exchange_halo): times, bytes and per-phase HIP-event times (pack, counts, collective, unpack) of both.
   `tile_sharded`: the result-identical mode on the same K frames (rank 0's segment, seen by every rank; starve frames
-           run their MIN all-reduce): frames/s = K / max-over-ranks time (strong scaling).
+           run their MIN all-reduce inside mrh_integrate): frames/s = K / max-over-ranks time (strong scaling).
+
+No torch on this path: device buffers through mrhash_amd.hipmem (hipMalloc on the runtime the library is bound to), the
+communicator through include/mrhash_comm.h (RCCL on the library's own stream) — one HIP runtime per rank.  The only
+exception is the test mode MRH_BENCH_SHARE_DEVICE=1 (N ranks on ONE device: RCCL refuses that, the ranks talk over gloo).
 """
 from __future__ import annotations
 
@@ -121,12 +125,12 @@ class Resident:
     """A stream uploaded to HBM once; `run` feeds frames [lo, hi) through the zero-copy setters."""
 
     def __init__(self, frames, K):
-        import torch
+        from mrhash_amd import hipmem
 
         self.frames, self.K = frames, K
-        self.depth = torch.from_numpy(np.stack([f.depth for f in frames])).cuda()
-        self.rgb = torch.from_numpy(np.stack([f.rgb for f in frames])).cuda()
-        torch.cuda.synchronize()
+        self.depth = hipmem.DeviceBuffer.from_numpy(np.stack([f.depth for f in frames]))
+        self.rgb = hipmem.DeviceBuffer.from_numpy(np.stack([f.rgb for f in frames]))
+        hipmem.synchronize()
         self.ds, self.rs = K.rows * K.cols * 4, K.rows * K.cols * 3
 
     def run(self, engine, lo, hi, integrate=None):
@@ -134,8 +138,8 @@ class Resident:
         for i in range(lo, hi):
             f = self.frames[i]
             engine.set_pose(f.R, f.t)
-            engine.set_depth_device(self.depth.data_ptr() + i * self.ds, K.rows, K.cols)
-            engine.set_rgb_device(self.rgb.data_ptr() + i * self.rs, K.rows, K.cols)
+            engine.set_depth_device(self.depth.ptr + i * self.ds, K.rows, K.cols)
+            engine.set_rgb_device(self.rgb.ptr + i * self.rs, K.rows, K.cols)
             if integrate is None:
                 engine.integrate()
             else:
@@ -166,6 +170,8 @@ def profiled_roofline(eng, res: Resident, W: int, total: int, label: str):
     eng.set_profile(False)
     n_k = int(s1.n_integrate_kernel - s0.n_integrate_kernel)
     k_ms = float(s1.sum_integrate_kernel_ms - s0.sum_integrate_kernel_ms) / max(n_k, 1)
+    n_f = int(s1.n_front_kernel - s0.n_front_kernel)
+    f_ms = float(s1.sum_front_kernel_ms - s0.sum_front_kernel_ms) / max(n_f, 1)
     U = (int(s1.total_updated_voxels) - int(s0.total_updated_voxels)) / max(n_k, 1)
     M = (int(s1.total_compact_blocks) - int(s0.total_compact_blocks)) / max(n_k, 1)
     alg = 24.0 * U + 24.0 * M + 7 * res.K.rows * res.K.cols
@@ -173,7 +179,8 @@ def profiled_roofline(eng, res: Resident, W: int, total: int, label: str):
     touched = (U / 512.0) * 6144.0  # payload of the block-equivalents the launch rewrites
     return {"bound": "hbm", "kernel": "k_back (depth->TSDF integrate + GC summary + GC decision)", "workload": label,
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-            "algorithmic_bytes_per_launch": alg, "kernel_ms_avg": k_ms, "launches": n_k, "updated_voxels_per_launch": U,
+            "algorithmic_bytes_per_launch": alg, "kernel_ms_avg": k_ms, "launches": n_k,
+            "k_front_ms_avg": f_ms, "updated_voxels_per_launch": U,
             "compact_blocks_per_launch": M, "working_set_bytes_per_frame": M * 6144.0 + 7 * res.K.rows * res.K.cols,
             "rewritten_payload_bytes_per_frame": touched, "exceeds_infinity_cache": bool(M * 6144.0 > MALL_BYTES),
             "profiled_pass_ms_per_step": prof_elapsed / max(total - W, 1) * 1e3}
@@ -220,9 +227,7 @@ def pmc_traffic(args, kernel_prefix: str, cache: str, inner: str = "--pmc-inner"
 # ---- N = 1 ---------------------------------------------------------------------------------------------------------
 
 def bench_single(args):
-    import torch
-
-    from mrhash_amd import capi, synth
+    from mrhash_amd import capi, hipmem, synth
 
     K, W = args.steps, args.warmup
     total = W + K
@@ -252,11 +257,11 @@ def bench_single(args):
     eng = make_engine(hip, params, Kc)
     res.run(eng, 0, W)
     eng.sync()
-    torch.cuda.synchronize()
+    hipmem.synchronize()  # the whole device, not only the library's stream
     t0 = time.perf_counter()
     res.run(eng, W, total)
     eng.sync()
-    torch.cuda.synchronize()
+    hipmem.synchronize()
     elapsed = time.perf_counter() - t0
     st = eng.stats()
     occupied = int(st.occupied_fine)
@@ -320,7 +325,7 @@ def bench_single(args):
             scene = synth.street_canyon()
             scans = [synth.lidar_scan(scene, t, q, rows=128, cols=1024) for t, q in poses]
             np.savez(lcache, scans=np.stack(scans))
-        d_scans = [torch.from_numpy(np.ascontiguousarray(sc)).cuda() for sc in scans]
+        d_scans = [hipmem.DeviceBuffer.from_numpy(np.ascontiguousarray(sc, dtype=np.float32)) for sc in scans]
         le = capi.Engine(hip, capi.Params(num_sdf_blocks=args.blocks, device_id=0, **synth.VBR_PARAMS))
         le.set_camera(1, 1, 0, 0, 1, 1, 0.2, 100.0, model=1)
 
@@ -328,7 +333,7 @@ def bench_single(args):
             for i in range(lo, hi):
                 t, q = poses[i]
                 le.set_pose(synth.quat_to_rot(q), t)
-                le.set_points_device(d_scans[i].data_ptr(), len(scans[i]))
+                le.set_points_device(d_scans[i].ptr, len(scans[i]))
                 le.integrate_points()
 
         run_scans(0, w_scans)
@@ -368,6 +373,79 @@ def bench_single(args):
         splat = {"workload": "3DGS splat initialisation (configs[4], second half) on the 640x480 stream: mrh_integrate + mrh_splat_seeds per frame",
                  "frames_per_s_with_seeding": nf / dt7, "seed_call_us": t_seed / nf * 1e6, "leaves_per_frame": n_leaves / nf, "seeds_per_frame": n_seeds / nf}
         se.close()
+
+    # ---- what the timed region may not contain: the starve frame (every 100th, replica.cfg) and the table census (every 64th).
+    # Single frames bracketed by synchronisations (so each figure carries one sync of overhead, the steady one too): the census
+    # falls on the 65th frame by itself; the starve sequence is triggered on the frame after the loop by passing its own index
+    # as the period (mrh_integrate(n): starve when frames % n == 0).
+    periodic = None
+    if not args.no_extras:
+        pf = make_engine(hip, params, Kc)
+        n_leg = min(total, 70)
+        per = []
+        for i in range(n_leg):
+            pf.sync()
+            c0 = time.perf_counter()
+            res.run(pf, i, i + 1)
+            pf.sync()
+            per.append((time.perf_counter() - c0) * 1e3)
+        st_ms = None
+        if n_leg < total or total > 1:
+            j = n_leg % total
+            pf.sync()
+            c0 = time.perf_counter()
+            res.run(pf, j, j + 1, integrate=lambda e: e.integrate(n_leg))  # frames == n_leg here: the starve frame of period n_leg
+            pf.sync()
+            st_ms = (time.perf_counter() - c0) * 1e3
+        steady = float(np.median(per[8:64])) if n_leg > 16 else float(np.median(per))
+        census = per[64] if n_leg > 64 else None
+        periodic = {"what": "single frames, each bracketed by mrh_sync (one synchronisation of overhead in every figure)",
+                    "steady_frame_ms": steady, "census_frame_ms": census, "starve_frame_ms": st_ms, "census_period": 64,
+                    "starve_period": int(synth.REPLICA_PARAMS["n_frames_invalidate_voxels"]),
+                    "amortised_extra_ms_per_frame": (((census - steady) / 64 if census else 0.0) +
+                                                     ((st_ms - steady) / synth.REPLICA_PARAMS["n_frames_invalidate_voxels"] if st_ms else 0.0))}
+        pf.close()
+
+    # ---- the image path under the SPHERICAL camera model (general kernels, mrh_softmath.h): 128 x 1024 range images of the street
+    spherical = None
+    if not args.no_extras:
+        cam = synth.spherical_camera(128, 1024)
+        n_img, w_img = 12, 3
+        scache = os.path.join(tempfile.gettempdir(), f"mrh_bench_sph_{n_img}.npz")
+        sposes = synth.drive_poses(n_img, step=0.5)
+        if os.path.exists(scache):
+            z = np.load(scache)
+            imgs = [(z["d"][i], z["c"][i]) for i in range(n_img)]
+        else:
+            scene = synth.street_canyon()
+            imgs = [synth.spherical_range_image(scene, t, q, cam) for t, q in sposes]
+            np.savez(scache, d=np.stack([a for a, _ in imgs]), c=np.stack([b for _, b in imgs]))
+        dd = hipmem.DeviceBuffer.from_numpy(np.stack([a for a, _ in imgs]).astype(np.float32))
+        dc = hipmem.DeviceBuffer.from_numpy(np.stack([b for _, b in imgs]).astype(np.uint8))
+        sp = dict(synth.VBR_PARAMS, n_frames_invalidate_voxels=100)
+        se_ = capi.Engine(hip, capi.Params(num_sdf_blocks=args.blocks, device_id=0, **sp))
+        se_.set_camera(cam["fx"], cam["fy"], cam["cx"], cam["cy"], cam["rows"], cam["cols"], sp["min_depth"], 100.0, model=1)
+        npx = cam["rows"] * cam["cols"]
+
+        def run_imgs(lo, hi):
+            for i in range(lo, hi):
+                t, q = sposes[i]
+                se_.set_pose(synth.quat_to_rot(q), t)
+                se_.set_depth_device(dd.ptr + i * npx * 4, cam["rows"], cam["cols"])
+                se_.set_rgb_device(dc.ptr + i * npx * 3, cam["rows"], cam["cols"])
+                se_.integrate()
+
+        run_imgs(0, w_img)
+        se_.sync()
+        c0 = time.perf_counter()
+        run_imgs(w_img, n_img)
+        se_.sync()
+        dts = time.perf_counter() - c0
+        spherical = {"workload": "128 x 1024 range images of the street scene through mrh_integrate under the spherical camera model "
+                                 "(vbr.cfg parameters; general kernels: k_cloud_depth, k_alloc, k_compact, k_integrate, GC)",
+                     "frames_per_s": (n_img - w_img) / dts, "ms_per_frame": dts / (n_img - w_img) * 1e3, "live_blocks_end": int(se_.stats().occupied_fine)}
+        se_.close()
+        del dd, dc
 
     # ---- pass B: same frames, HIP events around every integrate-kernel launch + device-side U/M counters
     roof = profiled_roofline(eng, res, W, total, "configs[1] (value's workload)")
@@ -441,19 +519,67 @@ def bench_single(args):
                    "frames_per_gpu": K, "voxel_size_m": 0.01, "truncation_m": 0.07, "parallelism": "single GPU", "live_blocks_end": occupied,
                    "hash_table": table},
         "roofline": roof, "roofline_hbm": roof_hbm, "mc": mc, "cpu_baseline": cpu,
-        "lidar": lidar, "splat": splat, "pcie_inclusive_frames_per_s": pcie_fps,
+        "lidar": lidar, "splat": splat, "pcie_inclusive_frames_per_s": pcie_fps, "periodic_frames": periodic, "spherical_images": spherical,
     }
     emit(out)
 
 
 # ---- N > 1 ---------------------------------------------------------------------------------------------------------
 
+class Group:
+    """The ranks of the run: RCCL behind the C ABI (capi.Comm; the product path, no torch in the process) or — test mode,
+    N ranks sharing one device — a gloo group."""
+
+    def __init__(self, hip, rank, world, device_index, backend):
+        from mrhash_amd import capi, parallel
+
+        self.rank, self.world, self.backend = rank, world, backend
+        if backend == "rccl":
+            self.handle = parallel.rendezvous(hip, rank, world, device_index)
+            self.dist = None
+        else:
+            self.dist = parallel.init_process_group("gloo")
+            self.handle = self.dist
+            if self.dist.get_world_size() != world:
+                raise SystemExit(f"bench.py: the process group reports {self.dist.get_world_size()} ranks, --gpus says {world}")
+        self._capi = capi
+
+    def barrier(self):
+        from mrhash_amd import hipmem
+
+        hipmem.synchronize()
+        if self.dist is None:
+            self.handle.barrier()
+        else:
+            self.dist.barrier()
+
+    def max(self, x: float) -> float:
+        if self.dist is None:
+            return float(self.handle.allreduce([x], self._capi.COMM_MAX)[0])
+        import torch
+
+        t = torch.tensor([x], dtype=torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def allgather(self, values) -> np.ndarray:
+        if self.dist is None:
+            return self.handle.allgather_i64(values)
+        import torch
+
+        mine = torch.tensor(list(values), dtype=torch.int64)
+        out = torch.empty(self.world * len(mine), dtype=torch.int64)
+        self.dist.all_gather_into_tensor(out, mine)
+        return out.numpy().reshape(self.world, len(mine))
+
+    def close(self):
+        if self.dist is None:
+            self.handle.close()
+        else:
+            self.dist.destroy_process_group()
+
+
 def bench_multi(args):
-    import torch
-    import torch.distributed as dist
-
-    from mrhash_amd import capi, parallel, synth
-
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -461,30 +587,25 @@ def bench_multi(args):
     total = W + K
     if world != args.gpus:
         raise SystemExit(f"bench.py --gpus {args.gpus}: launched with WORLD_SIZE={world}; refusing to report n_gpus = {args.gpus}")
-    # MRH_BENCH_DEVICE / MRH_BENCH_BACKEND exist so that the multi-rank code path can be exercised on a 1-GPU box
-    # (ranks sharing device 0 over gloo); the driver's runs use one GPU per rank over RCCL.
-    device_index = int(os.environ.get("MRH_BENCH_DEVICE", local_rank))
-    backend = os.environ.get("MRH_BENCH_BACKEND", "nccl")
-    torch.cuda.set_device(device_index)
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    if backend == "nccl":
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device_index))
-    else:
-        dist.init_process_group(backend=backend)
-    if dist.get_world_size() != args.gpus:
-        raise SystemExit(f"bench.py: the process group reports {dist.get_world_size()} ranks, --gpus says {args.gpus}")
-    cdev = "cuda" if backend == "nccl" else "cpu"
+    # MRH_BENCH_SHARE_DEVICE=1 exists so that the multi-rank code path can be exercised on a 1-GPU box: the ranks share device
+    # 0 and talk over gloo (RCCL refuses two ranks on one device).  The driver's runs use one GPU per rank over RCCL.
+    share = os.environ.get("MRH_BENCH_SHARE_DEVICE") == "1"
+    device_index = 0 if share else local_rank
+    backend = "gloo" if share else "rccl"
+    if share:
+        import torch  # noqa: F401  (gloo; imported before the library binds its HIP runtime, see mrhash_amd/_runtime.py)
 
-    def barrier():
-        torch.cuda.synchronize()
-        dist.barrier()
-
-    def max_over_ranks(x: float) -> float:
-        t = torch.tensor([x], dtype=torch.float64, device=cdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t.item())
+    from mrhash_amd import capi, hipmem, parallel, synth
 
     hip = capi.load_hip()
+    ndev = hipmem.device_count()
+    if not share and ndev < world:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {ndev} HIP device(s) visible; refusing to report n_gpus = {args.gpus}")
+    hipmem.set_device(device_index)
+    grp = Group(hip, rank, world, device_index, backend)
+    devices = sorted(set(int(v) for v in grp.allgather([device_index])[:, 0]))
+    n_gpus = 1 if share else len(devices)
+
     Kc = synth.SCANNET
     params = capi.Params(num_sdf_blocks=args.blocks, device_id=device_index, **synth.SCANNET_PARAMS)
     chunk_log2 = 3
@@ -492,32 +613,35 @@ def bench_multi(args):
     # ---- frame-sharded fusion (value): this rank's own segment of the walk
     mine = Resident(render_stream("scannet", total, start=rank * total), Kc)
     eng = make_engine(hip, params, Kc)
+    if grp.dist is None:
+        eng.attach_comm(grp.handle)
     mine.run(eng, 0, W)
     eng.sync()
-    barrier()
+    grp.barrier()
     t0 = time.perf_counter()
     mine.run(eng, W, total)
     eng.sync()
-    barrier()
-    elapsed = max_over_ranks(time.perf_counter() - t0)
+    grp.barrier()
+    elapsed = grp.max(time.perf_counter() - t0)
     sub_blocks = int(eng.stats().occupied_fine)
 
     # ---- sub-maps -> one tile-sharded map -> halo exchange (what a mesh extraction needs next)
-    barrier()
+    grp.barrier()
     t1 = time.perf_counter()
-    info = parallel.merge_submaps(eng, dist, chunk_log2)
-    barrier()
-    merge_s = max_over_ranks(time.perf_counter() - t1)
+    info = parallel.merge_submaps(eng, grp.handle, chunk_log2)
+    grp.barrier()
+    merge_s = grp.max(time.perf_counter() - t1)
+    merge_phases = eng.comm_phase_times() if grp.dist is None else None
     t2 = time.perf_counter()
-    n_halo = parallel.exchange_halo(eng, dist)
-    barrier()
-    halo_s = max_over_ranks(time.perf_counter() - t2)
+    n_halo = parallel.exchange_halo(eng, grp.handle)
+    grp.barrier()
+    halo_s = grp.max(time.perf_counter() - t2)
+    halo_phases = eng.comm_phase_times() if grp.dist is None else None
     owned = int(eng.stats().occupied_fine) - n_halo
     parallel.drop_halo(eng)
-    counts = torch.tensor([sub_blocks, info["sent"], owned, n_halo], dtype=torch.int64, device=cdev)
-    allc = torch.empty(world * 4, dtype=torch.int64, device=cdev)
-    dist.all_gather_into_tensor(allc, counts)
-    allc = allc.cpu().numpy().reshape(world, 4)
+    allc = grp.allgather([sub_blocks, info["sent"], owned, n_halo])
+    if grp.dist is None:
+        eng.attach_comm(None)
     eng.close()
 
     # ---- roofline of the integrate kernel on rank 0's own segment (profiled pass on a second context; the other ranks wait)
@@ -527,39 +651,54 @@ def bench_multi(args):
         roof = profiled_roofline(pe, mine, W, total, f"configs[3], rank 0's segment of the frame-sharded stream ({K} frames)")
         roof["cache_note"] = "per-frame working set inside the 256 MiB Infinity Cache (see the N = 1 line's roofline_hbm for the kernel outside it)"
         pe.close()
-    barrier()
+    grp.barrier()
 
     # ---- tile-sharded fusion of ONE stream (rank 0's segment) by all ranks
     shared = mine if rank == 0 else Resident(render_stream("scannet", total, start=0), Kc)
     tp = capi.Params(num_sdf_blocks=args.blocks, device_id=device_index, shard_rank=rank, shard_count=world, shard_chunk_log2=chunk_log2,
                      **synth.SCANNET_PARAMS)
     te = make_engine(hip, tp, Kc)
-    step = lambda e: parallel.integrate(e, dist)  # noqa: E731
+    if grp.dist is None:
+        te.attach_comm(grp.handle)  # starve frames: the two MIN all-reduces run inside mrh_integrate
+        step = None
+    else:
+        step = lambda e: parallel.integrate(e, grp.handle)  # noqa: E731
     shared.run(te, 0, W, integrate=step)
     te.sync()
-    barrier()
+    grp.barrier()
     t3 = time.perf_counter()
     shared.run(te, W, total, integrate=step)
     te.sync()
-    barrier()
-    tile_elapsed = max_over_ranks(time.perf_counter() - t3)
+    grp.barrier()
+    tile_elapsed = grp.max(time.perf_counter() - t3)
     tile_blocks = int(te.stats().occupied_fine)
+    tile_phases = te.comm_phase_times() if grp.dist is None else None
+    if grp.dist is None:
+        te.attach_comm(None)
     te.close()
 
     if rank == 0:
         rec = capi.RECORD_BYTES
+        phase_keys = ("pack_ms", "counts_ms", "collective_ms", "unpack_ms", "bytes_out", "bytes_in")
         out = {
             "metric": "depth frames/sec integrated (640x480)",
-            "value": world * K / elapsed, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3,
+            "value": world * K / elapsed, "unit": "frames/s", "n_gpus": n_gpus, "ranks": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "scannet-scene0000 stand-in 640x480 (furnished 8x3x6 m room, hand-held walk), single-resolution hash TSDF "
                                    "integrate (alloc+compact+integrate+GC per frame, scannet.cfg params), frames resident in HBM",
                        "frames_per_gpu": K, "voxel_size_m": 0.01, "truncation_m": 0.07,
                        "parallelism": f"value = FRAME-SHARDED: {world} ranks x {K} own frames into {world} sub-maps, no data-path collective in the timed "
-                                      f"region (backend {backend}); the sub-maps are merged afterwards (see merge)",
+                                      f"region (backend {backend}, devices {devices}); the sub-maps are merged afterwards (see merge)",
                        "sub_map_blocks_per_rank": [int(v) for v in allc[:, 0]]},
+            "phases": {"what": "HIP-event times on rank 0: the two launches of a frame (profiled pass over rank 0's segment), the phases of the two "
+                               "exchange calls, the starve all-reduces of the tile-sharded pass",
+                       "k_front_ms": roof["k_front_ms_avg"] if roof else None, "k_back_ms": roof["kernel_ms_avg"] if roof else None,
+                       "merge": {k: merge_phases[k] for k in phase_keys} if merge_phases else None,
+                       "halo": {k: halo_phases[k] for k in phase_keys} if halo_phases else None,
+                       "starve_allreduce_ms_avg": (tile_phases["allreduce_ms_sum"] / tile_phases["allreduce_count"]) if tile_phases and tile_phases["allreduce_count"] else None,
+                       "starve_allreduce_count": tile_phases["allreduce_count"] if tile_phases else None},
             "merge": {"what": "sub-maps -> one tile-sharded map: all-to-all of blocks to their tile owner + weighted merge on the device "
-                              "(parallel.merge_submaps), then all-gather of boundary blocks (parallel.exchange_halo)",
+                              "(mrh_comm_merge_submaps), then exchange of boundary blocks (mrh_comm_exchange_halo)",
                       "merge_ms": merge_s * 1e3, "halo_exchange_ms": halo_s * 1e3,
                       "blocks_sent_per_rank": [int(v) for v in allc[:, 1]], "bytes_sent_per_rank": [int(v) * rec for v in allc[:, 1]],
                       "owned_blocks_after_merge_per_rank": [int(v) for v in allc[:, 2]], "halo_blocks_taken_per_rank": [int(v) for v in allc[:, 3]],
@@ -571,39 +710,37 @@ def bench_multi(args):
             "roofline": roof, "cpu_baseline": None,
         }
         emit(out)
-    barrier()
-    dist.destroy_process_group()
+    grp.barrier()
+    grp.close()
 
 
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        # launched the single-process way: become N ranks (one per GPU) under torch.distributed.run
-        import torch
+        # launched the single-process way: become N ranks, one per GPU (what torch.distributed.run does for the driver: RANK /
+        # LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment of N copies of this script)
+        from mrhash_amd import hipmem
 
-        ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        ndev = hipmem.device_count()
         share = os.environ.get("MRH_BENCH_SHARE_DEVICE") == "1"  # test mode: N ranks on device 0
         if ndev < args.gpus and not share:
             raise SystemExit(f"bench.py --gpus {args.gpus}: only {ndev} HIP device(s) visible; refusing to report n_gpus = {args.gpus}")
-        env = dict(os.environ)
-        if share:
-            env.setdefault("MRH_BENCH_DEVICE", "0")
-            env.setdefault("MRH_BENCH_BACKEND", "gloo")
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
-               "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
-        raise SystemExit(subprocess.call(cmd, env=env))
+        port = free_port()
+        procs = []
+        for r in range(args.gpus):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                       MRH_RDZV_KEY=f"bench_{os.getpid()}_{port}")
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+        rcs = [p.wait() for p in procs]
+        raise SystemExit(max(abs(rc) for rc in rcs))
     if not args.pmc_inner and not args.pmc_inner_big:
         global _RESULT_FD
         sys.stdout.flush()
         _RESULT_FD = os.dup(1)
         os.dup2(2, 1)  # from here on fd 1 is stderr for every library in the process; emit() writes the result line
-    import torch
-
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device (torch.cuda.is_available() is False)")
-    # Python's cyclic collector stays off for the run: a generation-2 pass of an interpreter with torch loaded takes tens
-    # of milliseconds and fires after a fixed number of allocations, i.e. inside whichever timed loop happens to cross it
-    # (seen as a 20x outlier of one leg in tools/bench_tile_shards.py).  Nothing here builds reference cycles that matter.
+    # Python's cyclic collector stays off for the run: a generation-2 pass takes milliseconds and fires after a fixed number of
+    # allocations, i.e. inside whichever timed loop happens to cross it (seen as a 20x outlier of one leg in
+    # tools/bench_tile_shards.py).  Nothing here builds reference cycles that matter.
     gc.collect()
     gc.disable()
     if args.gpus > 1:
@@ -611,7 +748,11 @@ def main():
     else:
         if int(os.environ.get("WORLD_SIZE", "1")) != 1:
             raise SystemExit(f"bench.py --gpus 1 launched with WORLD_SIZE={os.environ['WORLD_SIZE']}")
-        torch.cuda.set_device(0)
+        from mrhash_amd import hipmem
+
+        if hipmem.device_count() < 1:
+            raise SystemExit("bench.py needs a HIP device (hipGetDeviceCount reports none)")
+        hipmem.set_device(0)
         bench_single(args)
 
 

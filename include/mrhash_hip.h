@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MRH_ABI_VERSION 2
+#define MRH_ABI_VERSION 3
 
 typedef enum mrh_status {
   MRH_OK                = 0,
@@ -141,6 +141,11 @@ typedef struct mrh_stats {
   float    last_mc_count_ms;
   float    last_mc_emit_ms;
   uint64_t last_mc_blocks;        /* blocks (fine + coarse) the last extraction walked                  */
+  /* profile mode, two-launch fast path: HIP-event time of the allocation + sweep launch (k_front), as sum_integrate_kernel_ms
+   * is that of the integrate launch (k_back)                                                                               */
+  float    sum_front_kernel_ms;
+  uint32_t reserved1;
+  uint64_t n_front_kernel;
 } mrh_stats;
 
 typedef struct mrh_ctx mrh_ctx;
@@ -387,7 +392,10 @@ typedef enum mrh_unpack_mode {
                            colour = u8(0.5 c0 + 0.5 c1 + 0.5); a voxel with weight 0 on one side takes the other
                            side unchanged; absent blocks are inserted.  Single-resolution maps only.             */
 } mrh_unpack_mode;
-/* `records` is a device pointer iff is_device_memory != 0 (what a RCCL collective leaves behind).  Blocks. */
+/* `records` is a device pointer iff is_device_memory != 0 (what a RCCL collective leaves behind).  Blocks.
+ * The records of ONE call must carry distinct block positions (the blocks of one rank's map do): every record is handled by
+ * its own workgroup, and two records of the same position in one MRH_UNPACK_MERGE call would race on that block.  Fold
+ * several sub-maps with one call per sub-map (mrh_comm_merge_submaps, mrhash_amd/parallel.py). */
 int mrh_unpack_blocks(mrh_ctx* ctx, int mode, const mrh_block_record* records, uint64_t n, int is_device_memory,
                       uint64_t* out_taken);
 

@@ -22,7 +22,7 @@ HIP_LIB = os.path.join(CSRC, "libmrhash_hip.so")
 HIPCC_FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
     "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math",
-    "-Wall", "-Wno-unused-function", "-Wno-unused-variable",
+    "-Wall", "-Wno-unused-function", "-Wno-unused-variable", "-ldl",
 ]
 
 

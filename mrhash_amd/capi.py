@@ -18,7 +18,7 @@ import numpy as np
 _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HIP_LIB_PATH = os.path.join(_ROOT, "mrhash_amd", "csrc", "libmrhash_hip.so")
 
-MRH_ABI_VERSION = 2
+MRH_ABI_VERSION = 3
 
 MRH_OK = 0
 MRH_PENDING_EXCHANGE = 1
@@ -88,6 +88,9 @@ class MrhStats(C.Structure):
         ("last_mc_count_ms", C.c_float),
         ("last_mc_emit_ms", C.c_float),
         ("last_mc_blocks", C.c_uint64),
+        ("sum_front_kernel_ms", C.c_float),
+        ("reserved1", C.c_uint32),
+        ("n_front_kernel", C.c_uint64),
     ]
 
 
@@ -116,6 +119,24 @@ ABI_SYMBOLS = (
     "mrh_extract_triangles mrh_extract_mesh mrh_get_stats mrh_set_profile mrh_dump_blocks "
     "mrh_get_voxel mrh_import_blocks mrh_get_triangle_blocks mrh_get_triangles_device mrh_process_triangle_runs mrh_process_triangles mrh_selftest_division mrh_version"
 ).split()
+
+
+# every symbol include/mrhash_comm.h declares (the HIP library only: the oracle has no communicator)
+COMM_SYMBOLS = (
+    "mrh_comm_unique_id mrh_comm_create mrh_comm_destroy mrh_comm_last_error mrh_comm_size mrh_comm_barrier mrh_comm_allreduce_f64 "
+    "mrh_comm_allgather_bytes mrh_comm_attach mrh_comm_exchange_halo mrh_comm_merge_submaps mrh_comm_gather_mesh mrh_comm_phase_times"
+).split()
+COMM_ID_BYTES = 128
+COMM_SUM, COMM_MAX, COMM_MIN = 0, 1, 2
+
+
+class MrhCommMergeInfo(C.Structure):
+    _fields_ = [("blocks_sent", C.c_uint64), ("blocks_received", C.c_uint64), ("bytes_sent", C.c_uint64), ("blocks_kept", C.c_uint64)]
+
+
+class MrhCommPhases(C.Structure):
+    _fields_ = [("pack_ms", C.c_float), ("counts_ms", C.c_float), ("collective_ms", C.c_float), ("unpack_ms", C.c_float),
+                ("bytes_out", C.c_uint64), ("bytes_in", C.c_uint64), ("allreduce_ms_sum", C.c_float), ("allreduce_count", C.c_uint32)]
 
 
 class MrhError(RuntimeError):
@@ -173,6 +194,24 @@ def _declare(lib: C.CDLL) -> C.CDLL:
         fn = getattr(lib, name)
         if name not in ("mrh_last_error", "mrh_version"):
             fn.restype = C.c_int
+    if hasattr(lib, "mrh_comm_create"):  # include/mrhash_comm.h
+        lib.mrh_comm_unique_id.argtypes = [C.c_void_p]
+        lib.mrh_comm_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, P(C.c_void_p)]
+        lib.mrh_comm_destroy.argtypes = [C.c_void_p]
+        lib.mrh_comm_last_error.argtypes = [C.c_void_p]
+        lib.mrh_comm_last_error.restype = C.c_char_p
+        lib.mrh_comm_size.argtypes = [C.c_void_p, P(C.c_int), P(C.c_int)]
+        lib.mrh_comm_barrier.argtypes = [C.c_void_p]
+        lib.mrh_comm_allreduce_f64.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int]
+        lib.mrh_comm_allgather_bytes.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+        lib.mrh_comm_attach.argtypes = [C.c_void_p, C.c_void_p]
+        lib.mrh_comm_exchange_halo.argtypes = [C.c_void_p, P(C.c_uint64)]
+        lib.mrh_comm_merge_submaps.argtypes = [C.c_void_p, C.c_int, P(MrhCommMergeInfo)]
+        lib.mrh_comm_gather_mesh.argtypes = [C.c_void_p, C.c_int, P(C.c_uint64)]
+        lib.mrh_comm_phase_times.argtypes = [C.c_void_p, P(MrhCommPhases)]
+        for name in COMM_SYMBOLS:
+            if name != "mrh_comm_last_error":
+                getattr(lib, name).restype = C.c_int
     return lib
 
 
@@ -196,6 +235,57 @@ def load_hip() -> C.CDLL:
         torch_first()  # see _runtime.py: torch's HIP runtime has to initialise before this library's
         _hip_lib = load_library(HIP_LIB_PATH)
     return _hip_lib
+
+
+class Comm:
+    """RCCL communicator behind the C ABI (include/mrhash_comm.h): one per process / GPU.  `unique_id()` on one rank, the 128
+    bytes handed to the others by the host (mrhash_amd.parallel.rendezvous), then `Comm(lib, id, rank, world, device)`."""
+
+    def __init__(self, lib: C.CDLL, uid: bytes, rank: int, world: int, device_id: int = 0):
+        self.lib, self.rank, self.world, self.device_id = lib, rank, world, device_id
+        self._comm = C.c_void_p()
+        buf = (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(uid)
+        rc = lib.mrh_comm_create(buf, rank, world, device_id, C.byref(self._comm))
+        if rc != MRH_OK:
+            raise MrhError(rc, lib.mrh_comm_last_error(None).decode())
+
+    @staticmethod
+    def unique_id(lib: C.CDLL) -> bytes:
+        buf = (C.c_uint8 * COMM_ID_BYTES)()
+        rc = lib.mrh_comm_unique_id(buf)
+        if rc != MRH_OK:
+            raise MrhError(rc, lib.mrh_comm_last_error(None).decode())
+        return bytes(buf)
+
+    def _check(self, rc: int):
+        if rc != MRH_OK:
+            raise MrhError(rc, self.lib.mrh_comm_last_error(self._comm).decode())
+
+    def barrier(self):
+        self._check(self.lib.mrh_comm_barrier(self._comm))
+
+    def allreduce(self, values, op: int = COMM_SUM) -> np.ndarray:
+        a = np.ascontiguousarray(np.atleast_1d(values), dtype=np.float64).copy()
+        self._check(self.lib.mrh_comm_allreduce_f64(self._comm, a.ctypes.data, a.size, op))
+        return a
+
+    def allgather_i64(self, values) -> np.ndarray:
+        """[world, len(values)] int64: every rank's `values`."""
+        a = np.ascontiguousarray(np.atleast_1d(values), dtype=np.int64)
+        out = np.empty((self.world, a.size), dtype=np.int64)
+        self._check(self.lib.mrh_comm_allgather_bytes(self._comm, a.ctypes.data, a.nbytes, out.ctypes.data))
+        return out
+
+    def close(self):
+        if self._comm:
+            self.lib.mrh_comm_destroy(self._comm)
+            self._comm = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 @dataclass
@@ -248,6 +338,7 @@ class Engine:
         if rc != MRH_OK:
             raise MrhError(rc, lib.mrh_last_error(None).decode())
         self._keep = []  # device tensors referenced by *_device setters
+        self._comm_ref = None  # keeps an attached Comm alive
 
     # -- helpers -------------------------------------------------------------------------------
     def _check(self, rc: int):
@@ -258,6 +349,7 @@ class Engine:
         if self._ctx:
             self.lib.mrh_destroy(self._ctx)
             self._ctx = C.c_void_p()
+            self._comm_ref = None
 
     def __del__(self):
         try:
@@ -422,6 +514,33 @@ class Engine:
         f = C.c_uint32()
         self._check(self.lib.mrh_peek_error_flags(self._ctx, C.byref(f)))
         return int(f.value)
+
+    # -- multi-GPU: RCCL behind the C ABI (include/mrhash_comm.h) -----------------------------------
+    def attach_comm(self, comm: Optional["Comm"]):
+        """While attached, a tile-sharded context runs the starve all-reduces itself (integrate() never returns True)."""
+        self._check(self.lib.mrh_comm_attach(self._ctx, comm._comm if comm is not None else None))
+        self._comm_ref = comm
+
+    def comm_exchange_halo(self) -> int:
+        n = C.c_uint64()
+        self._check(self.lib.mrh_comm_exchange_halo(self._ctx, C.byref(n)))
+        return int(n.value)
+
+    def comm_merge_submaps(self, chunk_log2: int = 3) -> dict:
+        info = MrhCommMergeInfo()
+        self._check(self.lib.mrh_comm_merge_submaps(self._ctx, chunk_log2, C.byref(info)))
+        self.params.shard_chunk_log2 = chunk_log2
+        return {"sent": int(info.blocks_sent), "received": int(info.blocks_received), "bytes": int(info.bytes_sent), "kept": int(info.blocks_kept)}
+
+    def comm_gather_mesh(self, root: int = 0) -> int:
+        n = C.c_uint64()
+        self._check(self.lib.mrh_comm_gather_mesh(self._ctx, root, C.byref(n)))
+        return int(n.value)
+
+    def comm_phase_times(self) -> dict:
+        p = MrhCommPhases()
+        self._check(self.lib.mrh_comm_phase_times(self._ctx, C.byref(p)))
+        return {k: (float(getattr(p, k)) if k.endswith("_ms") or k.endswith("_sum") else int(getattr(p, k))) for k, _ in MrhCommPhases._fields_}
 
     # -- multi-GPU block exchange ----------------------------------------------------------------
     def set_sharding(self, rank: int, count: int, chunk_log2: int = 0):

@@ -258,6 +258,10 @@ void GeoWrapper::extractMesh(const std::string& filename) {
   const bool dbg = std::getenv("MRH_DEBUG") != nullptr;
   auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const double t0 = now();
+  // the previous mesh goes first: if this extraction throws, the getters must not read buffers the library has already reused
+  mesh_v_ = mesh_c_ = nullptr; mesh_f_ = nullptr; mesh_nv_ = mesh_nf_ = 0;
+  V_.clear(); F_.clear(); C_.clear();
+  mesh_cached_ = true;
   streamInFromGrid(nullptr, 0.f);  // blocks the streamer paged out take part in the mesh (geowrapper.cpp:162-188 walks the grid)
   uint64_t nt = 0;
   std::cout << "GeoWrapper::extractMesh | extracting..." << std::endl;

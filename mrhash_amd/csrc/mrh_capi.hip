@@ -8,6 +8,9 @@
 #include <sys/mman.h>
 #if !defined(__HIP_DEVICE_COMPILE__)
 #include <immintrin.h>
+#define MRH_CPU_RELAX() _mm_pause()
+#else
+#define MRH_CPU_RELAX() ((void) 0)  // host code as the device pass sees it
 #endif
 
 #include <algorithm>
@@ -27,6 +30,7 @@
 #include <vector>
 
 #include "../../include/mrhash_hip.h"
+#include "../../include/mrhash_comm.h"
 #include "mrh_kernels.h"
 #include "mrh_mc.h"
 #include "mrh_fast.h"
@@ -195,8 +199,11 @@ struct mrh_ctx {
   int profile = 0;
   std::vector<EvPair> ev_pool;
   std::vector<EvPair> ev_pending;
+  std::vector<EvPair> ev_pending_front;  // the allocation launch (k_front) of profiled fast-path frames
   float sum_ms = 0.f, last_ms = 0.f;
   uint64_t n_ms = 0;
+  float sum_front_ms = 0.f;
+  uint64_t n_front_ms = 0;
   uint64_t prev_total_updated = 0, prev_inserted = 0, prev_freed = 0, total_compact = 0;
   uint64_t last_triangles = 0;
   // hash-table upkeep (mrh_kernels.h: k_table_census / k_rehash_*)
@@ -216,8 +223,18 @@ struct mrh_ctx {
   hipEvent_t mc_ev[4] = {};
   float last_mc_count_ms = 0.f, last_mc_emit_ms = 0.f;
   uint64_t last_mc_blocks = 0;
+  // RCCL (mrh_comm.h): the communicator this context is attached to, exchange buffers, phase clocks
+  mrh_comm* comm = nullptr;
+  char* d_xsend = nullptr; size_t xsend_cap = 0;
+  char* d_xrecv = nullptr; size_t xrecv_cap = 0;
+  hipEvent_t comm_ev[5] = {};
+  mrh_comm_phases comm_phases = {};
+  std::vector<EvPair> comm_ev_pool, comm_ev_pending;
   std::string err;
 };
+
+static int comm_allreduce_zbuf(mrh_ctx* c, mrh::u64* buf, size_t n);  // mrh_comm.h
+static void comm_release(mrh_ctx* c);
 
 namespace {
 
@@ -280,9 +297,15 @@ void free_all(mrh_ctx* c) {
   F(c->d_upd_partials); F(c->d_misc); F(c->d_rcp_w); F(c->d_cfree); F(c->d_zmin); F(c->d_points); F(c->d_pt_counts); F(c->d_pt_offsets); F(c->d_rec_keys[0]); F(c->d_rec_keys[1]); F(c->d_rec_vals[0]); F(c->d_rec_vals[1]); F(c->d_sort_tmp); F(c->fast.summary); F(c->fast.summary_c); F(c->fast.bbox); F(c->d_cnt_partials);
   F(c->d_pack); F(c->d_halo); F(c->d_taken); F(c->d_cloud); F(c->d_normals); F(c->d_soup);
   for (hipEvent_t e : c->mc_ev) if (e) (void) hipEventDestroy(e);
+  comm_release(c);
+  F(c->d_xsend); F(c->d_xrecv);
+  for (hipEvent_t e : c->comm_ev) if (e) (void) hipEventDestroy(e);
+  for (auto& e : c->comm_ev_pool) { (void) hipEventDestroy(e.a); (void) hipEventDestroy(e.b); }
+  for (auto& e : c->comm_ev_pending) { (void) hipEventDestroy(e.a); (void) hipEventDestroy(e.b); }
   F(c->d_qt_sums); F(c->d_qt_flags); F(c->d_qt_unc); F(c->d_qt_marks); F(c->d_qt_pos); F(c->d_qt_parked); F(c->d_qt_seeds); F(c->d_qt_leaves); F(c->d_qt_misc); F(c->d_qt_tmp);
   for (auto& e : c->ev_pool) { (void) hipEventDestroy(e.a); (void) hipEventDestroy(e.b); }
   for (auto& e : c->ev_pending) { (void) hipEventDestroy(e.a); (void) hipEventDestroy(e.b); }
+  for (auto& e : c->ev_pending_front) { (void) hipEventDestroy(e.a); (void) hipEventDestroy(e.b); }
   if (c->stream) (void) hipStreamDestroy(c->stream);
 }
 
@@ -317,6 +340,8 @@ int init_buffers(mrh_ctx* c) {
   c->prev_total_updated = c->prev_inserted = c->prev_freed = c->total_compact = 0;
   c->sum_ms = c->last_ms = 0.f;
   c->n_ms = 0;
+  c->sum_front_ms = 0.f;
+  c->n_front_ms = 0;
   c->tris.clear(); c->V.clear(); c->C.clear(); c->F.clear();
   c->last_triangles = 0;
   return MRH_OK;
@@ -332,6 +357,14 @@ int drain_events(mrh_ctx* c) {
     c->ev_pool.push_back(e);
   }
   c->ev_pending.clear();
+  for (auto& e : c->ev_pending_front) {
+    float ms = 0.f;
+    HIP_TRY(c, hipEventElapsedTime(&ms, e.a, e.b));
+    c->sum_front_ms += ms;
+    c->n_front_ms++;
+    c->ev_pool.push_back(e);
+  }
+  c->ev_pending_front.clear();
   return MRH_OK;
 }
 
@@ -350,6 +383,8 @@ int take_device_flags(mrh_ctx* c, u32* out) {
   HIP_TRY(c, hipMemcpyAsync(&flags, &c->tab.ctr[CTR_ERROR], sizeof(u32), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   if (flags) HIP_TRY(c, hipMemsetAsync(&c->tab.ctr[CTR_ERROR], 0, sizeof(u32), c->stream));
+  if (flags & ERR_POOL) c->table_dirty = true;  // keys without storage exist (publish_without_storage): census + rebuild before the next frame,
+                                                // so that the positions can be allocated again as soon as the pool has room (vds.cu:566-569 retries every frame)
   c->flags_seen |= flags;
   *out = flags;
   return MRH_OK;
@@ -628,6 +663,18 @@ int starve_and_tail(mrh_ctx* c, int max_num_frames) {
   if (starve) {
     int rc = launch_starve(c, 0);
     if (rc) return rc;
+    if (c->p.shard_count > 1 && c->comm) {
+      // a communicator is attached: the two min-reductions over the shards run on this stream, between the passes —
+      // ncclAllReduce(int64, MIN) over xGMI, no host synchronisation, the frame stays one enqueue
+      const size_t npix = (size_t) c->cam.rows * c->cam.cols;
+      rc = comm_allreduce_zbuf(c, c->d_zbuf, npix);
+      if (rc) return rc;
+      launch_starve(c, 1);
+      rc = comm_allreduce_zbuf(c, c->d_zbuf + npix, npix);
+      if (rc) return rc;
+      launch_starve(c, 2);
+      return frame_tail(c, starve, max_num_frames);
+    }
     if (c->p.shard_count > 1) {
       HIP_TRY(c, hipStreamSynchronize(c->stream));
       c->pending = 1;
@@ -644,7 +691,9 @@ int starve_and_tail(mrh_ctx* c, int max_num_frames) {
 
 extern "C" {
 
-const char* mrh_version(void) { return "mrhash_hip abi1 gfx950 hand-written-hip"; }
+#define MRH_STR2(x) #x
+#define MRH_STR(x) MRH_STR2(x)
+const char* mrh_version(void) { return "mrhash_hip abi" MRH_STR(MRH_ABI_VERSION) " gfx950 hand-written-hip"; }
 
 const char* mrh_last_error(const mrh_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 
@@ -907,21 +956,32 @@ void copy_chunk(void* dst, const void* src, size_t n) {
 // otherwise.  One pool per process, started by the first large upload, MRH_COPY_THREADS=0 turns it off.
 struct CopyPool {
   static constexpr size_t kChunk = 128u << 10;
+  struct Job { std::atomic<char*> dst{nullptr}; std::atomic<const char*> src{nullptr}; std::atomic<size_t> bytes{0}, nchunks{0}; };
   std::mutex m;
   std::condition_variable cv;
   std::vector<std::thread> threads;
-  std::atomic<uint64_t> generation{0};  // bumped once per job
-  std::atomic<size_t> next{0}, done{0};
+  std::atomic<uint64_t> generation{0};  // bumped once per job, after the job's tickets are out
+  // Chunk tickets carry the job they belong to: (generation << 32) | next chunk.  A helper that saw generation g and was
+  // descheduled can only ever claim a chunk of job g, and only while job g is unfinished (an unclaimed chunk of g exists):
+  // it can neither consume a ticket of a later job nor count a chunk into its `done`.  The descriptor of job g lives in
+  // jobs[g & 1], which is rewritten only by job g + 2, i.e. after g and g + 1 have both completed.
+  std::atomic<uint64_t> ticket{0};
+  std::atomic<size_t> done{0};
   std::atomic<int> sleepers{0};
-  std::atomic<char*> dst{nullptr}; std::atomic<const char*> src{nullptr}; std::atomic<size_t> bytes{0}, nchunks{0};
+  Job jobs[2];
   bool started = false;
 
-  void work() {
+  void work(const uint64_t g) {
+    Job& j = jobs[g & 1];
     for (;;) {
-      const size_t i = next.fetch_add(1, std::memory_order_acq_rel);
-      if (i >= nchunks.load(std::memory_order_relaxed)) break;
-      const size_t off = i * kChunk, len = std::min(kChunk, bytes.load(std::memory_order_relaxed) - off);
-      copy_chunk(dst.load(std::memory_order_relaxed) + off, src.load(std::memory_order_relaxed) + off, len);
+      uint64_t cur = ticket.load(std::memory_order_acquire);
+      if ((cur >> 32) != (g & 0xFFFFFFFFull)) break;  // another job's tickets: not ours to take
+      const size_t i = (size_t) (cur & 0xFFFFFFFFull);
+      if (i >= j.nchunks.load(std::memory_order_relaxed)) break;
+      if (!ticket.compare_exchange_weak(cur, cur + 1, std::memory_order_acq_rel, std::memory_order_acquire)) continue;
+      // chunk i of job g is ours: the job cannot complete before the done++ below, so its descriptor is stable
+      const size_t off = i * kChunk, len = std::min(kChunk, j.bytes.load(std::memory_order_relaxed) - off);
+      copy_chunk(j.dst.load(std::memory_order_relaxed) + off, j.src.load(std::memory_order_relaxed) + off, len);
       done.fetch_add(1, std::memory_order_acq_rel);
     }
   }
@@ -933,7 +993,7 @@ struct CopyPool {
       uint64_t g;
       int spins = 0;
       while ((g = generation.load(std::memory_order_acquire)) == seen) {
-        _mm_pause();
+        MRH_CPU_RELAX();
         if ((++spins & 255) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(150)) {
           std::unique_lock<std::mutex> lk(m);
           sleepers.fetch_add(1);
@@ -942,7 +1002,7 @@ struct CopyPool {
         }
       }
       seen = g;
-      work();
+      work(g);
     }
   }
   void start() {
@@ -960,13 +1020,16 @@ struct CopyPool {
     if (!started) start();
     if (threads.empty() || n < 4 * kChunk) { copy_chunk(d, s_, n); return; }
     const size_t nc = (n + kChunk - 1) / kChunk;
-    dst.store((char*) d); src.store((const char*) s_); bytes.store(n); nchunks.store(nc);
-    next.store(0, std::memory_order_release);
-    done.store(0, std::memory_order_release);
-    generation.fetch_add(1, std::memory_order_acq_rel);
+    const uint64_t g = generation.load(std::memory_order_relaxed) + 1;  // one submitter at a time (g_copy_mutex)
+    Job& j = jobs[g & 1];
+    j.dst.store((char*) d, std::memory_order_relaxed); j.src.store((const char*) s_, std::memory_order_relaxed);
+    j.bytes.store(n, std::memory_order_relaxed); j.nchunks.store(nc, std::memory_order_relaxed);
+    done.store(0, std::memory_order_relaxed);  // no ticket of an earlier job is outstanding: they all completed before their copy() returned
+    ticket.store((g & 0xFFFFFFFFull) << 32, std::memory_order_release);
+    generation.store(g, std::memory_order_release);
     if (sleepers.load(std::memory_order_acquire) > 0) { std::lock_guard<std::mutex> lk(m); cv.notify_all(); }
-    work();
-    while (done.load(std::memory_order_acquire) < nc) _mm_pause();
+    work(g);
+    while (done.load(std::memory_order_acquire) < nc) MRH_CPU_RELAX();
   }
 };
 CopyPool* copy_pool() {
@@ -1180,14 +1243,32 @@ static int integrate_frame(mrh_ctx* c, int n_frames_invalidate) {
     }
     // GC runs inside k_back unless this is a starve frame (the starve step changes weights after the integrate pass)
     c->frame_gc_inline = max_num_frames > 0 && !starve_now;
-    if (c->profile) k_front<true, false><<<n_tiles + c->sweep_wgs, 256, 0, s>>>(k, m, t, f, L, c->d_depth, c->d_rgb, tiles_x, n_tiles, stamp, parity, max_num_frames > 0 ? 1 : 0, gc_thr, 0, 0, nullptr);
+    auto take_events = [&](EvPair& e) -> int {
+      if (!c->ev_pool.empty()) { e = c->ev_pool.back(); c->ev_pool.pop_back(); return MRH_OK; }
+      if (c->ev_pending.size() >= 4096) {
+        HIP_TRY(c, hipStreamSynchronize(s));
+        const int r = drain_events(c);
+        if (r) return r;
+        e = c->ev_pool.back(); c->ev_pool.pop_back();
+        return MRH_OK;
+      }
+      HIP_TRY(c, hipEventCreate(&e.a)); HIP_TRY(c, hipEventCreate(&e.b));
+      return MRH_OK;
+    };
+    if (c->profile) {  // event pair attached to the launch, as for k_back below
+      EvPair evf;
+      rc = take_events(evf);
+      if (rc) return rc;
+      hipExtLaunchKernelGGL((k_front<true, false>), dim3(n_tiles + c->sweep_wgs), dim3(256), 0, s, evf.a, evf.b, 0u, k, m, t, f, L, c->d_depth, c->d_rgb, tiles_x, n_tiles, stamp, parity,
+                            max_num_frames > 0 ? 1 : 0, gc_thr, 0, 0, (const int*) nullptr);
+      c->ev_pending_front.push_back(evf);
+    }
     else k_front<false, false><<<n_tiles + c->sweep_wgs, 256, 0, s>>>(k, m, t, f, L, c->d_depth, c->d_rgb, tiles_x, n_tiles, stamp, parity, max_num_frames > 0 ? 1 : 0, gc_thr, 0, 0, nullptr);
     EvPair ev;
     if (c->profile) {
       k_count_updates<<<c->fused_grid, 256, 0, s>>>(k, m, t, f, c->d_cnt_partials, CTR_SET0 + 4 * parity);
-      if (!c->ev_pool.empty()) { ev = c->ev_pool.back(); c->ev_pool.pop_back(); }
-      else if (c->ev_pending.size() >= 4096) { HIP_TRY(c, hipStreamSynchronize(s)); rc = drain_events(c); if (rc) return rc; ev = c->ev_pool.back(); c->ev_pool.pop_back(); }
-      else { HIP_TRY(c, hipEventCreate(&ev.a)); HIP_TRY(c, hipEventCreate(&ev.b)); }
+      rc = take_events(ev);
+      if (rc) return rc;
     }
     // Profile mode: the event pair is attached to the launch itself (hipExtLaunchKernelGGL), so it holds the kernel's own
     // begin / end timestamps — the duration rocprofv3 reports — instead of a hipEventRecord bracket, which adds the
@@ -1378,7 +1459,7 @@ int mrh_integrate_points(mrh_ctx* c, int n_frames_invalidate) {
         const auto t0 = std::chrono::steady_clock::now();
         int spins = 0;
         while (*mark != seq) {
-          _mm_pause();
+          MRH_CPU_RELAX();
           if ((++spins & 1023) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;  // long scan or a fault
         }
         if (*mark != seq) HIP_TRY(c, hipStreamSynchronize(s));  // reports a device error if that is why the mark never came
@@ -1518,9 +1599,8 @@ int mrh_splat_seeds(mrh_ctx* c, float qtree_thresh, int qtree_min_pixel_size, co
   if (qt.total != c->qt.total || !c->d_qt_sums) {
     HIP_TRY(c, hipStreamSynchronize(s));
     auto F = [](auto*& p) { if (p) (void) hipFree(p); p = nullptr; };
-    F(c->d_pack); F(c->d_halo); F(c->d_taken); F(c->d_cloud); F(c->d_normals); F(c->d_soup);
-  for (hipEvent_t e : c->mc_ev) if (e) (void) hipEventDestroy(e);
-  F(c->d_qt_sums); F(c->d_qt_flags); F(c->d_qt_unc); F(c->d_qt_marks); F(c->d_qt_pos); F(c->d_qt_parked); F(c->d_qt_seeds); F(c->d_qt_leaves); F(c->d_qt_misc);
+    // only the quad-tree buffers are sized by qt.total: nothing else of the context is released here
+    F(c->d_qt_sums); F(c->d_qt_flags); F(c->d_qt_unc); F(c->d_qt_marks); F(c->d_qt_pos); F(c->d_qt_parked); F(c->d_qt_seeds); F(c->d_qt_leaves); F(c->d_qt_misc);
     const size_t n = qt.total;
     HIP_TRY(c, hipMalloc((void**) &c->d_qt_sums, n * sizeof(QSum)));
     HIP_TRY(c, hipMalloc((void**) &c->d_qt_flags, n * sizeof(u32)));
@@ -1649,6 +1729,7 @@ int mrh_peek_error_flags(mrh_ctx* c, uint32_t* out_new_flags) {
     if (q != hipSuccess) return fail(c, MRH_ERR_DEVICE, "mrh_peek_error_flags: %s", hipGetErrorString(q));
     const u32 flags = (u32) c->h_peek[8 * (seq % 8) + CTR_ERROR];
     *out_new_flags = flags & ~c->flags_peeked;
+    if (*out_new_flags & ERR_POOL) c->table_dirty = true;  // as in take_device_flags: drop the keys without storage before the next frame
     c->flags_peeked = flags;  // the device clears its flags only in mrh_sync: what is set now has been reported
     return MRH_OK;
   }
@@ -1711,6 +1792,8 @@ int mrh_get_stats(mrh_ctx* c, mrh_stats* out) {
   out->last_mc_count_ms = c->last_mc_count_ms;
   out->last_mc_emit_ms = c->last_mc_emit_ms;
   out->last_mc_blocks = c->last_mc_blocks;
+  out->sum_front_kernel_ms = c->sum_front_ms;
+  out->n_front_kernel = c->n_front_ms;
   HIP_TRY(c, hipMemsetAsync(&c->tab.ctr[CTR_TOMBS_NOW], 0, sizeof(int), s));  // the census accumulator belongs to maintain_table
   return MRH_OK;
 }
@@ -2240,3 +2323,5 @@ int mrh_selftest_division(mrh_ctx* c, uint64_t samples, uint64_t seed, uint64_t*
 }
 
 }  // extern "C"
+
+#include "mrh_comm.h"

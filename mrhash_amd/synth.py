@@ -255,6 +255,15 @@ def scan_normals(pts: np.ndarray) -> np.ndarray:
     return n.astype(np.float32)
 
 
+def spherical_camera(rows: int = 32, cols: int = 512, el_deg: Tuple[float, float] = (-22.5, 22.5)) -> dict:
+    """Spherical intrinsics that map a rows x cols LiDAR image onto [-pi, pi) x [el0, el1] (the layout of the reference's
+    test_projections.cu:146-158): col = fx * azimuth + cx, row = fy * elevation + cy."""
+    fx = cols / (2.0 * np.pi)
+    el0, el1 = np.deg2rad(el_deg[0]), np.deg2rad(el_deg[1])
+    fy = (rows - 1) / (el1 - el0)
+    return dict(fx=fx, fy=fy, cx=cols / 2.0, cy=-fy * el0, rows=rows, cols=cols)
+
+
 def spherical_range_image(scene: Scene, t: np.ndarray, q: np.ndarray, cam: dict) -> Tuple[np.ndarray, np.ndarray]:
     """Range image [rows, cols] float32 + colours for the spherical camera model (camera.cuh:91-99): pixel (row, col) looks
     along azimuth (col - cx - 0.5) / fx, elevation (row - cy - 0.5) / fy; the value is the range along that ray."""

@@ -34,12 +34,41 @@ def test_single_gpu_line():
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0
     assert d["roofline_hbm"]["exceeds_infinity_cache"] in (True, False) and d["mc"]["triangles"] > 0 and d["lidar"]["scans_per_s"] > 0 and d["splat"]["seeds_per_frame"] > 0
     assert d["pcie_inclusive_frames_per_s"] > 0 and "workload" in d["config"]
+    assert d["periodic_frames"]["steady_frame_ms"] > 0 and d["periodic_frames"]["starve_frame_ms"] > d["periodic_frames"]["steady_frame_ms"]
+    assert d["spherical_images"]["frames_per_s"] > 0 and d["roofline"]["k_front_ms_avg"] > 0
 
 
-def test_two_ranks_on_one_device_line():
-    """The N > 1 code path (self-spawned ranks, frame-sharded value, merge, tile-sharded mode) with both ranks on device 0 over gloo."""
-    d = _run(["--gpus", "2", "--steps", "6", "--warmup", "2"], env={"MRH_BENCH_SHARE_DEVICE": "1"})
+@pytest.mark.parametrize("ranks", [2, 8])
+def test_n_ranks_on_one_device_line(ranks):
+    """The N > 1 code path (self-spawned ranks, frame-sharded value, merge, tile-sharded mode) with all ranks on device 0 over
+    gloo — 8 ranks = BASELINE.json configs[3]'s rank count: the 8-way owner function, eight split lists, eight halo segments.
+    `n_gpus` counts DEVICES (one here); `ranks` says how many processes shared it."""
+    d = _run(["--gpus", str(ranks), "--steps", "6", "--warmup", "2", "--blocks", "65536"], env={"MRH_BENCH_SHARE_DEVICE": "1"}, timeout=900)
     assert all(k in d for k in KEYS)
-    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 1000
-    assert d["merge"]["merge_ms"] > 0 and len(d["merge"]["blocks_sent_per_rank"]) == 2 and d["tile_sharded"]["frames_per_s"] > 0
+    assert d["n_gpus"] == 1 and d["ranks"] == ranks and d["scaling"] == "weak" and d["value"] > 1000
+    m = d["merge"]
+    assert m["merge_ms"] > 0 and len(m["blocks_sent_per_rank"]) == ranks and all(v > 0 for v in m["blocks_sent_per_rank"])
+    assert all(v > 0 for v in m["owned_blocks_after_merge_per_rank"]) and all(v > 0 for v in m["halo_blocks_taken_per_rank"])
+    assert d["tile_sharded"]["frames_per_s"] > 0
     assert d["roofline"]["launches"] == 6 and d["cpu_baseline"] is None
+    assert d["phases"]["k_front_ms"] > 0 and d["phases"]["k_back_ms"] > 0
+
+
+def test_one_rank_rccl_line():
+    """bench.py --gpus N as the driver launches it (RANK / LOCAL_RANK / WORLD_SIZE in the environment), over RCCL behind the C
+    ABI — with the one rank this box's one GPU allows.  --gpus 1 with WORLD_SIZE=1 is the single-GPU line, so the multi-rank
+    function is entered directly."""
+    code = ("import os, sys; sys.argv = ['bench.py', '--gpus', '1', '--steps', '104', '--warmup', '2', '--blocks', '65536']; "
+            f"sys.path.insert(0, {ROOT!r}); import bench; a = bench.parse_args(); "
+            "sys.stdout.flush(); bench._RESULT_FD = os.dup(1); os.dup2(2, 1); bench.bench_multi(a)")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["ranks"] == 1 and d["value"] > 1000
+    ph = d["phases"]
+    assert ph["merge"]["pack_ms"] > 0 and ph["merge"]["unpack_ms"] > 0 and ph["halo"]["pack_ms"] > 0
+    assert ph["starve_allreduce_count"] == 2 and ph["starve_allreduce_ms_avg"] > 0  # frame 100 of 106 is a starve frame: two reductions
+    assert "backend rccl" in d["config"]["parallelism"]

@@ -127,13 +127,7 @@ def test_update_order_is_the_point_order(oracle):
     assert fold((p0, p1, p2))[1] != fold((p2, p1, p0))[1]  # the order is observable, so it has to be pinned
 
 
-def spherical_camera(rows=32, cols=512, el_deg=(-22.5, 22.5)):
-    """Spherical intrinsics that map a rows x cols LiDAR image onto [-pi, pi) x [el0, el1] (test_projections.cu:146-158):
-    col = fx * azimuth + cx, row = fy * elevation + cy."""
-    fx = cols / (2.0 * np.pi)
-    el0, el1 = np.deg2rad(el_deg[0]), np.deg2rad(el_deg[1])
-    fy = (rows - 1) / (el1 - el0)
-    return dict(fx=fx, fy=fy, cx=cols / 2.0, cy=-fy * el0, rows=rows, cols=cols)
+spherical_camera = synth.spherical_camera
 
 
 def _scan_engine(lib, params, cam=None, blocks=65536, max_depth=100.0):

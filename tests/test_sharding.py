@@ -174,14 +174,14 @@ def test_four_rank_gloo_mesh_equals_single_process(oracle, tmp_path):
     assert bool(got["refused"]) and int(got["n_dropped"]) == int(got["n_halo"]) and int(got["n_after"]) == int(got["n_own"])
 
 
-def check_merged_against_single(lib, tmp_path, got, world: int = 2):
+def check_merged_against_single(lib, tmp_path, got, world: int = 2, frames=None, min_same: float = None):
     """The merged tile-sharded map against ONE context that fused all frames.  Occupancy is the same (allocation depends on
     the depth frames only).  A voxel carries the same weight and — up to the order of the running mean, 1e-5 — the same
     TSDF value wherever every sub-map held the voxel's block while it fused; a sub-map that allocated the block late (or
     never) did not record its free-space observations of it, so there the merged weight is LOWER than the single-context
     one (never higher).  Colours are order-dependent by construction (50/50 blend) and not compared.
     The fold itself is exact: it equals the host restatement of combineVoxel over the two sub-maps, bit for bit."""
-    frames = merge_frames()
+    frames = merge_frames() if frames is None else frames
     single = pu.make_engine(lib, synth.CFG1, dict(synth.CFG1_PARAMS), 16384)
     for f in frames:
         pu.feed(single, f)
@@ -194,7 +194,9 @@ def check_merged_against_single(lib, tmp_path, got, world: int = 2):
     assert np.array_equal(d, d0), "occupancy of the merged map differs from the single-context map"
     assert np.all(v["weight"] <= v0["weight"])
     same = (v["weight"] == v0["weight"]) & (v0["weight"] > 0)
-    assert same.sum() > (0.8 if world == 2 else 0.5) * (v0["weight"] > 0).sum()
+    if min_same is None:
+        min_same = 0.8 if world == 2 else 0.5
+    assert same.sum() > min_same * (v0["weight"] > 0).sum(), same.sum() / (v0["weight"] > 0).sum()
     assert float(np.max(np.abs(v["sdf"][same] - v0["sdf"][same]))) <= 1e-5
     assert all(int(p["sent"]) > 0 and int(p["received"]) > 0 for p in parts)
     # the fold, restated on the host from the sub-maps in rank order
@@ -246,6 +248,25 @@ def test_three_rank_merge_of_uneven_submaps(oracle, tmp_path):
     """Three ranks, four frames (rank 0 fuses two): all-to-all with three different split lists, the fold in rank order."""
     got = run_two_ranks(tmp_path, use_hip=False, worker=MERGE_WORKER.replace("merge_frames()", "[synth.cfg1_sphere(zc=1.5 + 0.01 * k) for k in range(4)]"), nproc=3)
     check_merged_against_single(oracle, tmp_path, got, world=3)
+
+
+def test_eight_rank_gloo_mesh_equals_single_process(oracle, tmp_path):
+    """World size EIGHT — BASELINE.json configs[3]'s rank count: the 8-way owner function, eight halo segments of different
+    lengths, eight triangle runs interleaved back into the canonical order, the two starve reductions over eight buffers."""
+    got = run_two_ranks(tmp_path, use_hip=False, nproc=8)
+    t, V, F, C = reference_single(oracle)
+    assert int(got["n_halo"]) > 0 and int(got["n_own"]) > 0
+    assert np.array_equal(got["tris"], t.view(np.uint8)), "merged triangle buffer differs from the single-process one"
+    assert np.array_equal(got["F"], F) and np.array_equal(got["V"], V) and np.allclose(got["C"], C)
+    assert bool(got["refused"]) and int(got["n_dropped"]) == int(got["n_halo"]) and int(got["n_after"]) == int(got["n_own"])
+
+
+def test_eight_rank_merge_and_fold(oracle, tmp_path):
+    """Eight frame-sharded sub-maps (one frame each) -> merge_submaps: eight split lists per rank, the fold of up to eight
+    sub-maps per block in rank order equals the host restatement bit for bit; halo exchange + mesh gather on the result."""
+    frames_src = "[synth.cfg1_sphere(zc=1.5 + 0.005 * k) for k in range(8)]"
+    got = run_two_ranks(tmp_path, use_hip=False, worker=MERGE_WORKER.replace("merge_frames()", frames_src), nproc=8)
+    check_merged_against_single(oracle, tmp_path, got, world=8, frames=[synth.cfg1_sphere(zc=1.5 + 0.005 * k) for k in range(8)], min_same=0.3)
 
 
 def test_pack_unpack_drop_single_process(oracle):

@@ -87,55 +87,84 @@ def test_frame_sharded_submaps_merge_into_one_tile_sharded_map_hip(hip, tmp_path
     check_merged_against_single(hip, tmp_path, got)
 
 
-NCCL_WORKER = r"""
+RCCL_WORKER = r"""
 import os, sys
 sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
 import numpy as np
-import torch
 import parity_utils as pu
 from mrhash_amd import capi, parallel, synth
-os.environ["MRH_FORCE_COLLECTIVES"] = "1"
-dist = parallel.init_process_group("nccl")     # RCCL, one rank: every collective below runs through RCCL on device buffers
-assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
 hip = capi.load_hip()
+comm = parallel.rendezvous(hip)        # RCCL behind the C ABI: mrh_comm_unique_id -> file -> mrh_comm_create; one rank here
+assert (comm.rank, comm.world) == (0, 1)
+comm.barrier()
+assert float(comm.allreduce([3.5], capi.COMM_MAX)[0]) == 3.5 and comm.allgather_i64([7, 9]).tolist() == [[7, 9]]
 params = dict(synth.CFG1_PARAMS, n_frames_invalidate_voxels=2)
 frames = (synth.cfg1_sphere(), synth.cfg1_sphere(zc=1.51), synth.cfg1_sphere(zc=1.5), synth.cfg1_sphere(zc=1.49))
-# (1) a tile-sharded context that owns one of two shards: starve frames stop for the MIN all-reduce of the device z-buffer
-a = pu.make_engine(hip, synth.CFG1, params, 16384, shard_rank=0, shard_count=2, shard_chunk_log2=1)
-b = pu.make_engine(hip, synth.CFG1, params, 16384, shard_rank=0, shard_count=2, shard_chunk_log2=1)
+# (1) a tile-sharded context with the communicator attached: starve frames run ncclAllReduce(int64, MIN) on the library's
+#     z-buffer inside mrh_integrate (never MRH_PENDING_EXCHANGE); reference: the same frames with the host protocol and the
+#     exchange skipped (one rank: MIN over one buffer is the buffer)
+a = pu.make_engine(hip, synth.CFG1, params, 16384, shard_rank=0, shard_count=1)
+a.attach_comm(comm)
+a.set_sharding(0, 1, 1)
+b = pu.make_engine(hip, synth.CFG1, params, 16384, shard_rank=0, shard_count=1)
+# force the sharded code path on one rank: shard_count 1 owns everything, so run a second pair that owns one of two shards
+a2 = pu.make_engine(hip, synth.CFG1, params, 16384, shard_rank=0, shard_count=2, shard_chunk_log2=1)
+a2.attach_comm(comm)                   # world 1 != shard_count 2: allowed for the all-reduce (a reduction over the ranks present)
+b2 = pu.make_engine(hip, synth.CFG1, params, 16384, shard_rank=0, shard_count=2, shard_chunk_log2=1)
 for f in frames:
-    pu.feed(a, f, dist=dist)            # parallel.integrate: dist.all_reduce(MIN) over RCCL on the library's buffer
-    b.set_pose(f.R, f.t); b.upload_depth(f.depth); b.upload_rgb(f.rgb)
-    pending = b.integrate()
-    while pending:                      # the same frame with the exchange skipped (one shard: MIN over one buffer is the buffer)
-        pending = b.integrate_resume()
+    pu.feed(a, f); pu.feed(b, f)
+    pu.feed(a2, f)                      # integrate() must not report a pending exchange
+    b2.set_pose(f.R, f.t); b2.upload_depth(f.depth); b2.upload_rgb(f.rgb)
+    pending = b2.integrate()
+    while pending:
+        pending = b2.integrate_resume()
 pu.compare_maps(a, b)
-# (2) merge_submaps through all_to_all_single on device tensors: a one-rank fold reproduces the map
+pu.compare_maps(a2, b2)
+ph = a2.comm_phase_times()
+assert ph["allreduce_count"] == 4 and ph["allreduce_ms_sum"] > 0, ph   # two starve frames x two reductions
+# (2) mrh_comm_merge_submaps: a one-rank fold reproduces the map
 c = pu.make_engine(hip, synth.CFG1, dict(synth.CFG1_PARAMS), 16384)
+c.attach_comm(comm)
 for f in frames:
     pu.feed(c, f)
 d0, v0 = c.dump_blocks()
-info = parallel.merge_submaps(c, dist, chunk_log2=1)
+info = parallel.merge_submaps(c, comm, chunk_log2=1)
 d1, v1 = c.dump_blocks()
 assert len(d0) > 50 and np.array_equal(d0, d1) and np.array_equal(v0.view(np.uint8), v1.view(np.uint8))
-# (3) exchange_halo through all_gather_into_tensor on device tensors (no other rank: nothing is taken)
-assert parallel.exchange_halo(c, dist) == 0
-res = parallel.gather_mesh(c, dist)
+assert info["kept"] == len(d0) and info["sent"] == 0
+# (3) mrh_comm_exchange_halo (no other rank: nothing is taken) and mrh_comm_gather_mesh (device soup -> run merge -> mesh)
+assert parallel.exchange_halo(c, comm) == 0
+res = parallel.gather_mesh(c, comm)
 ref = pu.make_engine(hip, synth.CFG1, dict(synth.CFG1_PARAMS), 16384)
 for f in frames:
     pu.feed(ref, f)
 t = ref.extract_triangles()
-assert np.array_equal(res[0].view(np.uint8), t.view(np.uint8))
-open({out!r}, "w").write("ok")
-dist.destroy_process_group()
+Vr, Fr, Cr = ref.extract_mesh()
+assert len(t) > 1000 and np.array_equal(res[0].view(np.uint8), t.view(np.uint8))
+assert np.array_equal(res[1], Vr) and np.array_equal(res[2], Fr) and np.array_equal(res[3], Cr)
+ph = c.comm_phase_times()
+assert ph["pack_ms"] > 0 and ph["unpack_ms"] > 0, ph
+# (4) one HIP runtime, one RCCL, no torch in a product-path process
+assert "torch" not in sys.modules
+maps = open("/proc/self/maps").read()
+hips = sorted({{ln.split()[-1] for ln in maps.splitlines() if "libamdhip64" in ln}})
+rccls = sorted({{ln.split()[-1] for ln in maps.splitlines() if "librccl" in ln}})
+hsas = sorted({{ln.split()[-1] for ln in maps.splitlines() if "libhsa-runtime64" in ln}})
+assert len(hips) == 1 and len(rccls) == 1 and len(hsas) == 1, (hips, rccls, hsas)
+assert os.path.dirname(os.path.realpath(hips[0])) == os.path.dirname(os.path.realpath(rccls[0])), (hips, rccls)
+for e in (a, a2, c):
+    e.attach_comm(None)
+comm.close()
+open({out!r}, "w").write("ok " + hips[0] + " " + rccls[0])
 """
 
 
-def test_rccl_branches_run_in_a_one_rank_group(hip, tmp_path):
-    """The nccl branches of mrhash_amd.parallel (library device buffers -> RCCL collective -> library) cannot run with two
-    ranks on this one-GPU box (RCCL: "Duplicate GPU detected", profiles/r02/two_ranks_one_device_nccl_outcome.txt), so
-    they run here in a ONE-rank RCCL group with MRH_FORCE_COLLECTIVES=1: all_reduce(MIN) on the starve z-buffer,
-    all_to_all_single + device merge, all_gather_into_tensor of halo records."""
+def test_rccl_entry_points_of_the_c_abi_in_a_one_rank_group(hip, tmp_path):
+    """include/mrhash_comm.h on the GPU: communicator from the file rendezvous, the starve all-reduce inside mrh_integrate,
+    mrh_comm_merge_submaps, mrh_comm_exchange_halo, mrh_comm_gather_mesh — RCCL on the library's own stream and buffers.
+    Two RCCL ranks cannot share this box's one GPU ("Duplicate GPU detected", profiles/r02/two_ranks_one_device_nccl_outcome.txt),
+    so the group has ONE rank; the worker is a process without torch and checks that it holds exactly one libamdhip64, one
+    libhsa-runtime64 and one librccl, from the same directory."""
     import os
     import subprocess
     import sys
@@ -143,17 +172,18 @@ def test_rccl_branches_run_in_a_one_rank_group(hip, tmp_path):
     from test_sharding import ROOT
 
     out = str(tmp_path / "ok.txt")
-    script = tmp_path / "nccl_worker.py"
-    script.write_text(NCCL_WORKER.format(root=ROOT, out=out))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    script = tmp_path / "rccl_worker.py"
+    script.write_text(RCCL_WORKER.format(root=ROOT, out=out))
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MRH_RDZV_DIR=str(tmp_path))
     r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and os.path.exists(out), r.stdout[-2000:] + r.stderr[-4000:]
+    assert "/opt/rocm" in os.path.realpath(open(out).read().split()[1])
 
 
 def test_exchange_primitives_match_the_oracle(hip, oracle):
     """mrh_pack_blocks / mrh_unpack_blocks / mrh_drop_blocks on the device against the oracle's host versions: the same
     record sets (order aside), the same merged map."""
-    import torch
+    from mrhash_amd import hipmem
 
     a = pu.make_engine(hip, synth.CFG1, dict(synth.CFG1_PARAMS), 16384)
     b = pu.make_engine(oracle, synth.CFG1, dict(synth.CFG1_PARAMS), 16384)
@@ -170,7 +200,7 @@ def test_exchange_primitives_match_the_oracle(hip, oracle):
         if n == 0:
             return np.zeros(0, capi.RECORD_DTYPE)
         if on_dev:
-            raw = parallel._bytes_view(ptr, n * capi.RECORD_BYTES, True).cpu().numpy()
+            raw = np.frombuffer(hipmem.read(ptr, n * capi.RECORD_BYTES), dtype=np.uint8).copy()
         else:
             raw = np.frombuffer((ctypes.c_char * (n * capi.RECORD_BYTES)).from_address(ptr), dtype=np.uint8).copy()
         r = raw.view(capi.RECORD_DTYPE)
@@ -186,8 +216,8 @@ def test_exchange_primitives_match_the_oracle(hip, oracle):
     pu.feed(c, synth.cfg1_sphere(zc=1.51))
     c.set_sharding(0, 1, 0)
     rc_ = records(c, capi.PACK_OWNER, 0)
-    dev = torch.from_numpy(rc_.view(np.uint8).copy()).cuda()
-    assert a.unpack_blocks(capi.UNPACK_MERGE, dev.data_ptr(), len(rc_), True) == len(rc_)
+    dev = hipmem.DeviceBuffer.from_numpy(rc_.view(np.uint8))
+    assert a.unpack_blocks(capi.UNPACK_MERGE, dev.ptr, len(rc_), True) == len(rc_)
     assert b.unpack_blocks(capi.UNPACK_MERGE, rc_.ctypes.data, len(rc_), False) == len(rc_)
     pu.compare_maps(a, b)
     # halo import keeps exactly the adjacent foreign blocks; drop removes them again
@@ -195,7 +225,7 @@ def test_exchange_primitives_match_the_oracle(hip, oracle):
         e.drop_blocks(capi.DROP_FOREIGN)
     na, nb_ = len(a.dump_blocks()[0]), len(b.dump_blocks()[0])
     assert na == nb_ > 0
-    ta = a.unpack_blocks(capi.UNPACK_HALO, dev.data_ptr(), len(rc_), True)
+    ta = a.unpack_blocks(capi.UNPACK_HALO, dev.ptr, len(rc_), True)
     tb = b.unpack_blocks(capi.UNPACK_HALO, rc_.ctypes.data, len(rc_), False)
     assert ta == tb > 0
     pu.compare_maps(a, b)
