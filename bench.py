@@ -92,6 +92,7 @@ def parse_args():
     ap.add_argument("--no-extras", action="store_true", help="N=1: only the headline pass and its roofline (no mc / hbm / pcie legs)")
     ap.add_argument("--pmc-inner", action="store_true", help=argparse.SUPPRESS)  # the workload alone, under rocprofv3
     ap.add_argument("--pmc-inner-big", action="store_true", help=argparse.SUPPRESS)  # the roofline_hbm workload alone
+    ap.add_argument("--pmc-inner-mc", action="store_true", help=argparse.SUPPRESS)  # the multi-resolution map + two extractions
     ap.add_argument("--frames-cache", default="", help=argparse.SUPPRESS)
     return ap.parse_args()
 
@@ -186,7 +187,7 @@ def profiled_roofline(eng, res: Resident, W: int, total: int, label: str):
             "profiled_pass_ms_per_step": prof_elapsed / max(total - W, 1) * 1e3}
 
 
-def pmc_traffic(args, kernel_prefix: str, cache: str, inner: str = "--pmc-inner", steps: int = 0, warmup: int = 0):
+def pmc_traffic(args, kernel_prefix: str, cache: str, inner: str = "--pmc-inner", steps: int = 0, warmup: int = 0, per_run_of: int = 0):
     """HBM bytes per launch of `kernel_prefix` from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE: separate runs,
     no trace flags beside --pmc) of this workload run as a sub-process.  Units are KiB; on gfx950 FETCH_SIZE counts a
     wide coalesced read at half its bytes, so it is doubled (MI355X_MICROARCH.md, HBM section)."""
@@ -214,7 +215,11 @@ def pmc_traffic(args, kernel_prefix: str, cache: str, inner: str = "--pmc-inner"
                     rows.append((int(row.get("Dispatch_Id", len(rows))), float(row["Counter_Value"])))
         shutil.rmtree(d, ignore_errors=True)
         rows.sort()
-        rows = rows[warmup:] if len(rows) > warmup else rows  # the timed frames only (the map still grows during the warm-up)
+        if per_run_of:  # every dispatch of the prefix counts; the figure is per run (e.g. the count + emit launches of ONE extraction)
+            tot, n = sum(v for _, v in rows) / per_run_of, len(rows)
+            rows = [(0, tot)] if n else []
+        else:
+            rows = rows[warmup:] if len(rows) > warmup else rows  # the timed frames only (the map still grows during the warm-up)
         tot, n = sum(v for _, v in rows), len(rows)
         if n == 0:
             return None, f"rocprofv3 --pmc {counter}: no dispatch of {kernel_prefix} recorded (rc {r.returncode}: {r.stderr[-200:]})"
@@ -245,6 +250,16 @@ def bench_single(args):
         return
     frames = render_stream("replica", total, cache=cache)
     res = Resident(frames, Kc)
+
+    if args.pmc_inner_mc:  # configs[2]: the multi-resolution map, then two extractions (under rocprofv3 --pmc)
+        mp = capi.Params(num_sdf_blocks=args.blocks, device_id=0, **dict(synth.REPLICA_PARAMS, sdf_var_threshold=0.005))
+        me = make_engine(hip, mp, Kc)
+        res.run(me, 0, total)
+        me.sync()
+        me.extract_triangles(soup=False)
+        me.extract_triangles(soup=False)
+        me.close()
+        return
 
     if args.pmc_inner:  # the timed workload alone (under rocprofv3 --pmc)
         eng = make_engine(hip, params, Kc)
@@ -300,7 +315,10 @@ def bench_single(args):
         t4 = time.perf_counter()
         ntri = me.extract_triangles(soup=False)
         extract_ms = (time.perf_counter() - t4) * 1e3
+        me.set_profile(True)  # kernel times come from a third extraction: launches that carry events slow the queue down
+        me.extract_triangles(soup=False)
         ms = me.stats()
+        me.set_profile(False)
         mc_ms = float(ms.last_mc_count_ms + ms.last_mc_emit_ms)
         alg_mc = 6144.0 * int(ms.occupied_fine) + 768.0 * int(ms.occupied_coarse) + 72.0 * ntri
         ach = alg_mc / (mc_ms * 1e-3) / 1e9 if mc_ms > 0 else 0.0
@@ -475,6 +493,9 @@ def bench_single(args):
         del rb
         if not args.no_pmc:
             roof_hbm["traffic"], roof_hbm["traffic_note"] = pmc_traffic(args, "mrh::k_back<true, false", big_cache, "--pmc-inner-big", nb - wb, wb)
+
+    if mc is not None and not args.no_pmc:  # HBM bytes of the two k_mc launches of one extraction (two extractions in the sub-process)
+        mc["roofline"]["traffic"], mc["roofline"]["traffic_note"] = pmc_traffic(args, "mrh::k_mc<", cache, "--pmc-inner-mc", per_run_of=2)
 
     # ---- HBM traffic of the headline kernel, measured now (sub-processes under rocprofv3)
     if not args.no_pmc:
@@ -733,7 +754,7 @@ def main():
             procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
         rcs = [p.wait() for p in procs]
         raise SystemExit(max(abs(rc) for rc in rcs))
-    if not args.pmc_inner and not args.pmc_inner_big:
+    if not args.pmc_inner and not args.pmc_inner_big and not args.pmc_inner_mc:
         global _RESULT_FD
         sys.stdout.flush()
         _RESULT_FD = os.dup(1)

@@ -294,6 +294,16 @@ int mrh_extract_triangles(mrh_ctx* ctx, const mrh_triangle** out_triangles, uint
 int mrh_extract_mesh(mrh_ctx* ctx, const double** out_vertices, uint64_t* out_nv,
                      const int32_t** out_faces, uint64_t* out_nf, const double** out_colors);
 
+/* Replaces MeshExtractor::merge_mesh_ = true + the running vertices_ / faces_ / colors_ of the chunk loop in
+ * GeoWrapper::extractMesh (geowrapper.cpp:157-188; mesh_extractor.cpp:27-40 `combine`): between begin and end every
+ * mrh_extract_triangles ADDS its triangles to the running mesh (processTriangles on running mesh + new soup) instead of
+ * replacing it; an extraction without triangles leaves it alone (geowrapper.cpp:181).  After mrh_mesh_merge_end the merged
+ * mesh is read with mrh_extract_mesh; *out_total_triangles = triangles of all extractions in between (repeats included).
+ * begin also empties colors_ (the reference only empties vertices_ and faces_, geowrapper.cpp:157-158: a second extractMesh
+ * call would pair stale colours with new vertices — canonical choice D10: start from an empty mesh). */
+int mrh_mesh_merge_begin(mrh_ctx* ctx);
+int mrh_mesh_merge_end(mrh_ctx* ctx, uint64_t* out_total_triangles);
+
 /* ---- introspection --------------------------------------------------------------------- */
 
 /* Replaces the scalar read-backs getHeapHighFreeCount / getHeapLowFreeCount /

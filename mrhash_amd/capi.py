@@ -116,7 +116,7 @@ ABI_SYMBOLS = (
     "mrh_upload_points mrh_upload_normals mrh_set_points_device mrh_integrate_points mrh_stream_out mrh_get_free_blocks "
     "mrh_splat_seeds mrh_get_qtree_leaves mrh_peek_free_blocks mrh_peek_error_flags "
     "mrh_set_sharding mrh_pack_blocks mrh_unpack_blocks mrh_drop_blocks "
-    "mrh_extract_triangles mrh_extract_mesh mrh_get_stats mrh_set_profile mrh_dump_blocks "
+    "mrh_extract_triangles mrh_extract_mesh mrh_mesh_merge_begin mrh_mesh_merge_end mrh_get_stats mrh_set_profile mrh_dump_blocks "
     "mrh_get_voxel mrh_import_blocks mrh_get_triangle_blocks mrh_get_triangles_device mrh_process_triangle_runs mrh_process_triangles mrh_selftest_division mrh_version"
 ).split()
 
@@ -178,6 +178,8 @@ def _declare(lib: C.CDLL) -> C.CDLL:
     lib.mrh_sync.argtypes = [C.c_void_p]
     lib.mrh_extract_triangles.argtypes = [C.c_void_p, P(C.c_void_p), P(C.c_uint64)]
     lib.mrh_extract_mesh.argtypes = [C.c_void_p, P(C.c_void_p), P(C.c_uint64), P(C.c_void_p), P(C.c_uint64), P(C.c_void_p)]
+    lib.mrh_mesh_merge_begin.argtypes = [C.c_void_p]
+    lib.mrh_mesh_merge_end.argtypes = [C.c_void_p, P(C.c_uint64)]
     lib.mrh_get_stats.argtypes = [C.c_void_p, P(MrhStats)]
     lib.mrh_set_profile.argtypes = [C.c_void_p, C.c_int]
     lib.mrh_dump_blocks.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, P(C.c_uint64)]
@@ -481,6 +483,15 @@ class Engine:
             return np.frombuffer((C.c_char * sz).from_address(p.value), dtype=dt).reshape(n, 3).copy()
 
         return arr(pv, nv.value, np.float64), arr(pf, nf.value, np.int32), arr(pc, nv.value, np.float64)
+
+    def mesh_merge_begin(self):
+        """MeshExtractor::merge_mesh_: until mesh_merge_end() every extract_triangles() adds to the running mesh."""
+        self._check(self.lib.mrh_mesh_merge_begin(self._ctx))
+
+    def mesh_merge_end(self) -> int:
+        n = C.c_uint64()
+        self._check(self.lib.mrh_mesh_merge_end(self._ctx, C.byref(n)))
+        return int(n.value)
 
     def free_blocks(self) -> Tuple[int, int]:
         a, b = C.c_int64(), C.c_int64()

@@ -10,6 +10,7 @@
 #include <fstream>
 #include <iostream>
 #include <charconv>
+#include <climits>
 #include <chrono>
 #include <memory>
 #include <stdexcept>
@@ -69,6 +70,7 @@ GeoWrapper::GeoWrapper(float sdf_truncation, float sdf_truncation_scale, int int
   // MRHASH_NUM_SDF_BLOCKS / MRHASH_DEVICE override
   if (const char* e = std::getenv("MRHASH_NUM_SDF_BLOCKS")) p.num_sdf_blocks = std::strtoull(e, nullptr, 10);
   if (const char* e = std::getenv("MRHASH_DEVICE")) p.device_id = std::atoi(e);
+  device_id_ = p.device_id;
   if (const char* e = std::getenv("MRHASH_STREAM")) streaming_enabled_ = std::atoi(e) != 0;
   p.shard_count = 1;
   int rc = mrh_create(&p, &ctx_);
@@ -82,7 +84,34 @@ GeoWrapper::GeoWrapper(float sdf_truncation, float sdf_truncation_scale, int int
   camera_in_lidar_ = pose_;
 }
 
-GeoWrapper::~GeoWrapper() { mrh_destroy(ctx_); }
+GeoWrapper::~GeoWrapper() {
+  mrh_destroy(ctx_);  // detaches from the communicator
+  mrh_comm_destroy(comm_);
+}
+
+// ---- multi-GPU: RCCL behind the C ABI (include/mrhash_comm.h) ------------------------------------------------------------
+std::array<uint8_t, MRH_COMM_ID_BYTES> GeoWrapper::commUniqueId() {
+  std::array<uint8_t, MRH_COMM_ID_BYTES> id;
+  if (mrh_comm_unique_id(id.data()) != MRH_OK) throw std::runtime_error(std::string("GeoWrapper::commUniqueId | ") + mrh_comm_last_error(nullptr));
+  return id;
+}
+
+void GeoWrapper::commInit(const std::array<uint8_t, MRH_COMM_ID_BYTES>& id, int rank, int world, int chunk_log2, bool tile_sharded) {
+  if (comm_) throw std::runtime_error("GeoWrapper::commInit | a communicator is already attached");
+  if (mrh_comm_create(id.data(), rank, world, device_id_, &comm_) != MRH_OK)
+    throw std::runtime_error(std::string("GeoWrapper::commInit | ") + mrh_comm_last_error(nullptr));
+  check(mrh_comm_attach(ctx_, comm_), "commInit");
+  comm_rank_ = rank; comm_world_ = world; comm_chunk_log2_ = chunk_log2; tile_sharded_ = tile_sharded;
+  if (tile_sharded) check(mrh_set_sharding(ctx_, rank, world, chunk_log2), "commInit");
+  streaming_enabled_ = false;  // a sharded map is sized per rank; the host chunk grid and the exchange steps do not mix
+}
+
+void GeoWrapper::mergeSubmaps() {
+  if (!comm_) throw std::runtime_error("GeoWrapper::mergeSubmaps | commInit has not been called");
+  mrh_comm_merge_info info;
+  check(mrh_comm_merge_submaps(ctx_, comm_chunk_log2_, &info), "mergeSubmaps");
+  tile_sharded_ = true;
+}
 
 void GeoWrapper::setCurrPose(const std::array<float, 3>& t, const std::array<float, 4>& q) {
   // Eigen::Quaternionf(qw,qx,qy,qz).toRotationMatrix() (Eigen 3.4.0 Quaternion.h), float arithmetic, no normalisation
@@ -254,6 +283,43 @@ void GeoWrapper::compute() {
   }
 }
 
+// Streamer::isChunkInSphere (streamer.cuh:345-352), literally: the chunk CENTRE within |radius - chunk radius| of the sphere
+// centre.  Used by the chunk loop of extractMesh only (stream() pages with its own, transparent radii).
+bool GeoWrapper::chunkInSphereRef(const std::array<int, 3>& chunk, const std::array<float, 3>& center, float radius) const {
+  const float ext = (float) voxel_extents_scale_;
+  const float dx = chunk[0] * ext - center[0], dy = chunk[1] * ext - center[1], dz = chunk[2] * ext - center[2];
+  return std::sqrt(dx * dx + dy * dy + dz * dz) <= std::fabs(radius - chunkRadius());
+}
+
+// Streamer::streamInToGPU(center, radius) as the chunk loop uses it (streamer.cpp:292-331, :358-378): every chunk of the host
+// grid that lies in the sphere goes to the device and leaves the grid.  Refuses BEFORE touching anything when the sphere holds
+// more blocks than the pool has free (the reference would run its heap into the ground, silently).
+uint64_t GeoWrapper::streamInSphereRef(const std::array<float, 3>& center, float radius) {
+  std::vector<std::array<int, 3>> taken;
+  uint64_t n = 0;
+  for (const auto& kv : grid_)
+    if (chunkInSphereRef(kv.first, center, radius)) { taken.push_back(kv.first); n += kv.second.size(); }
+  if (n == 0) return 0;
+  int64_t free_fine = 0;
+  check(mrh_get_free_blocks(ctx_, &free_fine, nullptr), "extractMesh");
+  if ((int64_t) n > free_fine)
+    throw std::runtime_error("GeoWrapper::extractMesh | a sphere of radius " + std::to_string(radius) + " m holds " + std::to_string(n) +
+                             " blocks, the pool has " + std::to_string(free_fine) + " free (num_sdf_blocks " + std::to_string(num_sdf_blocks_) +
+                             "): nothing was moved, the map is intact on the host grid");
+  std::vector<mrh_block_desc> descs;
+  std::vector<mrh_voxel> vox;
+  descs.reserve(n);
+  vox.reserve(n * 512);
+  for (const auto& k : taken)
+    for (const HostBlock& b : grid_[k]) {
+      descs.push_back(b.desc);
+      vox.insert(vox.end(), b.voxels.begin(), b.voxels.end());
+    }
+  check(mrh_import_blocks(ctx_, descs.data(), vox.data(), descs.size()), "extractMesh");
+  for (const auto& k : taken) grid_.erase(k);
+  return n;
+}
+
 void GeoWrapper::extractMesh(const std::string& filename) {
   const bool dbg = std::getenv("MRH_DEBUG") != nullptr;
   auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -262,11 +328,96 @@ void GeoWrapper::extractMesh(const std::string& filename) {
   mesh_v_ = mesh_c_ = nullptr; mesh_f_ = nullptr; mesh_nv_ = mesh_nf_ = 0;
   V_.clear(); F_.clear(); C_.clear();
   mesh_cached_ = true;
-  streamInFromGrid(nullptr, 0.f);  // blocks the streamer paged out take part in the mesh (geowrapper.cpp:162-188 walks the grid)
+
+  if (comm_ && comm_world_ > 1) {
+    // sharded map: boundary blocks to every rank, every rank extracts what it owns, rank 0 merges the runs into the single-GPU
+    // canonical order and post-processes; the halo goes again so that fusion can continue
+    if (!tile_sharded_) throw std::runtime_error("GeoWrapper::extractMesh | frame-sharded sub-maps: call mergeSubmaps() first");
+    if (!grid_.empty()) throw std::runtime_error("GeoWrapper::extractMesh | a sharded map cannot have blocks on the host grid");
+    std::cout << "GeoWrapper::extractMesh | extracting (rank " << comm_rank_ << " of " << comm_world_ << ")..." << std::endl;
+    uint64_t taken = 0, nt_all = 0;
+    check(mrh_comm_exchange_halo(ctx_, &taken), "extractMesh");
+    check(mrh_comm_gather_mesh(ctx_, 0, &nt_all), "extractMesh");
+    check(mrh_drop_blocks(ctx_, MRH_DROP_HALO, nullptr), "extractMesh");
+    if (comm_rank_ != 0) return;  // the mesh lives on rank 0
+    std::cout << "MarchingCubesExtractor::extractIsoSurface | triangles extracted: " << nt_all << std::endl;
+    writeMesh(filename, t0);
+    return;
+  }
+
+  // ---- geowrapper.cpp:150-190.  The reference pages EVERYTHING out, then walks the chunk grid in steps of int(10 * max depth)
+  // chunks: stream in the sphere of radius 10 * max depth around the step's chunk, marching cubes, merge into the running
+  // mesh, page everything out again.  Whenever that loop has a single iteration whose sphere holds the whole map, and the map
+  // fits the pool, its triangles are those of ONE extraction over the resident map — taken here without paging 6 KiB per block
+  // out and in again (the only difference: the map stays on the device afterwards; the reference leaves it on the host).
+  const float radius = 10.0f * max_depth_;  // params.h:35 radius_scale_chunk
+  const int radiusi = std::max(1, (int) radius);  // (int) radius == 0 would never advance the reference's loops
+  uint64_t n_dev = 0;
+  check(mrh_dump_blocks(ctx_, nullptr, nullptr, 0, &n_dev), "extractMesh");
+  std::vector<mrh_block_desc> dev_descs(n_dev ? n_dev : 1);
+  if (n_dev) check(mrh_dump_blocks(ctx_, dev_descs.data(), nullptr, n_dev, &n_dev), "extractMesh");
+  const float bs = 8.f * virtual_voxel_size_;
+  std::array<int, 3> lo = {INT32_MAX, INT32_MAX, INT32_MAX}, hi = {INT32_MIN, INT32_MIN, INT32_MIN};
+  auto widen = [&](const std::array<int, 3>& c) { for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], c[a]); hi[a] = std::max(hi[a], c[a]); } };
+  std::vector<std::array<int, 3>> dev_chunks(n_dev);
+  for (uint64_t k = 0; k < n_dev; k++) {
+    dev_chunks[k] = worldToChunks({(float) dev_descs[k].x * bs, (float) dev_descs[k].y * bs, (float) dev_descs[k].z * bs});
+    widen(dev_chunks[k]);
+  }
+  for (const auto& kv : grid_) widen(kv.first);  // Streamer::computeBounds over what WOULD be on the host after streamAllOut
   uint64_t nt = 0;
   std::cout << "GeoWrapper::extractMesh | extracting..." << std::endl;
-  check(mrh_extract_triangles(ctx_, nullptr, &nt), "extractMesh");  // the soup itself stays on the device
+  if (n_dev + grid_.size() == 0) {
+    check(mrh_extract_triangles(ctx_, nullptr, &nt), "extractMesh");
+  } else {
+    for (int a = 0; a < 3; a++) if (lo[a] == hi[a]) hi[a] += 1;  // geowrapper.cpp:165-173
+    const std::array<float, 3> first_center = {(float) lo[0] * (float) voxel_extents_scale_, (float) lo[1] * (float) voxel_extents_scale_,
+                                               (float) lo[2] * (float) voxel_extents_scale_};
+    bool one_pass = true;
+    for (int a = 0; a < 3; a++) one_pass = one_pass && (lo[a] + radiusi >= hi[a]);
+    for (uint64_t k = 0; k < n_dev && one_pass; k++) one_pass = chunkInSphereRef(dev_chunks[k], first_center, radius);
+    for (const auto& kv : grid_) { if (!one_pass) break; one_pass = chunkInSphereRef(kv.first, first_center, radius); }
+    if (one_pass && !grid_.empty()) {
+      int64_t free_fine = 0;
+      check(mrh_get_free_blocks(ctx_, &free_fine, nullptr), "extractMesh");
+      one_pass = (int64_t) hostGridBlocks() <= free_fine;
+    }
+    if (one_pass) {
+      streamInFromGrid(nullptr, 0.f);  // whatever the streamer paged out takes part in the mesh
+      check(mrh_extract_triangles(ctx_, nullptr, &nt), "extractMesh");  // the soup itself stays on the device
+    } else {
+      const std::array<float, 3> origin = {0.f, 0.f, 0.f};
+      streamOutToGrid(origin, -1.f);  // Streamer::streamAllOut (geowrapper.cpp:153)
+      check(mrh_mesh_merge_begin(ctx_), "extractMesh");
+      try {
+        for (int x = lo[0]; x < hi[0]; x += radiusi)
+          for (int y = lo[1]; y < hi[1]; y += radiusi)
+            for (int z = lo[2]; z < hi[2]; z += radiusi) {
+              const float e = (float) voxel_extents_scale_;
+              const std::array<float, 3> center = {(float) x * e, (float) y * e, (float) z * e};  // Streamer::chunkToWorld
+              if (streamInSphereRef(center, radius) == 0) continue;  // an empty map: no triangles, nothing to merge (:181)
+              uint64_t n_it = 0;
+              check(mrh_extract_triangles(ctx_, nullptr, &n_it), "extractMesh");
+              streamOutToGrid(origin, -1.f);  // streamAllOut (:186)
+            }
+      } catch (...) {
+        uint64_t dummy = 0;
+        (void) mrh_mesh_merge_end(ctx_, &dummy);
+        const std::array<float, 3> o = {0.f, 0.f, 0.f};
+        try { streamOutToGrid(o, -1.f); } catch (...) {}  // every block in exactly one place: the host grid
+        throw;
+      }
+      check(mrh_mesh_merge_end(ctx_, &nt), "extractMesh");
+    }
+  }
   std::cout << "MarchingCubesExtractor::extractIsoSurface | triangles extracted: " << nt << std::endl;
+  writeMesh(filename, t0);
+}
+
+// the mesh of the last extraction out of the library, and the ASCII PLY of geowrapper.cpp:194-227
+void GeoWrapper::writeMesh(const std::string& filename, const double t0) {
+  const bool dbg = std::getenv("MRH_DEBUG") != nullptr;
+  auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const double *v = nullptr, *c = nullptr;
   const int32_t* f = nullptr;
   uint64_t nv = 0, nf = 0;

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "mrhash_hip.h"
+#include "mrhash_comm.h"
 
 namespace pygeowrapper {
 
@@ -86,6 +87,20 @@ public:
   void GSFinalOpt();
   const std::vector<mrh_splat_seed>& splatSeeds() const { return seeds_; }  // accumulated over compute() calls
 
+  // ---- multi-GPU (include/mrhash_comm.h; no reference counterpart): one GeoWrapper per process / GPU.
+  // commUniqueId() on one rank, the 128 bytes handed to the others by the launcher, then commInit on every rank.
+  //   tile_sharded = true : the result-identical mode — every rank is given every frame, compute() fuses the tiles this rank
+  //                         owns (starve frames reduce over the ranks inside the library), extractMesh() exchanges the boundary
+  //                         blocks, gathers the per-rank extractions on rank 0 and writes the file there (other ranks: no file,
+  //                         empty V / F / C).
+  //   tile_sharded = false: frame sharding — every rank fuses its own frames into its own sub-map; mergeSubmaps() folds them
+  //                         into one tile-sharded map, after which extractMesh() works as above.
+  static std::array<uint8_t, MRH_COMM_ID_BYTES> commUniqueId();
+  void commInit(const std::array<uint8_t, MRH_COMM_ID_BYTES>& id, int rank, int world, int chunk_log2 = 3, bool tile_sharded = true);
+  void mergeSubmaps();
+  int commRank() const { return comm_rank_; }
+  int commWorld() const { return comm_world_; }
+
   mrh_ctx* ctx() { return ctx_; }
 
 private:
@@ -100,6 +115,9 @@ private:
   bool chunkTouchesSphere(const std::array<int, 3>& chunk, const std::array<float, 3>& center, float radius) const;
   void streamOutToGrid(const std::array<float, 3>& center, float radius);
   void streamInFromGrid(const std::array<float, 3>* center, float radius);  // center == nullptr: everything
+  // the chunk loop of extractMesh (geowrapper.cpp:162-188): the reference's own sphere test and stream-in
+  bool chunkInSphereRef(const std::array<int, 3>& chunk, const std::array<float, 3>& center, float radius) const;
+  uint64_t streamInSphereRef(const std::array<float, 3>& center, float radius);
   std::map<std::array<int, 3>, std::vector<HostBlock>> grid_;
   bool streaming_enabled_ = true;  // MRHASH_STREAM=0 turns the per-frame test off
   float max_depth_ = 0.f;
@@ -122,6 +140,7 @@ private:
   size_t depth_rows_ = 0, depth_cols_ = 0, rgb_rows_ = 0, rgb_cols_ = 0;
   std::vector<float> point_cloud_, normals_;
   void cacheMesh() const;
+  void writeMesh(const std::string& filename, double t0);
   mutable std::vector<double> V_, C_;
   mutable std::vector<int32_t> F_;
   mutable bool mesh_cached_ = true;
@@ -134,6 +153,10 @@ private:
   int qtree_min_pixel_size_ = 1;
   std::vector<mrh_splat_seed> seeds_;
   mrh_ctx* ctx_ = nullptr;
+  mrh_comm* comm_ = nullptr;
+  int comm_rank_ = 0, comm_world_ = 1, comm_chunk_log2_ = 3;
+  bool tile_sharded_ = false;
+  int device_id_ = 0;
 };
 
 }  // namespace pygeowrapper

@@ -193,6 +193,11 @@ struct mrh_ctx {
   HostVec<mrh_triangle> tris;   // host copy of the soup: only when the caller of mrh_extract_triangles asks for it
   std::vector<mrh_block_desc> tri_blocks;
   std::vector<uint32_t> tri_counts;
+  // ... of the last extraction, still on the device (arena slot 0) until mrh_get_triangle_blocks asks
+  int tri_dev_n = 0;
+  const int4* d_tri_sorted = nullptr;
+  const u32* d_tri_counts = nullptr;
+  u64* h_mc = nullptr;  // pinned: triangle total of the extraction in flight
   HostVec<double> V, C;
   HostVec<int32_t> F;
   // profiling
@@ -223,6 +228,9 @@ struct mrh_ctx {
   hipEvent_t mc_ev[4] = {};
   float last_mc_count_ms = 0.f, last_mc_emit_ms = 0.f;
   uint64_t last_mc_blocks = 0;
+  // MeshExtractor::merge_mesh_ (mrh_mesh_merge_begin / _end): the soups of the extractions in between, back to back
+  bool merge_on = false;
+  mrh_triangle* d_acc = nullptr; size_t acc_cap = 0, acc_n = 0;
   // RCCL (mrh_comm.h): the communicator this context is attached to, exchange buffers, phase clocks
   mrh_comm* comm = nullptr;
   char* d_xsend = nullptr; size_t xsend_cap = 0;
@@ -292,13 +300,14 @@ void free_all(mrh_ctx* c) {
   for (hipEvent_t e : c->frame_done) if (e) (void) hipEventDestroy(e);
   if (c->h_peek) (void) hipHostFree(c->h_peek);
   if (c->h_scan) (void) hipHostFree(c->h_scan);
+  if (c->h_mc) (void) hipHostFree(c->h_mc);
   for (void* a : c->arena) if (a) (void) hipFree(a);
   F(c->d_decision); F(c->d_zbuf); F(c->d_realloc); F(c->d_reint); F(c->d_flag);
   F(c->d_upd_partials); F(c->d_misc); F(c->d_rcp_w); F(c->d_cfree); F(c->d_zmin); F(c->d_points); F(c->d_pt_counts); F(c->d_pt_offsets); F(c->d_rec_keys[0]); F(c->d_rec_keys[1]); F(c->d_rec_vals[0]); F(c->d_rec_vals[1]); F(c->d_sort_tmp); F(c->fast.summary); F(c->fast.summary_c); F(c->fast.bbox); F(c->d_cnt_partials);
   F(c->d_pack); F(c->d_halo); F(c->d_taken); F(c->d_cloud); F(c->d_normals); F(c->d_soup);
   for (hipEvent_t e : c->mc_ev) if (e) (void) hipEventDestroy(e);
   comm_release(c);
-  F(c->d_xsend); F(c->d_xrecv);
+  F(c->d_xsend); F(c->d_xrecv); F(c->d_acc);
   for (hipEvent_t e : c->comm_ev) if (e) (void) hipEventDestroy(e);
   for (auto& e : c->comm_ev_pool) { (void) hipEventDestroy(e.a); (void) hipEventDestroy(e.b); }
   for (auto& e : c->comm_ev_pending) { (void) hipEventDestroy(e.a); (void) hipEventDestroy(e.b); }
@@ -512,67 +521,65 @@ int arena_get(mrh_ctx* c, const int slot, const size_t bytes, void** out) {
 int process_triangles_device(mrh_ctx* c, const mrh_triangle* d_tris, const size_t nt) {
   c->V.clear(); c->C.clear(); c->F.clear();
   if (nt == 0) return MRH_OK;
-  if (nt * 3 >= 0xFFFFFFF0ull) return fail(c, MRH_ERR_CAPACITY, "mesh post-process: %zu triangles exceed 32-bit vertex indices", nt);
+  if (nt * 3 >= (1ull << 30)) return fail(c, MRH_ERR_CAPACITY, "mesh post-process: %zu triangles exceed the 2^30 soup vertices one index table holds", nt);
   hipStream_t s = c->stream;
   const u32 n = (u32) (nt * 3), ntr = (u32) nt;
   const double eps = (double) c->p.vertices_merging_threshold;
   const double inv_eps = eps != 0.0 ? 1.0 / eps : 0.0;
-  const size_t tmp_bytes = mesh_sort_tmp_bytes(n);
+  const size_t tmp_bytes = mesh_scan_tmp_bytes(n);
+  const u32 cap = (u32) next_pow2((uint64_t) n * 2);  // load factor <= 1/2; the face table (nt keys) reuses it
   MeshScratch m;
-  m.bytes = (size_t) n * (4 * 13 + 8 * 2) + tmp_bytes + 64 * 256;
+  m.bytes = (size_t) n * 4 * 5 + (size_t) cap * 4 + tmp_bytes + 32 * 256;
   {
     const int arc = arena_get(c, 1, m.bytes, &m.base);
     if (arc) return arc;
   }
-  u32* kx = m.take<u32>(n);      u64* kyz = m.take<u64>(n);     u32* idx0 = m.take<u32>(n);   u32* never = m.take<u32>(n);
-  u64* lo_s = m.take<u64>(n);    u32* mid = m.take<u32>(n);     u32* order = m.take<u32>(n);  u32* hi_g = m.take<u32>(n);
-  u32* hi_s = m.take<u32>(n);    u32* headpos = m.take<u32>(n); u32* rep = m.take<u32>(n);    u32* first = m.take<u32>(n);
-  u32* vid = m.take<u32>(n);     u32* corner = m.take<u32>(n);  u32* hscan = m.take<u32>(n);
-  void* tmp = m.take<char>(tmp_bytes);
+  u32* rep = m.take<u32>(n);   u32* first = m.take<u32>(n);   u32* vid = m.take<u32>(n);   u32* corner = m.take<u32>(n);
+  u32* keep = m.take<u32>(n);  // faces: keep + fpos share it (nt + nt <= n)
+  u32* fpos = keep + ntr;
+  u32* table = m.take<u32>(cap);
+  u64* d_totals = m.take<u64>(2);
+  void* tmp = m.take<char>(tmp_bytes ? tmp_bytes : 1);
   size_t tb = tmp_bytes;
   const u32 gv = (n + 255) / 256, gf = (ntr + 255) / 256;
   const float* soup = (const float*) d_tris;
   int rc = MRH_OK;
   double *dV = nullptr, *dC = nullptr;
   int* dF = nullptr;
+  if (!c->h_mc) {
+    HIP_TRY(c, hipHostMalloc((void**) &c->h_mc, 4 * sizeof(u64), hipHostMallocDefault));
+    memset(c->h_mc, 0, 4 * sizeof(u64));
+  }
 #define MESH_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { rc = fail(c, MRH_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(e_)); goto done; } } while (0)
   {
-    // ---- vertices
-    k_mesh_vertex_keys<<<gv, 256, 0, s>>>(soup, n, eps, inv_eps, kx, kyz, idx0, never);
-    MESH_TRY(mesh_sort96(tmp, tb, kx, kyz, idx0, mid, order, lo_s, hi_g, hi_s, n, s));
-    k_mesh_heads<<<gv, 256, 0, s>>>(kx, kyz, never, order, n, headpos);
-    MESH_TRY(rocprim::inclusive_scan(tmp, tb, headpos, hscan, n, rocprim::maximum<u32>(), s));
-    k_mesh_rep<<<gv, 256, 0, s>>>(order, hscan, n, rep, first);
-    MESH_TRY(rocprim::exclusive_scan(tmp, tb, first, vid, 0u, n, rocprim::plus<u32>(), s));
-    u32 last_vid = 0, last_first = 0;
-    MESH_TRY(hipMemcpyAsync(&last_vid, vid + (n - 1), sizeof(u32), hipMemcpyDeviceToHost, s));
-    MESH_TRY(hipMemcpyAsync(&last_first, first + (n - 1), sizeof(u32), hipMemcpyDeviceToHost, s));
-    MESH_TRY(hipStreamSynchronize(s));
-    const size_t nv = (size_t) last_vid + last_first;
-    {  // V, C and (at most nt) faces share slot 2
+    // V, C (at most n vertices each) and the faces (at most nt) share slot 2, sized by those bounds: nothing of the
+    // post-process waits for a count from the device
+    {
       void* vcf = nullptr;
-      const size_t vbytes = (nv * 3 * sizeof(double) + 255) & ~(size_t) 255;
+      const size_t vbytes = ((size_t) n * 3 * sizeof(double) + 255) & ~(size_t) 255;
       rc = arena_get(c, 2, 2 * vbytes + (size_t) ntr * 3 * sizeof(int), &vcf);
       if (rc) goto done;
       dV = (double*) vcf;
       dC = (double*) ((char*) vcf + vbytes);
       dF = (int*) ((char*) vcf + 2 * vbytes);
     }
+    // ---- vertices
+    MESH_TRY(hipMemsetAsync(table, 0xFF, (size_t) cap * 4, s));
+    k_mesh_vertex_insert<<<gv, 256, 0, s>>>(soup, n, eps, inv_eps, table, cap - 1);
+    k_mesh_vertex_rep<<<gv, 256, 0, s>>>(soup, n, eps, inv_eps, table, cap - 1, rep, first);
+    MESH_TRY(rocprim::exclusive_scan(tmp, tb, first, vid, 0u, n, rocprim::plus<u32>(), s));
     k_mesh_emit_vertices<<<gv, 256, 0, s>>>(soup, rep, first, vid, n, dV, dC, corner);
-    // ---- faces (the vertex buffers are reused: nt < n)
-    u32* ka = kx; u64* kbc = kyz; u32* fidx = idx0; u32* degenerate = never; u32* keep = rep; u32* fpos = vid;
-    k_mesh_face_keys<<<gf, 256, 0, s>>>(corner, ntr, ka, kbc, fidx, degenerate);
-    MESH_TRY(mesh_sort96(tmp, tb, ka, kbc, fidx, mid, order, lo_s, hi_g, hi_s, ntr, s));
-    k_mesh_heads<<<gf, 256, 0, s>>>(ka, kbc, nullptr, order, ntr, headpos);
-    MESH_TRY(rocprim::inclusive_scan(tmp, tb, headpos, hscan, ntr, rocprim::maximum<u32>(), s));
-    k_mesh_face_keep<<<gf, 256, 0, s>>>(order, hscan, degenerate, ntr, keep);
+    // ---- faces
+    const u32 fcap = (u32) next_pow2((uint64_t) ntr * 2);
+    MESH_TRY(hipMemsetAsync(table, 0xFF, (size_t) fcap * 4, s));
+    k_mesh_face_insert<<<gf, 256, 0, s>>>(corner, ntr, table, fcap - 1);
+    k_mesh_face_keep<<<gf, 256, 0, s>>>(corner, ntr, table, fcap - 1, keep);
     MESH_TRY(rocprim::exclusive_scan(tmp, tb, keep, fpos, 0u, ntr, rocprim::plus<u32>(), s));
-    u32 last_pos = 0, last_keep = 0;
-    MESH_TRY(hipMemcpyAsync(&last_pos, fpos + (ntr - 1), sizeof(u32), hipMemcpyDeviceToHost, s));
-    MESH_TRY(hipMemcpyAsync(&last_keep, keep + (ntr - 1), sizeof(u32), hipMemcpyDeviceToHost, s));
+    k_mesh_emit_faces<<<gf, 256, 0, s>>>(corner, keep, fpos, ntr, dF);
+    k_mesh_totals<<<1, 1, 0, s>>>(vid, first, n, fpos, keep, ntr, d_totals);
+    MESH_TRY(hipMemcpyAsync(c->h_mc + 2, d_totals, 2 * sizeof(u64), hipMemcpyDeviceToHost, s));
     MESH_TRY(hipStreamSynchronize(s));
-    const size_t nf = (size_t) last_pos + last_keep;
-    if (nf) k_mesh_emit_faces<<<gf, 256, 0, s>>>(corner, keep, fpos, ntr, dF);
+    const size_t nv = (size_t) c->h_mc[2], nf = (size_t) c->h_mc[3];
     c->V.resize_discard(nv * 3); c->C.resize_discard(nv * 3); c->F.resize_discard(nf * 3);
     MESH_TRY(hipMemcpyAsync(c->V.data(), dV, nv * 3 * sizeof(double), hipMemcpyDeviceToHost, s));
     MESH_TRY(hipMemcpyAsync(c->C.data(), dC, nv * 3 * sizeof(double), hipMemcpyDeviceToHost, s));
@@ -1812,77 +1819,102 @@ int mrh_extract_triangles(mrh_ctx* c, const mrh_triangle** out_tris, uint64_t* o
   auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   double t0 = now(), t1 = t0, t2 = t0, t3 = t0, t4 = t0, t5 = t0;
   int n = 0;
-  rc = compact_all(c, &n);
+  rc = compact_all(c, &n);  // the one scalar the host needs up front: it sizes the sort and the launches
   if (rc) return rc;
   c->tris.clear();
   c->tri_blocks.clear();
   c->tri_counts.clear();
+  c->tri_dev_n = 0;
   c->last_triangles = 0;
   c->soup_n = 0;
   bool processed = false;
   if (n > 0) {
-    // canonical order: sort the block list by position (packed-key order == (x,y,z) order) — on the device; the host
-    // only needs the sorted list for the per-block descriptors it hands out (mrh_get_triangle_blocks)
-    std::vector<int4> list((size_t) n);
-    // temporaries of this call, carved from the grow-only scratch (slot 0)
-    u64 *k_in, *k_out, *d_offsets;
+    // Everything between the block count and the triangle total stays on the device: canonical order by a radix sort of the
+    // packed keys (key order == (x, y, z) order), the 27-block neighbourhoods resolved by one thread per (block, neighbour),
+    // per-block triangle counts -> exclusive scan (rocPRIM) -> exact offsets, the emit pass launched right behind it.  The
+    // sorted list and the counts are read back only if somebody asks (mrh_get_triangle_blocks).
+    u64 *k_in, *k_out, *d_offsets, *d_total;
     int4* sorted;
-    u32* d_counts;
+    u32 *d_counts, *d_nb;
     uint8_t* d_per_voxel;  // triangles per voxel from the count pass: the emit pass skips the empty ones
     void* tmp;
-    size_t sort_bytes = 0;
+    size_t sort_bytes = 0, scan_bytes = 0;
     HIP_TRY(c, rocprim::radix_sort_pairs(nullptr, sort_bytes, (u64*) nullptr, (u64*) nullptr, (int4*) nullptr, (int4*) nullptr, (size_t) n, 0, 63, s));
+    HIP_TRY(c, rocprim::exclusive_scan(nullptr, scan_bytes, (u32*) nullptr, (u64*) nullptr, (u64) 0, (size_t) n, rocprim::plus<u64>(), s));
+    const size_t tmp_bytes = std::max(sort_bytes, scan_bytes);
     {
       MeshScratch a;
-      a.bytes = (size_t) n * (8 * 3 + 16 + 4 + 512) + sort_bytes + 16 * 256;
+      a.bytes = (size_t) n * (8 * 3 + 16 + 4 + 4 * kMcNbStride + 512) + tmp_bytes + 32 * 256;
       rc = arena_get(c, 0, a.bytes, &a.base);
       if (rc) return rc;
       k_in = a.take<u64>((size_t) n); k_out = a.take<u64>((size_t) n); d_offsets = a.take<u64>((size_t) n);
-      sorted = a.take<int4>((size_t) n); d_counts = a.take<u32>((size_t) n); d_per_voxel = a.take<uint8_t>((size_t) n * 512);
-      tmp = a.take<char>(sort_bytes ? sort_bytes : 1);
+      sorted = a.take<int4>((size_t) n); d_counts = a.take<u32>((size_t) n); d_nb = a.take<u32>((size_t) n * kMcNbStride);
+      d_per_voxel = a.take<uint8_t>((size_t) n * 512); d_total = a.take<u64>(2);
+      tmp = a.take<char>(tmp_bytes ? tmp_bytes : 1);
+    }
+    if (!c->h_mc) {
+      HIP_TRY(c, hipHostMalloc((void**) &c->h_mc, 4 * sizeof(u64), hipHostMallocDefault));
+      memset(c->h_mc, 0, 4 * sizeof(u64));
     }
     {
       k_list_keys<<<(n + 255) / 256, 256, 0, s>>>(c->tab.compact, n, k_in);
-      size_t bytes = sort_bytes;
+      size_t bytes = tmp_bytes;
       HIP_TRY(c, rocprim::radix_sort_pairs(tmp, bytes, k_in, k_out, c->tab.compact, sorted, (size_t) n, 0, 63, s));
-      HIP_TRY(c, hipMemcpyAsync(c->tab.compact, sorted, (size_t) n * sizeof(int4), hipMemcpyDeviceToDevice, s));
-      HIP_TRY(c, hipMemcpyAsync(list.data(), sorted, (size_t) n * sizeof(int4), hipMemcpyDeviceToHost, s));
-      HIP_TRY(c, hipStreamSynchronize(s));
+      k_mc_neighbors<<<(int) (((size_t) n * 32 + 255) / 256), 256, 0, s>>>(c->tab, sorted, n, d_nb);
     }
-    t1 = now();
+    if (dbg) { HIP_TRY(c, hipStreamSynchronize(s)); t1 = now(); }
     const int grid = n < 8192 ? n : 8192;
     // largest truncation a stored sample can carry (integration clamps to trunc + scale * depth, depth <= the integration distance)
     const float sdf_bound = c->has_camera && !getenv("MRH_MC_NO_PRESCREEN") ? c->map.trunc + c->map.trunc_scale * c->cam.max_int_dist : 0.f;
-    for (hipEvent_t& ev : c->mc_ev)
-      if (!ev) HIP_TRY(c, hipEventCreate(&ev));
     c->last_mc_count_ms = c->last_mc_emit_ms = 0.f;
     c->last_mc_blocks = (uint64_t) n;
-    hipExtLaunchKernelGGL((k_mc<false>), dim3(grid), dim3(kMcThreads), 0, s, c->mc_ev[0], c->mc_ev[1], 0u, c->map, c->tab, (const int4*) c->tab.compact, n,
-                          (u32*) d_counts, (const u64*) nullptr, (mrh_triangle*) nullptr, (u64) 0, (uint8_t*) d_per_voxel, sdf_bound);
-    std::vector<u32> counts((size_t) n);
-    HIP_TRY(c, hipMemcpyAsync(counts.data(), d_counts, (size_t) n * sizeof(u32), hipMemcpyDeviceToHost, s));
+    // kernel times for mrh_stats only in profile mode: launches that carry events switch the queue to its profiling mode,
+    // which slows every later dispatch of the process
+    const bool timed = c->profile != 0;
+    if (timed)
+      for (hipEvent_t& ev : c->mc_ev)
+        if (!ev) HIP_TRY(c, hipEventCreate(&ev));
+    if (timed) hipExtLaunchKernelGGL((k_mc<false>), dim3(grid), dim3(kMcThreads), 0, s, c->mc_ev[0], c->mc_ev[1], 0u, c->map, c->tab, (const int4*) sorted, n, (const u32*) d_nb,
+                                     (u32*) d_counts, (const u64*) nullptr, (mrh_triangle*) nullptr, (u64) 0, (uint8_t*) d_per_voxel, sdf_bound, 0);
+    else k_mc<false><<<grid, kMcThreads, 0, s>>>(c->map, c->tab, sorted, n, d_nb, d_counts, nullptr, nullptr, (u64) 0, d_per_voxel, sdf_bound, 0);
+    {
+      size_t bytes = tmp_bytes;
+      HIP_TRY(c, rocprim::exclusive_scan(tmp, bytes, d_counts, d_offsets, (u64) 0, (size_t) n, rocprim::plus<u64>(), s));
+      k_mc_total<<<1, 1, 0, s>>>(d_offsets, d_counts, n, d_total);
+      HIP_TRY(c, hipMemcpyAsync(c->h_mc, d_total, sizeof(u64), hipMemcpyDeviceToHost, s));
+    }
+    auto emit = [&](const u64 cap, const int flag_overflow) {
+      if (timed) hipExtLaunchKernelGGL((k_mc<true>), dim3(grid), dim3(kMcThreads), 0, s, c->mc_ev[2], c->mc_ev[3], 0u, c->map, c->tab, (const int4*) sorted, n, (const u32*) d_nb,
+                                       (u32*) d_counts, (const u64*) d_offsets, (mrh_triangle*) c->d_soup, cap, (uint8_t*) d_per_voxel, 0.f, flag_overflow);
+      else k_mc<true><<<grid, kMcThreads, 0, s>>>(c->map, c->tab, sorted, n, d_nb, d_counts, d_offsets, c->d_soup, cap, d_per_voxel, 0.f, flag_overflow);
+    };
+    // The emit pass goes out BEFORE the host knows the total, into the soup buffer of the previous extraction (grow-only, 12 %
+    // head room): a map that is extracted again — the usual case — needs no round trip between the two passes.  Writes beyond
+    // the capacity are suppressed by the kernel; if the total turns out larger, the buffer grows and the pass runs again.
+    const u64 spec_cap = std::min<u64>(c->soup_cap, c->max_triangles);
+    if (spec_cap > 0) emit(spec_cap, 0);
     HIP_TRY(c, hipStreamSynchronize(s));
-    HIP_TRY(c, hipEventElapsedTime(&c->last_mc_count_ms, c->mc_ev[0], c->mc_ev[1]));
-    t2 = now();
-    std::vector<u64> offsets((size_t) n);
-    u64 total = 0;
-    for (int i = 0; i < n; i++) { offsets[i] = total; total += counts[i]; }
-    c->tri_counts = counts;
-    c->tri_blocks.resize((size_t) n);
-    for (int i = 0; i < n; i++) c->tri_blocks[i] = {list[i].x, list[i].y, list[i].z, (list[i].w & (int) kValCoarseBit) ? 1 : 0};
+    const u64 total = c->h_mc[0];
+    if (dbg) t2 = now();
+    c->tri_dev_n = n;
+    c->d_tri_sorted = sorted;
+    c->d_tri_counts = d_counts;
     if (total > c->max_triangles) {
       return fail(c, MRH_ERR_CAPACITY, "triangle buffer full: %llu triangles > max_triangles %llu", (unsigned long long) total, (unsigned long long) c->max_triangles);
     }
     if (total > 0) {
-      rc = ensure_soup(c, (size_t) total);
-      if (rc) return rc;
+      if (total > spec_cap) {
+        rc = ensure_soup(c, (size_t) total);
+        if (rc) return rc;
+        emit(total, 1);
+      }
       mrh_triangle* d_tris = c->d_soup;
       c->soup_n = (size_t) total;
-      HIP_TRY(c, hipMemcpyAsync(d_offsets, offsets.data(), (size_t) n * sizeof(u64), hipMemcpyHostToDevice, s));
-      hipExtLaunchKernelGGL((k_mc<true>), dim3(grid), dim3(kMcThreads), 0, s, c->mc_ev[2], c->mc_ev[3], 0u, c->map, c->tab, (const int4*) c->tab.compact, n,
-                            (u32*) d_counts, (const u64*) d_offsets, (mrh_triangle*) d_tris, (u64) total, (uint8_t*) d_per_voxel, 0.f);
-      HIP_TRY(c, hipEventSynchronize(c->mc_ev[3]));
-      HIP_TRY(c, hipEventElapsedTime(&c->last_mc_emit_ms, c->mc_ev[2], c->mc_ev[3]));
+      if (timed) {
+        HIP_TRY(c, hipEventSynchronize(c->mc_ev[3]));
+        HIP_TRY(c, hipEventElapsedTime(&c->last_mc_count_ms, c->mc_ev[0], c->mc_ev[1]));
+        HIP_TRY(c, hipEventElapsedTime(&c->last_mc_emit_ms, c->mc_ev[2], c->mc_ev[3]));
+      }
       if (dbg) { HIP_TRY(c, hipStreamSynchronize(s)); t3 = now(); }
       if (want_soup) {
         c->tris.resize_discard(total);
@@ -1890,21 +1922,70 @@ int mrh_extract_triangles(mrh_ctx* c, const mrh_triangle** out_tris, uint64_t* o
       }
       if (dbg) { HIP_TRY(c, hipStreamSynchronize(s)); t4 = now(); }
       int prc = MRH_OK;
-      if (!c->mesh_on_host) { prc = process_triangles_device(c, d_tris, total); processed = true; }
+      if (c->merge_on) {  // the running mesh takes this soup; the post-process runs once, over everything, in mrh_mesh_merge_end
+        if (c->acc_n + total > c->acc_cap) {
+          const size_t cap = (c->acc_n + total) + (c->acc_n + total) / 2;
+          mrh_triangle* grown = nullptr;
+          HIP_TRY(c, hipMalloc((void**) &grown, cap * sizeof(mrh_triangle)));
+          if (c->acc_n) HIP_TRY(c, hipMemcpyAsync(grown, c->d_acc, c->acc_n * sizeof(mrh_triangle), hipMemcpyDeviceToDevice, s));
+          HIP_TRY(c, hipStreamSynchronize(s));
+          if (c->d_acc) HIP_TRY(c, hipFree(c->d_acc));
+          c->d_acc = grown; c->acc_cap = cap;
+        }
+        HIP_TRY(c, hipMemcpyAsync(c->d_acc + c->acc_n, d_tris, total * sizeof(mrh_triangle), hipMemcpyDeviceToDevice, s));
+        c->acc_n += total;
+        processed = true;
+      } else if (!c->mesh_on_host) { prc = process_triangles_device(c, d_tris, total); processed = true; }
       HIP_TRY(c, hipStreamSynchronize(s));
       if (prc) return prc;
       n_tris = total;
+    } else if (timed) {
+      HIP_TRY(c, hipEventElapsedTime(&c->last_mc_count_ms, c->mc_ev[0], c->mc_ev[1]));
     }
     HIP_TRY(c, hipGetLastError());
   }
   c->last_triangles = n_tris;
-  if (!processed) process_triangles(c);
+  if (!processed && !c->merge_on) process_triangles(c);
   t5 = now();
-  if (dbg) fprintf(stderr, "[mrhash_hip] extract: %d blocks, %llu triangles | list+sort %.2f ms, count %.2f, emit %.2f, soup D2H %.2f, post-process + V/F/C D2H %.2f, total %.2f\n",
+  if (dbg) fprintf(stderr, "[mrhash_hip] extract: %d blocks, %llu triangles | list+sort+neighbours %.2f ms, count+scan(+speculative emit) %.2f, emit %.2f, soup D2H %.2f, post-process + V/F/C D2H %.2f, total %.2f\n",
                    n, (unsigned long long) n_tris, t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4, t5 - t0);
   if (out_tris) *out_tris = c->tris.empty() ? nullptr : c->tris.data();
   *out_n = n_tris;
   return MRH_OK;
+}
+
+// MeshExtractor::merge_mesh_ = true (geowrapper.cpp:161) ... the chunk loop ... the final mesh.  The reference runs
+// processTriangles after every extraction, on (running mesh + new soup).  That equals ONE processTriangles over the soups back
+// to back: the vertex merge keeps first occurrences with their indices and colours, and "drop degenerate faces" / "drop
+// repeated faces keeping the first" are order-preserving filters, so applying them to a prefix first changes nothing
+// (tests/test_geowrapper_gpu.py compares with the oracle, which restates the incremental form literally).
+int mrh_mesh_merge_begin(mrh_ctx* c) {
+  if (!c) return MRH_ERR_INVALID_ARG;
+  c->merge_on = true;
+  c->acc_n = 0;
+  c->V.clear(); c->C.clear(); c->F.clear();
+  return MRH_OK;
+}
+
+int mrh_mesh_merge_end(mrh_ctx* c, uint64_t* out_total_triangles) {
+  int rc = ensure_ready(c, "mrh_mesh_merge_end");
+  if (rc) return rc;
+  if (!c->merge_on) return fail(c, MRH_ERR_STATE, "mrh_mesh_merge_end: no merge in progress (mrh_mesh_merge_begin)");
+  c->merge_on = false;
+  if (out_total_triangles) *out_total_triangles = c->acc_n;
+  c->last_triangles = c->acc_n;
+  c->tris.clear();
+  if (c->acc_n == 0) { c->V.clear(); c->C.clear(); c->F.clear(); return MRH_OK; }
+  if (c->mesh_on_host) {  // MRH_MESH_HOST=1: the host restatement of the post-process
+    c->tris.resize_discard(c->acc_n);
+    HIP_TRY(c, hipMemcpyAsync(c->tris.data(), c->d_acc, c->acc_n * sizeof(mrh_triangle), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    process_triangles(c);
+    return MRH_OK;
+  }
+  rc = process_triangles_device(c, c->d_acc, c->acc_n);
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return rc;
 }
 
 int mrh_extract_mesh(mrh_ctx* c, const double** v, uint64_t* nv, const int32_t** f, uint64_t* nf, const double** col) {
@@ -2215,6 +2296,17 @@ int mrh_drop_blocks(mrh_ctx* c, int mode, uint64_t* out_dropped) {
 
 int mrh_get_triangle_blocks(mrh_ctx* c, const mrh_block_desc** out_descs, const uint32_t** out_counts, uint64_t* out_n) {
   if (!c || !out_descs || !out_counts || !out_n) return MRH_ERR_INVALID_ARG;
+  if (c->tri_dev_n > 0) {  // the list and the counts of the last extraction are still where the kernels left them
+    const size_t n = (size_t) c->tri_dev_n;
+    std::vector<int4> list(n);
+    c->tri_counts.resize(n);
+    HIP_TRY(c, hipMemcpyAsync(list.data(), c->d_tri_sorted, n * sizeof(int4), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->tri_counts.data(), c->d_tri_counts, n * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->tri_blocks.resize(n);
+    for (size_t i = 0; i < n; i++) c->tri_blocks[i] = {list[i].x, list[i].y, list[i].z, (list[i].w & (int) kValCoarseBit) ? 1 : 0};
+    c->tri_dev_n = 0;
+  }
   *out_descs = c->tri_blocks.empty() ? nullptr : c->tri_blocks.data();
   *out_counts = c->tri_counts.empty() ? nullptr : c->tri_counts.data();
   *out_n = c->tri_blocks.size();
@@ -2261,6 +2353,7 @@ int mrh_process_triangle_runs(mrh_ctx* c, const mrh_block_desc* descs, const uin
     if (descs[a].y != descs[b].y) return descs[a].y < descs[b].y;
     return descs[a].z < descs[b].z;
   });
+  c->tri_dev_n = 0;
   c->tri_blocks.resize(n_blocks);
   c->tri_counts.resize(n_blocks);
   std::vector<ulonglong2> runs;  // {source offset, destination offset | count << 40}

@@ -447,6 +447,34 @@ __device__ __forceinline__ bool voxel_touches_coarse(const int v, const u32 cmas
   return (cube & cmask) != 0u;
 }
 
+// The 27-block neighbourhood of every block of the sorted list, resolved by one thread per (block, neighbour): 27 independent
+// probes per block at full occupancy instead of 27 lanes of one wave walking their probe paths at the head of every k_mc
+// workgroup while the other 229 threads wait; both passes read the table.  Layout: nb[e * 32 + i], i = (dz+1)*9 + (dy+1)*3 + (dx+1).
+constexpr int kMcNbStride = 32;
+__global__ __launch_bounds__(256) void k_mc_neighbors(const Tab t, const int4* __restrict__ sorted, const int n, u32* __restrict__ nb) {
+  const size_t g = (size_t) blockIdx.x * 256 + threadIdx.x;
+  const size_t e = g >> 5;
+  const int i = (int) (g & 31);
+  if (e >= (size_t) n || i >= 27) return;
+  const int4 ent = sorted[e];
+  u32 val = kNbAbsent;
+  if (i == 13) {
+    val = (u32) ent.w;  // the block itself: the list carries its table value
+  } else {
+    const i3 b = mki3(ent.x + (i % 3) - 1, ent.y + ((i / 3) % 3) - 1, ent.z + (i / 9) - 1);
+    u64 key;
+    if (pack_key(b, key)) {
+      const int slot = hash_find(t, key);
+      if (slot >= 0) val = t.vals[slot];
+    }
+  }
+  nb[e * kMcNbStride + i] = val;
+}
+// triangle total of an extraction = last exclusive offset + last count
+__global__ void k_mc_total(const u64* __restrict__ offsets, const u32* __restrict__ counts, const int n, u64* __restrict__ total) {
+  total[0] = offsets[n - 1] + counts[n - 1];
+}
+
 constexpr int kMcThreads = 256;
 constexpr int kMcFillIters = (kHaloCells + kMcThreads - 1) / kMcThreads;  // 11
 template <bool EMIT>
@@ -454,9 +482,10 @@ template <bool EMIT>
 // run 10-12 % faster — the staging half of the kernel is a chain of memory round trips and wants the extra workgroup per CU
 // (5 waves / 96 VGPRs: 100 bytes of scratch, no better).
 __global__ __launch_bounds__(kMcThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_mc(const Map m, const Tab t, const int4* __restrict__ sorted, const int n,
+                                                   const u32* __restrict__ nb_table,
                                                    u32* __restrict__ counts, const u64* __restrict__ offsets,
                                                    mrh_triangle* __restrict__ out, const u64 max_tris, uint8_t* __restrict__ per_voxel,
-                                                   const float sdf_bound) {
+                                                   const float sdf_bound, const int flag_overflow) {
   __shared__ u32 s_nb[27];
   __shared__ float s_sdf[kHaloCells];
   __shared__ u32 s_rgbw[kHaloCells];
@@ -477,13 +506,7 @@ __global__ __launch_bounds__(kMcThreads) __attribute__((amdgpu_waves_per_eu(4, 4
     nb.base = mki3(ent.x, ent.y, ent.z);
     nb.shift_limit = m.block_shift_limit;
     nb.r_vs = rcp_refined(m.vs);
-    if (tid < 27) {  // resolve the 27 surrounding blocks once
-      const i3 b = mki3(ent.x + (tid % 3) - 1, ent.y + ((tid / 3) % 3) - 1, ent.z + (tid / 9) - 1);
-      u64 key;
-      int slot = -1;
-      if (pack_key(b, key)) slot = hash_find(t, key);
-      s_nb[tid] = slot >= 0 ? t.vals[slot] : kNbAbsent;
-    }
+    if (tid < 27) s_nb[tid] = nb_table[(size_t) e * kMcNbStride + tid];  // the 27 surrounding blocks (k_mc_neighbors)
     if (tid < 2) s_ncand[tid] = 0;
     for (int i = tid; i < 512; i += kMcThreads) s_ntri[i] = 0;
     __syncthreads();
@@ -694,7 +717,7 @@ __global__ __launch_bounds__(kMcThreads) __attribute__((amdgpu_waves_per_eu(4, 4
           const u64 first = offsets[e] + s_off[v];
           const int room = first >= max_tris ? 0 : (int) (max_tris - first < 5 ? max_tris - first : 5);
           const int ntri = mc_group<true>(m, t, nb, voxel_position(v), v, kind == 0, corner, gb, active, out + first, room);  // straight to the exact offset
-          if (active && corner == 0 && ntri > room) atomicOr((u32*) &t.ctr[CTR_ERROR], ERR_TRI);
+          if (flag_overflow && active && corner == 0 && ntri > room) atomicOr((u32*) &t.ctr[CTR_ERROR], ERR_TRI);
         }
       }
     }

@@ -3,18 +3,23 @@
 // Reference (mesh_extractor.cpp:9-76, :156-259): a single CPU thread walks the triangle soup through two
 // std::unordered_maps — vertex merge (exact position, or floor(v / eps) cells; the first occurrence keeps index and
 // colour), then degenerate faces dropped and repeated faces dropped keeping the first.  At a million triangles that
-// is ~0.4 s of host time after a 12 ms extraction.  "First occurrence wins" is a statement about ORDER, so it maps
-// onto stable sorts and scans and gives the same arrays, element for element:
+// is ~0.4 s of host time after a millisecond of extraction.  "First occurrence wins" means: the representative of a
+// key is the SMALLEST soup index that carries it.  That is a min-reduction per key, which an open-address table of
+// soup indices computes in one pass with no ordering at all:
 //
-//   vertices  key = 3 x 32 bits (position bits, or the eps cell), value = soup index
-//             two stable LSD radix passes (rocPRIM) -> equal keys contiguous, soup indices ascending inside a run
-//             run head = representative;   is_first = (rep == self);   new index = exclusive scan of is_first
-//             -> V / C in order of first occurrence, face corner -> index of its representative
-//   faces     degenerate = two equal corners;  the same sort on the (a, b, c) index triples, run head = first
-//             occurrence, keep = head && !degenerate, position = exclusive scan of keep in soup order
+//   vertices  slot = hash(96-bit key) ...: empty -> CAS my index in; occupied by index j -> compare MY key with the key of
+//             soup vertex j (12 bytes, read where the soup lies): equal -> atomicMin(slot, my index), else next slot.
+//             Only indices of ONE key ever replace each other in a slot, so the comparison through whichever index is
+//             stored is stable.  Second pass: rep[i] = the slot's final index; is_first = (rep == self); new index =
+//             exclusive scan of is_first in soup order -> V / C in order of first occurrence.
+//   faces     degenerate = two equal corners; the same table on the (a, b, c) index triples; keep = (rep == self) &&
+//             !degenerate; position = exclusive scan of keep in soup order.
 //
-// NaN positions never compare equal in the reference (Vector3dEqual): every vertex with a NaN coordinate is its own
-// run head.  Used by mrh_extract_triangles (soup already on the device) and mrh_process_triangles (soup uploaded).
+// Round 2 did this with two stable 96-bit LSD radix sorts (12 + 12 passes over the soup per extraction); the arrays are
+// the same, element for element (tests compare with the host restatement and the oracle), at a fraction of the passes.
+// NaN positions never compare equal in the reference (Vector3dEqual): a vertex with a NaN coordinate stays out of the
+// table and is its own representative.  Used by mrh_extract_triangles (soup already on the device), the run merge of a
+// sharded extraction and mrh_process_triangles (soup uploaded).
 #pragma once
 
 #include <rocprim/rocprim.hpp>
@@ -23,50 +28,71 @@
 
 namespace mrh {
 
-// soup vertex i = corner (i % 3) of triangle (i / 3); mrh_triangle = 3 x {p[3], c[3]} floats
-__global__ __launch_bounds__(256) void k_mesh_vertex_keys(const float* __restrict__ soup, const u32 n, const double eps, const double inv_eps,
-                                                          u32* __restrict__ kx, u64* __restrict__ kyz, u32* __restrict__ idx,
-                                                          u32* __restrict__ nanflag) {
+constexpr u32 kMeshEmpty = 0xFFFFFFFFu;
+struct Key96 { u32 a, b, c; };
+__device__ __forceinline__ bool key_eq(const Key96 x, const Key96 y) { return x.a == y.a && x.b == y.b && x.c == y.c; }
+__device__ __forceinline__ u32 key_hash(const Key96 k) {
+  u64 h = ((u64) k.a << 32 | k.b) * 0x9E3779B97F4A7C15ull;
+  h ^= h >> 29;
+  h += (u64) k.c * 0xBF58476D1CE4E5B9ull;
+  h ^= h >> 32; h *= 0x94D049BB133111EBull; h ^= h >> 29;
+  return (u32) h;
+}
+// soup vertex i = corner (i % 3) of triangle (i / 3); mrh_triangle = 3 x {p[3], c[3]} floats.
+// Key: the position's bit pattern ((double) p is injective on it, -0 and +0 stay apart), or the eps cell (mesh_extractor.cpp:196-203)
+__device__ __forceinline__ Key96 vertex_key(const float* __restrict__ soup, const u32 i, const double eps, const double inv_eps, bool& has_nan) {
+  const float* v = soup + (size_t) i * 6;
+  const float p0 = v[0], p1 = v[1], p2 = v[2];
+  has_nan = p0 != p0 || p1 != p1 || p2 != p2;
+  Key96 k;
+  if (eps == 0.0) { k.a = __float_as_uint(p0); k.b = __float_as_uint(p1); k.c = __float_as_uint(p2); }
+  else { k.a = (u32) (int) floor((double) p0 * inv_eps); k.b = (u32) (int) floor((double) p1 * inv_eps); k.c = (u32) (int) floor((double) p2 * inv_eps); }
+  return k;
+}
+__device__ __forceinline__ Key96 face_key(const u32* __restrict__ corner, const u32 t) {
+  Key96 k;
+  k.a = corner[3 * t]; k.b = corner[3 * t + 1]; k.c = corner[3 * t + 2];
+  return k;
+}
+
+__global__ __launch_bounds__(256) void k_mesh_vertex_insert(const float* __restrict__ soup, const u32 n, const double eps, const double inv_eps,
+                                                            u32* __restrict__ table, const u32 mask) {
   const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const float* v = soup + (size_t) i * 6;
-  const float p[3] = {v[0], v[1], v[2]};
-  u32 k[3];
-#pragma unroll
-  for (int a = 0; a < 3; a++) {
-    if (eps == 0.0) k[a] = __float_as_uint(p[a]);  // (double) p is injective on the bit pattern, -0 and +0 stay apart
-    else k[a] = (u32) (int) floor((double) p[a] * inv_eps);
+  bool nan_i;
+  const Key96 key = vertex_key(soup, i, eps, inv_eps, nan_i);
+  if (nan_i) return;
+  u32 s = key_hash(key) & mask;
+  for (;;) {
+    u32 cur = __hip_atomic_load(&table[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (cur == kMeshEmpty) {
+      cur = atomicCAS(&table[s], kMeshEmpty, i);
+      if (cur == kMeshEmpty) return;
+    }
+    bool nan_c;
+    if (key_eq(vertex_key(soup, cur, eps, inv_eps, nan_c), key)) {
+      if (i < cur) atomicMin(&table[s], i);
+      return;
+    }
+    s = (s + 1) & mask;
   }
-  kx[i] = k[0];
-  kyz[i] = ((u64) k[1] << 32) | (u64) k[2];
-  idx[i] = i;
-  nanflag[i] = (p[0] != p[0] || p[1] != p[1] || p[2] != p[2]) ? 1u : 0u;
 }
-
-__global__ __launch_bounds__(256) void k_gather_u32(const u32* __restrict__ src, const u32* __restrict__ idx, const u32 n, u32* __restrict__ dst) {
-  const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j < n) dst[j] = src[idx[j]];
-}
-
-// sorted position j: head if its 96-bit key differs from the previous one (or the element never merges)
-__global__ __launch_bounds__(256) void k_mesh_heads(const u32* __restrict__ kx, const u64* __restrict__ kyz, const u32* __restrict__ never,
-                                                    const u32* __restrict__ order, const u32 n, u32* __restrict__ headpos) {
-  const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= n) return;
-  const u32 i = order[j];
-  bool head = j == 0 || (never && never[i]);
-  if (!head) {
-    const u32 p = order[j - 1];
-    head = kx[i] != kx[p] || kyz[i] != kyz[p];
+__global__ __launch_bounds__(256) void k_mesh_vertex_rep(const float* __restrict__ soup, const u32 n, const double eps, const double inv_eps,
+                                                         const u32* __restrict__ table, const u32 mask, u32* __restrict__ rep, u32* __restrict__ is_first) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  bool nan_i;
+  const Key96 key = vertex_key(soup, i, eps, inv_eps, nan_i);
+  u32 r = i;
+  if (!nan_i) {
+    u32 s = key_hash(key) & mask;
+    for (;;) {
+      const u32 cur = table[s];  // never empty before the key's own slot: this vertex was inserted
+      bool nan_c;
+      if (key_eq(vertex_key(soup, cur, eps, inv_eps, nan_c), key)) { r = cur; break; }
+      s = (s + 1) & mask;
+    }
   }
-  headpos[j] = head ? j : 0u;
-}
-
-__global__ __launch_bounds__(256) void k_mesh_rep(const u32* __restrict__ order, const u32* __restrict__ headpos, const u32 n,
-                                                  u32* __restrict__ rep, u32* __restrict__ is_first) {
-  const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= n) return;
-  const u32 i = order[j], r = order[headpos[j]];
   rep[i] = r;
   is_first[i] = (r == i) ? 1u : 0u;
 }
@@ -85,23 +111,38 @@ __global__ __launch_bounds__(256) void k_mesh_emit_vertices(const float* __restr
   }
 }
 
-__global__ __launch_bounds__(256) void k_mesh_face_keys(const u32* __restrict__ corner, const u32 nt, u32* __restrict__ ka, u64* __restrict__ kbc,
-                                                        u32* __restrict__ idx, u32* __restrict__ degenerate) {
+__global__ __launch_bounds__(256) void k_mesh_face_insert(const u32* __restrict__ corner, const u32 nt, u32* __restrict__ table, const u32 mask) {
   const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= nt) return;
-  const u32 a = corner[3 * t], b = corner[3 * t + 1], c = corner[3 * t + 2];
-  ka[t] = a;
-  kbc[t] = ((u64) b << 32) | (u64) c;
-  idx[t] = t;
-  degenerate[t] = (a == b || a == c || b == c) ? 1u : 0u;
+  const Key96 key = face_key(corner, t);
+  u32 s = key_hash(key) & mask;
+  for (;;) {
+    u32 cur = __hip_atomic_load(&table[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (cur == kMeshEmpty) {
+      cur = atomicCAS(&table[s], kMeshEmpty, t);
+      if (cur == kMeshEmpty) return;
+    }
+    if (key_eq(face_key(corner, cur), key)) {
+      if (t < cur) atomicMin(&table[s], t);
+      return;
+    }
+    s = (s + 1) & mask;
+  }
 }
-
-__global__ __launch_bounds__(256) void k_mesh_face_keep(const u32* __restrict__ order, const u32* __restrict__ headpos,
-                                                        const u32* __restrict__ degenerate, const u32 nt, u32* __restrict__ keep) {
-  const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= nt) return;
-  const u32 t = order[j];
-  keep[t] = (headpos[j] == j && !degenerate[t]) ? 1u : 0u;
+// keep = first occurrence of its (a, b, c) triple and not degenerate (mesh_extractor.cpp:57-75, :156-178)
+__global__ __launch_bounds__(256) void k_mesh_face_keep(const u32* __restrict__ corner, const u32 nt, const u32* __restrict__ table, const u32 mask,
+                                                        u32* __restrict__ keep) {
+  const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nt) return;
+  const Key96 key = face_key(corner, t);
+  u32 s = key_hash(key) & mask, r = t;
+  for (;;) {
+    const u32 cur = table[s];
+    if (key_eq(face_key(corner, cur), key)) { r = cur; break; }
+    s = (s + 1) & mask;
+  }
+  const bool degenerate = key.a == key.b || key.a == key.c || key.b == key.c;
+  keep[t] = (r == t && !degenerate) ? 1u : 0u;
 }
 
 __global__ __launch_bounds__(256) void k_mesh_emit_faces(const u32* __restrict__ corner, const u32* __restrict__ keep, const u32* __restrict__ fpos,
@@ -110,6 +151,12 @@ __global__ __launch_bounds__(256) void k_mesh_emit_faces(const u32* __restrict__
   if (t >= nt || !keep[t]) return;
   const size_t o = (size_t) fpos[t] * 3;
   F[o] = (int) corner[3 * t]; F[o + 1] = (int) corner[3 * t + 1]; F[o + 2] = (int) corner[3 * t + 2];
+}
+// {unique vertices, kept faces} for the host, once everything else of the post-process has been enqueued
+__global__ void k_mesh_totals(const u32* __restrict__ vid, const u32* __restrict__ first, const u32 n, const u32* __restrict__ fpos,
+                              const u32* __restrict__ keep, const u32 nt, u64* __restrict__ out) {
+  out[0] = (u64) vid[n - 1] + first[n - 1];
+  out[1] = (u64) fpos[nt - 1] + keep[nt - 1];
 }
 
 // ---- host driver ------------------------------------------------------------------------------------------
@@ -126,27 +173,10 @@ struct MeshScratch {
   }
 };
 
-// stable sort of `n` elements by the 96-bit key (hi32, lo64): order_out[j] = element at sorted position j.
-// order_in must be 0..n-1 ascending.  All buffers device; tmp/tmp_bytes is rocPRIM's scratch (sized by the caller
-// through mesh_sort_tmp_bytes).
-inline size_t mesh_sort_tmp_bytes(const u32 n) {
-  size_t a = 0, b = 0, c = 0, d = 0;
-  (void) rocprim::radix_sort_pairs(nullptr, a, (u64*) nullptr, (u64*) nullptr, (u32*) nullptr, (u32*) nullptr, n);
-  (void) rocprim::radix_sort_pairs(nullptr, b, (u32*) nullptr, (u32*) nullptr, (u32*) nullptr, (u32*) nullptr, n);
-  (void) rocprim::inclusive_scan(nullptr, c, (u32*) nullptr, (u32*) nullptr, n, rocprim::maximum<u32>());
+inline size_t mesh_scan_tmp_bytes(const u32 n) {
+  size_t d = 0;
   (void) rocprim::exclusive_scan(nullptr, d, (u32*) nullptr, (u32*) nullptr, 0u, n, rocprim::plus<u32>());
-  size_t m = a > b ? a : b;
-  m = m > c ? m : c;
-  return m > d ? m : d;
-}
-
-inline hipError_t mesh_sort96(void* tmp, size_t tmp_bytes, const u32* hi, const u64* lo, u32* order_in, u32* order_mid, u32* order_out,
-                              u64* lo_sorted, u32* hi_gathered, u32* hi_sorted, const u32 n, hipStream_t s) {
-  hipError_t e = rocprim::radix_sort_pairs(tmp, tmp_bytes, lo, lo_sorted, order_in, order_mid, n, 0, 64, s);
-  if (e != hipSuccess) return e;
-  const u32 grid = (n + 255) / 256;
-  k_gather_u32<<<grid, 256, 0, s>>>(hi, order_mid, n, hi_gathered);
-  return rocprim::radix_sort_pairs(tmp, tmp_bytes, hi_gathered, hi_sorted, order_mid, order_out, n, 0, 32, s);
+  return d;
 }
 
 // per-block triangle runs of several ranks -> one buffer in canonical block order (mrh_process_triangle_runs): run r copies

@@ -125,6 +125,19 @@ PYBIND11_MODULE(pygeowrapper, m) {
       g.stream({pos.data()[0], pos.data()[1], pos.data()[2]}, radius);
     })
     .def("_hostGridBlocks", &GeoWrapper::hostGridBlocks)
+    // multi-GPU (include/mrhash_comm.h, no reference counterpart): RCCL behind the C ABI, one GeoWrapper per rank
+    .def_static("_commUniqueId", []() {
+      const auto id = GeoWrapper::commUniqueId();
+      return py::bytes((const char*) id.data(), id.size());
+    })
+    .def("_commInit", [](GeoWrapper& g, py::bytes id, int rank, int world, int chunk_log2, bool tile_sharded) {
+      const std::string b = id;
+      if (b.size() != MRH_COMM_ID_BYTES) throw std::runtime_error("GeoWrapper::_commInit|the id has 128 bytes");
+      std::array<uint8_t, MRH_COMM_ID_BYTES> a;
+      std::memcpy(a.data(), b.data(), a.size());
+      g.commInit(a, rank, world, chunk_log2, tile_sharded);
+    }, py::arg("id"), py::arg("rank"), py::arg("world"), py::arg("chunk_log2") = 3, py::arg("tile_sharded") = true)
+    .def("_mergeSubmaps", &GeoWrapper::mergeSubmaps)
     // splat seeds accumulated so far (what the reference hands to GaussianModel::Add_gaussians): (xyz, scale, rgb)
     .def("_splatSeeds", [](const GeoWrapper& g) {
       const auto& seeds = g.splatSeeds();

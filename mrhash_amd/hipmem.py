@@ -28,6 +28,7 @@ def runtime() -> C.CDLL:
         _hip.hipSetDevice.argtypes = [C.c_int]
         _hip.hipGetDeviceCount.argtypes = [C.POINTER(C.c_int)]
         _hip.hipDeviceSynchronize.argtypes = []
+        _hip.hipMemGetInfo.argtypes = [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
         _hip.hipGetErrorString.argtypes = [C.c_int]
         _hip.hipGetErrorString.restype = C.c_char_p
     return _hip
@@ -50,6 +51,13 @@ def set_device(index: int):
 
 def synchronize():
     _check(runtime().hipDeviceSynchronize(), "hipDeviceSynchronize")
+
+
+def mem_get_info():
+    """(free, total) bytes of the current device."""
+    f, t = C.c_size_t(), C.c_size_t()
+    _check(runtime().hipMemGetInfo(C.byref(f), C.byref(t)), "hipMemGetInfo")
+    return int(f.value), int(t.value)
 
 
 class DeviceBuffer:

@@ -144,6 +144,8 @@ struct mrh_ctx {
   /* mesh */
   mrh_triangle* tris;
   uint64_t ntris, cap_tris, max_triangles;
+  int merge_on;            /* MeshExtractor::merge_mesh_ (mrh_mesh_merge_begin / _end) */
+  uint64_t merge_total;    /* triangles of all extractions since begin */
   mrh_block_desc* tri_blocks;
   uint32_t* tri_counts;
   uint64_t n_tri_blocks;
@@ -1226,28 +1228,43 @@ int64_t orc_remove_duplicate_faces(const int32_t* in_f, int64_t nf, int32_t* out
   return nu;
 }
 
-/* mesh_extractor.cpp:9-76 processTriangles for one extraction (merge into an empty mesh) */
+/* mesh_extractor.cpp:9-76 processTriangles.  merge_mesh_ == false, or an empty running mesh: the new soup alone (:24-31).
+ * merge_mesh_ == true with a running mesh: `combine` appends the soup's vertices and its faces (shifted by the number of
+ * running vertices) to the running, already de-duplicated mesh, colours likewise (:32-37), and the whole goes through the
+ * vertex merge, first-assigned colours, degenerate-face and repeated-face removal again (:39-75) - restated literally,
+ * incrementally, as the reference runs it. */
 static void process_triangles(mrh_ctx* c) {
   const int64_t nt = (int64_t) c->ntris;
-  const int64_t n = nt * 3;
-  free(c->V); free(c->C); free(c->F);
-  c->V = c->C = NULL; c->F = NULL; c->nv = c->nf = 0;
+  const int merging = c->merge_on && (c->nv || c->nf);
+  const int64_t pv = merging ? (int64_t) c->nv : 0, pf = merging ? (int64_t) c->nf : 0; /* running mesh */
+  const int64_t n = pv + nt * 3, nfa = pf + nt;
+  if (!merging) {
+    free(c->V); free(c->C); free(c->F);
+    c->V = c->C = NULL; c->F = NULL; c->nv = c->nf = 0;
+  }
   if (nt == 0) return;
   double* nv = (double*) malloc((size_t) n * 3 * sizeof(double));
   double* nc = (double*) malloc((size_t) n * 3 * sizeof(double));
-  int32_t* nf = (int32_t*) malloc((size_t) nt * 3 * sizeof(int32_t));
+  int32_t* nf = (int32_t*) malloc((size_t) nfa * 3 * sizeof(int32_t));
+  if (merging) {
+    memcpy(nv, c->V, (size_t) pv * 3 * sizeof(double));
+    memcpy(nc, c->C, (size_t) pv * 3 * sizeof(double));
+    memcpy(nf, c->F, (size_t) pf * 3 * sizeof(int32_t));
+    free(c->V); free(c->C); free(c->F);
+    c->V = c->C = NULL; c->F = NULL; c->nv = c->nf = 0;
+  }
   for (int64_t i = 0; i < nt; i++)
     for (int k = 0; k < 3; k++) {
       for (int a = 0; a < 3; a++) {
-        nv[(i * 3 + k) * 3 + a] = (double) c->tris[i].v[k].p[a];
-        nc[(i * 3 + k) * 3 + a] = (double) c->tris[i].v[k].c[a];
+        nv[(pv + i * 3 + k) * 3 + a] = (double) c->tris[i].v[k].p[a];
+        nc[(pv + i * 3 + k) * 3 + a] = (double) c->tris[i].v[k].c[a];
       }
-      nf[i * 3 + k] = (int32_t) (i * 3 + k);
+      nf[(pf + i) * 3 + k] = (int32_t) (pv + i * 3 + k);
     }
   double* uv = (double*) malloc((size_t) n * 3 * sizeof(double));
-  int32_t* uf = (int32_t*) malloc((size_t) nt * 3 * sizeof(int32_t));
+  int32_t* uf = (int32_t*) malloc((size_t) nfa * 3 * sizeof(int32_t));
   int32_t* map = (int32_t*) malloc((size_t) n * sizeof(int32_t));
-  const int64_t nu = orc_remove_duplicate_vertices(nv, n, nf, nt, (double) c->p.vertices_merging_threshold, uv, uf, map);
+  const int64_t nu = orc_remove_duplicate_vertices(nv, n, nf, nfa, (double) c->p.vertices_merging_threshold, uv, uf, map);
   double* uc = (double*) malloc((size_t) (nu ? nu : 1) * 3 * sizeof(double));
   uint8_t* assigned = (uint8_t*) calloc((size_t) (nu ? nu : 1), 1);
   for (int64_t i = 0; i < n; i++) {
@@ -1255,7 +1272,7 @@ static void process_triangles(mrh_ctx* c) {
     if (!assigned[ni]) { uc[ni * 3 + 0] = nc[i * 3 + 0]; uc[ni * 3 + 1] = nc[i * 3 + 1]; uc[ni * 3 + 2] = nc[i * 3 + 2]; assigned[ni] = 1; }
   }
   int64_t kept = 0;
-  for (int64_t i = 0; i < nt; i++) {
+  for (int64_t i = 0; i < nfa; i++) {
     const int32_t a = uf[i * 3], b = uf[i * 3 + 1], d = uf[i * 3 + 2];
     if (a != b && a != d && b != d) { nf[kept * 3] = a; nf[kept * 3 + 1] = b; nf[kept * 3 + 2] = d; kept++; }
   }
@@ -1680,10 +1697,33 @@ int mrh_sync(mrh_ctx* c) {
   return MRH_OK;
 }
 
+/* geowrapper.cpp:157-161 (the running mesh starts empty; D10: colors_ too) ... :181 ... end of the chunk loop */
+int mrh_mesh_merge_begin(mrh_ctx* c) {
+  if (!c) return MRH_ERR_INVALID_ARG;
+  free(c->V); free(c->C); free(c->F);
+  c->V = c->C = NULL; c->F = NULL; c->nv = c->nf = 0;
+  c->merge_on = 1;
+  c->merge_total = 0;
+  return MRH_OK;
+}
+
+int mrh_mesh_merge_end(mrh_ctx* c, uint64_t* out_total_triangles) {
+  if (!c) return MRH_ERR_INVALID_ARG;
+  if (!c->merge_on) return fail(c, MRH_ERR_STATE, "mrh_mesh_merge_end: no merge in progress");
+  c->merge_on = 0;
+  if (out_total_triangles) *out_total_triangles = c->merge_total;
+  return MRH_OK;
+}
+
 int mrh_extract_triangles(mrh_ctx* c, const mrh_triangle** out, uint64_t* out_n) {
   if (!c || !out_n) return MRH_ERR_INVALID_ARG; /* out == NULL: count + mesh only (include/mrhash_hip.h) */
   extract_iso_surface(c);
-  process_triangles(c);
+  if (c->merge_on) {
+    c->merge_total += c->ntris;
+    if (c->ntris > 0) process_triangles(c); /* geowrapper.cpp:181-183 */
+  } else {
+    process_triangles(c);
+  }
   if (out) *out = c->tris;
   *out_n = c->ntris;
   return (c->error_flags & 8u) ? fail(c, MRH_ERR_CAPACITY, "triangle buffer full") : MRH_OK;

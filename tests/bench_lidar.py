@@ -6,22 +6,21 @@ import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-import torch
-from mrhash_amd import capi, synth
+from mrhash_amd import capi, hipmem, synth
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rows, cols = 128, 1024
 hip = capi.load_hip()
 scene = synth.street_canyon()
 poses = synth.drive_poses(n, step=0.5)
 scans = [synth.lidar_scan(scene, t, q, rows=rows, cols=cols) for t, q in poses]
-d_scans = [torch.from_numpy(s).cuda() for s in scans]
+d_scans = [hipmem.DeviceBuffer.from_numpy(np.ascontiguousarray(s, dtype=np.float32)) for s in scans]
 e = capi.Engine(hip, capi.Params(num_sdf_blocks=262144, **synth.VBR_PARAMS))
 e.set_camera(1, 1, 0, 0, 1, 1, 0.2, 100.0, model=1)
 def run(lo, hi):
     for i in range(lo, hi):
         t, q = poses[i]
         e.set_pose(synth.quat_to_rot(q), t)
-        e.set_points_device(d_scans[i].data_ptr(), len(scans[i]))
+        e.set_points_device(d_scans[i].ptr, len(scans[i]))
         e.integrate_points()
 run(0, 5); e.sync()
 t0 = time.perf_counter(); run(5, n); e.sync(); dt = time.perf_counter() - t0

@@ -223,6 +223,134 @@ def test_streamer_pages_far_blocks_out_and_back(monkeypatch, tmp_path, var_thres
     assert np.array_equal(Vb, Vs) and np.array_equal(Fb, Fs)
 
 
+def _chunk_of(desc, vs, ext=1.0):
+    """Streamer::worldToChunks of a block's origin (streamer.cuh:251-262, streamer.cpp:214-247)."""
+    out = []
+    for a in ("x", "y", "z"):
+        p = np.float32(np.float32(int(desc[a])) * np.float32(8.0 * vs)) / np.float32(ext)
+        s = np.float32(int(p > 0) - int(p < 0))
+        out.append(int(np.float32(p + s * np.float32(0.5))))
+    return tuple(out)
+
+
+def reference_chunk_loop(e, vs, max_depth, ext=1.0):
+    """GeoWrapper::extractMesh's control flow (geowrapper.cpp:150-190) over an engine behind the C ABI — here the ORACLE, whose
+    merge mode restates MeshExtractor::processTriangles on (running mesh + new soup) literally: stream everything out into a
+    chunk grid, computeBounds, walk the grid in steps of int(10 * max depth) chunks, stream the sphere in, extract, merge,
+    stream everything out again.  Returns (V, F, C, iterations that found blocks, blocks left on the engine)."""
+    descs, vox = e.stream_out((0.0, 0.0, 0.0), -1.0)
+    grid = {}
+    for k in range(len(descs)):
+        grid.setdefault(_chunk_of(descs[k], vs, ext), []).append(k)
+    keys = np.array(sorted(grid))
+    lo, hi = keys.min(axis=0), keys.max(axis=0)
+    hi = np.where(lo == hi, hi + 1, hi)
+    radius = np.float32(10.0) * np.float32(max_depth)
+    radiusi = max(1, int(radius))
+    chunk_radius = np.float32(np.sqrt(np.float32(3.0 * ext * ext)) / np.float32(2.0))
+    e.mesh_merge_begin()
+    used = 0
+    for x in range(lo[0], hi[0], radiusi):
+        for y in range(lo[1], hi[1], radiusi):
+            for z in range(lo[2], hi[2], radiusi):
+                c = np.array([x, y, z], np.float32) * np.float32(ext)
+                sel = []
+                for ch, idx in grid.items():
+                    d = np.array(ch, np.float32) * np.float32(ext) - c
+                    if np.sqrt(np.float32(d[0] * d[0] + d[1] * d[1] + d[2] * d[2])) <= abs(radius - chunk_radius):
+                        sel += idx
+                if not sel:
+                    continue
+                used += 1
+                e.import_blocks(descs[sel], vox[sel])
+                e.extract_triangles(soup=False)
+                e.stream_out((0.0, 0.0, 0.0), -1.0)  # the host copies above ARE the grid: nothing changed on the engine
+    total = e.mesh_merge_end()
+    V, F, C = e.extract_mesh()
+    return V, F, C, used, len(e.dump_blocks()[0]), total
+
+
+def test_extract_mesh_walks_the_chunk_grid_when_the_map_exceeds_sphere_and_pool(monkeypatch, oracle, tmp_path):
+    """The unbuilt half of SURVEY.md 8f-1, built: a 24 m wall seen from 0.4 m with max_depth 0.5 m — 10 * max depth = 5 m, so the
+    reference's extractMesh walks the chunk grid in five overlapping spheres (geowrapper.cpp:162-188) — fused through a pool
+    SMALLER than the final map (compute() pages), extracted through the chunk loop (no single sphere holds the map, and the
+    map does not fit the pool).  V / F / C must equal the oracle's, driven through the same control flow by
+    reference_chunk_loop above; afterwards the device map is empty and every block is on the host grid, as in the reference."""
+    from mrhash_amd import synth as sy
+
+    K = sy.CFG1
+    vs, max_depth = 0.02, 0.5
+    kw = dict(sdf_truncation=0.06, sdf_truncation_scale=0.0, integration_weight_sample=1, virtual_voxel_size=vs,
+              n_frames_invalidate_voxels=1000, voxel_extents_scale=1, viewer_active=False, marching_cubes_threshold=1.5,
+              min_weight_threshold=1, min_depth=0.01, max_depth=max_depth)
+    scene = sy.Scene(sy.Box((-2.0, -1.5, -1.0), (27.0, 1.5, 0.4)), seed=5)
+    poses = [(np.array([x, 0.0, 0.0], np.float32), np.array([0, 0, 0, 1], np.float32)) for x in np.arange(0.0, 24.01, 0.16)]
+    frames = [sy.render(scene, K, t, q, depth_scaling=5000.0) for t, q in poses]
+    pool = 384
+    monkeypatch.setenv("MRHASH_NUM_SDF_BLOCKS", str(pool))
+    from mrhash.src.pygeowrapper import GeoWrapper
+
+    g = GeoWrapper(**kw)
+    g.setCamera(K.fx, K.fy, K.cx, K.cy, K.rows, K.cols, 0.01, max_depth, 0)
+    b = pu.make_engine(oracle, K, dict(sy.CFG1_PARAMS, sdf_truncation=0.06, virtual_voxel_size=vs, n_frames_invalidate_voxels=1000,
+                                       min_weight_threshold=1, max_depth=max_depth), 16384)
+    b.set_camera(K.fx, K.fy, K.cx, K.cy, K.rows, K.cols, 0.01, max_depth)
+    peak = 0
+    for f in frames:
+        g.setCurrPose(f.t, f.q)
+        g.setDepthImage(f.depth)
+        g.setRGBImage(f.rgb)
+        g.compute()
+        peak = max(peak, g._hostGridBlocks())
+        pu.feed(b, f)
+    n_map = len(b.dump_blocks()[0])
+    assert n_map > pool and peak > 0, (n_map, peak)  # the map does not fit the pool; compute() paged
+    Vb, Fb, Cb, used, left_b, total_b = reference_chunk_loop(b, vs, max_depth)
+    assert used >= 4 and left_b == 0
+    g.extractMesh(str(tmp_path / "walk.ply"))
+    V, F, C = g.getVertices(), g.getFaces(), g.getColors()
+    assert len(Fb) > 20000 and total_b > len(Fb)  # overlapping spheres extract the same triangles more than once
+    assert V.shape == Vb.shape and F.shape == Fb.shape
+    assert np.array_equal(V, Vb) and np.array_equal(F, Fb) and np.allclose(C, Cb, atol=1e-5)
+    assert g._hostGridBlocks() == n_map  # post-state of the reference: the device map is empty, everything is on the host
+    # ... and fusion simply continues: the next frame pages its surroundings back in
+    f = frames[len(frames) // 2]
+    g.setCurrPose(f.t, f.q); g.setDepthImage(f.depth); g.setRGBImage(f.rgb); g.compute()
+    assert 0 < g._hostGridBlocks() < n_map
+    # a second extraction gives the same mesh (the running mesh starts empty: D10)
+    g.extractMesh(str(tmp_path / "walk2.ply"))
+    assert np.array_equal(g.getVertices(), Vb) and np.array_equal(g.getFaces(), Fb)
+
+
+def test_extract_mesh_refuses_a_sphere_larger_than_the_pool_without_moving_blocks(monkeypatch, tmp_path):
+    """A map that neither fits the pool nor splits into spheres that do: extractMesh raises BEFORE importing anything, and
+    every block stays in exactly one place (round 2: the import failed half-way, blocks on both sides)."""
+    from mrhash_amd import synth as sy
+
+    K = sy.CFG1
+    kw = dict(sdf_truncation=0.06, sdf_truncation_scale=0.0, integration_weight_sample=1, virtual_voxel_size=0.02,
+              n_frames_invalidate_voxels=1000, voxel_extents_scale=1, viewer_active=False, marching_cubes_threshold=1.5,
+              min_weight_threshold=1, min_depth=0.01, max_depth=2.0)
+    scene = sy.Scene(sy.Box((-2.0, -1.5, -1.0), (23.0, 1.5, 0.4)), seed=5)
+    poses = [(np.array([x, 0.0, 0.0], np.float32), np.array([0, 0, 0, 1], np.float32)) for x in np.arange(0.0, 20.01, 0.16)]
+    monkeypatch.setenv("MRHASH_NUM_SDF_BLOCKS", "384")
+    from mrhash.src.pygeowrapper import GeoWrapper
+
+    g = GeoWrapper(**kw)
+    g.setCamera(K.fx, K.fy, K.cx, K.cy, K.rows, K.cols, 0.01, 2.0, 0)
+    for t, q in poses:
+        f = sy.render(scene, K, t, q, depth_scaling=5000.0)
+        g.setCurrPose(f.t, f.q); g.setDepthImage(f.depth); g.setRGBImage(f.rgb); g.compute()
+    g.streamAllOut()
+    before = g._hostGridBlocks()
+    assert before > 0
+    with pytest.raises(RuntimeError, match="holds .* blocks, the pool has"):
+        g.extractMesh(str(tmp_path / "no.ply"))
+    after = g._hostGridBlocks()
+    assert after > 384 and after >= before  # everything on the host grid, nothing lost, nothing doubled
+    assert len(g.getVertices()) == 0
+
+
 def test_gs_runner_sequence_accumulates_splat_seeds(geowrapper_cls, oracle, tmp_path):
     """apps/rgbd_gs_runner.py: the constructor gets configurations/params.json, every compute() seeds splats from the
     frame's quad-tree (geowrapper.cpp:142-143), GSSavePointCloud writes them; the optimiser itself is out of scope."""

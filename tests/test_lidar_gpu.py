@@ -82,16 +82,16 @@ def test_many_beams_per_voxel_follow_the_point_order(hip, oracle):
 
 
 def test_far_from_origin_and_device_pointer(hip, oracle):
-    import torch
+    from mrhash_amd import hipmem
 
     a, b = _pair(hip, oracle)
     scene = synth.street_canyon()
     off = np.array([900.0, -700.0, 120.0], np.float32)  # beyond the verified voxel->block shift range
     for t, q in synth.drive_poses(2, step=2.0):
         pts = synth.lidar_scan(scene, t, q, rows=16, cols=256)
-        d_pts = torch.from_numpy(pts).cuda()
+        d_pts = hipmem.DeviceBuffer.from_numpy(pts.astype(np.float32))
         a.set_pose(synth.quat_to_rot(q), t + off)
-        a.set_points_device(d_pts.data_ptr(), len(pts))
+        a.set_points_device(d_pts.ptr, len(pts))
         a.integrate_points()
         a.sync()
         b.set_pose(synth.quat_to_rot(q), t + off)

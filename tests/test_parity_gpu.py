@@ -381,6 +381,31 @@ def test_replica_640x480_stream(hip, oracle):
     assert m["triangles"] > 100000 and m["pos_bit_exact"]
 
 
+def test_roofline_counters_equal_the_oracles_per_frame(hip, oracle):
+    """"U, M come from the oracle's counters for the same frame".  bench.py's roofline numerator is
+    24 * U + 24 * M + 7 * H * W with U = voxels the integrate launch updates and M = compact (in-frustum) blocks, both counted on the
+    device in profile mode (k_count_updates re-evaluates the update predicate; the list counters).  Here those two numbers are
+    compared with the oracle's own counters — integrate_voxel's return values summed (vds.cu:1162-1180 reached) and the length of
+    the compacted list (vds.cu:447) — frame by frame on the 640x480 stream, GC on."""
+    a, b = _pair(hip, oracle, synth.REPLICA_640, synth.REPLICA_PARAMS, 131072)
+    a.set_profile(True)
+    tot_u = tot_m = 0
+    for f in synth.replica_stream(6):
+        pu.feed(a, f)
+        pu.feed(b, f)
+        sa, sb = a.stats(), b.stats()
+        assert sa.last_updated_voxels == sb.last_updated_voxels, (sa.last_updated_voxels, sb.last_updated_voxels)
+        assert sa.last_compact_blocks == sb.last_compact_blocks, (sa.last_compact_blocks, sb.last_compact_blocks)
+        tot_u += int(sb.last_updated_voxels)
+        tot_m += int(sb.last_compact_blocks)
+    sa = a.stats()
+    assert int(sa.total_updated_voxels) == tot_u and int(sa.total_compact_blocks) == tot_m
+    assert tot_u > 10_000_000 and tot_m > 30_000
+    assert sa.n_integrate_kernel == 6 and sa.n_front_kernel == 6 and sa.sum_integrate_kernel_ms > 0 and sa.sum_front_kernel_ms > 0
+    a.set_profile(False)
+    pu.compare_maps(a, b)  # the counting pass changes nothing
+
+
 def test_replica_640x480_crosses_the_starve_period_of_the_shipped_configuration(hip, oracle):
     """replica.cfg as shipped: GC every frame, starve every 100th.  103 frames of the 640x480 stream, so that frame 100 — the
     first starve frame of the shipped period, with the table churn and the high-water mark of a hundred frames behind it —
@@ -870,7 +895,7 @@ def test_marching_cubes_prescreen_changes_nothing(hip, monkeypatch):
 def test_contexts_release_their_device_memory(hip):
     """Create / use / destroy in a loop (uploads, frames, seeds, extraction — every lazily allocated buffer gets
     allocated): the free device memory afterwards is what it was before."""
-    import torch
+    from mrhash_amd import hipmem
 
     K = synth.CFG1
     f = synth.cfg1_sphere()
@@ -889,10 +914,10 @@ def test_contexts_release_their_device_memory(hip):
 
     for _ in range(3):  # the first uses pay one-off runtime allocations (code objects, queues, scratch)
         cycle()
-    torch.cuda.synchronize()
-    free0, _ = torch.cuda.mem_get_info()
+    hipmem.synchronize()
+    free0, _ = hipmem.mem_get_info()
     for _ in range(25):
         cycle()
-    torch.cuda.synchronize()
-    free1, _ = torch.cuda.mem_get_info()
+    hipmem.synchronize()
+    free1, _ = hipmem.mem_get_info()
     assert free0 - free1 < 32 << 20, f"device memory shrank by {(free0 - free1) >> 20} MiB over 25 create/destroy cycles"

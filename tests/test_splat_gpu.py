@@ -140,3 +140,44 @@ def test_multires_map_and_moving_camera(hip, oracle):
     assert n[-1][1] > 0
     a.close()
     b.close()
+
+
+def test_first_seeding_call_and_a_camera_change_leave_the_other_buffers_alone(hip, oracle):
+    """Round-2 advisor finding: the quad-tree (re)allocation branch of mrh_splat_seeds — first call, or another image shape —
+    also released the soup / pack / halo / cloud buffers and the marching-cubes events while their capacities stayed, so the
+    next extraction wrote triangles through a null pointer.  Sequence: integrate, extract, first seeding call, extract again,
+    another camera shape, seed, extract, pack; every step against the oracle."""
+    a = pu.make_engine(hip, synth.CFG1, dict(synth.CFG1_PARAMS), 16384)
+    b = pu.make_engine(oracle, synth.CFG1, dict(synth.CFG1_PARAMS), 16384)
+    f = synth.cfg1_sphere()
+    for e in (a, b):
+        pu.feed(e, f)
+    a.set_profile(True)  # the marching-cubes launches carry events in profile mode: they must survive the seeding call, too
+    m0 = pu.compare_meshes(a, b)
+    _same(a, b, 0.002, 1)                      # first call: quad-tree buffers are allocated
+    m1 = pu.compare_meshes(a, b)               # the soup buffer of the first extraction is still there
+    assert m1["triangles"] == m0["triangles"] > 1000 and a.stats().last_mc_count_ms > 0
+    a.set_sharding(0, 2, 1)
+    ptr, n, dev = a.pack_blocks(capi.PACK_OWNER, 0)
+    assert n > 0 and dev
+    a.set_sharding(0, 1, 0)
+    # another image shape: the quad-tree buffers are re-allocated
+    K2 = synth.Intrinsics(96.0, 96.0, 48.0, 40.0, 80, 96)
+    rng = np.random.default_rng(3)
+    depth = (1.2 + 0.1 * rng.random((80, 96))).astype(F32)
+    rgb = synth.textured_image(80, 96, seed=2)
+    for e in (a, b):
+        e.set_camera(K2.fx, K2.fy, K2.cx, K2.cy, K2.rows, K2.cols, 0.01, 30.0)
+        e.set_pose(np.eye(3, dtype=F32), np.zeros(3, F32))
+        e.upload_depth(depth)
+        e.upload_rgb(rgb)
+        assert not e.integrate()
+    _same(a, b, 0.001, 1)
+    pu.compare_meshes(a, b)
+    a.set_sharding(0, 2, 1)
+    ptr2, n2, _ = a.pack_blocks(capi.PACK_OWNER, 0)
+    assert n2 >= n
+    a.set_sharding(0, 1, 0)
+    pu.compare_maps(a, b)
+    a.close()
+    b.close()
