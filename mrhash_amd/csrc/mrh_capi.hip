@@ -121,12 +121,10 @@ struct mrh_ctx {
   uint64_t frame_seq = 1;
   // pool level for the host without a read-back stall (mrh_peek_free_blocks): a 2-int D2H per frame into pinned memory
   int* h_peek = nullptr;               // [8][8] pinned: ctr[0 .. 4] = free-list levels ... error flags per report
-  u32* h_scan = nullptr;               // pinned {hwm, last offset, last count, sequence}: the mid-scan report of mrh_integrate_points
   // grow-only device scratch of the extraction (0: block list / counts / per-voxel counts, 1: mesh post-process, 2: V / C / F):
   // a mesh of a million triangles needs ~400 MB of temporaries, and hipMalloc + hipFree of those cost more than the kernels
   void* arena[3] = {nullptr, nullptr, nullptr};
   size_t arena_cap[3] = {0, 0, 0};
-  u32 scan_seq = 0;
   uint64_t peek_seq[8] = {};
   bool peek_enabled = false;
   const float* d_depth = nullptr;
@@ -155,7 +153,9 @@ struct mrh_ctx {
   const float* d_points_cur = nullptr;  // ... or the caller's device pointer (mrh_set_points_device)
   uint64_t points_cap = 0, num_points = 0;
   u32* d_pt_counts = nullptr; u32* d_pt_offsets = nullptr; uint64_t pt_cap = 0;
-  u64* d_rec_keys[2] = {nullptr, nullptr}; float* d_rec_vals[2] = {nullptr, nullptr}; uint64_t rec_cap = 0;
+  u32* h_scan = nullptr;               // pinned {hwm, last offset, last count, sequence}: the one report of a scan
+  u32 scan_seq = 0;
+  void* d_rec_keys[2] = {nullptr, nullptr}; float* d_rec_vals[2] = {nullptr, nullptr}; uint64_t rec_cap = 0; size_t rec_key_bytes = 0;
   void* d_sort_tmp = nullptr; size_t sort_tmp_bytes = 0;
   // 3DGS splat seeds (mrh_splat.h): sized for one (image shape, min pixel size)
   QTree qt = {0, 0, 0, 0, 0};
@@ -299,8 +299,8 @@ void free_all(mrh_ctx* c) {
     }
   for (hipEvent_t e : c->frame_done) if (e) (void) hipEventDestroy(e);
   if (c->h_peek) (void) hipHostFree(c->h_peek);
-  if (c->h_scan) (void) hipHostFree(c->h_scan);
   if (c->h_mc) (void) hipHostFree(c->h_mc);
+  if (c->h_scan) (void) hipHostFree(c->h_scan);
   for (void* a : c->arena) if (a) (void) hipFree(a);
   F(c->d_decision); F(c->d_zbuf); F(c->d_realloc); F(c->d_reint); F(c->d_flag);
   F(c->d_upd_partials); F(c->d_misc); F(c->d_rcp_w); F(c->d_cfree); F(c->d_zmin); F(c->d_points); F(c->d_pt_counts); F(c->d_pt_offsets); F(c->d_rec_keys[0]); F(c->d_rec_keys[1]); F(c->d_rec_vals[0]); F(c->d_rec_vals[1]); F(c->d_sort_tmp); F(c->fast.summary); F(c->fast.summary_c); F(c->fast.bbox); F(c->d_cnt_partials);
@@ -1392,6 +1392,38 @@ int mrh_upload_normals(mrh_ctx* c, const float* nxyz, uint64_t n) {
   return MRH_OK;
 }
 
+}  // extern "C"
+
+namespace {
+// stable radix sort of the scan's (voxel id, sdf) records on key bits [0, end_bit): the padding key (all ones) ends up last,
+// equal ids keep their point-major order
+template <typename Config, typename K>
+int lidar_sort_with(mrh_ctx* c, K* k0, K* k1, float* v0, float* v1, const size_t n, const int end_bit) {
+  hipStream_t s = c->stream;
+  size_t need = 0;
+  HIP_TRY(c, rocprim::radix_sort_pairs<Config>(nullptr, need, k0, k1, v0, v1, n, 0, end_bit, s));
+  if (need > c->sort_tmp_bytes) {
+    HIP_TRY(c, hipStreamSynchronize(s));
+    if (c->d_sort_tmp) HIP_TRY(c, hipFree(c->d_sort_tmp));
+    c->d_sort_tmp = nullptr;
+    HIP_TRY(c, hipMalloc(&c->d_sort_tmp, need));
+    c->sort_tmp_bytes = need;
+  }
+  size_t tb = c->sort_tmp_bytes;
+  HIP_TRY(c, rocprim::radix_sort_pairs<Config>(c->d_sort_tmp, tb, k0, k1, v0, v1, n, 0, end_bit, s));
+  return MRH_OK;
+}
+template <typename K>
+int lidar_sort(mrh_ctx* c, K* k0, K* k1, float* v0, float* v1, const size_t n, const int end_bit) {
+  // merge-sort limit 0: always the onesweep path (rocPRIM would sort up to 2^20 items with block sort + ~10 merge passes).
+  // 8-bit digits are the widest it offers: its onesweep kernel keeps a per-digit table per thread in LDS (9 bits: 512 KiB).
+  using Cfg = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 0>;
+  return lidar_sort_with<Cfg>(c, k0, k1, v0, v1, n, end_bit);
+}
+}  // namespace
+
+extern "C" {
+
 // VoxelContainer::integrate(point_cloud, ...) voxel_data_structures.cpp:112-135 (mrh_lidar.h)
 int mrh_integrate_points(mrh_ctx* c, int n_frames_invalidate) {
   int rc = ensure_ready(c, "mrh_integrate_points");
@@ -1424,6 +1456,36 @@ int mrh_integrate_points(mrh_ctx* c, int n_frames_invalidate) {
       k_refill<<<(c->low_blocks_to_allocate + 255) / 256, 256, 0, s>>>(t, c->low_blocks_to_allocate, c->d_flag);
     }
     k_alloc3d<<<grid, 256, 0, s>>>(k, m, t, c->fast, pts, normals, np, stamp);
+    // ---- integrate3D (vds.cu:1215-1410): records of every (point, voxel) in point-major order -> stable sort by voxel -> fold.
+    // The record buffers are sized by a bound the host can compute (a beam crosses at most `slots` voxels), so the emit pass
+    // needs nothing from the host and runs WHILE the host picks up the scan's one report (record count, high-water mark: they
+    // size the sort): count -> scan -> report -> emit are enqueued together, the sort and the fold follow the report.
+    // slots: the voxel-level DDA walks from voxel(p_min) to voxel(p_max), |p_max - p_min| <= 2 tr, tr <= trunc + scale *
+    // integration distance: at most sum_axis(|end - start|) + 1 steps <= (2 tr / vs) * sqrt(3) + 3, plus the roundings
+    const double tr_max = (double) m.trunc + (double) m.trunc_scale * (double) k.max_int_dist;
+    const uint64_t slots = std::min<uint64_t>(kMaxDdaIter, (uint64_t) std::floor(2.0 * tr_max / (double) m.vs * 1.7320508) + 10);
+    const uint64_t rec_bound = n * slots;
+    if (rec_bound >= 0xFFFFFFF0ull) return fail(c, MRH_ERR_CAPACITY, "mrh_integrate_points: %llu points x %llu voxels per beam exceed 2^32 records per scan", (unsigned long long) n, (unsigned long long) slots);
+    // key width from the pool capacity: voxel id < cap * 512, one more bit for coarse units
+    auto bits_for = [](uint64_t max_value) { int b = 1; while (b < 63 && (max_value >> b)) b++; return b; };
+    const int coarse_bit = bits_for((uint64_t) c->num_blocks * 512 - 1);
+    const bool wide = coarse_bit + (t.multi_res ? 1 : 0) > 32;
+    const size_t key_bytes = wide ? 8 : 4;
+    if (rec_bound > c->rec_cap || key_bytes > c->rec_key_bytes) {
+      HIP_TRY(c, hipStreamSynchronize(s));
+      for (int b = 0; b < 2; b++) {
+        if (c->d_rec_keys[b]) HIP_TRY(c, hipFree(c->d_rec_keys[b]));
+        if (c->d_rec_vals[b]) HIP_TRY(c, hipFree(c->d_rec_vals[b]));
+        c->d_rec_keys[b] = nullptr; c->d_rec_vals[b] = nullptr;
+      }
+      const uint64_t cap = std::max<uint64_t>(rec_bound, c->rec_cap);
+      for (int b = 0; b < 2; b++) {
+        HIP_TRY(c, hipMalloc((void**) &c->d_rec_keys[b], cap * std::max(key_bytes, c->rec_key_bytes)));
+        HIP_TRY(c, hipMalloc((void**) &c->d_rec_vals[b], cap * sizeof(float)));
+      }
+      c->rec_cap = cap;
+      c->rec_key_bytes = std::max(key_bytes, c->rec_key_bytes);
+    }
     if (n > c->pt_cap) {
       HIP_TRY(c, hipStreamSynchronize(s));
       if (c->d_pt_counts) HIP_TRY(c, hipFree(c->d_pt_counts));
@@ -1433,33 +1495,29 @@ int mrh_integrate_points(mrh_ctx* c, int n_frames_invalidate) {
       HIP_TRY(c, hipMalloc((void**) &c->d_pt_offsets, n * sizeof(u32)));
       c->pt_cap = n;
     }
-    auto ensure_tmp = [&](size_t bytes) -> int {
-      if (bytes <= c->sort_tmp_bytes) return MRH_OK;
-      HIP_TRY(c, hipStreamSynchronize(s));
-      if (c->d_sort_tmp) HIP_TRY(c, hipFree(c->d_sort_tmp));
-      c->d_sort_tmp = nullptr;
-      HIP_TRY(c, hipMalloc(&c->d_sort_tmp, bytes));
-      c->sort_tmp_bytes = bytes;
-      return MRH_OK;
-    };
-    // integrate3D (vds.cu:1215-1410): records of every (point, voxel) -> sorted by voxel, stable in the point index -> folded
+    if (!c->h_scan) {
+      HIP_TRY(c, hipHostMalloc((void**) &c->h_scan, 4 * sizeof(u32), hipHostMallocDefault));
+      memset(c->h_scan, 0, 4 * sizeof(u32));
+    }
     auto integrate_scan = [&]() -> int {
-      k_points_walk<false><<<grid, 256, 0, s>>>(k, m, t, pts, normals, np, c->d_pt_counts, nullptr, nullptr, nullptr, 0);
+      k_points_walk<false, u32><<<grid, 256, 0, s>>>(k, m, t, pts, normals, np, c->d_pt_counts, nullptr, (u32*) nullptr, nullptr, coarse_bit);
       size_t need = 0;
       HIP_TRY(c, rocprim::exclusive_scan(nullptr, need, c->d_pt_counts, c->d_pt_offsets, 0u, n, rocprim::plus<u32>(), s));
-      int r = ensure_tmp(need);
-      if (r) return r;
+      if (need > c->sort_tmp_bytes) {
+        HIP_TRY(c, hipStreamSynchronize(s));
+        if (c->d_sort_tmp) HIP_TRY(c, hipFree(c->d_sort_tmp));
+        c->d_sort_tmp = nullptr;
+        HIP_TRY(c, hipMalloc(&c->d_sort_tmp, need));
+        c->sort_tmp_bytes = need;
+      }
       size_t tb = c->sort_tmp_bytes;
       HIP_TRY(c, rocprim::exclusive_scan(c->d_sort_tmp, tb, c->d_pt_counts, c->d_pt_offsets, 0u, n, rocprim::plus<u32>(), s));
-      // the one host round trip of a scan (the record count sizes the sort): a one-lane kernel writes the three numbers and
-      // a sequence mark into pinned memory and the host watches the mark — three small hipMemcpyAsync + a stream
-      // synchronisation cost ~60 us of host and copy-engine latency per scan with the device idle meanwhile
-      if (!c->h_scan) {
-        HIP_TRY(c, hipHostMalloc((void**) &c->h_scan, 4 * sizeof(u32), hipHostMallocDefault));
-        memset(c->h_scan, 0, 4 * sizeof(u32));
-      }
+      // the one host round trip of a scan: a one-lane kernel writes {high-water mark, last offset, last count} and a sequence
+      // mark into pinned memory; the emit pass is enqueued behind it and runs while the report travels and the host reads it
       const u32 seq = ++c->scan_seq;
       k_scan_report<<<1, 64, 0, s>>>(t.ctr, c->d_pt_offsets, c->d_pt_counts, np, c->h_scan, seq);
+      if (wide) k_points_walk<true, u64><<<grid, 256, 0, s>>>(k, m, t, pts, normals, np, nullptr, c->d_pt_offsets, (u64*) c->d_rec_keys[0], c->d_rec_vals[0], coarse_bit);
+      else k_points_walk<true, u32><<<grid, 256, 0, s>>>(k, m, t, pts, normals, np, nullptr, c->d_pt_offsets, (u32*) c->d_rec_keys[0], c->d_rec_vals[0], coarse_bit);
       HIP_TRY(c, hipGetLastError());
       {
         volatile u32* mark = c->h_scan + 3;
@@ -1474,40 +1532,24 @@ int mrh_integrate_points(mrh_ctx* c, int n_frames_invalidate) {
         std::atomic_thread_fence(std::memory_order_acquire);
       }
       const int hwm = (int) c->h_scan[0];
-      const u32 last_off = c->h_scan[1], last_cnt = c->h_scan[2];
-      const uint64_t n_rec = (uint64_t) last_off + last_cnt;
-      if (n_rec >= 0xFFFFFFF0ull) return fail(c, MRH_ERR_CAPACITY, "mrh_integrate_points: %llu voxel updates in one scan", (unsigned long long) n_rec);
+      const uint64_t n_rec = (uint64_t) c->h_scan[1] + c->h_scan[2];
+      if (n_rec > rec_bound) return fail(c, MRH_ERR_DEVICE, "mrh_integrate_points: %llu records exceed the bound of %llu", (unsigned long long) n_rec, (unsigned long long) rec_bound);
       if (n_rec == 0) return MRH_OK;
-      if (n_rec > c->rec_cap) {
-        for (int b = 0; b < 2; b++) {
-          if (c->d_rec_keys[b]) HIP_TRY(c, hipFree(c->d_rec_keys[b]));
-          if (c->d_rec_vals[b]) HIP_TRY(c, hipFree(c->d_rec_vals[b]));
-          c->d_rec_keys[b] = nullptr; c->d_rec_vals[b] = nullptr;
-        }
-        const uint64_t cap = n_rec + n_rec / 4;
-        for (int b = 0; b < 2; b++) {
-          HIP_TRY(c, hipMalloc((void**) &c->d_rec_keys[b], cap * sizeof(u64)));
-          HIP_TRY(c, hipMalloc((void**) &c->d_rec_vals[b], cap * sizeof(float)));
-        }
-        c->rec_cap = cap;
+      // the sort only looks at the bits a voxel id of THIS map can have (the high-water mark of the pool); it is stable, and the
+      // records were emitted in point order: every voxel's run ends up in ascending point index (D6)
+      const int end_bit = t.multi_res ? coarse_bit + 1 : bits_for((uint64_t) (hwm > 0 ? hwm : 1) * 512 - 1);
+      const u32 agrid = (u32) ((n_rec + kApplyChunk - 1) / kApplyChunk);
+      int r;
+      if (wide) {
+        r = lidar_sort(c, (u64*) c->d_rec_keys[0], (u64*) c->d_rec_keys[1], c->d_rec_vals[0], c->d_rec_vals[1], (size_t) n_rec, end_bit);
+        if (r) return r;
+        k_points_apply<u64><<<agrid, 256, 0, s>>>(m, t, (const u64*) c->d_rec_keys[1], c->d_rec_vals[1], (u32) n_rec, coarse_bit, c->profile);
+      } else {
+        r = lidar_sort(c, (u32*) c->d_rec_keys[0], (u32*) c->d_rec_keys[1], c->d_rec_vals[0], c->d_rec_vals[1], (size_t) n_rec, end_bit);
+        if (r) return r;
+        k_points_apply<u32><<<agrid, 256, 0, s>>>(m, t, (const u32*) c->d_rec_keys[1], c->d_rec_vals[1], (u32) n_rec, coarse_bit, c->profile);
       }
-      // sort key = voxel id above the point index.  The records are emitted in (point, step) order and an LSD radix sort is
-      // stable, so sorting on the voxel bits alone already leaves every voxel's run in ascending point index (D6): the
-      // point bits stay in the key for k_points_apply but take no part in the passes
-      // rocPRIM sorts up to 2^20 items with block sort + log2(n / block) merge passes (10 x 2 launches for one scan's
-      // ~650 k records); with ~21 significant bits the onesweep radix path is 1 histogram + 3 passes
-      using LidarSortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 0>;
-      auto bits_for = [](uint64_t max_value) { int b = 1; while (b < 63 && (max_value >> b)) b++; return b; };
-      const int pbits = bits_for(n - 1);
-      const int end_bit = pbits + (t.multi_res ? 38 : bits_for((uint64_t) (hwm > 0 ? hwm : 1) * 512 - 1));  // coarse flag: bit 37 of the voxel id
-      k_points_walk<true><<<grid, 256, 0, s>>>(k, m, t, pts, normals, np, nullptr, c->d_pt_offsets, c->d_rec_keys[0], c->d_rec_vals[0], pbits);
-      need = 0;
-      HIP_TRY(c, rocprim::radix_sort_pairs<LidarSortConfig>(nullptr, need, c->d_rec_keys[0], c->d_rec_keys[1], c->d_rec_vals[0], c->d_rec_vals[1], n_rec, pbits, end_bit, s));
-      r = ensure_tmp(need);
-      if (r) return r;
-      tb = c->sort_tmp_bytes;
-      HIP_TRY(c, rocprim::radix_sort_pairs<LidarSortConfig>(c->d_sort_tmp, tb, c->d_rec_keys[0], c->d_rec_keys[1], c->d_rec_vals[0], c->d_rec_vals[1], n_rec, pbits, end_bit, s));
-      k_points_apply<<<(u32) ((n_rec + 255) / 256), 256, 0, s>>>(m, t, c->d_rec_keys[1], c->d_rec_vals[1], (u32) n_rec, pbits);
+      HIP_TRY(c, hipGetLastError());
       return MRH_OK;
     };
     rc = integrate_scan();
@@ -1769,7 +1811,7 @@ int mrh_get_stats(mrh_ctx* c, mrh_stats* out) {
   HIP_TRY(c, hipGetLastError());
   rc = drain_events(c);
   if (rc) return rc;
-  u64 total_upd = 0;
+  u64 total_upd = h_prof[PROF_UPDATED];  // LiDAR scans (k_points_apply); the image paths count through the partials
   for (u64 v : partials) total_upd += v;
   memset(out, 0, sizeof *out);
   out->frames_integrated = c->frames;
@@ -1860,7 +1902,7 @@ int mrh_extract_triangles(mrh_ctx* c, const mrh_triangle** out_tris, uint64_t* o
       k_list_keys<<<(n + 255) / 256, 256, 0, s>>>(c->tab.compact, n, k_in);
       size_t bytes = tmp_bytes;
       HIP_TRY(c, rocprim::radix_sort_pairs(tmp, bytes, k_in, k_out, c->tab.compact, sorted, (size_t) n, 0, 63, s));
-      k_mc_neighbors<<<(int) (((size_t) n * 32 + 255) / 256), 256, 0, s>>>(c->tab, sorted, n, d_nb);
+      k_mc_neighbors<<<(int) (((size_t) n * 64 + 255) / 256), 256, 0, s>>>(c->tab, sorted, n, d_nb);
     }
     if (dbg) { HIP_TRY(c, hipStreamSynchronize(s)); t1 = now(); }
     const int grid = n < 8192 ? n : 8192;

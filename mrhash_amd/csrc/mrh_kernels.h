@@ -590,7 +590,7 @@ __global__ __launch_bounds__(64) void k_reintegrate(const Cam c, const Map m, co
 __global__ __launch_bounds__(256) void k_init_table(u64* keys, const size_t slots) {
   for (size_t i = (size_t) blockIdx.x * 256 + threadIdx.x; i < slots; i += (size_t) gridDim.x * 256) keys[i] = kKeyEmpty;
 }
-// mid-scan report of mrh_integrate_points into pinned host memory: {high-water mark, last offset, last count}, then the mark
+// the one report of a LiDAR scan (mrh_integrate_points) into pinned host memory: {high-water mark, last offset, last count}, then the mark
 __global__ void k_scan_report(const int* __restrict__ ctr, const u32* __restrict__ offsets, const u32* __restrict__ counts, const u32 n,
                               u32* __restrict__ host_rec, const u32 seq) {
   if (threadIdx.x != 0) return;

@@ -8,11 +8,13 @@
 //                    set, then one probe per distinct key and the lock-free insert of mrh_fast2.h (no mutex, no retry).
 //   k_points_walk    integrate3DKernel vds.cu:1215-1379, split in two so that the result does not depend on a race:
 //                    the reference updates a voxel with a non-atomic read-modify-write per point.  Here a point's
-//                    VOXEL-level DDA only produces (voxel, point, clamped sdf) records — counted, prefix-summed and
-//                    written at exact offsets, no atomics — the records are sorted by (voxel, point index)
-//                    (rocPRIM radix sort on a 55-bit key) and
-//   k_points_apply   one lane per voxel folds its records in ascending point index (combineVoxel, vhu.cuh:167-181, and
-//                    the variance term) — the oracle's sequential order (D6), with plain coalesced loads and stores.
+//                    VOXEL-level DDA only produces (voxel id, clamped sdf) records — counted, prefix-summed and written at
+//                    exact offsets in point-major order, no atomics.  The records are sorted by voxel id with a STABLE radix
+//                    sort (rocPRIM onesweep over the id's significant bits), which keeps every voxel's records in ascending
+//                    point index, and
+//   k_points_apply   folds each voxel's run in that order (combineVoxel, vhu.cuh:167-181, and the variance term) — the
+//                    oracle's sequential order (D6).  A workgroup stages a chunk of the sorted records in LDS; the lane at
+//                    the head of a run walks it there instead of through dependent global loads (round 2: 57 us per scan).
 #pragma once
 
 #include <rocprim/rocprim.hpp>
@@ -32,7 +34,8 @@ __device__ __forceinline__ i3 voxel_to_block_fast(const Map& m, const i3 v) {
   return voxel_to_block(v, m.vs);
 }
 
-constexpr u64 kVidCoarse = 1ull << 37;  // record key: voxel id = fine block index * 512 + local index (< 2^37), this bit = coarse unit
+// record key = voxel id: fine block index * 512 + local index; on a coarse unit u = 8 H + k: (H * 512 + k * 64 + local index) | coarse bit,
+// coarse bit = 1 << (9 + bits of the pool capacity) — the host picks the key width (32 or 64 bits) from it.
 
 __global__ __launch_bounds__(256) void k_alloc3d(const Cam c, const Map m, const Tab t, const Fast f, const float* __restrict__ pts,
                                                  const float* __restrict__ normals, const u32 n, const u32 stamp) {
@@ -124,15 +127,13 @@ __global__ __launch_bounds__(256) void k_alloc3d(const Cam c, const Map m, const
 }
 
 // One record per (point, traversed voxel of an allocated block) up to the first voxel with sdf <= -truncation.
-// EMIT = false: counts[i] = number of records of point i.  EMIT = true: records written at offsets[i]...
-//   key = voxel id << pbits | point index     value = the clamped sdf
-//   voxel id = fine block index * 512 + local index; on a coarse unit u = 8 H + k: H * 512 + k * 64 + local index, | kVidCoarse
-// (pbits = bits needed for the point index: the sort then only has to look at pbits + bits(voxel id) key bits)
-template <bool EMIT>
+// EMIT = false: counts[i] = number of records of point i.  EMIT = true: records written at offsets[i] ...: key = voxel id,
+// value = the clamped sdf.
+template <bool EMIT, typename K>
 __global__ __launch_bounds__(256) void k_points_walk(const Cam c, const Map m, const Tab t, const float* __restrict__ pts,
                                                      const float* __restrict__ normals, const u32 n, u32* __restrict__ counts,
-                                                     const u32* __restrict__ offsets, u64* __restrict__ keys, float* __restrict__ vals,
-                                                     const int pbits) {
+                                                     const u32* __restrict__ offsets, K* __restrict__ keys, float* __restrict__ vals,
+                                                     const int coarse_bit) {
   const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   u32 cnt = 0;
@@ -174,13 +175,21 @@ __global__ __launch_bounds__(256) void k_points_walk(const Cam c, const Map m, c
     t_max.x = gx ? kFltMax : t_max.x; t_delta.x = gx ? kFltMax : t_delta.x;
     t_max.y = gy ? kFltMax : t_max.y; t_delta.y = gy ? kFltMax : t_delta.y;
     t_max.z = gz ? kFltMax : t_max.z; t_delta.z = gz ? kFltMax : t_delta.z;
+    // consecutive voxels of a beam mostly lie in one block: the last lookup is kept
+    i3 last_block = mki3(0x7FFFFFFF, 0, 0);
+    u32 last_val = kValNone;
 #pragma unroll 1
     for (u32 iter = 0; iter < kMaxDdaIter; iter++) {
       const i3 block = voxel_to_block_fast(m, cur);
-      u64 bkey;
-      int slot = -1;
-      if (pack_key(block, bkey)) slot = hash_find(t, bkey);
-      const u32 val = slot >= 0 ? t.vals[slot] : kValNone;
+      u32 val = last_val;
+      if (block.x != last_block.x || block.y != last_block.y || block.z != last_block.z) {
+        u64 bkey;
+        int slot = -1;
+        if (pack_key(block, bkey)) slot = hash_find(t, bkey);
+        val = slot >= 0 ? t.vals[slot] : kValNone;
+        last_block = block;
+        last_val = val;
+      }
       if (val != kValNone) {
         const int res = (val & kValCoarseBit) ? 1 : 0;
         const int scale = 1 << res;
@@ -197,9 +206,9 @@ __global__ __launch_bounds__(256) void k_points_walk(const Cam c, const Map m, c
         if (EMIT) {
           const u32 li = voxel_local_index(cur, res);
           u64 vid;
-          if (res) { const u32 u = val & ~kValCoarseBit; vid = ((u64) (u >> 3) * 512u + (u64) (u & 7u) * 64u + li) | kVidCoarse; }
+          if (res) { const u32 u = val & ~kValCoarseBit; vid = ((u64) (u >> 3) * 512u + (u64) (u & 7u) * 64u + li) | (1ull << coarse_bit); }
           else vid = (u64) val * 512u + li;
-          keys[out + cnt] = (vid << pbits) | (u64) i;
+          keys[out + cnt] = (K) vid;
           vals[out + cnt] = sdf;
         }
         cnt++;
@@ -217,50 +226,77 @@ __global__ __launch_bounds__(256) void k_points_walk(const Cam c, const Map m, c
   if (!EMIT) counts[i] = cnt;
 }
 
-// sorted records: the lane at the head of a voxel's run folds the run into the voxel, in order
-__global__ __launch_bounds__(256) void k_points_apply(const Map m, const Tab t, const u64* __restrict__ keys, const float* __restrict__ vals,
-                                                      const u32 n_rec, const int pbits) {
-  const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= n_rec) return;
-  const u64 vid = keys[j] >> pbits;
-  if (j > 0 && (keys[j - 1] >> pbits) == vid) return;
-  const u64 id = vid & (kVidCoarse - 1);
-  const u32 H = (u32) (id >> 9);
-  char* base = t.pool + (size_t) H * kFineBytes;
-  float *p_sdf, *p_ss;
-  u32* p_rgbw;
-  if (vid & kVidCoarse) {
-    const u32 k = (u32) (id >> 6) & 7u, li = (u32) (id & 63u);
-    base += (size_t) k * kCoarseBytes;
-    p_sdf = (float*) base + li; p_ss = (float*) (base + 256) + li; p_rgbw = (u32*) (base + 512) + li;
-  } else {
-    const u32 li = (u32) (id & 511u);
-    p_sdf = (float*) base + li; p_ss = (float*) (base + 2048) + li; p_rgbw = (u32*) (base + 4096) + li;
-  }
-  float s0 = *p_sdf, ss = *p_ss;
-  u32 rgbw = *p_rgbw;
+// Sorted records -> voxels.  A workgroup stages kApplyChunk consecutive records (keys + values) in LDS; the lane that finds
+// the head of a run (its key differs from its predecessor's) loads the voxel, folds the run in order — from LDS, from global
+// memory once the run leaves the chunk — and stores the voxel.  Runs that begin in an earlier chunk belong to that chunk's
+// head lane.
+constexpr int kApplyChunk = 2048;
+template <typename K>
+__global__ __launch_bounds__(256) void k_points_apply(const Map m, const Tab t, const K* __restrict__ keys, const float* __restrict__ vals,
+                                                      const u32 n_rec, const int coarse_bit, const int count_updates) {
+  __shared__ K s_key[kApplyChunk];
+  __shared__ float s_val[kApplyChunk];
+  const u32 c0 = blockIdx.x * kApplyChunk;
+  if (c0 >= n_rec) return;
+  const u32 cn = min((u32) kApplyChunk, n_rec - c0);
+  for (u32 j = threadIdx.x; j < cn; j += 256) { s_key[j] = keys[c0 + j]; s_val[j] = vals[c0 + j]; }
+  __syncthreads();
   const u32 w1 = (u32) (m.weight_sample & 0xFF), wmax = (u32) (m.weight_max & 0xFF);
   const float half_vs = m.vs / 2;
-  for (u32 k = j; k < n_rec && (keys[k] >> pbits) == vid; k++) {
-    const float sdf = vals[k];
-    const u32 w0 = rgbw >> 24;
-    const float curr_mean = w0 > 0 ? s0 : 0.f;
-    const float delta = (sdf - curr_mean) / half_vs;
-    // combineVoxel with curr = {sdf, weight_update, rgb (0, 0, 0)} (vhu.cuh:167-181)
-    const u32 r0 = rgbw & 0xFF, g0 = (rgbw >> 8) & 0xFF, b0 = (rgbw >> 16) & 0xFF;
-    const u32 rn = (u32) f2i((0.5f * (float) r0 + 0.5f * 0.f) + 0.5f) & 0xFF;
-    const u32 gn = (u32) f2i((0.5f * (float) g0 + 0.5f * 0.f) + 0.5f) & 0xFF;
-    const u32 bn = (u32) f2i((0.5f * (float) b0 + 0.5f * 0.f) + 0.5f) & 0xFF;
-    const float sn = (s0 * (float) w0 + sdf * (float) w1) / (float) (int) (w0 + w1);
-    const u32 wn = (w0 + w1) < wmax ? (w0 + w1) : wmax;
-    const float delta2 = (sdf - sn) / half_vs;
-    s0 = sn;
-    ss = 0.f + delta * delta2;
-    rgbw = rn | (gn << 8) | (bn << 16) | (wn << 24);
+  const u64 cmask = 1ull << coarse_bit;
+  u32 my_heads = 0;
+  for (u32 j = threadIdx.x; j < cn; j += 256) {
+    const K key = s_key[j];
+    if (j > 0 ? s_key[j - 1] == key : (c0 > 0 && keys[c0 - 1] == key)) continue;  // not the head of its run
+    my_heads++;
+    const u64 vid = (u64) key;
+    const u64 id = vid & (cmask - 1);
+    const u32 H = (u32) (id >> 9);
+    char* base = t.pool + (size_t) H * kFineBytes;
+    float *p_sdf, *p_ss;
+    u32* p_rgbw;
+    if (vid & cmask) {
+      const u32 k = (u32) (id >> 6) & 7u, li = (u32) (id & 63u);
+      base += (size_t) k * kCoarseBytes;
+      p_sdf = (float*) base + li; p_ss = (float*) (base + 256) + li; p_rgbw = (u32*) (base + 512) + li;
+    } else {
+      const u32 li = (u32) (id & 511u);
+      p_sdf = (float*) base + li; p_ss = (float*) (base + 2048) + li; p_rgbw = (u32*) (base + 4096) + li;
+    }
+    float s0 = *p_sdf, ss = *p_ss;
+    u32 rgbw = *p_rgbw;
+    for (u32 k = j;; k++) {
+      float sdf;
+      if (k < cn) {
+        if (s_key[k] != key) break;
+        sdf = s_val[k];
+      } else {  // the run leaves the chunk
+        if (c0 + k >= n_rec || keys[c0 + k] != key) break;
+        sdf = vals[c0 + k];
+      }
+      const u32 w0 = rgbw >> 24;
+      const float curr_mean = w0 > 0 ? s0 : 0.f;
+      const float delta = (sdf - curr_mean) / half_vs;
+      // combineVoxel with curr = {sdf, weight_update, rgb (0, 0, 0)} (vhu.cuh:167-181)
+      const u32 r0 = rgbw & 0xFF, g0 = (rgbw >> 8) & 0xFF, b0 = (rgbw >> 16) & 0xFF;
+      const u32 rn = (u32) f2i((0.5f * (float) r0 + 0.5f * 0.f) + 0.5f) & 0xFF;
+      const u32 gn = (u32) f2i((0.5f * (float) g0 + 0.5f * 0.f) + 0.5f) & 0xFF;
+      const u32 bn = (u32) f2i((0.5f * (float) b0 + 0.5f * 0.f) + 0.5f) & 0xFF;
+      const float sn = (s0 * (float) w0 + sdf * (float) w1) / (float) (int) (w0 + w1);
+      const u32 wn = (w0 + w1) < wmax ? (w0 + w1) : wmax;
+      const float delta2 = (sdf - sn) / half_vs;
+      s0 = sn;
+      ss = 0.f + delta * delta2;
+      rgbw = rn | (gn << 8) | (bn << 16) | (wn << 24);
+    }
+    *p_sdf = s0;
+    *p_ss = ss;
+    *p_rgbw = rgbw;
   }
-  *p_sdf = s0;
-  *p_ss = ss;
-  *p_rgbw = rgbw;
+  if (count_updates) {  // profile mode: voxels this scan updated (one per run), for the roofline figure of bench.py
+    for (int off = 32; off > 0; off >>= 1) my_heads += __shfl_xor(my_heads, off);
+    if ((threadIdx.x & 63) == 0 && my_heads) atomicAdd(&t.prof[PROF_UPDATED], (u64) my_heads);
+  }
 }
 
 }  // namespace mrh
