@@ -18,7 +18,7 @@
 #ifndef MRH_SOFTMATH_H
 #define MRH_SOFTMATH_H
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define MRH_SM_FN __host__ __device__ static inline
 #else
 #include <math.h>

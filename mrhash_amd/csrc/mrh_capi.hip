@@ -2170,19 +2170,42 @@ int mrh_import_blocks(mrh_ctx* c, const mrh_block_desc* descs, const mrh_voxel* 
   rc = set_aside_flags(c);
   if (rc) return rc;
   map_changed_in_bulk(c);
-  const uint64_t chunk = 8192;
-  DevBuf<int4> d_descs;
-  DevBuf<char> d_vox;
-  HIP_TRY(c, d_descs.alloc(chunk));
-  HIP_TRY(c, d_vox.alloc(chunk * (size_t) kFineBytes));
-  for (uint64_t first = 0; first < n; first += chunk) {
-    const uint64_t cnt = (n - first) < chunk ? (n - first) : chunk;
-    HIP_TRY(c, hipMemcpyAsync(d_descs, &descs[first], cnt * sizeof(int4), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(d_vox, &voxels[first * 512], cnt * (size_t) kFineBytes, hipMemcpyHostToDevice, c->stream));
-    k_import<kImportPlain><<<(int) (cnt < 2048 ? cnt : 2048), 512, 0, c->stream>>>(c->map, c->tab, c->fast.summary, (int) cnt, (const char*) (int4*) d_descs, sizeof(int4),
-                                                                                   (const char*) d_vox, (size_t) kFineBytes, nullptr, nullptr);
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+  // two staging buffers, the copies on their own stream: the host-to-device copy of chunk i + 1 (the caller's memory is
+  // pageable: the runtime stages it) runs under the insert kernel of chunk i; one synchronisation at the end
+  const uint64_t chunk = 4096;  // 24 MiB of voxels
+  struct Pipe {
+    hipStream_t copy = nullptr;
+    hipEvent_t copied[2] = {nullptr, nullptr}, done[2] = {nullptr, nullptr};
+    ~Pipe() {
+      if (copy) { (void) hipStreamSynchronize(copy); (void) hipStreamDestroy(copy); }
+      for (hipEvent_t e : copied) if (e) (void) hipEventDestroy(e);
+      for (hipEvent_t e : done) if (e) (void) hipEventDestroy(e);
+    }
+  } pipe;
+  DevBuf<int4> d_descs[2];
+  DevBuf<char> d_vox[2];
+  const int nbuf = n > chunk ? 2 : 1;
+  HIP_TRY(c, hipStreamCreateWithFlags(&pipe.copy, hipStreamNonBlocking));
+  for (int b = 0; b < nbuf; b++) {
+    HIP_TRY(c, d_descs[b].alloc(chunk));
+    HIP_TRY(c, d_vox[b].alloc(chunk * (size_t) kFineBytes));
+    HIP_TRY(c, hipEventCreateWithFlags(&pipe.copied[b], hipEventDisableTiming));
+    HIP_TRY(c, hipEventCreateWithFlags(&pipe.done[b], hipEventDisableTiming));
   }
+  uint64_t it = 0;
+  for (uint64_t first = 0; first < n; first += chunk, it++) {
+    const uint64_t cnt = (n - first) < chunk ? (n - first) : chunk;
+    const int b = (int) (it & 1);
+    if (it >= 2) HIP_TRY(c, hipStreamWaitEvent(pipe.copy, pipe.done[b], 0));  // the kernel that read this buffer two chunks ago
+    HIP_TRY(c, hipMemcpyAsync(d_descs[b], &descs[first], cnt * sizeof(int4), hipMemcpyHostToDevice, pipe.copy));
+    HIP_TRY(c, hipMemcpyAsync(d_vox[b], &voxels[first * 512], cnt * (size_t) kFineBytes, hipMemcpyHostToDevice, pipe.copy));
+    HIP_TRY(c, hipEventRecord(pipe.copied[b], pipe.copy));
+    HIP_TRY(c, hipStreamWaitEvent(c->stream, pipe.copied[b], 0));
+    k_import<kImportPlain><<<(int) (cnt < 2048 ? cnt : 2048), 512, 0, c->stream>>>(c->map, c->tab, c->fast.summary, (int) cnt, (const char*) (int4*) d_descs[b], sizeof(int4),
+                                                                                   (const char*) d_vox[b], (size_t) kFineBytes, nullptr, nullptr);
+    HIP_TRY(c, hipEventRecord(pipe.done[b], c->stream));
+  }
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
   HIP_TRY(c, hipGetLastError());
   u32 flags = 0;
   rc = take_device_flags(c, &flags);

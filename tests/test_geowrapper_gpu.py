@@ -462,3 +462,35 @@ def test_example_runner_script_runs(tmp_path):
         head = open(out).read(400).splitlines()
         assert head[0] == "ply" and head[1] == "format ascii 1.0" and head[2].startswith("element vertex ")
         assert int(head[2].split()[-1]) > 10000
+
+
+def test_geowrapper_comm_entry_points_one_rank(geowrapper_cls, oracle, tmp_path):
+    """The multi-GPU surface of the C++ GeoWrapper (include/mrhash_comm.h behind it: _commUniqueId / _commInit / _mergeSubmaps)
+    with the one rank this box allows: the communicator comes up on the wrapper's device, a tile-sharded wrapper fuses and
+    extracts as before (world 1: the shard owns everything), a frame-sharded one folds its sub-map through mrh_comm_merge_submaps
+    and then extracts — the same mesh as the oracle's."""
+    K = synth.CFG1
+    frames = [synth.cfg1_sphere(), synth.cfg1_sphere(zc=1.51), synth.cfg1_sphere(zc=1.5)]
+    b = pu.make_engine(oracle, K, dict(synth.CFG1_PARAMS, n_frames_invalidate_voxels=2), 32768)
+    for f in frames:
+        pu.feed(b, f)
+    b.extract_triangles()
+    Vb, Fb, Cb = b.extract_mesh()
+    for tile_sharded in (True, False):
+        g = _make(geowrapper_cls)
+        g.setCamera(K.fx, K.fy, K.cx, K.cy, K.rows, K.cols, 0.01, 30.0, 0)
+        uid = geowrapper_cls._commUniqueId()
+        assert isinstance(uid, bytes) and len(uid) == 128
+        g._commInit(uid, 0, 1, 1, tile_sharded)
+        with pytest.raises(RuntimeError, match="already attached"):
+            g._commInit(uid, 0, 1, 1, tile_sharded)
+        for f in frames:
+            g.setCurrPose(f.t, f.q)
+            g.setDepthImage(f.depth)
+            g.setRGBImage(f.rgb)
+            g.compute()
+        if not tile_sharded:
+            g._mergeSubmaps()
+        g.extractMesh(str(tmp_path / f"comm{int(tile_sharded)}.ply"))
+        assert np.array_equal(g.getVertices(), Vb) and np.array_equal(g.getFaces(), Fb)
+        del g
