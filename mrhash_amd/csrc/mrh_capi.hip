@@ -38,6 +38,7 @@
 #include "mrh_fast2.h"
 #include "mrh_mesh.h"
 #include "mrh_lidar.h"
+#include "mrh_sort.h"
 #include "mrh_splat.h"
 
 using namespace mrh;
@@ -169,6 +170,7 @@ struct mrh_ctx {
   std::vector<mrh_qtree_leaf> qt_leaves;
   uint64_t qt_n_leaves = 0;            // leaves of the last mrh_splat_seeds, still on the device (d_qt_leaves) until someone asks
   bool qt_leaves_on_host = true;
+  int lidar_sort_rocprim = 0;  // MRH_LIDAR_SORT_ROCPRIM=1: the record sort of a scan through rocPRIM's onesweep instead of mrh_sort.h (cross-check)
   int mr_fused = 1;          // MRH_MR_FUSED=0: multi-resolution maps always through the general kernels (mrh_kernels.h)
   bool mr_next_general = true;    // the next multi-resolution frame must take the general path (frame 0 / after a starve frame / after an import)
   bool mr_summaries_valid = false;  // fast.summary / summary_c describe every live block (the general kernels do not maintain them)
@@ -853,6 +855,7 @@ int mrh_create(const mrh_params* p, mrh_ctx** out) {
   if (const char* g = getenv("MRH_MESH_HOST")) c->mesh_on_host = atoi(g) ? 1 : 0;
   if (const char* g = getenv("MRH_QTREE_LITERAL")) c->qt_literal = atoi(g) ? 1 : 0;
   if (const char* g = getenv("MRH_MR_FUSED")) c->mr_fused = atoi(g) ? 1 : 0;
+  if (const char* g = getenv("MRH_LIDAR_SORT_ROCPRIM")) c->lidar_sort_rocprim = atoi(g) ? 1 : 0;
   if (const char* g = getenv("MRH_REHASH_PERIOD")) { const int v = atoi(g); if (v > 0) c->census_period = v; }
   if (const char* g = getenv("MRH_REHASH_FORCE")) c->census_force = atoi(g) ? 1 : 0;
   if (const char* g = getenv("MRH_REHASH_OFF")) { if (atoi(g)) c->census_period = -1; }  // no upkeep at all (tests: shows what it prevents)
@@ -1413,12 +1416,39 @@ int lidar_sort_with(mrh_ctx* c, K* k0, K* k1, float* v0, float* v1, const size_t
   HIP_TRY(c, rocprim::radix_sort_pairs<Config>(c->d_sort_tmp, tb, k0, k1, v0, v1, n, 0, end_bit, s));
   return MRH_OK;
 }
+// *out_buf = which of the two buffer pairs holds the sorted records
 template <typename K>
-int lidar_sort(mrh_ctx* c, K* k0, K* k1, float* v0, float* v1, const size_t n, const int end_bit) {
-  // merge-sort limit 0: always the onesweep path (rocPRIM would sort up to 2^20 items with block sort + ~10 merge passes).
-  // 8-bit digits are the widest it offers: its onesweep kernel keeps a per-digit table per thread in LDS (9 bits: 512 KiB).
-  using Cfg = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 0>;
-  return lidar_sort_with<Cfg>(c, k0, k1, v0, v1, n, end_bit);
+int lidar_sort(mrh_ctx* c, K* k0, K* k1, float* v0, float* v1, const size_t n, const int end_bit, int* out_buf) {
+  const u32 ntiles = (u32) ((n + kSortTile - 1) / kSortTile);
+  const u32 total = 256u * ntiles;
+  if (c->lidar_sort_rocprim || total > kSortScanMax) {
+    // merge-sort limit 0: always the onesweep path (rocPRIM would sort up to 2^20 items with block sort + ~10 merge passes)
+    using Cfg = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 0>;
+    *out_buf = 1;
+    return lidar_sort_with<Cfg>(c, k0, k1, v0, v1, n, end_bit);
+  }
+  // the scan-sized sort of mrh_sort.h: per 8-bit digit a tile histogram, a one-workgroup scan, a stable scatter
+  hipStream_t s = c->stream;
+  if ((size_t) total * sizeof(u32) > c->sort_tmp_bytes) {
+    HIP_TRY(c, hipStreamSynchronize(s));
+    if (c->d_sort_tmp) HIP_TRY(c, hipFree(c->d_sort_tmp));
+    c->d_sort_tmp = nullptr;
+    HIP_TRY(c, hipMalloc(&c->d_sort_tmp, (size_t) total * sizeof(u32) * 2));
+    c->sort_tmp_bytes = (size_t) total * sizeof(u32) * 2;
+  }
+  u32* hist = (u32*) c->d_sort_tmp;
+  K* ks[2] = {k0, k1};
+  float* vs[2] = {v0, v1};
+  int src = 0;
+  for (int shift = 0; shift < end_bit; shift += 8) {
+    k_sort_hist<K><<<ntiles, kSortThreads, 0, s>>>(ks[src], (u32) n, shift, hist, ntiles);
+    k_sort_scan<<<1, 1024, 0, s>>>(hist, total);
+    k_sort_scatter<K><<<ntiles, kSortThreads, 0, s>>>(ks[src], vs[src], ks[src ^ 1], vs[src ^ 1], (u32) n, shift, hist, ntiles);
+    src ^= 1;
+  }
+  HIP_TRY(c, hipGetLastError());
+  *out_buf = src;
+  return MRH_OK;
 }
 }  // namespace
 
@@ -1539,15 +1569,15 @@ int mrh_integrate_points(mrh_ctx* c, int n_frames_invalidate) {
       // records were emitted in point order: every voxel's run ends up in ascending point index (D6)
       const int end_bit = t.multi_res ? coarse_bit + 1 : bits_for((uint64_t) (hwm > 0 ? hwm : 1) * 512 - 1);
       const u32 agrid = (u32) ((n_rec + kApplyChunk - 1) / kApplyChunk);
-      int r;
+      int r, sb = 1;
       if (wide) {
-        r = lidar_sort(c, (u64*) c->d_rec_keys[0], (u64*) c->d_rec_keys[1], c->d_rec_vals[0], c->d_rec_vals[1], (size_t) n_rec, end_bit);
+        r = lidar_sort(c, (u64*) c->d_rec_keys[0], (u64*) c->d_rec_keys[1], c->d_rec_vals[0], c->d_rec_vals[1], (size_t) n_rec, end_bit, &sb);
         if (r) return r;
-        k_points_apply<u64><<<agrid, 256, 0, s>>>(m, t, (const u64*) c->d_rec_keys[1], c->d_rec_vals[1], (u32) n_rec, coarse_bit, c->profile);
+        k_points_apply<u64><<<agrid, 256, 0, s>>>(m, t, (const u64*) c->d_rec_keys[sb], c->d_rec_vals[sb], (u32) n_rec, coarse_bit, c->profile);
       } else {
-        r = lidar_sort(c, (u32*) c->d_rec_keys[0], (u32*) c->d_rec_keys[1], c->d_rec_vals[0], c->d_rec_vals[1], (size_t) n_rec, end_bit);
+        r = lidar_sort(c, (u32*) c->d_rec_keys[0], (u32*) c->d_rec_keys[1], c->d_rec_vals[0], c->d_rec_vals[1], (size_t) n_rec, end_bit, &sb);
         if (r) return r;
-        k_points_apply<u32><<<agrid, 256, 0, s>>>(m, t, (const u32*) c->d_rec_keys[1], c->d_rec_vals[1], (u32) n_rec, coarse_bit, c->profile);
+        k_points_apply<u32><<<agrid, 256, 0, s>>>(m, t, (const u32*) c->d_rec_keys[sb], c->d_rec_vals[sb], (u32) n_rec, coarse_bit, c->profile);
       }
       HIP_TRY(c, hipGetLastError());
       return MRH_OK;
@@ -1902,7 +1932,7 @@ int mrh_extract_triangles(mrh_ctx* c, const mrh_triangle** out_tris, uint64_t* o
       k_list_keys<<<(n + 255) / 256, 256, 0, s>>>(c->tab.compact, n, k_in);
       size_t bytes = tmp_bytes;
       HIP_TRY(c, rocprim::radix_sort_pairs(tmp, bytes, k_in, k_out, c->tab.compact, sorted, (size_t) n, 0, 63, s));
-      k_mc_neighbors<<<(int) (((size_t) n * 64 + 255) / 256), 256, 0, s>>>(c->tab, sorted, n, d_nb);
+      k_mc_neighbors<<<(int) (((size_t) n * 32 + 255) / 256), 256, 0, s>>>(c->tab, sorted, n, d_nb);
     }
     if (dbg) { HIP_TRY(c, hipStreamSynchronize(s)); t1 = now(); }
     const int grid = n < 8192 ? n : 8192;

@@ -226,29 +226,47 @@ __global__ __launch_bounds__(256) void k_points_walk(const Cam c, const Map m, c
   if (!EMIT) counts[i] = cnt;
 }
 
-// Sorted records -> voxels.  A workgroup stages kApplyChunk consecutive records (keys + values) in LDS; the lane that finds
-// the head of a run (its key differs from its predecessor's) loads the voxel, folds the run in order — from LDS, from global
-// memory once the run leaves the chunk — and stores the voxel.  Runs that begin in an earlier chunk belong to that chunk's
-// head lane.
-constexpr int kApplyChunk = 2048;
+// Sorted records -> voxels.  A workgroup stages kApplyChunk consecutive records (keys + values) in LDS, lists the heads of the
+// runs that begin in its chunk (key differs from the predecessor's), and hands them out one per lane: the lane loads the voxel,
+// folds the run in order — from LDS, from global memory once the run leaves the chunk — and stores the voxel.  The fold is a
+// serial chain by nature (a running mean in fp32), so what the kernel can do is keep an iteration short: the sdf update (one
+// division), the weight, and the three colour channels as integers — u8(0.5 c + 0.5 * 0 + 0.5) of combineVoxel (vhu.cuh:170-176)
+// is (c + 1) >> 1 for every c in 0 .. 255; the variance term delta * delta2 (vds.cu:1352-1366) is overwritten by every
+// update, so only the LAST record of a run computes it.
+constexpr int kApplyChunk = 1024;
 template <typename K>
 __global__ __launch_bounds__(256) void k_points_apply(const Map m, const Tab t, const K* __restrict__ keys, const float* __restrict__ vals,
                                                       const u32 n_rec, const int coarse_bit, const int count_updates) {
   __shared__ K s_key[kApplyChunk];
   __shared__ float s_val[kApplyChunk];
+  __shared__ unsigned short s_head[kApplyChunk];
+  __shared__ u32 s_nhead;
   const u32 c0 = blockIdx.x * kApplyChunk;
   if (c0 >= n_rec) return;
   const u32 cn = min((u32) kApplyChunk, n_rec - c0);
+  if (threadIdx.x == 0) s_nhead = 0;
   for (u32 j = threadIdx.x; j < cn; j += 256) { s_key[j] = keys[c0 + j]; s_val[j] = vals[c0 + j]; }
   __syncthreads();
+  for (u32 j = threadIdx.x; j < cn; j += 256) {
+    const K key = s_key[j];
+    const bool head = !(j > 0 ? s_key[j - 1] == key : (c0 > 0 && keys[c0 - 1] == key));
+    const u64 ballot = __ballot(head);
+    if (ballot) {
+      u32 base = 0;
+      const int leader = __ffsll((long long) ballot) - 1;
+      if ((int) lane_id() == leader) base = atomicAdd(&s_nhead, (u32) __popcll(ballot));
+      base = __shfl(base, leader);
+      if (head) s_head[base + __popcll(ballot & lanemask_lt())] = (unsigned short) j;
+    }
+  }
+  __syncthreads();
+  const u32 nhead = s_nhead;
   const u32 w1 = (u32) (m.weight_sample & 0xFF), wmax = (u32) (m.weight_max & 0xFF);
   const float half_vs = m.vs / 2;
   const u64 cmask = 1ull << coarse_bit;
-  u32 my_heads = 0;
-  for (u32 j = threadIdx.x; j < cn; j += 256) {
+  for (u32 h = threadIdx.x; h < nhead; h += 256) {
+    const u32 j = s_head[h];
     const K key = s_key[j];
-    if (j > 0 ? s_key[j - 1] == key : (c0 > 0 && keys[c0 - 1] == key)) continue;  // not the head of its run
-    my_heads++;
     const u64 vid = (u64) key;
     const u64 id = vid & (cmask - 1);
     const u32 H = (u32) (id >> 9);
@@ -263,8 +281,11 @@ __global__ __launch_bounds__(256) void k_points_apply(const Map m, const Tab t, 
       const u32 li = (u32) (id & 511u);
       p_sdf = (float*) base + li; p_ss = (float*) (base + 2048) + li; p_rgbw = (u32*) (base + 4096) + li;
     }
-    float s0 = *p_sdf, ss = *p_ss;
-    u32 rgbw = *p_rgbw;
+    float s0 = *p_sdf;
+    const u32 rgbw0 = *p_rgbw;
+    u32 w0 = rgbw0 >> 24, r0 = rgbw0 & 0xFF, g0 = (rgbw0 >> 8) & 0xFF, b0 = (rgbw0 >> 16) & 0xFF;
+    float s_prev = s0, sdf_last = 0.f;  // state BEFORE the last update, and the last record's sdf: the variance term needs them
+    u32 w_prev = w0;
     for (u32 k = j;; k++) {
       float sdf;
       if (k < cn) {
@@ -274,29 +295,21 @@ __global__ __launch_bounds__(256) void k_points_apply(const Map m, const Tab t, 
         if (c0 + k >= n_rec || keys[c0 + k] != key) break;
         sdf = vals[c0 + k];
       }
-      const u32 w0 = rgbw >> 24;
-      const float curr_mean = w0 > 0 ? s0 : 0.f;
-      const float delta = (sdf - curr_mean) / half_vs;
+      s_prev = s0; w_prev = w0; sdf_last = sdf;
       // combineVoxel with curr = {sdf, weight_update, rgb (0, 0, 0)} (vhu.cuh:167-181)
-      const u32 r0 = rgbw & 0xFF, g0 = (rgbw >> 8) & 0xFF, b0 = (rgbw >> 16) & 0xFF;
-      const u32 rn = (u32) f2i((0.5f * (float) r0 + 0.5f * 0.f) + 0.5f) & 0xFF;
-      const u32 gn = (u32) f2i((0.5f * (float) g0 + 0.5f * 0.f) + 0.5f) & 0xFF;
-      const u32 bn = (u32) f2i((0.5f * (float) b0 + 0.5f * 0.f) + 0.5f) & 0xFF;
-      const float sn = (s0 * (float) w0 + sdf * (float) w1) / (float) (int) (w0 + w1);
-      const u32 wn = (w0 + w1) < wmax ? (w0 + w1) : wmax;
-      const float delta2 = (sdf - sn) / half_vs;
-      s0 = sn;
-      ss = 0.f + delta * delta2;
-      rgbw = rn | (gn << 8) | (bn << 16) | (wn << 24);
+      s0 = (s0 * (float) w0 + sdf * (float) w1) / (float) (int) (w0 + w1);
+      w0 = (w0 + w1) < wmax ? (w0 + w1) : wmax;
+      r0 = (r0 + 1) >> 1; g0 = (g0 + 1) >> 1; b0 = (b0 + 1) >> 1;
     }
+    // vds.cu:1352-1366 for the last update: delta against the mean before it (0 for a voxel without weight), delta2 against the mean after
+    const float curr_mean = w_prev > 0 ? s_prev : 0.f;
+    const float delta = (sdf_last - curr_mean) / half_vs;
+    const float delta2 = (sdf_last - s0) / half_vs;
     *p_sdf = s0;
-    *p_ss = ss;
-    *p_rgbw = rgbw;
+    *p_ss = 0.f + delta * delta2;
+    *p_rgbw = r0 | (g0 << 8) | (b0 << 16) | (w0 << 24);
   }
-  if (count_updates) {  // profile mode: voxels this scan updated (one per run), for the roofline figure of bench.py
-    for (int off = 32; off > 0; off >>= 1) my_heads += __shfl_xor(my_heads, off);
-    if ((threadIdx.x & 63) == 0 && my_heads) atomicAdd(&t.prof[PROF_UPDATED], (u64) my_heads);
-  }
+  if (count_updates && threadIdx.x == 0 && nhead) atomicAdd(&t.prof[PROF_UPDATED], (u64) nhead);  // profile mode: voxels this scan updated
 }
 
 }  // namespace mrh

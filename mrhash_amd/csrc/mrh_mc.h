@@ -37,12 +37,8 @@ constexpr int kHaloRim = 3;
 constexpr int kHaloSide = 8 + 2 * kHaloRim;                      // 14
 constexpr int kHaloCells = kHaloSide * kHaloSide * kHaloSide;    // 2744
 struct Neigh {
-  const u32* vals;  // LDS [27 + 8], index (dz + 1) * 9 + (dy + 1) * 3 + (dx + 1); nullptr: no table (lookups outside k_mc)
-                    // [27 .. 34] (multi-resolution maps): the 2^3 blocks at qbase + {0, 1}^3 — where trilinearInterpolation's
-                    // base-resolution lookup lands when the sampled block is coarse: it converts the position with the COARSE voxel
-                    // size (vds.cu:264), i.e. to about half the block coordinates, far outside the 27 neighbours; without this
-                    // entry every such corner walked the global hash table (the bulk of the literal evaluation's time)
-  i3 base;          // block position of the workgroup's block; the 2^3 extra blocks start at floor((base - 1) / 2) per axis
+  const u32* vals;  // LDS [27], index (dz + 1) * 9 + (dy + 1) * 3 + (dx + 1); nullptr: no table (lookups outside k_mc)
+  i3 base;          // block position of the workgroup's block
   int shift_limit;  // Map::block_shift_limit
   // LDS halo (nullptr: none); valid for cells within `halo_rim` of the block, under the workgroup's guarantee that
   // voxel -> block is the arithmetic shift for every voxel it can reach
@@ -63,10 +59,6 @@ __device__ __forceinline__ u32 block_val(const Tab& t, const Neigh& nb, const i3
   if (nb.vals) {
     const int dx = b.x - nb.base.x, dy = b.y - nb.base.y, dz = b.z - nb.base.z;
     if ((u32) (dx + 1) < 3u && (u32) (dy + 1) < 3u && (u32) (dz + 1) < 3u) return nb.vals[(dz + 1) * 9 + (dy + 1) * 3 + (dx + 1)];
-    if (t.multi_res) {  // entries 27 .. 34 exist on multi-resolution maps only; nothing is kept live for them
-      const int qx = b.x - ((nb.base.x - 1) >> 1), qy = b.y - ((nb.base.y - 1) >> 1), qz = b.z - ((nb.base.z - 1) >> 1);
-      if ((u32) qx < 2u && (u32) qy < 2u && (u32) qz < 2u) return nb.vals[27 + qz * 4 + qy * 2 + qx];
-    }
   }
   u64 key;
   if (!pack_key(b, key)) return kNbAbsent;
@@ -458,21 +450,18 @@ __device__ __forceinline__ bool voxel_touches_coarse(const int v, const u32 cmas
 // The 27-block neighbourhood of every block of the sorted list, resolved by one thread per (block, neighbour): 27 independent
 // probes per block at full occupancy instead of 27 lanes of one wave walking their probe paths at the head of every k_mc
 // workgroup while the other 229 threads wait; both passes read the table.  Layout: nb[e * 32 + i], i = (dz+1)*9 + (dy+1)*3 + (dx+1).
-constexpr int kMcNbStride = 40, kMcNbCount = 35;
-__device__ __forceinline__ int floor_half(const int v) { return v >> 1; }  // floor(v / 2), arithmetic shift
+constexpr int kMcNbStride = 32;
 __global__ __launch_bounds__(256) void k_mc_neighbors(const Tab t, const int4* __restrict__ sorted, const int n, u32* __restrict__ nb) {
   const size_t g = (size_t) blockIdx.x * 256 + threadIdx.x;
-  const size_t e = g >> 6;
-  const int i = (int) (g & 63);
-  if (e >= (size_t) n || i >= (t.multi_res ? kMcNbCount : 27)) return;
+  const size_t e = g >> 5;
+  const int i = (int) (g & 31);
+  if (e >= (size_t) n || i >= 27) return;
   const int4 ent = sorted[e];
   u32 val = kNbAbsent;
   if (i == 13) {
     val = (u32) ent.w;  // the block itself: the list carries its table value
   } else {
-    i3 b;
-    if (i < 27) b = mki3(ent.x + (i % 3) - 1, ent.y + ((i / 3) % 3) - 1, ent.z + (i / 9) - 1);
-    else b = mki3(floor_half(ent.x - 1) + ((i - 27) & 1), floor_half(ent.y - 1) + (((i - 27) >> 1) & 1), floor_half(ent.z - 1) + ((i - 27) >> 2));
+    const i3 b = mki3(ent.x + (i % 3) - 1, ent.y + ((i / 3) % 3) - 1, ent.z + (i / 9) - 1);
     u64 key;
     if (pack_key(b, key)) {
       const int slot = hash_find(t, key);
@@ -497,7 +486,7 @@ __global__ __launch_bounds__(kMcThreads) __attribute__((amdgpu_waves_per_eu(4, 4
                                                    u32* __restrict__ counts, const u64* __restrict__ offsets,
                                                    mrh_triangle* __restrict__ out, const u64 max_tris, uint8_t* __restrict__ per_voxel,
                                                    const float sdf_bound, const int flag_overflow) {
-  __shared__ u32 s_nb[kMcNbCount];
+  __shared__ u32 s_nb[27];
   __shared__ float s_sdf[kHaloCells];
   __shared__ u32 s_rgbw[kHaloCells];
   __shared__ uint8_t s_cls[2][kHaloCells];
@@ -517,7 +506,7 @@ __global__ __launch_bounds__(kMcThreads) __attribute__((amdgpu_waves_per_eu(4, 4
     nb.base = mki3(ent.x, ent.y, ent.z);
     nb.shift_limit = m.block_shift_limit;
     nb.r_vs = rcp_refined(m.vs);
-    if (tid < (t.multi_res ? kMcNbCount : 27)) s_nb[tid] = nb_table[(size_t) e * kMcNbStride + tid];  // the surrounding blocks (k_mc_neighbors)
+    if (tid < 27) s_nb[tid] = nb_table[(size_t) e * kMcNbStride + tid];  // the 27 surrounding blocks (k_mc_neighbors)
     if (tid < 2) s_ncand[tid] = 0;
     for (int i = tid; i < 512; i += kMcThreads) s_ntri[i] = 0;
     __syncthreads();
