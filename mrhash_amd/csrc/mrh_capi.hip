@@ -1429,21 +1429,21 @@ int lidar_sort(mrh_ctx* c, K* k0, K* k1, float* v0, float* v1, const size_t n, c
   }
   // the scan-sized sort of mrh_sort.h: per 8-bit digit a tile histogram, a one-workgroup scan, a stable scatter
   hipStream_t s = c->stream;
-  if ((size_t) total * sizeof(u32) > c->sort_tmp_bytes) {
+  if ((size_t) total * sizeof(u32) + 1024 > c->sort_tmp_bytes) {
     HIP_TRY(c, hipStreamSynchronize(s));
     if (c->d_sort_tmp) HIP_TRY(c, hipFree(c->d_sort_tmp));
     c->d_sort_tmp = nullptr;
-    HIP_TRY(c, hipMalloc(&c->d_sort_tmp, (size_t) total * sizeof(u32) * 2));
-    c->sort_tmp_bytes = (size_t) total * sizeof(u32) * 2;
+    HIP_TRY(c, hipMalloc(&c->d_sort_tmp, (size_t) total * sizeof(u32) * 2 + 1024));
+    c->sort_tmp_bytes = (size_t) total * sizeof(u32) * 2 + 1024;
   }
-  u32* hist = (u32*) c->d_sort_tmp;
+  u32* hist = (u32*) c->d_sort_tmp + 256;  // [0, 256): the digit totals
   K* ks[2] = {k0, k1};
   float* vs[2] = {v0, v1};
   int src = 0;
   for (int shift = 0; shift < end_bit; shift += 8) {
     k_sort_hist<K><<<ntiles, kSortThreads, 0, s>>>(ks[src], (u32) n, shift, hist, ntiles);
-    k_sort_scan<<<1, 1024, 0, s>>>(hist, total);
-    k_sort_scatter<K><<<ntiles, kSortThreads, 0, s>>>(ks[src], vs[src], ks[src ^ 1], vs[src ^ 1], (u32) n, shift, hist, ntiles);
+    k_sort_scan<<<256, 256, 0, s>>>(hist, ntiles, (u32*) c->d_sort_tmp);
+    k_sort_scatter<K><<<ntiles, kSortThreads, 0, s>>>(ks[src], vs[src], ks[src ^ 1], vs[src ^ 1], (u32) n, shift, hist, ntiles, (const u32*) c->d_sort_tmp);
     src ^= 1;
   }
   HIP_TRY(c, hipGetLastError());

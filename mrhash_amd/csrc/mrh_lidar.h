@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256) void k_points_walk(const Cam c, const Map m, c
 // runs that begin in its chunk (key differs from the predecessor's), and hands them out one per lane: the lane loads the voxel,
 // folds the run in order — from LDS, from global memory once the run leaves the chunk — and stores the voxel.  The fold is a
 // serial chain by nature (a running mean in fp32), so what the kernel can do is keep an iteration short: the sdf update (one
-// division), the weight, and the three colour channels as integers — u8(0.5 c + 0.5 * 0 + 0.5) of combineVoxel (vhu.cuh:170-176)
+// division, through the refined reciprocal of the weight sum), the weight, and the three colour channels as integers — u8(0.5 c + 0.5 * 0 + 0.5) of combineVoxel (vhu.cuh:170-176)
 // is (c + 1) >> 1 for every c in 0 .. 255; the variance term delta * delta2 (vds.cu:1352-1366) is overwritten by every
 // update, so only the LAST record of a run computes it.
 constexpr int kApplyChunk = 1024;
@@ -286,20 +286,33 @@ __global__ __launch_bounds__(256) void k_points_apply(const Map m, const Tab t, 
     u32 w0 = rgbw0 >> 24, r0 = rgbw0 & 0xFF, g0 = (rgbw0 >> 8) & 0xFF, b0 = (rgbw0 >> 16) & 0xFF;
     float s_prev = s0, sdf_last = 0.f;  // state BEFORE the last update, and the last record's sdf: the variance term needs them
     u32 w_prev = w0;
-    for (u32 k = j;; k++) {
-      float sdf;
-      if (k < cn) {
-        if (s_key[k] != key) break;
-        sdf = s_val[k];
-      } else {  // the run leaves the chunk
-        if (c0 + k >= n_rec || keys[c0 + k] != key) break;
-        sdf = vals[c0 + k];
+    // four records at a time: their keys and values are fetched together (independent LDS reads), so that what is serial in an
+    // iteration is the arithmetic of the running mean only — a voxel near the sensor collects hundreds of beams, and the
+    // longest run of a scan is what the kernel waits for
+    bool more = true;
+    for (u32 k = j; more; k += 4) {
+      K kk[4];
+      float vv[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const u32 idx = k + q;
+        if (idx < cn) { kk[q] = s_key[idx]; vv[q] = s_val[idx]; }
+        else if (c0 + idx < n_rec) { kk[q] = keys[c0 + idx]; vv[q] = vals[c0 + idx]; }  // the run leaves the chunk
+        else { kk[q] = ~key; vv[q] = 0.f; }
       }
-      s_prev = s0; w_prev = w0; sdf_last = sdf;
-      // combineVoxel with curr = {sdf, weight_update, rgb (0, 0, 0)} (vhu.cuh:167-181)
-      s0 = (s0 * (float) w0 + sdf * (float) w1) / (float) (int) (w0 + w1);
-      w0 = (w0 + w1) < wmax ? (w0 + w1) : wmax;
-      r0 = (r0 + 1) >> 1; g0 = (g0 + 1) >> 1; b0 = (b0 + 1) >> 1;
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        if (!more || kk[q] != key) { more = false; continue; }
+        const float sdf = vv[q];
+        s_prev = s0; w_prev = w0; sdf_last = sdf;
+        // combineVoxel with curr = {sdf, weight_update, rgb (0, 0, 0)} (vhu.cuh:167-181).  The division by the weight sum is the
+        // long pole of the chain: with the correctly rounded reciprocal (checked at mrh_create for every sum 1 .. 510, as for
+        // k_back) one residual correction gives the IEEE quotient (div_cr, mrh_device.h) — 3 dependent instructions instead of ~10
+        const float num = s0 * (float) w0 + sdf * (float) w1, den = (float) (int) (w0 + w1);
+        s0 = m.wsum_two_steps ? num / den : div_cr(num, den, rcp_refined(den));
+        w0 = (w0 + w1) < wmax ? (w0 + w1) : wmax;
+        r0 = (r0 + 1) >> 1; g0 = (g0 + 1) >> 1; b0 = (b0 + 1) >> 1;
+      }
     }
     // vds.cu:1352-1366 for the last update: delta against the mean before it (0 for a voxel without weight), delta2 against the mean after
     const float curr_mean = w_prev > 0 ? s_prev : 0.f;

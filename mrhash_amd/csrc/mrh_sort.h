@@ -4,8 +4,9 @@
 // 10^7+ items: at this size each of its three passes is a latency-bound chain (decoupled look-back over ~300 tiles, 26 us
 // measured) and every call adds 5-7 hipMemsetAsync of look-back state (5 us each): 130 us of a 200 us scan
 // (profiles/r03/lidar_kernel_stats_rocprim_sort.csv).  At this size the classic three-kernel pass is the better fit:
-//   k_sort_hist      per tile (4096 records, one workgroup): 256-bin histogram of the pass's digit -> hist[digit][tile]
-//   k_sort_scan      exclusive scan of hist in (digit, tile) order — one workgroup, the table has 256 x ~160 entries
+//   k_sort_hist      per tile (1024 records, one workgroup): 256-bin histogram of the pass's digit -> hist[digit][tile]
+//   k_sort_scan      per digit (256 workgroups): exclusive scan of its row over the tiles + the row total; the scan over the
+//                    256 totals is redone by every scatter workgroup in LDS
 //   k_sort_scatter   per tile: every record's rank among the records of its digit that precede it — inside its wave by a
 //                    ballot match (8 ballots give the lanes holding the same digit; rank = popcount of the lower ones), across
 //                    the rounds of a wave and the waves of a tile by per-wave digit counters in LDS — plus the scanned
@@ -18,10 +19,10 @@
 
 namespace mrh {
 
-constexpr int kSortTile = 4096;     // records per workgroup
-constexpr int kSortThreads = 256;   // 4 waves x 16 rounds x 64 lanes
+constexpr int kSortTile = 1024;     // records per workgroup: a scan has ~10^6 records, smaller tiles mean more workgroups (640 for 0.65 M) and a short chain each
+constexpr int kSortThreads = 256;   // 4 waves x 4 rounds x 64 lanes
 constexpr int kSortRounds = kSortTile / kSortThreads;
-constexpr u32 kSortScanMax = 1u << 17;  // histogram entries the one-workgroup scan takes (512 tiles = 2 M records); beyond: rocPRIM
+constexpr u32 kSortScanMax = 1u << 22;  // histogram entries (16 k tiles = 16 M records); beyond: rocPRIM
 
 __device__ __forceinline__ u32 sort_lane() { return (u32) __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
@@ -42,41 +43,60 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_hist(const K* __restrict_
   hist[threadIdx.x * ntiles + tile] = s_h[threadIdx.x];
 }
 
-// exclusive scan of hist[0 .. total) in place, one workgroup of 1024 threads (total <= kSortScanMax)
-__global__ __launch_bounds__(1024) void k_sort_scan(u32* __restrict__ hist, const u32 total) {
-  __shared__ u32 s_part[1024];
-  const u32 per = (total + 1023) / 1024;
-  const u32 lo = threadIdx.x * per, hi = min(total, lo + per);
-  u32 sum = 0;
-  for (u32 i = lo; i < hi; i++) sum += hist[i];
-  s_part[threadIdx.x] = sum;
-  __syncthreads();
-  // Hillis-Steele over the 1024 partial sums
-  for (u32 off = 1; off < 1024; off <<= 1) {
-    const u32 v = threadIdx.x >= off ? s_part[threadIdx.x - off] : 0u;
+// workgroup d: exclusive scan of digit d's row hist[d][0 .. ntiles) in place (records of that digit in earlier tiles) and the
+// row's total -> totals[d].  256 workgroups, each a short block scan: the table is scanned in parallel, not by one workgroup
+// walking 40 k entries (a first version did that: 60 us per pass, all of it load latency).
+__global__ __launch_bounds__(256) void k_sort_scan(u32* __restrict__ hist, const u32 ntiles, u32* __restrict__ totals) {
+  __shared__ u32 s_wave[4];
+  u32* row = hist + (size_t) blockIdx.x * ntiles;
+  const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  u32 carry = 0;
+  for (u32 base = 0; base < ntiles; base += 256) {
+    const u32 i = base + threadIdx.x;
+    const u32 v = i < ntiles ? row[i] : 0u;
+    u32 incl = v;
+    for (int off = 1; off < 64; off <<= 1) {
+      const u32 o = __shfl_up(incl, off);
+      if ((int) lane >= off) incl += o;
+    }
+    if (lane == 63) s_wave[wave] = incl;
     __syncthreads();
-    s_part[threadIdx.x] += v;
+    u32 woff = 0, all = 0;
+    for (u32 w = 0; w < 4; w++) { if (w < wave) woff += s_wave[w]; all += s_wave[w]; }
+    if (i < ntiles) row[i] = carry + woff + incl - v;
+    carry += all;
     __syncthreads();
   }
-  u32 run = s_part[threadIdx.x] - sum;  // exclusive prefix of this thread's segment
-  for (u32 i = lo; i < hi; i++) {
-    const u32 v = hist[i];
-    hist[i] = run;
-    run += v;
-  }
+  if (threadIdx.x == 0) totals[blockIdx.x] = carry;
 }
 
 template <typename K>
 __global__ __launch_bounds__(kSortThreads) void k_sort_scatter(const K* __restrict__ keys_in, const float* __restrict__ vals_in, K* __restrict__ keys_out,
                                                                float* __restrict__ vals_out, const u32 n, const int shift,
-                                                               const u32* __restrict__ hist_scanned, const u32 ntiles) {
+                                                               const u32* __restrict__ hist_scanned, const u32 ntiles,
+                                                               const u32* __restrict__ totals) {
   constexpr int NW = kSortThreads / 64;
+  __shared__ u32 s_dig[256];       // records of all smaller digits (exclusive scan of the digit totals)
   __shared__ u32 s_cnt[NW][256];   // records of each digit seen so far by each wave; afterwards: the wave's first output position per digit
   const u32 tile = blockIdx.x;
   const u32 wave = threadIdx.x >> 6, lane = sort_lane();
   for (int i = threadIdx.x; i < NW * 256; i += kSortThreads) (&s_cnt[0][0])[i] = 0;
+  {  // exclusive scan of the 256 digit totals: thread d holds digit d
+    const u32 v = totals[threadIdx.x];
+    u32 incl = v;
+    for (int off = 1; off < 64; off <<= 1) {
+      const u32 o = __shfl_up(incl, off);
+      if ((int) lane >= off) incl += o;
+    }
+    s_dig[threadIdx.x] = incl - v;   // within the wave; the earlier waves' sums are added below
+    __syncthreads();
+    u32 before = 0;
+    for (u32 w = 0; w < wave; w++) before += s_dig[w * 64 + 63] + totals[w * 64 + 63];
+    __syncthreads();
+    s_dig[threadIdx.x] += before;
+  }
   __syncthreads();
-  // wave w takes records [t0 + w * 1024, + 1024) in 16 rounds of 64 consecutive records
+  // wave w takes records [t0 + w * (tile / 4), + tile / 4) in rounds of 64 consecutive records
   const u32 w0 = tile * kSortTile + wave * (kSortTile / NW);
   K key[kSortRounds];
   float val[kSortRounds];
@@ -109,7 +129,7 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_scatter(const K* __restri
   __syncthreads();
   {  // thread d: first output position of digit d for each wave = scanned histogram entry + the earlier waves' counts
     const u32 d = threadIdx.x;
-    u32 run = hist_scanned[d * ntiles + tile];
+    u32 run = s_dig[d] + hist_scanned[d * ntiles + tile];
 #pragma unroll
     for (int w = 0; w < NW; w++) {
       const u32 c = s_cnt[w][d];
