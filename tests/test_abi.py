@@ -27,6 +27,18 @@ def test_hip_library_exports_every_declared_symbol(hip):
     assert hip.mrh_version().startswith(b"mrhash_hip")
 
 
+def test_comm_header_and_binding_agree_and_the_library_exports_them(hip):
+    """include/mrhash_comm.h (RCCL behind the C ABI): every declared symbol is bound by capi and exported by the product library.
+    Nothing is called: RCCL is only opened by the first communicator call."""
+    hdr = open(os.path.join(ROOT, "include", "mrhash_comm.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(mrh_comm_[a-z_0-9]+)\s*\(", hdr)))
+    assert declared == sorted(capi.COMM_SYMBOLS)
+    for name in declared:
+        assert hasattr(hip, name), f"libmrhash_hip.so does not export {name}"
+    assert C.sizeof(capi.MrhCommPhases) == 40 and C.sizeof(capi.MrhCommMergeInfo) == 32  # = sizeof in C (gcc probe)
+
+
 def test_oracle_exports_the_same_abi(oracle):
     for name in _declared_symbols():
         assert hasattr(oracle, name)
