@@ -568,17 +568,82 @@ def bench_single(args):
 
 # ---- N > 1 ---------------------------------------------------------------------------------------------------------
 
+class HostGroup:
+    """Barrier / max / all-gather of a few numbers through files under MRH_RDZV_DIR (one node): what the TIMING of the frame-sharded
+    run needs, and nothing more.  Used only when the RCCL communicator cannot be created (the run then reports `value` with
+    `"backend": "host"` and the reason, and leaves the exchange phases out) or when MRH_BENCH_BACKEND=host asks for it (tests)."""
+
+    def __init__(self, rank, world):
+        key = os.environ.get("MRH_RDZV_KEY") or f"{os.getppid()}_{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'none')}"
+        self.base = os.path.join(os.environ.get("MRH_RDZV_DIR", "/tmp"), f"mrh_hostgrp_{key}")
+        self.rank, self.world, self.seq, self.mine = rank, world, 0, []
+
+    def _exchange(self, payload: str, timeout_s: float = 600.0):
+        self.seq += 1
+        path = f"{self.base}.{self.seq}.{self.rank}"
+        with open(path + ".tmp", "w") as f:
+            f.write(payload)
+        os.replace(path + ".tmp", path)
+        self.mine.append(path)
+        out, t0 = [], time.time()
+        for r in range(self.world):
+            p = f"{self.base}.{self.seq}.{r}"
+            while True:
+                try:
+                    with open(p) as f:
+                        out.append(f.read())
+                    break
+                except FileNotFoundError:
+                    if time.time() - t0 > timeout_s:
+                        raise TimeoutError(f"host group: rank {r} never reached step {self.seq}")
+                    time.sleep(2e-5)
+        return out
+
+    def barrier(self):
+        self._exchange("")
+
+    def allgather_f64(self, values):
+        return np.array([json.loads(v) for v in self._exchange(json.dumps([float(x) for x in values]))], dtype=np.float64)
+
+    def close(self):
+        self._exchange("")  # everybody has read every earlier step; this last step's (empty) files stay behind
+        for p in self.mine[:-1]:
+            try:
+                os.unlink(p)
+            except OSError:
+                pass
+
+
 class Group:
     """The ranks of the run: RCCL behind the C ABI (capi.Comm; the product path, no torch in the process) or — test mode,
-    N ranks sharing one device — a gloo group."""
+    N ranks sharing one device — a gloo group; `host` (files, timing only) if the communicator cannot be created."""
 
     def __init__(self, hip, rank, world, device_index, backend):
         from mrhash_amd import capi, parallel
 
-        self.rank, self.world, self.backend = rank, world, backend
+        self.rank, self.world, self.backend, self.note = rank, world, backend, None
+        self.dist = self.handle = self.host = None
         if backend == "rccl":
-            self.handle = parallel.rendezvous(hip, rank, world, device_index)
-            self.dist = None
+            # every rank learns whether EVERY rank got its communicator: a rank that failed alone would otherwise leave the
+            # others inside their first collective
+            host = HostGroup(rank, world)
+            err = ""
+            try:
+                self.handle = parallel.rendezvous(hip, rank, world, device_index, timeout_s=120.0)
+            except Exception as e:  # noqa: BLE001  (library missing, bootstrap refused, ...)
+                err = f"{type(e).__name__}: {e}"
+            errs = [e for e in host._exchange(err) if e]
+            if errs:
+                if self.handle is not None:
+                    self.handle.close()
+                    self.handle = None
+                self.backend, self.host, self.note = "host", host, "RCCL communicator not created: " + errs[0][:300]
+                if rank == 0:
+                    print(f"[bench.py] {self.note}; timing through the host group, exchange phases skipped", file=sys.stderr)
+            else:
+                host.close()
+        elif backend == "host":
+            self.host = HostGroup(rank, world)
         else:
             self.dist = parallel.init_process_group("gloo")
             self.handle = self.dist
@@ -586,16 +651,24 @@ class Group:
                 raise SystemExit(f"bench.py: the process group reports {self.dist.get_world_size()} ranks, --gpus says {world}")
         self._capi = capi
 
+    @property
+    def exchanges(self) -> bool:
+        return self.host is None
+
     def barrier(self):
         from mrhash_amd import hipmem
 
         hipmem.synchronize()
-        if self.dist is None:
+        if self.host is not None:
+            self.host.barrier()
+        elif self.dist is None:
             self.handle.barrier()
         else:
             self.dist.barrier()
 
     def max(self, x: float) -> float:
+        if self.host is not None:
+            return float(self.host.allgather_f64([x]).max())
         if self.dist is None:
             return float(self.handle.allreduce([x], self._capi.COMM_MAX)[0])
         import torch
@@ -605,6 +678,8 @@ class Group:
         return float(t.item())
 
     def allgather(self, values) -> np.ndarray:
+        if self.host is not None:
+            return self.host.allgather_f64(values).astype(np.int64)
         if self.dist is None:
             return self.handle.allgather_i64(values)
         import torch
@@ -615,10 +690,18 @@ class Group:
         return out.numpy().reshape(self.world, len(mine))
 
     def close(self):
-        if self.dist is None:
+        if self.host is not None:
+            self.host.close()
+        elif self.dist is None:
             self.handle.close()
         else:
             self.dist.destroy_process_group()
+
+
+def _scannet_params():
+    from mrhash_amd import synth
+
+    return synth.SCANNET_PARAMS
 
 
 def bench_multi(args):
@@ -633,8 +716,8 @@ def bench_multi(args):
     # 0 and talk over gloo (RCCL refuses two ranks on one device).  The driver's runs use one GPU per rank over RCCL.
     share = os.environ.get("MRH_BENCH_SHARE_DEVICE") == "1"
     device_index = 0 if share else local_rank
-    backend = "gloo" if share else "rccl"
-    if share:
+    backend = os.environ.get("MRH_BENCH_BACKEND") or ("gloo" if share else "rccl")
+    if backend == "gloo":
         import torch  # noqa: F401  (gloo; imported before the library binds its HIP runtime, see mrhash_amd/_runtime.py)
 
     from mrhash_amd import capi, hipmem, parallel, synth
@@ -645,8 +728,10 @@ def bench_multi(args):
         raise SystemExit(f"bench.py --gpus {args.gpus}: only {ndev} HIP device(s) visible; refusing to report n_gpus = {args.gpus}")
     hipmem.set_device(device_index)
     grp = Group(hip, rank, world, device_index, backend)
+    backend = grp.backend
     devices = sorted(set(int(v) for v in grp.allgather([device_index])[:, 0]))
     n_gpus = 1 if share else len(devices)
+    rccl = grp.exchanges and grp.dist is None
 
     Kc = synth.SCANNET
     params = capi.Params(num_sdf_blocks=args.blocks, device_id=device_index, **synth.SCANNET_PARAMS)
@@ -655,7 +740,7 @@ def bench_multi(args):
     # ---- frame-sharded fusion (value): this rank's own segment of the walk
     mine = Resident(render_stream("scannet", total, start=rank * total), Kc)
     eng = make_engine(hip, params, Kc)
-    if grp.dist is None:
+    if rccl:
         eng.attach_comm(grp.handle)
     mine.run(eng, 0, W)
     eng.sync()
@@ -666,25 +751,88 @@ def bench_multi(args):
     grp.barrier()
     elapsed = grp.max(time.perf_counter() - t0)
     sub_blocks = int(eng.stats().occupied_fine)
+    sub_all = grp.allgather([sub_blocks])[:, 0]
 
-    # ---- sub-maps -> one tile-sharded map -> halo exchange (what a mesh extraction needs next)
+    out = {
+        "metric": "depth frames/sec integrated (640x480)",
+        "value": world * K / elapsed, "unit": "frames/s", "n_gpus": n_gpus, "ranks": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "scannet-scene0000 stand-in 640x480 (furnished 8x3x6 m room, hand-held walk), single-resolution hash TSDF "
+                               "integrate (alloc+compact+integrate+GC per frame, scannet.cfg params), frames resident in HBM",
+                   "frames_per_gpu": K, "voxel_size_m": 0.01, "truncation_m": 0.07,
+                   "parallelism": f"value = FRAME-SHARDED: {world} ranks x {K} own frames into {world} sub-maps, no data-path collective in the timed "
+                                  f"region (backend {backend}, devices {devices}); the sub-maps are merged afterwards (see merge)",
+                   "sub_map_blocks_per_rank": [int(v) for v in sub_all]},
+        "backend": backend, "backend_note": grp.note,
+        "phases": None, "merge": None, "tile_sharded": None, "roofline": None, "cpu_baseline": None,
+    }
+
+    # Everything below is reported BESIDE the value.  A collective that never returns (one rank lost, a fabric problem) must
+    # not take the measured value with it: after MRH_BENCH_PHASE_TIMEOUT seconds rank 0 prints the line with what it has and
+    # every rank leaves.
+    import threading
+
+    def give_up():
+        if rank == 0:
+            out["phases_error"] = f"the exchange phases did not finish within {limit:.0f} s; value is the completed frame-sharded measurement"
+            emit(out)
+        os._exit(0)
+
+    limit = float(os.environ.get("MRH_BENCH_PHASE_TIMEOUT", "420"))
+    dog = threading.Timer(limit, give_up)
+    dog.daemon = True
+    dog.start()
+    try:
+        bench_multi_phases(args, grp, eng, mine, hip, params, Kc, chunk_log2, device_index, out, rccl, sub_blocks)
+    except Exception as e:  # noqa: BLE001
+        print(f"[bench.py] rank {rank}: exchange phases failed: {type(e).__name__}: {e}", file=sys.stderr)
+        dog.cancel()
+        if rank == 0:
+            out["phases_error"] = f"{type(e).__name__}: {e}"[:400]
+            emit(out)
+        os._exit(0)  # the other ranks may be inside a collective this rank will never join: their own timers end them
+    dog.cancel()
+    if rank == 0:
+        emit(out)
     grp.barrier()
-    t1 = time.perf_counter()
-    info = parallel.merge_submaps(eng, grp.handle, chunk_log2)
-    grp.barrier()
-    merge_s = grp.max(time.perf_counter() - t1)
-    merge_phases = eng.comm_phase_times() if grp.dist is None else None
-    t2 = time.perf_counter()
-    n_halo = parallel.exchange_halo(eng, grp.handle)
-    grp.barrier()
-    halo_s = grp.max(time.perf_counter() - t2)
-    halo_phases = eng.comm_phase_times() if grp.dist is None else None
-    owned = int(eng.stats().occupied_fine) - n_halo
-    parallel.drop_halo(eng)
-    allc = grp.allgather([sub_blocks, info["sent"], owned, n_halo])
-    if grp.dist is None:
+    grp.close()
+
+
+def bench_multi_phases(args, grp, eng, mine, hip, params, Kc, chunk_log2, device_index, out, rccl, sub_blocks):
+    from mrhash_amd import capi, parallel
+
+    rank, world = grp.rank, grp.world
+    K, W = args.steps, args.warmup
+    total = W + K
+    merge = None
+    merge_phases = halo_phases = tile_phases = None
+    if grp.exchanges:
+        # ---- sub-maps -> one tile-sharded map -> halo exchange (what a mesh extraction needs next)
+        grp.barrier()
+        t1 = time.perf_counter()
+        info = parallel.merge_submaps(eng, grp.handle, chunk_log2)
+        grp.barrier()
+        merge_s = grp.max(time.perf_counter() - t1)
+        merge_phases = eng.comm_phase_times() if rccl else None
+        t2 = time.perf_counter()
+        n_halo = parallel.exchange_halo(eng, grp.handle)
+        grp.barrier()
+        halo_s = grp.max(time.perf_counter() - t2)
+        halo_phases = eng.comm_phase_times() if rccl else None
+        owned = int(eng.stats().occupied_fine) - n_halo
+        parallel.drop_halo(eng)
+        allc = grp.allgather([sub_blocks, info["sent"], owned, n_halo])
+        rec = capi.RECORD_BYTES
+        merge = {"what": "sub-maps -> one tile-sharded map: all-to-all of blocks to their tile owner + weighted merge on the device "
+                         "(mrh_comm_merge_submaps), then exchange of boundary blocks (mrh_comm_exchange_halo)",
+                 "merge_ms": merge_s * 1e3, "halo_exchange_ms": halo_s * 1e3,
+                 "blocks_sent_per_rank": [int(v) for v in allc[:, 1]], "bytes_sent_per_rank": [int(v) * rec for v in allc[:, 1]],
+                 "owned_blocks_after_merge_per_rank": [int(v) for v in allc[:, 2]], "halo_blocks_taken_per_rank": [int(v) for v in allc[:, 3]],
+                 "value_including_merge": world * K / (out["ms_per_step"] * K / 1e3 + merge_s)}
+    if rccl:
         eng.attach_comm(None)
     eng.close()
+    out["merge"] = merge
 
     # ---- roofline of the integrate kernel on rank 0's own segment (profiled pass on a second context; the other ranks wait)
     roof = None
@@ -693,67 +841,46 @@ def bench_multi(args):
         roof = profiled_roofline(pe, mine, W, total, f"configs[3], rank 0's segment of the frame-sharded stream ({K} frames)")
         roof["cache_note"] = "per-frame working set inside the 256 MiB Infinity Cache (see the N = 1 line's roofline_hbm for the kernel outside it)"
         pe.close()
+    out["roofline"] = roof
     grp.barrier()
 
     # ---- tile-sharded fusion of ONE stream (rank 0's segment) by all ranks
-    shared = mine if rank == 0 else Resident(render_stream("scannet", total, start=0), Kc)
-    tp = capi.Params(num_sdf_blocks=args.blocks, device_id=device_index, shard_rank=rank, shard_count=world, shard_chunk_log2=chunk_log2,
-                     **synth.SCANNET_PARAMS)
-    te = make_engine(hip, tp, Kc)
-    if grp.dist is None:
-        te.attach_comm(grp.handle)  # starve frames: the two MIN all-reduces run inside mrh_integrate
-        step = None
-    else:
-        step = lambda e: parallel.integrate(e, grp.handle)  # noqa: E731
-    shared.run(te, 0, W, integrate=step)
-    te.sync()
-    grp.barrier()
-    t3 = time.perf_counter()
-    shared.run(te, W, total, integrate=step)
-    te.sync()
-    grp.barrier()
-    tile_elapsed = grp.max(time.perf_counter() - t3)
-    tile_blocks = int(te.stats().occupied_fine)
-    tile_phases = te.comm_phase_times() if grp.dist is None else None
-    if grp.dist is None:
-        te.attach_comm(None)
-    te.close()
+    if grp.exchanges:
+        shared = mine if rank == 0 else Resident(render_stream("scannet", total, start=0), Kc)
+        tp = capi.Params(num_sdf_blocks=args.blocks, device_id=device_index, shard_rank=rank, shard_count=world, shard_chunk_log2=chunk_log2,
+                         **_scannet_params())
+        te = make_engine(hip, tp, Kc)
+        if rccl:
+            te.attach_comm(grp.handle)  # starve frames: the two MIN all-reduces run inside mrh_integrate
+            step = None
+        else:
+            step = lambda e: parallel.integrate(e, grp.handle)  # noqa: E731
+        shared.run(te, 0, W, integrate=step)
+        te.sync()
+        grp.barrier()
+        t3 = time.perf_counter()
+        shared.run(te, W, total, integrate=step)
+        te.sync()
+        grp.barrier()
+        tile_elapsed = grp.max(time.perf_counter() - t3)
+        tile_blocks = int(te.stats().occupied_fine)
+        tile_phases = te.comm_phase_times() if rccl else None
+        if rccl:
+            te.attach_comm(None)
+        te.close()
+        out["tile_sharded"] = {"what": f"the result-identical mode: every rank sees the same {K} frames and fuses only the tiles it owns (union of the "
+                                       f"{world} tables == the single-GPU map); starve frames run their MIN all-reduce; strong scaling",
+                               "frames_per_s": K / tile_elapsed, "ms_per_step": tile_elapsed / K * 1e3, "owned_blocks_rank0": tile_blocks,
+                               "chunk_log2": chunk_log2}
 
-    if rank == 0:
-        rec = capi.RECORD_BYTES
-        phase_keys = ("pack_ms", "counts_ms", "collective_ms", "unpack_ms", "bytes_out", "bytes_in")
-        out = {
-            "metric": "depth frames/sec integrated (640x480)",
-            "value": world * K / elapsed, "unit": "frames/s", "n_gpus": n_gpus, "ranks": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "scannet-scene0000 stand-in 640x480 (furnished 8x3x6 m room, hand-held walk), single-resolution hash TSDF "
-                                   "integrate (alloc+compact+integrate+GC per frame, scannet.cfg params), frames resident in HBM",
-                       "frames_per_gpu": K, "voxel_size_m": 0.01, "truncation_m": 0.07,
-                       "parallelism": f"value = FRAME-SHARDED: {world} ranks x {K} own frames into {world} sub-maps, no data-path collective in the timed "
-                                      f"region (backend {backend}, devices {devices}); the sub-maps are merged afterwards (see merge)",
-                       "sub_map_blocks_per_rank": [int(v) for v in allc[:, 0]]},
-            "phases": {"what": "HIP-event times on rank 0: the two launches of a frame (profiled pass over rank 0's segment), the phases of the two "
-                               "exchange calls, the starve all-reduces of the tile-sharded pass",
-                       "k_front_ms": roof["k_front_ms_avg"] if roof else None, "k_back_ms": roof["kernel_ms_avg"] if roof else None,
-                       "merge": {k: merge_phases[k] for k in phase_keys} if merge_phases else None,
-                       "halo": {k: halo_phases[k] for k in phase_keys} if halo_phases else None,
-                       "starve_allreduce_ms_avg": (tile_phases["allreduce_ms_sum"] / tile_phases["allreduce_count"]) if tile_phases and tile_phases["allreduce_count"] else None,
-                       "starve_allreduce_count": tile_phases["allreduce_count"] if tile_phases else None},
-            "merge": {"what": "sub-maps -> one tile-sharded map: all-to-all of blocks to their tile owner + weighted merge on the device "
-                              "(mrh_comm_merge_submaps), then exchange of boundary blocks (mrh_comm_exchange_halo)",
-                      "merge_ms": merge_s * 1e3, "halo_exchange_ms": halo_s * 1e3,
-                      "blocks_sent_per_rank": [int(v) for v in allc[:, 1]], "bytes_sent_per_rank": [int(v) * rec for v in allc[:, 1]],
-                      "owned_blocks_after_merge_per_rank": [int(v) for v in allc[:, 2]], "halo_blocks_taken_per_rank": [int(v) for v in allc[:, 3]],
-                      "value_including_merge": world * K / (elapsed + merge_s)},
-            "tile_sharded": {"what": f"the result-identical mode: every rank sees the same {K} frames and fuses only the tiles it owns (union of the "
-                                     f"{world} tables == the single-GPU map); starve frames run their MIN all-reduce; strong scaling",
-                             "frames_per_s": K / tile_elapsed, "ms_per_step": tile_elapsed / K * 1e3, "owned_blocks_rank0": tile_blocks,
-                             "chunk_log2": chunk_log2},
-            "roofline": roof, "cpu_baseline": None,
-        }
-        emit(out)
-    grp.barrier()
-    grp.close()
+    phase_keys = ("pack_ms", "counts_ms", "collective_ms", "unpack_ms", "bytes_out", "bytes_in")
+    out["phases"] = {"what": "HIP-event times on rank 0: the two launches of a frame (profiled pass over rank 0's segment), the phases of the two "
+                             "exchange calls, the starve all-reduces of the tile-sharded pass",
+                     "k_front_ms": roof["k_front_ms_avg"] if roof else None, "k_back_ms": roof["kernel_ms_avg"] if roof else None,
+                     "merge": {k: merge_phases[k] for k in phase_keys} if merge_phases else None,
+                     "halo": {k: halo_phases[k] for k in phase_keys} if halo_phases else None,
+                     "starve_allreduce_ms_avg": (tile_phases["allreduce_ms_sum"] / tile_phases["allreduce_count"]) if tile_phases and tile_phases["allreduce_count"] else None,
+                     "starve_allreduce_count": tile_phases["allreduce_count"] if tile_phases else None}
 
 
 def main():

@@ -72,3 +72,21 @@ def test_one_rank_rccl_line():
     assert ph["merge"]["pack_ms"] > 0 and ph["merge"]["unpack_ms"] > 0 and ph["halo"]["pack_ms"] > 0
     assert ph["starve_allreduce_count"] == 0  # one shard: nothing to reduce (tests/test_sharding_gpu.py drives the all-reduce)
     assert "backend rccl" in d["config"]["parallelism"]
+
+
+def test_value_survives_without_a_communicator():
+    """The measured value must not depend on the exchange phases: with the file-based host group (what bench.py falls back to
+    when the RCCL communicator cannot be created) two ranks report the frame-sharded value, the roofline of rank 0's
+    segment, and say that the exchange phases were left out."""
+    d = _run(["--gpus", "2", "--steps", "6", "--warmup", "2", "--blocks", "65536"], env={"MRH_BENCH_SHARE_DEVICE": "1", "MRH_BENCH_BACKEND": "host"}, timeout=900)
+    assert all(k in d for k in KEYS)
+    assert d["ranks"] == 2 and d["value"] > 1000 and d["backend"] == "host"
+    assert d["merge"] is None and d["tile_sharded"] is None and d["roofline"]["launches"] == 6
+    assert len(d["config"]["sub_map_blocks_per_rank"]) == 2 and all(v > 0 for v in d["config"]["sub_map_blocks_per_rank"])
+
+
+def test_value_survives_a_stuck_exchange_phase():
+    """A watchdog ends the run with the value it has if the phases beside the value do not finish in time (forced here
+    with a limit the merge of two sub-maps cannot meet)."""
+    d = _run(["--gpus", "2", "--steps", "6", "--warmup", "2", "--blocks", "65536"], env={"MRH_BENCH_SHARE_DEVICE": "1", "MRH_BENCH_PHASE_TIMEOUT": "0.001"}, timeout=900)
+    assert d["ranks"] == 2 and d["value"] > 1000 and "phases_error" in d and d["merge"] is None
