@@ -703,6 +703,17 @@ extern "C" {
 #define MRH_STR2(x) #x
 #define MRH_STR(x) MRH_STR2(x)
 const char* mrh_version(void) { return "mrhash_hip abi" MRH_STR(MRH_ABI_VERSION) " gfx950 hand-written-hip"; }
+#ifdef MRH_MC_TRACE
+// tuning builds only (tools/trace_mc.sh): read (and optionally clear) the phase accumulators of k_mc
+int mrh_debug_mc_trace(uint32_t* out, int clear) {  // out: 2 x 65536 x 8 words
+  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(d_mc_trace), sizeof(d_mc_trace)) != hipSuccess) return MRH_ERR_DEVICE;
+  if (clear) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(d_mc_trace)) != hipSuccess || hipMemset(p, 0, sizeof(d_mc_trace)) != hipSuccess) return MRH_ERR_DEVICE;
+  }
+  return MRH_OK;
+}
+#endif
 
 const char* mrh_last_error(const mrh_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 

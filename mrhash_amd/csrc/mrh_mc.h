@@ -420,8 +420,9 @@ __global__ __launch_bounds__(256) void k_list_keys(const int4* __restrict__ list
 //        the two shells where the observed band ends (weighted cells of one sign next to unseen ones), which made up most
 //        of what the one-class rule of the first version let through (4.03 M candidates for 1.47 M triangles).
 //        w = 3, a coarse voxel or a fine one next to a coarse block (Neigh's comment derives the reach): a re-sample blends
-//        the sdf of a possibly UNWEIGHTED cell in (vds.cu:268, :296-309), so only a window whose cells all share one class
-//        is skipped.
+//        the sdf of a possibly UNWEIGHTED cell in (vds.cu:268, :296-309); such a cell reads +-0 unless its weight was
+//        starved away (class bit 16), and a zero cannot turn the sign of the clearly-signed value it is averaged with:
+//        the same rule holds with bit 16 counted as "anything else" (argument at the test in the kernel).
 //      "Clearly" = 1e-3 x sdf_bound <= |sdf| <= 1.001 x sdf_bound, sdf_bound = the largest truncation a sample can carry;
 //      anything outside (or NaN) is class 8.
 //      EMIT pass: the candidates are the voxels the count pass found non-empty (per_voxel).
@@ -476,6 +477,21 @@ __global__ void k_mc_total(const u64* __restrict__ offsets, const u32* __restric
 }
 
 constexpr int kMcThreads = 256;
+#ifdef MRH_MC_TRACE
+// tuning builds only (tools/trace_mc.sh): shader-clock cycles of thread 0 per phase, one record per block and pass (no atomics:
+// 14 k workgroups adding to the same few words would time the atomics).  Record: [0] class + 1 (0: fine block, no coarse
+// neighbour; 1: fine next to coarse; 2: coarse), [1..4] staging, prescreen, known-stencil evaluation, literal evaluation,
+// [5] whole block, [6] known candidates, [7] literal candidates
+constexpr int kMcTraceBlocks = 65536;
+__device__ unsigned int d_mc_trace[2][kMcTraceBlocks][8];
+#define MRH_MC_TS(var) const long long var = (long long) clock64()
+#define MRH_MC_ACC(slot, a, b) do { if (tid == 0 && e < kMcTraceBlocks) d_mc_trace[EMIT ? 1 : 0][e][(slot) + 1] += (unsigned int) ((b) - (a)); } while (0)
+#define MRH_MC_ADD(slot, v) do { if (tid == 0 && e < kMcTraceBlocks) d_mc_trace[EMIT ? 1 : 0][e][slot] = (unsigned int) (v); } while (0)
+#else
+#define MRH_MC_TS(var) do { } while (0)
+#define MRH_MC_ACC(slot, a, b) do { } while (0)
+#define MRH_MC_ADD(slot, v) do { } while (0)
+#endif
 constexpr int kMcFillIters = (kHaloCells + kMcThreads - 1) / kMcThreads;  // 11
 template <bool EMIT>
 // 4 waves per SIMD: left alone the allocator takes 147 VGPRs (3 waves); capped at 128 it spills 8-24 bytes and both passes
@@ -498,6 +514,7 @@ __global__ __launch_bounds__(kMcThreads) __attribute__((amdgpu_waves_per_eu(4, 4
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   for (int e = blockIdx.x; e < n; e += gridDim.x) {
+    MRH_MC_TS(ts0);
     const int4 ent = sorted[e];
     const u32 val = (u32) ent.w;
     const bool coarse = (val & kValCoarseBit) != 0;
@@ -521,6 +538,9 @@ __global__ __launch_bounds__(kMcThreads) __attribute__((amdgpu_waves_per_eu(4, 4
     // cells to stage around the block: the count pass classifies up to 3 cells out when a coarse block is near, the emit
     // pass only needs what its few candidates read (anything farther falls back to the neighbour table)
     const int rim = (EMIT ? coarse : cmask != 0u) ? kHaloRim : 1;  // uniform
+#ifdef MRH_MC_TRACE
+    const int tr_cls = coarse ? 2 : (cmask ? 1 : 0);
+#endif
     if (staged) {
       const int side = kBlockSide + 2 * rim;
       const int ncell = side * side * side;
@@ -559,6 +579,7 @@ __global__ __launch_bounds__(kMcThreads) __attribute__((amdgpu_waves_per_eu(4, 4
           if (!EMIT) {
             uint8_t cls = unseen;
             if ((rw[it] >> 24) != 0) cls = (sv[it] >= lo && sv[it] <= hi) ? 1 : ((sv[it] <= -lo && sv[it] >= -hi) ? 2 : 8);
+            else if ((__float_as_uint(sv[it]) & 0x7FFFFFFFu) != 0u) cls |= 16;  // unseen, but a non-zero sdf is stored (weight starved to 0)
             s_cls[0][idx] = cls;
           }
         }
@@ -568,6 +589,7 @@ __global__ __launch_bounds__(kMcThreads) __attribute__((amdgpu_waves_per_eu(4, 4
       nb.halo_rgbw = s_rgbw;
       nb.halo_rim = rim;
     }
+    MRH_MC_TS(ts1);
     // a fine voxel whose 3^3 cells lie in fine (or absent) blocks has a known trilinear stencil (trilinear_known)
     const bool fine_known = staged && !coarse && (amax + 2) * kBlockSide < (1 << 18);  // uniform
     // ---- candidates, in two groups so that a wave evaluates voxels of ONE kind: the known-stencil evaluation is ~10x shorter
@@ -642,7 +664,15 @@ __global__ __launch_bounds__(kMcThreads) __attribute__((amdgpu_waves_per_eu(4, 4
             acc = 0u;
 #pragma unroll
             for (int d = -kHaloRim; d <= kHaloRim; d++) acc |= s_cls[0][base + d * kHaloSide * kHaloSide];
-            empty = acc == 1u || acc == 2u || acc == 4u;  // the whole window shares one class (re-samples on resolution jumps blend UNWEIGHTED cells in, so nothing weaker holds here)
+            // A resolution jump blends the sdf of a cell in WITHOUT looking at its weight (vds.cu:268, :296-309: 0.5 pos_sdf +
+            // 0.5 np_sdf), so here an unseen cell can contribute a value — but only its stored sdf, and that is +-0 unless the
+            // weight was starved away (class bit 16; a missing block reads 0, vds.cu:163-176).  Every SAMPLE of a stencil must
+            // still carry weight (vds.cu:283-284), and pos_sdf is sample 0.  Without class 8 / 16 and without both signs in the
+            // window: a valid stencil averages (the dual cell is centred on the corner: every weight is 1/2) eight values that
+            // are each a clearly-signed sdf or the mean of one and a zero — all of one sign, magnitude >= lo / 2, against an
+            // evaluation error < 2e-5 sdf_bound; an invalid one falls back to the weighted raw sample (same sign) or ends the
+            // voxel.  Eight corners of one sign: cube index 0 or 255, no triangle.
+            empty = (acc & (8u | 16u)) == 0u && (acc & 3u) != 3u;
           } else {
             // no resolution jump can occur: every corner value is a convex combination of WEIGHTED cells (a sample without
             // weight invalidates the stencil, vds.cu:283-284) or a weighted raw sample — or the voxel returns without a
@@ -658,6 +688,7 @@ __global__ __launch_bounds__(kMcThreads) __attribute__((amdgpu_waves_per_eu(4, 4
     }
     __syncthreads();
     const int ncand[2] = {(int) s_ncand[0], (int) s_ncand[1]};
+    MRH_MC_TS(ts2);
     auto voxel_position = [&](const int v) {
       i3 pi;
       if (!coarse) pi = mki3(ent.x * kBlockSide + (v & 7), ent.y * kBlockSide + ((v >> 3) & 7), ent.z * kBlockSide + (v >> 6));
@@ -678,8 +709,14 @@ __global__ __launch_bounds__(kMcThreads) __attribute__((amdgpu_waves_per_eu(4, 4
           const int ntri = mc_group<false>(m, t, nb, voxel_position(v), v, kind == 0, corner, gb, active, nullptr, 0);
           if (active && corner == 0) s_ntri[v] = (uint8_t) ntri;
         }
+#ifdef MRH_MC_TRACE
+        if (kind == 0) { __syncthreads(); MRH_MC_TS(tsk); MRH_MC_ACC(2, ts2, tsk); MRH_MC_ACC(3, 0, -tsk); }
+#endif
       }
       __syncthreads();
+#ifdef MRH_MC_TRACE
+      { MRH_MC_TS(tsl); MRH_MC_ACC(3, 0, tsl); }
+#endif
     }
     // ---- block-wide exclusive scan of the per-voxel counts, 2 voxels per thread, in voxel order
     const int v0 = 2 * tid;
@@ -719,9 +756,22 @@ __global__ __launch_bounds__(kMcThreads) __attribute__((amdgpu_waves_per_eu(4, 4
           const int ntri = mc_group<true>(m, t, nb, voxel_position(v), v, kind == 0, corner, gb, active, out + first, room);  // straight to the exact offset
           if (flag_overflow && active && corner == 0 && ntri > room) atomicOr((u32*) &t.ctr[CTR_ERROR], ERR_TRI);
         }
+#ifdef MRH_MC_TRACE
+        if (kind == 0) { __syncthreads(); MRH_MC_TS(tsk); MRH_MC_ACC(2, ts2, tsk); MRH_MC_ACC(3, 0, -tsk); }
+#endif
       }
+#ifdef MRH_MC_TRACE
+      { __syncthreads(); MRH_MC_TS(tsl); MRH_MC_ACC(3, 0, tsl); }
+#endif
     }
     __syncthreads();
+#ifdef MRH_MC_TRACE
+    {
+      MRH_MC_TS(ts5);
+      MRH_MC_ACC(0, ts0, ts1); MRH_MC_ACC(1, ts1, ts2); MRH_MC_ADD(5, ts5 - ts0);
+      MRH_MC_ADD(0, tr_cls + 1); MRH_MC_ADD(6, ncand[0]); MRH_MC_ADD(7, ncand[1]);
+    }
+#endif
   }
 }
 
