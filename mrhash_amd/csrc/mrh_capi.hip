@@ -66,18 +66,28 @@ struct UpRing {
   hipEvent_t last_copy = nullptr;  // newest copy event of this ring the main stream has not waited for yet
 };
 
-// Host result buffer of the blocking calls (triangle soup, V / F / C): grow-only, never zero-filled, 2 MiB-aligned
-// and advised to transparent huge pages.  A device-to-host copy into resident pages runs at link speed on this
-// platform (tools/micro/d2h_paths.hip: 128 MB in 2.4 ms) — what costs is the first touch of fresh 4 KiB pages (+8 ms) and
-// the zero fill of std::vector::resize, so the pages are kept across calls and faulted in as huge pages.
+// Host result buffer of the blocking calls (triangle soup, V / F / C): grow-only, never zero-filled, PINNED (hipHostMalloc).
+// A device-to-host copy into pageable memory is pinned and unpinned by the runtime around every call, page by page: with
+// transparent huge pages behind the buffer that is cheap (tools/micro/d2h_paths.hip: 128 MB in 2.4 ms), with 4 KiB pages it
+// doubles the copy (30 MB of V / F / C: 0.57 -> 1.5 ms) — and which of the two a malloc'ed buffer gets depends on what the
+// process freed before (glibc raises its mmap threshold after the first large free; the next buffer then comes from the heap,
+// where MADV_HUGEPAGE does nothing for pages that already exist).  Pinned once, the copy runs at link speed every time.  If
+// the pinned allocation is refused the buffer falls back to an anonymous 2 MiB-aligned mapping advised to huge pages.
 template <typename T>
 struct HostVec {
   T* p = nullptr;
   size_t n = 0, cap = 0;
+  size_t mapped = 0, head = 0;  // fallback mapping: its size (0: p is pinned memory) and the bytes between its base and p
   HostVec() = default;
   HostVec(const HostVec&) = delete;
   HostVec& operator=(const HostVec&) = delete;
-  ~HostVec() { std::free(p); }
+  ~HostVec() { release(); }
+  void release() {
+    if (!p) return;
+    if (mapped) (void) munmap((void*) ((char*) p - head), mapped);
+    else (void) hipHostFree((void*) p);
+    p = nullptr; cap = 0; mapped = 0; head = 0;
+  }
   T* data() { return p; }
   const T* data() const { return p; }
   size_t size() const { return n; }
@@ -87,11 +97,24 @@ struct HostVec {
   // contents are NOT preserved when the buffer grows
   void resize_discard(size_t count) {
     if (count > cap) {
-      std::free(p);
-      const size_t bytes = ((count * sizeof(T) + (2u << 20) - 1) >> 21) << 21;
-      p = (T*) std::aligned_alloc(2u << 20, bytes);
-      if (!p) throw std::bad_alloc();
-      (void) madvise(p, bytes, MADV_HUGEPAGE);
+      release();
+      const size_t want = count + count / 8;  // head room: a map that grows a little keeps its buffer
+      const size_t bytes = ((want * sizeof(T) + (2u << 20) - 1) >> 21) << 21;
+      void* q = nullptr;
+      if (hipHostMalloc(&q, bytes, hipHostMallocDefault) == hipSuccess && q) {
+        p = (T*) q;
+      } else {
+        (void) hipGetLastError();
+        const size_t span = bytes + (2u << 20);
+        void* m = mmap(nullptr, span, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        if (m == MAP_FAILED) throw std::bad_alloc();
+        // keep the whole span (the unaligned head stays untouched, i.e. unbacked): one munmap releases it
+        char* aligned = (char*) (((uintptr_t) m + (2u << 20) - 1) & ~(uintptr_t) ((2u << 20) - 1));
+        (void) madvise(aligned, bytes, MADV_HUGEPAGE);
+        mapped = span;
+        head = (size_t) (aligned - (char*) m);
+        p = (T*) aligned;
+      }
       cap = bytes / sizeof(T);
     }
     n = count;
@@ -200,6 +223,8 @@ struct mrh_ctx {
   const int4* d_tri_sorted = nullptr;
   const u32* d_tri_counts = nullptr;
   u64* h_mc = nullptr;  // pinned: triangle total of the extraction in flight
+  u32* d_mc_recs = nullptr; size_t mc_rec_cap = 0;  // corner records of the count pass (mrh_mc.h McRecords), grow-only
+  uint64_t mc_rec_fallbacks = 0;                    // extractions whose records did not fit (emitted by k_mc<emit> instead)
   HostVec<double> V, C;
   HostVec<int32_t> F;
   // profiling
@@ -306,7 +331,7 @@ void free_all(mrh_ctx* c) {
   for (void* a : c->arena) if (a) (void) hipFree(a);
   F(c->d_decision); F(c->d_zbuf); F(c->d_realloc); F(c->d_reint); F(c->d_flag);
   F(c->d_upd_partials); F(c->d_misc); F(c->d_rcp_w); F(c->d_cfree); F(c->d_zmin); F(c->d_points); F(c->d_pt_counts); F(c->d_pt_offsets); F(c->d_rec_keys[0]); F(c->d_rec_keys[1]); F(c->d_rec_vals[0]); F(c->d_rec_vals[1]); F(c->d_sort_tmp); F(c->fast.summary); F(c->fast.summary_c); F(c->fast.bbox); F(c->d_cnt_partials);
-  F(c->d_pack); F(c->d_halo); F(c->d_taken); F(c->d_cloud); F(c->d_normals); F(c->d_soup);
+  F(c->d_pack); F(c->d_halo); F(c->d_taken); F(c->d_cloud); F(c->d_normals); F(c->d_soup); F(c->d_mc_recs);
   for (hipEvent_t e : c->mc_ev) if (e) (void) hipEventDestroy(e);
   comm_release(c);
   F(c->d_xsend); F(c->d_xrecv); F(c->d_acc);
@@ -518,6 +543,29 @@ int arena_get(mrh_ctx* c, const int slot, const size_t bytes, void** out) {
   return MRH_OK;
 }
 
+// Results leave the device through a copy KERNEL writing pinned host memory, not through hipMemcpyAsync: the runtime's choice
+// of SDMA engine for a stream is not stable within a process — the second context of a process (and every later one) moved its
+// V / C / F at 22 GB/s instead of 54 (tools/dbg_extract2.py: 30 MB in 1.24 vs 0.56 ms; tools/micro/d2h_streams.hip and
+// d2h_second_alloc.hip rule out the host buffer and the stream order in isolation) while 16-byte stores of a kernel reach 53-54 GB/s
+// every time.  It also lets the copy read its sizes on the device: no host round trip between the post-process and the copy.
+//   part p copies ceil(min(count[p], cap[p]) * unit[p] / 16) 16-byte words (both sides are padded to a multiple of 16 bytes)
+struct CopyOut {
+  const uint4* src[3];
+  uint4* dst[3];
+  const u64* count[3];  // device: elements of part p (nullptr: use fixed[p])
+  u64 fixed[3], cap[3];
+  u32 unit[3];          // bytes per element
+};
+__global__ __launch_bounds__(256) void k_copy_out(const CopyOut a) {
+#pragma unroll 1
+  for (int p = 0; p < 3; p++) {
+    if (!a.dst[p]) continue;
+    u64 n = a.count[p] ? *a.count[p] : a.fixed[p];
+    if (n > a.cap[p]) n = a.cap[p];
+    const size_t n16 = (size_t) ((n * a.unit[p] + 15) / 16);
+    for (size_t i = (size_t) blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t) gridDim.x * 256) a.dst[p][i] = a.src[p][i];
+  }
+}
 // MeshExtractor::processTriangles on the device (mrh_mesh.h): fills V / C / F from a triangle soup in device memory.
 // MRH_MESH_HOST=1 keeps the host restatement above (same arrays; tests compare the two).
 int process_triangles_device(mrh_ctx* c, const mrh_triangle* d_tris, const size_t nt) {
@@ -559,7 +607,7 @@ int process_triangles_device(mrh_ctx* c, const mrh_triangle* d_tris, const size_
     {
       void* vcf = nullptr;
       const size_t vbytes = ((size_t) n * 3 * sizeof(double) + 255) & ~(size_t) 255;
-      rc = arena_get(c, 2, 2 * vbytes + (size_t) ntr * 3 * sizeof(int), &vcf);
+      rc = arena_get(c, 2, 2 * vbytes + (size_t) ntr * 3 * sizeof(int) + 16, &vcf);  // + 16: k_copy_out reads whole 16-byte words
       if (rc) goto done;
       dV = (double*) vcf;
       dC = (double*) ((char*) vcf + vbytes);
@@ -579,15 +627,44 @@ int process_triangles_device(mrh_ctx* c, const mrh_triangle* d_tris, const size_
     MESH_TRY(rocprim::exclusive_scan(tmp, tb, keep, fpos, 0u, ntr, rocprim::plus<u32>(), s));
     k_mesh_emit_faces<<<gf, 256, 0, s>>>(corner, keep, fpos, ntr, dF);
     k_mesh_totals<<<1, 1, 0, s>>>(vid, first, n, fpos, keep, ntr, d_totals);
+    const bool dbg = getenv("MRH_DEBUG") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = now();
+    // V, C, F go out behind the post-process without the host in between (k_copy_out reads the two totals on the device), into
+    // the buffers of the previous extraction; if they turn out too small (or not pinned) they grow and the copy runs again
+    const bool pinned = !c->V.mapped && !c->C.mapped && !c->F.mapped;
+    auto copy_out = [&](const bool by_kernel, const size_t nv_known, const size_t nf_known) {
+      if (by_kernel) {
+        CopyOut a;
+        a.src[0] = (const uint4*) dV; a.dst[0] = (uint4*) c->V.data(); a.count[0] = d_totals; a.cap[0] = c->V.cap / 3; a.unit[0] = 24;
+        a.src[1] = (const uint4*) dC; a.dst[1] = (uint4*) c->C.data(); a.count[1] = d_totals; a.cap[1] = c->C.cap / 3; a.unit[1] = 24;
+        a.src[2] = (const uint4*) dF; a.dst[2] = (uint4*) c->F.data(); a.count[2] = d_totals + 1; a.cap[2] = c->F.cap / 3; a.unit[2] = 12;
+        a.fixed[0] = a.fixed[1] = a.fixed[2] = 0;
+        k_copy_out<<<1024, 256, 0, s>>>(a);
+        return hipGetLastError();
+      }
+      hipError_t e = hipMemcpyAsync(c->V.data(), dV, nv_known * 3 * sizeof(double), hipMemcpyDeviceToHost, s);
+      if (e == hipSuccess) e = hipMemcpyAsync(c->C.data(), dC, nv_known * 3 * sizeof(double), hipMemcpyDeviceToHost, s);
+      if (e == hipSuccess && nf_known) e = hipMemcpyAsync(c->F.data(), dF, nf_known * 3 * sizeof(int), hipMemcpyDeviceToHost, s);
+      return e;
+    };
+    const size_t cap_v = std::min(c->V.cap, c->C.cap) / 3, cap_f = c->F.cap / 3;
+    const bool speculative = pinned && cap_v > 0 && c->V.data() && c->C.data() && c->F.data();
+    if (speculative) MESH_TRY(copy_out(true, 0, 0));
     MESH_TRY(hipMemcpyAsync(c->h_mc + 2, d_totals, 2 * sizeof(u64), hipMemcpyDeviceToHost, s));
     MESH_TRY(hipStreamSynchronize(s));
+    const double t1 = now();
     const size_t nv = (size_t) c->h_mc[2], nf = (size_t) c->h_mc[3];
-    c->V.resize_discard(nv * 3); c->C.resize_discard(nv * 3); c->F.resize_discard(nf * 3);
-    MESH_TRY(hipMemcpyAsync(c->V.data(), dV, nv * 3 * sizeof(double), hipMemcpyDeviceToHost, s));
-    MESH_TRY(hipMemcpyAsync(c->C.data(), dC, nv * 3 * sizeof(double), hipMemcpyDeviceToHost, s));
-    if (nf) MESH_TRY(hipMemcpyAsync(c->F.data(), dF, nf * 3 * sizeof(int), hipMemcpyDeviceToHost, s));
-    MESH_TRY(hipStreamSynchronize(s));
+    const bool fits = speculative && nv <= cap_v && nf <= cap_f;
+    c->V.resize_discard(nv * 3); c->C.resize_discard(nv * 3); c->F.resize_discard(std::max<size_t>(nf, 1) * 3);
+    c->F.n = nf * 3;
+    if (!fits) {
+      MESH_TRY(copy_out(!c->V.mapped && !c->C.mapped && !c->F.mapped, nv, nf));
+      MESH_TRY(hipStreamSynchronize(s));
+    }
     MESH_TRY(hipGetLastError());
+    if (dbg) fprintf(stderr, "[mrhash_hip] mesh post-process: %u soup vertices -> %zu vertices, %zu faces | kernels%s %.2f ms, second copy (buffers grown) %.2f (%.1f MB)\n",
+                     n, nv, nf, speculative ? " + copy to the host" : "", t1 - t0, now() - t1, (nv * 48 + nf * 12) / 1e6);
   }
 done:
 #undef MESH_TRY
@@ -603,7 +680,7 @@ int ensure_soup(mrh_ctx* c, size_t n) {
     if (c->d_soup) HIP_TRY(c, hipFree(c->d_soup));
     c->d_soup = nullptr; c->soup_cap = 0;
     const size_t cap = n + n / 8;
-    HIP_TRY(c, hipMalloc((void**) &c->d_soup, cap * sizeof(mrh_triangle)));
+    HIP_TRY(c, hipMalloc((void**) &c->d_soup, cap * sizeof(mrh_triangle) + 16));  // + 16: k_copy_out reads whole 16-byte words
     c->soup_cap = cap;
   }
   return MRH_OK;
@@ -1918,8 +1995,8 @@ int mrh_extract_triangles(mrh_ctx* c, const mrh_triangle** out_tris, uint64_t* o
     // sorted list and the counts are read back only if somebody asks (mrh_get_triangle_blocks).
     u64 *k_in, *k_out, *d_offsets, *d_total;
     int4* sorted;
-    u32 *d_counts, *d_nb;
-    uint8_t* d_per_voxel;  // triangles per voxel from the count pass: the emit pass skips the empty ones
+    u32 *d_counts, *d_nb, *d_rec_base, *d_rec_n, *d_rec_ctr;
+    uint8_t* d_per_voxel;  // triangles per voxel from the count pass: k_mc<emit> (the fallback of the record pass) skips the empty ones
     void* tmp;
     size_t sort_bytes = 0, scan_bytes = 0;
     HIP_TRY(c, rocprim::radix_sort_pairs(nullptr, sort_bytes, (u64*) nullptr, (u64*) nullptr, (int4*) nullptr, (int4*) nullptr, (size_t) n, 0, 63, s));
@@ -1927,12 +2004,13 @@ int mrh_extract_triangles(mrh_ctx* c, const mrh_triangle** out_tris, uint64_t* o
     const size_t tmp_bytes = std::max(sort_bytes, scan_bytes);
     {
       MeshScratch a;
-      a.bytes = (size_t) n * (8 * 3 + 16 + 4 + 4 * kMcNbStride + 512) + tmp_bytes + 32 * 256;
+      a.bytes = (size_t) n * (8 * 3 + 16 + 4 + 4 * kMcNbStride + 512 + 8) + tmp_bytes + 32 * 256;
       rc = arena_get(c, 0, a.bytes, &a.base);
       if (rc) return rc;
       k_in = a.take<u64>((size_t) n); k_out = a.take<u64>((size_t) n); d_offsets = a.take<u64>((size_t) n);
       sorted = a.take<int4>((size_t) n); d_counts = a.take<u32>((size_t) n); d_nb = a.take<u32>((size_t) n * kMcNbStride);
       d_per_voxel = a.take<uint8_t>((size_t) n * 512); d_total = a.take<u64>(2);
+      d_rec_base = a.take<u32>((size_t) n); d_rec_n = a.take<u32>((size_t) n); d_rec_ctr = a.take<u32>(2);
       tmp = a.take<char>(tmp_bytes ? tmp_bytes : 1);
     }
     if (!c->h_mc) {
@@ -1957,27 +2035,65 @@ int mrh_extract_triangles(mrh_ctx* c, const mrh_triangle** out_tris, uint64_t* o
     if (timed)
       for (hipEvent_t& ev : c->mc_ev)
         if (!ev) HIP_TRY(c, hipEventCreate(&ev));
+    // Corner records (mrh_mc.h McRecords): the count pass parks the corner values of every voxel that produces triangles, the
+    // emit pass interpolates them.  The buffer is sized from the last extraction's demand (first time: 128 records a block);
+    // if a block finds no room the whole extraction is emitted by k_mc<emit> and the buffer grows for the next one.
+    // MRH_MC_NO_RECORDS=1 keeps the two-pass evaluation (tests compare the two).
+    const bool use_records = getenv("MRH_MC_NO_RECORDS") == nullptr;
+    if (use_records && c->mc_rec_cap == 0) {
+      const char* per_block = getenv("MRH_MC_RECORDS_PER_BLOCK");  // tests: a first buffer too small for the map
+      const size_t cap = std::max<size_t>((size_t) n * (size_t) (per_block ? std::max(1, atoi(per_block)) : 128), 16);
+      HIP_TRY(c, hipMalloc((void**) &c->d_mc_recs, cap * kMcRecWords * sizeof(u32)));
+      c->mc_rec_cap = cap;
+    }
+    McRecords R;
+    R.ctr = d_rec_ctr; R.recs = use_records ? c->d_mc_recs : nullptr; R.base = d_rec_base; R.count = d_rec_n;
+    R.cap = (u32) std::min<size_t>(c->mc_rec_cap, 0xFFFFFFF0u);
+    McRecords none;
+    none.ctr = nullptr; none.recs = nullptr; none.base = nullptr; none.count = nullptr; none.cap = 0;
+    if (use_records) HIP_TRY(c, hipMemsetAsync(d_rec_ctr, 0, 2 * sizeof(u32), s));
     if (timed) hipExtLaunchKernelGGL((k_mc<false>), dim3(grid), dim3(kMcThreads), 0, s, c->mc_ev[0], c->mc_ev[1], 0u, c->map, c->tab, (const int4*) sorted, n, (const u32*) d_nb,
-                                     (u32*) d_counts, (const u64*) nullptr, (mrh_triangle*) nullptr, (u64) 0, (uint8_t*) d_per_voxel, sdf_bound, 0);
-    else k_mc<false><<<grid, kMcThreads, 0, s>>>(c->map, c->tab, sorted, n, d_nb, d_counts, nullptr, nullptr, (u64) 0, d_per_voxel, sdf_bound, 0);
+                                     (u32*) d_counts, (const u64*) nullptr, (mrh_triangle*) nullptr, (u64) 0, (uint8_t*) d_per_voxel, sdf_bound, 0, R);
+    else k_mc<false><<<grid, kMcThreads, 0, s>>>(c->map, c->tab, sorted, n, d_nb, d_counts, nullptr, nullptr, (u64) 0, d_per_voxel, sdf_bound, 0, R);
     {
       size_t bytes = tmp_bytes;
       HIP_TRY(c, rocprim::exclusive_scan(tmp, bytes, d_counts, d_offsets, (u64) 0, (size_t) n, rocprim::plus<u64>(), s));
-      k_mc_total<<<1, 1, 0, s>>>(d_offsets, d_counts, n, d_total);
-      HIP_TRY(c, hipMemcpyAsync(c->h_mc, d_total, sizeof(u64), hipMemcpyDeviceToHost, s));
+      k_mc_total<<<1, 1, 0, s>>>(d_offsets, d_counts, n, use_records ? d_rec_ctr : nullptr, d_total);
+      HIP_TRY(c, hipMemcpyAsync(c->h_mc, d_total, 2 * sizeof(u64), hipMemcpyDeviceToHost, s));
     }
-    auto emit = [&](const u64 cap, const int flag_overflow) {
-      if (timed) hipExtLaunchKernelGGL((k_mc<true>), dim3(grid), dim3(kMcThreads), 0, s, c->mc_ev[2], c->mc_ev[3], 0u, c->map, c->tab, (const int4*) sorted, n, (const u32*) d_nb,
-                                       (u32*) d_counts, (const u64*) d_offsets, (mrh_triangle*) c->d_soup, cap, (uint8_t*) d_per_voxel, 0.f, flag_overflow);
-      else k_mc<true><<<grid, kMcThreads, 0, s>>>(c->map, c->tab, sorted, n, d_nb, d_counts, d_offsets, c->d_soup, cap, d_per_voxel, 0.f, flag_overflow);
+    auto emit = [&](const u64 cap, const int flag_overflow, const bool from_records) {
+      if (from_records) {
+        if (timed) hipExtLaunchKernelGGL(k_mc_emit_records, dim3(grid), dim3(kMcThreads), 0, s, c->mc_ev[2], c->mc_ev[3], 0u, c->map, c->tab, (const int4*) sorted, n, R,
+                                         (const u64*) d_offsets, (mrh_triangle*) c->d_soup, cap, flag_overflow);
+        else k_mc_emit_records<<<grid, kMcThreads, 0, s>>>(c->map, c->tab, sorted, n, R, d_offsets, c->d_soup, cap, flag_overflow);
+      } else {
+        if (timed) hipExtLaunchKernelGGL((k_mc<true>), dim3(grid), dim3(kMcThreads), 0, s, c->mc_ev[2], c->mc_ev[3], 0u, c->map, c->tab, (const int4*) sorted, n, (const u32*) d_nb,
+                                         (u32*) d_counts, (const u64*) d_offsets, (mrh_triangle*) c->d_soup, cap, (uint8_t*) d_per_voxel, 0.f, flag_overflow, none);
+        else k_mc<true><<<grid, kMcThreads, 0, s>>>(c->map, c->tab, sorted, n, d_nb, d_counts, d_offsets, c->d_soup, cap, d_per_voxel, 0.f, flag_overflow, none);
+      }
     };
     // The emit pass goes out BEFORE the host knows the total, into the soup buffer of the previous extraction (grow-only, 12 %
     // head room): a map that is extracted again — the usual case — needs no round trip between the two passes.  Writes beyond
     // the capacity are suppressed by the kernel; if the total turns out larger, the buffer grows and the pass runs again.
     const u64 spec_cap = std::min<u64>(c->soup_cap, c->max_triangles);
-    if (spec_cap > 0) emit(spec_cap, 0);
+    if (spec_cap > 0) emit(spec_cap, 0, use_records);
     HIP_TRY(c, hipStreamSynchronize(s));
     const u64 total = c->h_mc[0];
+    const u64 rec_demand = c->h_mc[1] & ~(1ull << 63);
+    const bool records_ok = use_records && (c->h_mc[1] >> 63) == 0;
+    const bool emitted = spec_cap > 0 && total <= spec_cap && (records_ok || !use_records);
+    struct GrowRecords {  // on every way out: room for this map's demand (+ 25 %) at the next extraction
+      mrh_ctx* c; u64 demand;
+      ~GrowRecords() {
+        if (demand <= c->mc_rec_cap) return;
+        (void) hipStreamSynchronize(c->stream);
+        if (c->d_mc_recs) (void) hipFree(c->d_mc_recs);
+        c->d_mc_recs = nullptr; c->mc_rec_cap = 0;
+        const size_t cap = (size_t) (demand + demand / 4);
+        if (hipMalloc((void**) &c->d_mc_recs, cap * kMcRecWords * sizeof(u32)) == hipSuccess) c->mc_rec_cap = cap;
+        else (void) hipGetLastError();  // no room: the next extraction starts from the default again
+      }
+    } grow_records{c, use_records ? rec_demand : 0};
     if (dbg) t2 = now();
     c->tri_dev_n = n;
     c->d_tri_sorted = sorted;
@@ -1986,10 +2102,11 @@ int mrh_extract_triangles(mrh_ctx* c, const mrh_triangle** out_tris, uint64_t* o
       return fail(c, MRH_ERR_CAPACITY, "triangle buffer full: %llu triangles > max_triangles %llu", (unsigned long long) total, (unsigned long long) c->max_triangles);
     }
     if (total > 0) {
-      if (total > spec_cap) {
+      if (!emitted) {
         rc = ensure_soup(c, (size_t) total);
         if (rc) return rc;
-        emit(total, 1);
+        emit(total, 1, records_ok);
+        if (use_records && !records_ok) c->mc_rec_fallbacks++;
       }
       mrh_triangle* d_tris = c->d_soup;
       c->soup_n = (size_t) total;
@@ -2001,7 +2118,14 @@ int mrh_extract_triangles(mrh_ctx* c, const mrh_triangle** out_tris, uint64_t* o
       if (dbg) { HIP_TRY(c, hipStreamSynchronize(s)); t3 = now(); }
       if (want_soup) {
         c->tris.resize_discard(total);
-        HIP_TRY(c, hipMemcpyAsync(c->tris.data(), d_tris, total * sizeof(mrh_triangle), hipMemcpyDeviceToHost, s));
+        if (!c->tris.mapped) {  // pinned: out through the copy kernel (see k_copy_out)
+          CopyOut a;
+          for (int p = 0; p < 3; p++) { a.src[p] = nullptr; a.dst[p] = nullptr; a.count[p] = nullptr; a.fixed[p] = 0; a.cap[p] = 0; a.unit[p] = 0; }
+          a.src[0] = (const uint4*) d_tris; a.dst[0] = (uint4*) c->tris.data(); a.fixed[0] = total; a.cap[0] = total; a.unit[0] = (u32) sizeof(mrh_triangle);
+          k_copy_out<<<1024, 256, 0, s>>>(a);
+        } else {
+          HIP_TRY(c, hipMemcpyAsync(c->tris.data(), d_tris, total * sizeof(mrh_triangle), hipMemcpyDeviceToHost, s));
+        }
       }
       if (dbg) { HIP_TRY(c, hipStreamSynchronize(s)); t4 = now(); }
       int prc = MRH_OK;

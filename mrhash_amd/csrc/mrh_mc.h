@@ -331,14 +331,38 @@ __device__ __forceinline__ int mc_voxel(const Map& m, const Tab& t, const Neigh&
 // values as the sequential mc_voxel, so the same result.  With EMIT the up to 15 vertices of the voxel are interpolated
 // by the 8 lanes (two each) and stored straight into out[0 .. min(ntri, room)).  Must be called by all 8 lanes of a group
 // (inactive groups pass active = false and take part in the ballots with neutral values).
+// the up to 15 vertices of one voxel by its 8 lanes (two slots each): lane `k` holds corner k's value and colour, `row` = the
+// voxel's triangle-table row, triangles j < room are stored to out[j] (marching_cubes.cu:205-261)
+__device__ __forceinline__ void mc_emit_vertices(const f3 pf, const f3 sP, const f3 sM, const float dist, const u32 col, const uint8_t* row,
+                                                 const int ntri, const int k, const int gb, mrh_triangle* out, const int room) {
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    const int sidx = k + 8 * h;  // vertex slot: triangle sidx / 3, corner sidx % 3
+    const bool mine = sidx < 3 * ntri;
+    const int code = mine ? (int) row[1 + sidx] : 0;
+    const int a = code >> 4, b = code & 0xF;
+    const float da = __shfl(dist, gb + a), db = __shfl(dist, gb + b);
+    const u32 ca = (u32) __shfl((int) col, gb + a), cb = (u32) __shfl((int) col, gb + b);
+    const f3 pa = mk3(pf.x + ((a & 1) ? sP.x : sM.x), pf.y + ((a & 2) ? sP.y : sM.y), pf.z + ((a & 4) ? sP.z : sM.z));
+    const f3 pb = mk3(pf.x + ((b & 1) ? sP.x : sM.x), pf.y + ((b & 2) ? sP.y : sM.y), pf.z + ((b & 4) ? sP.z : sM.z));
+    if (mine && sidx / 3 < room) out[sidx / 3].v[sidx % 3] = vertex_interp(pa, pb, da, db, ca, cb);
+  }
+}
+
+// corner record of the count pass (k_mc_emit_records): this lane's corner value and colour, and the six checkVertexVoxels flags
+struct McCorner {
+  float dist;
+  u32 col, flags;
+};
 template <bool EMIT>
 __device__ __forceinline__ int mc_group(const Map& m, const Tab& t, const Neigh& nb, const f3 pf, const int v, const bool stencil_known,
-                                        const int k, const int gb, const bool active, mrh_triangle* out, const int room) {
+                                        const int k, const int gb, const bool active, mrh_triangle* out, const int room, McCorner* rec = nullptr) {
   const float vvs = get_voxel_size_f(m, t, nb, pf);
   const float P = vvs * 0.5f;
   const float M = -P;
   f3 sP = mk3(P * 1.f, P * 1.f, P * 1.f);
   f3 sM = mk3(M * 1.f, M * 1.f, M * 1.f);
+  u32 vflags = 0;
   if (t.multi_res) {
     // marching_cubes.cu:7-69 checkVertexVoxels: six independent tests, lane j < 6 takes test j (+x, -x, +y, -y, +z, -z)
     bool flag = false;
@@ -349,6 +373,7 @@ __device__ __forceinline__ int mc_group(const Map& m, const Tab& t, const Neigh&
       flag = vs > 0 && vs < 1 && vs != vvs;
     }
     const u32 flags = (u32) (__ballot(flag) >> gb) & 0x3Fu;
+    vflags = flags;
     if (flags & 1u) sP.x *= 0.499f;
     if (flags & 2u) sM.x *= 0.499f;
     if (flags & 4u) sP.y *= 0.499f;
@@ -379,20 +404,8 @@ __device__ __forceinline__ int mc_group(const Map& m, const Tab& t, const Neigh&
   const u32 failmask = (u32) (__ballot(fail && active) >> gb) & 0xFFu;
   const uint8_t* row = d_mc_tri[cube];
   const int ntri = (!active || badmask || failmask) ? 0 : (int) row[0];
-  if (EMIT) {
-#pragma unroll
-    for (int h = 0; h < 2; h++) {
-      const int sidx = k + 8 * h;  // vertex slot: triangle sidx / 3, corner sidx % 3
-      const bool mine = sidx < 3 * ntri;
-      const int code = mine ? (int) row[1 + sidx] : 0;
-      const int a = code >> 4, b = code & 0xF;
-      const float da = __shfl(dist, gb + a), db = __shfl(dist, gb + b);
-      const u32 ca = (u32) __shfl((int) col, gb + a), cb = (u32) __shfl((int) col, gb + b);
-      const f3 pa = mk3(pf.x + ((a & 1) ? sP.x : sM.x), pf.y + ((a & 2) ? sP.y : sM.y), pf.z + ((a & 4) ? sP.z : sM.z));
-      const f3 pb = mk3(pf.x + ((b & 1) ? sP.x : sM.x), pf.y + ((b & 2) ? sP.y : sM.y), pf.z + ((b & 4) ? sP.z : sM.z));
-      if (mine && sidx / 3 < room) out[sidx / 3].v[sidx % 3] = vertex_interp(pa, pb, da, db, ca, cb);
-    }
-  }
+  if (!EMIT && rec) { rec->dist = dist; rec->col = col; rec->flags = vflags | (vvs != m.vs * (float) (1 << 0) ? 64u : 0u); }
+  if (EMIT) mc_emit_vertices(pf, sP, sM, dist, col, row, ntri, k, gb, out, room);
   return ntri;
 }
 
@@ -472,10 +485,27 @@ __global__ __launch_bounds__(256) void k_mc_neighbors(const Tab t, const int4* _
   nb[e * kMcNbStride + i] = val;
 }
 // triangle total of an extraction = last exclusive offset + last count
-__global__ void k_mc_total(const u64* __restrict__ offsets, const u32* __restrict__ counts, const int n, u64* __restrict__ total) {
+__global__ void k_mc_total(const u64* __restrict__ offsets, const u32* __restrict__ counts, const int n, const u32* __restrict__ rec_ctr,
+                           u64* __restrict__ total) {
   total[0] = offsets[n - 1] + counts[n - 1];
+  total[1] = rec_ctr ? ((u64) rec_ctr[0] | ((u64) (rec_ctr[1] & 1u) << 63)) : (1ull << 63);  // records asked for | did not fit
 }
 
+// The count pass evaluates every candidate's eight corner values anyway; for the voxels that produce triangles it parks them
+// (72 bytes a voxel) so that the emit pass is a flat interpolation of records instead of a second staging + evaluation:
+//   record r = 18 words: [0..7] corner values, [8..15] corner colours (rgbw), [16] voxel | checkVertexVoxels flags << 16,
+//   [17] triangles of the block's earlier voxels (patched in after the block's scan)
+// Space is reserved per block by its candidate count (one atomic per block); a block that finds no room sets the overflow word
+// and the host falls back to k_mc<emit> for the whole extraction (and grows the buffer for the next one).
+constexpr u32 kMcNoRecords = 0xFFFFFFFFu;
+constexpr int kMcRecWords = 18;
+struct McRecords {
+  u32* ctr;       // [0] records reserved so far (keeps counting past the capacity: the demand), [1] overflow flag
+  u32* recs;      // [cap * kMcRecWords]
+  u32* base;      // [n] first record of block e, or kMcNoRecords
+  u32* count;     // [n] records of block e
+  u32 cap;
+};
 constexpr int kMcThreads = 256;
 #ifdef MRH_MC_TRACE
 // tuning builds only (tools/trace_mc.sh): shader-clock cycles of thread 0 per phase, one record per block and pass (no atomics:
@@ -501,16 +531,17 @@ __global__ __launch_bounds__(kMcThreads) __attribute__((amdgpu_waves_per_eu(4, 4
                                                    const u32* __restrict__ nb_table,
                                                    u32* __restrict__ counts, const u64* __restrict__ offsets,
                                                    mrh_triangle* __restrict__ out, const u64 max_tris, uint8_t* __restrict__ per_voxel,
-                                                   const float sdf_bound, const int flag_overflow) {
+                                                   const float sdf_bound, const int flag_overflow, const McRecords R) {
   __shared__ u32 s_nb[27];
   __shared__ float s_sdf[kHaloCells];
   __shared__ u32 s_rgbw[kHaloCells];
-  __shared__ uint8_t s_cls[2][kHaloCells];
+  __shared__ __attribute__((aligned(16))) uint8_t s_cls[2][kHaloCells];
   __shared__ unsigned short s_cand[512];
   __shared__ uint8_t s_ntri[512];
   __shared__ u32 s_off[512];
   __shared__ u32 s_wave[kMcThreads / 64];
   __shared__ u32 s_ncand[2];  // [0] candidates with a known stencil (list grows from s_cand[0] up), [1] the others (from s_cand[511] down)
+  __shared__ u32 s_rec[2];    // count pass: [0] first record of this block (kMcNoRecords: none), [1] records written
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   for (int e = blockIdx.x; e < n; e += gridDim.x) {
@@ -688,6 +719,19 @@ __global__ __launch_bounds__(kMcThreads) __attribute__((amdgpu_waves_per_eu(4, 4
     }
     __syncthreads();
     const int ncand[2] = {(int) s_ncand[0], (int) s_ncand[1]};
+    if (!EMIT && R.recs) {  // room for one record per candidate
+      if (tid == 0) {
+        const u32 want = (u32) (ncand[0] + ncand[1]);
+        u32 first = kMcNoRecords;
+        if (want) {
+          first = atomicAdd(&R.ctr[0], want);
+          if (first > R.cap || want > R.cap - first) { first = kMcNoRecords; atomicOr(&R.ctr[1], 1u); }
+        }
+        s_rec[0] = first;
+        s_rec[1] = 0;
+      }
+      __syncthreads();
+    }
     MRH_MC_TS(ts2);
     auto voxel_position = [&](const int v) {
       i3 pi;
@@ -696,6 +740,7 @@ __global__ __launch_bounds__(kMcThreads) __attribute__((amdgpu_waves_per_eu(4, 4
       return voxel_to_world(m.vs, pi);
     };
     const int gb = lane & ~7, corner = lane & 7;
+    unsigned short* s_recv = (unsigned short*) &s_cls[1][0];  // voxel of record slot i (the class planes are done with)
     if (!EMIT) {
       // ---- dense evaluation of the candidates, 8 lanes each; per-voxel counts to LDS
 #pragma unroll 1
@@ -706,8 +751,18 @@ __global__ __launch_bounds__(kMcThreads) __attribute__((amdgpu_waves_per_eu(4, 4
           const bool active = i < ncand[kind] * 8;
           const int ci = active ? (i >> 3) : 0;
           const int v = s_cand[kind == 0 ? ci : 511 - ci];
-          const int ntri = mc_group<false>(m, t, nb, voxel_position(v), v, kind == 0, corner, gb, active, nullptr, 0);
+          McCorner cr;
+          const int ntri = mc_group<false>(m, t, nb, voxel_position(v), v, kind == 0, corner, gb, active, nullptr, 0, &cr);
           if (active && corner == 0) s_ntri[v] = (uint8_t) ntri;
+          if (R.recs && ntri > 0 && s_rec[0] != kMcNoRecords) {  // group-uniform
+            u32 slot = 0;
+            if (corner == 0) slot = atomicAdd(&s_rec[1], 1u);
+            slot = (u32) __shfl((int) slot, gb);
+            u32* r = R.recs + (size_t) (s_rec[0] + slot) * kMcRecWords;
+            r[corner] = __float_as_uint(cr.dist);
+            r[8 + corner] = cr.col;
+            if (corner == 0) { r[16] = (u32) v | (cr.flags << 16); s_recv[slot] = (unsigned short) v; }
+          }
         }
 #ifdef MRH_MC_TRACE
         if (kind == 0) { __syncthreads(); MRH_MC_TS(tsk); MRH_MC_ACC(2, ts2, tsk); MRH_MC_ACC(3, 0, -tsk); }
@@ -737,6 +792,16 @@ __global__ __launch_bounds__(kMcThreads) __attribute__((amdgpu_waves_per_eu(4, 4
     for (int i = 0; i < kMcThreads / 64; i++) { if (i < (tid >> 6)) wave_off += s_wave[i]; total += s_wave[i]; }
     if (!EMIT) {
       if (tid == 0) counts[e] = total;
+      if (R.recs) {
+        const u32 ex0 = wave_off + incl - (c0 + c1);
+        s_off[v0] = ex0;
+        s_off[v0 + 1] = ex0 + c0;
+        __syncthreads();
+        const u32 first = s_rec[0], nrec = s_rec[1];
+        if (first != kMcNoRecords)
+          for (u32 i = tid; i < nrec; i += kMcThreads) R.recs[(size_t) (first + i) * kMcRecWords + 17] = s_off[s_recv[i]];
+        if (tid == 0) { R.base[e] = first; R.count[e] = first != kMcNoRecords ? nrec : 0u; }
+      }
     } else {
       // exclusive offsets of this thread's two voxels, parked in LDS for the groups that evaluate them
       const u32 ex0 = wave_off + incl - (c0 + c1);
@@ -772,6 +837,55 @@ __global__ __launch_bounds__(kMcThreads) __attribute__((amdgpu_waves_per_eu(4, 4
       MRH_MC_ADD(0, tr_cls + 1); MRH_MC_ADD(6, ncand[0]); MRH_MC_ADD(7, ncand[1]);
     }
 #endif
+  }
+}
+
+// The emit pass over the records of the count pass: eight lanes per record, no staging, no evaluation.  Block e's records are
+// R.base[e] .. + R.count[e]; a record's triangles start at offsets[e] + word 17 — the canonical (block, voxel, triangle) order of
+// k_mc<emit>, whose vertex arithmetic (mc_emit_vertices on the recorded corner values) this shares.
+__global__ __launch_bounds__(kMcThreads) void k_mc_emit_records(const Map m, const Tab t, const int4* __restrict__ sorted, const int n, const McRecords R,
+                                                               const u64* __restrict__ offsets, mrh_triangle* __restrict__ out, const u64 max_tris,
+                                                               const int flag_overflow) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int gb = lane & ~7, corner = lane & 7;
+  for (int e = blockIdx.x; e < n; e += gridDim.x) {
+    const u32 first_rec = R.base[e], nrec = R.count[e];
+    if (first_rec == kMcNoRecords || nrec == 0) continue;  // uniform
+    const int4 ent = sorted[e];
+    const bool coarse = ((u32) ent.w & kValCoarseBit) != 0;
+    const u64 block_first = offsets[e];
+    for (u32 base = 0; base < nrec * 8u; base += kMcThreads) {
+      const u32 i = base + tid;
+      const bool active = i < nrec * 8u;
+      const u32* r = R.recs + (size_t) (first_rec + (active ? (i >> 3) : 0u)) * kMcRecWords;
+      const float dist = __uint_as_float(r[corner]);
+      const u32 col = r[8 + corner];
+      const u32 w16 = r[16], voff = r[17];
+      const int v = (int) (w16 & 0xFFFFu);
+      const u32 flags = w16 >> 16;
+      i3 pi;
+      if (!coarse) pi = mki3(ent.x * kBlockSide + (v & 7), ent.y * kBlockSide + ((v >> 3) & 7), ent.z * kBlockSide + (v >> 6));
+      else pi = mki3(ent.x * kBlockSide + 2 * (v & 3), ent.y * kBlockSide + 2 * ((v >> 2) & 3), ent.z * kBlockSide + 2 * (v >> 4));
+      const f3 pf = voxel_to_world(m.vs, pi);
+      const float vvs = m.vs * (float) (1 << ((flags & 64u) ? 1 : 0));
+      const float P = vvs * 0.5f;
+      const float M = -P;
+      f3 sP = mk3(P * 1.f, P * 1.f, P * 1.f);
+      f3 sM = mk3(M * 1.f, M * 1.f, M * 1.f);
+      if (flags & 1u) sP.x *= 0.499f;
+      if (flags & 2u) sM.x *= 0.499f;
+      if (flags & 4u) sP.y *= 0.499f;
+      if (flags & 8u) sM.y *= 0.499f;
+      if (flags & 16u) sP.z *= 0.499f;
+      if (flags & 32u) sM.z *= 0.499f;
+      const u32 cube = (u32) (__ballot(dist < 0.f) >> gb) & 0xFFu;
+      const uint8_t* row = d_mc_tri[cube];
+      const int ntri = active ? (int) row[0] : 0;
+      const u64 first = block_first + voff;
+      const int room = first >= max_tris ? 0 : (int) (max_tris - first < 5 ? max_tris - first : 5);
+      mc_emit_vertices(pf, sP, sM, dist, col, row, ntri, corner, gb, out + first, room);
+      if (flag_overflow && active && corner == 0 && ntri > room) atomicOr((u32*) &t.ctr[CTR_ERROR], ERR_TRI);
+    }
   }
 }
 

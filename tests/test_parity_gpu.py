@@ -513,6 +513,28 @@ def test_multires_640x480_long_run_and_mesh(hip, oracle):
     assert m["triangles"] > 300000
 
 
+@pytest.mark.parametrize("var", [0.0, 0.005])
+def test_emit_from_corner_records_equals_the_two_pass_emit(hip, monkeypatch, var):
+    """The emit pass has two forms: interpolation of the corner records the count pass parked (k_mc_emit_records) and the
+    second evaluation (k_mc<emit>: MRH_MC_NO_RECORDS=1, and the fallback when the record buffer is too small).  Same
+    soup, byte for byte — single- and multi-resolution map — through: a first buffer that is too small (fallback, the
+    buffer grows), the grown buffer (records), and records switched off."""
+    params = dict(synth.REPLICA_PARAMS, sdf_var_threshold=var, n_frames_invalidate_voxels=10)
+    monkeypatch.setenv("MRH_MC_RECORDS_PER_BLOCK", "1")
+    e = pu.make_engine(hip, synth.REPLICA_640, params, 131072)
+    for f in synth.replica_stream(12):
+        pu.feed(e, f)
+    e.sync()
+    first = e.extract_triangles()       # one record per block: does not fit -> k_mc<emit>
+    second = e.extract_triangles()      # buffer grown to the demand: k_mc_emit_records
+    third = e.extract_triangles()
+    monkeypatch.setenv("MRH_MC_NO_RECORDS", "1")
+    plain = e.extract_triangles()
+    assert len(plain) > 100000
+    assert first.tobytes() == plain.tobytes() and second.tobytes() == plain.tobytes() and third.tobytes() == plain.tobytes()
+    e.close()
+
+
 def test_stream_out_and_import_match_oracle(hip, oracle):
     """Streamer device half (mrh_stream_out / mrh_import_blocks): the same blocks leave, in position order, with the
     same payload; what stays is the same map; importing them back restores the original; fusion continues identically."""
