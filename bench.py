@@ -187,7 +187,7 @@ def profiled_roofline(eng, res: Resident, W: int, total: int, label: str):
             "profiled_pass_ms_per_step": prof_elapsed / max(total - W, 1) * 1e3}
 
 
-def pmc_traffic(args, kernel_prefix: str, cache: str, inner: str = "--pmc-inner", steps: int = 0, warmup: int = 0, per_run_of: int = 0):
+def pmc_traffic(args, kernel_prefix, cache: str, inner: str = "--pmc-inner", steps: int = 0, warmup: int = 0, per_run_of: int = 0):
     """HBM bytes per launch of `kernel_prefix` from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE: separate runs,
     no trace flags beside --pmc) of this workload run as a sub-process.  Units are KiB; on gfx950 FETCH_SIZE counts a
     wide coalesced read at half its bytes, so it is doubled (MI355X_MICROARCH.md, HBM section)."""
@@ -330,9 +330,9 @@ def bench_single(args):
               "multires_frames_per_s": K / mr_elapsed, "multires_ms_per_step": mr_elapsed / K * 1e3,
               "fine_blocks": int(ms.occupied_fine), "coarse_blocks": int(ms.occupied_coarse), "triangles": int(ntri),
               "extract_ms_in_library": extract_ms, "extract_ms_runs": ext, "k_mc_count_ms": float(ms.last_mc_count_ms), "k_mc_emit_ms": float(ms.last_mc_emit_ms),
-              "roofline": {"bound": "hbm", "kernel": "k_mc<count> + k_mc<emit>", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+              "roofline": {"bound": "hbm", "kernel": "k_mc<count> + k_mc_emit_records", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": ach / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes": alg_mc,
-                           "note": "6144 B per fine block + 768 B per coarse block read once + 72 B per triangle written; latency / issue-bound, far below the HBM roof"}}
+                           "note": "6144 B per fine block + 768 B per coarse block read once + 72 B per triangle written; the count pass parks 72 B of corner values per productive voxel for the emit pass (in `traffic`, not in the algorithmic bytes); latency / issue-bound, far below the HBM roof"}}
         me.close()
 
     # ---- configs[4], LiDAR half: 128 x 1024 scans along a street (vbr.cfg parameters), scans resident in HBM
@@ -516,7 +516,7 @@ def bench_single(args):
             roof_hbm["traffic"], roof_hbm["traffic_note"] = pmc_traffic(args, "mrh::k_back<true, false", big_cache, "--pmc-inner-big", nb - wb, wb)
 
     if mc is not None and not args.no_pmc:  # HBM bytes of the two k_mc launches of one extraction (two extractions in the sub-process)
-        mc["roofline"]["traffic"], mc["roofline"]["traffic_note"] = pmc_traffic(args, "mrh::k_mc<", cache, "--pmc-inner-mc", per_run_of=2)
+        mc["roofline"]["traffic"], mc["roofline"]["traffic_note"] = pmc_traffic(args, ("mrh::k_mc<", "mrh::k_mc_emit_records"), cache, "--pmc-inner-mc", per_run_of=2)
 
     # ---- HBM traffic of the headline kernel, measured now (sub-processes under rocprofv3)
     if not args.no_pmc:

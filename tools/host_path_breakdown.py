@@ -19,11 +19,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--frames", type=int, default=300)
     args = ap.parse_args()
-    import torch
+    from mrhash_amd import capi, hipmem, synth
 
-    from mrhash_amd import capi, synth
-
-    torch.cuda.set_device(0)
+    hipmem.set_device(0)
     hip = capi.load_hip()
     K, P = synth.REPLICA_640, synth.REPLICA_PARAMS
     frames = bench.render_stream("replica", 40)
@@ -57,7 +55,7 @@ def main():
         e.upload_depth(f.depth); e.upload_rgb(f.rgb)
     t_host = time.perf_counter() - t0
     e.sync()
-    torch.cuda.synchronize()
+    hipmem.synchronize()
     print(f"uploads alone: {t_host / n * 1e6:.1f} us per frame")
     # the same loop with inputs already in HBM: the host cost of mrh_integrate's own enqueues
     res = bench.Resident(frames, K)
