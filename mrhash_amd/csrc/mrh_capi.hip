@@ -632,7 +632,7 @@ int process_triangles_device(mrh_ctx* c, const mrh_triangle* d_tris, const size_
     const double t0 = now();
     // V, C, F go out behind the post-process without the host in between (k_copy_out reads the two totals on the device), into
     // the buffers of the previous extraction; if they turn out too small (or not pinned) they grow and the copy runs again
-    const bool pinned = !c->V.mapped && !c->C.mapped && !c->F.mapped;
+    const bool pinned = !c->V.mapped && !c->C.mapped && !c->F.mapped && !getenv("MRH_D2H_MEMCPY");  // MRH_D2H_MEMCPY=1: hipMemcpyAsync instead (A/B)
     auto copy_out = [&](const bool by_kernel, const size_t nv_known, const size_t nf_known) {
       if (by_kernel) {
         CopyOut a;
@@ -659,7 +659,7 @@ int process_triangles_device(mrh_ctx* c, const mrh_triangle* d_tris, const size_
     c->V.resize_discard(nv * 3); c->C.resize_discard(nv * 3); c->F.resize_discard(std::max<size_t>(nf, 1) * 3);
     c->F.n = nf * 3;
     if (!fits) {
-      MESH_TRY(copy_out(!c->V.mapped && !c->C.mapped && !c->F.mapped, nv, nf));
+      MESH_TRY(copy_out(!c->V.mapped && !c->C.mapped && !c->F.mapped && !getenv("MRH_D2H_MEMCPY"), nv, nf));
       MESH_TRY(hipStreamSynchronize(s));
     }
     MESH_TRY(hipGetLastError());
