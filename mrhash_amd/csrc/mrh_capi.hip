@@ -177,6 +177,7 @@ struct mrh_ctx {
   const float* d_points_cur = nullptr;  // ... or the caller's device pointer (mrh_set_points_device)
   uint64_t points_cap = 0, num_points = 0;
   u32* d_pt_counts = nullptr; u32* d_pt_offsets = nullptr; uint64_t pt_cap = 0;
+  u32 scan_ticket = 0;  // value of the device's workgroup ticket before the next LiDAR count pass (mrh_lidar.h ScanState)
   u32* h_scan = nullptr;               // pinned {hwm, last offset, last count, sequence}: the one report of a scan
   u32 scan_seq = 0;
   void* d_rec_keys[2] = {nullptr, nullptr}; float* d_rec_vals[2] = {nullptr, nullptr}; uint64_t rec_cap = 0; size_t rec_key_bytes = 0;
@@ -1610,7 +1611,9 @@ int mrh_integrate_points(mrh_ctx* c, int n_frames_invalidate) {
       if (c->d_pt_offsets) HIP_TRY(c, hipFree(c->d_pt_offsets));
       c->d_pt_counts = c->d_pt_offsets = nullptr;
       HIP_TRY(c, hipMalloc((void**) &c->d_pt_counts, n * sizeof(u32)));
-      HIP_TRY(c, hipMalloc((void**) &c->d_pt_offsets, n * sizeof(u32)));
+      HIP_TRY(c, hipMalloc((void**) &c->d_pt_offsets, (n / 256 + 2) * sizeof(u32)));  // one total per count workgroup + the ticket
+      HIP_TRY(c, hipMemsetAsync(c->d_pt_offsets, 0, (n / 256 + 2) * sizeof(u32), s));
+      c->scan_ticket = 0;
       c->pt_cap = n;
     }
     if (!c->h_scan) {
@@ -1618,24 +1621,17 @@ int mrh_integrate_points(mrh_ctx* c, int n_frames_invalidate) {
       memset(c->h_scan, 0, 4 * sizeof(u32));
     }
     auto integrate_scan = [&]() -> int {
-      k_points_walk<false, u32><<<grid, 256, 0, s>>>(k, m, t, pts, normals, np, c->d_pt_counts, nullptr, (u32*) nullptr, nullptr, coarse_bit);
-      size_t need = 0;
-      HIP_TRY(c, rocprim::exclusive_scan(nullptr, need, c->d_pt_counts, c->d_pt_offsets, 0u, n, rocprim::plus<u32>(), s));
-      if (need > c->sort_tmp_bytes) {
-        HIP_TRY(c, hipStreamSynchronize(s));
-        if (c->d_sort_tmp) HIP_TRY(c, hipFree(c->d_sort_tmp));
-        c->d_sort_tmp = nullptr;
-        HIP_TRY(c, hipMalloc(&c->d_sort_tmp, need));
-        c->sort_tmp_bytes = need;
-      }
-      size_t tb = c->sort_tmp_bytes;
-      HIP_TRY(c, rocprim::exclusive_scan(c->d_sort_tmp, tb, c->d_pt_counts, c->d_pt_offsets, 0u, n, rocprim::plus<u32>(), s));
-      // the one host round trip of a scan: a one-lane kernel writes {high-water mark, last offset, last count} and a sequence
-      // mark into pinned memory; the emit pass is enqueued behind it and runs while the report travels and the host reads it
-      const u32 seq = ++c->scan_seq;
-      k_scan_report<<<1, 64, 0, s>>>(t.ctr, c->d_pt_offsets, c->d_pt_counts, np, c->h_scan, seq);
-      if (wide) k_points_walk<true, u64><<<grid, 256, 0, s>>>(k, m, t, pts, normals, np, nullptr, c->d_pt_offsets, (u64*) c->d_rec_keys[0], c->d_rec_vals[0], coarse_bit);
-      else k_points_walk<true, u32><<<grid, 256, 0, s>>>(k, m, t, pts, normals, np, nullptr, c->d_pt_offsets, (u32*) c->d_rec_keys[0], c->d_rec_vals[0], coarse_bit);
+      // the one host round trip of a scan: the LAST count workgroup to finish writes {high-water mark, records} and a sequence
+      // mark into pinned memory; the emit pass — which derives its offsets from the per-workgroup totals itself — is enqueued
+      // behind the count pass and runs while the report travels and the host reads it
+      ScanState ss;
+      ss.wg_totals = c->d_pt_offsets + 1; ss.ticket = c->d_pt_offsets; ss.host_rec = c->h_scan; ss.seq = ++c->scan_seq;
+      ss.ticket_base = c->scan_ticket;
+      c->scan_ticket += grid;
+      const u32 seq = ss.seq;
+      k_points_walk<false, u32><<<grid, 256, 0, s>>>(k, m, t, pts, normals, np, c->d_pt_counts, ss, (u32*) nullptr, nullptr, coarse_bit);
+      if (wide) k_points_walk<true, u64><<<grid, 256, 0, s>>>(k, m, t, pts, normals, np, c->d_pt_counts, ss, (u64*) c->d_rec_keys[0], c->d_rec_vals[0], coarse_bit);
+      else k_points_walk<true, u32><<<grid, 256, 0, s>>>(k, m, t, pts, normals, np, c->d_pt_counts, ss, (u32*) c->d_rec_keys[0], c->d_rec_vals[0], coarse_bit);
       HIP_TRY(c, hipGetLastError());
       {
         volatile u32* mark = c->h_scan + 3;
@@ -1650,7 +1646,7 @@ int mrh_integrate_points(mrh_ctx* c, int n_frames_invalidate) {
         std::atomic_thread_fence(std::memory_order_acquire);
       }
       const int hwm = (int) c->h_scan[0];
-      const uint64_t n_rec = (uint64_t) c->h_scan[1] + c->h_scan[2];
+      const uint64_t n_rec = (uint64_t) c->h_scan[1];
       if (n_rec > rec_bound) return fail(c, MRH_ERR_DEVICE, "mrh_integrate_points: %llu records exceed the bound of %llu", (unsigned long long) n_rec, (unsigned long long) rec_bound);
       if (n_rec == 0) return MRH_OK;
       // the sort only looks at the bits a voxel id of THIS map can have (the high-water mark of the pool); it is stable, and the

@@ -590,16 +590,6 @@ __global__ __launch_bounds__(64) void k_reintegrate(const Cam c, const Map m, co
 __global__ __launch_bounds__(256) void k_init_table(u64* keys, const size_t slots) {
   for (size_t i = (size_t) blockIdx.x * 256 + threadIdx.x; i < slots; i += (size_t) gridDim.x * 256) keys[i] = kKeyEmpty;
 }
-// the one report of a LiDAR scan (mrh_integrate_points) into pinned host memory: {high-water mark, last offset, last count}, then the mark
-__global__ void k_scan_report(const int* __restrict__ ctr, const u32* __restrict__ offsets, const u32* __restrict__ counts, const u32 n,
-                              u32* __restrict__ host_rec, const u32 seq) {
-  if (threadIdx.x != 0) return;
-  host_rec[0] = (u32) ctr[CTR_HWM_FINE];
-  host_rec[1] = offsets[n - 1];
-  host_rec[2] = counts[n - 1];
-  __threadfence_system();
-  __hip_atomic_store(&host_rec[3], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-}
 // the per-frame report of mrh_peek_free_blocks / mrh_peek_error_flags: ctr[0 .. 4] into a pinned host record (one lane; a
 // 20-byte hipMemcpyAsync would cost the host as much as the two launches of the frame together)
 __global__ void k_report(const int* __restrict__ ctr, int* __restrict__ host_rec) {

@@ -129,20 +129,59 @@ __global__ __launch_bounds__(256) void k_alloc3d(const Cam c, const Map m, const
 // One record per (point, traversed voxel of an allocated block) up to the first voxel with sdf <= -truncation.
 // EMIT = false: counts[i] = number of records of point i.  EMIT = true: records written at offsets[i] ...: key = voxel id,
 // value = the clamped sdf.
+// The exact offsets need no scan kernel and no offsets array (round 3b): the count pass leaves counts[i] and one total per
+// workgroup (256 consecutive points); an emit workgroup adds up the totals of the workgroups before it (at most a few hundred
+// words, one coalesced read) and scans its own 256 counts in LDS.  The last count workgroup to finish (ticket) adds up all
+// totals and writes the scan's one report into pinned host memory: {high-water mark, records, 0}, then the sequence mark.
+struct ScanState {
+  u32* wg_totals;   // [grid]
+  u32* ticket;      // [1], counts workgroups and is never reset: this scan's last arrival reads ticket_base + grid - 1
+  u32* host_rec;    // pinned [4]
+  u32 seq, ticket_base;
+};
+__device__ __forceinline__ u32 wg_sum_256(const u32 v, u32* s_part) {  // sum over the 256 threads of the workgroup, to every thread
+  u32 x = v;
+  for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
+  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = x;
+  __syncthreads();
+  const u32 r = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+  __syncthreads();
+  return r;
+}
 template <bool EMIT, typename K>
 __global__ __launch_bounds__(256) void k_points_walk(const Cam c, const Map m, const Tab t, const float* __restrict__ pts,
                                                      const float* __restrict__ normals, const u32 n, u32* __restrict__ counts,
-                                                     const u32* __restrict__ offsets, K* __restrict__ keys, float* __restrict__ vals,
+                                                     const ScanState ss, K* __restrict__ keys, float* __restrict__ vals,
                                                      const int coarse_bit) {
+  __shared__ u32 s_part[4];
+  __shared__ u32 s_last;
   const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+  const bool live = i < n;
   u32 cnt = 0;
-  const u32 out = EMIT ? offsets[i] : 0u;
-  const f3 pcam = mk3(pts[3 * (size_t) i], pts[3 * (size_t) i + 1], pts[3 * (size_t) i + 2]);
+  u32 out = 0;
+  if (EMIT) {
+    // records of the points before this one: the earlier workgroups' totals + the earlier points of this workgroup
+    u32 before = 0;
+    for (u32 j = threadIdx.x; j < blockIdx.x; j += 256) before += ss.wg_totals[j];
+    const u32 base = wg_sum_256(before, s_part);
+    const u32 mine = live ? counts[i] : 0u;
+    u32 incl = mine;
+    const u32 lane = threadIdx.x & 63;
+    for (int off = 1; off < 64; off <<= 1) {
+      const u32 o = __shfl_up(incl, off);
+      if ((int) lane >= off) incl += o;
+    }
+    if (lane == 63) s_part[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    u32 woff = 0;
+    for (u32 w = 0; w < (threadIdx.x >> 6); w++) woff += s_part[w];
+    out = base + woff + incl - mine;
+  }
+  const f3 pcam = live ? mk3(pts[3 * (size_t) i], pts[3 * (size_t) i + 1], pts[3 * (size_t) i + 2]) : mk3(0.f, 0.f, 0.f);
   const float range = norm3(pcam);
   const float tr = get_truncation(range, m.trunc, m.trunc_scale);
   const float dmin = fminf(c.max_int_dist, range - tr), dmax = fminf(c.max_int_dist, range + tr);
-  if (!((double) range < 1e-6 || range > c.max_int_dist) && !(dmin >= dmax)) {
+  if (live && !((double) range < 1e-6 || range > c.max_int_dist) && !(dmin >= dmax)) {
     const f3 dir0 = normalize3(pcam);
     f3 norm_dir = mk3(0.f, 0.f, 0.f);
     f3 pc_min, pc_max;
@@ -223,7 +262,29 @@ __global__ __launch_bounds__(256) void k_points_walk(const Cam c, const Map m, c
       t_max.z = az ? t_max.z + t_delta.z : t_max.z;
     }
   }
-  if (!EMIT) counts[i] = cnt;
+  if (!EMIT) {
+    if (live) counts[i] = cnt;
+    const u32 total = wg_sum_256(cnt, s_part);
+    if (threadIdx.x == 0) {
+      __hip_atomic_store(&ss.wg_totals[blockIdx.x], total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __threadfence();
+      s_last = atomicAdd(ss.ticket, 1u) == ss.ticket_base + gridDim.x - 1u ? 1u : 0u;
+    }
+    __syncthreads();
+    if (s_last) {  // every other workgroup has published its total
+      __threadfence();
+      u32 sum = 0;
+      for (u32 j = threadIdx.x; j < gridDim.x; j += 256) sum += __hip_atomic_load(&ss.wg_totals[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const u32 all = wg_sum_256(sum, s_part);
+      if (threadIdx.x == 0) {
+        ss.host_rec[0] = (u32) t.ctr[CTR_HWM_FINE];
+        ss.host_rec[1] = all;
+        ss.host_rec[2] = 0;
+        __threadfence_system();
+        __hip_atomic_store(&ss.host_rec[3], ss.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+  }
 }
 
 // Sorted records -> voxels.  A workgroup stages kApplyChunk consecutive records (keys + values) in LDS, lists the heads of the
