@@ -2035,12 +2035,12 @@ int mrh_extract_triangles(mrh_ctx* c, const mrh_triangle** out_tris, uint64_t* o
     // emit pass interpolates them.  The buffer is sized from the last extraction's demand (first time: 128 records a block);
     // if a block finds no room the whole extraction is emitted by k_mc<emit> and the buffer grows for the next one.
     // MRH_MC_NO_RECORDS=1 keeps the two-pass evaluation (tests compare the two).
-    const bool use_records = getenv("MRH_MC_NO_RECORDS") == nullptr;
+    bool use_records = getenv("MRH_MC_NO_RECORDS") == nullptr;
     if (use_records && c->mc_rec_cap == 0) {
       const char* per_block = getenv("MRH_MC_RECORDS_PER_BLOCK");  // tests: a first buffer too small for the map
       const size_t cap = std::max<size_t>((size_t) n * (size_t) (per_block ? std::max(1, atoi(per_block)) : 128), 16);
-      HIP_TRY(c, hipMalloc((void**) &c->d_mc_recs, cap * kMcRecWords * sizeof(u32)));
-      c->mc_rec_cap = cap;
+      if (hipMalloc((void**) &c->d_mc_recs, cap * kMcRecWords * sizeof(u32)) == hipSuccess) c->mc_rec_cap = cap;
+      else { (void) hipGetLastError(); c->d_mc_recs = nullptr; use_records = false; }  // no room for the records: the two-pass emit needs none
     }
     McRecords R;
     R.ctr = d_rec_ctr; R.recs = use_records ? c->d_mc_recs : nullptr; R.base = d_rec_base; R.count = d_rec_n;
