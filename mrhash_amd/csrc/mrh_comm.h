@@ -160,6 +160,14 @@ int need_comm(mrh_ctx* c, const char* who) {
   return MRH_OK;
 }
 
+// MRH_COMM_SELF_LOOP=1 (tests on a one-GPU box): a rank's own part of an exchange travels through ncclSend / ncclRecv to itself
+// instead of staying where it is, so that the grouped point-to-point calls, their offsets and their sizes run through RCCL with
+// real payloads even in a one-rank group.  Results are identical.
+bool comm_self_loop() {
+  static const bool on = getenv("MRH_COMM_SELF_LOOP") != nullptr;
+  return on;
+}
+
 struct PhaseClock {
   mrh_ctx* c;
   int at = 0;
@@ -356,14 +364,15 @@ int mrh_comm_exchange_halo(mrh_ctx* c, uint64_t* out_taken) {
   if ((rc = clk.mark())) return rc;
   uint64_t total_in = 0;
   std::vector<uint64_t> off((size_t) world, 0);
-  for (int r = 0; r < world; r++) { off[r] = total_in; if (r != rank) total_in += counts[r]; }
+  const bool self = comm_self_loop();
+  for (int r = 0; r < world; r++) { off[r] = total_in; if (r != rank || self) total_in += counts[r]; }
   const size_t rec = sizeof(mrh_block_record);
   rc = ctx_grow(c, c->d_xrecv, c->xrecv_cap, std::max<size_t>(total_in * rec, 256), 0);
   if (rc) return rc;
-  if (world > 1) {
+  if (world > 1 || self) {
     CTX_NCCL(c, rccl()->GroupStart());
     for (int r = 0; r < world; r++) {
-      if (r == rank) continue;
+      if (r == rank && !self) continue;
       if (n) CTX_NCCL(c, rccl()->Send(mine, (size_t) n * rec, ncclUint8, r, m->nccl, c->stream));
       if (counts[r]) CTX_NCCL(c, rccl()->Recv(c->d_xrecv + off[r] * rec, (size_t) counts[r] * rec, ncclUint8, r, m->nccl, c->stream));
     }
@@ -418,22 +427,23 @@ int mrh_comm_merge_submaps(mrh_ctx* c, int chunk_log2, mrh_comm_merge_info* out)
   if (rc) return rc;
   std::vector<uint64_t> in_counts((size_t) world), in_off((size_t) world, 0);
   uint64_t total_in = 0;
+  const bool self = comm_self_loop();
   for (int src = 0; src < world; src++) {
     in_counts[src] = matrix[(size_t) src * world + rank];
     in_off[src] = total_in;
-    if (src != rank) total_in += in_counts[src];
+    if (src != rank || self) total_in += in_counts[src];
   }
   rc = ctx_grow(c, c->d_xrecv, c->xrecv_cap, std::max<size_t>(total_in * rec, 256), 0);
   if (rc) return rc;
   if ((rc = clk.mark())) return rc;
   uint64_t sent = 0;
-  if (world > 1) {
+  if (world > 1 || self) {
     CTX_NCCL(c, rccl()->GroupStart());
     for (int r = 0; r < world; r++) {
-      if (r == rank) continue;
+      if (r == rank && !self) continue;
       if (out_counts[r]) CTX_NCCL(c, rccl()->Send(c->d_xsend + out_off[r] * rec, (size_t) out_counts[r] * rec, ncclUint8, r, m->nccl, c->stream));
       if (in_counts[r]) CTX_NCCL(c, rccl()->Recv(c->d_xrecv + in_off[r] * rec, (size_t) in_counts[r] * rec, ncclUint8, r, m->nccl, c->stream));
-      sent += out_counts[r];
+      if (r != rank) sent += out_counts[r];
     }
     CTX_NCCL(c, rccl()->GroupEnd());
   }
@@ -442,16 +452,16 @@ int mrh_comm_merge_submaps(mrh_ctx* c, int chunk_log2, mrh_comm_merge_info* out)
   rc = mrh_drop_blocks(c, MRH_DROP_ALL, nullptr);
   if (rc) return rc;
   for (int src = 0; src < world; src++) {
-    const char* seg = src == rank ? c->d_xsend + out_off[rank] * rec : c->d_xrecv + in_off[src] * rec;
+    const char* seg = (src == rank && !self) ? c->d_xsend + out_off[rank] * rec : c->d_xrecv + in_off[src] * rec;
     if (in_counts[src] == 0) continue;
     rc = mrh_unpack_blocks(c, MRH_UNPACK_MERGE, (const mrh_block_record*) seg, in_counts[src], 1, nullptr);
     if (rc) return rc;
   }
   if ((rc = clk.mark())) return rc;
   if (out) {
-    out->blocks_sent = sent; out->blocks_received = total_in; out->bytes_sent = sent * rec; out->blocks_kept = out_counts[rank];
+    out->blocks_sent = sent; out->blocks_received = total_in - (self ? in_counts[rank] : 0); out->bytes_sent = sent * rec; out->blocks_kept = out_counts[rank];
   }
-  return clk.finish(sent * rec, total_in * rec);
+  return clk.finish(sent * rec, (total_in - (self ? in_counts[rank] : 0)) * rec);
 }
 
 int mrh_comm_gather_mesh(mrh_ctx* c, int root, uint64_t* out_triangles) {
@@ -502,11 +512,16 @@ int mrh_comm_gather_mesh(mrh_ctx* c, int root, uint64_t* out_triangles) {
   char* d_meta = c->d_xrecv;             // root: [rank r's descs | counts] at boff[r] * 20
   char* d_tris = c->d_xrecv + meta_all;  // root: rank r's triangles at toff[r]
   const mrh_triangle* soup = c->soup_n ? c->d_soup : nullptr;
-  if (world > 1) {
+  const bool self = comm_self_loop();
+  if (world > 1 || self) {
     CTX_NCCL(c, rccl()->GroupStart());
+    if (rank == root && self) {
+      if (nb) CTX_NCCL(c, rccl()->Send(c->d_xsend, meta_mine, ncclUint8, root, m->nccl, c->stream));
+      if (nt) CTX_NCCL(c, rccl()->Send(soup, (size_t) nt * tri, ncclUint8, root, m->nccl, c->stream));
+    }
     if (rank == root) {
       for (int r = 0; r < world; r++) {
-        if (r == root) continue;
+        if (r == root && !self) continue;
         if (sizes[2 * r]) CTX_NCCL(c, rccl()->Recv(d_meta + boff[r] * 20, (size_t) sizes[2 * r] * 20, ncclUint8, r, m->nccl, c->stream));
         if (sizes[2 * r + 1]) CTX_NCCL(c, rccl()->Recv(d_tris + toff[r] * tri, (size_t) sizes[2 * r + 1] * tri, ncclUint8, r, m->nccl, c->stream));
       }
@@ -518,8 +533,8 @@ int mrh_comm_gather_mesh(mrh_ctx* c, int root, uint64_t* out_triangles) {
   }
   uint64_t bytes_in = 0;
   if (rank == root) {
-    if (nb) HIP_TRY(c, hipMemcpyAsync(d_meta + boff[root] * 20, c->d_xsend, meta_mine, hipMemcpyDeviceToDevice, c->stream));
-    if (nt) HIP_TRY(c, hipMemcpyAsync(d_tris + toff[root] * tri, soup, (size_t) nt * tri, hipMemcpyDeviceToDevice, c->stream));
+    if (nb && !self) HIP_TRY(c, hipMemcpyAsync(d_meta + boff[root] * 20, c->d_xsend, meta_mine, hipMemcpyDeviceToDevice, c->stream));
+    if (nt && !self) HIP_TRY(c, hipMemcpyAsync(d_tris + toff[root] * tri, soup, (size_t) nt * tri, hipMemcpyDeviceToDevice, c->stream));
     bytes_in = (tot_b - nb) * 20 + (tot_t - nt) * tri;
   }
   if ((rc = clk.mark())) return rc;

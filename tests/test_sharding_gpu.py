@@ -159,12 +159,15 @@ open({out!r}, "w").write("ok " + hips[0] + " " + rccls[0])
 """
 
 
-def test_rccl_entry_points_of_the_c_abi_in_a_one_rank_group(hip, tmp_path):
+@pytest.mark.parametrize("self_loop", [False, True])
+def test_rccl_entry_points_of_the_c_abi_in_a_one_rank_group(hip, tmp_path, self_loop):
     """include/mrhash_comm.h on the GPU: communicator from the file rendezvous, the starve all-reduce inside mrh_integrate,
     mrh_comm_merge_submaps, mrh_comm_exchange_halo, mrh_comm_gather_mesh — RCCL on the library's own stream and buffers.
     Two RCCL ranks cannot share this box's one GPU ("Duplicate GPU detected", profiles/r02/two_ranks_one_device_nccl_outcome.txt),
     so the group has ONE rank; the worker is a process without torch and checks that it holds exactly one libamdhip64, one
-    libhsa-runtime64 and one librccl, from the same directory."""
+    libhsa-runtime64 and one librccl, from the same directory.  self_loop: MRH_COMM_SELF_LOOP=1 sends the rank's own part of
+    every exchange (sub-map blocks, halo candidates, block metadata and triangle runs) through grouped ncclSend / ncclRecv to
+    itself, so the point-to-point calls carry real payloads at real offsets; every result must be the same."""
     import os
     import subprocess
     import sys
@@ -175,6 +178,8 @@ def test_rccl_entry_points_of_the_c_abi_in_a_one_rank_group(hip, tmp_path):
     script = tmp_path / "rccl_worker.py"
     script.write_text(RCCL_WORKER.format(root=ROOT, out=out))
     env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MRH_RDZV_DIR=str(tmp_path))
+    if self_loop:
+        env["MRH_COMM_SELF_LOOP"] = "1"
     r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and os.path.exists(out), r.stdout[-2000:] + r.stderr[-4000:]
     assert "/opt/rocm" in os.path.realpath(open(out).read().split()[1])
