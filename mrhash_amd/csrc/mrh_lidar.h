@@ -351,48 +351,28 @@ __global__ __launch_bounds__(256) void k_points_apply(const Map m, const Tab t, 
     // iteration is the arithmetic of the running mean only — a voxel near the sensor collects hundreds of beams, and the
     // longest run of a scan is what the kernel waits for
     bool more = true;
-    auto fold = [&](const float sdf) {
-      s_prev = s0; w_prev = w0; sdf_last = sdf;
-      // combineVoxel with curr = {sdf, weight_update, rgb (0, 0, 0)} (vhu.cuh:167-181).  The division by the weight sum is the
-      // long pole of the chain: with the correctly rounded reciprocal (checked at mrh_create for every sum 1 .. 510, as for
-      // k_back) one residual correction gives the IEEE quotient (div_cr, mrh_device.h) — 3 dependent instructions instead of ~10
-      const float num = s0 * (float) w0 + sdf * (float) w1, den = (float) (int) (w0 + w1);
-      s0 = m.wsum_two_steps ? num / den : div_cr(num, den, rcp_refined(den));
-      w0 = (w0 + w1) < wmax ? (w0 + w1) : wmax;
-      r0 = (r0 + 1) >> 1; g0 = (g0 + 1) >> 1; b0 = (b0 + 1) >> 1;
-    };
-    u32 k = j;
-    for (; more && k < cn; k += 4) {  // inside the staged chunk
+    for (u32 k = j; more; k += 4) {
       K kk[4];
       float vv[4];
 #pragma unroll
       for (int q = 0; q < 4; q++) {
         const u32 idx = k + q;
         if (idx < cn) { kk[q] = s_key[idx]; vv[q] = s_val[idx]; }
-        else { kk[q] = key; vv[q] = 0.f; }  // past the chunk: decided by the loop below
-      }
-#pragma unroll
-      for (int q = 0; q < 4; q++) {
-        if (!more || k + q >= cn) continue;
-        if (kk[q] != key) { more = false; continue; }
-        fold(vv[q]);
-      }
-    }
-    // the run leaves the chunk: sixteen records per round trip to global memory (a dependent load per four records made the longest
-    // run of a scan — ~300 beams on one voxel next to the sensor — the floor of the whole kernel)
-    for (k = cn; more; k += 16) {
-      K kk[16];
-      float vv[16];
-#pragma unroll
-      for (int q = 0; q < 16; q++) {
-        const u32 idx = c0 + k + q;
-        if (idx < n_rec) { kk[q] = keys[idx]; vv[q] = vals[idx]; }
+        else if (c0 + idx < n_rec) { kk[q] = keys[c0 + idx]; vv[q] = vals[c0 + idx]; }  // the run leaves the chunk
         else { kk[q] = ~key; vv[q] = 0.f; }
       }
 #pragma unroll
-      for (int q = 0; q < 16; q++) {
+      for (int q = 0; q < 4; q++) {
         if (!more || kk[q] != key) { more = false; continue; }
-        fold(vv[q]);
+        const float sdf = vv[q];
+        s_prev = s0; w_prev = w0; sdf_last = sdf;
+        // combineVoxel with curr = {sdf, weight_update, rgb (0, 0, 0)} (vhu.cuh:167-181).  The division by the weight sum is the
+        // long pole of the chain: with the correctly rounded reciprocal (checked at mrh_create for every sum 1 .. 510, as for
+        // k_back) one residual correction gives the IEEE quotient (div_cr, mrh_device.h) — 3 dependent instructions instead of ~10
+        const float num = s0 * (float) w0 + sdf * (float) w1, den = (float) (int) (w0 + w1);
+        s0 = m.wsum_two_steps ? num / den : div_cr(num, den, rcp_refined(den));
+        w0 = (w0 + w1) < wmax ? (w0 + w1) : wmax;
+        r0 = (r0 + 1) >> 1; g0 = (g0 + 1) >> 1; b0 = (b0 + 1) >> 1;
       }
     }
     // vds.cu:1352-1366 for the last update: delta against the mean before it (0 for a voxel without weight), delta2 against the mean after
