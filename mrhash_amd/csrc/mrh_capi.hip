@@ -177,7 +177,6 @@ struct mrh_ctx {
   const float* d_points_cur = nullptr;  // ... or the caller's device pointer (mrh_set_points_device)
   uint64_t points_cap = 0, num_points = 0;
   u32* d_pt_counts = nullptr; u32* d_pt_offsets = nullptr; uint64_t pt_cap = 0;
-  u32 scan_ticket = 0;  // value of the device's workgroup ticket before the next LiDAR count pass (mrh_lidar.h ScanState)
   u32* h_scan = nullptr;               // pinned {hwm, last offset, last count, sequence}: the one report of a scan
   u32 scan_seq = 0;
   void* d_rec_keys[2] = {nullptr, nullptr}; float* d_rec_vals[2] = {nullptr, nullptr}; uint64_t rec_cap = 0; size_t rec_key_bytes = 0;
@@ -1611,9 +1610,7 @@ int mrh_integrate_points(mrh_ctx* c, int n_frames_invalidate) {
       if (c->d_pt_offsets) HIP_TRY(c, hipFree(c->d_pt_offsets));
       c->d_pt_counts = c->d_pt_offsets = nullptr;
       HIP_TRY(c, hipMalloc((void**) &c->d_pt_counts, n * sizeof(u32)));
-      HIP_TRY(c, hipMalloc((void**) &c->d_pt_offsets, (n / 256 + 2) * sizeof(u32)));  // one total per count workgroup + the ticket
-      HIP_TRY(c, hipMemsetAsync(c->d_pt_offsets, 0, (n / 256 + 2) * sizeof(u32), s));
-      c->scan_ticket = 0;
+      HIP_TRY(c, hipMalloc((void**) &c->d_pt_offsets, (n / 256 + 2) * sizeof(u32)));  // one total per count workgroup
       c->pt_cap = n;
     }
     if (!c->h_scan) {
@@ -1621,13 +1618,11 @@ int mrh_integrate_points(mrh_ctx* c, int n_frames_invalidate) {
       memset(c->h_scan, 0, 4 * sizeof(u32));
     }
     auto integrate_scan = [&]() -> int {
-      // the one host round trip of a scan: the LAST count workgroup to finish writes {high-water mark, records} and a sequence
-      // mark into pinned memory; the emit pass — which derives its offsets from the per-workgroup totals itself — is enqueued
-      // behind the count pass and runs while the report travels and the host reads it
+      // the one host round trip of a scan: the emit pass derives its offsets from the per-workgroup totals itself, and its LAST
+      // workgroup, which knows the grand total before its walk starts, writes {high-water mark, records} and a sequence mark into
+      // pinned memory: the host reads it and enqueues the sort while the emit pass runs
       ScanState ss;
-      ss.wg_totals = c->d_pt_offsets + 1; ss.ticket = c->d_pt_offsets; ss.host_rec = c->h_scan; ss.seq = ++c->scan_seq;
-      ss.ticket_base = c->scan_ticket;
-      c->scan_ticket += grid;
+      ss.wg_totals = c->d_pt_offsets; ss.host_rec = c->h_scan; ss.seq = ++c->scan_seq;
       const u32 seq = ss.seq;
       k_points_walk<false, u32><<<grid, 256, 0, s>>>(k, m, t, pts, normals, np, c->d_pt_counts, ss, (u32*) nullptr, nullptr, coarse_bit);
       if (wide) k_points_walk<true, u64><<<grid, 256, 0, s>>>(k, m, t, pts, normals, np, c->d_pt_counts, ss, (u64*) c->d_rec_keys[0], c->d_rec_vals[0], coarse_bit);

@@ -131,13 +131,14 @@ __global__ __launch_bounds__(256) void k_alloc3d(const Cam c, const Map m, const
 // value = the clamped sdf.
 // The exact offsets need no scan kernel and no offsets array (round 3b): the count pass leaves counts[i] and one total per
 // workgroup (256 consecutive points); an emit workgroup adds up the totals of the workgroups before it (at most a few hundred
-// words, one coalesced read) and scans its own 256 counts in LDS.  The last count workgroup to finish (ticket) adds up all
-// totals and writes the scan's one report into pinned host memory: {high-water mark, records, 0}, then the sequence mark.
+// words, one coalesced read) and scans its own 256 counts in LDS.  The LAST emit workgroup thereby knows the grand total before
+// its own walk starts and writes the scan's one report into pinned host memory: {high-water mark, records, 0}, then the
+// sequence mark.  (A ticket in the count pass — the last workgroup to finish adds up the totals — cost that pass 9 us: 512
+// same-address atomics behind a fence each, and the reduction on the launch's critical path.)
 struct ScanState {
   u32* wg_totals;   // [grid]
-  u32* ticket;      // [1], counts workgroups and is never reset: this scan's last arrival reads ticket_base + grid - 1
   u32* host_rec;    // pinned [4]
-  u32 seq, ticket_base;
+  u32 seq;
 };
 __device__ __forceinline__ u32 wg_sum_256(const u32 v, u32* s_part) {  // sum over the 256 threads of the workgroup, to every thread
   u32 x = v;
@@ -154,7 +155,6 @@ __global__ __launch_bounds__(256) void k_points_walk(const Cam c, const Map m, c
                                                      const ScanState ss, K* __restrict__ keys, float* __restrict__ vals,
                                                      const int coarse_bit) {
   __shared__ u32 s_part[4];
-  __shared__ u32 s_last;
   const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = i < n;
   u32 cnt = 0;
@@ -176,6 +176,15 @@ __global__ __launch_bounds__(256) void k_points_walk(const Cam c, const Map m, c
     u32 woff = 0;
     for (u32 w = 0; w < (threadIdx.x >> 6); w++) woff += s_part[w];
     out = base + woff + incl - mine;
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) {
+      // the scan's one report: the last workgroup knows the grand total before it starts its own walk; the host reads it (and
+      // sizes the sort) while the emit pass runs
+      ss.host_rec[0] = (u32) t.ctr[CTR_HWM_FINE];
+      ss.host_rec[1] = out + mine;
+      ss.host_rec[2] = 0;
+      __threadfence_system();
+      __hip_atomic_store(&ss.host_rec[3], ss.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
   const f3 pcam = live ? mk3(pts[3 * (size_t) i], pts[3 * (size_t) i + 1], pts[3 * (size_t) i + 2]) : mk3(0.f, 0.f, 0.f);
   const float range = norm3(pcam);
@@ -265,25 +274,7 @@ __global__ __launch_bounds__(256) void k_points_walk(const Cam c, const Map m, c
   if (!EMIT) {
     if (live) counts[i] = cnt;
     const u32 total = wg_sum_256(cnt, s_part);
-    if (threadIdx.x == 0) {
-      __hip_atomic_store(&ss.wg_totals[blockIdx.x], total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __threadfence();
-      s_last = atomicAdd(ss.ticket, 1u) == ss.ticket_base + gridDim.x - 1u ? 1u : 0u;
-    }
-    __syncthreads();
-    if (s_last) {  // every other workgroup has published its total
-      __threadfence();
-      u32 sum = 0;
-      for (u32 j = threadIdx.x; j < gridDim.x; j += 256) sum += __hip_atomic_load(&ss.wg_totals[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const u32 all = wg_sum_256(sum, s_part);
-      if (threadIdx.x == 0) {
-        ss.host_rec[0] = (u32) t.ctr[CTR_HWM_FINE];
-        ss.host_rec[1] = all;
-        ss.host_rec[2] = 0;
-        __threadfence_system();
-        __hip_atomic_store(&ss.host_rec[3], ss.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-      }
-    }
+    if (threadIdx.x == 0) ss.wg_totals[blockIdx.x] = total;
   }
 }
 
