@@ -296,20 +296,39 @@ __global__ __launch_bounds__(256) void k_points_apply(const Map m, const Tab t, 
   const u32 c0 = blockIdx.x * kApplyChunk;
   if (c0 >= n_rec) return;
   const u32 cn = min((u32) kApplyChunk, n_rec - c0);
-  if (threadIdx.x == 0) s_nhead = 0;
   for (u32 j = threadIdx.x; j < cn; j += 256) { s_key[j] = keys[c0 + j]; s_val[j] = vals[c0 + j]; }
   __syncthreads();
-  for (u32 j = threadIdx.x; j < cn; j += 256) {
-    const K key = s_key[j];
-    const bool head = !(j > 0 ? s_key[j - 1] == key : (c0 > 0 && keys[c0 - 1] == key));
-    const u64 ballot = __ballot(head);
-    if (ballot) {
-      u32 base = 0;
-      const int leader = __ffsll((long long) ballot) - 1;
-      if ((int) lane_id() == leader) base = atomicAdd(&s_nhead, (u32) __popcll(ballot));
-      base = __shfl(base, leader);
-      if (head) s_head[base + __popcll(ballot & lanemask_lt())] = (unsigned short) j;
+  // heads of the runs that begin in this chunk, compacted IN ORDER (round r, wave w, lane = ascending record index): the run of
+  // head h then ends where head h + 1 begins — a lane knows its trip count and reads no key while it folds
+  constexpr int kRounds = kApplyChunk / 256;
+  __shared__ u32 s_cnt[kRounds * 4];
+  const u32 wave = threadIdx.x >> 6;
+  u32 hflag = 0, hpre[kRounds];
+#pragma unroll
+  for (int r = 0; r < kRounds; r++) {
+    const u32 j = (u32) r * 256 + threadIdx.x;
+    bool head = false;
+    if (j < cn) {
+      const K key = s_key[j];
+      head = !(j > 0 ? s_key[j - 1] == key : (c0 > 0 && keys[c0 - 1] == key));
     }
+    const u64 ballot = __ballot(head);
+    hpre[r] = (u32) __popcll(ballot & lanemask_lt());
+    hflag |= head ? (1u << r) : 0u;
+    if ((threadIdx.x & 63) == 0) s_cnt[r * 4 + wave] = (u32) __popcll(ballot);
+  }
+  __syncthreads();
+  {
+    u32 run = 0;
+#pragma unroll
+    for (int r = 0; r < kRounds; r++) {
+#pragma unroll
+      for (int w = 0; w < 4; w++) {
+        if ((u32) w == wave && ((hflag >> r) & 1u)) s_head[run + hpre[r]] = (unsigned short) (r * 256 + threadIdx.x);
+        run += s_cnt[r * 4 + w];
+      }
+    }
+    if (threadIdx.x == 0) s_nhead = run;
   }
   __syncthreads();
   const u32 nhead = s_nhead;
@@ -336,35 +355,66 @@ __global__ __launch_bounds__(256) void k_points_apply(const Map m, const Tab t, 
     float s0 = *p_sdf;
     const u32 rgbw0 = *p_rgbw;
     u32 w0 = rgbw0 >> 24, r0 = rgbw0 & 0xFF, g0 = (rgbw0 >> 8) & 0xFF, b0 = (rgbw0 >> 16) & 0xFF;
-    float s_prev = s0, sdf_last = 0.f;  // state BEFORE the last update, and the last record's sdf: the variance term needs them
-    u32 w_prev = w0;
-    // four records at a time: their keys and values are fetched together (independent LDS reads), so that what is serial in an
-    // iteration is the arithmetic of the running mean only — a voxel near the sensor collects hundreds of beams, and the
-    // longest run of a scan is what the kernel waits for
-    bool more = true;
-    for (u32 k = j; more; k += 4) {
-      K kk[4];
-      float vv[4];
-#pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const u32 idx = k + q;
-        if (idx < cn) { kk[q] = s_key[idx]; vv[q] = s_val[idx]; }
-        else if (c0 + idx < n_rec) { kk[q] = keys[c0 + idx]; vv[q] = vals[c0 + idx]; }  // the run leaves the chunk
-        else { kk[q] = ~key; vv[q] = 0.f; }
+    // combineVoxel with curr = {sdf, weight_update, rgb (0, 0, 0)} (vhu.cuh:167-181), one record.  What a wave pays for is the
+    // LONGEST of its 64 runs (mean 6 records, one in a hundred above 50, the voxels next to the sensor ~200) times the
+    // latency of one step, so the step carries nothing that can wait for the end of the run: the colours — (c + 1) >> 1 per record
+    // = ceil(c / 2), n times = ceil(c / 2^n) — and the state before the LAST update (the variance term's) are settled after the
+    // loop (a record is folded once its successor is known to belong to the run), and no step waits for memory.
+    // One step, s0 <- (s0 w0 + sdf w1) / (w0 + w1), is a chain of five dependent operations on s0 (multiply, add, and the three of
+    // div_cr); everything else of the step — the weight, its conversion, the reciprocal of the NEXT weight sum (rcp_refined: the
+    // values of the table, no memory access), the next record — is computed one step ahead, off that chain.
+    const float w1f = (float) w1;
+    u32 wsum = w0 + w1;
+    float w0f = (float) w0, den = (float) (int) wsum, rden = rcp_refined(den);
+    auto fold = [&](const float sdf) {
+      const float num = s0 * w0f + sdf * w1f;
+      // the state of the step after this one (independent of s0)
+      const u32 w0n = wsum < wmax ? wsum : wmax, wsum_n = w0n + w1;
+      const float w0f_n = (float) w0n, den_n = (float) (int) wsum_n, rden_n = rcp_refined(den_n);
+      s0 = m.wsum_two_steps ? num / den : div_cr(num, den, rden);
+      w0 = w0n; wsum = wsum_n; w0f = w0f_n; den = den_n; rden = rden_n;
+    };
+    float pend = s_val[j];  // the head's own record
+    const u32 end = h + 1 < nhead ? (u32) s_head[h + 1] : cn;  // the chunk's last run may go on in the next chunk
+    u32 nfold = end - j;
+    {
+      u32 i = j + 1;
+      for (; i + 4 <= end; i += 4) {  // four records fetched together, folded one after the other
+        const float v0 = s_val[i], v1 = s_val[i + 1], v2 = s_val[i + 2], v3 = s_val[i + 3];
+        fold(pend); fold(v0); fold(v1); fold(v2);
+        pend = v3;
       }
-#pragma unroll
-      for (int q = 0; q < 4; q++) {
-        if (!more || kk[q] != key) { more = false; continue; }
-        const float sdf = vv[q];
-        s_prev = s0; w_prev = w0; sdf_last = sdf;
-        // combineVoxel with curr = {sdf, weight_update, rgb (0, 0, 0)} (vhu.cuh:167-181).  The division by the weight sum is the
-        // long pole of the chain: with the correctly rounded reciprocal (checked at mrh_create for every sum 1 .. 510, as for
-        // k_back) one residual correction gives the IEEE quotient (div_cr, mrh_device.h) — 3 dependent instructions instead of ~10
-        const float num = s0 * (float) w0 + sdf * (float) w1, den = (float) (int) (w0 + w1);
-        s0 = m.wsum_two_steps ? num / den : div_cr(num, den, rcp_refined(den));
-        w0 = (w0 + w1) < wmax ? (w0 + w1) : wmax;
-        r0 = (r0 + 1) >> 1; g0 = (g0 + 1) >> 1; b0 = (b0 + 1) >> 1;
+      for (; i < end; i++) {
+        fold(pend);
+        pend = s_val[i];
       }
+    }
+    if (h + 1 == nhead && c0 + cn < n_rec) {  // one lane per workgroup: the rest of its run, from global memory, by key
+      bool more = true;
+      for (u32 k = c0 + cn; more; k += 4) {
+        K kk[4];
+        float vv[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const u32 idx = k + q;
+          if (idx < n_rec) { kk[q] = keys[idx]; vv[q] = vals[idx]; }
+          else { kk[q] = ~key; vv[q] = 0.f; }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          if (!more || kk[q] != key) { more = false; continue; }
+          fold(pend);
+          pend = vv[q];
+          nfold++;
+        }
+      }
+    }
+    const float s_prev = s0, sdf_last = pend;  // state BEFORE the last update, and the last record's sdf: the variance term needs them
+    const u32 w_prev = w0;
+    fold(pend);
+    {
+      const u32 sh = nfold < 8u ? nfold : 8u, add = (1u << sh) - 1u;  // c <= 255: eight halvings leave 1 (or 0 for c == 0), as do more
+      r0 = (r0 + add) >> sh; g0 = (g0 + add) >> sh; b0 = (b0 + add) >> sh;
     }
     // vds.cu:1352-1366 for the last update: delta against the mean before it (0 for a voxel without weight), delta2 against the mean after
     const float curr_mean = w_prev > 0 ? s_prev : 0.f;
