@@ -66,27 +66,31 @@ struct UpRing {
   hipEvent_t last_copy = nullptr;  // newest copy event of this ring the main stream has not waited for yet
 };
 
-// Host result buffer of the blocking calls (triangle soup, V / F / C): grow-only, never zero-filled, PINNED (hipHostMalloc).
+// Host result buffer of the blocking calls (triangle soup, V / F / C): grow-only, never zero-filled, PINNED.
 // A device-to-host copy into pageable memory is pinned and unpinned by the runtime around every call, page by page: with
 // transparent huge pages behind the buffer that is cheap (tools/micro/d2h_paths.hip: 128 MB in 2.4 ms), with 4 KiB pages it
 // doubles the copy (30 MB of V / F / C: 0.57 -> 1.5 ms) — and which of the two a malloc'ed buffer gets depends on what the
 // process freed before (glibc raises its mmap threshold after the first large free; the next buffer then comes from the heap,
-// where MADV_HUGEPAGE does nothing for pages that already exist).  Pinned once, the copy runs at link speed every time.  If
-// the pinned allocation is refused the buffer falls back to an anonymous 2 MiB-aligned mapping advised to huge pages.
+// where MADV_HUGEPAGE does nothing for pages that already exist).  Pinned once, the copy runs at link speed every time, and a
+// kernel can write the buffer (k_copy_out).  The pinned memory is an anonymous 2 MiB-aligned mapping advised to huge pages,
+// touched, and registered (hipHostRegister): 1.5 ms for 36 MB where hipHostMalloc takes 5-9 ms (tools/micro/pinned_alloc_cost.hip)
+// — what a context's FIRST extraction pays.  If the registration is refused the mapping stays as a pageable buffer (dev == nullptr:
+// copies go through hipMemcpyAsync).
 template <typename T>
 struct HostVec {
-  T* p = nullptr;
+  T* p = nullptr;    // host pointer
+  T* dev = nullptr;  // the same memory as the device sees it (nullptr: not registered)
   size_t n = 0, cap = 0;
-  size_t mapped = 0, head = 0;  // fallback mapping: its size (0: p is pinned memory) and the bytes between its base and p
+  size_t span = 0, head = 0;  // the mapping: its size and the bytes between its base and p
   HostVec() = default;
   HostVec(const HostVec&) = delete;
   HostVec& operator=(const HostVec&) = delete;
   ~HostVec() { release(); }
   void release() {
     if (!p) return;
-    if (mapped) (void) munmap((void*) ((char*) p - head), mapped);
-    else (void) hipHostFree((void*) p);
-    p = nullptr; cap = 0; mapped = 0; head = 0;
+    if (dev) (void) hipHostUnregister((void*) p);
+    (void) munmap((void*) ((char*) p - head), span);
+    p = nullptr; dev = nullptr; cap = 0; span = 0; head = 0;
   }
   T* data() { return p; }
   const T* data() const { return p; }
@@ -100,20 +104,24 @@ struct HostVec {
       release();
       const size_t want = count + count / 8;  // head room: a map that grows a little keeps its buffer
       const size_t bytes = ((want * sizeof(T) + (2u << 20) - 1) >> 21) << 21;
-      void* q = nullptr;
-      if (hipHostMalloc(&q, bytes, hipHostMallocDefault) == hipSuccess && q) {
-        p = (T*) q;
+      const size_t sp = bytes + (2u << 20);
+      void* m = mmap(nullptr, sp, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+      if (m == MAP_FAILED) throw std::bad_alloc();
+      // the whole span is kept (the unaligned head stays untouched, i.e. unbacked): one munmap releases it
+      char* aligned = (char*) (((uintptr_t) m + (2u << 20) - 1) & ~(uintptr_t) ((2u << 20) - 1));
+      (void) madvise(aligned, bytes, MADV_HUGEPAGE);
+      for (size_t o = 0; o < bytes; o += 4096) ((volatile char*) aligned)[o] = 0;  // fault the pages in (as huge pages) before they are pinned
+      span = sp;
+      head = (size_t) (aligned - (char*) m);
+      p = (T*) aligned;
+      void* d = nullptr;
+      if (hipHostRegister(aligned, bytes, hipHostRegisterDefault) == hipSuccess && hipHostGetDevicePointer(&d, aligned, 0) == hipSuccess && d) {
+        dev = (T*) d;
       } else {
         (void) hipGetLastError();
-        const size_t span = bytes + (2u << 20);
-        void* m = mmap(nullptr, span, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
-        if (m == MAP_FAILED) throw std::bad_alloc();
-        // keep the whole span (the unaligned head stays untouched, i.e. unbacked): one munmap releases it
-        char* aligned = (char*) (((uintptr_t) m + (2u << 20) - 1) & ~(uintptr_t) ((2u << 20) - 1));
-        (void) madvise(aligned, bytes, MADV_HUGEPAGE);
-        mapped = span;
-        head = (size_t) (aligned - (char*) m);
-        p = (T*) aligned;
+        (void) hipHostUnregister(aligned);
+        (void) hipGetLastError();
+        dev = nullptr;
       }
       cap = bytes / sizeof(T);
     }
@@ -632,13 +640,13 @@ int process_triangles_device(mrh_ctx* c, const mrh_triangle* d_tris, const size_
     const double t0 = now();
     // V, C, F go out behind the post-process without the host in between (k_copy_out reads the two totals on the device), into
     // the buffers of the previous extraction; if they turn out too small (or not pinned) they grow and the copy runs again
-    const bool pinned = !c->V.mapped && !c->C.mapped && !c->F.mapped && !getenv("MRH_D2H_MEMCPY");  // MRH_D2H_MEMCPY=1: hipMemcpyAsync instead (A/B)
+    const bool pinned = c->V.dev && c->C.dev && c->F.dev && !getenv("MRH_D2H_MEMCPY");  // MRH_D2H_MEMCPY=1: hipMemcpyAsync instead (A/B)
     auto copy_out = [&](const bool by_kernel, const size_t nv_known, const size_t nf_known) {
       if (by_kernel) {
         CopyOut a;
-        a.src[0] = (const uint4*) dV; a.dst[0] = (uint4*) c->V.data(); a.count[0] = d_totals; a.cap[0] = c->V.cap / 3; a.unit[0] = 24;
-        a.src[1] = (const uint4*) dC; a.dst[1] = (uint4*) c->C.data(); a.count[1] = d_totals; a.cap[1] = c->C.cap / 3; a.unit[1] = 24;
-        a.src[2] = (const uint4*) dF; a.dst[2] = (uint4*) c->F.data(); a.count[2] = d_totals + 1; a.cap[2] = c->F.cap / 3; a.unit[2] = 12;
+        a.src[0] = (const uint4*) dV; a.dst[0] = (uint4*) c->V.dev; a.count[0] = d_totals; a.cap[0] = c->V.cap / 3; a.unit[0] = 24;
+        a.src[1] = (const uint4*) dC; a.dst[1] = (uint4*) c->C.dev; a.count[1] = d_totals; a.cap[1] = c->C.cap / 3; a.unit[1] = 24;
+        a.src[2] = (const uint4*) dF; a.dst[2] = (uint4*) c->F.dev; a.count[2] = d_totals + 1; a.cap[2] = c->F.cap / 3; a.unit[2] = 12;
         a.fixed[0] = a.fixed[1] = a.fixed[2] = 0;
         k_copy_out<<<1024, 256, 0, s>>>(a);
         return hipGetLastError();
@@ -659,7 +667,7 @@ int process_triangles_device(mrh_ctx* c, const mrh_triangle* d_tris, const size_
     c->V.resize_discard(nv * 3); c->C.resize_discard(nv * 3); c->F.resize_discard(std::max<size_t>(nf, 1) * 3);
     c->F.n = nf * 3;
     if (!fits) {
-      MESH_TRY(copy_out(!c->V.mapped && !c->C.mapped && !c->F.mapped && !getenv("MRH_D2H_MEMCPY"), nv, nf));
+      MESH_TRY(copy_out(c->V.dev && c->C.dev && c->F.dev && !getenv("MRH_D2H_MEMCPY"), nv, nf));
       MESH_TRY(hipStreamSynchronize(s));
     }
     MESH_TRY(hipGetLastError());
@@ -2109,10 +2117,10 @@ int mrh_extract_triangles(mrh_ctx* c, const mrh_triangle** out_tris, uint64_t* o
       if (dbg) { HIP_TRY(c, hipStreamSynchronize(s)); t3 = now(); }
       if (want_soup) {
         c->tris.resize_discard(total);
-        if (!c->tris.mapped) {  // pinned: out through the copy kernel (see k_copy_out)
+        if (c->tris.dev) {  // pinned: out through the copy kernel (see k_copy_out)
           CopyOut a;
           for (int p = 0; p < 3; p++) { a.src[p] = nullptr; a.dst[p] = nullptr; a.count[p] = nullptr; a.fixed[p] = 0; a.cap[p] = 0; a.unit[p] = 0; }
-          a.src[0] = (const uint4*) d_tris; a.dst[0] = (uint4*) c->tris.data(); a.fixed[0] = total; a.cap[0] = total; a.unit[0] = (u32) sizeof(mrh_triangle);
+          a.src[0] = (const uint4*) d_tris; a.dst[0] = (uint4*) c->tris.dev; a.fixed[0] = total; a.cap[0] = total; a.unit[0] = (u32) sizeof(mrh_triangle);
           k_copy_out<<<1024, 256, 0, s>>>(a);
         } else {
           HIP_TRY(c, hipMemcpyAsync(c->tris.data(), d_tris, total * sizeof(mrh_triangle), hipMemcpyDeviceToHost, s));
