@@ -93,6 +93,7 @@ def parse_args():
     ap.add_argument("--pmc-inner", action="store_true", help=argparse.SUPPRESS)  # the workload alone, under rocprofv3
     ap.add_argument("--pmc-inner-big", action="store_true", help=argparse.SUPPRESS)  # the roofline_hbm workload alone
     ap.add_argument("--pmc-inner-mc", action="store_true", help=argparse.SUPPRESS)  # the multi-resolution map + two extractions
+    ap.add_argument("--pmc-inner-lidar", action="store_true", help=argparse.SUPPRESS)  # the LiDAR scans alone
     ap.add_argument("--frames-cache", default="", help=argparse.SUPPRESS)
     return ap.parse_args()
 
@@ -229,6 +230,36 @@ def pmc_traffic(args, kernel_prefix, cache: str, inner: str = "--pmc-inner", ste
                               f"{vals['FETCH_SIZE'][1]} dispatches, 2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction)")
 
 
+LIDAR_SCANS, LIDAR_WARMUP = 25, 5
+
+
+def lidar_setup(hip, blocks):
+    """configs[4], LiDAR half: engine + the 128 x 1024 scans of the street resident in HBM + the loop that feeds them."""
+    from mrhash_amd import capi, hipmem, synth
+
+    n_scans = LIDAR_SCANS
+    lcache = os.path.join(tempfile.gettempdir(), f"mrh_bench_vbr_{n_scans}.npz")
+    poses = synth.drive_poses(n_scans, step=0.5)
+    if os.path.exists(lcache):
+        scans = list(np.load(lcache)["scans"])
+    else:
+        scene = synth.street_canyon()
+        scans = [synth.lidar_scan(scene, t, q, rows=128, cols=1024) for t, q in poses]
+        np.savez(lcache, scans=np.stack(scans))
+    d_scans = [hipmem.DeviceBuffer.from_numpy(np.ascontiguousarray(sc, dtype=np.float32)) for sc in scans]
+    le = capi.Engine(hip, capi.Params(num_sdf_blocks=blocks, device_id=0, **synth.VBR_PARAMS))
+    le.set_camera(1, 1, 0, 0, 1, 1, 0.2, 100.0, model=1)
+
+    def run_scans(lo, hi):
+        for i in range(lo, hi):
+            t, q = poses[i]
+            le.set_pose(synth.quat_to_rot(q), t)
+            le.set_points_device(d_scans[i].ptr, len(scans[i]))
+            le.integrate_points()
+
+    return le, scans, d_scans, run_scans
+
+
 # ---- N = 1 ---------------------------------------------------------------------------------------------------------
 
 def bench_single(args):
@@ -247,6 +278,12 @@ def bench_single(args):
         rb.run(be, 0, total)
         be.sync()
         be.close()
+        return
+    if args.pmc_inner_lidar:  # configs[4]: the scans alone (under rocprofv3 --pmc)
+        le, scans, d_scans, run_scans = lidar_setup(hip, args.blocks)
+        run_scans(0, LIDAR_SCANS)
+        le.sync()
+        le.close()
         return
     frames = render_stream("replica", total, cache=cache)
     res = Resident(frames, Kc)
@@ -281,6 +318,10 @@ def bench_single(args):
     st = eng.stats()
     occupied = int(st.occupied_fine)
     table = {"hash_slots": int(st.hash_slots), "tombstones": int(st.tombstones), "max_probe_length": int(st.max_probe_length), "rehash_count": int(st.rehash_count)}
+    # the map the timed loop produced, kept for the check against the oracle in the cpu_baseline leg (which runs the oracle over
+    # the same frames anyway): taken now, before the profiled pass resets the engine
+    want_check = not args.no_cpu and args.cpu_frames > 0
+    timed_map = eng.dump_blocks() if want_check and min(args.cpu_frames, total) == total else None
 
     # ---- the boundary as the reference uses it: host buffers -> mrh_upload_depth / mrh_upload_rgb each frame.  Runs BEFORE
     # any profiled pass: launches that carry start / stop events switch the queue to profiling mode, which slows every
@@ -338,25 +379,8 @@ def bench_single(args):
     # ---- configs[4], LiDAR half: 128 x 1024 scans along a street (vbr.cfg parameters), scans resident in HBM
     lidar = None
     if not args.no_extras:
-        n_scans, w_scans = 25, 5
-        lcache = os.path.join(tempfile.gettempdir(), f"mrh_bench_vbr_{n_scans}.npz")
-        poses = synth.drive_poses(n_scans, step=0.5)
-        if os.path.exists(lcache):
-            scans = list(np.load(lcache)["scans"])
-        else:
-            scene = synth.street_canyon()
-            scans = [synth.lidar_scan(scene, t, q, rows=128, cols=1024) for t, q in poses]
-            np.savez(lcache, scans=np.stack(scans))
-        d_scans = [hipmem.DeviceBuffer.from_numpy(np.ascontiguousarray(sc, dtype=np.float32)) for sc in scans]
-        le = capi.Engine(hip, capi.Params(num_sdf_blocks=args.blocks, device_id=0, **synth.VBR_PARAMS))
-        le.set_camera(1, 1, 0, 0, 1, 1, 0.2, 100.0, model=1)
-
-        def run_scans(lo, hi):
-            for i in range(lo, hi):
-                t, q = poses[i]
-                le.set_pose(synth.quat_to_rot(q), t)
-                le.set_points_device(d_scans[i].ptr, len(scans[i]))
-                le.integrate_points()
+        n_scans, w_scans = LIDAR_SCANS, LIDAR_WARMUP
+        le, scans, d_scans, run_scans = lidar_setup(hip, args.blocks)
 
         run_scans(0, w_scans)
         le.sync()
@@ -518,6 +542,9 @@ def bench_single(args):
     if mc is not None and not args.no_pmc:  # HBM bytes of the two k_mc launches of one extraction (two extractions in the sub-process)
         mc["roofline"]["traffic"], mc["roofline"]["traffic_note"] = pmc_traffic(args, ("mrh::k_mc<", "mrh::k_mc_emit_records"), cache, "--pmc-inner-mc", per_run_of=2)
 
+    if lidar is not None and not args.no_pmc:  # HBM bytes of all kernels of a scan (every mrh:: launch of the sub-process / scans)
+        lidar["roofline"]["traffic"], lidar["roofline"]["traffic_note"] = pmc_traffic(args, ("mrh::k_alloc3d", "mrh::k_points_", "mrh::k_sort_"), cache, "--pmc-inner-lidar", per_run_of=LIDAR_SCANS)
+
     # ---- HBM traffic of the headline kernel, measured now (sub-processes under rocprofv3)
     if not args.no_pmc:
         traffic, note = pmc_traffic(args, "mrh::k_back<true, false", cache)
@@ -547,8 +574,30 @@ def bench_single(args):
             c0 = time.perf_counter()
             ce.integrate()  # the reference brackets exactly this call (voxel_data_structures.cpp:94-109)
             tc += time.perf_counter() - c0
+        # the oracle's map after these frames against the HIP engine's: the TIMED engine's own map when the sample covers the whole
+        # run (the driver's --steps 20 --warmup 5 does), otherwise a replay of the sample through the same entry points
+        if timed_map is not None:
+            da, va, which = timed_map[0], timed_map[1], "the timed engine (map taken right after the timed loop)"
+        else:
+            rp = make_engine(hip, params, Kc)
+            res.run(rp, 0, n_cpu)
+            rp.sync()
+            da, va = rp.dump_blocks()
+            rp.close()
+            which = f"a replay of the first {n_cpu} frames through the timed loop's entry points (mrh_set_depth_device / mrh_set_rgb_device)"
+        db, vb = ce.dump_blocks()
+        same_occ = bool(len(da) == len(db) and np.array_equal(da, db))
+        same_u8 = bool(same_occ and np.array_equal(va["weight"], vb["weight"]) and np.array_equal(va["rgb"], vb["rgb"]))
+        same_sdf = bool(same_occ and np.array_equal(va["sdf"].view(np.uint32), vb["sdf"].view(np.uint32)))
+        same_ssq = bool(same_occ and np.array_equal(va["sum_squared"].view(np.uint32), vb["sum_squared"].view(np.uint32)))
+        max_dsdf = float(np.nanmax(np.abs(va["sdf"] - vb["sdf"]), initial=0.0)) if same_occ else None
+        parity = {"checked": which, "frames": n_cpu, "blocks": int(len(da)), "oracle_blocks": int(len(db)),
+                  "weighted_voxels": int((va["weight"] > 0).sum()), "occupancy_equal": same_occ, "weights_and_colours_equal": same_u8,
+                  "sdf_bit_exact": same_sdf, "sum_squared_bit_exact": same_ssq, "max_abs_sdf_diff": max_dsdf,
+                  "ok": bool(same_occ and same_u8 and max_dsdf is not None and max_dsdf <= 1e-5)}
+        del da, va, db, vb
         ce.close()
-        cpu = {"value": n_cpu / tc, "unit": "frames/s", "cores": cores, "kind": "port",
+        cpu = {"value": n_cpu / tc, "unit": "frames/s", "cores": cores, "kind": "port", "parity": parity,
                "sample": f"first {n_cpu} frames of the same 640x480 stream through the test oracle (oracle/mrh_oracle.c, gcc -O2 -fopenmp, "
                          f"allocation single-threaded: a restatement for checking results, not a tuned CPU implementation), time of mrh_integrate only"}
 
@@ -561,6 +610,7 @@ def bench_single(args):
                    "frames_per_gpu": K, "voxel_size_m": 0.01, "truncation_m": 0.07, "parallelism": "single GPU", "live_blocks_end": occupied,
                    "hash_table": table},
         "roofline": roof, "roofline_hbm": roof_hbm, "mc": mc, "cpu_baseline": cpu,
+        "parity_checked": bool(cpu and cpu["parity"]["ok"]), "blocks": (cpu["parity"]["blocks"] if cpu else None),
         "lidar": lidar, "splat": splat, "pcie_inclusive_frames_per_s": pcie_fps, "periodic_frames": periodic, "spherical_images": spherical,
     }
     emit(out)
@@ -902,7 +952,7 @@ def main():
             procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
         rcs = [p.wait() for p in procs]
         raise SystemExit(max(abs(rc) for rc in rcs))
-    if not args.pmc_inner and not args.pmc_inner_big and not args.pmc_inner_mc:
+    if not (args.pmc_inner or args.pmc_inner_big or args.pmc_inner_mc or args.pmc_inner_lidar):
         global _RESULT_FD
         sys.stdout.flush()
         _RESULT_FD = os.dup(1)

@@ -36,6 +36,8 @@ def test_single_gpu_line():
     assert d["pcie_inclusive_frames_per_s"] > 0 and "workload" in d["config"]
     assert d["periodic_frames"]["steady_frame_ms"] > 0 and d["periodic_frames"]["starve_frame_ms"] > d["periodic_frames"]["steady_frame_ms"]
     assert d["spherical_images"]["frames_per_s"] > 0 and d["roofline"]["k_front_ms_avg"] > 0
+    # the oracle of the cpu_baseline leg also checks the map of the same frames through the timed loop's entry points
+    assert d["parity_checked"] is True and c["parity"]["frames"] == 2 and c["parity"]["sdf_bit_exact"] and d["blocks"] == c["parity"]["oracle_blocks"] > 1000
 
 
 @pytest.mark.parametrize("ranks", [2, 8])
@@ -90,3 +92,34 @@ def test_value_survives_a_stuck_exchange_phase():
     with a limit the merge of two sub-maps cannot meet)."""
     d = _run(["--gpus", "2", "--steps", "6", "--warmup", "2", "--blocks", "65536"], env={"MRH_BENCH_SHARE_DEVICE": "1", "MRH_BENCH_PHASE_TIMEOUT": "0.001"}, timeout=900)
     assert d["ranks"] == 2 and d["value"] > 1000 and "phases_error" in d and d["merge"] is None
+
+
+def test_the_timed_entry_point_of_bench_py_matches_the_oracle():
+    """The timed region of bench.py feeds the engine through mrh_set_depth_device / mrh_set_rgb_device (caller-owned device
+    pointers, `Resident.run`), not through the upload ring every other parity test uses.  Exactly that loop — the driver's 5
+    warm-up + 20 timed frames of the 640x480 stream, one sync at the end — against the oracle fed the same frames from host
+    memory: complete map and mesh (VoxelContainer::integrate as the reference brackets it, voxel_data_structures.cpp:90-110)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    import parity_utils as pu
+    from mrhash_amd import capi, synth
+
+    hip, orc = capi.load_hip(), pu.oracle_lib()
+    W, K = 5, 20
+    frames = bench.render_stream("replica", W + K)  # the very frames bench.py renders
+    res = bench.Resident(frames, synth.REPLICA_640)
+    a = bench.make_engine(hip, capi.Params(num_sdf_blocks=131072, device_id=0, **synth.REPLICA_PARAMS), synth.REPLICA_640)
+    b = pu.make_engine(orc, synth.REPLICA_640, synth.REPLICA_PARAMS, 131072)
+    res.run(a, 0, W)
+    a.sync()
+    res.run(a, W, W + K)  # the timed loop: no synchronisation between the frames
+    a.sync()
+    for f in frames:
+        pu.feed(b, f)
+    r = pu.compare_maps(a, b)
+    assert r["blocks"] > 10000 and r["sdf_bit_exact"] and r["sumsq_bit_exact"]
+    assert a.stats().frames_integrated == W + K and a.stats().error_flags == 0
+    m = pu.compare_meshes(a, b)
+    assert m["triangles"] > 300000 and m["pos_bit_exact"]
+    a.close()
+    b.close()
