@@ -278,6 +278,7 @@ struct mrh_ctx {
 
 static int comm_allreduce_zbuf(mrh_ctx* c, mrh::u64* buf, size_t n);  // mrh_comm.h
 static void comm_release(mrh_ctx* c);
+static bool comm_matches_sharding(const mrh_ctx* c, int* comm_rank, int* comm_world);
 
 namespace {
 
@@ -763,10 +764,10 @@ int starve_and_tail(mrh_ctx* c, int max_num_frames) {
       const size_t npix = (size_t) c->cam.rows * c->cam.cols;
       rc = comm_allreduce_zbuf(c, c->d_zbuf, npix);
       if (rc) return rc;
-      launch_starve(c, 1);
+      if ((rc = launch_starve(c, 1))) return rc;
       rc = comm_allreduce_zbuf(c, c->d_zbuf + npix, npix);
       if (rc) return rc;
-      launch_starve(c, 2);
+      if ((rc = launch_starve(c, 2))) return rc;
       return frame_tail(c, starve, max_num_frames);
     }
     if (c->p.shard_count > 1) {
@@ -775,8 +776,8 @@ int starve_and_tail(mrh_ctx* c, int max_num_frames) {
       c->pending_max_frames = max_num_frames;
       return MRH_PENDING_EXCHANGE;
     }
-    launch_starve(c, 1);
-    launch_starve(c, 2);
+    if ((rc = launch_starve(c, 1))) return rc;
+    if ((rc = launch_starve(c, 2))) return rc;
   }
   return frame_tail(c, starve, max_num_frames);
 }
@@ -1276,6 +1277,12 @@ static int integrate_frame(mrh_ctx* c, int n_frames_invalidate) {
   if (c->pending) return fail(c, MRH_ERR_STATE, "mrh_integrate: an exchange is pending (call mrh_integrate_resume)");
   if (c->halo_upper) return fail(c, MRH_ERR_STATE, "mrh_integrate: halo blocks of other shards are present (call mrh_drop_blocks(MRH_DROP_HALO) after the extraction)");
   if (!c->has_camera) return fail(c, MRH_ERR_STATE, "mrh_integrate: set_camera has not been called");
+  if (c->comm && c->p.shard_count > 1) {  // the starve all-reduce runs over the communicator's ranks: they must be this map's shards
+    int cr = 0, cw = 1;
+    // MRH_COMM_ALLOW_SHARD_MISMATCH=1 is a test hook for one-GPU boxes (a one-rank group reducing the buffer of one of two shards)
+    if (!comm_matches_sharding(c, &cr, &cw) && !getenv("MRH_COMM_ALLOW_SHARD_MISMATCH"))
+      return fail(c, MRH_ERR_STATE, "mrh_integrate: the context is shard %d of %d, the attached communicator rank %d of %d", c->p.shard_rank, c->p.shard_count, cr, cw);
+  }
   if (!c->d_depth || !c->d_rgb) return fail(c, MRH_ERR_STATE, "mrh_integrate: depth and rgb images are required");
   const Cam& k = c->cam;
   if (c->depth_rows != k.rows || c->depth_cols != k.cols || c->rgb_rows != k.rows || c->rgb_cols != k.cols)

@@ -152,6 +152,27 @@ int ctx_allgather_u64(mrh_ctx* c, const uint64_t* mine, const size_t n_words, ui
   return MRH_OK;
 }
 
+// Every rank contributes the status of its local steps as word 0 of a small all-gather (plus `n_words` payload words); the
+// call fails on EVERY rank if it failed on any, so that no rank walks into a data collective its peers will never join (a
+// pack error, an out-of-memory in ctx_grow, a broken owner partition on one rank used to leave the others hanging inside
+// ncclSend / ncclRecv, which have no time limit).  all: world * (1 + n_words) words, rank r's at r * (1 + n_words).
+int ctx_agree(mrh_ctx* c, const int local_rc, const char* who, const uint64_t* mine, const size_t n_words, std::vector<uint64_t>& all) {
+  mrh_comm* m = c->comm;
+  std::vector<uint64_t> send(1 + n_words, 0);
+  send[0] = (uint64_t) (uint32_t) local_rc;
+  for (size_t i = 0; i < n_words; i++) send[1 + i] = mine ? mine[i] : 0;
+  all.assign((size_t) m->world * (1 + n_words), 0);
+  const std::string local_err = local_rc ? c->err : std::string();
+  const int rc = ctx_allgather_u64(c, send.data(), 1 + n_words, all.data());
+  if (rc) return rc;  // the collective itself failed: nothing more can be agreed on
+  if (local_rc) { c->err = local_err; return local_rc; }
+  for (int r = 0; r < m->world; r++) {
+    const int prc = (int) (uint32_t) all[(size_t) r * (1 + n_words)];
+    if (prc) return fail(c, MRH_ERR_STATE, "%s: rank %d reported error %d before the exchange; nothing was moved", who, r, prc);
+  }
+  return MRH_OK;
+}
+
 int need_comm(mrh_ctx* c, const char* who) {
   int rc = ensure_ready(c, who);
   if (rc) return rc;
@@ -189,6 +210,11 @@ struct PhaseClock {
 };
 
 }  // namespace
+
+static bool comm_matches_sharding(const mrh_ctx* c, int* comm_rank, int* comm_world) {
+  *comm_rank = c->comm->rank; *comm_world = c->comm->world;
+  return c->p.shard_count == c->comm->world && c->p.shard_rank == c->comm->rank;
+}
 
 static void comm_release(mrh_ctx* c) {  // free_all: the context goes away
   if (c->comm) { c->comm->attached--; c->comm = nullptr; }
@@ -352,22 +378,25 @@ int mrh_comm_exchange_halo(mrh_ctx* c, uint64_t* out_taken) {
   if (c->p.shard_count != world || c->p.shard_rank != rank)
     return fail(c, MRH_ERR_STATE, "mrh_comm_exchange_halo: the context is shard %d of %d, the communicator rank %d of %d", c->p.shard_rank, c->p.shard_count, rank, world);
   PhaseClock clk(c);
-  if ((rc = clk.mark())) return rc;
   const mrh_block_record* mine = nullptr;
   uint64_t n = 0;
-  rc = mrh_pack_blocks(c, MRH_PACK_HALO, 0, &mine, &n, nullptr);
+  const size_t rec = sizeof(mrh_block_record);
+  // local steps first, their status travels with the counts: either every rank enters the data exchange or none does
+  rc = clk.mark();
+  if (!rc) rc = mrh_pack_blocks(c, MRH_PACK_HALO, 0, &mine, &n, nullptr);
+  if (!rc) rc = clk.mark();
+  std::vector<uint64_t> agreed;
+  rc = ctx_agree(c, rc, "mrh_comm_exchange_halo", &n, 1, agreed);
   if (rc) return rc;
-  if ((rc = clk.mark())) return rc;
   std::vector<uint64_t> counts((size_t) world);
-  rc = ctx_allgather_u64(c, &n, 1, counts.data());
-  if (rc) return rc;
+  for (int r = 0; r < world; r++) counts[r] = agreed[2 * (size_t) r + 1];
   if ((rc = clk.mark())) return rc;
   uint64_t total_in = 0;
   std::vector<uint64_t> off((size_t) world, 0);
   const bool self = comm_self_loop();
   for (int r = 0; r < world; r++) { off[r] = total_in; if (r != rank || self) total_in += counts[r]; }
-  const size_t rec = sizeof(mrh_block_record);
   rc = ctx_grow(c, c->d_xrecv, c->xrecv_cap, std::max<size_t>(total_in * rec, 256), 0);
+  rc = ctx_agree(c, rc, "mrh_comm_exchange_halo", nullptr, 0, agreed);  // the receive buffer exists on every rank
   if (rc) return rc;
   if (world > 1 || self) {
     CTX_NCCL(c, rccl()->GroupStart());
@@ -397,44 +426,53 @@ int mrh_comm_merge_submaps(mrh_ctx* c, int chunk_log2, mrh_comm_merge_info* out)
   if (c->halo_upper) return fail(c, MRH_ERR_STATE, "mrh_comm_merge_submaps: halo blocks are present (mrh_drop_blocks(MRH_DROP_HALO) first)");
   mrh_comm* m = c->comm;
   const int world = m->world, rank = m->rank;
-  rc = mrh_set_sharding(c, rank, world, chunk_log2);
-  if (rc) return rc;
+  const int old_rank = c->p.shard_rank, old_count = c->p.shard_count, old_log2 = c->p.shard_chunk_log2;
   const size_t rec = sizeof(mrh_block_record);
   PhaseClock clk(c);
-  if ((rc = clk.mark())) return rc;
-  // one send buffer, the parts in destination order (every live block has exactly one owner: n_all records in total)
-  int n_all = 0;
-  rc = select_blocks(c, kSelAll, 0, &n_all);
-  if (rc) return rc;
-  rc = ctx_grow(c, c->d_xsend, c->xsend_cap, std::max<size_t>((size_t) n_all * rec, 256), 0);
-  if (rc) return rc;
+  // one send buffer, the parts in destination order (every live block has exactly one owner: n_all records in total).
+  // Local steps first; their status travels with the count matrix, so a rank that failed keeps the others out of the exchange.
   std::vector<uint64_t> out_counts((size_t) world, 0), out_off((size_t) world, 0);
-  uint64_t packed = 0;
-  for (int dest = 0; dest < world; dest++) {
-    int n = 0;
-    rc = select_blocks(c, kSelOwner, dest, &n);
-    if (rc) return rc;
-    out_off[dest] = packed;
-    out_counts[dest] = (uint64_t) n;
-    if (packed + (uint64_t) n > (uint64_t) n_all) return fail(c, MRH_ERR_STATE, "mrh_comm_merge_submaps: the owner partition does not add up");
-    if (n) k_pack_records<<<n < 4096 ? n : 4096, 512, 0, c->stream>>>(c->tab, 0, n, c->d_xsend + packed * rec);
-    packed += (uint64_t) n;
-  }
-  HIP_TRY(c, hipGetLastError());
-  if ((rc = clk.mark())) return rc;
-  std::vector<uint64_t> matrix((size_t) world * world);  // matrix[src * world + dest]
-  rc = ctx_allgather_u64(c, out_counts.data(), (size_t) world, matrix.data());
-  if (rc) return rc;
+  auto pack_all = [&]() -> int {
+    int r2 = mrh_set_sharding(c, rank, world, chunk_log2);
+    if (r2) return r2;
+    if ((r2 = clk.mark())) return r2;
+    int n_all = 0;
+    if ((r2 = select_blocks(c, kSelAll, 0, &n_all))) return r2;
+    if ((r2 = ctx_grow(c, c->d_xsend, c->xsend_cap, std::max<size_t>((size_t) n_all * rec, 256), 0))) return r2;
+    uint64_t packed = 0;
+    for (int dest = 0; dest < world; dest++) {
+      int n = 0;
+      if ((r2 = select_blocks(c, kSelOwner, dest, &n))) return r2;
+      out_off[dest] = packed;
+      out_counts[dest] = (uint64_t) n;
+      if (packed + (uint64_t) n > (uint64_t) n_all) return fail(c, MRH_ERR_STATE, "mrh_comm_merge_submaps: the owner partition does not add up");
+      if (n) k_pack_records<<<n < 4096 ? n : 4096, 512, 0, c->stream>>>(c->tab, 0, n, c->d_xsend + packed * rec);
+      packed += (uint64_t) n;
+    }
+    HIP_TRY(c, hipGetLastError());
+    return clk.mark();
+  };
+  auto restore_sharding = [&](const int code) {  // nothing has been moved or dropped yet: the context goes back to what it was
+    const std::string keep = c->err;
+    (void) mrh_set_sharding(c, old_rank, old_count, old_log2);
+    c->err = keep;
+    return code;
+  };
+  rc = pack_all();
+  std::vector<uint64_t> agreed;
+  rc = ctx_agree(c, rc, "mrh_comm_merge_submaps", out_counts.data(), (size_t) world, agreed);
+  if (rc) return restore_sharding(rc);
   std::vector<uint64_t> in_counts((size_t) world), in_off((size_t) world, 0);
   uint64_t total_in = 0;
   const bool self = comm_self_loop();
   for (int src = 0; src < world; src++) {
-    in_counts[src] = matrix[(size_t) src * world + rank];
+    in_counts[src] = agreed[(size_t) src * (world + 1) + 1 + rank];  // matrix[src][dest = this rank]
     in_off[src] = total_in;
     if (src != rank || self) total_in += in_counts[src];
   }
   rc = ctx_grow(c, c->d_xrecv, c->xrecv_cap, std::max<size_t>(total_in * rec, 256), 0);
-  if (rc) return rc;
+  rc = ctx_agree(c, rc, "mrh_comm_merge_submaps", nullptr, 0, agreed);
+  if (rc) return restore_sharding(rc);
   if ((rc = clk.mark())) return rc;
   uint64_t sent = 0;
   if (world > 1 || self) {
@@ -472,45 +510,46 @@ int mrh_comm_gather_mesh(mrh_ctx* c, int root, uint64_t* out_triangles) {
   const int world = m->world, rank = m->rank;
   if (root < 0 || root >= world) return fail(c, MRH_ERR_INVALID_ARG, "mrh_comm_gather_mesh: root %d of %d ranks", root, world);
   PhaseClock clk(c);
-  if ((rc = clk.mark())) return rc;
   uint64_t nt = 0;
-  rc = mrh_extract_triangles(c, nullptr, &nt);  // the soup stays in c->d_soup
-  if (rc) return rc;
   const mrh_block_desc* descs = nullptr;
   const uint32_t* cnts = nullptr;
   uint64_t nblk = 0;
-  rc = mrh_get_triangle_blocks(c, &descs, &cnts, &nblk);
-  if (rc) return rc;
+  rc = clk.mark();
+  if (!rc) rc = mrh_extract_triangles(c, nullptr, &nt);  // the soup stays in c->d_soup
+  if (!rc) rc = mrh_get_triangle_blocks(c, &descs, &cnts, &nblk);
   // per-block metadata of the non-empty blocks: 16-byte descriptor + 4-byte count
   std::vector<mrh_block_desc> my_d;
   std::vector<uint32_t> my_c;
-  for (uint64_t i = 0; i < nblk; i++)
-    if (cnts[i]) { my_d.push_back(descs[i]); my_c.push_back(cnts[i]); }
+  if (!rc)
+    for (uint64_t i = 0; i < nblk; i++)
+      if (cnts[i]) { my_d.push_back(descs[i]); my_c.push_back(cnts[i]); }
   const uint64_t nb = my_d.size();
-  if ((rc = clk.mark())) return rc;
-  const uint64_t mine[2] = {nb, nt};
-  std::vector<uint64_t> sizes((size_t) world * 2);
-  rc = ctx_allgather_u64(c, mine, 2, sizes.data());
+  if (!rc) rc = clk.mark();
+  const uint64_t mine[2] = {nb, rc ? 0 : nt};
+  std::vector<uint64_t> agreed;
+  rc = ctx_agree(c, rc, "mrh_comm_gather_mesh", mine, 2, agreed);
   if (rc) return rc;
+  std::vector<uint64_t> sizes((size_t) world * 2);
+  for (int r = 0; r < world; r++) { sizes[2 * r] = agreed[3 * (size_t) r + 1]; sizes[2 * r + 1] = agreed[3 * (size_t) r + 2]; }
   if ((rc = clk.mark())) return rc;
   uint64_t tot_b = 0, tot_t = 0;
   std::vector<uint64_t> boff((size_t) world), toff((size_t) world);
   for (int r = 0; r < world; r++) { boff[r] = tot_b; toff[r] = tot_t; tot_b += sizes[2 * r]; tot_t += sizes[2 * r + 1]; }
-  // metadata travels through device staging (20 bytes a block), the triangles from soup to soup
-  const size_t meta_mine = (size_t) nb * 20, meta_all = (size_t) tot_b * 20;
+  // metadata travels through device staging (20 bytes a block), the triangles from soup to soup.  The triangle area starts on a
+  // 256-byte boundary: the run merge reads it with 16-byte loads (k_permute_runs), and 20 * tot_b is only 4-byte aligned.
+  const size_t meta_mine = (size_t) nb * 20, meta_all = (size_t) tot_b * 20, meta_span = (meta_all + 255) & ~(size_t) 255;
   rc = ctx_grow(c, c->d_xsend, c->xsend_cap, std::max<size_t>(meta_mine, 256), 0);
-  if (rc) return rc;
-  if (nb) {
-    HIP_TRY(c, hipMemcpyAsync(c->d_xsend, my_d.data(), nb * 16, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->d_xsend + nb * 16, my_c.data(), nb * 4, hipMemcpyHostToDevice, c->stream));
+  if (!rc && nb) {
+    hipError_t e = hipMemcpyAsync(c->d_xsend, my_d.data(), nb * 16, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(c->d_xsend + nb * 16, my_c.data(), nb * 4, hipMemcpyHostToDevice, c->stream);
+    if (e != hipSuccess) rc = fail(c, MRH_ERR_DEVICE, "mrh_comm_gather_mesh: staging the block metadata failed: %s", hipGetErrorString(e));
   }
   const size_t tri = sizeof(mrh_triangle);
-  if (rank == root) {
-    rc = ctx_grow(c, c->d_xrecv, c->xrecv_cap, std::max<size_t>(meta_all + tot_t * tri, 256), 0);
-    if (rc) return rc;
-  }
+  if (!rc && rank == root) rc = ctx_grow(c, c->d_xrecv, c->xrecv_cap, std::max<size_t>(meta_span + tot_t * tri, 256), 0);
+  rc = ctx_agree(c, rc, "mrh_comm_gather_mesh", nullptr, 0, agreed);  // buffers exist everywhere before anybody sends
+  if (rc) return rc;
   char* d_meta = c->d_xrecv;             // root: [rank r's descs | counts] at boff[r] * 20
-  char* d_tris = c->d_xrecv + meta_all;  // root: rank r's triangles at toff[r]
+  char* d_tris = c->d_xrecv + meta_span;  // root: rank r's triangles at toff[r]
   const mrh_triangle* soup = c->soup_n ? c->d_soup : nullptr;
   const bool self = comm_self_loop();
   if (world > 1 || self) {

@@ -54,33 +54,85 @@ def shard_frames(n_frames: int, rank: int, world: int) -> range:
     return range(rank * n_frames, (rank + 1) * n_frames)
 
 
+def rdzv_dir() -> str:
+    """Directory of the rendezvous files: MRH_RDZV_DIR if given, else a per-user directory (mode 0700, owned by this user) under
+    XDG_RUNTIME_DIR or /tmp — not the world-writable /tmp itself, where another local user could pre-create a file of a
+    predictable name."""
+    d = os.environ.get("MRH_RDZV_DIR")
+    if d:
+        return d
+    base = os.environ.get("XDG_RUNTIME_DIR")
+    d = os.path.join(base if base and os.path.isdir(base) else "/tmp", f"mrh_rdzv_u{os.getuid()}")
+    os.makedirs(d, mode=0o700, exist_ok=True)
+    st = os.stat(d)
+    if st.st_uid != os.getuid() or (st.st_mode & 0o077):
+        raise PermissionError(f"rendezvous directory {d} is not private to uid {os.getuid()}")
+    return d
+
+
+def launcher_start_time() -> float:
+    """Wall-clock start of the parent process (the launcher every rank of a node shares: torch.distributed.run's agent, bench.py's
+    own launcher, mpirun): a rendezvous file older than that is left over from an earlier run (a crashed job, a reused key or
+    pid) and must not be believed.  0.0 when /proc does not say."""
+    try:
+        with open(f"/proc/{os.getppid()}/stat") as f:
+            ticks = float(f.read().rsplit(")", 1)[1].split()[19])  # field 22 (starttime), counted after "pid (comm)"
+        with open("/proc/stat") as f:
+            btime = next(float(ln.split()[1]) for ln in f if ln.startswith("btime"))
+        return btime + ticks / os.sysconf("SC_CLK_TCK")
+    except Exception:  # noqa: BLE001
+        return 0.0
+
+
+def publish_file(path: str, payload: bytes) -> None:
+    """All of `payload` or nothing at `path`: written to a fresh private file (O_EXCL, mode 0600) and renamed."""
+    tmp = f"{path}.{os.getpid()}.tmp"
+    try:
+        os.unlink(tmp)
+    except FileNotFoundError:
+        pass
+    fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL, 0o600)
+    try:
+        os.write(fd, payload)
+    finally:
+        os.close(fd)
+    os.replace(tmp, path)
+
+
 def rendezvous(lib, rank: Optional[int] = None, world: Optional[int] = None, device_id: Optional[int] = None, timeout_s: float = 300.0) -> capi.Comm:
     """RCCL communicator from the launcher's environment (RANK / LOCAL_RANK / WORLD_SIZE as torch.distributed.run, mpirun
-    wrappers and bench.py's own launcher set them).  Rank 0 creates the ncclUniqueId and publishes its 128 bytes in a file under
-    MRH_RDZV_DIR (default /tmp) named after the launcher — parent pid, MASTER_PORT, TORCHELASTIC_RUN_ID — written to a
-    temporary name and renamed, so a reader sees all of it or nothing; the other ranks of the node poll for it.  One node, as
-    the bench contract says; a multi-node launcher hands the id over itself and calls capi.Comm directly."""
+    wrappers and bench.py's own launcher set them).  Rank 0 removes whatever an earlier run left under the name, creates the
+    ncclUniqueId and publishes its 128 bytes in a file under `rdzv_dir()` named after the launcher — parent pid, MASTER_PORT,
+    TORCHELASTIC_RUN_ID — private (0600, O_EXCL), written to a temporary name and renamed, so a reader sees all of it or
+    nothing; the other ranks of the node poll for it and believe only a file that is theirs and not older than their launcher
+    (a stale id would leave them inside ncclCommInitRank for ever: the time limit covers the poll only).  One node, as the
+    bench contract says; a multi-node launcher hands the id over itself and calls capi.Comm directly."""
     rank = int(os.environ.get("RANK", "0")) if rank is None else rank
     world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else world
     device_id = int(os.environ.get("LOCAL_RANK", str(rank))) if device_id is None else device_id
     key = os.environ.get("MRH_RDZV_KEY") or f"{os.getppid()}_{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'none')}"
-    path = os.path.join(os.environ.get("MRH_RDZV_DIR", "/tmp"), f"mrh_rdzv_{key}.id")
+    path = os.path.join(rdzv_dir(), f"mrh_rdzv_{key}.id")
     if rank == 0:
+        try:
+            os.unlink(path)  # a leftover of an earlier run with the same key
+        except FileNotFoundError:
+            pass
         uid = capi.Comm.unique_id(lib)
-        tmp = f"{path}.{os.getpid()}.tmp"
-        with open(tmp, "wb") as f:
-            f.write(uid)
-        os.replace(tmp, path)
+        publish_file(path, uid)
     else:
         t0 = time.time()
+        not_before = launcher_start_time() - 2.0  # clock granularity of /proc
         uid = b""
         while len(uid) != capi.COMM_ID_BYTES:
             try:
-                with open(path, "rb") as f:
-                    uid = f.read()
+                st = os.stat(path)
+                if st.st_uid == os.getuid() and st.st_mtime >= not_before:
+                    with open(path, "rb") as f:
+                        uid = f.read()
             except FileNotFoundError:
                 uid = b""
             if len(uid) != capi.COMM_ID_BYTES:
+                uid = b""
                 if time.time() - t0 > timeout_s:
                     raise TimeoutError(f"rendezvous: rank 0 never published {path}")
                 time.sleep(0.01)

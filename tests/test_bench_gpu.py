@@ -47,7 +47,10 @@ def test_n_ranks_on_one_device_line(ranks):
     `n_gpus` counts DEVICES (one here); `ranks` says how many processes shared it."""
     d = _run(["--gpus", str(ranks), "--steps", "6", "--warmup", "2", "--blocks", "65536"], env={"MRH_BENCH_SHARE_DEVICE": "1"}, timeout=900)
     assert all(k in d for k in KEYS)
-    assert d["n_gpus"] == 1 and d["ranks"] == ranks and d["scaling"] == "weak" and d["value"] > 1000
+    assert d["n_gpus"] == 1 and d["ranks"] == ranks and d["scaling"] == "weak" and d["fuse_only_frames_per_s"] > 1000
+    # `value` contains the sub-map merge and the boundary-block exchange (here through gloo and host tensors: slow)
+    assert 0 < d["value"] < d["fuse_only_frames_per_s"] and "mrh_comm_merge_submaps" in d["value_definition"]
+    assert abs(d["value"] * d["ms_per_step"] / 1e3 - ranks) < 1e-6 * ranks
     m = d["merge"]
     assert m["merge_ms"] > 0 and len(m["blocks_sent_per_rank"]) == ranks and all(v > 0 for v in m["blocks_sent_per_rank"])
     assert all(v > 0 for v in m["owned_blocks_after_merge_per_rank"]) and all(v > 0 for v in m["halo_blocks_taken_per_rank"])
@@ -69,7 +72,8 @@ def test_one_rank_rccl_line():
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 1 and d["ranks"] == 1 and d["value"] > 1000
+    assert d["n_gpus"] == 1 and d["ranks"] == 1 and d["fuse_only_frames_per_s"] > 1000 and 100 < d["value"] < d["fuse_only_frames_per_s"]
+    assert "mrh_comm_exchange_halo" in d["value_definition"]
     ph = d["phases"]
     assert ph["merge"]["pack_ms"] > 0 and ph["merge"]["unpack_ms"] > 0 and ph["halo"]["pack_ms"] > 0
     assert ph["starve_allreduce_count"] == 0  # one shard: nothing to reduce (tests/test_sharding_gpu.py drives the all-reduce)
@@ -82,7 +86,7 @@ def test_value_survives_without_a_communicator():
     segment, and say that the exchange phases were left out."""
     d = _run(["--gpus", "2", "--steps", "6", "--warmup", "2", "--blocks", "65536"], env={"MRH_BENCH_SHARE_DEVICE": "1", "MRH_BENCH_BACKEND": "host"}, timeout=900)
     assert all(k in d for k in KEYS)
-    assert d["ranks"] == 2 and d["value"] > 1000 and d["backend"] == "host"
+    assert d["ranks"] == 2 and d["value"] > 1000 and d["backend"] == "host" and d["value_definition"].startswith("fuse only")
     assert d["merge"] is None and d["tile_sharded"] is None and d["roofline"]["launches"] == 6
     assert len(d["config"]["sub_map_blocks_per_rank"]) == 2 and all(v > 0 for v in d["config"]["sub_map_blocks_per_rank"])
 

@@ -38,3 +38,26 @@ def test_host_group_barrier_allgather_and_cleanup(tmp_path):
     # every step's files are gone except the last (empty) ones
     left = sorted(os.listdir(tmp_path))
     assert [f for f in left if f.startswith("mrh_hostgrp_") and not f.split(".")[-2] == "5"] == [], left
+
+
+def test_rendezvous_ignores_a_stale_id_file_and_keeps_its_files_private(tmp_path, monkeypatch):
+    """A file of the right name and size that is OLDER than the launcher (a crashed earlier run, a reused key) must not be taken
+    for this run's ncclUniqueId — a rank that believed it would sit in ncclCommInitRank for ever; what is published is private
+    (0600) and the default directory is per-user (0700)."""
+    import pytest
+
+    from mrhash_amd import capi, parallel
+
+    monkeypatch.setenv("MRH_RDZV_DIR", str(tmp_path))
+    monkeypatch.setenv("MRH_RDZV_KEY", "pytest_stale")
+    stale = tmp_path / "mrh_rdzv_pytest_stale.id"
+    stale.write_bytes(b"\x01" * capi.COMM_ID_BYTES)
+    os.utime(stale, (1.0, 1.0))  # 1970: older than any launcher
+    with pytest.raises(TimeoutError):
+        parallel.rendezvous(None, rank=1, world=2, device_id=0, timeout_s=0.3)
+    parallel.publish_file(str(tmp_path / "x"), b"abc")
+    assert (os.stat(tmp_path / "x").st_mode & 0o777) == 0o600 and (tmp_path / "x").read_bytes() == b"abc"
+    monkeypatch.delenv("MRH_RDZV_DIR")
+    d = parallel.rdzv_dir()
+    assert (os.stat(d).st_mode & 0o777) == 0o700 and os.stat(d).st_uid == os.getuid()
+    assert parallel.launcher_start_time() > 1e9

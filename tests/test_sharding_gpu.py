@@ -109,8 +109,15 @@ a.set_sharding(0, 1, 1)
 b = pu.make_engine(hip, synth.CFG1, params, 16384, shard_rank=0, shard_count=1)
 # force the sharded code path on one rank: shard_count 1 owns everything, so run a second pair that owns one of two shards
 a2 = pu.make_engine(hip, synth.CFG1, params, 16384, shard_rank=0, shard_count=2, shard_chunk_log2=1)
-a2.attach_comm(comm)                   # world 1 != shard_count 2: allowed for the all-reduce (a reduction over the ranks present)
-b2 = pu.make_engine(hip, synth.CFG1, params, 16384, shard_rank=0, shard_count=2, shard_chunk_log2=1)
+a2.attach_comm(comm)                   # world 1 != shard_count 2: a reduction over the wrong set of ranks would silently give
+b2 = pu.make_engine(hip, synth.CFG1, params, 16384, shard_rank=0, shard_count=2, shard_chunk_log2=1)  # another map, so it is refused ...
+a2.set_pose(frames[0].R, frames[0].t); a2.upload_depth(frames[0].depth); a2.upload_rgb(frames[0].rgb)
+try:
+    a2.integrate()
+    raise SystemExit("a communicator whose ranks are not the map's shards was accepted")
+except capi.MrhError as e:
+    assert "shard 0 of 2" in str(e) and "rank 0 of 1" in str(e), str(e)
+os.environ["MRH_COMM_ALLOW_SHARD_MISMATCH"] = "1"   # ... unless this test hook says otherwise (one-GPU box: one rank reduces its own buffer)
 for f in frames:
     pu.feed(a, f); pu.feed(b, f)
     pu.feed(a2, f)                      # integrate() must not report a pending exchange
@@ -283,3 +290,119 @@ def test_lidar_and_splat_seeds_on_tile_shards_hip(hip):
     key = lambda a: np.lexsort((a["p"][:, 2], a["p"][:, 1], a["p"][:, 0], a["scale"]))  # noqa: E731
     assert both[key(both)].tobytes() == s0[key(s0)].tobytes()
     assert np.array_equal(single.qtree_leaves(), shards[0].qtree_leaves())  # the tree depends on the image only
+
+
+@pytest.mark.parametrize("self_loop", [False, True])
+def test_plain_c_program_drives_the_comm_abi(hip, tmp_path, self_loop):
+    """examples/comm_smoke.c: N processes in plain C — mrh_comm_create, frame-sharded sub-maps, mrh_comm_merge_submaps,
+    mrh_comm_exchange_halo, mrh_comm_gather_mesh, the merged map checked against a single context — so that first contact with
+    an 8-GPU node can be diagnosed without Python.  On this box: one rank (and, with MRH_COMM_SELF_LOOP, its own parts through
+    ncclSend / ncclRecv to itself); MRH_TEST_WORLD=N runs it with N ranks where N devices exist."""
+    import os
+    import subprocess
+
+    from mrhash_amd import hipmem
+    from test_sharding import ROOT
+
+    exe = str(tmp_path / "comm_smoke")
+    libdir = os.path.join(ROOT, "mrhash_amd", "csrc")
+    subprocess.run(["gcc", "-std=c11", "-O1", "-Wall", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "comm_smoke.c"), "-o", exe,
+                    "-L" + libdir, "-lmrhash_hip", "-Wl,-rpath," + libdir, "-lm"], check=True)
+    world = min(int(os.environ.get("MRH_TEST_WORLD", "1")), max(hipmem.device_count(), 1))
+    env = dict(os.environ, XDG_RUNTIME_DIR=str(tmp_path))
+    if self_loop:
+        env["MRH_COMM_SELF_LOOP"] = "1"
+    r = subprocess.run([exe, str(world)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert f"comm_smoke: {world} of {world} ranks passed" in r.stdout and r.stdout.count("PASS") == world
+    assert "position checksum equal" in r.stdout and "mesh on root" in r.stdout
+
+
+NRANK_WORKER = r"""
+import os, sys
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import numpy as np
+import parity_utils as pu
+from mrhash_amd import capi, hipmem, parallel, synth
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+hip = capi.load_hip()
+hipmem.set_device(rank)
+comm = parallel.rendezvous(hip)          # rank r on device r, RCCL over xGMI
+assert (comm.rank, comm.world) == (rank, world)
+comm.barrier()
+params = dict(synth.CFG1_PARAMS, n_frames_invalidate_voxels=2)
+frames = [synth.cfg1_sphere(zc=1.5 + 0.005 * k) for k in range(2 * world)]
+# (1) tile-sharded fusion of ONE stream: starve frames all-reduce inside mrh_integrate; halo; mesh on rank 0 == single context
+te = pu.make_engine(hip, synth.CFG1, params, 16384, device_id=rank, shard_rank=rank, shard_count=world, shard_chunk_log2=1)
+te.attach_comm(comm)
+for f in frames:
+    pu.feed(te, f)
+te.sync()
+n_halo = parallel.exchange_halo(te, comm)
+res = parallel.gather_mesh(te, comm)
+if rank == 0:
+    ref = pu.make_engine(hip, synth.CFG1, params, 16384, device_id=rank)
+    for f in frames:
+        pu.feed(ref, f)
+    t = ref.extract_triangles()
+    Vr, Fr, Cr = ref.extract_mesh()
+    assert len(t) > 1000 and np.array_equal(res[0].view(np.uint8), t.view(np.uint8)), (len(t), len(res[0]))
+    assert np.array_equal(res[1], Vr) and np.array_equal(res[2], Fr) and np.array_equal(res[3], Cr)
+ph = te.comm_phase_times()
+assert ph["allreduce_count"] == 2 * ((2 * world - 1) // 2), ph
+parallel.drop_halo(te)
+te.attach_comm(None)
+# (2) frame-sharded sub-maps -> one tile-sharded map: the union of the owned blocks has the single fusion's occupancy
+fe = pu.make_engine(hip, synth.CFG1, dict(synth.CFG1_PARAMS), 16384, device_id=rank)
+fe.attach_comm(comm)
+for f in frames[2 * rank: 2 * rank + 2]:
+    pu.feed(fe, f)
+info = parallel.merge_submaps(fe, comm, chunk_log2=1)
+d, v = fe.dump_blocks()
+own = parallel.owner_of_blocks(np.stack([d["x"], d["y"], d["z"]], 1), world, 1)
+assert (own == rank).all()
+counts = comm.allgather_i64([len(d), info["sent"], info["received"]])
+se = pu.make_engine(hip, synth.CFG1, dict(synth.CFG1_PARAMS), 16384, device_id=rank)
+for f in frames:
+    pu.feed(se, f)
+ds, vs = se.dump_blocks()
+assert int(counts[:, 0].sum()) == len(ds), (counts.tolist(), len(ds))
+assert int(counts[:, 1].sum()) == int(counts[:, 2].sum()) > 0     # what was sent arrived
+fe.attach_comm(None)
+comm.barrier()
+comm.close()
+open({out!r} + str(rank), "w").write("ok")
+"""
+
+
+def test_rccl_exchanges_between_real_devices(hip, tmp_path):
+    """The grouped ncclSend / ncclRecv of include/mrhash_comm.h between DISTINCT devices — what a one-GPU box cannot run.
+    Un-skips itself where at least two devices are visible: WORLD_SIZE = min(devices, MRH_TEST_WORLD or 8) ranks, rank r on
+    device r; tile-sharded fusion with the starve all-reduce, halo exchange and the gathered mesh == a single context's,
+    byte for byte; frame-sharded sub-maps merged into the single fusion's occupancy."""
+    import os
+    import subprocess
+    import sys
+
+    from mrhash_amd import hipmem
+    from test_sharding import ROOT
+
+    ndev = hipmem.device_count()
+    if ndev < 2:
+        pytest.skip(f"{ndev} HIP device(s) visible: RCCL refuses two ranks on one device")
+    world = min(ndev, int(os.environ.get("MRH_TEST_WORLD", "8")))
+    out = str(tmp_path / "ok")
+    script = tmp_path / "nrank_worker.py"
+    script.write_text(NRANK_WORKER.format(root=ROOT, out=out))
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MRH_RDZV_DIR=str(tmp_path), MRH_RDZV_KEY="pytest_nrank")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=900)[0])
+        except subprocess.TimeoutExpired:
+            p.kill()
+            outs.append("TIMEOUT " + p.communicate()[0])
+    assert all(p.returncode == 0 for p in procs) and all(os.path.exists(out + str(r)) for r in range(world)), "\n----\n".join(o[-2000:] for o in outs)
