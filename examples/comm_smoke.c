@@ -87,8 +87,9 @@ static uint64_t pos_hash(const mrh_block_desc* d) {
   h ^= ((uint64_t) (uint32_t) d->z + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2));
   return h * 0xD6E8FEB86659FD93ull;
 }
+typedef struct { mrh_block_desc d; uint64_t i; } keyed;  /* a block and where its voxels sit in the dump */
 static int cmp_desc(const void* a, const void* b) {
-  const mrh_block_desc *p = (const mrh_block_desc*) a, *q = (const mrh_block_desc*) b;
+  const mrh_block_desc *p = &((const keyed*) a)->d, *q = &((const keyed*) b)->d;
   if (p->x != q->x) return p->x < q->x ? -1 : 1;
   if (p->y != q->y) return p->y < q->y ? -1 : 1;
   if (p->z != q->z) return p->z < q->z ? -1 : 1;
@@ -99,7 +100,7 @@ static int dump(mrh_ctx* ctx, mrh_block_desc** descs, mrh_voxel** vox, uint64_t*
   CHECK(ctx, mrh_dump_blocks(ctx, NULL, NULL, 0, n));
   *descs = (mrh_block_desc*) malloc(sizeof(mrh_block_desc) * (*n + 1));
   *vox = (mrh_voxel*) malloc(sizeof(mrh_voxel) * 512 * (*n + 1));
-  CHECK(ctx, mrh_dump_blocks(ctx, *descs, *vox, *n, n)); /* canonical (x, y, z) order */
+  CHECK(ctx, mrh_dump_blocks(ctx, *descs, *vox, *n, n)); /* in no particular order */
   return 0;
 }
 
@@ -150,7 +151,9 @@ static int run_rank(int rank, int world, const char* id_file) {
   mrh_block_desc* sd; mrh_voxel* sv; uint64_t sn = 0;
   if (dump(single, &sd, &sv, &sn)) return 1;
   uint64_t single_hash = 0;
-  for (uint64_t i = 0; i < sn; i++) single_hash += pos_hash(&sd[i]);
+  keyed* sk = (keyed*) malloc(sizeof(keyed) * (sn + 1));
+  for (uint64_t i = 0; i < sn; i++) { single_hash += pos_hash(&sd[i]); sk[i].d = sd[i]; sk[i].i = i; }
+  qsort(sk, sn, sizeof *sk, cmp_desc);
 
   /* ---- this rank's sub-map */
   mrh_ctx* ctx = NULL;
@@ -174,9 +177,11 @@ static int run_rank(int rank, int world, const char* id_file) {
   double max_d = 0.0;
   for (uint64_t i = 0; i < mn; i++) {
     my_hash += pos_hash(&md[i]);
-    const mrh_block_desc* hit = (const mrh_block_desc*) bsearch(&md[i], sd, sn, sizeof *sd, cmp_desc);
+    keyed probe;
+    probe.d = md[i]; probe.i = 0;
+    const keyed* hit = (const keyed*) bsearch(&probe, sk, sn, sizeof *sk, cmp_desc);
     if (!hit) { missing++; continue; }
-    const mrh_voxel *a = mv + 512 * i, *b = sv + 512 * (uint64_t) (hit - sd);
+    const mrh_voxel *a = mv + 512 * i, *b = sv + 512 * hit->i;
     for (int v = 0; v < 512; v++) {
       bad_w += a[v].weight != b[v].weight;
       bad_c += a[v].weight && memcmp(a[v].rgb, b[v].rgb, 3) != 0;
@@ -220,7 +225,7 @@ static int run_rank(int rank, int world, const char* id_file) {
   mrh_destroy(single);
   CHECKM(comm, mrh_comm_barrier(comm));
   CHECKM(comm, mrh_comm_destroy(comm));
-  free(depth); free(rgb); free(sd); free(sv); free(md); free(mv); free(all);
+  free(depth); free(rgb); free(sd); free(sv); free(sk); free(md); free(mv); free(all);
   SAY("%s", map_ok && mesh_ok ? "PASS" : "FAIL");
   return map_ok && mesh_ok ? 0 : 1;
 }

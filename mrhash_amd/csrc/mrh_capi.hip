@@ -43,6 +43,8 @@
 
 using namespace mrh;
 
+constexpr int kPipeRing = 6;  // = mrh::kListSets: frames in flight + 2
+
 namespace {
 
 thread_local std::string g_create_err;
@@ -175,6 +177,43 @@ struct mrh_ctx {
   Fast fast;              // fast path buffers
   size_t fast_npix = 0;
   uint2* dcx_buf = nullptr;  // {cleaned depth, packed colour} of the current frame (written by k_front)
+  // ---- pipelined frames (integrate_lazy; MRH_PIPE=0 keeps the two serial launches on one stream) ----
+  // The front half of a frame (k_front<..., LAZY>) is launched on `stream_front`, its integration (k_back<..., LZ = 2>) on the
+  // main stream behind one event; the front stream never waits for the main one, so the front half of frame g + 1 runs next to
+  // the integration of frame g.  Up to kPipeRing - 1 frames are in flight, each with its own {depth, colour} image, lists,
+  // list-counter set and want stamps.  Everything that is not a pipelined frame meets the map only after k_reclaim.
+  int pipe = 1;
+  int pipe_period = 32;                     // the reclaim (and one serial frame) every so many pipelined frames; MRH_PIPE_PERIOD
+  hipStream_t stream_front = nullptr;
+  hipEvent_t ev_front[kPipeRing] = {};
+  uint2* pipe_dcx[kPipeRing] = {};
+  size_t pipe_npix = 0;
+  int4* ring_vis[kPipeRing] = {}; int4* ring_bbox[kPipeRing] = {}; int4* ring_cfree[kPipeRing] = {}; float* ring_zmin[kPipeRing] = {};  // [0] = the context's own
+  u32* want_ring = nullptr;                 // kPipeRing x slots stamps
+  int* h_levels = nullptr;                  // pinned {fine free-list level, zombies, sequence number of the last integration that started}
+  uint64_t pipe_seq = 0;                    // frames issued by integrate_lazy (pipelined or not)
+  uint64_t pipe_base = 0;                   // every frame below this sequence number is known complete (host synchronised)
+  int lazy_run = 0;                         // pipelined frames since the last reclaim
+  bool zombies_possible = false;
+  bool last_frame_lazy = false;
+  bool front_needs_sync = false;            // the main stream changed the table / free list behind the front stream's back
+  // the integration of the newest pipelined frame is enqueued by the NEXT mrh_integrate (or by whichever other entry point comes
+  // first): by then its front half has usually finished, the host sees that (hipEventQuery) and the main stream needs no
+  // cross-stream wait in front of the launch — such a wait costs ~6 us of idle main stream per frame on this runtime
+  struct PendingBack {
+    bool on = false;
+    Cam cam;
+    Fast f;
+    Lists L;
+    int set = 0, zero_set = 0, ring = 0, seq = 0;
+    u32 stamp = 0;
+    float thr = 0.f;
+    bool free_ = false, profile = false, safe_div = false, count_zombies = false;
+    EvPair ev = {nullptr, nullptr};
+    uint64_t report_seq = 0;  // frame mark whose pool report was written before this integration ran (refreshed behind it)
+  } pend;
+  uint64_t dbg_waits = 0;
+  double dbg_spin_us = 0, dbg_api_us = 0; uint64_t dbg_lazy_frames = 0;  // MRH_DEBUG: where the host's time in integrate_lazy goes
   int4* d_cfree = nullptr;
   // LiDAR scan of the current frame (mrh_lidar.h)
   float* d_cloud = nullptr; size_t cloud_n = 0;  // spherical camera: getDepth(cloud) image of the current frame (k_cloud_depth)
@@ -322,9 +361,13 @@ void free_all(mrh_ctx* c) {
   (void) hipSetDevice(c->device);
   for (UpRing* r : {&c->up_depth, &c->up_rgb})
     if (r->stream) { (void) hipStreamSynchronize(r->stream); (void) hipStreamDestroy(r->stream); }
+  if (c->stream_front) (void) hipStreamSynchronize(c->stream_front);
   if (c->stream) (void) hipStreamSynchronize(c->stream);
   auto F = [](void* p) { if (p) (void) hipFree(p); };
-  F(c->dcx_buf);
+  F(c->dcx_buf); F(c->want_ring); F(c->fast.zlist);
+  for (int i = 0; i < kPipeRing; i++) { F(c->pipe_dcx[i]); if (i) { F(c->ring_vis[i]); F(c->ring_bbox[i]); F(c->ring_cfree[i]); F(c->ring_zmin[i]); } if (c->ev_front[i]) (void) hipEventDestroy(c->ev_front[i]); }
+  if (c->h_levels) (void) hipHostFree(c->h_levels);
+  if (c->stream_front) { (void) hipStreamSynchronize(c->stream_front); (void) hipStreamDestroy(c->stream_front); }
   F(c->tab.keys); F(c->tab.vals); F(c->tab.heap_fine); F(c->tab.heap_coarse); F(c->tab.desc_fine); F(c->tab.desc_coarse);
   F(c->tab.pool); F(c->tab.compact); F(c->tab.ctr); F(c->tab.prof);
   for (UpRing* r : {&c->up_depth, &c->up_rgb})
@@ -348,6 +391,8 @@ void free_all(mrh_ctx* c) {
   for (auto& e : c->comm_ev_pool) { (void) hipEventDestroy(e.a); (void) hipEventDestroy(e.b); }
   for (auto& e : c->comm_ev_pending) { (void) hipEventDestroy(e.a); (void) hipEventDestroy(e.b); }
   F(c->d_qt_sums); F(c->d_qt_flags); F(c->d_qt_unc); F(c->d_qt_marks); F(c->d_qt_pos); F(c->d_qt_parked); F(c->d_qt_seeds); F(c->d_qt_leaves); F(c->d_qt_misc); F(c->d_qt_tmp);
+  if (c->pend.on && c->pend.profile) c->ev_pool.push_back(c->pend.ev);
+  c->pend.on = false;
   for (auto& e : c->ev_pool) { (void) hipEventDestroy(e.a); (void) hipEventDestroy(e.b); }
   for (auto& e : c->ev_pending) { (void) hipEventDestroy(e.a); (void) hipEventDestroy(e.b); }
   for (auto& e : c->ev_pending_front) { (void) hipEventDestroy(e.a); (void) hipEventDestroy(e.b); }
@@ -361,6 +406,16 @@ int init_buffers(mrh_ctx* c) {
   c->refill_flag_valid = false;
   c->mr_summaries_valid = false;
   c->fast_frames = 0;
+  if (c->stream_front) HIP_TRY(c, hipStreamSynchronize(c->stream_front));
+  if (c->pend.on && c->pend.profile) c->ev_pool.push_back(c->pend.ev);
+  c->pend.on = false;  // a reset map has nothing left to integrate
+  c->pipe_seq = 0;
+  c->pipe_base = 0;
+  c->lazy_run = 0;
+  c->zombies_possible = false;
+  c->front_needs_sync = false;
+  if (c->h_levels) { c->h_levels[0] = (int) c->num_blocks - 1; c->h_levels[1] = 0; c->h_levels[2] = -1; }
+  if (c->want_ring) HIP_TRY(c, hipMemsetAsync(c->want_ring, 0, (size_t) kPipeRing * c->slots * sizeof(u32), s));
   const Tab& t = c->tab;
   k_init_table<<<1024, 256, 0, s>>>(t.keys, c->slots);
   k_init_heap<<<1024, 256, 0, s>>>(t.heap_fine, (u32) c->num_blocks, getenv("MRH_DEBUG_HEAP_DESCENDING") ? 1 : 0);
@@ -453,11 +508,21 @@ int maintain_table(mrh_ctx* c, bool force_census) {
   return MRH_OK;
 }
 
-int ensure_ready(mrh_ctx* c, const char* who) {
+int ensure_device(mrh_ctx* c, const char* who) {
   if (!c) return MRH_ERR_INVALID_ARG;
   hipError_t e = hipSetDevice(c->device);
   if (e != hipSuccess) return fail(c, MRH_ERR_DEVICE, "%s: hipSetDevice failed: %s", who, hipGetErrorString(e));
   return MRH_OK;
+}
+int strict_point(mrh_ctx* c);
+// every entry point except the per-frame ones (setters, mrh_integrate, the non-blocking peeks): behind the pipelined frames issued
+// so far, the zombies nobody wanted leave the table, so that whatever the call reads, changes or waits for is exactly the map two
+// serial launches per frame would have left
+int ensure_ready(mrh_ctx* c, const char* who) {
+  const int rc = ensure_device(c, who);
+  if (rc) return rc;
+  if (c->stream_front) c->front_needs_sync = true;  // whatever this call does to the map, the front stream must see it before its next launch
+  return strict_point(c);
 }
 
 // compacts every live block (no frustum filter) and returns the count; blocking
@@ -948,6 +1013,8 @@ int mrh_create(const mrh_params* p, mrh_ctx** out) {
     const int v = atoi(g);
     if (v > 0 && v <= 32768) c->fused_grid = v;
   }
+  if (const char* g = getenv("MRH_PIPE")) c->pipe = atoi(g) ? 1 : 0;
+  if (const char* g = getenv("MRH_PIPE_PERIOD")) { const int v = atoi(g); if (v > 0) c->pipe_period = v; }
   if (const char* g = getenv("MRH_SWEEP_WGS")) { const int v = atoi(g); if (v > 0 && v <= 4096) c->sweep_wgs = v; }
   if (const char* g = getenv("MRH_MESH_HOST")) c->mesh_on_host = atoi(g) ? 1 : 0;
   if (const char* g = getenv("MRH_QTREE_LITERAL")) c->qt_literal = atoi(g) ? 1 : 0;
@@ -976,6 +1043,9 @@ int mrh_create(const mrh_params* p, mrh_ctx** out) {
 
 int mrh_destroy(mrh_ctx* c) {
   if (!c) return MRH_OK;
+  if (getenv("MRH_DEBUG") && c->dbg_lazy_frames)
+    fprintf(stderr, "[mrhash_hip] pipelined frames %llu: host waited %.1f us per frame for the ring, spent %.1f us per frame in the launch calls, %llu cross-stream waits\n",
+            (unsigned long long) c->dbg_lazy_frames, c->dbg_spin_us / c->dbg_lazy_frames, c->dbg_api_us / c->dbg_lazy_frames, (unsigned long long) c->dbg_waits);
 #ifdef MRH_TRACE
   if (const char* path = getenv("MRH_TRACE_FILE")) {  // tuning builds: phase timestamps of the last k_back launch
     if (c->fast.trace) {
@@ -1194,6 +1264,7 @@ int wait_inputs(mrh_ctx* c) {
   for (UpRing* r : {&c->up_depth, &c->up_rgb})
     if (r->last_copy) {
       HIP_TRY(c, hipStreamWaitEvent(c->stream, r->last_copy, 0));
+      if (c->stream_front) HIP_TRY(c, hipStreamWaitEvent(c->stream_front, r->last_copy, 0));  // pipelined frames read the images there
       r->last_copy = nullptr;
     }
   return MRH_OK;
@@ -1213,15 +1284,17 @@ int mark_frame(mrh_ctx* c) {
   }
   if (!c->frame_done[0])
     for (hipEvent_t& e : c->frame_done) HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  HIP_TRY(c, hipEventRecord(c->frame_done[seq % 8], c->stream));
+  // the raw images of a pipelined frame are read by its front half, on the front stream (its integration reads the cleaned copy)
+  HIP_TRY(c, hipEventRecord(c->frame_done[seq % 8], (c->last_frame_lazy && c->pend.on) ? c->stream_front : c->stream));
   for (UpSlot* u : used) if (u) u->last_seq = seq;
+  if (c->pend.on && c->peek_enabled) c->pend.report_seq = seq;  // written before the deferred integration: refreshed behind it
   return MRH_OK;
 }
 
 }  // namespace
 
 int mrh_upload_depth(mrh_ctx* c, const float* depth, int rows, int cols) {
-  int rc = ensure_ready(c, "mrh_upload_depth");
+  int rc = ensure_device(c, "mrh_upload_depth");
   if (rc) return rc;
   if (!depth || rows <= 0 || cols <= 0) return fail(c, MRH_ERR_INVALID_ARG, "mrh_upload_depth: bad argument");
   const void* dev = nullptr;
@@ -1233,7 +1306,7 @@ int mrh_upload_depth(mrh_ctx* c, const float* depth, int rows, int cols) {
 }
 
 int mrh_upload_rgb(mrh_ctx* c, const uint8_t* rgb, int rows, int cols) {
-  int rc = ensure_ready(c, "mrh_upload_rgb");
+  int rc = ensure_device(c, "mrh_upload_rgb");
   if (rc) return rc;
   if (!rgb || rows <= 0 || cols <= 0) return fail(c, MRH_ERR_INVALID_ARG, "mrh_upload_rgb: bad argument");
   const void* dev = nullptr;
@@ -1262,7 +1335,7 @@ int mrh_set_rgb_device(mrh_ctx* c, const uint8_t* d_rgb, int rows, int cols) {
 static int integrate_frame(mrh_ctx* c, int n_frames_invalidate);
 
 int mrh_integrate(mrh_ctx* c, int n_frames_invalidate) {
-  int rc = ensure_ready(c, "mrh_integrate");
+  int rc = ensure_device(c, "mrh_integrate");
   if (rc) return rc;
   rc = wait_inputs(c);
   if (rc) return rc;
@@ -1271,6 +1344,253 @@ int mrh_integrate(mrh_ctx* c, int n_frames_invalidate) {
   const int mrc = mark_frame(c);
   return mrc ? mrc : rc;
 }
+
+extern "C++" {
+namespace {
+
+int take_event_pair(mrh_ctx* c, EvPair& e) {
+  if (!c->ev_pool.empty()) { e = c->ev_pool.back(); c->ev_pool.pop_back(); return MRH_OK; }
+  if (c->ev_pending.size() >= 4096) {
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const int r = drain_events(c);
+    if (r) return r;
+    e = c->ev_pool.back(); c->ev_pool.pop_back();
+    return MRH_OK;
+  }
+  HIP_TRY(c, hipEventCreate(&e.a)); HIP_TRY(c, hipEventCreate(&e.b));
+  return MRH_OK;
+}
+
+Lists ring_lists(const mrh_ctx* c, const int i) {
+  return Lists{c->ring_vis[i], c->ring_bbox[i], c->ring_cfree[i], c->ring_zmin[i], (u32) c->num_blocks};
+}
+
+// Behind the pipelined frames issued so far (their integrations are all on the main stream, each behind its front half), the
+// zombies nobody wanted leave the table: k_reclaim runs alone on the main stream — the front stream is idle once the last
+// integration has started, and nothing is enqueued on it before the host has seen the main stream drain (front_needs_sync).
+// the integration of the newest pipelined frame, behind its front half
+int launch_pending(mrh_ctx* c) {
+  if (!c->pend.on) return MRH_OK;
+  const mrh_ctx::PendingBack pb = c->pend;
+  c->pend.on = false;
+  hipStream_t s = c->stream;
+  const hipError_t q = hipEventQuery(c->ev_front[pb.ring]);
+  if (q == hipErrorNotReady) {
+    (void) hipGetLastError();
+    HIP_TRY(c, hipStreamWaitEvent(s, c->ev_front[pb.ring], 0));
+    c->dbg_waits++;
+  } else if (q != hipSuccess) {
+    return fail(c, MRH_ERR_DEVICE, "mrh_integrate: front half of a pipelined frame: %s", hipGetErrorString(q));
+  }
+  const Map& m = c->map;
+  const Tab& t = c->tab;
+  const size_t lds = (size_t) 4 * kTileMaxPx * sizeof(uint2);
+  if (pb.profile)  // U and M of the frame (device-side counters of the roofline numerator): after its front half, before its integration
+    k_count_updates<<<c->fused_grid, 256, 0, s>>>(pb.cam, m, t, pb.f, c->d_cnt_partials, CTR_SET0 + 4 * pb.set, pb.L.vis, pb.L.cfree, pb.stamp, pb.count_zombies ? 1 : 0);
+#define MRH_KB(FREE, PROF, SAFE)                                                                                                                      \
+  do {                                                                                                                                                \
+    if (pb.profile) hipExtLaunchKernelGGL((k_back<FREE, PROF, false, SAFE, 2>), dim3(c->fused_grid), dim3(256), (uint32_t) lds, s, pb.ev.a, pb.ev.b, 0u, pb.cam, m, t, pb.f, \
+                                          pb.L, pb.set, pb.zero_set, pb.thr, (const float*) nullptr, (const uint8_t*) nullptr, (u32*) nullptr, pb.stamp, pb.seq); \
+    else k_back<FREE, PROF, false, SAFE, 2><<<c->fused_grid, 256, lds, s>>>(pb.cam, m, t, pb.f, pb.L, pb.set, pb.zero_set, pb.thr, nullptr, nullptr, nullptr, pb.stamp, pb.seq); \
+  } while (0)
+#define MRH_KB2(FREE, PROF) do { if (pb.safe_div) MRH_KB(FREE, PROF, true); else MRH_KB(FREE, PROF, false); } while (0)
+  if (pb.free_ && pb.profile) MRH_KB2(true, true);
+  else if (pb.free_) MRH_KB2(true, false);
+  else MRH_KB2(false, false);
+#undef MRH_KB2
+#undef MRH_KB
+  if (pb.profile) c->ev_pending.push_back(pb.ev);
+  if (pb.free_) c->zombies_possible = true;
+  if (pb.report_seq && c->peek_enabled) {  // the frame's pool report was written before its integration: write it again, behind it
+    k_report<<<1, 64, 0, s>>>(&c->tab.ctr[CTR_HEAP_FINE], c->h_peek + 8 * (pb.report_seq % 8));
+    HIP_TRY(c, hipEventRecord(c->frame_done[pb.report_seq % 8], s));
+  }
+  HIP_TRY(c, hipGetLastError());
+  return MRH_OK;
+}
+
+int strict_point(mrh_ctx* c) {
+  {
+    const int rc = launch_pending(c);
+    if (rc) return rc;
+  }
+  if (!c->zombies_possible) return MRH_OK;
+  k_reclaim<<<64, 256, 0, c->stream>>>(c->tab, c->fast);
+  k_reclaim_done<<<1, 1, 0, c->stream>>>(c->tab);
+  c->zombies_possible = false;
+  c->lazy_run = 0;
+  c->front_needs_sync = true;
+  HIP_TRY(c, hipGetLastError());
+  return MRH_OK;
+}
+
+int ensure_pipe_buffers(mrh_ctx* c, const size_t npix) {
+  if (!c->stream_front) {
+    const size_t cap = c->num_blocks;
+    HIP_TRY(c, hipStreamCreateWithFlags(&c->stream_front, hipStreamNonBlocking));
+    for (hipEvent_t& e : c->ev_front) HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    c->ring_vis[0] = c->tab.compact; c->ring_bbox[0] = c->fast.bbox; c->ring_cfree[0] = c->d_cfree; c->ring_zmin[0] = c->d_zmin;
+    for (int i = 1; i < kPipeRing; i++) {
+      HIP_TRY(c, hipMalloc((void**) &c->ring_vis[i], cap * sizeof(int4)));
+      HIP_TRY(c, hipMalloc((void**) &c->ring_bbox[i], cap * sizeof(int4)));
+      HIP_TRY(c, hipMalloc((void**) &c->ring_cfree[i], cap * sizeof(int4)));
+      HIP_TRY(c, hipMalloc((void**) &c->ring_zmin[i], cap * sizeof(float)));
+    }
+    HIP_TRY(c, hipMalloc((void**) &c->fast.zlist, cap * sizeof(int4)));
+    HIP_TRY(c, hipMalloc((void**) &c->want_ring, (size_t) kPipeRing * c->slots * sizeof(u32)));
+    HIP_TRY(c, hipMemsetAsync(c->want_ring, 0, (size_t) kPipeRing * c->slots * sizeof(u32), c->stream));  // stamps start at 1
+    HIP_TRY(c, hipHostMalloc((void**) &c->h_levels, 4 * sizeof(int), hipHostMallocDefault));
+    c->h_levels[0] = (int) c->num_blocks - 1; c->h_levels[1] = 0; c->h_levels[2] = -1;
+    c->tab.h_levels = c->h_levels;
+    c->front_needs_sync = true;  // the memset above
+  }
+  if (c->pipe_npix < npix) {
+    {
+      const int rc = strict_point(c);  // the pending integration reads the buffers that are about to go
+      if (rc) return rc;
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream_front));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (uint2*& d : c->pipe_dcx) { if (d) HIP_TRY(c, hipFree(d)); d = nullptr; }
+    c->pipe_npix = 0;
+    for (uint2*& d : c->pipe_dcx) HIP_TRY(c, hipMalloc((void**) &d, npix * sizeof(uint2)));
+    c->pipe_npix = npix;
+  }
+  return MRH_OK;
+}
+
+// One single-resolution pinhole frame of a pipelining context.
+//   pipelined: front stream: k_front<LAZY> (+ event) | main stream: wait for that event, k_back<LZ = 2>.  The front stream never
+//              waits for the main one, so this frame's front half runs next to the integration of the frame(s) before it;
+//              the host only holds back when it is kPipeRing - 1 frames ahead of the integration that has started.
+//   serial:    [k_reclaim] -> k_front -> k_back (-> the starve passes), all on the main stream, no zombies anywhere.
+// A serial frame comes after anything else touched the map, every `pipe_period` frames (the reclaim bounds the zombies), on
+// starve frames, and while the pool is short of room: zombies hold their pool slots until the reclaim, so a pool that is
+// nearly full is fused serially — the reference's accounting, exactly.
+int integrate_lazy(mrh_ctx* c, const int max_num_frames, const bool starve_now) {
+  int rc = MRH_OK;
+  hipStream_t s = c->stream;
+  const Cam& k = c->cam;
+  const Map& m = c->map;
+  const Tab& t = c->tab;
+  const size_t npix = (size_t) k.rows * k.cols;
+  rc = ensure_pipe_buffers(c, npix);
+  if (rc) return rc;
+  if (c->fast_summaries_stale) {  // a general frame (spherical camera) ran since: rebuild the GC summaries once
+    rc = strict_point(c);
+    if (rc) return rc;
+    k_summarize_all<<<2048, 256, 0, s>>>(t, c->fast);
+    c->fast_summaries_stale = false;
+    c->front_needs_sync = true;
+  }
+  const int tiles_x = (k.cols + kRayTile - 1) / kRayTile, tiles_y = (k.rows + kRayTile - 1) / kRayTile;
+  const int n_tiles = tiles_x * tiles_y;
+  // room in the pool, as the last integration launch reported it (a few frames old: the margins are generous)
+  const int64_t free_known = (int64_t) ((volatile int*) c->h_levels)[0] + 1, zombies_known = ((volatile int*) c->h_levels)[1];
+  const bool roomy = free_known >= (int64_t) (c->num_blocks / 4) && zombies_known <= (int64_t) (c->num_blocks / 8);
+  const bool lazy = !starve_now && roomy && c->lazy_run < c->pipe_period && !getenv("MRH_PIPE_SERIAL");
+  if (!lazy) {
+    rc = strict_point(c);
+    if (rc) return rc;
+  }
+  const int seq = (int) (c->pipe_seq & 0x3FFFFFFF);
+  const int ring = lazy ? (int) (c->pipe_seq % kPipeRing) : 0;  // a serial frame runs behind everything on the main stream: any slot
+  c->pipe_seq++;                                                // is free for it, and the starve passes walk slot 0's lists
+  const int set = (int) (c->fast_frames % kListSets), zero_set = (set + kListSets - 1) % kListSets;
+  c->frame_parity = set;
+  c->fast_frames++;
+  c->fast.dcx = c->pipe_dcx[ring];
+  c->fast.want = c->want_ring + (size_t) ring * c->slots;
+  const Fast f = c->fast;
+  const u32 stamp = (u32) ((c->frames + 1) & 0x3FFFFFFFu);
+  const float gc_thr = m.trunc + m.trunc_scale * k.max_depth;  // getTruncation(camera.maxDepth(), ...), vds.cu:1720
+  const bool safe_div = m.half_vs_two_steps || m.wsum_two_steps;  // the short divisions failed their check at mrh_create
+  const int gc_on = max_num_frames > 0 ? 1 : 0;
+  c->frame_gc_inline = max_num_frames > 0 && !starve_now;
+  const Lists L = ring_lists(c, ring);
+  const size_t lds = (size_t) 4 * kTileMaxPx * sizeof(uint2);
+  EvPair ev = {nullptr, nullptr}, evf = {nullptr, nullptr};
+  if (c->profile) {
+    rc = take_event_pair(c, evf);
+    if (rc) return rc;
+    rc = take_event_pair(c, ev);
+    if (rc) return rc;
+  }
+  if (lazy) {
+    if (c->front_needs_sync) {  // the main stream erased keys / pushed the free list (reclaim, a serial frame, any other entry
+      HIP_TRY(c, hipStreamSynchronize(s));  // point) after the front stream last looked: the front half must see all of it
+      c->front_needs_sync = false;
+      c->pipe_base = c->pipe_seq - 1;
+    }
+    // ring slot `ring` was last used by frame seq - kPipeRing; its integration is complete once the one after it has started,
+    // and that one has also cleared the list-counter set this frame appends to
+    {
+      const int64_t need = (int64_t) seq - kPipeRing + 2;
+      if (need > (int64_t) c->pipe_base) {
+        const auto t0 = std::chrono::steady_clock::now();
+        while ((int64_t) ((volatile int*) c->h_levels)[2] < need) {
+          MRH_CPU_RELAX();
+          if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(10)) return fail(c, MRH_ERR_DEVICE, "mrh_integrate: the integration of frame %lld never started", (long long) need);
+        }
+        c->dbg_spin_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+      }
+    }
+    c->dbg_lazy_frames++;
+    const auto t_api = std::chrono::steady_clock::now();
+    hipStream_t a = c->stream_front;
+    if (c->profile) hipExtLaunchKernelGGL((k_front<true, false, true>), dim3(n_tiles + c->sweep_wgs), dim3(256), 0, a, evf.a, evf.b, 0u, k, m, t, f, L, c->d_depth, c->d_rgb, tiles_x, n_tiles, stamp,
+                                          set, gc_on, gc_thr, 0, 0, (const int*) nullptr);
+    else k_front<false, false, true><<<n_tiles + c->sweep_wgs, 256, 0, a>>>(k, m, t, f, L, c->d_depth, c->d_rgb, tiles_x, n_tiles, stamp, set, gc_on, gc_thr, 0, 0, nullptr);
+    HIP_TRY(c, hipEventRecord(c->ev_front[ring], a));
+    if (c->profile) c->ev_pending_front.push_back(evf);
+    // the integration of the PREVIOUS pipelined frame goes out now (its front half ran a frame ago: usually no wait), this
+    // frame's is left for the next call
+    const bool zombies_before = c->zombies_possible;
+    rc = launch_pending(c);
+    if (rc) return rc;
+    mrh_ctx::PendingBack& pb = c->pend;
+    pb.on = true;
+    pb.cam = k; pb.f = f; pb.L = L;
+    pb.set = set; pb.zero_set = zero_set; pb.ring = ring; pb.seq = seq; pb.stamp = stamp; pb.thr = gc_thr;
+    pb.free_ = c->frame_gc_inline; pb.profile = c->profile != 0; pb.safe_div = safe_div;
+    pb.count_zombies = zombies_before || c->zombies_possible;
+    pb.ev = ev;
+    pb.report_seq = 0;
+    c->last_frame_lazy = true;
+    c->lazy_run++;
+    c->frames++;  // frame_tail's bookkeeping; nothing else of it applies (GC runs inside the integration)
+    c->dbg_api_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_api).count();
+    HIP_TRY(c, hipGetLastError());
+    return MRH_OK;
+  }
+  // ---- serial frame, all on the main stream (strict_point above has flushed and reclaimed)
+  c->last_frame_lazy = false;
+  if (c->profile) hipExtLaunchKernelGGL((k_front<true, false, false>), dim3(n_tiles + c->sweep_wgs), dim3(256), 0, s, evf.a, evf.b, 0u, k, m, t, f, L, c->d_depth, c->d_rgb, tiles_x, n_tiles, stamp,
+                                        set, gc_on, gc_thr, 0, 0, (const int*) nullptr);
+  else k_front<false, false, false><<<n_tiles + c->sweep_wgs, 256, 0, s>>>(k, m, t, f, L, c->d_depth, c->d_rgb, tiles_x, n_tiles, stamp, set, gc_on, gc_thr, 0, 0, nullptr);
+  if (c->profile) {
+    c->ev_pending_front.push_back(evf);
+    k_count_updates<<<c->fused_grid, 256, 0, s>>>(k, m, t, f, c->d_cnt_partials, CTR_SET0 + 4 * set, L.vis, L.cfree, stamp, 0);
+  }
+#define MRH_KB(FREE, PROF, SAFE)                                                                                                                      \
+  do {                                                                                                                                                \
+    if (c->profile) hipExtLaunchKernelGGL((k_back<FREE, PROF, false, SAFE, 0>), dim3(c->fused_grid), dim3(256), (uint32_t) lds, s, ev.a, ev.b, 0u, k, m, t, f, L, \
+                                          set, zero_set, gc_thr, (const float*) nullptr, (const uint8_t*) nullptr, (u32*) nullptr, stamp, seq);        \
+    else k_back<FREE, PROF, false, SAFE, 0><<<c->fused_grid, 256, lds, s>>>(k, m, t, f, L, set, zero_set, gc_thr, nullptr, nullptr, nullptr, stamp, seq); \
+  } while (0)
+#define MRH_KB2(FREE, PROF) do { if (safe_div) MRH_KB(FREE, PROF, true); else MRH_KB(FREE, PROF, false); } while (0)
+  if (c->frame_gc_inline && c->profile) MRH_KB2(true, true);
+  else if (c->frame_gc_inline) MRH_KB2(true, false);
+  else MRH_KB2(false, false);
+#undef MRH_KB2
+#undef MRH_KB
+  c->front_needs_sync = true;  // direct frees on the main stream
+  if (c->profile) c->ev_pending.push_back(ev);
+  return starve_and_tail(c, max_num_frames);
+}
+
+}  // namespace
+}  // extern "C++"
 
 static int integrate_frame(mrh_ctx* c, int n_frames_invalidate) {
   int rc = MRH_OK;
@@ -1291,6 +1611,11 @@ static int integrate_frame(mrh_ctx* c, int n_frames_invalidate) {
   hipStream_t s = c->stream;
   const Tab& t = c->tab;
   const Map& m = c->map;
+  // the table upkeep rebuilds from the descriptors: the zombies of the pipelined frames leave first
+  if (c->zombies_possible && c->census_period >= 0 && (c->table_dirty || c->frames_since_census >= (uint64_t) c->census_period)) {
+    rc = strict_point(c);
+    if (rc) return rc;
+  }
   rc = maintain_table(c, false);
   if (rc) return rc;
   c->frames_since_census++;
@@ -1309,6 +1634,12 @@ static int integrate_frame(mrh_ctx* c, int n_frames_invalidate) {
     c->mr_next_general = starve_now || c->frames == 0;
     c->refill_flag_valid = false;
   }
+  const bool pipe_frame = c->pipe && !c->frame_general && !t.multi_res;
+  if (!pipe_frame) {  // a frame of another kind follows pipelined ones
+    rc = strict_point(c);
+    if (rc) return rc;
+  }
+  if (pipe_frame) return integrate_lazy(c, max_num_frames, starve_now);
   if (!c->frame_general) {
     // ---- fast path: alloc + sweep -> fused integrate / summary / GC (mrh_fast2.h)
     if (!t.multi_res && c->fast_summaries_stale) {  // a general frame (spherical camera) ran since: rebuild the GC summaries once
@@ -1326,7 +1657,7 @@ static int integrate_frame(mrh_ctx* c, int n_frames_invalidate) {
     }
     c->fast.dcx = c->dcx_buf;
     const Fast& f = c->fast;
-    const int parity = (int) (c->fast_frames & 1);
+    const int parity = (int) (c->fast_frames % kListSets), zero_set = (parity + kListSets - 1) % kListSets;  // the frame's list-counter set, and the one to clear
     c->frame_parity = parity;
     c->fast_frames++;
     const u32 stamp = (u32) ((c->frames + 1) & 0x3FFFFFFFu);
@@ -1347,8 +1678,8 @@ static int integrate_frame(mrh_ctx* c, int n_frames_invalidate) {
       const int n_refill = (c->low_blocks_to_allocate + 255) / 256;
       k_front<false, true><<<n_tiles + c->sweep_wgs_mr + n_refill, 256, 0, s>>>(k, m, t, f, L, c->d_depth, c->d_rgb, tiles_x, n_tiles, stamp, parity, 1, gc_thr,
                                                                                    n_refill, c->low_blocks_to_allocate, c->d_flag);
-      if (safe_div) k_back<true, false, true, true><<<c->fused_grid, 256, lds, s>>>(k, m, t, f, L, parity, gc_thr, c->d_depth, c->d_rgb, (u32*) c->d_reint);
-      else k_back<true, false, true, false><<<c->fused_grid, 256, lds, s>>>(k, m, t, f, L, parity, gc_thr, c->d_depth, c->d_rgb, (u32*) c->d_reint);
+      if (safe_div) k_back<true, false, true, true><<<c->fused_grid, 256, lds, s>>>(k, m, t, f, L, parity, zero_set, gc_thr, c->d_depth, c->d_rgb, (u32*) c->d_reint, 0u, 0);
+      else k_back<true, false, true, false><<<c->fused_grid, 256, lds, s>>>(k, m, t, f, L, parity, zero_set, gc_thr, c->d_depth, c->d_rgb, (u32*) c->d_reint, 0u, 0);
       k_mr_tail<<<1, 256, 0, s>>>(t, (const u32*) c->d_reint, c->low_blocks_to_allocate, c->d_flag);
       rc = starve_and_tail(c, max_num_frames);
       c->refill_flag_valid = rc == MRH_OK;
@@ -1379,7 +1710,7 @@ static int integrate_frame(mrh_ctx* c, int n_frames_invalidate) {
     else k_front<false, false><<<n_tiles + c->sweep_wgs, 256, 0, s>>>(k, m, t, f, L, c->d_depth, c->d_rgb, tiles_x, n_tiles, stamp, parity, max_num_frames > 0 ? 1 : 0, gc_thr, 0, 0, nullptr);
     EvPair ev;
     if (c->profile) {
-      k_count_updates<<<c->fused_grid, 256, 0, s>>>(k, m, t, f, c->d_cnt_partials, CTR_SET0 + 4 * parity);
+      k_count_updates<<<c->fused_grid, 256, 0, s>>>(k, m, t, f, c->d_cnt_partials, CTR_SET0 + 4 * parity, L.vis, L.cfree, 0u, 0);
       rc = take_events(ev);
       if (rc) return rc;
     }
@@ -1389,8 +1720,8 @@ static int integrate_frame(mrh_ctx* c, int n_frames_invalidate) {
 #define MRH_K_BACK_V(FREE, PROF, SAFE)                                                                                                   \
   do {                                                                                                                                   \
     if (c->profile) hipExtLaunchKernelGGL((k_back<FREE, PROF, false, SAFE>), dim3(c->fused_grid), dim3(256), (uint32_t) lds, s, ev.a, ev.b, 0u, k, m, t, f, L,   \
-                                          parity, gc_thr, (const float*) nullptr, (const uint8_t*) nullptr, (u32*) nullptr);              \
-    else k_back<FREE, PROF, false, SAFE><<<c->fused_grid, 256, lds, s>>>(k, m, t, f, L, parity, gc_thr, nullptr, nullptr, nullptr);        \
+                                          parity, zero_set, gc_thr, (const float*) nullptr, (const uint8_t*) nullptr, (u32*) nullptr, 0u, 0);  \
+    else k_back<FREE, PROF, false, SAFE><<<c->fused_grid, 256, lds, s>>>(k, m, t, f, L, parity, zero_set, gc_thr, nullptr, nullptr, nullptr, 0u, 0); \
   } while (0)
 #define MRH_K_BACK(FREE, PROF) do { if (safe_div) MRH_K_BACK_V(FREE, PROF, true); else MRH_K_BACK_V(FREE, PROF, false); } while (0)
     if (c->frame_gc_inline && c->profile) MRH_K_BACK(true, true);
@@ -1573,6 +1904,11 @@ int mrh_integrate_points(mrh_ctx* c, int n_frames_invalidate) {
   const Cam& k = c->cam;
   const Map& m = c->map;
   const Tab& t = c->tab;
+  // the table upkeep rebuilds from the descriptors: the zombies of the pipelined frames leave first
+  if (c->zombies_possible && c->census_period >= 0 && (c->table_dirty || c->frames_since_census >= (uint64_t) c->census_period)) {
+    rc = strict_point(c);
+    if (rc) return rc;
+  }
   rc = maintain_table(c, false);
   if (rc) return rc;
   c->frames_since_census++;
@@ -1860,7 +2196,7 @@ int mrh_get_free_blocks(mrh_ctx* c, int64_t* out_free_fine, int64_t* out_free_co
 }
 
 int mrh_peek_free_blocks(mrh_ctx* c, int64_t* out_free_fine, int64_t* out_free_coarse, uint64_t* out_frames_behind) {
-  int rc = ensure_ready(c, "mrh_peek_free_blocks");
+  int rc = ensure_device(c, "mrh_peek_free_blocks");
   if (rc) return rc;
   if (!c->peek_enabled) {  // first call: reports start with the next frame; answer this one the blocking way
     HIP_TRY(c, hipHostMalloc((void**) &c->h_peek, 64 * sizeof(int), hipHostMallocDefault));
@@ -1884,7 +2220,7 @@ int mrh_peek_free_blocks(mrh_ctx* c, int64_t* out_free_fine, int64_t* out_free_c
 }
 
 int mrh_peek_error_flags(mrh_ctx* c, uint32_t* out_new_flags) {
-  int rc = ensure_ready(c, "mrh_peek_error_flags");
+  int rc = ensure_device(c, "mrh_peek_error_flags");
   if (rc) return rc;
   if (!out_new_flags) return MRH_ERR_INVALID_ARG;
   *out_new_flags = 0;
@@ -1910,7 +2246,8 @@ int mrh_peek_error_flags(mrh_ctx* c, uint32_t* out_new_flags) {
 }
 
 int mrh_set_profile(mrh_ctx* c, int enabled) {
-  if (!c) return MRH_ERR_INVALID_ARG;
+  int rc = ensure_ready(c, "mrh_set_profile");
+  if (rc) return rc;
   c->profile = enabled ? 1 : 0;
   return MRH_OK;
 }
@@ -1945,6 +2282,7 @@ int mrh_get_stats(mrh_ctx* c, mrh_stats* out) {
   out->free_fine = (int64_t) h_ctr[CTR_HEAP_FINE] + 1;
   out->free_coarse = (int64_t) h_ctr[CTR_HEAP_COARSE] + 1;
   out->last_compact_blocks = (uint64_t) h_ctr[CTR_COMPACT] + (fastp ? (uint64_t) h_ctr[CTR_CULLED] + (uint64_t) h_ctr[CTR_FREED_EARLY] : 0);
+  if (fastp && c->h_levels && out->last_compact_blocks >= (uint64_t) h_ctr[CTR_ZSKIP]) out->last_compact_blocks -= (uint64_t) h_ctr[CTR_ZSKIP];  // list entries that were unwanted zombies
   out->total_updated_voxels = total_upd;
   out->last_updated_voxels = total_upd - c->prev_total_updated;
   out->last_inserted_blocks = h_prof[PROF_INSERTED] - c->prev_inserted;
@@ -2390,6 +2728,10 @@ int mrh_set_sharding(mrh_ctx* c, int shard_rank, int shard_count, int shard_chun
   if (!c) return MRH_ERR_INVALID_ARG;
   if (shard_count < 1 || shard_rank < 0 || shard_rank >= shard_count) return fail(c, MRH_ERR_INVALID_ARG, "mrh_set_sharding: rank %d of %d", shard_rank, shard_count);
   if (c->pending) return fail(c, MRH_ERR_STATE, "mrh_set_sharding: an exchange is pending (call mrh_integrate_resume)");
+  {
+    const int frc = ensure_ready(c, "mrh_set_sharding");  // the last pipelined frame is integrated under the ownership it was allocated with
+    if (frc) return frc;
+  }
   c->p.shard_rank = shard_rank; c->p.shard_count = shard_count; c->p.shard_chunk_log2 = shard_chunk_log2;
   c->map.shard_rank = shard_rank;
   c->map.shard_count = shard_count;

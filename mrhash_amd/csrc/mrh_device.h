@@ -53,13 +53,15 @@ enum Ctr : int {
   // 12, 13: CTR_CULLED, CTR_FREED_EARLY (mrh_fast.h)
   CTR_REHASH = 14,       // decision of the last census: 1 = rebuild the table from the dense descriptors
   CTR_ORPHANS = 15,      // keys published without storage since the last rebuild (kValNone)
-  // 16..23: the two list-counter sets of the two-launch fast path (mrh_fast2.h)
   CTR_NREHASH = 24,      // table rebuilds since create / reset
   CTR_HALO = 25,         // halo blocks imported from other shards (mrh_halo_import), dropped by mrh_halo_drop
   CTR_MAXPROBE = 26,     // longest probe path of a live key (filled by k_count_live for mrh_get_stats)
   CTR_TOMBS_NOW = 27,    // census accumulator
   CTR_PACK = 28,         // blocks selected by k_halo_select / k_owner_select
-  CTR_COUNT = 32
+  CTR_ZOMBIES = 29,      // entries on the zombie list (mrh_fast2.h: lazy garbage collection of pipelined frames)
+  CTR_ZSKIP = 30,        // list entries of the frame being integrated that turned out to be unwanted zombies (not blocks of that frame)
+  // 32..55: the six list-counter sets of the fast path (mrh_fast2.h)
+  CTR_COUNT = 56
 };
 // 64-bit profile counters
 enum Prof : int { PROF_UPDATED = 0, PROF_INSERTED = 1, PROF_FREED = 2, PROF_COMPACT = 3, PROF_COUNT = 4 };
@@ -113,6 +115,7 @@ struct Tab {
   u64* prof;
   u32 cap_blocks;
   u32 multi_res;  // 1 when sdf_var_threshold > 0
+  int* h_levels;  // pinned host memory {fine free-list level, zombies} written by the integration launch of a pipelining context (else nullptr)
 };
 
 // ---- scalar helpers -----------------------------------------------------------------------------

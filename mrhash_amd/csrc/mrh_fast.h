@@ -23,6 +23,9 @@ struct Fast {
   u32 compact_cap;     // entries in Tab::compact
   int4* bbox;          // [compact_cap] per VISIBLE compact entry: pixel footprint {col0, row0, w, h}; w == 0: none
   uint2* summary_c;    // [8 * cap_blocks] the same summary per COARSE unit (multi-resolution maps only)
+  u32* want;           // [hash slots] stamp of the last frame whose rays found this slot's key in the table (pipelined frames,
+                       // mrh_fast2.h: decides whether a block that the previous frame's garbage collection emptied lives on)
+  int4* zlist;         // [cap_blocks] blocks emptied by a pipelined frame's garbage collection and not yet taken out of the table
 #ifdef MRH_TRACE
   u64* trace;          // [compact_cap * 8] per-block phase timestamps of the last k_back launch (tuning builds only)
 #endif
@@ -285,15 +288,27 @@ __device__ __forceinline__ void tile_lookup(const Fast& f, const int cols, const
 // profile mode only: U = voxels the next k_back launch will write (the predicate depends on pose, depth image and
 // block list only, not on voxel contents), M = compact blocks.  Runs outside the timed bracket.
 __global__ __launch_bounds__(256) void k_count_updates(const Cam c, const Map m, const Tab t, const Fast f, u64* __restrict__ partials,
-                                                       const int merged_set) {
+                                                       const int merged_set, const int4* __restrict__ vis, const int4* __restrict__ cfree, const u32 want_stamp, const int zombies) {
   // merged_set >= 0: list counters of the two-launch path live at ctr[merged_set .. merged_set + 2]
+  // zombies: entries of blocks the previous (pipelined) frame's GC emptied may be on the list (mrh_fast2.h); the ones this
+  // frame's rays do not want are not blocks of this frame — neither updated nor counted
   const int nvis = merged_set >= 0 ? t.ctr[merged_set] : t.ctr[CTR_COMPACT];
   const int lane = threadIdx.x & 63;
   const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int nw = gridDim.x * 4;
-  u32 cnt = 0;
+  u32 cnt = 0, zskip = 0, zcul = 0;
   for (int e = gw; e < nvis; e += nw) {
-    const int4 ent = t.compact[e];
+    const int4 ent = vis[e];
+    if (zombies && (f.summary[ent.w].y & 0x80000000u)) {
+      int wanted = 0;
+      if (lane == 0) {
+        u64 key;
+        pack_key(mki3(ent.x, ent.y, ent.z), key);
+        const int slot = hash_find(t, key);
+        wanted = (slot >= 0 && f.want[slot] == want_stamp) ? 1 : 0;
+      }
+      if (!__builtin_amdgcn_readfirstlane(wanted)) { zskip++; continue; }
+    }
 #pragma unroll
     for (int b = 0; b < 2; b++) {
       const Proj4 P = project4(c, m, ent, lane + 64 * b);
@@ -303,12 +318,27 @@ __global__ __launch_bounds__(256) void k_count_updates(const Cam c, const Map m,
       cnt += __popc(update_mask4(c, m, P, d));
     }
   }
+  if (zombies && merged_set >= 0) {  // the same for the culled list (all candidates: one lane each)
+    const int ncf = t.ctr[merged_set + 2];
+    for (int e = gw * 64 + lane; e < ncf; e += nw * 64) {
+      const int4 ent = cfree[e];
+      if (f.summary[ent.w].y & 0x80000000u) {
+        u64 key;
+        pack_key(mki3(ent.x, ent.y, ent.z), key);
+        const int slot = hash_find(t, key);
+        if (!(slot >= 0 && f.want[slot] == want_stamp)) zcul++;
+      }
+    }
+    for (int off = 32; off > 0; off >>= 1) zcul += __shfl_xor(zcul, off);
+    zskip += zcul;  // zskip (visible list) is wave-uniform, zcul was per lane
+  }
   for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
   if (lane == 0) {
     partials[gw] += (u64) cnt;
+    if (zskip) atomicAdd((unsigned long long*) &t.prof[PROF_COMPACT], (unsigned long long) (0ull - (u64) zskip));  // modular: taken off the frame's M
     if (gw == 0)
-      t.prof[PROF_COMPACT] += merged_set >= 0 ? (u64) (nvis + t.ctr[merged_set + 1] + t.ctr[merged_set + 2])
-                                              : (u64) (nvis + t.ctr[CTR_CULLED] + t.ctr[CTR_FREED_EARLY]);
+      atomicAdd((unsigned long long*) &t.prof[PROF_COMPACT], merged_set >= 0 ? (unsigned long long) (nvis + t.ctr[merged_set + 1] + t.ctr[merged_set + 2])
+                                                                             : (unsigned long long) (nvis + t.ctr[CTR_CULLED] + t.ctr[CTR_FREED_EARLY]));
   }
 }
 

@@ -12,8 +12,8 @@
 //   k_back    one wave per visible block:   depth->TSDF integration + GC summary + GC decision + free;
 //             then the same waves free the CULLED-FREE list.  This launch only PUSHES the fine free list.
 //
-// List counters are double-buffered by frame parity: k_front(f) appends to set f&1, k_back(f) reads it and zeroes
-// set (f+1)&1 for the next frame, so no reset launch or memset is needed.
+// List counters rotate over six sets: k_front(f) appends to set f % 6, k_back(f) reads it and zeroes set (f - 1) % 6, so no
+// reset launch or memset is needed (six, not two: a pipelining context keeps up to four frames in flight).
 // Reference mapping: allocBlocksKernel vds.cu:758-857, flatAndReduceHashTableKernel :406-434, integrateDepthMapKernel
 // :1095-1181, garbageCollectIdentify/Free :1674-1713 / :1827-1844 — four+ launches with host round trips there.
 #pragma once
@@ -22,9 +22,13 @@
 
 namespace mrh {
 
-// counter slots (ints) inside Tab::ctr for the two list sets
-constexpr int CTR_SET0 = 16;       // set p lives at CTR_SET0 + 4 * p: {n_visible, n_culled_kept, n_culled_free, unused}
-constexpr int kCtrTotal = 32;
+// counter slots (ints) inside Tab::ctr for the SIX list sets: frame g appends to set g % 6; the launch that integrates frame g
+// reads it and zeroes set (g - 1) % 6 — the set of the frame before it, whose integration is complete (stream order) and whose
+// next user, frame g + 5, is not enqueued before this launch is known to have started (integrate_lazy's throttle)
+constexpr int CTR_SET0 = 32;       // set p lives at CTR_SET0 + 4 * p: {n_visible, n_culled_kept, n_culled_free, unused}
+constexpr int kListSets = 6;       // = frames a pipelining context keeps in flight + 2 (kPipeRing)
+constexpr u32 kZombieBit = 0x80000000u;  // in Fast::summary[H].y: the block was emptied by a pipelined frame's garbage collection
+                                         // and still sits in the table (pipelined frames)
 
 struct Lists {
   int4* vis;        // = Tab::compact (front)
@@ -60,39 +64,30 @@ __device__ __forceinline__ int commit_block(const Tab& t, const Fast& f, const i
   return (int) H;
 }
 
-// Allocation for one 16x16 pixel tile (allocBlocksKernel vds.cu:758-857 for these pixels).
-// Also writes the cleaned depth / packed colour of its pixels (calculateCloudKernel's validity rule, camera.cu:13-18).
-template <bool PROFILE>
-__device__ __forceinline__ void front_tile(const Cam& c, const Map& m, const Tab& t, const Fast& f, const Lists& L,
-                                           const float* __restrict__ depth, const uint8_t* __restrict__ rgb, const int tiles_x,
-                                           const int tile_id, const u32 stamp, const int cs, FrontShared& sh) {
+// Rays of one 16x16 pixel tile (allocBlocksKernel vds.cu:758-857 up to the insert): distinct keys of the traversed blocks in
+// sh.list[0, sh.count).  Also writes the cleaned depth / packed colour of its pixels (calculateCloudKernel's validity rule,
+// camera.cu:13-18).  Returns true for a lane whose pixel needs the literal walk (LDS set saturated by far, sparse rays; keys
+// out of range): the caller re-walks it with walk_ray.  Ends with the workgroup barrier that completes the list.
+__device__ __forceinline__ bool tile_rays(const Cam& c, const Map& m, uint2* __restrict__ dcx, const float* __restrict__ depth,
+                                          const uint8_t* __restrict__ rgb, const int tiles_x, const int tile_id, FrontShared& sh, float& d_out) {
   constexpr int NT = 256;
   const int tid = threadIdx.x;
-  const int hwm0 = t.ctr[CTR_HWM_FINE];  // scalar load, before any store of this launch
   for (int i = tid; i < kRayCap; i += NT) sh.set[i] = kKeyEmpty;
   if (tid == 0) { sh.count = 0; sh.inserted = 0; }
   __syncthreads();
-  MRH_TSF(1);
-  // a new block is listed without a pixel footprint (k_back derives it): a few hundred blocks per frame, not
-  // worth 8 serial corner projections on the allocation workgroup's critical path.  If no voxel of it lands in the
-  // image it stays at weight 0 and is collected, exactly what GC does with it in the reference.
-  auto list_new = [&](const int4 ent) {  // single lane
-    const int li = atomicAdd(&t.ctr[cs + 0], 1);
-    L.vis[li] = ent;
-    L.bbox[li] = make_int4(0, 0, 0, 0);
-  };
   const int ty = tile_id / tiles_x, tx = tile_id - ty * tiles_x;
   const int row = ty * kRayTile + (tid >> 4), col = tx * kRayTile + (tid & 15);
+  bool slow = false;
+  d_out = 0.f;
   if (row < c.rows && col < c.cols) {
     const size_t pix = (size_t) row * c.cols + col;
     float d = depth[pix];
     if (d <= c.min_depth || d > c.max_depth) d = 0.f;  // camera.cu:13-18
+    d_out = d;
     const uint8_t* px = rgb + pix * 3;
-    f.dcx[pix] = make_uint2(__float_as_uint(d), (u32) px[0] | ((u32) px[1] << 8) | ((u32) px[2] << 16));
-    // hot path: keys into the LDS set; anything rare (set saturated by far, sparse rays; keys out of range) is left to
-    // the literal walk below, outside the loop every lane runs
+    dcx[pix] = make_uint2(__float_as_uint(d), (u32) px[0] | ((u32) px[1] << 8) | ((u32) px[2] << 16));
+    // hot path: keys into the LDS set; anything rare is left to the literal walk, outside the loop every lane runs
     const RayState ray = ray_setup(c, m, row, col, d);
-    bool slow = false;
     if (ray.valid) {
       if (!ray_keys_in_range(ray)) {
         slow = true;
@@ -111,68 +106,112 @@ __device__ __forceinline__ void front_tile(const Cam& c, const Map& m, const Tab
         });
       }
     }
-    if (slow) {
-      walk_ray(c, m, t, row, col, d, [&](const i3 cur, const u64 key) {  // direct insert of every block of this ray
-        if (!block_in_frustum_approx(c, m.vs, cur)) return;
-        const int slot = hash_insert(t, key);
-        if (slot == -2) atomicOr((u32*) &t.ctr[CTR_ERROR], ERR_TABLE);
-        if (slot < 0) return;
-        const int H = commit_block(t, f, slot, atomicSub(&t.ctr[CTR_HEAP_FINE], 1), cur, stamp, hwm0);
-        if (H < 0) return;
-        list_new(make_int4(cur.x, cur.y, cur.z, H));
-        if (PROFILE) atomicAdd(&t.prof[PROF_INSERTED], 1ull);
-      });
+  }
+  __syncthreads();
+  return slow;
+}
+
+// the literal walk of one pixel with a direct insert of every block of its ray (the rare path of a tile)
+template <bool PROFILE, bool MARK>
+__device__ __forceinline__ void tile_slow_pixel(const Cam& c, const Map& m, const Tab& t, const Fast& f, const Lists& L, const int row, const int col,
+                                                const float d, const u32 stamp, const int cs, const int hwm0) {
+  walk_ray(c, m, t, row, col, d, [&](const i3 cur, const u64 key) {
+    if (MARK) {  // a block that is in the table is wanted by this frame (pipelined frames)
+      const int s0 = hash_find(t, key);
+      if (s0 >= 0) { f.want[s0] = stamp; return; }
+    }
+    if (!block_in_frustum_approx(c, m.vs, cur)) return;
+    const int slot = hash_insert(t, key);
+    if (slot == -2) atomicOr((u32*) &t.ctr[CTR_ERROR], ERR_TABLE);
+    if (slot < 0) return;
+    const int H = commit_block(t, f, slot, atomicSub(&t.ctr[CTR_HEAP_FINE], 1), cur, stamp, hwm0);
+    if (H < 0) return;
+    // listed without a pixel footprint (k_back derives it)
+    const int li = atomicAdd(&t.ctr[cs + 0], 1);
+    L.vis[li] = make_int4(cur.x, cur.y, cur.z, H);
+    L.bbox[li] = make_int4(0, 0, 0, 0);
+    if (PROFILE) atomicAdd(&t.prof[PROF_INSERTED], 1ull);
+  });
+}
+
+// Probe + insert of up to 64 distinct keys of a tile by one wave (`key` = kKeyEmpty on idle lanes): one probe per key
+// (hash_find_claim also remembers where an insert would land) -> frustum test -> one CAS on the remembered slot -> free-list
+// pop wave-aggregated, list append issued together with the read of the popped entries.  Returns the blocks this lane inserted.
+template <bool MARK>
+__device__ __forceinline__ u32 wave_insert_keys(const Cam& c, const Map& m, const Tab& t, const Fast& f, const Lists& L, const u64 key,
+                                                const u32 stamp, const int cs, const int hwm0) {
+  const bool active = key != kKeyEmpty;
+  const i3 b = active ? unpack_key(key) : mki3(0, 0, 0);
+  bool won = false;
+  int slot = -1;
+  // probe first: ~95 % of a tile's blocks already exist, and for those neither the 8-corner frustum test nor
+  // the insert protocol is needed
+  int claim;
+  u64 claim_val;
+  if (active) {
+    const int found = hash_find_claim(t, key, claim, claim_val);
+    if (found >= 0) {
+      // pipelined frames: an earlier frame's garbage collection runs next to this probe and may be emptying this very block; it then
+      // stays in the table, and whether it lives on is decided by this mark: "frame `stamp` has a ray through it"
+      if (MARK) f.want[found] = stamp;
+    } else if (block_in_frustum_approx(c, m.vs, b)) {
+      slot = hash_insert_at(t, key, claim, claim_val);
+      if (slot == -2) atomicOr((u32*) &t.ctr[CTR_ERROR], ERR_TABLE);
+      won = slot >= 0;
     }
   }
-  MRH_TSF(2);
-  __syncthreads();
+  // wave-aggregated pop of the fine free list and append to the list
+  const u64 ballot = __ballot(won);
+  u32 inserted = 0;
+  if (ballot) {
+    const int leader = __ffsll((long long) ballot) - 1;
+    int hb = 0;
+    if ((int) lane_id() == leader) hb = atomicSub(&t.ctr[CTR_HEAP_FINE], __popcll(ballot));
+    hb = __shfl(hb, leader);
+    // the pop decides who got a block (index >= 0); the list append is then issued together with the read of the
+    // popped stack entries, so the two round trips overlap
+    const int hidx = hb - __popcll(ballot & lanemask_lt());
+    const u64 ok = __ballot(won && hidx >= 0);
+    int lb = 0;
+    if (ok && (int) lane_id() == __ffsll((long long) ok) - 1) lb = atomicAdd(&t.ctr[cs + 0], __popcll(ok));
+    int H = -1;
+    if (won) H = commit_block(t, f, slot, hidx, b, stamp, hwm0);
+    if (ok) {
+      const int lead2 = __ffsll((long long) ok) - 1;
+      lb = __shfl(lb, lead2);
+      if (H >= 0) {
+        const int idx = lb + __popcll(ok & lanemask_lt());
+        L.vis[idx] = make_int4(b.x, b.y, b.z, H);
+        L.bbox[idx] = make_int4(0, 0, 0, 0);  // k_back derives footprint and zmin itself
+        inserted = 1;
+      }
+    }
+  }
+  return inserted;
+}
+
+// Allocation for one 16x16 pixel tile in ONE launch (k_front): rays, then probe / insert of the tile's keys.
+template <bool PROFILE, bool MARK>
+__device__ __forceinline__ void front_tile(const Cam& c, const Map& m, const Tab& t, const Fast& f, const Lists& L,
+                                           const float* __restrict__ depth, const uint8_t* __restrict__ rgb, const int tiles_x,
+                                           const int tile_id, const u32 stamp, const int cs, FrontShared& sh) {
+  constexpr int NT = 256;
+  const int tid = threadIdx.x;
+  const int hwm0 = t.ctr[CTR_HWM_FINE];  // scalar load, before any store of this launch
+  MRH_TSF(1);
+  float d;
+  const bool slow = tile_rays(c, m, f.dcx, depth, rgb, tiles_x, tile_id, sh, d);
   MRH_TSF(3);
+  if (slow) {
+    const int ty = tile_id / tiles_x, tx = tile_id - ty * tiles_x;
+    tile_slow_pixel<PROFILE, MARK>(c, m, t, f, L, ty * kRayTile + (tid >> 4), tx * kRayTile + (tid & 15), d, stamp, cs, hwm0);
+  }
   const int n = (int) sh.count;
   u32 my_inserted = 0;
 #pragma unroll 1
   for (int base = 0; base < n; base += NT) {
     const int i = base + tid;
-    const bool active = i < n;
-    const u64 key = active ? sh.list[i] : kKeyEmpty;
-    const i3 b = active ? unpack_key(key) : mki3(0, 0, 0);
-    bool won = false;
-    int slot = -1;
-    // probe first: ~95 % of a tile's blocks already exist, and for those neither the 8-corner frustum test nor
-    // the insert protocol is needed
-    int claim;
-    u64 claim_val;
-    if (active && hash_find_claim(t, key, claim, claim_val) < 0 && block_in_frustum_approx(c, m.vs, b)) {
-      slot = hash_insert_at(t, key, claim, claim_val);
-      if (slot == -2) atomicOr((u32*) &t.ctr[CTR_ERROR], ERR_TABLE);
-      won = slot >= 0;
-    }
-    // wave-aggregated pop of the fine free list and append to the list
-    const u64 ballot = __ballot(won);
-    if (ballot) {
-      const int leader = __ffsll((long long) ballot) - 1;
-      int hb = 0;
-      if ((int) lane_id() == leader) hb = atomicSub(&t.ctr[CTR_HEAP_FINE], __popcll(ballot));
-      hb = __shfl(hb, leader);
-      // the pop decides who got a block (index >= 0); the list append is then issued together with the read of the
-      // popped stack entries, so the two round trips overlap
-      const int hidx = hb - __popcll(ballot & lanemask_lt());
-      const u64 ok = __ballot(won && hidx >= 0);
-      int lb = 0;
-      if (ok && (int) lane_id() == __ffsll((long long) ok) - 1) lb = atomicAdd(&t.ctr[cs + 0], __popcll(ok));
-      int H = -1;
-      if (won) H = commit_block(t, f, slot, hidx, b, stamp, hwm0);
-      if (ok) {
-        const int lead2 = __ffsll((long long) ok) - 1;
-        lb = __shfl(lb, lead2);
-        if (H >= 0) {
-          const int idx = lb + __popcll(ok & lanemask_lt());
-          const int4 ent = make_int4(b.x, b.y, b.z, H);
-          L.vis[idx] = ent;
-          L.bbox[idx] = make_int4(0, 0, 0, 0);  // k_back derives footprint and zmin itself
-          if (PROFILE) my_inserted++;
-        }
-      }
-    }
+    my_inserted += wave_insert_keys<MARK>(c, m, t, f, L, i < n ? sh.list[i] : kKeyEmpty, stamp, cs, hwm0);
   }
   MRH_TSF(4);
 #ifdef MRH_TRACE
@@ -198,7 +237,9 @@ __device__ __forceinline__ void front_tile(const Cam& c, const Map& m, const Tab
 // (~3 atomics x 1250 batches per frame) is bound by exactly that.  Each sweep workgroup therefore owns one
 // contiguous chunk of descriptors, stages its results in LDS (aliasing the key set / list of the allocation role)
 // and publishes them with three atomics per workgroup.
-template <bool MULTI>
+// DEFER (pipelined frames): the previous frame's integration runs next to this sweep, so the stored summaries are not final: every culled
+// block goes on the culled list as a CANDIDATE and the launch that integrates this frame decides from the then-final summary.
+template <bool MULTI, bool DEFER = false>
 __device__ __forceinline__ void front_sweep(const Cam& c, const Map& m, const Tab& t, const Fast& f, const Lists& L, const u32 stamp,
                                             const int cs, const int gc_on, const float trunc_threshold, const int sw, const int n_sweep,
                                             FrontShared& sh) {
@@ -289,7 +330,7 @@ __device__ __forceinline__ void front_sweep(const Cam& c, const Map& m, const Ta
         } else {
           bool collect = false;
           if (gc_on) {  // culled: untouched by this frame, so the stored summary already decides (vds.cu:1708-1711)
-            collect = (__uint_as_float(sm.x) >= trunc_threshold) || (sm.y == 0u);
+            collect = DEFER || (__uint_as_float(sm.x) >= trunc_threshold) || (sm.y == 0u);
           }
           if (collect) st_free[atomicAdd(&sh.nfree, 1)] = e;
           else atomicAdd(&sh.nkeep, 1);
@@ -327,20 +368,22 @@ __device__ __forceinline__ void front_refill(const Tab& t, const int low_blocks_
   for (int idx = 1; idx <= 8; idx++) t.heap_coarse[addr_low + idx] = H * 8 + 8 - idx;
 }
 
-template <bool PROFILE, bool MULTI>
+// LAZY (pipelined frames, see k_back<..., LZ = 2>): the launch may run next to the integration of earlier frames on another
+// stream: its probes stamp Fast::want for every key they find, its sweep leaves the culled decisions to the integration.
+template <bool PROFILE, bool MULTI, bool LAZY = false>
 __global__ __launch_bounds__(256) void k_front(const Cam c, const Map m, const Tab t, const Fast f, const Lists L,
                                                const float* __restrict__ depth, const uint8_t* __restrict__ rgb, const int tiles_x,
-                                               const int n_tiles, const u32 stamp, const int parity, const int gc_on,
+                                               const int n_tiles, const u32 stamp, const int set, const int gc_on,
                                                const float trunc_threshold, const int n_refill, const int low_blocks_to_allocate,
                                                const int* __restrict__ refill_flag) {
   __shared__ FrontShared sh;
-  const int cs = CTR_SET0 + 4 * parity;
+  const int cs = CTR_SET0 + 4 * set;
   // grid = [sweep | tiles | refill]: the sweep workgroups come FIRST so that they start first
   const int n_sweep = (int) gridDim.x - n_tiles - n_refill;
   MRH_TSF(0);
   if (MULTI && (int) blockIdx.x >= n_sweep + n_tiles) front_refill(t, low_blocks_to_allocate, refill_flag, (int) blockIdx.x - n_sweep - n_tiles);
-  else if ((int) blockIdx.x >= n_sweep) front_tile<PROFILE>(c, m, t, f, L, depth, rgb, tiles_x, (int) blockIdx.x - n_sweep, stamp, cs, sh);
-  else front_sweep<MULTI>(c, m, t, f, L, stamp, cs, gc_on, trunc_threshold, (int) blockIdx.x, n_sweep, sh);
+  else if ((int) blockIdx.x >= n_sweep) front_tile<PROFILE, LAZY>(c, m, t, f, L, depth, rgb, tiles_x, (int) blockIdx.x - n_sweep, stamp, cs, sh);
+  else front_sweep<MULTI, LAZY>(c, m, t, f, L, stamp, cs, gc_on, trunc_threshold, (int) blockIdx.x, n_sweep, sh);
 }
 
 // pixel footprint of a block computed by the wave that is about to integrate it (lanes 0..7 take one corner each):
@@ -471,11 +514,52 @@ __device__ __forceinline__ bool variance_says_coarsen(const Map& m, const uint2*
 //   MULTI multi-resolution map: entries may be coarse units; a fine block is variance-checked right after its update
 //         and, if the reference would coarsen it, converted on the spot (checkVarSDF -> reallocBlocks ->
 //         reintegrateDepthMap, vds.cu:1857-2107): same table slot, new coarse unit, fine slot zeroed and released
-template <bool FREE, bool PROFILE, bool MULTI, bool SAFEDIV>
+// ---- lazy garbage collection of pipelined frames ---------------------------------------------------------------------
+// A pipelining context (mrh_capi.hip: integrate_lazy) launches the FRONT half of frame g + 1 (k_front<..., LAZY>: rays, probes,
+// inserts, sweep) on a second stream, where it runs next to the integration of frame g (k_back<..., LZ = 2>) — and possibly of
+// frame g - 1 — instead of behind it.  A block that a frame's garbage collection empties can therefore not leave the table in
+// that launch: erasing a key would break the invariant the lock-free insert rests on (an occupied slot stays occupied while
+// inserts run), pushing the free list would race with the pops, and the probes of the later frame could not tell "still
+// there" from "gone".  Instead such a block becomes a ZOMBIE: payload zeroed (as a freed block's is), summary {FLT_MAX,
+// kZombieBit}, key, descriptor and pool slot kept.  In the reference the block is gone after frame g and comes back — empty —
+// iff a ray of a later frame crosses it inside that frame's approx frustum (allocBlocksKernel); here the rays of every frame
+// stamp Fast::want[slot] (one array per frame in flight) of every key they FIND, and whoever meets the zombie on a frame's
+// lists checks that frame's stamp: wanted -> it IS that fresh block (zero payload, nothing to insert), not wanted -> it is not
+// a block of that frame and is skipped.  Which pool slot a block occupies is not observable, so "freed and re-inserted" and
+// "emptied and kept" are the same map.  Zombies that nobody wants are taken out of the table by k_reclaim, which runs alone
+// (every few frames, and before anything that is not a pipelined frame looks at the map).  The two halves exchange nothing
+// inside a launch: every hand-over (lists, stamps, summaries) crosses a kernel boundary and a stream dependency.
+__device__ __forceinline__ void wave_zombify(const Tab& t, const Fast& f, const int4 ent, const int lane) {
+  const u32 H = (u32) ent.w;
+  if (lane == 0) {
+    f.summary[H] = make_uint2(0x7F7FFFFFu, kZombieBit);
+    f.zlist[atomicAdd(&t.ctr[CTR_ZOMBIES], 1)] = ent;
+  }
+  uint4* p = (uint4*) (t.pool + (size_t) H * kFineBytes);
+  const uint4 z = make_uint4(0, 0, 0, 0);
+#pragma unroll
+  for (int k = 0; k < kFineBytes / 16 / kWave; k++) p[k * kWave + lane] = z;
+}
+// is the zombie behind list entry `ent` wanted by the frame with stamp `want_stamp`?  (wave-uniform; lane 0 walks the table)
+__device__ __forceinline__ bool zombie_wanted(const Tab& t, const Fast& f, const int4 ent, const u32 want_stamp, const int lane) {
+  int wanted = 0;
+  if (lane == 0) {
+    u64 key;
+    pack_key(mki3(ent.x, ent.y, ent.z), key);
+    const int slot = hash_find(t, key);
+    wanted = (slot >= 0 && f.want[slot] == want_stamp) ? 1 : 0;
+  }
+  return __builtin_amdgcn_readfirstlane(wanted) != 0;
+}
+
+// LZ: 0 = no zombies can exist (strict launches of contexts that never pipeline); 1 = zombie-aware, collected blocks are freed
+// on the spot (a launch that runs alone); 2 = zombie-aware, collected blocks become zombies (pipelined frames)
+template <bool FREE, bool PROFILE, bool MULTI, bool SAFEDIV, int LZ = 0>
 __device__ __forceinline__ void back_range(const Cam& c, const Map& m, const Tab& t, const Fast& f, const Lists& L,
                                            const float trunc_threshold, const int n, const int gw, const int nw, const int lane,
                                            uint2* tile, const float* __restrict__ depth_raw, const uint8_t* __restrict__ rgb_raw,
-                                           u32* __restrict__ deferred) {
+                                           u32* __restrict__ deferred, const u32 want_stamp = 0) {
+  static_assert(!(MULTI && LZ), "multi-resolution maps are not pipelined");
   for (int e = __builtin_amdgcn_readfirstlane(gw); e < n; e += nw) {
     MRH_TS(0);
     int4 ent, bb;
@@ -493,6 +577,8 @@ __device__ __forceinline__ void back_range(const Cam& c, const Map& m, const Tab
     float4* ps = (float4*) (t.pool + (size_t) H * kFineBytes);
     float4* pq = ps + 128;
     uint4* pw = (uint4*) (ps + 256);
+    uint2 sm0 = make_uint2(0u, 0u);
+    if (LZ) sm0 = f.summary[H];  // requested first: it is needed first (zombie?), and loads return in order
     float4 S[2];
     uint4 W[2];
 #pragma unroll
@@ -511,6 +597,16 @@ __device__ __forceinline__ void back_range(const Cam& c, const Map& m, const Tab
     tile_issue(c, f, bb, lane, tr);  // footprint gathers in flight behind the voxel planes ...
 #pragma unroll
     for (int b = 0; b < 2; b++) P[b] = project4(c, m, ent, lane + 64 * b);  // ... while the projections (entry-only) run
+    if (LZ && (sm0.y & kZombieBit)) {  // wave-uniform; rare
+      if (!zombie_wanted(t, f, ent, want_stamp, lane)) {  // emptied by the previous frame's GC and no ray of this frame crosses it:
+        if (lane == 0) atomicAdd(&t.ctr[CTR_ZSKIP], 1);   // not a block of this frame (the sweep listed it by its descriptor)
+        continue;
+      }
+      // wanted: this IS the block allocBlocksKernel would have inserted for this frame — empty payload, fresh summary
+      sm0 = make_uint2(0x7F7FFFFFu, 0u);
+      if (lane == 0) f.summary[H] = sm0;
+      if (PROFILE && lane == 0) atomicAdd(&t.prof[PROF_INSERTED], 1ull);
+    }
     const float reach = tile_commit(c, m, f, bb, lane, tile, tr);
     // Early out (exact): camera-frame z is monotone in each voxel coordinate under fp32 rounding, so every voxel of
     // the block has pc.z >= zmin (the smallest corner value); every in-image voxel projects into the footprint
@@ -524,7 +620,7 @@ __device__ __forceinline__ void back_range(const Cam& c, const Map& m, const Tab
     u32 trace_upd = 0;
 #endif
     if (skip) {
-      const uint2 sm = f.summary[H];
+      const uint2 sm = LZ ? sm0 : f.summary[H];
       mn = __uint_as_float(sm.x);
       mx = sm.y;
     } else {
@@ -634,7 +730,8 @@ __device__ __forceinline__ void back_range(const Cam& c, const Map& m, const Tab
       if (lane == 0) f.summary[H] = make_uint2(__float_as_uint(mn), mx);
     }
     if (FREE && (mn >= trunc_threshold || mx == 0)) {
-      wave_free_block(t, ent, lane);
+      if (LZ == 2) wave_zombify(t, f, ent, lane);
+      else wave_free_block(t, ent, lane);
       if (PROFILE && lane == 0) atomicAdd(&t.prof[PROF_FREED], 1ull);
     }
     MRH_TS(6);
@@ -655,10 +752,48 @@ __device__ __forceinline__ void free_range(const Tab& t, const Lists& L, const i
     if (PROFILE && lane == 0) atomicAdd(&t.prof[PROF_FREED], 1ull);
   }
 }
+// The culled list of a pipelined frame holds CANDIDATES (front_sweep<DEFER>): every culled block, undecided.  One lane per
+// candidate reads the now-final summary (vds.cu:1708-1711), the wave then empties the blocks to collect one after the other.
+// A zombie on the list is not a block of this frame (no voxel of a culled block can be updated: wanted or not, the reference
+// would have inserted it empty and collected it again).
+template <bool PROFILE, int LZ>
+__device__ __forceinline__ void free_candidates(const Tab& t, const Fast& f, const Lists& L, const float trunc_threshold, const int n, const int gw,
+                                                const int nw, const int lane, const u32 want_stamp) {
+  for (int base = gw * kWave; base < n; base += nw * kWave) {
+    const int e = base + lane;
+    int4 ent = make_int4(0, 0, 0, 0);
+    bool collect = false;
+    if (e < n) {
+      ent = L.cfree[e];
+      const uint2 sm = f.summary[ent.w];
+      collect = !(sm.y & kZombieBit) && ((__uint_as_float(sm.x) >= trunc_threshold) || (sm.y == 0u));
+      if (sm.y & kZombieBit) {  // counted as a block of this frame only if its rays want it (the frame's M, mrh_get_stats)
+        u64 key;
+        pack_key(mki3(ent.x, ent.y, ent.z), key);
+        const int slot = hash_find(t, key);
+        if (!(slot >= 0 && f.want[slot] == want_stamp)) atomicAdd(&t.ctr[CTR_ZSKIP], 1);
+      }
+    }
+    u64 todo = __ballot(collect);
+    if (PROFILE && todo && lane == 0) atomicAdd(&t.prof[PROF_FREED], (u64) __popcll(todo));
+    while (todo) {
+      const int src = __ffsll((long long) todo) - 1;
+      todo &= todo - 1;
+      const int4 b = make_int4(__shfl(ent.x, src), __shfl(ent.y, src), __shfl(ent.z, src), __shfl(ent.w, src));
+      if (LZ == 2) wave_zombify(t, f, b, lane);
+      else wave_free_block(t, b, lane);
+    }
+  }
+}
 
-// end of a frame: the other parity's counters are zeroed for the next frame's appends; stats mirror for the host
-__device__ __forceinline__ void frame_epilogue(const Tab& t, const int parity, const int n_integrated, const int n_culled, const int lane) {
-  if (lane < 4) t.ctr[CTR_SET0 + 4 * (parity ^ 1) + lane] = 0;
+// end of a frame: the counters of set `zero_set` are zeroed for a later frame's appends; stats mirror for the host
+__device__ __forceinline__ void frame_epilogue(const Tab& t, const int zero_set, const int n_integrated, const int n_culled, const int lane, const int seq) {
+  if (lane < 4) t.ctr[CTR_SET0 + 4 * zero_set + lane] = 0;
+  if (lane == 0 && t.h_levels) {  // for the host's choice of the next launch (pinned memory): pool level and zombie count as this
+    t.h_levels[0] = t.ctr[CTR_HEAP_FINE];  // launch found them, and the sequence number of the frame whose integration has now
+    t.h_levels[1] = t.ctr[CTR_ZOMBIES];    // STARTED — every earlier integration is complete, its buffers are free
+    t.h_levels[2] = seq;
+  }
   if (lane == 0) {
     t.ctr[CTR_COMPACT] = n_integrated;  // M = visible + culled
     t.ctr[CTR_CULLED] = n_culled;
@@ -666,27 +801,61 @@ __device__ __forceinline__ void frame_epilogue(const Tab& t, const int parity, c
   }
 }
 
-// ---- two-launch path: K2 = integrate + summary + GC of the visible list, then the culled-free list -------------
-template <bool FREE, bool PROFILE, bool MULTI, bool SAFEDIV>
-__global__ __launch_bounds__(256) void k_back(const Cam c, const Map m, const Tab t, const Fast f, const Lists L, const int parity,
-                                              const float trunc_threshold, const float* __restrict__ depth_raw,
-                                              const uint8_t* __restrict__ rgb_raw, u32* __restrict__ deferred) {
-  extern __shared__ __attribute__((aligned(16))) uint2 s_tile[];
-  const int cs = CTR_SET0 + 4 * parity;
-  const int lane = threadIdx.x & 63;
-  const int wpw = blockDim.x >> 6;
-  const int gw = blockIdx.x * wpw + (threadIdx.x >> 6);
-  const int nw = gridDim.x * wpw;
+// ---- K2 = integrate + summary + GC of the visible list, then the culled-free list -------------
+// `gw` of `nw` waves; `tile`: this wave's LDS pixel tile; `set`: the frame's list-counter set, `zero_set`: the one to clear
+template <bool FREE, bool PROFILE, bool MULTI, bool SAFEDIV, int LZ = 0>
+__device__ __forceinline__ void back_role(const Cam& c, const Map& m, const Tab& t, const Fast& f, const Lists& L, const int set, const int zero_set,
+                                          const float trunc_threshold, const float* __restrict__ depth_raw, const uint8_t* __restrict__ rgb_raw,
+                                          u32* __restrict__ deferred, const int gw, const int nw, const int lane, uint2* tile, const u32 want_stamp = 0,
+                                          const int seq = 0) {
+  const int cs = CTR_SET0 + 4 * set;
   // the counters are read (scalar loads) BEFORE wave 0 stores to the counter array: a load after those stores would
   // have to be a vector load with a full memory round trip at the head of every wave
   const int nvis = t.ctr[cs + 0];
   const int ncfree = FREE ? t.ctr[cs + 2] : 0;
   const int nkept = t.ctr[cs + 1];
-  if (gw == 0) frame_epilogue(t, parity, nvis, nkept + t.ctr[cs + 2], lane);
-  uint2* tile = &s_tile[(threadIdx.x >> 6) * kTileMaxPx];
-  back_range<FREE, PROFILE, MULTI, SAFEDIV>(c, m, t, f, L, trunc_threshold, nvis, gw, nw, lane, tile, depth_raw, rgb_raw, deferred);
-  if (FREE) free_range<PROFILE, MULTI>(t, L, ncfree, gw, nw, lane, deferred);
+  if (gw == 0) frame_epilogue(t, zero_set, nvis, nkept + t.ctr[cs + 2], lane, seq);
+  back_range<FREE, PROFILE, MULTI, SAFEDIV, LZ>(c, m, t, f, L, trunc_threshold, nvis, gw, nw, lane, tile, depth_raw, rgb_raw, deferred, want_stamp);
+  if (FREE) {
+    // a zombie-aware launch takes every culled-list entry as a candidate: the list may come from a sweep that could not decide
+    // (front_sweep<DEFER>), and for one that did decide the then-stable summary gives the same answer again
+    if (LZ) free_candidates<PROFILE, LZ>(t, f, L, trunc_threshold, ncfree, gw, nw, lane, want_stamp);
+    else free_range<PROFILE, MULTI>(t, L, ncfree, gw, nw, lane, deferred);
+  }
 }
+
+// LZ = 2: the integration of a pipelined frame (zombies on its lists: `want_stamp` = the stamp of ITS frame; its culled list
+// holds candidates; what it collects becomes a zombie).  LZ = 1: the same reading, collected blocks freed on the spot.
+// `seq`: the frame's sequence number in a pipelining context (reported to the host through Tab::h_levels).
+template <bool FREE, bool PROFILE, bool MULTI, bool SAFEDIV, int LZ = 0>
+__global__ __launch_bounds__(256) void k_back(const Cam c, const Map m, const Tab t, const Fast f, const Lists L, const int set, const int zero_set,
+                                              const float trunc_threshold, const float* __restrict__ depth_raw,
+                                              const uint8_t* __restrict__ rgb_raw, u32* __restrict__ deferred, const u32 want_stamp, const int seq) {
+  extern __shared__ __attribute__((aligned(16))) uint2 s_tile[];
+  const int wpw = blockDim.x >> 6;
+  back_role<FREE, PROFILE, MULTI, SAFEDIV, LZ>(c, m, t, f, L, set, zero_set, trunc_threshold, depth_raw, rgb_raw, deferred, blockIdx.x * wpw + (threadIdx.x >> 6),
+                                               gridDim.x * wpw, threadIdx.x & 63, &s_tile[(threadIdx.x >> 6) * kTileMaxPx], want_stamp, seq);
+}
+
+// Takes the zombies nobody wanted out of the table (deleteHashEntryElement + the free-list push that their garbage collection
+// left out).  Runs ALONE on the stream — no probe, insert or pop next to it.  A block on the list twice (emptied, wanted,
+// emptied again) or one that lives again (wanted: its summary was rewritten) is recognised by the flag, cleared atomically.
+__global__ __launch_bounds__(256) void k_reclaim(const Tab t, const Fast f) {
+  const int n = t.ctr[CTR_ZOMBIES];
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
+    const int4 ent = f.zlist[e];
+    const u32 H = (u32) ent.w;
+    const u32 old = atomicAnd(&f.summary[H].y, ~kZombieBit);
+    if (!(old & kZombieBit)) continue;
+    u64 key;
+    pack_key(mki3(ent.x, ent.y, ent.z), key);
+    hash_erase(t, key);
+    const int idx = atomicAdd(&t.ctr[CTR_HEAP_FINE], 1);
+    t.heap_fine[idx + 1] = H;  // vds.cu:53-57
+    t.desc_fine[H].w = 0;
+  }
+}
+__global__ void k_reclaim_done(const Tab t) { t.ctr[CTR_ZOMBIES] = 0; }
 
 // after a multi-resolution k_back: the coarse units freed during the launch go onto the coarse free list, and the
 // refill test of the NEXT frame (vds.cu:885-891: coarse list below low_blocks_to_allocate?) is taken here, on the final
@@ -751,8 +920,8 @@ __global__ __launch_bounds__(256) void k_summarize_all(const Tab t, const Fast f
 }
 
 // starve frames: GC after the weights changed — visible list by refreshed summary, plus the culled-free list
-__global__ __launch_bounds__(256) void k_free_lists(const Tab t, const Fast f, const Lists L, const int parity, const float trunc_threshold) {
-  const int cs = CTR_SET0 + 4 * parity;
+__global__ __launch_bounds__(256) void k_free_lists(const Tab t, const Fast f, const Lists L, const int set, const float trunc_threshold) {
+  const int cs = CTR_SET0 + 4 * set;
   const int nvis = t.ctr[cs + 0], ncfree = t.ctr[cs + 2];
   const int lane = threadIdx.x & 63;
   const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
