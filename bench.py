@@ -514,6 +514,23 @@ def bench_single(args):
     # ---- pass B: same frames, HIP events around every integrate-kernel launch + device-side U/M counters
     roof = profiled_roofline(eng, res, W, total, "configs[1] (value's workload)")
     eng.close()
+    roof["schedule"] = ("pipelined, as in the timed region: the front half of frame g + 1 (k_front, second stream) runs next to this kernel, "
+                        "so its duration includes the share of the machine it gives away; `serial` = the same kernel with MRH_PIPE=0 "
+                        "(two serial launches per frame: the kernel alone on the chip)")
+    if os.environ.get("MRH_PIPE", "1") != "0":
+        os.environ["MRH_PIPE"] = "0"
+        try:
+            se0 = make_engine(hip, params, Kc)
+        finally:
+            del os.environ["MRH_PIPE"]
+        rs = profiled_roofline(se0, res, W, total, "configs[1], serial launches")
+        se0.close()
+        roof["serial"] = {k: rs[k] for k in ("achieved", "frac", "kernel_ms_avg", "k_front_ms_avg", "algorithmic_bytes_per_launch", "launches", "profiled_pass_ms_per_step")}
+    # the whole frame against the same roof: integrate bytes + what the front half moves (4 B depth + 3 B colour read and 8 B written per
+    # pixel, 24 B per descriptor swept) over the frame time of the timed region
+    frame_bytes = roof["algorithmic_bytes_per_launch"] + 15.0 * Kc.rows * Kc.cols + 24.0 * occupied
+    roof["frame"] = {"algorithmic_bytes_per_frame": frame_bytes, "achieved": frame_bytes / (elapsed / K) / 1e9, "frac": frame_bytes / (elapsed / K) / 1e9 / HBM_PEAK_GBS,
+                     "note": "k_back's algorithmic bytes + 15 B per pixel (front half: 7 read, 8 written) + 24 B per live block (descriptor sweep) over ms_per_step"}
     roof["cache_note"] = "the per-frame working set sits inside the 256 MiB Infinity Cache between frames: see roofline_hbm for the same kernel outside it"
 
     # ---- the same kernel with a working set above the Infinity Cache

@@ -65,7 +65,8 @@ struct UpRing {
   UpSlot s[3];
   int cur = -1;                 // slot holding the current image; -1: none, or a caller's device pointer
   hipStream_t stream = nullptr; // this ring's copy stream
-  hipEvent_t last_copy = nullptr;  // newest copy event of this ring the main stream has not waited for yet
+  hipEvent_t last_copy = nullptr;  // newest copy event of this ring
+  bool waited[2] = {false, false}; // ... has been waited for by {main, front} stream
 };
 
 // Host result buffer of the blocking calls (triangle soup, V / F / C): grow-only, never zero-filled, PINNED.
@@ -150,7 +151,7 @@ struct mrh_ctx {
   // device buffer — on a second stream, so the copy of frame N+1 overlaps the kernels of frame N; the frame's kernels
   // wait for the newest copy event, a slot is rewritten only after the last frame that read it (frame_done event).
   UpRing up_depth, up_rgb;
-  bool copy_ready = false;             // copy streams and frame marks exist
+  bool copy_ready = false;             // copy stream and frame marks exist
   hipEvent_t frame_done[8] = {};       // recorded on the main stream after every frame that read ring slots / when peeks are on
   uint64_t frame_seq = 1;
   // pool level for the host without a read-back stall (mrh_peek_free_blocks): a 2-int D2H per frame into pinned memory
@@ -183,6 +184,7 @@ struct mrh_ctx {
   // the integration of frame g.  Up to kPipeRing - 1 frames are in flight, each with its own {depth, colour} image, lists,
   // list-counter set and want stamps.  Everything that is not a pipelined frame meets the map only after k_reclaim.
   int pipe = 1;
+  int pipe_uploads = 0;                     // MRH_PIPE_UPLOADS=1: pipeline frames whose images came through mrh_upload_* too
   int pipe_period = 32;                     // the reclaim (and one serial frame) every so many pipelined frames; MRH_PIPE_PERIOD
   hipStream_t stream_front = nullptr;
   hipEvent_t ev_front[kPipeRing] = {};
@@ -196,6 +198,8 @@ struct mrh_ctx {
   int lazy_run = 0;                         // pipelined frames since the last reclaim
   bool zombies_possible = false;
   bool last_frame_lazy = false;
+  bool flushed_since_frame = false;          // an entry point other than the per-frame ones ran since the last frame
+  int sync_streak = 0;
   bool front_needs_sync = false;            // the main stream changed the table / free list behind the front stream's back
   // the integration of the newest pipelined frame is enqueued by the NEXT mrh_integrate (or by whichever other entry point comes
   // first): by then its front half has usually finished, the host sees that (hipEventQuery) and the main stream needs no
@@ -522,6 +526,7 @@ int ensure_ready(mrh_ctx* c, const char* who) {
   const int rc = ensure_device(c, who);
   if (rc) return rc;
   if (c->stream_front) c->front_needs_sync = true;  // whatever this call does to the map, the front stream must see it before its next launch
+  c->flushed_since_frame = true;
   return strict_point(c);
 }
 
@@ -1014,6 +1019,7 @@ int mrh_create(const mrh_params* p, mrh_ctx** out) {
     if (v > 0 && v <= 32768) c->fused_grid = v;
   }
   if (const char* g = getenv("MRH_PIPE")) c->pipe = atoi(g) ? 1 : 0;
+  if (const char* g = getenv("MRH_PIPE_UPLOADS")) c->pipe_uploads = atoi(g) ? 1 : 0;
   if (const char* g = getenv("MRH_PIPE_PERIOD")) { const int v = atoi(g); if (v > 0) c->pipe_period = v; }
   if (const char* g = getenv("MRH_SWEEP_WGS")) { const int v = atoi(g); if (v > 0 && v <= 4096) c->sweep_wgs = v; }
   if (const char* g = getenv("MRH_MESH_HOST")) c->mesh_on_host = atoi(g) ? 1 : 0;
@@ -1254,18 +1260,20 @@ int upload_image(mrh_ctx* c, UpRing& ring, const void* src, const size_t bytes, 
   u.copied_rec = true;
   u.last_seq = 0;
   ring.last_copy = u.copied;  // a ring's copies are ordered on its stream: the newest event covers the earlier ones
+  ring.waited[0] = ring.waited[1] = false;
   ring.cur = next;
   *out_dev = u.d;
   return MRH_OK;
 }
 
-// before kernels that read the images: the main stream waits for the newest upload
-int wait_inputs(mrh_ctx* c) {
+// before kernels that read the images: `reader` — the stream those kernels are launched on: the front stream for a pipelined
+// frame (its integration reads the cleaned copy the front half wrote), the main stream otherwise — waits for the newest uploads
+int send_uploads(mrh_ctx* c, hipStream_t reader) {
+  const int w = (reader == c->stream) ? 0 : 1;
   for (UpRing* r : {&c->up_depth, &c->up_rgb})
-    if (r->last_copy) {
-      HIP_TRY(c, hipStreamWaitEvent(c->stream, r->last_copy, 0));
-      if (c->stream_front) HIP_TRY(c, hipStreamWaitEvent(c->stream_front, r->last_copy, 0));  // pipelined frames read the images there
-      r->last_copy = nullptr;
+    if (r->last_copy && !r->waited[w]) {
+      HIP_TRY(c, hipStreamWaitEvent(reader, r->last_copy, 0));
+      r->waited[w] = true;
     }
   return MRH_OK;
 }
@@ -1337,8 +1345,6 @@ static int integrate_frame(mrh_ctx* c, int n_frames_invalidate);
 int mrh_integrate(mrh_ctx* c, int n_frames_invalidate) {
   int rc = ensure_device(c, "mrh_integrate");
   if (rc) return rc;
-  rc = wait_inputs(c);
-  if (rc) return rc;
   rc = integrate_frame(c, n_frames_invalidate);
   if (rc < 0) return rc;
   const int mrc = mark_frame(c);
@@ -1369,7 +1375,7 @@ Lists ring_lists(const mrh_ctx* c, const int i) {
 // zombies nobody wanted leave the table: k_reclaim runs alone on the main stream — the front stream is idle once the last
 // integration has started, and nothing is enqueued on it before the host has seen the main stream drain (front_needs_sync).
 // the integration of the newest pipelined frame, behind its front half
-int launch_pending(mrh_ctx* c) {
+int launch_pending(mrh_ctx* c, const bool count_skips = false) {
   if (!c->pend.on) return MRH_OK;
   const mrh_ctx::PendingBack pb = c->pend;
   c->pend.on = false;
@@ -1385,6 +1391,7 @@ int launch_pending(mrh_ctx* c) {
   const Map& m = c->map;
   const Tab& t = c->tab;
   const size_t lds = (size_t) 4 * kTileMaxPx * sizeof(uint2);
+  if (count_skips) HIP_TRY(c, hipMemsetAsync(&c->tab.ctr[CTR_ZSKIP], 0, sizeof(int), s));  // mrh_get_stats: M of the last frame, exactly
   if (pb.profile)  // U and M of the frame (device-side counters of the roofline numerator): after its front half, before its integration
     k_count_updates<<<c->fused_grid, 256, 0, s>>>(pb.cam, m, t, pb.f, c->d_cnt_partials, CTR_SET0 + 4 * pb.set, pb.L.vis, pb.L.cfree, pb.stamp, pb.count_zombies ? 1 : 0);
 #define MRH_KB(FREE, PROF, SAFE)                                                                                                                      \
@@ -1411,7 +1418,7 @@ int launch_pending(mrh_ctx* c) {
 
 int strict_point(mrh_ctx* c) {
   {
-    const int rc = launch_pending(c);
+    const int rc = launch_pending(c, true);
     if (rc) return rc;
   }
   if (!c->zombies_possible) return MRH_OK;
@@ -1488,11 +1495,24 @@ int integrate_lazy(mrh_ctx* c, const int max_num_frames, const bool starve_now) 
   // room in the pool, as the last integration launch reported it (a few frames old: the margins are generous)
   const int64_t free_known = (int64_t) ((volatile int*) c->h_levels)[0] + 1, zombies_known = ((volatile int*) c->h_levels)[1];
   const bool roomy = free_known >= (int64_t) (c->num_blocks / 4) && zombies_known <= (int64_t) (c->num_blocks / 8);
-  const bool lazy = !starve_now && roomy && c->lazy_run < c->pipe_period && !getenv("MRH_PIPE_SERIAL");
+  // a caller that synchronises (or asks for statistics, a mesh, ...) after EVERY frame gains nothing from the pipeline and would pay
+  // for its flush each time: three frames in a row that found the pipeline flushed switch to serial frames, the first frame that
+  // follows another frame directly switches back
+  c->sync_streak = c->flushed_since_frame ? c->sync_streak + 1 : 0;
+  c->flushed_since_frame = false;
+  // images that come from the host (mrh_upload_*) make the frame loop host- and link-bound (staging copy + 2.15 MB over PCIe: ~60 us
+  // per frame at 640x480 against ~40 us of GPU work): nothing to gain from overlapping kernels, and the second stream's events
+  // only add to the host's bill (measured: 77 us per frame pipelined, 64 serial) — such frames are fused serially unless
+  // MRH_PIPE_UPLOADS=1 says otherwise (the test-suite sets it, so that its upload-fed streams exercise the pipeline)
+  const bool resident_inputs = c->up_depth.cur < 0 && c->up_rgb.cur < 0;
+  const bool lazy = !starve_now && roomy && c->lazy_run < c->pipe_period && c->sync_streak < 3 && (resident_inputs || c->pipe_uploads) &&
+                    !getenv("MRH_PIPE_SERIAL");
   if (!lazy) {
     rc = strict_point(c);
     if (rc) return rc;
   }
+  rc = send_uploads(c, lazy ? c->stream_front : s);  // the raw images are read by the front half
+  if (rc) return rc;
   const int seq = (int) (c->pipe_seq & 0x3FFFFFFF);
   const int ring = lazy ? (int) (c->pipe_seq % kPipeRing) : 0;  // a serial frame runs behind everything on the main stream: any slot
   c->pipe_seq++;                                                // is free for it, and the starve passes walk slot 0's lists
@@ -1640,6 +1660,8 @@ static int integrate_frame(mrh_ctx* c, int n_frames_invalidate) {
     if (rc) return rc;
   }
   if (pipe_frame) return integrate_lazy(c, max_num_frames, starve_now);
+  rc = send_uploads(c, s);  // the frame's kernels read the images on the main stream
+  if (rc) return rc;
   if (!c->frame_general) {
     // ---- fast path: alloc + sweep -> fused integrate / summary / GC (mrh_fast2.h)
     if (!t.multi_res && c->fast_summaries_stale) {  // a general frame (spherical camera) ran since: rebuild the GC summaries once
@@ -2129,7 +2151,7 @@ int mrh_splat_seeds(mrh_ctx* c, float qtree_thresh, int qtree_min_pixel_size, co
     }
   }
   c->qt = qt;
-  rc = wait_inputs(c);
+  rc = send_uploads(c, c->stream);
   if (rc) return rc;
   const u32 grid = (qt.total + 255) / 256;
   u32* unc_count = (u32*) (c->d_qt_misc + 1);

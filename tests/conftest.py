@@ -9,6 +9,13 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 
+# Frames whose images come through mrh_upload_* are fused serially by default (host- and link-bound: the kernel pipeline buys
+# nothing there); the parity tests feed exactly that way, so the suite asks for the pipeline on those frames too — every map the
+# tests compare with the oracle has then been through the second stream, the zombies and the reclaim.  MRH_PIPE=0 (set by
+# individual tests) is the serial path.
+os.environ.setdefault("MRH_PIPE_UPLOADS", "1")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -943,3 +943,59 @@ def test_contexts_release_their_device_memory(hip):
     hipmem.synchronize()
     free1, _ = hipmem.mem_get_info()
     assert free0 - free1 < 32 << 20, f"device memory shrank by {(free0 - free1) >> 20} MiB over 25 create/destroy cycles"
+
+
+@pytest.mark.parametrize("period", ["2", "5", "1000"])
+def test_pipelined_frames_build_the_serial_map(hip, oracle, monkeypatch, period):
+    """Pipelined frames (mrh_capi.hip integrate_lazy: front half on a second stream next to the integrations before it, lazy
+    garbage collection through zombies and per-frame want stamps, k_reclaim every `period` frames) against the oracle AND against
+    the same library fusing serially (MRH_PIPE=0): 40 frames of the 640x480 orbit without a synchronisation in between, GC on
+    every frame — the blocks of the truncation band's near edge are collected and wanted again every single frame, blocks that
+    leave the band stay zombies until the reclaim.  Occupancy, payload and mesh must be the serial ones, bit for bit; the
+    statistics too (blocks freed / inserted are counted where the reference frees / inserts)."""
+    monkeypatch.setenv("MRH_PIPE_PERIOD", period)
+    a = pu.make_engine(hip, synth.REPLICA_640, synth.REPLICA_PARAMS, 131072)
+    monkeypatch.setenv("MRH_PIPE", "0")
+    s = pu.make_engine(hip, synth.REPLICA_640, synth.REPLICA_PARAMS, 131072)
+    monkeypatch.delenv("MRH_PIPE")
+    b = pu.make_engine(oracle, synth.REPLICA_640, synth.REPLICA_PARAMS, 131072)
+    frames = list(synth.replica_stream(40))
+    for i, f in enumerate(frames):
+        pu.feed(a, f)
+        pu.feed(s, f)
+        pu.feed(b, f)
+        if i == 17:  # an entry point in the middle of the pipeline: the pending integration and the reclaim come first
+            assert a.free_blocks() == s.free_blocks() == b.free_blocks()
+    sa, ss, sb = a.stats(), s.stats(), b.stats()  # before anything else compacts the block list
+    for k in ("occupied_fine", "free_fine", "frames_integrated", "last_compact_blocks", "error_flags"):
+        assert getattr(sa, k) == getattr(ss, k) == getattr(sb, k), (k, getattr(sa, k), getattr(ss, k), getattr(sb, k))
+    r = pu.compare_maps(a, b)
+    assert r["blocks"] > 15000 and r["sdf_bit_exact"] and r["sumsq_bit_exact"]
+    pu.compare_maps(a, s)
+    m = pu.compare_meshes(a, b)
+    assert m["triangles"] > 400000 and m["pos_bit_exact"]
+    for e in (a, s, b):
+        e.close()
+
+
+def test_pipelined_frames_with_a_moving_scene_and_a_small_pool(hip, oracle, monkeypatch):
+    """The same on the 128x128 case with things that stress the zombie rules: a sphere that jumps back and forth (blocks are
+    collected, stay unwanted for some frames, and are wanted again before or after the reclaim), a pool so small that the
+    context leaves the pipelined mode when room gets short (free < pool / 4), and interleaved entry points."""
+    monkeypatch.setenv("MRH_PIPE_PERIOD", "4")
+    params = dict(synth.CFG1_PARAMS, n_frames_invalidate_voxels=1000)  # GC every frame, no starve
+    a, b = _pair(hip, oracle, synth.CFG1, params, 2048)
+    rng = np.random.default_rng(11)
+    for i in range(60):
+        zc = 1.3 + 0.4 * float(rng.random()) if i % 3 else 1.5
+        f = synth.cfg1_sphere(zc=zc, radius=0.3 + 0.2 * float(rng.random()))
+        pu.feed(a, f)
+        pu.feed(b, f)
+        if i in (7, 31):
+            pu.compare_maps(a, b)
+        if i == 44:
+            assert a.peek_free_blocks()[:2] is not None
+    r = pu.compare_maps(a, b)
+    assert r["blocks"] > 50 and r["sdf_bit_exact"]
+    pu.compare_meshes(a, b)
+    assert a.stats().error_flags == 0
