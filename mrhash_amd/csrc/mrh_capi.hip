@@ -215,7 +215,11 @@ struct mrh_ctx {
     bool free_ = false, profile = false, safe_div = false, count_zombies = false;
     EvPair ev = {nullptr, nullptr};
     uint64_t report_seq = 0;  // frame mark whose pool report was written before this integration ran (refreshed behind it)
-  } pend;
+  };
+  static constexpr int kPendMax = 3;
+  PendingBack pendq[kPendMax];            // oldest first
+  int npend = 0;
+  int pipe_defer = 1;                     // integrations kept back (MRH_PIPE_DEFER, 1 .. kPendMax - 1): the older a front half, the surer it has finished
   uint64_t dbg_waits = 0;
   double dbg_spin_us = 0, dbg_api_us = 0; uint64_t dbg_lazy_frames = 0;  // MRH_DEBUG: where the host's time in integrate_lazy goes
   int4* d_cfree = nullptr;
@@ -395,8 +399,8 @@ void free_all(mrh_ctx* c) {
   for (auto& e : c->comm_ev_pool) { (void) hipEventDestroy(e.a); (void) hipEventDestroy(e.b); }
   for (auto& e : c->comm_ev_pending) { (void) hipEventDestroy(e.a); (void) hipEventDestroy(e.b); }
   F(c->d_qt_sums); F(c->d_qt_flags); F(c->d_qt_unc); F(c->d_qt_marks); F(c->d_qt_pos); F(c->d_qt_parked); F(c->d_qt_seeds); F(c->d_qt_leaves); F(c->d_qt_misc); F(c->d_qt_tmp);
-  if (c->pend.on && c->pend.profile) c->ev_pool.push_back(c->pend.ev);
-  c->pend.on = false;
+  for (int i = 0; i < c->npend; i++) if (c->pendq[i].profile) c->ev_pool.push_back(c->pendq[i].ev);
+  c->npend = 0;
   for (auto& e : c->ev_pool) { (void) hipEventDestroy(e.a); (void) hipEventDestroy(e.b); }
   for (auto& e : c->ev_pending) { (void) hipEventDestroy(e.a); (void) hipEventDestroy(e.b); }
   for (auto& e : c->ev_pending_front) { (void) hipEventDestroy(e.a); (void) hipEventDestroy(e.b); }
@@ -411,8 +415,8 @@ int init_buffers(mrh_ctx* c) {
   c->mr_summaries_valid = false;
   c->fast_frames = 0;
   if (c->stream_front) HIP_TRY(c, hipStreamSynchronize(c->stream_front));
-  if (c->pend.on && c->pend.profile) c->ev_pool.push_back(c->pend.ev);
-  c->pend.on = false;  // a reset map has nothing left to integrate
+  for (int i = 0; i < c->npend; i++) if (c->pendq[i].profile) c->ev_pool.push_back(c->pendq[i].ev);
+  c->npend = 0;  // a reset map has nothing left to integrate
   c->pipe_seq = 0;
   c->pipe_base = 0;
   c->lazy_run = 0;
@@ -1019,6 +1023,7 @@ int mrh_create(const mrh_params* p, mrh_ctx** out) {
     if (v > 0 && v <= 32768) c->fused_grid = v;
   }
   if (const char* g = getenv("MRH_PIPE")) c->pipe = atoi(g) ? 1 : 0;
+  if (const char* g = getenv("MRH_PIPE_DEFER")) { const int v = atoi(g); if (v >= 1 && v < mrh_ctx::kPendMax) c->pipe_defer = v; }
   if (const char* g = getenv("MRH_PIPE_UPLOADS")) c->pipe_uploads = atoi(g) ? 1 : 0;
   if (const char* g = getenv("MRH_PIPE_PERIOD")) { const int v = atoi(g); if (v > 0) c->pipe_period = v; }
   if (const char* g = getenv("MRH_SWEEP_WGS")) { const int v = atoi(g); if (v > 0 && v <= 4096) c->sweep_wgs = v; }
@@ -1293,9 +1298,9 @@ int mark_frame(mrh_ctx* c) {
   if (!c->frame_done[0])
     for (hipEvent_t& e : c->frame_done) HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
   // the raw images of a pipelined frame are read by its front half, on the front stream (its integration reads the cleaned copy)
-  HIP_TRY(c, hipEventRecord(c->frame_done[seq % 8], (c->last_frame_lazy && c->pend.on) ? c->stream_front : c->stream));
+  HIP_TRY(c, hipEventRecord(c->frame_done[seq % 8], (c->last_frame_lazy && c->npend) ? c->stream_front : c->stream));
   for (UpSlot* u : used) if (u) u->last_seq = seq;
-  if (c->pend.on && c->peek_enabled) c->pend.report_seq = seq;  // written before the deferred integration: refreshed behind it
+  if (c->npend && c->last_frame_lazy && c->peek_enabled) c->pendq[c->npend - 1].report_seq = seq;  // written before the deferred integration: refreshed behind it
   return MRH_OK;
 }
 
@@ -1376,9 +1381,10 @@ Lists ring_lists(const mrh_ctx* c, const int i) {
 // integration has started, and nothing is enqueued on it before the host has seen the main stream drain (front_needs_sync).
 // the integration of the newest pipelined frame, behind its front half
 int launch_pending(mrh_ctx* c, const bool count_skips = false) {
-  if (!c->pend.on) return MRH_OK;
-  const mrh_ctx::PendingBack pb = c->pend;
-  c->pend.on = false;
+  if (!c->npend) return MRH_OK;
+  const mrh_ctx::PendingBack pb = c->pendq[0];  // the oldest
+  for (int i = 1; i < c->npend; i++) c->pendq[i - 1] = c->pendq[i];
+  c->npend--;
   hipStream_t s = c->stream;
   const hipError_t q = hipEventQuery(c->ev_front[pb.ring]);
   if (q == hipErrorNotReady) {
@@ -1417,8 +1423,8 @@ int launch_pending(mrh_ctx* c, const bool count_skips = false) {
 }
 
 int strict_point(mrh_ctx* c) {
-  {
-    const int rc = launch_pending(c, true);
+  while (c->npend) {
+    const int rc = launch_pending(c, c->npend == 1);
     if (rc) return rc;
   }
   if (!c->zombies_possible) return MRH_OK;
@@ -1434,6 +1440,7 @@ int strict_point(mrh_ctx* c) {
 int ensure_pipe_buffers(mrh_ctx* c, const size_t npix) {
   if (!c->stream_front) {
     const size_t cap = c->num_blocks;
+    // (a high-priority front stream, a ring of eight and integrations deferred by two calls were measured: no difference)
     HIP_TRY(c, hipStreamCreateWithFlags(&c->stream_front, hipStreamNonBlocking));
     for (hipEvent_t& e : c->ev_front) HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     c->ring_vis[0] = c->tab.compact; c->ring_bbox[0] = c->fast.bbox; c->ring_cfree[0] = c->d_cfree; c->ring_zmin[0] = c->d_zmin;
@@ -1566,14 +1573,16 @@ int integrate_lazy(mrh_ctx* c, const int max_num_frames, const bool starve_now) 
     // the integration of the PREVIOUS pipelined frame goes out now (its front half ran a frame ago: usually no wait), this
     // frame's is left for the next call
     const bool zombies_before = c->zombies_possible;
-    rc = launch_pending(c);
-    if (rc) return rc;
-    mrh_ctx::PendingBack& pb = c->pend;
+    while (c->npend >= c->pipe_defer) {
+      rc = launch_pending(c);
+      if (rc) return rc;
+    }
+    mrh_ctx::PendingBack& pb = c->pendq[c->npend++];
     pb.on = true;
     pb.cam = k; pb.f = f; pb.L = L;
     pb.set = set; pb.zero_set = zero_set; pb.ring = ring; pb.seq = seq; pb.stamp = stamp; pb.thr = gc_thr;
     pb.free_ = c->frame_gc_inline; pb.profile = c->profile != 0; pb.safe_div = safe_div;
-    pb.count_zombies = zombies_before || c->zombies_possible;
+    pb.count_zombies = zombies_before || c->zombies_possible || c->frame_gc_inline;
     pb.ev = ev;
     pb.report_seq = 0;
     c->last_frame_lazy = true;

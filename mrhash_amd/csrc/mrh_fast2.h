@@ -26,7 +26,7 @@ namespace mrh {
 // reads it and zeroes set (g - 1) % 6 — the set of the frame before it, whose integration is complete (stream order) and whose
 // next user, frame g + 5, is not enqueued before this launch is known to have started (integrate_lazy's throttle)
 constexpr int CTR_SET0 = 32;       // set p lives at CTR_SET0 + 4 * p: {n_visible, n_culled_kept, n_culled_free, unused}
-constexpr int kListSets = 6;       // = frames a pipelining context keeps in flight + 2 (kPipeRing)
+constexpr int kListSets = 6;       // = kPipeRing: frames a pipelining context may have between its newest front half and the oldest unfinished integration, + 2
 constexpr u32 kZombieBit = 0x80000000u;  // in Fast::summary[H].y: the block was emptied by a pipelined frame's garbage collection
                                          // and still sits in the table (pipelined frames)
 
