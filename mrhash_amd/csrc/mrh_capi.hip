@@ -2006,9 +2006,9 @@ int mrh_integrate_points(mrh_ctx* c, int n_frames_invalidate) {
       ScanState ss;
       ss.wg_totals = c->d_pt_offsets; ss.host_rec = c->h_scan; ss.seq = ++c->scan_seq;
       const u32 seq = ss.seq;
-      k_points_walk<false, u32><<<grid, 256, 0, s>>>(k, m, t, pts, normals, np, c->d_pt_counts, ss, (u32*) nullptr, nullptr, coarse_bit);
-      if (wide) k_points_walk<true, u64><<<grid, 256, 0, s>>>(k, m, t, pts, normals, np, c->d_pt_counts, ss, (u64*) c->d_rec_keys[0], c->d_rec_vals[0], coarse_bit);
-      else k_points_walk<true, u32><<<grid, 256, 0, s>>>(k, m, t, pts, normals, np, c->d_pt_counts, ss, (u32*) c->d_rec_keys[0], c->d_rec_vals[0], coarse_bit);
+      k_points_walk<false, u32><<<grid, 256, 0, s>>>(k, m, t, pts, normals, np, c->d_pt_counts, ss, (u32*) nullptr, nullptr, coarse_bit, 0u);
+      if (wide) k_points_walk<true, u64><<<grid, 256, 0, s>>>(k, m, t, pts, normals, np, c->d_pt_counts, ss, (u64*) c->d_rec_keys[0], c->d_rec_vals[0], coarse_bit, (u32) std::min<uint64_t>(c->rec_cap, 0xFFFFFFFFull));
+      else k_points_walk<true, u32><<<grid, 256, 0, s>>>(k, m, t, pts, normals, np, c->d_pt_counts, ss, (u32*) c->d_rec_keys[0], c->d_rec_vals[0], coarse_bit, (u32) std::min<uint64_t>(c->rec_cap, 0xFFFFFFFFull));
       HIP_TRY(c, hipGetLastError());
       {
         volatile u32* mark = c->h_scan + 3;

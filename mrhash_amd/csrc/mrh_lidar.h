@@ -153,7 +153,10 @@ template <bool EMIT, typename K>
 __global__ __launch_bounds__(256) void k_points_walk(const Cam c, const Map m, const Tab t, const float* __restrict__ pts,
                                                      const float* __restrict__ normals, const u32 n, u32* __restrict__ counts,
                                                      const ScanState ss, K* __restrict__ keys, float* __restrict__ vals,
-                                                     const int coarse_bit) {
+                                                     const int coarse_bit, const u32 rec_cap) {
+  // rec_cap: records the buffers hold.  The host sizes them by a bound on the voxels a beam can cross, but the bound is derived,
+  // not enforced by the walk (kMaxDdaIter is its only limit): a record beyond the capacity is not written, the host sees the
+  // total in the scan's report and fails the call cleanly
   __shared__ u32 s_part[4];
   const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = i < n;
@@ -256,8 +259,10 @@ __global__ __launch_bounds__(256) void k_points_walk(const Cam c, const Map m, c
           u64 vid;
           if (res) { const u32 u = val & ~kValCoarseBit; vid = ((u64) (u >> 3) * 512u + (u64) (u & 7u) * 64u + li) | (1ull << coarse_bit); }
           else vid = (u64) val * 512u + li;
-          keys[out + cnt] = (K) vid;
-          vals[out + cnt] = sdf;
+          if (out + cnt < rec_cap) {
+            keys[out + cnt] = (K) vid;
+            vals[out + cnt] = sdf;
+          }
         }
         cnt++;
       }
