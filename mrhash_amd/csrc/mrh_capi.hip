@@ -212,7 +212,7 @@ struct mrh_ctx {
     int set = 0, zero_set = 0, ring = 0, seq = 0;
     u32 stamp = 0;
     float thr = 0.f;
-    bool free_ = false, profile = false, safe_div = false, count_zombies = false;
+    bool free_ = false, profile = false, safe_div = false, count_zombies = false, sph = false;
     EvPair ev = {nullptr, nullptr};
     uint64_t report_seq = 0;  // frame mark whose pool report was written before this integration ran (refreshed behind it)
   };
@@ -1400,17 +1400,19 @@ int launch_pending(mrh_ctx* c, const bool count_skips = false) {
   if (count_skips) HIP_TRY(c, hipMemsetAsync(&c->tab.ctr[CTR_ZSKIP], 0, sizeof(int), s));  // mrh_get_stats: M of the last frame, exactly
   if (pb.profile)  // U and M of the frame (device-side counters of the roofline numerator): after its front half, before its integration
     k_count_updates<<<c->fused_grid, 256, 0, s>>>(pb.cam, m, t, pb.f, c->d_cnt_partials, CTR_SET0 + 4 * pb.set, pb.L.vis, pb.L.cfree, pb.stamp, pb.count_zombies ? 1 : 0);
-#define MRH_KB(FREE, PROF, SAFE)                                                                                                                      \
+#define MRH_KB(FREE, PROF, SAFE, SPH)                                                                                                                 \
   do {                                                                                                                                                \
-    if (pb.profile) hipExtLaunchKernelGGL((k_back<FREE, PROF, false, SAFE, 2>), dim3(c->fused_grid), dim3(256), (uint32_t) lds, s, pb.ev.a, pb.ev.b, 0u, pb.cam, m, t, pb.f, \
+    if (pb.profile) hipExtLaunchKernelGGL((k_back<FREE, PROF, false, SAFE, 2, SPH>), dim3(c->fused_grid), dim3(256), (uint32_t) lds, s, pb.ev.a, pb.ev.b, 0u, pb.cam, m, t, pb.f, \
                                           pb.L, pb.set, pb.zero_set, pb.thr, (const float*) nullptr, (const uint8_t*) nullptr, (u32*) nullptr, pb.stamp, pb.seq); \
-    else k_back<FREE, PROF, false, SAFE, 2><<<c->fused_grid, 256, lds, s>>>(pb.cam, m, t, pb.f, pb.L, pb.set, pb.zero_set, pb.thr, nullptr, nullptr, nullptr, pb.stamp, pb.seq); \
+    else k_back<FREE, PROF, false, SAFE, 2, SPH><<<c->fused_grid, 256, lds, s>>>(pb.cam, m, t, pb.f, pb.L, pb.set, pb.zero_set, pb.thr, nullptr, nullptr, nullptr, pb.stamp, pb.seq); \
   } while (0)
-#define MRH_KB2(FREE, PROF) do { if (pb.safe_div) MRH_KB(FREE, PROF, true); else MRH_KB(FREE, PROF, false); } while (0)
+#define MRH_KB3(FREE, PROF, SAFE) do { if (pb.sph) MRH_KB(FREE, PROF, SAFE, true); else MRH_KB(FREE, PROF, SAFE, false); } while (0)
+#define MRH_KB2(FREE, PROF) do { if (pb.safe_div) MRH_KB3(FREE, PROF, true); else MRH_KB3(FREE, PROF, false); } while (0)
   if (pb.free_ && pb.profile) MRH_KB2(true, true);
   else if (pb.free_) MRH_KB2(true, false);
   else MRH_KB2(false, false);
 #undef MRH_KB2
+#undef MRH_KB3
 #undef MRH_KB
   if (pb.profile) c->ev_pending.push_back(pb.ev);
   if (pb.free_) c->zombies_possible = true;
@@ -1512,7 +1514,7 @@ int integrate_lazy(mrh_ctx* c, const int max_num_frames, const bool starve_now) 
   // only add to the host's bill (measured: 77 us per frame pipelined, 64 serial) — such frames are fused serially unless
   // MRH_PIPE_UPLOADS=1 says otherwise (the test-suite sets it, so that its upload-fed streams exercise the pipeline)
   const bool resident_inputs = c->up_depth.cur < 0 && c->up_rgb.cur < 0;
-  const bool lazy = !starve_now && roomy && c->lazy_run < c->pipe_period && c->sync_streak < 3 && (resident_inputs || c->pipe_uploads) &&
+  const bool lazy = c->pipe && !starve_now && roomy && c->lazy_run < c->pipe_period && c->sync_streak < 3 && (resident_inputs || c->pipe_uploads) &&
                     !getenv("MRH_PIPE_SERIAL");
   if (!lazy) {
     rc = strict_point(c);
@@ -1533,6 +1535,7 @@ int integrate_lazy(mrh_ctx* c, const int max_num_frames, const bool starve_now) 
   const float gc_thr = m.trunc + m.trunc_scale * k.max_depth;  // getTruncation(camera.maxDepth(), ...), vds.cu:1720
   const bool safe_div = m.half_vs_two_steps || m.wsum_two_steps;  // the short divisions failed their check at mrh_create
   const int gc_on = max_num_frames > 0 ? 1 : 0;
+  const bool sph = c->spherical;
   c->frame_gc_inline = max_num_frames > 0 && !starve_now;
   const Lists L = ring_lists(c, ring);
   const size_t lds = (size_t) 4 * kTileMaxPx * sizeof(uint2);
@@ -1565,9 +1568,18 @@ int integrate_lazy(mrh_ctx* c, const int max_num_frames, const bool starve_now) 
     c->dbg_lazy_frames++;
     const auto t_api = std::chrono::steady_clock::now();
     hipStream_t a = c->stream_front;
-    if (c->profile) hipExtLaunchKernelGGL((k_front<true, false, true>), dim3(n_tiles + c->sweep_wgs), dim3(256), 0, a, evf.a, evf.b, 0u, k, m, t, f, L, c->d_depth, c->d_rgb, tiles_x, n_tiles, stamp,
-                                          set, gc_on, gc_thr, 0, 0, (const int*) nullptr);
-    else k_front<false, false, true><<<n_tiles + c->sweep_wgs, 256, 0, a>>>(k, m, t, f, L, c->d_depth, c->d_rgb, tiles_x, n_tiles, stamp, set, gc_on, gc_thr, 0, 0, nullptr);
+#define MRH_KF(PROF, LAZY, SPH, STREAM)                                                                                                                \
+  do {                                                                                                                                                \
+    if (PROF) hipExtLaunchKernelGGL((k_front<PROF, false, LAZY, SPH>), dim3(n_tiles + c->sweep_wgs), dim3(256), 0, STREAM, evf.a, evf.b, 0u, k, m, t, f, L, c->d_depth, c->d_rgb, \
+                                    tiles_x, n_tiles, stamp, set, gc_on, gc_thr, 0, 0, (const int*) nullptr);                                          \
+    else k_front<PROF, false, LAZY, SPH><<<n_tiles + c->sweep_wgs, 256, 0, STREAM>>>(k, m, t, f, L, c->d_depth, c->d_rgb, tiles_x, n_tiles, stamp, set, gc_on, gc_thr, 0, 0, nullptr); \
+  } while (0)
+#define MRH_KF2(LAZY, STREAM)                                                                                                                         \
+  do {                                                                                                                                                \
+    if (c->profile && sph) MRH_KF(true, LAZY, true, STREAM); else if (c->profile) MRH_KF(true, LAZY, false, STREAM);                                   \
+    else if (sph) MRH_KF(false, LAZY, true, STREAM); else MRH_KF(false, LAZY, false, STREAM);                                                          \
+  } while (0)
+    MRH_KF2(true, a);
     HIP_TRY(c, hipEventRecord(c->ev_front[ring], a));
     if (c->profile) c->ev_pending_front.push_back(evf);
     // the integration of the PREVIOUS pipelined frame goes out now (its front half ran a frame ago: usually no wait), this
@@ -1581,7 +1593,7 @@ int integrate_lazy(mrh_ctx* c, const int max_num_frames, const bool starve_now) 
     pb.on = true;
     pb.cam = k; pb.f = f; pb.L = L;
     pb.set = set; pb.zero_set = zero_set; pb.ring = ring; pb.seq = seq; pb.stamp = stamp; pb.thr = gc_thr;
-    pb.free_ = c->frame_gc_inline; pb.profile = c->profile != 0; pb.safe_div = safe_div;
+    pb.free_ = c->frame_gc_inline; pb.profile = c->profile != 0; pb.safe_div = safe_div; pb.sph = sph;
     pb.count_zombies = zombies_before || c->zombies_possible || c->frame_gc_inline;
     pb.ev = ev;
     pb.report_seq = 0;
@@ -1594,24 +1606,26 @@ int integrate_lazy(mrh_ctx* c, const int max_num_frames, const bool starve_now) 
   }
   // ---- serial frame, all on the main stream (strict_point above has flushed and reclaimed)
   c->last_frame_lazy = false;
-  if (c->profile) hipExtLaunchKernelGGL((k_front<true, false, false>), dim3(n_tiles + c->sweep_wgs), dim3(256), 0, s, evf.a, evf.b, 0u, k, m, t, f, L, c->d_depth, c->d_rgb, tiles_x, n_tiles, stamp,
-                                        set, gc_on, gc_thr, 0, 0, (const int*) nullptr);
-  else k_front<false, false, false><<<n_tiles + c->sweep_wgs, 256, 0, s>>>(k, m, t, f, L, c->d_depth, c->d_rgb, tiles_x, n_tiles, stamp, set, gc_on, gc_thr, 0, 0, nullptr);
+  MRH_KF2(false, s);
+#undef MRH_KF2
+#undef MRH_KF
   if (c->profile) {
     c->ev_pending_front.push_back(evf);
     k_count_updates<<<c->fused_grid, 256, 0, s>>>(k, m, t, f, c->d_cnt_partials, CTR_SET0 + 4 * set, L.vis, L.cfree, stamp, 0);
   }
-#define MRH_KB(FREE, PROF, SAFE)                                                                                                                      \
+#define MRH_KB(FREE, PROF, SAFE, SPH)                                                                                                                 \
   do {                                                                                                                                                \
-    if (c->profile) hipExtLaunchKernelGGL((k_back<FREE, PROF, false, SAFE, 0>), dim3(c->fused_grid), dim3(256), (uint32_t) lds, s, ev.a, ev.b, 0u, k, m, t, f, L, \
+    if (c->profile) hipExtLaunchKernelGGL((k_back<FREE, PROF, false, SAFE, 0, SPH>), dim3(c->fused_grid), dim3(256), (uint32_t) lds, s, ev.a, ev.b, 0u, k, m, t, f, L, \
                                           set, zero_set, gc_thr, (const float*) nullptr, (const uint8_t*) nullptr, (u32*) nullptr, stamp, seq);        \
-    else k_back<FREE, PROF, false, SAFE, 0><<<c->fused_grid, 256, lds, s>>>(k, m, t, f, L, set, zero_set, gc_thr, nullptr, nullptr, nullptr, stamp, seq); \
+    else k_back<FREE, PROF, false, SAFE, 0, SPH><<<c->fused_grid, 256, lds, s>>>(k, m, t, f, L, set, zero_set, gc_thr, nullptr, nullptr, nullptr, stamp, seq); \
   } while (0)
-#define MRH_KB2(FREE, PROF) do { if (safe_div) MRH_KB(FREE, PROF, true); else MRH_KB(FREE, PROF, false); } while (0)
+#define MRH_KB3(FREE, PROF, SAFE) do { if (sph) MRH_KB(FREE, PROF, SAFE, true); else MRH_KB(FREE, PROF, SAFE, false); } while (0)
+#define MRH_KB2(FREE, PROF) do { if (safe_div) MRH_KB3(FREE, PROF, true); else MRH_KB3(FREE, PROF, false); } while (0)
   if (c->frame_gc_inline && c->profile) MRH_KB2(true, true);
   else if (c->frame_gc_inline) MRH_KB2(true, false);
   else MRH_KB2(false, false);
 #undef MRH_KB2
+#undef MRH_KB3
 #undef MRH_KB
   c->front_needs_sync = true;  // direct frees on the main stream
   if (c->profile) c->ev_pending.push_back(ev);
@@ -1657,13 +1671,13 @@ static int integrate_frame(mrh_ctx* c, int n_frames_invalidate) {
   const bool starve_now = max_num_frames > 0 && c->frames > 0 && c->frames % (uint64_t) max_num_frames == 0;
   c->frame_fused_mr = t.multi_res && c->mr_fused && !c->profile && max_num_frames > 0 && !starve_now && !c->mr_next_general &&
                       c->frames >= 2 && !c->spherical;
-  c->frame_general = c->spherical || (t.multi_res && !c->frame_fused_mr);
+  c->frame_general = t.multi_res && !c->frame_fused_mr;  // (round 4: single-resolution maps take the two launches under the spherical model, too)
   if (t.multi_res && !c->frame_fused_mr) {
     c->mr_summaries_valid = false;
     c->mr_next_general = starve_now || c->frames == 0;
     c->refill_flag_valid = false;
   }
-  const bool pipe_frame = c->pipe && !c->frame_general && !t.multi_res;
+  const bool pipe_frame = (c->pipe || c->spherical) && !c->frame_general && !t.multi_res;  // integrate_lazy also carries the spherical model's serial frames
   if (!pipe_frame) {  // a frame of another kind follows pipelined ones
     rc = strict_point(c);
     if (rc) return rc;

@@ -118,6 +118,40 @@ __device__ __forceinline__ Proj4 project4(const Cam& c, const Map& m, const int4
   return P;
 }
 
+// The same under the spherical camera model (Camera::projectPoint, camera.cuh:147-164, as project_point_m<false> states it): range,
+// azimuth = atan2(y, x), elevation = asin(z / range) through mrh_softmath.h (D8); `pcz` carries getDepth(pc) = the range
+// (camera.cuh:120-129), which is what integrateDepthMapKernel subtracts from the pixel's depth (vds.cu:1138).
+__device__ __forceinline__ Proj4 project4_sph(const Cam& c, const Map& m, const int4 ent, const int q) {
+  Proj4 P;
+  const int x0 = ent.x * kBlockSide + (q & 1) * 4;
+  const int y = ent.y * kBlockSide + ((q >> 1) & 7);
+  const int z = ent.z * kBlockSide + (q >> 4);
+  const float py = y * m.vs, pz = z * m.vs;
+  const float a1 = c.Ri[1] * py, a2 = c.Ri[2] * pz;
+  const float b1 = c.Ri[4] * py, b2 = c.Ri[5] * pz;
+  const float c1 = c.Ri[7] * py, c2 = c.Ri[8] * pz;
+  P.mask = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const float px = (x0 + k) * m.vs;
+    const float X = ((c.Ri[0] * px + a1) + a2) + c.ti[0];
+    const float Y = ((c.Ri[3] * px + b1) + b2) + c.ti[1];
+    const float Z = ((c.Ri[6] * px + c1) + c2) + c.ti[2];
+    const float range = sqrtf(X * X + Y * Y + Z * Z);
+    P.pcz[k] = range;
+    const bool depth_ok = !(range < c.min_depth || range > c.max_depth);
+    const float az = mrh_atan2f(Y, X);
+    const float el = mrh_asinf(Z / range);
+    const int row = f2i_hw((c.fy * el + c.cy) + 0.5f);
+    const int col = f2i_hw((c.fx * az + c.cx) + 0.5f);
+    const bool ok = depth_ok && row >= 0 && col >= 0 && row < c.rows && col < c.cols;
+    P.row[k] = row;
+    P.col[k] = col;
+    P.mask |= ok ? (1u << k) : 0u;
+  }
+  return P;
+}
+
 // which of the 4 voxels get written: depth valid and sdf > -truncation (vds.cu:1134-1145)
 template <typename PT>
 __device__ __forceinline__ u32 update_mask4(const Cam& c, const Map& m, const PT& P, const float (&d)[4]) {
@@ -311,7 +345,7 @@ __global__ __launch_bounds__(256) void k_count_updates(const Cam c, const Map m,
     }
 #pragma unroll
     for (int b = 0; b < 2; b++) {
-      const Proj4 P = project4(c, m, ent, lane + 64 * b);
+      const Proj4 P = c.model ? project4_sph(c, m, ent, lane + 64 * b) : project4(c, m, ent, lane + 64 * b);
       float d[4];
 #pragma unroll
       for (int k = 0; k < 4; k++) d[k] = __uint_as_float(f.dcx[((P.mask >> k) & 1u) ? (u32) (__mul24(P.row[k], c.cols) + P.col[k]) : 0u].x);

@@ -68,6 +68,9 @@ __device__ __forceinline__ int commit_block(const Tab& t, const Fast& f, const i
 // sh.list[0, sh.count).  Also writes the cleaned depth / packed colour of its pixels (calculateCloudKernel's validity rule,
 // camera.cu:13-18).  Returns true for a lane whose pixel needs the literal walk (LDS set saturated by far, sparse rays; keys
 // out of range): the caller re-walks it with walk_ray.  Ends with the workgroup barrier that completes the list.
+// SPH: the spherical camera model (camera.cuh:91-99): the "depth" every later step reads is getDepth(cloud) — the norm of the
+// back-projected point (k_cloud_depth in the general path) —, rays leave through inverse_projection_m (mrh_softmath.h, D8).
+template <bool SPH = false>
 __device__ __forceinline__ bool tile_rays(const Cam& c, const Map& m, uint2* __restrict__ dcx, const float* __restrict__ depth,
                                           const uint8_t* __restrict__ rgb, const int tiles_x, const int tile_id, FrontShared& sh, float& d_out) {
   constexpr int NT = 256;
@@ -83,11 +86,12 @@ __device__ __forceinline__ bool tile_rays(const Cam& c, const Map& m, uint2* __r
     const size_t pix = (size_t) row * c.cols + col;
     float d = depth[pix];
     if (d <= c.min_depth || d > c.max_depth) d = 0.f;  // camera.cu:13-18
+    if (SPH && d != 0.f) d = get_depth(c, inverse_projection_m(c, (u32) row, (u32) col, d));  // camera.cuh:120-129
     d_out = d;
     const uint8_t* px = rgb + pix * 3;
     dcx[pix] = make_uint2(__float_as_uint(d), (u32) px[0] | ((u32) px[1] << 8) | ((u32) px[2] << 16));
     // hot path: keys into the LDS set; anything rare is left to the literal walk, outside the loop every lane runs
-    const RayState ray = ray_setup(c, m, row, col, d);
+    const RayState ray = ray_setup<SPH>(c, m, row, col, d);
     if (ray.valid) {
       if (!ray_keys_in_range(ray)) {
         slow = true;
@@ -112,15 +116,15 @@ __device__ __forceinline__ bool tile_rays(const Cam& c, const Map& m, uint2* __r
 }
 
 // the literal walk of one pixel with a direct insert of every block of its ray (the rare path of a tile)
-template <bool PROFILE, bool MARK>
+template <bool PROFILE, bool MARK, bool SPH = false>
 __device__ __forceinline__ void tile_slow_pixel(const Cam& c, const Map& m, const Tab& t, const Fast& f, const Lists& L, const int row, const int col,
                                                 const float d, const u32 stamp, const int cs, const int hwm0) {
-  walk_ray(c, m, t, row, col, d, [&](const i3 cur, const u64 key) {
+  walk_ray<SPH>(c, m, t, row, col, d, [&](const i3 cur, const u64 key) {
     if (MARK) {  // a block that is in the table is wanted by this frame (pipelined frames)
       const int s0 = hash_find(t, key);
       if (s0 >= 0) { f.want[s0] = stamp; return; }
     }
-    if (!block_in_frustum_approx(c, m.vs, cur)) return;
+    if (!(SPH ? block_in_frustum_approx_m(c, m.vs, cur) : block_in_frustum_approx(c, m.vs, cur))) return;
     const int slot = hash_insert(t, key);
     if (slot == -2) atomicOr((u32*) &t.ctr[CTR_ERROR], ERR_TABLE);
     if (slot < 0) return;
@@ -137,7 +141,7 @@ __device__ __forceinline__ void tile_slow_pixel(const Cam& c, const Map& m, cons
 // Probe + insert of up to 64 distinct keys of a tile by one wave (`key` = kKeyEmpty on idle lanes): one probe per key
 // (hash_find_claim also remembers where an insert would land) -> frustum test -> one CAS on the remembered slot -> free-list
 // pop wave-aggregated, list append issued together with the read of the popped entries.  Returns the blocks this lane inserted.
-template <bool MARK>
+template <bool MARK, bool SPH = false>
 __device__ __forceinline__ u32 wave_insert_keys(const Cam& c, const Map& m, const Tab& t, const Fast& f, const Lists& L, const u64 key,
                                                 const u32 stamp, const int cs, const int hwm0) {
   const bool active = key != kKeyEmpty;
@@ -154,7 +158,7 @@ __device__ __forceinline__ u32 wave_insert_keys(const Cam& c, const Map& m, cons
       // pipelined frames: an earlier frame's garbage collection runs next to this probe and may be emptying this very block; it then
       // stays in the table, and whether it lives on is decided by this mark: "frame `stamp` has a ray through it"
       if (MARK) f.want[found] = stamp;
-    } else if (block_in_frustum_approx(c, m.vs, b)) {
+    } else if (SPH ? block_in_frustum_approx_m(c, m.vs, b) : block_in_frustum_approx(c, m.vs, b)) {
       slot = hash_insert_at(t, key, claim, claim_val);
       if (slot == -2) atomicOr((u32*) &t.ctr[CTR_ERROR], ERR_TABLE);
       won = slot >= 0;
@@ -191,7 +195,7 @@ __device__ __forceinline__ u32 wave_insert_keys(const Cam& c, const Map& m, cons
 }
 
 // Allocation for one 16x16 pixel tile in ONE launch (k_front): rays, then probe / insert of the tile's keys.
-template <bool PROFILE, bool MARK>
+template <bool PROFILE, bool MARK, bool SPH = false>
 __device__ __forceinline__ void front_tile(const Cam& c, const Map& m, const Tab& t, const Fast& f, const Lists& L,
                                            const float* __restrict__ depth, const uint8_t* __restrict__ rgb, const int tiles_x,
                                            const int tile_id, const u32 stamp, const int cs, FrontShared& sh) {
@@ -200,18 +204,18 @@ __device__ __forceinline__ void front_tile(const Cam& c, const Map& m, const Tab
   const int hwm0 = t.ctr[CTR_HWM_FINE];  // scalar load, before any store of this launch
   MRH_TSF(1);
   float d;
-  const bool slow = tile_rays(c, m, f.dcx, depth, rgb, tiles_x, tile_id, sh, d);
+  const bool slow = tile_rays<SPH>(c, m, f.dcx, depth, rgb, tiles_x, tile_id, sh, d);
   MRH_TSF(3);
   if (slow) {
     const int ty = tile_id / tiles_x, tx = tile_id - ty * tiles_x;
-    tile_slow_pixel<PROFILE, MARK>(c, m, t, f, L, ty * kRayTile + (tid >> 4), tx * kRayTile + (tid & 15), d, stamp, cs, hwm0);
+    tile_slow_pixel<PROFILE, MARK, SPH>(c, m, t, f, L, ty * kRayTile + (tid >> 4), tx * kRayTile + (tid & 15), d, stamp, cs, hwm0);
   }
   const int n = (int) sh.count;
   u32 my_inserted = 0;
 #pragma unroll 1
   for (int base = 0; base < n; base += NT) {
     const int i = base + tid;
-    my_inserted += wave_insert_keys<MARK>(c, m, t, f, L, i < n ? sh.list[i] : kKeyEmpty, stamp, cs, hwm0);
+    my_inserted += wave_insert_keys<MARK, SPH>(c, m, t, f, L, i < n ? sh.list[i] : kKeyEmpty, stamp, cs, hwm0);
   }
   MRH_TSF(4);
 #ifdef MRH_TRACE
@@ -239,7 +243,9 @@ __device__ __forceinline__ void front_tile(const Cam& c, const Map& m, const Tab
 // and publishes them with three atomics per workgroup.
 // DEFER (pipelined frames): the previous frame's integration runs next to this sweep, so the stored summaries are not final: every culled
 // block goes on the culled list as a CANDIDATE and the launch that integrates this frame decides from the then-final summary.
-template <bool MULTI, bool DEFER = false>
+// SPH: the approx-frustum predicate of the spherical model (camera.cuh:184-201); no exact-image cull and no pixel footprint (both
+// rest on the pinhole projection being a ratio of affine functions): every block of the approx frustum is VISIBLE, its lookups gather.
+template <bool MULTI, bool DEFER = false, bool SPH = false>
 __device__ __forceinline__ void front_sweep(const Cam& c, const Map& m, const Tab& t, const Fast& f, const Lists& L, const u32 stamp,
                                             const int cs, const int gc_on, const float trunc_threshold, const int sw, const int n_sweep,
                                             FrontShared& sh) {
@@ -294,9 +300,9 @@ __device__ __forceinline__ void front_sweep(const Cam& c, const Map& m, const Ta
         const i3 v = mki3(d.x * kBlockSide + ((corner & 4) ? 7 : 0), d.y * kBlockSide + ((corner & 2) ? 7 : 0), d.z * kBlockSide + ((corner & 1) ? 7 : 0));
         const f3 pc = se3_apply(c.Ri, c.ti, voxel_to_world(m.vs, v));
         int r, cc;
-        any_approx |= project_point<true>(c, pc, r, cc) ? 1 : 0;
+        any_approx |= (SPH ? project_point_m<true>(c, pc, r, cc) : project_point<true>(c, pc, r, cc)) ? 1 : 0;
         zmin = fminf(zmin, pc.z); zmax = fmaxf(zmax, pc.z);
-        if (pc.z >= 0.05f) {
+        if (!SPH && pc.z >= 0.05f) {
           const float u = c.fx * pc.x / pc.z + c.cx;
           const float w = c.fy * pc.y / pc.z + c.cy;
           umin = fminf(umin, u); umax = fmaxf(umax, u);
@@ -311,12 +317,12 @@ __device__ __forceinline__ void front_sweep(const Cam& c, const Map& m, const Ta
         vmin = fminf(vmin, __shfl_xor(vmin, off)); vmax = fmaxf(vmax, __shfl_xor(vmax, off));
       }
       if (sub == 0 && live && any_approx) {
-        bool cull = (zmax <= c.min_depth - 1e-3f) || (zmin > c.max_depth + 1e-3f);
-        if (!cull && zmin >= 0.05f) cull = umax < -3.f || umin > (float) c.cols + 1.f || vmax < -3.f || vmin > (float) c.rows + 1.f;
+        bool cull = !SPH && ((zmax <= c.min_depth - 1e-3f) || (zmin > c.max_depth + 1e-3f));
+        if (!SPH && !cull && zmin >= 0.05f) cull = umax < -3.f || umin > (float) c.cols + 1.f || vmax < -3.f || vmin > (float) c.rows + 1.f;
         const int4 e = make_int4(d.x, d.y, d.z, (int) ((u32) i | valbit));
         if (!cull) {
           int4 bb = make_int4(0, 0, 0, 0);
-          if (zmin >= 0.05f) {
+          if (!SPH && zmin >= 0.05f) {
             int c0 = f2i_hw(floorf(umin + 0.5f)) - 1, c1 = f2i_hw(floorf(umax + 0.5f)) + 1;
             int r0 = f2i_hw(floorf(vmin + 0.5f)) - 1, r1 = f2i_hw(floorf(vmax + 0.5f)) + 1;
             c0 = c0 < 0 ? 0 : c0; r0 = r0 < 0 ? 0 : r0;
@@ -370,7 +376,7 @@ __device__ __forceinline__ void front_refill(const Tab& t, const int low_blocks_
 
 // LAZY (pipelined frames, see k_back<..., LZ = 2>): the launch may run next to the integration of earlier frames on another
 // stream: its probes stamp Fast::want for every key they find, its sweep leaves the culled decisions to the integration.
-template <bool PROFILE, bool MULTI, bool LAZY = false>
+template <bool PROFILE, bool MULTI, bool LAZY = false, bool SPH = false>
 __global__ __launch_bounds__(256) void k_front(const Cam c, const Map m, const Tab t, const Fast f, const Lists L,
                                                const float* __restrict__ depth, const uint8_t* __restrict__ rgb, const int tiles_x,
                                                const int n_tiles, const u32 stamp, const int set, const int gc_on,
@@ -382,8 +388,8 @@ __global__ __launch_bounds__(256) void k_front(const Cam c, const Map m, const T
   const int n_sweep = (int) gridDim.x - n_tiles - n_refill;
   MRH_TSF(0);
   if (MULTI && (int) blockIdx.x >= n_sweep + n_tiles) front_refill(t, low_blocks_to_allocate, refill_flag, (int) blockIdx.x - n_sweep - n_tiles);
-  else if ((int) blockIdx.x >= n_sweep) front_tile<PROFILE, LAZY>(c, m, t, f, L, depth, rgb, tiles_x, (int) blockIdx.x - n_sweep, stamp, cs, sh);
-  else front_sweep<MULTI, LAZY>(c, m, t, f, L, stamp, cs, gc_on, trunc_threshold, (int) blockIdx.x, n_sweep, sh);
+  else if ((int) blockIdx.x >= n_sweep) front_tile<PROFILE, LAZY, SPH>(c, m, t, f, L, depth, rgb, tiles_x, (int) blockIdx.x - n_sweep, stamp, cs, sh);
+  else front_sweep<MULTI, LAZY, SPH>(c, m, t, f, L, stamp, cs, gc_on, trunc_threshold, (int) blockIdx.x, n_sweep, sh);
 }
 
 // pixel footprint of a block computed by the wave that is about to integrate it (lanes 0..7 take one corner each):
@@ -554,12 +560,15 @@ __device__ __forceinline__ bool zombie_wanted(const Tab& t, const Fast& f, const
 
 // LZ: 0 = no zombies can exist (strict launches of contexts that never pipeline); 1 = zombie-aware, collected blocks are freed
 // on the spot (a launch that runs alone); 2 = zombie-aware, collected blocks become zombies (pipelined frames)
-template <bool FREE, bool PROFILE, bool MULTI, bool SAFEDIV, int LZ = 0>
+// SPH: spherical camera model — voxels project through atan2 / asin (project4_sph), "depth" of a voxel is its range; entries carry
+// no footprint, so every pixel lookup is a gather and the behind-the-surface early-out does not apply
+template <bool FREE, bool PROFILE, bool MULTI, bool SAFEDIV, int LZ = 0, bool SPH = false>
 __device__ __forceinline__ void back_range(const Cam& c, const Map& m, const Tab& t, const Fast& f, const Lists& L,
                                            const float trunc_threshold, const int n, const int gw, const int nw, const int lane,
                                            uint2* tile, const float* __restrict__ depth_raw, const uint8_t* __restrict__ rgb_raw,
                                            u32* __restrict__ deferred, const u32 want_stamp = 0) {
   static_assert(!(MULTI && LZ), "multi-resolution maps are not pipelined");
+  static_assert(!(MULTI && SPH), "multi-resolution maps under the spherical model take the general kernels");
   for (int e = __builtin_amdgcn_readfirstlane(gw); e < n; e += nw) {
     MRH_TS(0);
     int4 ent, bb;
@@ -588,7 +597,7 @@ __device__ __forceinline__ void back_range(const Cam& c, const Map& m, const Tab
 #pragma unroll
       for (int b = 0; b < 2; b++) Q[b] = pq[lane + 64 * b];
     }
-    if (bb.z == 0) bb = wave_bbox(c, m.vs, ent, lane, zmin);  // listed without a footprint (inserted this frame)
+    if (!SPH && bb.z == 0) bb = wave_bbox(c, m.vs, ent, lane, zmin);  // listed without a footprint (inserted this frame)
     Proj4 P[2];
     float d[2][4];
     u32 cpx[2][4];
@@ -596,7 +605,7 @@ __device__ __forceinline__ void back_range(const Cam& c, const Map& m, const Tab
     TileRegs tr;
     tile_issue(c, f, bb, lane, tr);  // footprint gathers in flight behind the voxel planes ...
 #pragma unroll
-    for (int b = 0; b < 2; b++) P[b] = project4(c, m, ent, lane + 64 * b);  // ... while the projections (entry-only) run
+    for (int b = 0; b < 2; b++) P[b] = SPH ? project4_sph(c, m, ent, lane + 64 * b) : project4(c, m, ent, lane + 64 * b);  // ... while the projections (entry-only) run
     if (LZ && (sm0.y & kZombieBit)) {  // wave-uniform; rare
       if (!zombie_wanted(t, f, ent, want_stamp, lane)) {  // emptied by the previous frame's GC and no ray of this frame crosses it:
         if (lane == 0) atomicAdd(&t.ctr[CTR_ZSKIP], 1);   // not a block of this frame (the sweep listed it by its descriptor)
@@ -803,7 +812,7 @@ __device__ __forceinline__ void frame_epilogue(const Tab& t, const int zero_set,
 
 // ---- K2 = integrate + summary + GC of the visible list, then the culled-free list -------------
 // `gw` of `nw` waves; `tile`: this wave's LDS pixel tile; `set`: the frame's list-counter set, `zero_set`: the one to clear
-template <bool FREE, bool PROFILE, bool MULTI, bool SAFEDIV, int LZ = 0>
+template <bool FREE, bool PROFILE, bool MULTI, bool SAFEDIV, int LZ = 0, bool SPH = false>
 __device__ __forceinline__ void back_role(const Cam& c, const Map& m, const Tab& t, const Fast& f, const Lists& L, const int set, const int zero_set,
                                           const float trunc_threshold, const float* __restrict__ depth_raw, const uint8_t* __restrict__ rgb_raw,
                                           u32* __restrict__ deferred, const int gw, const int nw, const int lane, uint2* tile, const u32 want_stamp = 0,
@@ -815,7 +824,7 @@ __device__ __forceinline__ void back_role(const Cam& c, const Map& m, const Tab&
   const int ncfree = FREE ? t.ctr[cs + 2] : 0;
   const int nkept = t.ctr[cs + 1];
   if (gw == 0) frame_epilogue(t, zero_set, nvis, nkept + t.ctr[cs + 2], lane, seq);
-  back_range<FREE, PROFILE, MULTI, SAFEDIV, LZ>(c, m, t, f, L, trunc_threshold, nvis, gw, nw, lane, tile, depth_raw, rgb_raw, deferred, want_stamp);
+  back_range<FREE, PROFILE, MULTI, SAFEDIV, LZ, SPH>(c, m, t, f, L, trunc_threshold, nvis, gw, nw, lane, tile, depth_raw, rgb_raw, deferred, want_stamp);
   if (FREE) {
     // a zombie-aware launch takes every culled-list entry as a candidate: the list may come from a sweep that could not decide
     // (front_sweep<DEFER>), and for one that did decide the then-stable summary gives the same answer again
@@ -827,13 +836,13 @@ __device__ __forceinline__ void back_role(const Cam& c, const Map& m, const Tab&
 // LZ = 2: the integration of a pipelined frame (zombies on its lists: `want_stamp` = the stamp of ITS frame; its culled list
 // holds candidates; what it collects becomes a zombie).  LZ = 1: the same reading, collected blocks freed on the spot.
 // `seq`: the frame's sequence number in a pipelining context (reported to the host through Tab::h_levels).
-template <bool FREE, bool PROFILE, bool MULTI, bool SAFEDIV, int LZ = 0>
+template <bool FREE, bool PROFILE, bool MULTI, bool SAFEDIV, int LZ = 0, bool SPH = false>
 __global__ __launch_bounds__(256) void k_back(const Cam c, const Map m, const Tab t, const Fast f, const Lists L, const int set, const int zero_set,
                                               const float trunc_threshold, const float* __restrict__ depth_raw,
                                               const uint8_t* __restrict__ rgb_raw, u32* __restrict__ deferred, const u32 want_stamp, const int seq) {
   extern __shared__ __attribute__((aligned(16))) uint2 s_tile[];
   const int wpw = blockDim.x >> 6;
-  back_role<FREE, PROFILE, MULTI, SAFEDIV, LZ>(c, m, t, f, L, set, zero_set, trunc_threshold, depth_raw, rgb_raw, deferred, blockIdx.x * wpw + (threadIdx.x >> 6),
+  back_role<FREE, PROFILE, MULTI, SAFEDIV, LZ, SPH>(c, m, t, f, L, set, zero_set, trunc_threshold, depth_raw, rgb_raw, deferred, blockIdx.x * wpw + (threadIdx.x >> 6),
                                                gridDim.x * wpw, threadIdx.x & 63, &s_tile[(threadIdx.x >> 6) * kTileMaxPx], want_stamp, seq);
 }
 

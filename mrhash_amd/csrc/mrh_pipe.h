@@ -12,14 +12,14 @@ constexpr int kRayCap = kRayTile * kRayTile * 4;  // keys per tile list / LDS se
 
 // Amanatides-Woo walk over the blocks of one pixel's segment [d - t, d + t] (vds.cu:771-853); visit(block, key) is
 // called for every traversed block this shard owns.  `d` is the cleaned depth (0 = invalid pixel).
-template <typename V>
+template <bool SPH = false, typename V>
 __device__ __forceinline__ void walk_ray(const Cam& c, const Map& m, const Tab& t, const int row, const int col, const float d, V&& visit) {
   const float tr = get_truncation(d, m.trunc, m.trunc_scale);
   const float dmin = fminf(c.max_int_dist, d - tr);
   const float dmax = fminf(c.max_int_dist, d + tr);
   if ((d == 0.f) || (dmin >= dmax)) return;
-  const f3 pw_min = se3_apply(c.R, c.t, inverse_projection(c, (u32) row, (u32) col, dmin));
-  const f3 pw_max = se3_apply(c.R, c.t, inverse_projection(c, (u32) row, (u32) col, dmax));
+  const f3 pw_min = se3_apply(c.R, c.t, SPH ? inverse_projection_m(c, (u32) row, (u32) col, dmin) : inverse_projection(c, (u32) row, (u32) col, dmin));
+  const f3 pw_max = se3_apply(c.R, c.t, SPH ? inverse_projection_m(c, (u32) row, (u32) col, dmax) : inverse_projection(c, (u32) row, (u32) col, dmax));
   const f3 dd = mk3(pw_max.x - pw_min.x, pw_max.y - pw_min.y, pw_max.z - pw_min.z);
   const float inv_len = 1.0f / sqrtf(dd.x * dd.x + dd.y * dd.y + dd.z * dd.z);  // normalize, cuda_math.cuh:1075-1078
   const f3 dir = mk3(dd.x * inv_len, dd.y * inv_len, dd.z * inv_len);
@@ -103,6 +103,7 @@ __device__ __forceinline__ RayState ray_from_segment(const Map& m, const f3 pw_m
   r.valid = true;
   return r;
 }
+template <bool SPH = false>
 __device__ __forceinline__ RayState ray_setup(const Cam& c, const Map& m, const int row, const int col, const float d) {
   RayState r;
   r.valid = false;
@@ -110,8 +111,8 @@ __device__ __forceinline__ RayState ray_setup(const Cam& c, const Map& m, const 
   const float dmin = fminf(c.max_int_dist, d - tr);
   const float dmax = fminf(c.max_int_dist, d + tr);
   if ((d == 0.f) || (dmin >= dmax)) return r;
-  const f3 pw_min = se3_apply(c.R, c.t, inverse_projection(c, (u32) row, (u32) col, dmin));
-  const f3 pw_max = se3_apply(c.R, c.t, inverse_projection(c, (u32) row, (u32) col, dmax));
+  const f3 pw_min = se3_apply(c.R, c.t, SPH ? inverse_projection_m(c, (u32) row, (u32) col, dmin) : inverse_projection(c, (u32) row, (u32) col, dmin));
+  const f3 pw_max = se3_apply(c.R, c.t, SPH ? inverse_projection_m(c, (u32) row, (u32) col, dmax) : inverse_projection(c, (u32) row, (u32) col, dmax));
   return ray_from_segment(m, pw_min, pw_max);
 }
 // true if every block key of the walk is representable (pack_key cannot fail inside the loop)

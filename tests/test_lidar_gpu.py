@@ -279,3 +279,36 @@ def test_randomised_scans(hip, oracle, seed):
     r = pu.compare_maps(a, b)
     assert r["blocks"] > 20 and r["sdf_bit_exact"] and r["sumsq_bit_exact"], params
     pu.compare_meshes(a, b)
+
+
+@pytest.mark.parametrize("pipe", ["1", "0"], ids=["pipelined", "serial"])
+def test_spherical_images_on_the_two_launch_path_full_size(hip, oracle, monkeypatch, pipe):
+    """Round 4: single-resolution maps under the spherical camera model take the two launches of the pinhole path (k_front / k_back
+    templated on the model: rays through inverse_projection_m, getDepth(cloud) as the frame's depth, the approx-frustum predicate
+    of camera.cuh:184-201 in the sweep, every voxel projected through sqrt / atan2 / asin of mrh_softmath.h) — pipelined or
+    serial.  128 x 1024 range images of the street, 10 frames, GC every frame, starve on the 5th: map, statistics and mesh
+    against the oracle."""
+    monkeypatch.setenv("MRH_PIPE", pipe)
+    cam = spherical_camera(128, 1024)
+    p = dict(synth.VBR_PARAMS, min_weight_threshold=1, n_frames_invalidate_voxels=5)
+    engines = []
+    for lib in (hip, oracle):
+        e = capi.Engine(lib, capi.Params(num_sdf_blocks=65536, **p))
+        e.set_camera(cam["fx"], cam["fy"], cam["cx"], cam["cy"], cam["rows"], cam["cols"], p["min_depth"], 100.0, model=1)
+        engines.append(e)
+    a, b = engines
+    scene = synth.street_canyon()
+    for i, (t, q) in enumerate(synth.drive_poses(10, step=0.5)):
+        depth, rgb = synth.spherical_range_image(scene, t, q, cam)
+        for e in engines:
+            e.set_pose(synth.quat_to_rot(q), t)
+            e.upload_depth(depth)
+            e.upload_rgb(rgb)
+            assert not e.integrate()
+        if i == 6:
+            sa, sb = a.stats(), b.stats()
+            assert (sa.occupied_fine, sa.free_fine, sa.last_compact_blocks) == (sb.occupied_fine, sb.free_fine, sb.last_compact_blocks)
+    r = pu.compare_maps(a, b)
+    assert r["blocks"] > 1500 and r["sdf_bit_exact"] and r["sumsq_bit_exact"]
+    pu.compare_meshes(a, b)
+    assert a.stats().error_flags == 0
