@@ -184,6 +184,9 @@ struct mrh_ctx {
   // the integration of frame g.  Up to kPipeRing - 1 frames are in flight, each with its own {depth, colour} image, lists,
   // list-counter set and want stamps.  Everything that is not a pipelined frame meets the map only after k_reclaim.
   int pipe = 1;
+  int pipe_grid = 1024;                     // workgroups of a pipelined integration: ONE resident generation (4 per CU x 256 CUs).  With 2048 the
+                                            // second generation competes with the front half's workgroups for the slots the first one frees: 37.3 against
+                                            // 34.8 us per frame (MRH_PIPE_GRID; the serial launch keeps 2048)
   int pipe_uploads = 0;                     // MRH_PIPE_UPLOADS=1: pipeline frames whose images came through mrh_upload_* too
   int pipe_period = 32;                     // the reclaim (and one serial frame) every so many pipelined frames; MRH_PIPE_PERIOD
   hipStream_t stream_front = nullptr;
@@ -1023,6 +1026,7 @@ int mrh_create(const mrh_params* p, mrh_ctx** out) {
     if (v > 0 && v <= 32768) c->fused_grid = v;
   }
   if (const char* g = getenv("MRH_PIPE")) c->pipe = atoi(g) ? 1 : 0;
+  if (const char* g = getenv("MRH_PIPE_GRID")) { const int v = atoi(g); if (v > 0 && v <= 32768) c->pipe_grid = v; }
   if (const char* g = getenv("MRH_PIPE_DEFER")) { const int v = atoi(g); if (v >= 1 && v < mrh_ctx::kPendMax) c->pipe_defer = v; }
   if (const char* g = getenv("MRH_PIPE_UPLOADS")) c->pipe_uploads = atoi(g) ? 1 : 0;
   if (const char* g = getenv("MRH_PIPE_PERIOD")) { const int v = atoi(g); if (v > 0) c->pipe_period = v; }
@@ -1402,9 +1406,9 @@ int launch_pending(mrh_ctx* c, const bool count_skips = false) {
     k_count_updates<<<c->fused_grid, 256, 0, s>>>(pb.cam, m, t, pb.f, c->d_cnt_partials, CTR_SET0 + 4 * pb.set, pb.L.vis, pb.L.cfree, pb.stamp, pb.count_zombies ? 1 : 0);
 #define MRH_KB(FREE, PROF, SAFE, SPH)                                                                                                                 \
   do {                                                                                                                                                \
-    if (pb.profile) hipExtLaunchKernelGGL((k_back<FREE, PROF, false, SAFE, 2, SPH>), dim3(c->fused_grid), dim3(256), (uint32_t) lds, s, pb.ev.a, pb.ev.b, 0u, pb.cam, m, t, pb.f, \
+    if (pb.profile) hipExtLaunchKernelGGL((k_back<FREE, PROF, false, SAFE, 2, SPH>), dim3(c->pipe_grid), dim3(256), (uint32_t) lds, s, pb.ev.a, pb.ev.b, 0u, pb.cam, m, t, pb.f, \
                                           pb.L, pb.set, pb.zero_set, pb.thr, (const float*) nullptr, (const uint8_t*) nullptr, (u32*) nullptr, pb.stamp, pb.seq); \
-    else k_back<FREE, PROF, false, SAFE, 2, SPH><<<c->fused_grid, 256, lds, s>>>(pb.cam, m, t, pb.f, pb.L, pb.set, pb.zero_set, pb.thr, nullptr, nullptr, nullptr, pb.stamp, pb.seq); \
+    else k_back<FREE, PROF, false, SAFE, 2, SPH><<<c->pipe_grid, 256, lds, s>>>(pb.cam, m, t, pb.f, pb.L, pb.set, pb.zero_set, pb.thr, nullptr, nullptr, nullptr, pb.stamp, pb.seq); \
   } while (0)
 #define MRH_KB3(FREE, PROF, SAFE) do { if (pb.sph) MRH_KB(FREE, PROF, SAFE, true); else MRH_KB(FREE, PROF, SAFE, false); } while (0)
 #define MRH_KB2(FREE, PROF) do { if (pb.safe_div) MRH_KB3(FREE, PROF, true); else MRH_KB3(FREE, PROF, false); } while (0)
