@@ -38,6 +38,7 @@
 #include "mrh_fast2.h"
 #include "mrh_mesh.h"
 #include "mrh_lidar.h"
+#include "mrh_scan.h"
 #include "mrh_sort.h"
 #include "mrh_splat.h"
 
@@ -239,6 +240,15 @@ struct mrh_ctx {
   u32 scan_seq = 0;
   void* d_rec_keys[2] = {nullptr, nullptr}; float* d_rec_vals[2] = {nullptr, nullptr}; uint64_t rec_cap = 0; size_t rec_key_bytes = 0;
   void* d_sort_tmp = nullptr; size_t sort_tmp_bytes = 0;
+  // voxel-bucket scans (mrh_scan.h): per-voxel counters + block stamps (allocated with the first scan), stash, placed records, chunks
+  Scan scan = {};
+  int lidar_buckets = 1;         // MRH_LIDAR_BUCKETS=0: scans through the sorted records of mrh_lidar.h (cross-check)
+  int scan_state = 0;            // 0: scratch not tried yet, 1: allocated, -1: does not fit / not applicable (sorted path)
+  bool scan_dirty = false;       // a scan failed half way: the counters are cleared before the next one
+  uint64_t scan_rec_cap = 0, scan_wg_cap = 0;
+  u32* d_scan_ctr = nullptr;
+  u32 scan2_seq = 0;
+  size_t scan_lds_set = 0;
   // 3DGS splat seeds (mrh_splat.h): sized for one (image shape, min pixel size)
   QTree qt = {0, 0, 0, 0, 0};
   QSum* d_qt_sums = nullptr; u32* d_qt_flags = nullptr; u32* d_qt_unc = nullptr; u64* d_qt_marks = nullptr; u64* d_qt_pos = nullptr;
@@ -393,7 +403,7 @@ void free_all(mrh_ctx* c) {
   if (c->h_scan) (void) hipHostFree(c->h_scan);
   for (void* a : c->arena) if (a) (void) hipFree(a);
   F(c->d_decision); F(c->d_zbuf); F(c->d_realloc); F(c->d_reint); F(c->d_flag);
-  F(c->d_upd_partials); F(c->d_misc); F(c->d_rcp_w); F(c->d_cfree); F(c->d_zmin); F(c->d_points); F(c->d_pt_counts); F(c->d_pt_offsets); F(c->d_rec_keys[0]); F(c->d_rec_keys[1]); F(c->d_rec_vals[0]); F(c->d_rec_vals[1]); F(c->d_sort_tmp); F(c->fast.summary); F(c->fast.summary_c); F(c->fast.bbox); F(c->d_cnt_partials);
+  F(c->d_upd_partials); F(c->d_misc); F(c->d_rcp_w); F(c->d_cfree); F(c->d_zmin); F(c->d_points); F(c->d_pt_counts); F(c->d_pt_offsets); F(c->d_rec_keys[0]); F(c->d_rec_keys[1]); F(c->d_rec_vals[0]); F(c->d_rec_vals[1]); F(c->d_sort_tmp); F(c->scan.vcnt); F(c->scan.bstamp); F(c->scan.touched); F(c->scan.st_meta); F(c->scan.st_sdf); F(c->scan.st_grp); F(c->scan.wgdesc); F(c->scan.rp); F(c->scan.rs); F(c->scan.chunks); F(c->d_scan_ctr); F(c->fast.summary); F(c->fast.summary_c); F(c->fast.bbox); F(c->d_cnt_partials);
   F(c->d_pack); F(c->d_halo); F(c->d_taken); F(c->d_cloud); F(c->d_normals); F(c->d_soup); F(c->d_mc_recs);
   for (hipEvent_t e : c->mc_ev) if (e) (void) hipEventDestroy(e);
   comm_release(c);
@@ -484,6 +494,10 @@ int check_device_flags(mrh_ctx* c, u32 flags) {
   if (flags & ERR_POOL) return fail(c, MRH_ERR_CAPACITY, "SDF block pool exhausted (num_sdf_blocks = %llu)", (unsigned long long) c->num_blocks);
   if (flags & ERR_TABLE) return fail(c, MRH_ERR_CAPACITY, "hash table probe limit reached (hash_slots = %llu)", (unsigned long long) c->slots);
   if (flags & ERR_TRI) return fail(c, MRH_ERR_CAPACITY, "triangle buffer full (max_triangles = %llu)", (unsigned long long) c->max_triangles);
+  if (flags & ERR_SCAN) {
+    c->scan_dirty = true;
+    return fail(c, MRH_ERR_DEVICE, "a LiDAR scan left its bounds (voxels per beam, touched blocks or chunks): the map is not usable");
+  }
   return MRH_OK;
 }
 
@@ -1035,6 +1049,7 @@ int mrh_create(const mrh_params* p, mrh_ctx** out) {
   if (const char* g = getenv("MRH_QTREE_LITERAL")) c->qt_literal = atoi(g) ? 1 : 0;
   if (const char* g = getenv("MRH_MR_FUSED")) c->mr_fused = atoi(g) ? 1 : 0;
   if (const char* g = getenv("MRH_LIDAR_SORT_ROCPRIM")) c->lidar_sort_rocprim = atoi(g) ? 1 : 0;
+  if (const char* g = getenv("MRH_LIDAR_BUCKETS")) c->lidar_buckets = atoi(g) ? 1 : 0;
   if (const char* g = getenv("MRH_REHASH_PERIOD")) { const int v = atoi(g); if (v > 0) c->census_period = v; }
   if (const char* g = getenv("MRH_REHASH_FORCE")) c->census_force = atoi(g) ? 1 : 0;
   if (const char* g = getenv("MRH_REHASH_OFF")) { if (atoi(g)) c->census_period = -1; }  // no upkeep at all (tests: shows what it prevents)
@@ -1937,6 +1952,70 @@ int lidar_sort(mrh_ctx* c, K* k0, K* k1, float* v0, float* v1, const size_t n, c
 
 extern "C" {
 
+// Scratch and buffers of the voxel-bucket scans (mrh_scan.h).  0: ready, 1: not on this context (the sorted path takes over), < 0: error.
+static int scan_prepare(mrh_ctx* c, const uint64_t n, const uint64_t rec_bound, const size_t walk_lds) {
+  hipStream_t s = c->stream;
+  Scan& sc = c->scan;
+  if (c->scan_state == 0) {
+    const size_t nb = (size_t) c->num_blocks;
+    bool ok = hipMalloc((void**) &sc.vcnt, nb * 512 * sizeof(u32)) == hipSuccess;
+    ok = ok && hipMalloc((void**) &sc.bstamp, nb * sizeof(u32)) == hipSuccess;
+    ok = ok && hipMalloc((void**) &sc.touched, nb * sizeof(u32)) == hipSuccess;
+    ok = ok && hipMalloc((void**) &c->d_scan_ctr, 2 * SC_N * sizeof(u32)) == hipSuccess;
+    if (!ok) {  // one counter per voxel slot does not fit next to this map
+      (void) hipGetLastError();
+      auto F = [](void* p) { if (p) (void) hipFree(p); };
+      F(sc.vcnt); F(sc.bstamp); F(sc.touched); F(c->d_scan_ctr);
+      sc.vcnt = sc.bstamp = sc.touched = c->d_scan_ctr = nullptr;
+      c->scan_state = -1;
+      return 1;
+    }
+    sc.touched_cap = (u32) nb;
+    HIP_TRY(c, hipMemsetAsync(sc.vcnt, 0, nb * 512 * sizeof(u32), s));
+    HIP_TRY(c, hipMemsetAsync(sc.bstamp, 0, nb * sizeof(u32), s));
+    HIP_TRY(c, hipMemsetAsync(c->d_scan_ctr, 0, 2 * SC_N * sizeof(u32), s));
+    c->scan_state = 1;
+    c->scan_dirty = false;
+  }
+  if (c->scan_dirty) {  // a scan that failed half way leaves counters behind
+    HIP_TRY(c, hipMemsetAsync(sc.vcnt, 0, (size_t) c->num_blocks * 512 * sizeof(u32), s));
+    HIP_TRY(c, hipMemsetAsync(c->d_scan_ctr, 0, 2 * SC_N * sizeof(u32), s));
+    c->scan_dirty = false;
+  }
+  if (rec_bound > c->scan_rec_cap) {
+    HIP_TRY(c, hipStreamSynchronize(s));
+    for (void* p : {(void*) sc.st_meta, (void*) sc.st_sdf, (void*) sc.st_grp, (void*) sc.rp, (void*) sc.rs, (void*) sc.chunks})
+      if (p) HIP_TRY(c, hipFree(p));
+    sc.st_meta = nullptr; sc.st_sdf = nullptr; sc.st_grp = nullptr; sc.rp = nullptr; sc.rs = nullptr; sc.chunks = nullptr;
+    c->scan_rec_cap = 0;
+    const uint64_t cap = rec_bound;
+    // chunks: one per touched block + one per 2^16 of weight (<= records / 128) + two per long run
+    const uint64_t chunk_cap = std::min<uint64_t>(c->num_blocks, cap) + cap / 128 + 64;
+    HIP_TRY(c, hipMalloc((void**) &sc.st_meta, cap * sizeof(uint2)));
+    HIP_TRY(c, hipMalloc((void**) &sc.st_sdf, cap * sizeof(float)));
+    HIP_TRY(c, hipMalloc((void**) &sc.st_grp, cap * sizeof(uint4)));
+    HIP_TRY(c, hipMalloc((void**) &sc.rp, cap * sizeof(u32)));
+    HIP_TRY(c, hipMalloc((void**) &sc.rs, cap * sizeof(float)));
+    HIP_TRY(c, hipMalloc((void**) &sc.chunks, chunk_cap * sizeof(uint4)));
+    sc.rec_cap = (u32) std::min<uint64_t>(cap, 0xFFFFFFF0ull);
+    sc.chunk_cap = (u32) std::min<uint64_t>(chunk_cap, 0xFFFFFFF0ull);
+    c->scan_rec_cap = cap;
+  }
+  const uint64_t wgs = (n + 255) / 256;
+  if (wgs > c->scan_wg_cap) {
+    HIP_TRY(c, hipStreamSynchronize(s));
+    if (sc.wgdesc) HIP_TRY(c, hipFree(sc.wgdesc));
+    sc.wgdesc = nullptr;
+    HIP_TRY(c, hipMalloc((void**) &sc.wgdesc, wgs * sizeof(uint2)));
+    c->scan_wg_cap = wgs;
+  }
+  if (walk_lds > 65536 && walk_lds > c->scan_lds_set) {
+    HIP_TRY(c, hipFuncSetAttribute((const void*) k_scan_walk, hipFuncAttributeMaxDynamicSharedMemorySize, (int) walk_lds));
+    c->scan_lds_set = walk_lds;
+  }
+  return 0;
+}
+
 // VoxelContainer::integrate(point_cloud, ...) voxel_data_structures.cpp:112-135 (mrh_lidar.h)
 int mrh_integrate_points(mrh_ctx* c, int n_frames_invalidate) {
   int rc = ensure_ready(c, "mrh_integrate_points");
@@ -1989,7 +2068,34 @@ int mrh_integrate_points(mrh_ctx* c, int n_frames_invalidate) {
     const int coarse_bit = bits_for((uint64_t) c->num_blocks * 512 - 1);
     const bool wide = coarse_bit + (t.multi_res ? 1 : 0) > 32;
     const size_t key_bytes = wide ? 8 : 4;
-    if (rec_bound > c->rec_cap || key_bytes > c->rec_key_bytes) {
+    // voxel buckets (mrh_scan.h) unless the map's voxel ids, the beam length or the memory say otherwise: then the sorted records below
+    bool buckets = c->lidar_buckets && c->scan_state >= 0 && !wide && (uint64_t) c->num_blocks * 512 < 0x7FFFFE00ull &&
+                   slots <= (uint64_t) kScanMaxSlots;
+    if (buckets) {
+      rc = scan_prepare(c, n, rec_bound, (size_t) (2 * slots * 256 + 2 * kScanSetSize) * sizeof(u32));
+      if (rc < 0) return rc;
+      buckets = rc == 0;
+    }
+    auto integrate_scan_buckets = [&]() -> int {
+      Scan sc = c->scan;
+      sc.seq = ++c->scan2_seq;
+      if (sc.seq == 0) {  // the stamps wrapped
+        HIP_TRY(c, hipMemsetAsync(sc.bstamp, 0, (size_t) c->num_blocks * sizeof(u32), s));
+        sc.seq = ++c->scan2_seq;
+      }
+      sc.ctr = c->d_scan_ctr + (sc.seq & 1u) * SC_N;
+      sc.ctr_next = c->d_scan_ctr + ((sc.seq + 1u) & 1u) * SC_N;
+      sc.ord_shift = t.multi_res ? 5 : 0;
+      const size_t lds = (size_t) (2 * slots * 256 + 2 * kScanSetSize) * sizeof(u32);
+      k_scan_walk<<<grid, 256, lds, s>>>(k, m, t, pts, normals, np, sc, (int) slots);
+      k_scan_collect<<<std::min<u32>(256u, (u32) ((c->num_blocks + 1023) / 1024)), 1024, 0, s>>>(t, sc, t.multi_res ? (u32) c->num_blocks : 0u);
+      k_scan_offsets<<<256, 1024, 0, s>>>(t, sc);
+      k_scan_place<<<grid, 256, 0, s>>>(sc, (int) slots);
+      k_scan_apply<<<2048, 256, 0, s>>>(m, t, sc, np << sc.ord_shift, c->profile);
+      HIP_TRY(c, hipGetLastError());
+      return MRH_OK;
+    };
+    if (!buckets && (rec_bound > c->rec_cap || key_bytes > c->rec_key_bytes)) {
       HIP_TRY(c, hipStreamSynchronize(s));
       for (int b = 0; b < 2; b++) {
         if (c->d_rec_keys[b]) HIP_TRY(c, hipFree(c->d_rec_keys[b]));
@@ -2004,7 +2110,7 @@ int mrh_integrate_points(mrh_ctx* c, int n_frames_invalidate) {
       c->rec_cap = cap;
       c->rec_key_bytes = std::max(key_bytes, c->rec_key_bytes);
     }
-    if (n > c->pt_cap) {
+    if (!buckets && n > c->pt_cap) {
       HIP_TRY(c, hipStreamSynchronize(s));
       if (c->d_pt_counts) HIP_TRY(c, hipFree(c->d_pt_counts));
       if (c->d_pt_offsets) HIP_TRY(c, hipFree(c->d_pt_offsets));
@@ -2061,7 +2167,7 @@ int mrh_integrate_points(mrh_ctx* c, int n_frames_invalidate) {
       HIP_TRY(c, hipGetLastError());
       return MRH_OK;
     };
-    rc = integrate_scan();
+    rc = buckets ? integrate_scan_buckets() : integrate_scan();
     if (rc) return rc;
     if (t.multi_res && c->frames > 0) {
       // checkVarSDF -> reallocBlocks -> flatAndReduceHashTable() -> reintegrate3D, which launches integrate3DKernel again
@@ -2071,7 +2177,7 @@ int mrh_integrate_points(mrh_ctx* c, int n_frames_invalidate) {
       HIP_TRY(c, hipMemsetAsync(&t.ctr[CTR_NREALLOC], 0, 2 * sizeof(int), s));  // NREALLOC, NREINT
       k_check_var<<<2048, 64, 0, s>>>(m, t, c->d_realloc);
       k_realloc<<<64, 256, 0, s>>>(t, c->d_realloc, c->d_reint);
-      rc = integrate_scan();
+      rc = buckets ? integrate_scan_buckets() : integrate_scan();
       if (rc) return rc;
     }
   }

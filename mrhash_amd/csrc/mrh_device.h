@@ -66,7 +66,7 @@ enum Ctr : int {
 // 64-bit profile counters
 enum Prof : int { PROF_UPDATED = 0, PROF_INSERTED = 1, PROF_FREED = 2, PROF_COMPACT = 3, PROF_COUNT = 4 };
 
-enum ErrBit : u32 { ERR_POOL = 1u, ERR_TABLE = 2u, ERR_RANGE = 4u, ERR_TRI = 8u };
+enum ErrBit : u32 { ERR_POOL = 1u, ERR_TABLE = 2u, ERR_RANGE = 4u, ERR_TRI = 8u, ERR_SCAN = 16u };
 
 struct Cam {
   float fx, fy, cx, cy, ifx, ify;

@@ -149,46 +149,13 @@ __device__ __forceinline__ u32 wg_sum_256(const u32 v, u32* s_part) {  // sum ov
   __syncthreads();
   return r;
 }
-template <bool EMIT, typename K>
-__global__ __launch_bounds__(256) void k_points_walk(const Cam c, const Map m, const Tab t, const float* __restrict__ pts,
-                                                     const float* __restrict__ normals, const u32 n, u32* __restrict__ counts,
-                                                     const ScanState ss, K* __restrict__ keys, float* __restrict__ vals,
-                                                     const int coarse_bit, const u32 rec_cap) {
-  // rec_cap: records the buffers hold.  The host sizes them by a bound on the voxels a beam can cross, but the bound is derived,
-  // not enforced by the walk (kMaxDdaIter is its only limit): a record beyond the capacity is not written, the host sees the
-  // total in the scan's report and fails the call cleanly
-  __shared__ u32 s_part[4];
-  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool live = i < n;
-  u32 cnt = 0;
-  u32 out = 0;
-  if (EMIT) {
-    // records of the points before this one: the earlier workgroups' totals + the earlier points of this workgroup
-    u32 before = 0;
-    for (u32 j = threadIdx.x; j < blockIdx.x; j += 256) before += ss.wg_totals[j];
-    const u32 base = wg_sum_256(before, s_part);
-    const u32 mine = live ? counts[i] : 0u;
-    u32 incl = mine;
-    const u32 lane = threadIdx.x & 63;
-    for (int off = 1; off < 64; off <<= 1) {
-      const u32 o = __shfl_up(incl, off);
-      if ((int) lane >= off) incl += o;
-    }
-    if (lane == 63) s_part[threadIdx.x >> 6] = incl;
-    __syncthreads();
-    u32 woff = 0;
-    for (u32 w = 0; w < (threadIdx.x >> 6); w++) woff += s_part[w];
-    out = base + woff + incl - mine;
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) {
-      // the scan's one report: the last workgroup knows the grand total before it starts its own walk; the host reads it (and
-      // sizes the sort) while the emit pass runs
-      ss.host_rec[0] = (u32) t.ctr[CTR_HWM_FINE];
-      ss.host_rec[1] = out + mine;
-      ss.host_rec[2] = 0;
-      __threadfence_system();
-      __hip_atomic_store(&ss.host_rec[3], ss.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-  }
+// One beam of integrate3DKernel (vds.cu:1215-1379): the voxel-level DDA over the segment range -+ truncation; rec(val, res, li,
+// sdf) is called for every traversed voxel of an allocated block (val = its table value, res = 1 on a coarse unit, li = the
+// voxel's index in the block, sdf clamped) up to the first voxel with sdf <= -truncation.  Both record paths (sorted records
+// below, voxel buckets in mrh_scan.h) walk through this one function: the arithmetic exists once.
+template <typename Rec>
+__device__ __forceinline__ void walk_beam(const Cam& c, const Map& m, const Tab& t, const float* __restrict__ pts,
+                                          const float* __restrict__ normals, const u32 i, const bool live, Rec&& rec) {
   const f3 pcam = live ? mk3(pts[3 * (size_t) i], pts[3 * (size_t) i + 1], pts[3 * (size_t) i + 2]) : mk3(0.f, 0.f, 0.f);
   const float range = norm3(pcam);
   const float tr = get_truncation(range, m.trunc, m.trunc_scale);
@@ -254,17 +221,7 @@ __global__ __launch_bounds__(256) void k_points_walk(const Cam c, const Map m, c
         if (sdf <= -tr) break;
         if (sdf >= 0.f) sdf = fminf(tr, sdf);
         else sdf = fmaxf(-tr, sdf);
-        if (EMIT) {
-          const u32 li = voxel_local_index(cur, res);
-          u64 vid;
-          if (res) { const u32 u = val & ~kValCoarseBit; vid = ((u64) (u >> 3) * 512u + (u64) (u & 7u) * 64u + li) | (1ull << coarse_bit); }
-          else vid = (u64) val * 512u + li;
-          if (out + cnt < rec_cap) {
-            keys[out + cnt] = (K) vid;
-            vals[out + cnt] = sdf;
-          }
-        }
-        cnt++;
+        rec(val, res, voxel_local_index(cur, res), sdf);
       }
       const bool ax = t_max.x < t_max.y && t_max.x < t_max.z;
       const bool az = !ax && (t_max.z < t_max.y);
@@ -276,6 +233,60 @@ __global__ __launch_bounds__(256) void k_points_walk(const Cam c, const Map m, c
       t_max.z = az ? t_max.z + t_delta.z : t_max.z;
     }
   }
+}
+
+template <bool EMIT, typename K>
+__global__ __launch_bounds__(256) void k_points_walk(const Cam c, const Map m, const Tab t, const float* __restrict__ pts,
+                                                     const float* __restrict__ normals, const u32 n, u32* __restrict__ counts,
+                                                     const ScanState ss, K* __restrict__ keys, float* __restrict__ vals,
+                                                     const int coarse_bit, const u32 rec_cap) {
+  // rec_cap: records the buffers hold.  The host sizes them by a bound on the voxels a beam can cross, but the bound is derived,
+  // not enforced by the walk (kMaxDdaIter is its only limit): a record beyond the capacity is not written, the host sees the
+  // total in the scan's report and fails the call cleanly
+  __shared__ u32 s_part[4];
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = i < n;
+  u32 cnt = 0;
+  u32 out = 0;
+  if (EMIT) {
+    // records of the points before this one: the earlier workgroups' totals + the earlier points of this workgroup
+    u32 before = 0;
+    for (u32 j = threadIdx.x; j < blockIdx.x; j += 256) before += ss.wg_totals[j];
+    const u32 base = wg_sum_256(before, s_part);
+    const u32 mine = live ? counts[i] : 0u;
+    u32 incl = mine;
+    const u32 lane = threadIdx.x & 63;
+    for (int off = 1; off < 64; off <<= 1) {
+      const u32 o = __shfl_up(incl, off);
+      if ((int) lane >= off) incl += o;
+    }
+    if (lane == 63) s_part[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    u32 woff = 0;
+    for (u32 w = 0; w < (threadIdx.x >> 6); w++) woff += s_part[w];
+    out = base + woff + incl - mine;
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) {
+      // the scan's one report: the last workgroup knows the grand total before it starts its own walk; the host reads it (and
+      // sizes the sort) while the emit pass runs
+      ss.host_rec[0] = (u32) t.ctr[CTR_HWM_FINE];
+      ss.host_rec[1] = out + mine;
+      ss.host_rec[2] = 0;
+      __threadfence_system();
+      __hip_atomic_store(&ss.host_rec[3], ss.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+  walk_beam(c, m, t, pts, normals, i, live, [&](const u32 val, const int res, const u32 li, const float sdf) {
+    if (EMIT) {
+      u64 vid;
+      if (res) { const u32 u = val & ~kValCoarseBit; vid = ((u64) (u >> 3) * 512u + (u64) (u & 7u) * 64u + li) | (1ull << coarse_bit); }
+      else vid = (u64) val * 512u + li;
+      if (out + cnt < rec_cap) {
+        keys[out + cnt] = (K) vid;
+        vals[out + cnt] = sdf;
+      }
+    }
+    cnt++;
+  });
   if (!EMIT) {
     if (live) counts[i] = cnt;
     const u32 total = wg_sum_256(cnt, s_part);

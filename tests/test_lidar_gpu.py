@@ -81,6 +81,29 @@ def test_many_beams_per_voxel_follow_the_point_order(hip, oracle):
     assert v["weight"].max() == 255  # clamped: far more than 255 updates reached some voxels
 
 
+@pytest.mark.parametrize("buckets", ["1", "0"], ids=["buckets", "sorted"])
+@pytest.mark.parametrize("n,spread", [(3000, 0.08), (30000, 0.08), (30000, 0.6)])
+def test_runs_of_every_length_follow_the_point_order(hip, oracle, monkeypatch, buckets, n, spread):
+    """Beams crowded onto a patch of a near wall: with a spread below the voxel size every beam crosses the same few voxels,
+    so a voxel's run is as long as the scan (3 000: sorted inside the LDS by the bitonic network of k_scan_apply; 30 000:
+    beyond the LDS, windows over the point index); with a wider patch the runs are a mix of tens to thousands.  The order
+    inside a run decides the result (running mean in fp32, weight clamp at 255), so every path must agree with the oracle's
+    sequential loop — twice, the second time with the points reversed."""
+    monkeypatch.setenv("MRH_LIDAR_BUCKETS", buckets)
+    a, b = _pair(hip, oracle, dict(virtual_voxel_size=0.25, sdf_truncation=0.5), blocks=16384)
+    rng = np.random.default_rng(n + int(spread * 100))
+    yz = rng.uniform(-spread, spread, (n, 2)) + 0.11
+    pts = np.concatenate([np.full((n, 1), 4.0) + rng.normal(0, 0.05, (n, 1)), yz], axis=1).astype(np.float32)
+    t, q = np.zeros(3, np.float32), np.array([0, 0, 0, 1], np.float32)
+    _feed((a, b), pts, t, q)
+    _feed((a, b), pts[::-1].copy(), t, q)
+    _feed((a, b), pts[: n // 3].copy(), t, q)
+    a.sync()
+    r = pu.compare_maps(a, b)
+    assert r["blocks"] >= 1 and r["sdf_bit_exact"] and r["sumsq_bit_exact"]
+    assert not a.stats().error_flags
+
+
 def test_far_from_origin_and_device_pointer(hip, oracle):
     from mrhash_amd import hipmem
 
@@ -128,12 +151,14 @@ def _drive(engines, n, rows, cols, step=1.5, normals=False, noise=0.0, seed=0):
             assert not e.integrate_points()
 
 
-@pytest.mark.parametrize("sort", ["own", "rocprim"])
+@pytest.mark.parametrize("sort", ["buckets", "own", "rocprim"])
 def test_full_size_vbr_scans_match_oracle(hip, oracle, monkeypatch, sort):
     """BASELINE configs[4] at its stated size: 128 x 1024 = 131 072 points per scan, vbr.cfg parameters, three scans of a
-    drive; occupancy, payload and mesh against the oracle — with the scan-sized record sort of mrh_sort.h and, as a
-    cross-check of it, with rocPRIM's (MRH_LIDAR_SORT_ROCPRIM=1): the fold is order-dependent, so a sort that were not stable
-    (or lost a record) would show up in the payload."""
+    drive; occupancy, payload and mesh against the oracle — through the voxel buckets of mrh_scan.h (the default), through
+    the sorted records of mrh_lidar.h with the scan-sized sort of mrh_sort.h (MRH_LIDAR_BUCKETS=0) and, as a cross-check of
+    that sort, with rocPRIM's (MRH_LIDAR_SORT_ROCPRIM=1): the fold is order-dependent, so a path that did not keep a voxel's
+    records in point order (or lost a record) would show up in the payload."""
+    monkeypatch.setenv("MRH_LIDAR_BUCKETS", "1" if sort == "buckets" else "0")
     monkeypatch.setenv("MRH_LIDAR_SORT_ROCPRIM", "1" if sort == "rocprim" else "0")
     a, b = _scan_pair(hip, oracle, dict(min_weight_threshold=1), blocks=262144)
     _drive((a, b), 3, 128, 1024, step=2.0, noise=0.02)
