@@ -391,7 +391,7 @@ def bench_single(args):
         dt = time.perf_counter() - t6
         npts = int(sum(len(sc) for sc in scans[w_scans:]))
         live_end = int(le.stats().occupied_fine)
-        # voxels a scan updates (one per (voxel, scan) pair: the runs k_points_apply folds), counted in a second pass in profile mode
+        # voxels a scan updates (one per (voxel, scan) pair: the runs k_scan_apply folds), counted in a second pass in profile mode
         le.reset()
         le.set_profile(True)
         run_scans(0, w_scans)
@@ -406,11 +406,12 @@ def bench_single(args):
                              "truncation 0.40 m, projective SDF), scans resident in HBM",
                  "scans_per_s": (n_scans - w_scans) / dt, "us_per_scan": us_scan, "points_per_s": npts / dt,
                  "points_per_scan": int(len(scans[0])), "live_blocks_end": live_end,
-                 "roofline": {"bound": "hbm", "kernel": "one scan: k_alloc3d + k_points_walk x 2 + record sort + k_points_apply", "achieved": ach_l,
+                 "roofline": {"bound": "hbm", "kernel": "one scan: k_alloc3d + k_scan_walk + k_scan_collect + k_scan_offsets + k_scan_place + k_scan_apply (mrh_scan.h: voxel buckets, no sort)", "achieved": ach_l,
                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_l / HBM_PEAK_GBS, "traffic": None,
                               "algorithmic_bytes_per_scan": alg_l, "updated_voxels_per_scan": upd,
-                              "note": "12 B per point read + 24 B per updated voxel (12 B read + 12 B write); a scan is a chain of latency-bound "
-                                      "launches over ~10^5 points and ~10^6 records, two orders of magnitude below the HBM roof"}}
+                              "note": "12 B per point read + 24 B per updated voxel (12 B read + 12 B write); a scan is a chain of six latency-bound "
+                                      "launches over ~10^5 points and ~10^6 records (each record written twice and read twice), two orders of "
+                                      "magnitude below the HBM roof"}}
         le.close()
         del d_scans
 
@@ -583,7 +584,7 @@ def bench_single(args):
         mc["roofline"]["traffic"], mc["roofline"]["traffic_note"] = pmc_traffic(args, ("mrh::k_mc<", "mrh::k_mc_emit_records"), cache, "--pmc-inner-mc", per_run_of=2)
 
     if lidar is not None and not args.no_pmc:  # HBM bytes of all kernels of a scan (every mrh:: launch of the sub-process / scans)
-        lidar["roofline"]["traffic"], lidar["roofline"]["traffic_note"] = pmc_traffic(args, ("mrh::k_alloc3d", "mrh::k_points_", "mrh::k_sort_"), cache, "--pmc-inner-lidar", per_run_of=LIDAR_SCANS)
+        lidar["roofline"]["traffic"], lidar["roofline"]["traffic_note"] = pmc_traffic(args, ("mrh::k_alloc3d", "mrh::k_points_", "mrh::k_sort_", "mrh::k_scan_"), cache, "--pmc-inner-lidar", per_run_of=LIDAR_SCANS)
 
     # ---- HBM traffic of the headline kernel, measured now (sub-processes under rocprofv3)
     if not args.no_pmc:

@@ -403,7 +403,7 @@ void free_all(mrh_ctx* c) {
   if (c->h_scan) (void) hipHostFree(c->h_scan);
   for (void* a : c->arena) if (a) (void) hipFree(a);
   F(c->d_decision); F(c->d_zbuf); F(c->d_realloc); F(c->d_reint); F(c->d_flag);
-  F(c->d_upd_partials); F(c->d_misc); F(c->d_rcp_w); F(c->d_cfree); F(c->d_zmin); F(c->d_points); F(c->d_pt_counts); F(c->d_pt_offsets); F(c->d_rec_keys[0]); F(c->d_rec_keys[1]); F(c->d_rec_vals[0]); F(c->d_rec_vals[1]); F(c->d_sort_tmp); F(c->scan.vcnt); F(c->scan.bstamp); F(c->scan.touched); F(c->scan.st_meta); F(c->scan.st_sdf); F(c->scan.st_grp); F(c->scan.wgdesc); F(c->scan.rp); F(c->scan.rs); F(c->scan.chunks); F(c->d_scan_ctr); F(c->fast.summary); F(c->fast.summary_c); F(c->fast.bbox); F(c->d_cnt_partials);
+  F(c->d_upd_partials); F(c->d_misc); F(c->d_rcp_w); F(c->d_cfree); F(c->d_zmin); F(c->d_points); F(c->d_pt_counts); F(c->d_pt_offsets); F(c->d_rec_keys[0]); F(c->d_rec_keys[1]); F(c->d_rec_vals[0]); F(c->d_rec_vals[1]); F(c->d_sort_tmp); F(c->scan.vcnt); F(c->scan.bstamp); F(c->scan.touched); F(c->scan.st_meta); F(c->scan.st_sdf); F(c->scan.st_grp); F(c->scan.wgdesc); F(c->scan.rec); F(c->scan.chunks); F(c->d_scan_ctr); F(c->fast.summary); F(c->fast.summary_c); F(c->fast.bbox); F(c->d_cnt_partials);
   F(c->d_pack); F(c->d_halo); F(c->d_taken); F(c->d_cloud); F(c->d_normals); F(c->d_soup); F(c->d_mc_recs);
   for (hipEvent_t e : c->mc_ev) if (e) (void) hipEventDestroy(e);
   comm_release(c);
@@ -713,34 +713,17 @@ int process_triangles_device(mrh_ctx* c, const mrh_triangle* d_tris, const size_
       dC = (double*) ((char*) vcf + vbytes);
       dF = (int*) ((char*) vcf + 2 * vbytes);
     }
-    // ---- vertices
-    MESH_TRY(hipMemsetAsync(table, 0xFF, (size_t) cap * 4, s));
-    k_mesh_vertex_insert<<<gv, 256, 0, s>>>(soup, n, eps, inv_eps, table, cap - 1);
-    k_mesh_vertex_rep<<<gv, 256, 0, s>>>(soup, n, eps, inv_eps, table, cap - 1, rep, first);
-    MESH_TRY(rocprim::exclusive_scan(tmp, tb, first, vid, 0u, n, rocprim::plus<u32>(), s));
-    k_mesh_emit_vertices<<<gv, 256, 0, s>>>(soup, rep, first, vid, n, dV, dC, corner);
-    // ---- faces
-    const u32 fcap = (u32) next_pow2((uint64_t) ntr * 2);
-    MESH_TRY(hipMemsetAsync(table, 0xFF, (size_t) fcap * 4, s));
-    k_mesh_face_insert<<<gf, 256, 0, s>>>(corner, ntr, table, fcap - 1);
-    k_mesh_face_keep<<<gf, 256, 0, s>>>(corner, ntr, table, fcap - 1, keep);
-    MESH_TRY(rocprim::exclusive_scan(tmp, tb, keep, fpos, 0u, ntr, rocprim::plus<u32>(), s));
-    k_mesh_emit_faces<<<gf, 256, 0, s>>>(corner, keep, fpos, ntr, dF);
-    k_mesh_totals<<<1, 1, 0, s>>>(vid, first, n, fpos, keep, ntr, d_totals);
-    const bool dbg = getenv("MRH_DEBUG") != nullptr;
-    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    const double t0 = now();
     // V, C, F go out behind the post-process without the host in between (k_copy_out reads the two totals on the device), into
-    // the buffers of the previous extraction; if they turn out too small (or not pinned) they grow and the copy runs again
+    // the buffers of the previous extraction; if they turn out too small (or not pinned) they grow and the copy runs again.
     const bool pinned = c->V.dev && c->C.dev && c->F.dev && !getenv("MRH_D2H_MEMCPY");  // MRH_D2H_MEMCPY=1: hipMemcpyAsync instead (A/B)
-    auto copy_out = [&](const bool by_kernel, const size_t nv_known, const size_t nf_known) {
+    auto copy_out = [&](const bool by_kernel, const int parts, hipStream_t on, const size_t nv_known, const size_t nf_known) {
       if (by_kernel) {
         CopyOut a;
-        a.src[0] = (const uint4*) dV; a.dst[0] = (uint4*) c->V.dev; a.count[0] = d_totals; a.cap[0] = c->V.cap / 3; a.unit[0] = 24;
-        a.src[1] = (const uint4*) dC; a.dst[1] = (uint4*) c->C.dev; a.count[1] = d_totals; a.cap[1] = c->C.cap / 3; a.unit[1] = 24;
-        a.src[2] = (const uint4*) dF; a.dst[2] = (uint4*) c->F.dev; a.count[2] = d_totals + 1; a.cap[2] = c->F.cap / 3; a.unit[2] = 12;
+        a.src[0] = (const uint4*) dV; a.dst[0] = (parts & 1) ? (uint4*) c->V.dev : nullptr; a.count[0] = d_totals; a.cap[0] = c->V.cap / 3; a.unit[0] = 24;
+        a.src[1] = (const uint4*) dC; a.dst[1] = (parts & 1) ? (uint4*) c->C.dev : nullptr; a.count[1] = d_totals; a.cap[1] = c->C.cap / 3; a.unit[1] = 24;
+        a.src[2] = (const uint4*) dF; a.dst[2] = (parts & 2) ? (uint4*) c->F.dev : nullptr; a.count[2] = d_totals + 1; a.cap[2] = c->F.cap / 3; a.unit[2] = 12;
         a.fixed[0] = a.fixed[1] = a.fixed[2] = 0;
-        k_copy_out<<<1024, 256, 0, s>>>(a);
+        k_copy_out<<<1024, 256, 0, on>>>(a);
         return hipGetLastError();
       }
       hipError_t e = hipMemcpyAsync(c->V.data(), dV, nv_known * 3 * sizeof(double), hipMemcpyDeviceToHost, s);
@@ -750,7 +733,28 @@ int process_triangles_device(mrh_ctx* c, const mrh_triangle* d_tris, const size_
     };
     const size_t cap_v = std::min(c->V.cap, c->C.cap) / 3, cap_f = c->F.cap / 3;
     const bool speculative = pinned && cap_v > 0 && c->V.data() && c->C.data() && c->F.data();
-    if (speculative) MESH_TRY(copy_out(true, 0, 0));
+    // ---- vertices
+    MESH_TRY(hipMemsetAsync(table, 0xFF, (size_t) cap * 4, s));
+    k_mesh_vertex_insert<<<gv, 256, 0, s>>>(soup, n, eps, inv_eps, table, cap - 1);
+    k_mesh_vertex_rep<<<gv, 256, 0, s>>>(soup, n, eps, inv_eps, table, cap - 1, rep, first);
+    MESH_TRY(rocprim::exclusive_scan(tmp, tb, first, vid, 0u, n, rocprim::plus<u32>(), s));
+    k_mesh_emit_vertices<<<gv, 256, 0, s>>>(soup, rep, first, vid, n, dV, dC, corner);
+    k_mesh_vertex_total<<<1, 1, 0, s>>>(vid, first, n, d_totals);
+    // ---- faces
+    const u32 fcap = (u32) next_pow2((uint64_t) ntr * 2);
+    MESH_TRY(hipMemsetAsync(table, 0xFF, (size_t) fcap * 4, s));
+    k_mesh_face_insert<<<gf, 256, 0, s>>>(corner, ntr, table, fcap - 1);
+    k_mesh_face_keep<<<gf, 256, 0, s>>>(corner, ntr, table, fcap - 1, keep);
+    MESH_TRY(rocprim::exclusive_scan(tmp, tb, keep, fpos, 0u, ntr, rocprim::plus<u32>(), s));
+    k_mesh_emit_faces<<<gf, 256, 0, s>>>(corner, keep, fpos, ntr, dF);
+    k_mesh_face_total<<<1, 1, 0, s>>>(fpos, keep, ntr, d_totals);
+    const bool dbg = getenv("MRH_DEBUG") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = now();
+    // (Tried in round 4: V and C on a second stream as soon as the vertices are final, next to the face kernels.  The copy kernel and
+    // k_mesh_face_insert do not share the memory system gracefully — the insert's atomics ran 37 -> 240-450 us whether the copy had
+    // 1 024 or 128 workgroups — and the extraction took as long as before.)
+    if (speculative) MESH_TRY(copy_out(true, 3, s, 0, 0));
     MESH_TRY(hipMemcpyAsync(c->h_mc + 2, d_totals, 2 * sizeof(u64), hipMemcpyDeviceToHost, s));
     MESH_TRY(hipStreamSynchronize(s));
     const double t1 = now();
@@ -759,7 +763,7 @@ int process_triangles_device(mrh_ctx* c, const mrh_triangle* d_tris, const size_
     c->V.resize_discard(nv * 3); c->C.resize_discard(nv * 3); c->F.resize_discard(std::max<size_t>(nf, 1) * 3);
     c->F.n = nf * 3;
     if (!fits) {
-      MESH_TRY(copy_out(c->V.dev && c->C.dev && c->F.dev && !getenv("MRH_D2H_MEMCPY"), nv, nf));
+      MESH_TRY(copy_out(c->V.dev && c->C.dev && c->F.dev && !getenv("MRH_D2H_MEMCPY"), 3, s, nv, nf));
       MESH_TRY(hipStreamSynchronize(s));
     }
     MESH_TRY(hipGetLastError());
@@ -1076,6 +1080,13 @@ int mrh_destroy(mrh_ctx* c) {
   if (getenv("MRH_DEBUG") && c->dbg_lazy_frames)
     fprintf(stderr, "[mrhash_hip] pipelined frames %llu: host waited %.1f us per frame for the ring, spent %.1f us per frame in the launch calls, %llu cross-stream waits\n",
             (unsigned long long) c->dbg_lazy_frames, c->dbg_spin_us / c->dbg_lazy_frames, c->dbg_api_us / c->dbg_lazy_frames, (unsigned long long) c->dbg_waits);
+  if (getenv("MRH_DEBUG") && c->d_scan_ctr && c->scan2_seq) {  // the last scan's counters (mrh_scan.h)
+    u32 h[2 * SC_N] = {0};
+    (void) hipStreamSynchronize(c->stream);
+    (void) hipMemcpy(h, c->d_scan_ctr, sizeof(h), hipMemcpyDeviceToHost);
+    const u32* k = h + (c->scan2_seq & 1u) * SC_N;
+    fprintf(stderr, "[mrhash_hip] last scan: %u touched blocks, %u records, %u chunks + %u runs beyond a wave\n", k[SC_TOUCHED], k[SC_PLACED], k[SC_CHUNKS], k[SC_BIG]);
+  }
 #ifdef MRH_TRACE
   if (const char* path = getenv("MRH_TRACE_FILE")) {  // tuning builds: phase timestamps of the last k_back launch
     if (c->fast.trace) {
@@ -1984,9 +1995,9 @@ static int scan_prepare(mrh_ctx* c, const uint64_t n, const uint64_t rec_bound, 
   }
   if (rec_bound > c->scan_rec_cap) {
     HIP_TRY(c, hipStreamSynchronize(s));
-    for (void* p : {(void*) sc.st_meta, (void*) sc.st_sdf, (void*) sc.st_grp, (void*) sc.rp, (void*) sc.rs, (void*) sc.chunks})
+    for (void* p : {(void*) sc.st_meta, (void*) sc.st_sdf, (void*) sc.st_grp, (void*) sc.rec, (void*) sc.chunks})
       if (p) HIP_TRY(c, hipFree(p));
-    sc.st_meta = nullptr; sc.st_sdf = nullptr; sc.st_grp = nullptr; sc.rp = nullptr; sc.rs = nullptr; sc.chunks = nullptr;
+    sc.st_meta = nullptr; sc.st_sdf = nullptr; sc.st_grp = nullptr; sc.rec = nullptr; sc.chunks = nullptr;
     c->scan_rec_cap = 0;
     const uint64_t cap = rec_bound;
     // chunks: one per touched block + one per 2^16 of weight (<= records / 128) + two per long run
@@ -1994,8 +2005,7 @@ static int scan_prepare(mrh_ctx* c, const uint64_t n, const uint64_t rec_bound, 
     HIP_TRY(c, hipMalloc((void**) &sc.st_meta, cap * sizeof(uint2)));
     HIP_TRY(c, hipMalloc((void**) &sc.st_sdf, cap * sizeof(float)));
     HIP_TRY(c, hipMalloc((void**) &sc.st_grp, cap * sizeof(uint4)));
-    HIP_TRY(c, hipMalloc((void**) &sc.rp, cap * sizeof(u32)));
-    HIP_TRY(c, hipMalloc((void**) &sc.rs, cap * sizeof(float)));
+    HIP_TRY(c, hipMalloc((void**) &sc.rec, cap * sizeof(uint4)));
     HIP_TRY(c, hipMalloc((void**) &sc.chunks, chunk_cap * sizeof(uint4)));
     sc.rec_cap = (u32) std::min<uint64_t>(cap, 0xFFFFFFF0ull);
     sc.chunk_cap = (u32) std::min<uint64_t>(chunk_cap, 0xFFFFFFF0ull);
@@ -2091,7 +2101,7 @@ int mrh_integrate_points(mrh_ctx* c, int n_frames_invalidate) {
       k_scan_collect<<<std::min<u32>(256u, (u32) ((c->num_blocks + 1023) / 1024)), 1024, 0, s>>>(t, sc, t.multi_res ? (u32) c->num_blocks : 0u);
       k_scan_offsets<<<256, 1024, 0, s>>>(t, sc);
       k_scan_place<<<grid, 256, 0, s>>>(sc, (int) slots);
-      k_scan_apply<<<2048, 256, 0, s>>>(m, t, sc, np << sc.ord_shift, c->profile);
+      k_scan_apply<<<1536, 256, 0, s>>>(m, t, sc, np << sc.ord_shift, c->profile);
       HIP_TRY(c, hipGetLastError());
       return MRH_OK;
     };
@@ -2494,7 +2504,7 @@ int mrh_extract_triangles(mrh_ctx* c, const mrh_triangle** out_tris, uint64_t* o
     // sorted list and the counts are read back only if somebody asks (mrh_get_triangle_blocks).
     u64 *k_in, *k_out, *d_offsets, *d_total;
     int4* sorted;
-    u32 *d_counts, *d_nb, *d_rec_base, *d_rec_n, *d_rec_ctr;
+    u32 *d_counts, *d_nb, *d_rec_base, *d_rec_n, *d_rec_ctr, *d_partial;
     uint8_t* d_per_voxel;  // triangles per voxel from the count pass: k_mc<emit> (the fallback of the record pass) skips the empty ones
     void* tmp;
     size_t sort_bytes = 0, scan_bytes = 0;
@@ -2503,25 +2513,32 @@ int mrh_extract_triangles(mrh_ctx* c, const mrh_triangle** out_tris, uint64_t* o
     const size_t tmp_bytes = std::max(sort_bytes, scan_bytes);
     {
       MeshScratch a;
-      a.bytes = (size_t) n * (8 * 3 + 16 + 4 + 4 * kMcNbStride + 512 + 8) + tmp_bytes + 32 * 256;
+      const size_t rank_words = n <= kRankSortMax ? (size_t) n * (size_t) ((n + kRankSlice - 1) / kRankSlice) : 1;  // k_block_rank: one row of partial ranks per slice
+      a.bytes = (size_t) n * (8 * 3 + 16 + 4 + 4 * kMcNbStride + 512 + 8) + rank_words * 4 + tmp_bytes + 32 * 256;
       rc = arena_get(c, 0, a.bytes, &a.base);
       if (rc) return rc;
       k_in = a.take<u64>((size_t) n); k_out = a.take<u64>((size_t) n); d_offsets = a.take<u64>((size_t) n);
       sorted = a.take<int4>((size_t) n); d_counts = a.take<u32>((size_t) n); d_nb = a.take<u32>((size_t) n * kMcNbStride);
       d_per_voxel = a.take<uint8_t>((size_t) n * 512); d_total = a.take<u64>(2);
       d_rec_base = a.take<u32>((size_t) n); d_rec_n = a.take<u32>((size_t) n); d_rec_ctr = a.take<u32>(2);
+      d_partial = a.take<u32>(rank_words);
       tmp = a.take<char>(tmp_bytes ? tmp_bytes : 1);
     }
     if (!c->h_mc) {
       HIP_TRY(c, hipHostMalloc((void**) &c->h_mc, 4 * sizeof(u64), hipHostMallocDefault));
       memset(c->h_mc, 0, 4 * sizeof(u64));
     }
-    {
+    const bool no_rank_sort = getenv("MRH_MC_RADIX_SORT") != nullptr;  // MRH_MC_RADIX_SORT=1: rocPRIM's sort + scan for every list (A/B, tests)
+    if (n <= kRankSortMax && !no_rank_sort) {  // canonical order by counting (mrh_mc.h: k_block_rank)
+      const int slices = (n + kRankSlice - 1) / kRankSlice;
+      k_block_rank<<<dim3((n + 255) / 256, slices), 256, 0, s>>>(c->tab.compact, n, d_partial);
+      k_block_scatter<<<(n + 255) / 256, 256, 0, s>>>(c->tab.compact, n, d_partial, slices, sorted);
+    } else {
       k_list_keys<<<(n + 255) / 256, 256, 0, s>>>(c->tab.compact, n, k_in);
       size_t bytes = tmp_bytes;
       HIP_TRY(c, rocprim::radix_sort_pairs(tmp, bytes, k_in, k_out, c->tab.compact, sorted, (size_t) n, 0, 63, s));
-      k_mc_neighbors<<<(int) (((size_t) n * 32 + 255) / 256), 256, 0, s>>>(c->tab, sorted, n, d_nb);
     }
+    k_mc_neighbors<<<(int) (((size_t) n * 32 + 255) / 256), 256, 0, s>>>(c->tab, sorted, n, d_nb);
     if (dbg) { HIP_TRY(c, hipStreamSynchronize(s)); t1 = now(); }
     const int grid = n < 8192 ? n : 8192;
     // largest truncation a stored sample can carry (integration clamps to trunc + scale * depth, depth <= the integration distance)
@@ -2554,7 +2571,10 @@ int mrh_extract_triangles(mrh_ctx* c, const mrh_triangle** out_tris, uint64_t* o
     if (timed) hipExtLaunchKernelGGL((k_mc<false>), dim3(grid), dim3(kMcThreads), 0, s, c->mc_ev[0], c->mc_ev[1], 0u, c->map, c->tab, (const int4*) sorted, n, (const u32*) d_nb,
                                      (u32*) d_counts, (const u64*) nullptr, (mrh_triangle*) nullptr, (u64) 0, (uint8_t*) d_per_voxel, sdf_bound, 0, R);
     else k_mc<false><<<grid, kMcThreads, 0, s>>>(c->map, c->tab, sorted, n, d_nb, d_counts, nullptr, nullptr, (u64) 0, d_per_voxel, sdf_bound, 0, R);
-    {
+    if (n <= kScanTotalMax && !no_rank_sort) {
+      k_mc_scan_total<<<1, 1024, 0, s>>>(d_counts, n, d_offsets, use_records ? d_rec_ctr : nullptr, d_total);
+      HIP_TRY(c, hipMemcpyAsync(c->h_mc, d_total, 2 * sizeof(u64), hipMemcpyDeviceToHost, s));
+    } else {
       size_t bytes = tmp_bytes;
       HIP_TRY(c, rocprim::exclusive_scan(tmp, bytes, d_counts, d_offsets, (u64) 0, (size_t) n, rocprim::plus<u64>(), s));
       k_mc_total<<<1, 1, 0, s>>>(d_offsets, d_counts, n, use_records ? d_rec_ctr : nullptr, d_total);

@@ -418,6 +418,68 @@ __global__ __launch_bounds__(256) void k_list_keys(const int4* __restrict__ list
   keys[i] = key;
 }
 
+// The block list in canonical order (packed key order == (x, y, z) order) without a sort library: a list has 10^3 .. 10^4 blocks
+// and every key is distinct, so a block's place is the number of keys below its own.  Grid (blocks / 256, slices of
+// kRankSlice keys): a workgroup counts, for its 256 blocks, the keys of one slice (staged in LDS, read as broadcasts) that
+// are smaller, and adds that to the block's rank; k_block_scatter then moves the entries.  n^2 comparisons — 5 x 10^7 for the
+// 7 000 blocks of a 640 x 480 room, a few microseconds of the whole chip — against rocPRIM's radix sort of 64-bit keys, which
+// for a list this small is one workgroup working for 74 us (profiles/r04/driver_cmd_mc_kernel_stats.csv).  Lists beyond
+// kRankSortMax keep the radix sort.
+constexpr int kRankSlice = 512;
+constexpr int kRankSortMax = 32768;
+__global__ __launch_bounds__(256) void k_block_rank(const int4* __restrict__ list, const int n, u32* __restrict__ partial) {
+  __shared__ u64 s_k[kRankSlice];
+  const int s0 = blockIdx.y * kRankSlice;
+  for (int j = threadIdx.x; j < kRankSlice; j += 256) {
+    u64 k = ~0ull;  // padding: never below a key
+    if (s0 + j < n) pack_key(mki3(list[s0 + j].x, list[s0 + j].y, list[s0 + j].z), k);
+    s_k[j] = k;
+  }
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  u64 key = 0;
+  if (i < n) pack_key(mki3(list[i].x, list[i].y, list[i].z), key);
+  __syncthreads();
+  u32 below = 0;
+#pragma unroll 8
+  for (int j = 0; j < kRankSlice; j++) below += s_k[j] < key ? 1u : 0u;
+  if (i < n) partial[(size_t) blockIdx.y * n + i] = below;  // one row per slice: plain stores, nothing to clear, no atomics
+}
+__global__ __launch_bounds__(256) void k_block_scatter(const int4* __restrict__ list, const int n, const u32* __restrict__ partial, const int slices,
+                                                       int4* __restrict__ sorted) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  u32 rank = 0;
+  for (int sl = 0; sl < slices; sl++) rank += partial[(size_t) sl * n + i];
+  sorted[rank] = list[i];
+}
+
+// per-block triangle counts -> exact offsets, the total and the record demand for the host: one workgroup, every thread a
+// contiguous piece of the list (sum, scan of the 1024 sums, offsets: two passes of independent loads); lists beyond
+// kScanTotalMax blocks keep rocPRIM's scan + k_mc_total
+constexpr int kScanTotalMax = 65536;
+__global__ __launch_bounds__(1024) void k_mc_scan_total(const u32* __restrict__ counts, const int n, u64* __restrict__ offsets,
+                                                        const u32* __restrict__ rec_ctr, u64* __restrict__ total) {
+  __shared__ u64 s_w[16];
+  const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int per = (n + 1023) / 1024, lo = min(n, (int) threadIdx.x * per), hi = min(n, lo + per);
+  u64 mine = 0;
+  for (int i = lo; i < hi; i++) mine += counts[i];
+  u64 incl = mine;
+  for (int off = 1; off < 64; off <<= 1) {
+    const u64 o = __shfl_up(incl, off);
+    if ((int) lane >= off) incl += o;
+  }
+  if (lane == 63) s_w[wave] = incl;
+  __syncthreads();
+  u64 run = incl - mine, all = 0;
+  for (u32 w = 0; w < 16; w++) { if (w < wave) run += s_w[w]; all += s_w[w]; }
+  for (int i = lo; i < hi; i++) { offsets[i] = run; run += counts[i]; }
+  if (threadIdx.x == 0) {
+    total[0] = all;
+    total[1] = rec_ctr ? ((u64) rec_ctr[0] | ((u64) (rec_ctr[1] & 1u) << 63)) : (1ull << 63);  // records asked for | did not fit
+  }
+}
+
 // One workgroup (256 threads) per block of the sorted list.
 //   1. the 27 surrounding blocks are resolved once (table value or absent)                              -> s_nb
 //   2. every voxel marching cubes can sample for this block is staged in LDS ({sdf, rgbw} per fine cell) -> halo

@@ -152,10 +152,11 @@ __global__ __launch_bounds__(256) void k_mesh_emit_faces(const u32* __restrict__
   const size_t o = (size_t) fpos[t] * 3;
   F[o] = (int) corner[3 * t]; F[o + 1] = (int) corner[3 * t + 1]; F[o + 2] = (int) corner[3 * t + 2];
 }
-// {unique vertices, kept faces} for the host, once everything else of the post-process has been enqueued
-__global__ void k_mesh_totals(const u32* __restrict__ vid, const u32* __restrict__ first, const u32 n, const u32* __restrict__ fpos,
-                              const u32* __restrict__ keep, const u32 nt, u64* __restrict__ out) {
+// {unique vertices, kept faces} for the host and for the copy kernel: each as soon as its half of the post-process is done
+__global__ void k_mesh_vertex_total(const u32* __restrict__ vid, const u32* __restrict__ first, const u32 n, u64* __restrict__ out) {
   out[0] = (u64) vid[n - 1] + first[n - 1];
+}
+__global__ void k_mesh_face_total(const u32* __restrict__ fpos, const u32* __restrict__ keep, const u32 nt, u64* __restrict__ out) {
   out[1] = (u64) fpos[nt - 1] + keep[nt - 1];
 }
 

@@ -11,16 +11,17 @@
 //                   group's size to the voxel's counter (neighbouring beams hit the same voxels: the hot voxels next to the
 //                   sensor take 10-30 x fewer atomics than records), marks the voxel's block as touched by this scan, and the
 //                   records + groups are parked in a stash (one allocation per workgroup, order irrelevant).
-//   k_scan_offsets  one wave per touched block: its 512 counters become offsets (block base from one atomic on the record
-//                   cursor — the order of the blocks in the buffer does not matter), and its voxels are cut into chunks of
-//                   bounded work for the last kernel (<= 4096 records and a bounded sum of squared run lengths; a run longer
+//   k_scan_collect  the blocks this scan touched, from their stamps.
+//   k_scan_offsets  one wave per touched block: its 512 counters become offsets (the bases of 16 blocks from one atomic on the
+//                   record cursor — the order of the blocks in the buffer does not matter), and its voxels are cut into chunks
+//                   of bounded work for the last kernel (< 512 records and a bounded sum of squared run lengths; a run longer
 //                   than kScanLongRun gets a chunk of its own).
-//   k_scan_place    per walk workgroup: one atomic per group reserves the group's slots behind the voxel's offset, the records
-//                   land there tagged with (point index, ordinal along the beam) — unordered inside the run.
-//   k_scan_apply    per chunk: records -> LDS, every record finds its rank inside its run (counting the smaller tags: runs are
-//                   short; a long run is sorted by a bitonic network instead, a run beyond the LDS by windows over the tag
-//                   range), then one lane per voxel folds the ordered run exactly as k_points_apply does, and the counters are
-//                   zero again for the next scan.
+//   k_scan_place    per walk workgroup: the records land in their voxel's run — start of the run + what the walk's atomic
+//                   returned + rank in the group — tagged with (point index, ordinal along the beam); unordered inside the run.
+//   k_scan_apply    per chunk, ONE WAVE: records -> LDS, every record finds its rank inside its run (counting the smaller tags:
+//                   runs are short; a long run is sorted by a bitonic network instead, a run beyond the LDS by windows over
+//                   the tag range), then one lane per voxel folds the ordered run exactly as k_points_apply does — the voxels
+//                   dealt to the lanes in order of falling run length —, and the counters are zero again for the next scan.
 //
 // Nothing is sorted globally, every record is written twice and read twice, and the host needs nothing back from the device
 // before the last launch is enqueued (the sorted path waits for the record count to size its sort).
@@ -34,15 +35,17 @@
 
 namespace mrh {
 
-constexpr u32 kScanSetSize = 4096;        // LDS set of a walk workgroup (distinct voxels of 256 beams: typically 600-1000)
+constexpr u32 kScanSetSize = 2048;        // LDS set of a walk workgroup (distinct voxels of 256 beams: typically 600-1000)
 constexpr int kScanSetProbe = 16;
+static_assert(kScanSetSize <= 4096 && (kScanSetSize & (kScanSetSize - 1)) == 0, "a set slot is kept in 12 bits");
 constexpr int kScanMaxSlots = 32;         // records per beam this path accepts (LDS of the walk: slots * 2 KB + 32 KB)
-constexpr u32 kScanChunkRecs = 2048;      // records an apply workgroup holds in LDS
-constexpr u32 kScanChunkWeight = 1u << 15;  // work bound of a chunk: sum of cnt * max(cnt, 32) stays below twice this
-constexpr u32 kScanLongRun = 128;         // a run longer than this is a chunk of its own (bitonic network / windows); its square must not exceed the weight
+constexpr u32 kScanWaveRecs = 512;        // records of a chunk: one WAVE of k_scan_apply holds them in its slice of the LDS
+constexpr u32 kScanChunkWeight = 1u << 13;  // work bound of a chunk: sum of cnt * max(cnt, 32) stays below twice this (so: < 512 records)
+constexpr u32 kScanLongRun = 64;          // a run longer than this is a chunk of its own (bitonic network); its square must not exceed the weight
+constexpr u32 kScanBigRecs = 2048;        // a run beyond a wave's slice is sorted by a whole workgroup (<= this: bitonic; beyond: windows)
 constexpr u32 kScanEmpty = 0xFFFFFFFFu;
 constexpr u32 kScanCoarse = 0x80000000u;  // voxel id of a coarse unit
-enum ScanCtr : int { SC_TOUCHED = 0, SC_PLACED = 1, SC_CHUNKS = 2, SC_N = 4 };
+enum ScanCtr : int { SC_TOUCHED = 0, SC_PLACED = 1, SC_CHUNKS = 2, SC_BIG = 3, SC_N = 4 };
 
 struct Scan {
   u32* vcnt;      // [pool blocks * 512] all zero between scans
@@ -54,9 +57,8 @@ struct Scan {
   float* st_sdf;
   uint4* st_grp;  // stash: {voxel id, records, records of the voxel that arrived before this group, 0}
   uint2* wgdesc;  // per walk workgroup {records, groups}
-  u32* rp;        // placed records: point index << ord_shift | ordinal
-  float* rs;
-  uint4* chunks;  // {block | coarse, v0 | v1 << 16, r0, r1}
+  uint4* rec;     // placed records: {point index << ord_shift | ordinal, sdf, the voxel's index in its block, 0}
+  uint4* chunks;  // {block | coarse, v0 | v1 << 16, r0, r1}; runs beyond kScanWaveRecs from the END of the array downwards
   u32 rec_cap, chunk_cap, touched_cap, seq;
   int ord_shift;  // 5 on variance-adaptive maps (a beam can cross several fine cells of one coarse voxel), else 0
 };
@@ -103,7 +105,7 @@ __global__ __launch_bounds__(256) void k_scan_walk(const Cam c, const Map m, con
   u32 ovf = 0;
   for (u32 j = 0; j < cnt; j++) {
     const u32 key = s_id[j * 256 + tid];
-    u32 h = (key * 0x9E3779B1u) >> 20;
+    u32 h = (key * 0x9E3779B1u) >> 21;
     bool ok = false;
 #pragma unroll 1
     for (int p = 0; p < kScanSetProbe; p++) {
@@ -137,25 +139,36 @@ __global__ __launch_bounds__(256) void k_scan_walk(const Cam c, const Map m, con
       if (key[k] != kScanEmpty) {
         sc.st_grp[off + g[k]] = make_uint4(key[k], cv[k], prev[k], 0u);
         const u32 H = (key[k] & ~kScanCoarse) >> 9, stamp = sc.seq * 2u + (key[k] >> 31);
-        if (sc.bstamp[H] != stamp) sc.bstamp[H] = stamp;  // every writer stores the same value
+        sc.bstamp[H] = stamp;  // every writer stores the same value (a test first would cost a dependent load per group)
       }
   }
   __syncthreads();
-  // C: the records
-  for (u32 j = 0; j < cnt; j++) {
-    const u32 v = s_id[j * 256 + tid];
-    u32 meta;
-    if ((ovf >> j) & 1u) {
-      const u32 g = atomicAdd(&s_ng, 1u);
-      const u32 prev = atomicAdd(&sc.vcnt[v & ~kScanCoarse], 1u);
-      sc.st_grp[off + g] = make_uint4(v, 1u, prev, 0u);
-      sc.bstamp[(v & ~kScanCoarse) >> 9] = sc.seq * 2u + (v >> 31);
-      meta = g;
-    } else {
-      meta = s_cnt[v & 0xFFFu] | ((v >> 12) << 13);
+  // C: the records, each wave's in its own part of the workgroup's stash, ordinal-major (the lanes that have a j-th record
+  // store it side by side: coalesced)
+  {
+    u32 pos = lane_off - (incl - cnt);  // records of the earlier waves
+    for (u32 j = 0;; j++) {
+      const bool has = j < cnt;
+      const u64 bal = __ballot(has);
+      if (!bal) break;
+      if (has) {
+        const u32 v = s_id[j * 256 + tid];
+        u32 meta;
+        if ((ovf >> j) & 1u) {
+          const u32 g = atomicAdd(&s_ng, 1u);
+          const u32 prev = atomicAdd(&sc.vcnt[v & ~kScanCoarse], 1u);
+          sc.st_grp[off + g] = make_uint4(v, 1u, prev, 0u);
+          sc.bstamp[(v & ~kScanCoarse) >> 9] = sc.seq * 2u + (v >> 31);
+          meta = g;
+        } else {
+          meta = s_cnt[v & 0xFFFu] | ((v >> 12) << 13);  // v = set slot (< 4096) | rank << 12
+        }
+        const u32 at = off + pos + (u32) __popcll(bal & lanemask_lt());
+        sc.st_meta[at] = make_uint2(meta, (tid << 5) | j);
+        sc.st_sdf[at] = s_sdf[j * 256 + tid];
+      }
+      pos += (u32) __popcll(bal);
     }
-    sc.st_meta[off + lane_off + j] = make_uint2(meta, (tid << 5) | j);
-    sc.st_sdf[off + lane_off + j] = s_sdf[j * 256 + tid];
   }
   __syncthreads();
   if (tid == 0) sc.wgdesc[blockIdx.x] = make_uint2(R, s_ng);
@@ -193,7 +206,7 @@ __global__ __launch_bounds__(1024) void k_scan_collect(const Tab t, const Scan s
 __global__ __launch_bounds__(1024) void k_scan_offsets(const Tab t, const Scan sc) {
   __shared__ u32 s_excl[16][513];
   __shared__ unsigned short s_start[16][514];
-  __shared__ u32 s_tot[16], s_nch[16], s_rbase, s_cbase;
+  __shared__ u32 s_tot[16], s_nch[16], s_nbig[16], s_rbase, s_cbase, s_bbase;
   const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const u32 nt = min(sc.ctr[SC_TOUCHED], sc.touched_cap);
   for (u32 t0 = blockIdx.x * 16u; t0 < nt; t0 += gridDim.x * 16u) {
@@ -207,7 +220,7 @@ __global__ __launch_bounds__(1024) void k_scan_offsets(const Tab t, const Scan s
     u32 w[8], sumc = 0, sumw = 0;
 #pragma unroll
     for (int k = 0; k < 8; k++) {
-      const u32 cc = min(cv[k], kScanChunkRecs);
+      const u32 cc = min(cv[k], 1024u);
       w[k] = min(cc * max(cc, 32u), kScanChunkWeight);
       sumc += cv[k];
       sumw += w[k];
@@ -247,26 +260,56 @@ __global__ __launch_bounds__(1024) void k_scan_offsets(const Tab t, const Scan s
 #pragma unroll
     for (int k = 0; k < 8; k++)
       if ((flags >> k) & 1u) s_start[wave][idx++] = (unsigned short) (lane * 8 + k);
-    if (lane == 0) { s_start[wave][nch_all] = 512; s_tot[wave] = total; s_nch[wave] = nch; }
+    // chunks of this block: small ones (a wave's work) from the front of the list, runs beyond a wave's slice from its end
+    if (lane == 0) s_start[wave][nch_all] = 512;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    u32 nbig = 0;
+    for (u32 k0 = 0; k0 < nch; k0 += 64) {
+      const u32 k = k0 + lane;
+      bool big = false;
+      if (k < nch) {
+        const u32 v0 = s_start[wave][k], v1 = s_start[wave][k + 1];
+        big = v1 - v0 == 1 && s_excl[wave][v1] - s_excl[wave][v0] > kScanWaveRecs;
+      }
+      nbig += (u32) __popcll(__ballot(big));
+    }
+    if (lane == 0) { s_tot[wave] = total; s_nch[wave] = nch - nbig; s_nbig[wave] = nbig; }
     __syncthreads();
-    if (tid == 0) {
-      u32 rt = 0, ct = 0;
-      for (int k = 0; k < 16; k++) { rt += s_tot[k]; ct += s_nch[k]; }
-      s_rbase = rt ? atomicAdd(&sc.ctr[SC_PLACED], rt) : 0u;
-      s_cbase = ct ? atomicAdd(&sc.ctr[SC_CHUNKS], ct) : 0u;
+    if (tid == 0 || tid == 64 || tid == 128) {  // three counters, three lanes: the round trips overlap
+      const u32* src = tid == 0 ? s_tot : tid == 64 ? s_nch : s_nbig;
+      u32 sum = 0;
+      for (int k = 0; k < 16; k++) sum += src[k];
+      const u32 got = sum ? atomicAdd(&sc.ctr[tid == 0 ? SC_PLACED : tid == 64 ? SC_CHUNKS : SC_BIG], sum) : 0u;
+      if (tid == 0) s_rbase = got; else if (tid == 64) s_cbase = got; else s_bbase = got;
     }
     __syncthreads();
     if (total) {
-      u32 base = s_rbase, cbase = s_cbase;
-      for (u32 k = 0; k < wave; k++) { base += s_tot[k]; cbase += s_nch[k]; }
+      u32 base = s_rbase, cbase = s_cbase, bbase = s_bbase, call = 0, ball = 0;
+      for (u32 k = 0; k < 16; k++) {
+        if (k < wave) { base += s_tot[k]; cbase += s_nch[k]; bbase += s_nbig[k]; }
+        call += s_nch[k]; ball += s_nbig[k];
+      }
       p[0] = make_uint4(base + st[0], base + st[1], base + st[2], base + st[3]);
       p[1] = make_uint4(base + st[4], base + st[5], base + st[6], base + st[7]);
-      if (cbase + nch > sc.chunk_cap) {
+      if (s_cbase + call + s_bbase + ball > sc.chunk_cap) {
         if (lane == 0) atomicOr((u32*) &t.ctr[CTR_ERROR], ERR_SCAN);
       } else {
-        for (u32 k = lane; k < nch; k += 64) {
-          const u32 v0 = s_start[wave][k], v1 = s_start[wave][k + 1];
-          sc.chunks[cbase + k] = make_uint4(Hc, v0 | (v1 << 16), base + s_excl[wave][v0], base + s_excl[wave][v1]);
+        for (u32 k0 = 0; k0 < nch; k0 += 64) {
+          const u32 k = k0 + lane;
+          bool big = false, small = false;
+          uint4 d = make_uint4(0, 0, 0, 0);
+          if (k < nch) {
+            const u32 v0 = s_start[wave][k], v1 = s_start[wave][k + 1];
+            d = make_uint4(Hc, v0 | (v1 << 16), base + s_excl[wave][v0], base + s_excl[wave][v1]);
+            big = v1 - v0 == 1 && d.w - d.z > kScanWaveRecs;
+            small = !big;
+          }
+          const u64 bs = __ballot(small), bb = __ballot(big);
+          if (small) sc.chunks[cbase + (u32) __popcll(bs & lanemask_lt())] = d;
+          if (big) sc.chunks[sc.chunk_cap - 1u - (bbase + (u32) __popcll(bb & lanemask_lt()))] = d;
+          cbase += (u32) __popcll(bs);
+          bbase += (u32) __popcll(bb);
         }
       }
     }
@@ -278,11 +321,13 @@ __global__ __launch_bounds__(1024) void k_scan_offsets(const Tab t, const Scan s
 // before the group (k_scan_walk's atomic) + rank inside the group.  No atomics.
 __global__ __launch_bounds__(256) void k_scan_place(const Scan sc, const int slots) {
   __shared__ u32 s_base[256 * kScanMaxSlots];
+  __shared__ unsigned short s_li[256 * kScanMaxSlots];
   const uint2 d = sc.wgdesc[blockIdx.x];
   const u32 off = blockIdx.x * 256u * (u32) slots, R = d.x, G = d.y;
   for (u32 g = threadIdx.x; g < G; g += 256) {
     const uint4 grp = sc.st_grp[off + g];
     s_base[g] = sc.vcnt[grp.x & ~kScanCoarse] + grp.z;
+    s_li[g] = (unsigned short) (grp.x & 511u);
   }
   __syncthreads();
   for (u32 r = threadIdx.x; r < R; r += 256) {
@@ -291,8 +336,7 @@ __global__ __launch_bounds__(256) void k_scan_place(const Scan sc, const int slo
     const u32 slot = s_base[meta.x & 0x1FFFu] + (meta.x >> 13);
     if (slot < sc.rec_cap) {
       const u32 pidx = blockIdx.x * 256 + (meta.y >> 5);
-      sc.rp[slot] = sc.ord_shift ? (pidx << 5) | (meta.y & 31u) : pidx;
-      sc.rs[slot] = sdf;
+      sc.rec[slot] = make_uint4(sc.ord_shift ? (pidx << 5) | (meta.y & 31u) : pidx, __float_as_uint(sdf), s_li[meta.x & 0x1FFFu], 0u);
     }
   }
 }
@@ -349,6 +393,69 @@ struct VoxFold {
     for (; i < n; i++) { step(pend); pend = vals[i]; }
     nfold = n;
   }
+  // A LONG run: the step's state apart from the running mean — the weight before step i, min(W + i w1, wmax), and the refined
+  // reciprocal of the weight sum — does not depend on the records.  Until the weight has reached its clamp (at most 255 steps)
+  // the other lanes lay that state out in LDS (fill_tables), after that it is constant: the one lane that folds is left with
+  // the chain itself — multiply, add, and the three operations of div_cr per record, a fifth of the instructions of step().
+  // Same operations on the same values: same bits.
+  static constexpr u32 kTable = 256;
+  __device__ __forceinline__ u32 steps_to_clamp() const {  // first step whose weight-before is wmax (w1 >= 1); 0 when W >= wmax
+    const u32 W = rgb0 >> 24;
+    if (W >= wmax || w1 == 0) return W == wmax ? 0u : 0xFFFFFFFFu;
+    return (wmax - W + w1 - 1) / w1;
+  }
+  template <int NT>
+  __device__ __forceinline__ void fill_tables(const u32 me, float* x, float* a, float* r, const u32 n) const {
+    const u32 W = rgb0 >> 24;
+    const u32 nt = min(min(steps_to_clamp(), kTable), n - 1);
+    for (u32 i = me; i < nt; i += NT) {
+      const u32 wi = i ? min(W + i * w1, wmax) : W;
+      a[i] = (float) wi;
+      r[i] = rcp_refined((float) (int) (wi + w1));
+    }
+    for (u32 i = me; i + 1 < n; i += NT) x[i] = x[i] * w1f;  // the last record keeps its value: end() needs it
+  }
+  __device__ __forceinline__ void run_tables(const float* x, const float* a, const float* r, const u32 n) {
+    const u32 W = rgb0 >> 24, clamp_at = steps_to_clamp();
+    float s = s0;
+    u32 i = 0;
+    if (!two && clamp_at <= kTable) {
+      const u32 nt = min(clamp_at, n - 1);
+      for (; i < nt; i++) s = div_cr(s * a[i] + x[i], a[i] + w1f, r[i]);
+      const float aw = (float) wmax, dw = (float) (int) (wmax + w1), rw = rcp_refined(dw);
+      if (i + 4 < n) {  // four records in registers while the four before them are folded: no step waits for the LDS
+        float x0 = x[i], x1 = x[i + 1], x2 = x[i + 2], x3 = x[i + 3];
+        for (; i + 8 < n; i += 4) {
+          const float y0 = x[i + 4], y1 = x[i + 5], y2 = x[i + 6], y3 = x[i + 7];
+          s = div_cr(s * aw + x0, dw, rw);
+          s = div_cr(s * aw + x1, dw, rw);
+          s = div_cr(s * aw + x2, dw, rw);
+          s = div_cr(s * aw + x3, dw, rw);
+          x0 = y0; x1 = y1; x2 = y2; x3 = y3;
+        }
+        s = div_cr(s * aw + x0, dw, rw);
+        s = div_cr(s * aw + x1, dw, rw);
+        s = div_cr(s * aw + x2, dw, rw);
+        s = div_cr(s * aw + x3, dw, rw);
+        i += 4;
+      }
+      for (; i + 1 < n; i++) s = div_cr(s * aw + x[i], dw, rw);
+    } else {  // a divisor that needs the full division, or a weight above its clamp: the general step (x is scaled by w1 already)
+      for (; i + 1 < n; i++) {
+        const u32 wi = i ? min(W + i * w1, wmax) : W;
+        const float num = s * (float) wi + x[i], den_i = (float) (int) (wi + w1);
+        s = two ? num / den_i : div_cr(num, den_i, rcp_refined(den_i));
+      }
+    }
+    // the state before the last record, as step() would have left it
+    const u32 last = n - 1;
+    s0 = s;
+    w0 = last ? min(W + last * w1, wmax) : W;
+    wsum = w0 + w1;
+    w0f = (float) w0; den = (float) (int) wsum; rden = rcp_refined(den);
+    pend = x[last];
+    nfold = n;
+  }
   __device__ __forceinline__ void end() {
     const float s_prev = s0, sdf_last = pend;  // the variance term of the LAST update (vds.cu:1352-1366) needs the state before it
     const u32 w_prev = w0;
@@ -365,146 +472,228 @@ struct VoxFold {
   }
 };
 
-__global__ __launch_bounds__(256) void k_scan_apply(const Map m, const Tab t, const Scan sc, const u32 tag_space, const int count_updates) {
-  constexpr int PER = kScanChunkRecs / 256;
-  __shared__ u32 s_tag[kScanChunkRecs];
-  __shared__ float s_sdf[kScanChunkRecs];
-  __shared__ float s_sorted[kScanChunkRecs];
-  __shared__ u32 s_end[513];          // s_end[u] = first record of run u, s_end[u + 1] = one past its last
-  __shared__ unsigned short s_order[512];
-  __shared__ u32 s_bcnt[16];
+__device__ __forceinline__ void wave_sync() {  // LDS written by the lanes of this wave is visible to all of them
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// Chunks -> voxels.  A chunk (< 512 records: a typical block has ~300 in ~50 voxels) is the work of ONE wave, in its slice of
+// the LDS, without workgroup barriers: 6 000 waves are resident, so all chunks of a scan are in flight at once and the kernel
+// lasts as long as its longest chain (a long run: sort + fold), not as long as a queue of chunks.  The few runs beyond a
+// wave's slice follow, a workgroup each.
+struct ApplyWaveLds {
+  u32 tag[kScanWaveRecs];
+  float sdf[kScanWaveRecs];
+  union {
+    struct { unsigned short st[514]; unsigned short order[512]; };  // st[u] = first record of run u, st[u + 1] = one past its last
+    struct { float a[VoxFold::kTable]; float r[VoxFold::kTable]; };  // a long run: the weights / reciprocals until the clamp
+  };
+  u32 bcnt[16];
+};
+
+// bitonic network over (tag, value) pairs in LDS; NT lanes, every stage's pairs read before any is written
+template <int NT, typename Sync>
+__device__ __forceinline__ void bitonic_lds(u32* tag, float* val, const u32 N, const u32 me, Sync&& sync) {
+  for (u32 k = 2; k <= N; k <<= 1) {
+    for (u32 j = k >> 1; j > 0; j >>= 1) {
+      for (u32 i0 = 0; i0 < N / 2; i0 += 4 * NT) {
+        u32 lo[4], ta[4], tb[4];
+        float va[4], vb[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const u32 i = i0 + q * NT + me;
+          lo[q] = ((i & ~(j - 1)) << 1) | (i & (j - 1));
+          if (i < N / 2) { ta[q] = tag[lo[q]]; tb[q] = tag[lo[q] | j]; va[q] = val[lo[q]]; vb[q] = val[lo[q] | j]; }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const u32 i = i0 + q * NT + me;
+          if (i < N / 2 && (ta[q] > tb[q]) == ((lo[q] & k) == 0)) {
+            tag[lo[q]] = tb[q]; tag[lo[q] | j] = ta[q];
+            val[lo[q]] = vb[q]; val[lo[q] | j] = va[q];
+          }
+        }
+      }
+      sync();
+    }
+  }
+}
+
+__global__ __launch_bounds__(256, 6) void k_scan_apply(const Map m, const Tab t, const Scan sc, const u32 tag_space, const int count_updates) {
+  __shared__ ApplyWaveLds s_w[4];
   __shared__ u32 s_part[4];
+  static_assert(sizeof(ApplyWaveLds) * 4 >= kScanBigRecs * 12, "the workgroup pass reuses the waves' slices");
   const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const u32 nch = min(sc.ctr[SC_CHUNKS], sc.chunk_cap);
+  const u32 n_small = min(sc.ctr[SC_CHUNKS], sc.chunk_cap);
+  const u32 n_big = min(sc.ctr[SC_BIG], sc.chunk_cap - n_small);
   u32 updated = 0;
-  for (u32 ci = blockIdx.x; ci < nch; ci += gridDim.x) {
+  ApplyWaveLds& L = s_w[wave];
+  for (u32 ci = blockIdx.x * 4u + wave; ci < n_small; ci += gridDim.x * 4u) {
     const uint4 ch = sc.chunks[ci];
     const u32 H = ch.x & ~kScanCoarse, v0 = ch.y & 0xFFFFu, v1 = ch.y >> 16, r0 = ch.z, nr = ch.w - ch.z, nv = v1 - v0;
     const bool coarse = (ch.x & kScanCoarse) != 0;
-    for (u32 u = tid; u < nv; u += 256) {  // where the runs start; the counters are zero again for the next scan
-      u32* p = sc.vcnt + (size_t) H * 512 + v0 + u;
-      s_end[u] = *p - r0;
-      *p = 0;
+    const bool long_run = nv == 1 && nr > kScanLongRun;
+    u32* pc = sc.vcnt + (size_t) H * 512 + v0 + lane;
+    if (nr == 0 || long_run) {  // nothing to order by voxel: the counters are zero again for the next scan
+#pragma unroll
+      for (int r = 0; r < 8; r++)
+        if (lane + 64u * r < nv) pc[64 * r] = 0;
+      if (nr == 0) continue;
     }
-    if (tid == 0) s_end[nv] = nr;
-    if (tid < 16) s_bcnt[tid] = 0;
-    if (nr == 0) { __syncthreads(); continue; }
-    if (nv == 1 && nr > kScanLongRun) {
-      VoxFold f;
-      if (tid == 0) f.begin(m, t, H, coarse, v0);
-      if (nr <= kScanChunkRecs) {  // one long run: bitonic network over the tags
-        u32 N = 256;
-        while (N < nr) N <<= 1;
-        for (u32 q = tid; q < N; q += 256) {
-          s_tag[q] = q < nr ? sc.rp[r0 + q] : kScanEmpty;
-          s_sdf[q] = q < nr ? sc.rs[r0 + q] : 0.f;
-        }
-        __syncthreads();
-        for (u32 k = 2; k <= N; k <<= 1) {
-          for (u32 j = k >> 1; j > 0; j >>= 1) {
-            for (u32 i = tid; i < N / 2; i += 256) {
-              const u32 lo = ((i & ~(j - 1)) << 1) | (i & (j - 1)), hi = lo | j;
-              const bool asc = (lo & k) == 0;
-              const u32 a = s_tag[lo], b = s_tag[hi];
-              if ((a > b) == asc) {
-                s_tag[lo] = b; s_tag[hi] = a;
-                const float x = s_sdf[lo];
-                s_sdf[lo] = s_sdf[hi]; s_sdf[hi] = x;
-              }
-            }
-            __syncthreads();
-          }
-        }
-        if (tid == 0) f.run(s_sdf, nr);
-      } else {  // beyond the LDS: windows over the tag range, every tag is unique inside a voxel -> direct addressing
-        for (u32 w0 = 0; w0 < tag_space; w0 += kScanChunkRecs) {
-          for (u32 q = tid; q < kScanChunkRecs; q += 256) s_tag[q] = 0;
-          __syncthreads();
-          for (u32 q = tid; q < nr; q += 256) {
-            const u32 d = sc.rp[r0 + q] - w0;
-            if (d < kScanChunkRecs) { s_sdf[d] = sc.rs[r0 + q]; s_tag[d] = 1; }
-          }
-          __syncthreads();
-          // in-order compaction: thread t owns slots [PER t, PER t + PER)
-          u32 mine = 0;
-#pragma unroll
-          for (int k = 0; k < PER; k++) mine += s_tag[tid * PER + k];
-          u32 incl = mine;
-          for (int off = 1; off < 64; off <<= 1) {
-            const u32 o = __shfl_up(incl, off);
-            if ((int) lane >= off) incl += o;
-          }
-          if (lane == 63) s_part[wave] = incl;
-          __syncthreads();
-          u32 pos = incl - mine, tot = 0;
-          for (u32 w = 0; w < 4; w++) { if (w < wave) pos += s_part[w]; tot += s_part[w]; }
-#pragma unroll
-          for (int k = 0; k < PER; k++)
-            if (s_tag[tid * PER + k]) s_sorted[pos++] = s_sdf[tid * PER + k];
-          __syncthreads();
-          if (tid == 0)
-            for (u32 q = 0; q < tot; q++) f.push(s_sorted[q]);
-          __syncthreads();
-        }
+    if (long_run) {  // one long run: bitonic network over the tags, then one lane folds
+      u32 N = 128;
+      while (N < nr) N <<= 1;
+      for (u32 q = lane; q < N; q += 64) {
+        const uint4 rc = q < nr ? sc.rec[r0 + q] : make_uint4(kScanEmpty, 0u, 0u, 0u);
+        L.tag[q] = rc.x;
+        L.sdf[q] = __uint_as_float(rc.y);
       }
-      if (tid == 0) { f.end(); updated++; }
-      __syncthreads();
+      VoxFold f;
+      f.begin(m, t, H, coarse, v0);  // every lane (one address): the tables start from the voxel's weight
+      wave_sync();
+      bitonic_lds<64>(L.tag, L.sdf, N, lane, [] { wave_sync(); });
+      f.fill_tables<64>(lane, L.sdf, L.a, L.r, nr);
+      wave_sync();
+      if (lane == 0) {
+        f.run_tables(L.sdf, L.a, L.r, nr);
+        f.end();
+        updated++;
+      }
+      wave_sync();
       continue;
     }
-    for (u32 q = tid; q < nr; q += 256) { s_tag[q] = sc.rp[r0 + q]; s_sdf[q] = sc.rs[r0 + q]; }
-    __syncthreads();
-    for (u32 q = tid; q < nr; q += 256) {  // rank of record q inside its run
-      u32 lo = 0, hi = nv;  // largest u with s_end[u] <= q (empty runs share a start: the last of them is the run that holds q)
-      while (hi - lo > 1) {
-        const u32 mid = (lo + hi) >> 1;
-        if (s_end[mid] <= q) lo = mid; else hi = mid;
-      }
-      const u32 a = s_end[lo], b = s_end[lo + 1];
-      u32 rank = 0;
-      if (b - a > 1) {
-        const u32 tag = s_tag[q];
-        for (u32 j = a; j < b; j++) rank += s_tag[j] < tag ? 1u : 0u;
-      }
-      s_sorted[a + rank] = s_sdf[q];
-    }
-    // the voxels in order of falling run length (by power of two): the lanes of a wave then fold runs of similar length, and a
-    // wave is as slow as its longest run
-    u32 myb[2], mypos[2];
+    // all loads of the chunk first (a store in between would order them): where the runs start, the records
+    u32 stv[8], tg[8], li[8];
+    float sv[8];
 #pragma unroll
-    for (int r = 0; r < 2; r++) {
-      const u32 u = tid + 256u * r;
+    for (int r = 0; r < 8; r++) {
+      stv[r] = lane + 64u * r < nv ? pc[64 * r] : 0u;
+      const u32 q = lane + 64u * r;
+      tg[r] = 0; li[r] = 0; sv[r] = 0.f;
+      if (q < nr) { const uint4 rc = sc.rec[r0 + q]; tg[r] = rc.x; sv[r] = __uint_as_float(rc.y); li[r] = rc.z; }
+    }
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+      if (lane + 64u * r < nv) { L.st[lane + 64u * r] = (unsigned short) (stv[r] - r0); pc[64 * r] = 0; }
+      if (lane + 64u * r < nr) L.tag[lane + 64u * r] = tg[r];
+    }
+    if (lane == 0) L.st[nv] = (unsigned short) nr;
+    if (lane < 16) L.bcnt[lane] = 0;
+    wave_sync();
+    // rank of every record inside its run (the tags smaller than its own), then the values into run order
+    u32 pos[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+      pos[r] = 0;
+      if (lane + 64u * r < nr) {
+        const u32 u = li[r] - v0, a = L.st[u], b = L.st[u + 1];
+        u32 rank = 0;
+        for (u32 j = a; j < b; j++) rank += L.tag[j] < tg[r] ? 1u : 0u;
+        pos[r] = a + rank;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 8; r++)
+      if (lane + 64u * r < nr) L.sdf[pos[r]] = sv[r];
+    // the voxels in order of falling run length (by power of two): the lanes then fold runs of similar length at the same
+    // time, and a wave is as slow as its longest run
+    u32 myb[8], mypos[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+      const u32 u = lane + 64u * r;
       myb[r] = 16;
       if (u < nv) {
-        const u32 len = s_end[u + 1] - s_end[u];
-        if (len) { myb[r] = 31u - (u32) __clz(len); mypos[r] = atomicAdd(&s_bcnt[myb[r]], 1u); }
+        const u32 len = (u32) L.st[u + 1] - (u32) L.st[u];
+        if (len) { myb[r] = 31u - (u32) __clz(len); mypos[r] = atomicAdd(&L.bcnt[myb[r]], 1u); }
       }
     }
-    __syncthreads();
+    wave_sync();
     u32 nnz = 0;
     {
       u32 boff[16], run = 0;
 #pragma unroll
-      for (int b = 15; b >= 0; b--) { boff[b] = run; run += s_bcnt[b]; }
+      for (int b = 15; b >= 0; b--) { boff[b] = run; run += L.bcnt[b]; }
       nnz = run;
 #pragma unroll
-      for (int r = 0; r < 2; r++)
+      for (int r = 0; r < 8; r++)
         if (myb[r] < 16) {
           u32 o = 0;
 #pragma unroll
           for (int b = 0; b < 16; b++) o = myb[r] == (u32) b ? boff[b] : o;
-          s_order[o + mypos[r]] = (unsigned short) (tid + 256u * r);
+          L.order[o + mypos[r]] = (unsigned short) (lane + 64u * r);
         }
     }
-    __syncthreads();
-    for (u32 i = tid; i < nnz; i += 256) {
-      const u32 u = s_order[i];
-      const u32 a = s_end[u], b = s_end[u + 1];
+    wave_sync();
+    for (u32 i = lane; i < nnz; i += 64) {
+      const u32 u = L.order[i];
+      const u32 a = L.st[u], b = L.st[u + 1];
       VoxFold f;
       f.begin(m, t, H, coarse, v0 + u);
-      f.run(s_sorted + a, b - a);
+      f.run(L.sdf + a, b - a);
       f.end();
       updated++;
     }
+    wave_sync();
+  }
+  // runs beyond a wave's slice: one workgroup each, over the same LDS
+  __syncthreads();
+  u32* s_tag = (u32*) &s_w[0];
+  float* s_sdf = (float*) (s_tag + kScanBigRecs);
+  float* s_sorted = s_sdf + kScanBigRecs;  // windows only; the tables of the bitonic path lie here
+  constexpr int PER = kScanBigRecs / 256;
+  for (u32 bi = blockIdx.x; bi < n_big; bi += gridDim.x) {
+    const uint4 ch = sc.chunks[sc.chunk_cap - 1u - bi];
+    const u32 H = ch.x & ~kScanCoarse, v0 = ch.y & 0xFFFFu, r0 = ch.z, nr = ch.w - ch.z;
+    const bool coarse = (ch.x & kScanCoarse) != 0;
+    if (tid == 0) sc.vcnt[(size_t) H * 512 + v0] = 0;
+    VoxFold f;
+    f.begin(m, t, H, coarse, v0);
+    if (nr <= kScanBigRecs) {
+      u32 N = 1024;
+      while (N < nr) N <<= 1;
+      for (u32 q = tid; q < N; q += 256) {
+        const uint4 rc = q < nr ? sc.rec[r0 + q] : make_uint4(kScanEmpty, 0u, 0u, 0u);
+        s_tag[q] = rc.x;
+        s_sdf[q] = __uint_as_float(rc.y);
+      }
+      __syncthreads();
+      bitonic_lds<256>(s_tag, s_sdf, N, tid, [] { __syncthreads(); });
+      f.fill_tables<256>(tid, s_sdf, s_sorted, s_sorted + VoxFold::kTable, nr);
+      __syncthreads();
+      if (tid == 0) f.run_tables(s_sdf, s_sorted, s_sorted + VoxFold::kTable, nr);
+    } else {  // beyond the LDS: windows over the tag range, every tag is unique inside a voxel -> direct addressing
+      for (u32 w0 = 0; w0 < tag_space; w0 += kScanBigRecs) {
+        for (u32 q = tid; q < kScanBigRecs; q += 256) s_tag[q] = 0;
+        __syncthreads();
+        for (u32 q = tid; q < nr; q += 256) {
+          const uint4 rc = sc.rec[r0 + q];
+          const u32 d = rc.x - w0;
+          if (d < kScanBigRecs) { s_sdf[d] = __uint_as_float(rc.y); s_tag[d] = 1; }
+        }
+        __syncthreads();
+        // in-order compaction: thread t owns slots [PER t, PER t + PER)
+        u32 mine = 0;
+#pragma unroll
+        for (int k = 0; k < PER; k++) mine += s_tag[tid * PER + k];
+        u32 incl = mine;
+        for (int off = 1; off < 64; off <<= 1) {
+          const u32 o = __shfl_up(incl, off);
+          if ((int) lane >= off) incl += o;
+        }
+        if (lane == 63) s_part[wave] = incl;
+        __syncthreads();
+        u32 pos = incl - mine, tot = 0;
+        for (u32 w = 0; w < 4; w++) { if (w < wave) pos += s_part[w]; tot += s_part[w]; }
+#pragma unroll
+        for (int k = 0; k < PER; k++)
+          if (s_tag[tid * PER + k]) s_sorted[pos++] = s_sdf[tid * PER + k];
+        __syncthreads();
+        if (tid == 0)
+          for (u32 q = 0; q < tot; q++) f.push(s_sorted[q]);
+        __syncthreads();
+      }
+    }
+    if (tid == 0) { f.end(); updated++; }
     __syncthreads();
   }
   if (count_updates && updated) atomicAdd(&t.prof[PROF_UPDATED], (u64) updated);  // profile mode: voxels this scan updated

@@ -535,6 +535,25 @@ def test_emit_from_corner_records_equals_the_two_pass_emit(hip, monkeypatch, var
     e.close()
 
 
+def test_block_order_by_counting_equals_the_radix_sort(hip, monkeypatch):
+    """The extraction's canonical block order comes from a rank-by-counting pass (k_block_rank) with the offsets from a
+    one-workgroup scan; rocPRIM's radix sort + scan stay for long lists (MRH_MC_RADIX_SORT=1 forces them).  Same soup,
+    same V / F / C, byte for byte."""
+    e = pu.make_engine(hip, synth.REPLICA_640, synth.REPLICA_PARAMS, 131072)
+    for f in synth.replica_stream(8):
+        pu.feed(e, f)
+    e.sync()
+    soup = e.extract_triangles().tobytes()
+    mesh = [a.tobytes() for a in e.extract_mesh()]
+    again = [a.tobytes() for a in (e.extract_triangles(), *e.extract_mesh())]  # second extraction: the speculative copy
+    assert again[0] == soup and again[1:] == mesh
+    monkeypatch.setenv("MRH_MC_RADIX_SORT", "1")
+    ref = [a.tobytes() for a in (e.extract_triangles(), *e.extract_mesh())]
+    assert len(soup) > 72 * 100000
+    assert ref[0] == soup and ref[1:] == mesh
+    e.close()
+
+
 def test_stream_out_and_import_match_oracle(hip, oracle):
     """Streamer device half (mrh_stream_out / mrh_import_blocks): the same blocks leave, in position order, with the
     same payload; what stays is the same map; importing them back restores the original; fusion continues identically."""
