@@ -84,6 +84,7 @@ template <typename T>
 struct HostVec {
   T* p = nullptr;    // host pointer
   T* dev = nullptr;  // the same memory as the device sees it (nullptr: not registered)
+  bool pin = true;   // false: a plain huge-page mapping the device never touches (V / C doubles, filled by the host's widening)
   size_t n = 0, cap = 0;
   size_t span = 0, head = 0;  // the mapping: its size and the bytes between its base and p
   HostVec() = default;
@@ -119,7 +120,9 @@ struct HostVec {
       head = (size_t) (aligned - (char*) m);
       p = (T*) aligned;
       void* d = nullptr;
-      if (hipHostRegister(aligned, bytes, hipHostRegisterDefault) == hipSuccess && hipHostGetDevicePointer(&d, aligned, 0) == hipSuccess && d) {
+      if (!pin) {
+        dev = nullptr;
+      } else if (hipHostRegister(aligned, bytes, hipHostRegisterDefault) == hipSuccess && hipHostGetDevicePointer(&d, aligned, 0) == hipSuccess && d) {
         dev = (T*) d;
       } else {
         (void) hipGetLastError();
@@ -295,6 +298,11 @@ struct mrh_ctx {
   uint64_t mc_rec_fallbacks = 0;                    // extractions whose records did not fit (emitted by k_mc<emit> instead)
   HostVec<double> V, C;
   HostVec<int32_t> F;
+  // V and C cross the link in fp32 (k_stage_out) and are widened by the host while the rest is still on its way (widen_from_staging)
+  HostVec<float> V32, C32;     // pinned staging
+  HostVec<u32> stage_ctl;      // pinned: [0..5] {vertices, faces, epoch} as three u64, [16..] one flag word per 64 KiB chunk of V32, then of C32
+  u32 stage_epoch = 0;
+  bool f64_link = false;       // MRH_MESH_F64_LINK=1: V / C widened on the device and copied as doubles (the round-3 path; A/B, tests)
   // profiling
   int profile = 0;
   std::vector<EvPair> ev_pool;
@@ -666,6 +674,69 @@ __global__ __launch_bounds__(256) void k_copy_out(const CopyOut a) {
     for (size_t i = (size_t) blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t) gridDim.x * 256) a.dst[p][i] = a.src[p][i];
   }
 }
+// V / C / F of an extraction are 48 B per vertex + 12 B per face as the reference hands them out (Eigen::MatrixXd / MatrixXi,
+// geowrapper.h:91-93) — 30 MB at the driver's workload, 0.56 ms of a 1.3 ms extraction at the link's 54 GB/s.  The vertex
+// arithmetic is fp32 (mesh_extractor.cu:6-36), so the doubles carry no more than the floats they are widened from: V and C cross the
+// link as fp32 (24 B per vertex) into pinned staging, in 64 KiB chunks that each raise a flag word when they have landed, and
+// host threads widen chunk after chunk into the caller-visible double arrays while the following chunks and the faces are still
+// on the link (widen_from_staging below; (double) (float) is exact, the arrays are the same bytes as before).  F goes straight
+// to its final buffer.  Few workgroups, each walking its chunks in order: the link is the bottleneck, and chunks must COMPLETE in
+// order for the host to overlap, not all at the end.
+constexpr u32 kStageChunk = 64u << 10;            // bytes
+constexpr u32 kStageWords = kStageChunk / 16;     // uint4 per chunk
+constexpr u32 kStageHdrWords = 16;                // u32 words of stage_ctl before the first flag
+struct StageOut {
+  const uint4* src[3];   // device: V32, C32, F
+  uint4* dst[3];         // pinned: V32 staging, C32 staging, F
+  const u64* totals;     // device: [0] vertices, [1] faces
+  u64 cap_v, cap_f;      // elements the destinations hold
+  u64* hdr;              // pinned: [0] vertices, [1] faces, [2] epoch (written last)
+  u32* flags;            // pinned: chunk c of V32 -> flags[c], of C32 -> flags[flag_stride + c]
+  u32 flag_stride;
+  u32 epoch;
+};
+__global__ __launch_bounds__(256) void k_stage_out(const StageOut a) {
+  const u64 nv = a.totals[0], nf = a.totals[1];
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    a.hdr[0] = nv; a.hdr[1] = nf;
+    __hip_atomic_store(&a.hdr[2], (u64) a.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  if (nv > a.cap_v || nf > a.cap_f) return;  // uniform: the host grows the buffers and launches again
+  const size_t w16[3] = {(size_t) ((nv * 12 + 15) / 16), (size_t) ((nv * 12 + 15) / 16), (size_t) ((nf * 12 + 15) / 16)};
+  const u32 nch[3] = {(u32) ((w16[0] + kStageWords - 1) / kStageWords), (u32) ((w16[1] + kStageWords - 1) / kStageWords),
+                      (u32) ((w16[2] + kStageWords - 1) / kStageWords)};
+  const u32 total = nch[0] + nch[1] + nch[2];
+  for (u32 ch = blockIdx.x; ch < total; ch += gridDim.x) {  // uniform per workgroup
+    const int p = ch < nch[0] ? 0 : (ch < nch[0] + nch[1] ? 1 : 2);
+    const u32 lc = ch - (p > 0 ? nch[0] : 0u) - (p > 1 ? nch[1] : 0u);
+    const size_t lo = (size_t) lc * kStageWords, hi = lo + kStageWords < w16[p] ? lo + kStageWords : w16[p];
+    const uint4* __restrict__ src = a.src[p];
+    uint4* __restrict__ dst = a.dst[p];
+    uint4 r[kStageWords / 256];
+#pragma unroll
+    for (u32 k = 0; k < kStageWords / 256; k++) {
+      const size_t i = lo + k * 256 + threadIdx.x;
+      if (i < hi) r[k] = src[i];
+    }
+#pragma unroll
+    for (u32 k = 0; k < kStageWords / 256; k++) {
+      const size_t i = lo + k * 256 + threadIdx.x;
+      if (i < hi) dst[i] = r[k];
+    }
+    if (p < 2) {
+      __threadfence_system();
+      __syncthreads();
+      if (threadIdx.x == 0) __hip_atomic_store(&a.flags[(p ? a.flag_stride : 0u) + lc], a.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+// host side of the above (defined with the copy pool further down): widens nfloat floats of each of the two staging parts into
+// dst[0] / dst[1], chunk by chunk as flags[part][chunk] reaches `epoch` (flags == nullptr: everything has landed already).
+// `drained(arg)` tells whether the stream has run dry (then a missing flag means a failed launch).  Returns false if it gave up.
+bool widen_from_staging(double* const dst[2], const float* const src[2], const volatile u32* const flags[2], u32 epoch, size_t nfloat,
+                        bool (*drained)(void*), void* arg);
+void widen_prewake();
+
 // MeshExtractor::processTriangles on the device (mrh_mesh.h): fills V / C / F from a triangle soup in device memory.
 // MRH_MESH_HOST=1 keeps the host restatement above (same arrays; tests compare the two).
 int process_triangles_device(mrh_ctx* c, const mrh_triangle* d_tris, const size_t nt) {
@@ -694,81 +765,184 @@ int process_triangles_device(mrh_ctx* c, const mrh_triangle* d_tris, const size_
   const u32 gv = (n + 255) / 256, gf = (ntr + 255) / 256;
   const float* soup = (const float*) d_tris;
   int rc = MRH_OK;
-  double *dV = nullptr, *dC = nullptr;
+  void *dV = nullptr, *dC = nullptr;  // doubles with f64_link, floats otherwise
   int* dF = nullptr;
   if (!c->h_mc) {
     HIP_TRY(c, hipHostMalloc((void**) &c->h_mc, 4 * sizeof(u64), hipHostMallocDefault));
     memset(c->h_mc, 0, 4 * sizeof(u64));
   }
+  const bool f64 = c->f64_link;
+  if (!f64) widen_prewake();  // the helper threads are awake and spinning by the time the first chunk lands
 #define MESH_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { rc = fail(c, MRH_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(e_)); goto done; } } while (0)
   {
     // V, C (at most n vertices each) and the faces (at most nt) share slot 2, sized by those bounds: nothing of the
     // post-process waits for a count from the device
     {
       void* vcf = nullptr;
-      const size_t vbytes = ((size_t) n * 3 * sizeof(double) + 255) & ~(size_t) 255;
-      rc = arena_get(c, 2, 2 * vbytes + (size_t) ntr * 3 * sizeof(int) + 16, &vcf);  // + 16: k_copy_out reads whole 16-byte words
+      const size_t vbytes = ((size_t) n * 3 * (f64 ? sizeof(double) : sizeof(float)) + 16 + 255) & ~(size_t) 255;  // + 16: the copy kernels read whole 16-byte words
+      rc = arena_get(c, 2, 2 * vbytes + (size_t) ntr * 3 * sizeof(int) + 16, &vcf);
       if (rc) goto done;
-      dV = (double*) vcf;
-      dC = (double*) ((char*) vcf + vbytes);
+      dV = vcf;
+      dC = (char*) vcf + vbytes;
       dF = (int*) ((char*) vcf + 2 * vbytes);
     }
-    // V, C, F go out behind the post-process without the host in between (k_copy_out reads the two totals on the device), into
-    // the buffers of the previous extraction; if they turn out too small (or not pinned) they grow and the copy runs again.
-    const bool pinned = c->V.dev && c->C.dev && c->F.dev && !getenv("MRH_D2H_MEMCPY");  // MRH_D2H_MEMCPY=1: hipMemcpyAsync instead (A/B)
-    auto copy_out = [&](const bool by_kernel, const int parts, hipStream_t on, const size_t nv_known, const size_t nf_known) {
-      if (by_kernel) {
-        CopyOut a;
-        a.src[0] = (const uint4*) dV; a.dst[0] = (parts & 1) ? (uint4*) c->V.dev : nullptr; a.count[0] = d_totals; a.cap[0] = c->V.cap / 3; a.unit[0] = 24;
-        a.src[1] = (const uint4*) dC; a.dst[1] = (parts & 1) ? (uint4*) c->C.dev : nullptr; a.count[1] = d_totals; a.cap[1] = c->C.cap / 3; a.unit[1] = 24;
-        a.src[2] = (const uint4*) dF; a.dst[2] = (parts & 2) ? (uint4*) c->F.dev : nullptr; a.count[2] = d_totals + 1; a.cap[2] = c->F.cap / 3; a.unit[2] = 12;
-        a.fixed[0] = a.fixed[1] = a.fixed[2] = 0;
-        k_copy_out<<<1024, 256, 0, on>>>(a);
-        return hipGetLastError();
-      }
-      hipError_t e = hipMemcpyAsync(c->V.data(), dV, nv_known * 3 * sizeof(double), hipMemcpyDeviceToHost, s);
-      if (e == hipSuccess) e = hipMemcpyAsync(c->C.data(), dC, nv_known * 3 * sizeof(double), hipMemcpyDeviceToHost, s);
-      if (e == hipSuccess && nf_known) e = hipMemcpyAsync(c->F.data(), dF, nf_known * 3 * sizeof(int), hipMemcpyDeviceToHost, s);
-      return e;
-    };
-    const size_t cap_v = std::min(c->V.cap, c->C.cap) / 3, cap_f = c->F.cap / 3;
-    const bool speculative = pinned && cap_v > 0 && c->V.data() && c->C.data() && c->F.data();
     // ---- vertices
     MESH_TRY(hipMemsetAsync(table, 0xFF, (size_t) cap * 4, s));
-    k_mesh_vertex_insert<<<gv, 256, 0, s>>>(soup, n, eps, inv_eps, table, cap - 1);
-    k_mesh_vertex_rep<<<gv, 256, 0, s>>>(soup, n, eps, inv_eps, table, cap - 1, rep, first);
+    k_mesh_vertex_insert<<<(n + kMeshTile - 1) / kMeshTile, kMeshTile, 0, s>>>(soup, n, eps, inv_eps, table, cap - 1, rep);
+    k_mesh_vertex_rep<<<(n + kMeshTile - 1) / kMeshTile, kMeshTile, 0, s>>>(soup, n, eps, inv_eps, table, cap - 1, rep, first);
     MESH_TRY(rocprim::exclusive_scan(tmp, tb, first, vid, 0u, n, rocprim::plus<u32>(), s));
-    k_mesh_emit_vertices<<<gv, 256, 0, s>>>(soup, rep, first, vid, n, dV, dC, corner);
-    k_mesh_vertex_total<<<1, 1, 0, s>>>(vid, first, n, d_totals);
+    if (f64) k_mesh_emit_vertices<double><<<gv, 256, 0, s>>>(soup, rep, first, vid, n, (double*) dV, (double*) dC, corner, d_totals);
+    else k_mesh_emit_vertices<float><<<gv, 256, 0, s>>>(soup, rep, first, vid, n, (float*) dV, (float*) dC, corner, d_totals);
     // ---- faces
     const u32 fcap = (u32) next_pow2((uint64_t) ntr * 2);
     MESH_TRY(hipMemsetAsync(table, 0xFF, (size_t) fcap * 4, s));
     k_mesh_face_insert<<<gf, 256, 0, s>>>(corner, ntr, table, fcap - 1);
     k_mesh_face_keep<<<gf, 256, 0, s>>>(corner, ntr, table, fcap - 1, keep);
     MESH_TRY(rocprim::exclusive_scan(tmp, tb, keep, fpos, 0u, ntr, rocprim::plus<u32>(), s));
-    k_mesh_emit_faces<<<gf, 256, 0, s>>>(corner, keep, fpos, ntr, dF);
-    k_mesh_face_total<<<1, 1, 0, s>>>(fpos, keep, ntr, d_totals);
+    k_mesh_emit_faces<<<gf, 256, 0, s>>>(corner, keep, fpos, ntr, dF, d_totals);
     const bool dbg = getenv("MRH_DEBUG") != nullptr;
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t0 = now();
     // (Tried in round 4: V and C on a second stream as soon as the vertices are final, next to the face kernels.  The copy kernel and
     // k_mesh_face_insert do not share the memory system gracefully — the insert's atomics ran 37 -> 240-450 us whether the copy had
     // 1 024 or 128 workgroups — and the extraction took as long as before.)
-    if (speculative) MESH_TRY(copy_out(true, 3, s, 0, 0));
-    MESH_TRY(hipMemcpyAsync(c->h_mc + 2, d_totals, 2 * sizeof(u64), hipMemcpyDeviceToHost, s));
-    MESH_TRY(hipStreamSynchronize(s));
-    const double t1 = now();
-    const size_t nv = (size_t) c->h_mc[2], nf = (size_t) c->h_mc[3];
-    const bool fits = speculative && nv <= cap_v && nf <= cap_f;
-    c->V.resize_discard(nv * 3); c->C.resize_discard(nv * 3); c->F.resize_discard(std::max<size_t>(nf, 1) * 3);
-    c->F.n = nf * 3;
-    if (!fits) {
-      MESH_TRY(copy_out(c->V.dev && c->C.dev && c->F.dev && !getenv("MRH_D2H_MEMCPY"), 3, s, nv, nf));
+    if (f64) {
+      // ---- the round-3 way out: doubles over the link.  V, C, F go out behind the post-process without the host in between
+      // (k_copy_out reads the two totals on the device), into the buffers of the previous extraction; if they turn out too small
+      // (or not pinned) they grow and the copy runs again.
+      const bool pinned = c->V.dev && c->C.dev && c->F.dev && !getenv("MRH_D2H_MEMCPY");  // MRH_D2H_MEMCPY=1: hipMemcpyAsync instead (A/B)
+      auto copy_out = [&](const bool by_kernel, const size_t nv_known, const size_t nf_known) {
+        if (by_kernel) {
+          CopyOut a;
+          a.src[0] = (const uint4*) dV; a.dst[0] = (uint4*) c->V.dev; a.count[0] = d_totals; a.cap[0] = c->V.cap / 3; a.unit[0] = 24;
+          a.src[1] = (const uint4*) dC; a.dst[1] = (uint4*) c->C.dev; a.count[1] = d_totals; a.cap[1] = c->C.cap / 3; a.unit[1] = 24;
+          a.src[2] = (const uint4*) dF; a.dst[2] = (uint4*) c->F.dev; a.count[2] = d_totals + 1; a.cap[2] = c->F.cap / 3; a.unit[2] = 12;
+          a.fixed[0] = a.fixed[1] = a.fixed[2] = 0;
+          k_copy_out<<<1024, 256, 0, s>>>(a);
+          return hipGetLastError();
+        }
+        hipError_t e = hipMemcpyAsync(c->V.data(), dV, nv_known * 3 * sizeof(double), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(c->C.data(), dC, nv_known * 3 * sizeof(double), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess && nf_known) e = hipMemcpyAsync(c->F.data(), dF, nf_known * 3 * sizeof(int), hipMemcpyDeviceToHost, s);
+        return e;
+      };
+      const size_t cap_v = std::min(c->V.cap, c->C.cap) / 3, cap_f = c->F.cap / 3;
+      const bool speculative = pinned && cap_v > 0 && c->V.data() && c->C.data() && c->F.data();
+      if (speculative) MESH_TRY(copy_out(true, 0, 0));
+      MESH_TRY(hipMemcpyAsync(c->h_mc + 2, d_totals, 2 * sizeof(u64), hipMemcpyDeviceToHost, s));
       MESH_TRY(hipStreamSynchronize(s));
+      const double t1 = now();
+      const size_t nv = (size_t) c->h_mc[2], nf = (size_t) c->h_mc[3];
+      const bool fits = speculative && nv <= cap_v && nf <= cap_f;
+      c->V.resize_discard(nv * 3); c->C.resize_discard(nv * 3); c->F.resize_discard(std::max<size_t>(nf, 1) * 3);
+      c->F.n = nf * 3;
+      if (!fits) {
+        MESH_TRY(copy_out(c->V.dev && c->C.dev && c->F.dev && !getenv("MRH_D2H_MEMCPY"), nv, nf));
+        MESH_TRY(hipStreamSynchronize(s));
+      }
+      MESH_TRY(hipGetLastError());
+      if (dbg) fprintf(stderr, "[mrhash_hip] mesh post-process: %u soup vertices -> %zu vertices, %zu faces | kernels%s %.2f ms, second copy (buffers grown) %.2f (%.1f MB)\n",
+                       n, nv, nf, speculative ? " + copy to the host" : "", t1 - t0, now() - t1, (nv * 48 + nf * 12) / 1e6);
+    } else {
+      // ---- fp32 over the link, widened by the host as the chunks land (k_stage_out).  Speculative like the above: into the
+      // staging of the previous extraction, and again if that turns out too small.
+      struct Drain { hipStream_t s; };
+      Drain drain{s};
+      auto drained = [](void* a) { return hipStreamQuery(((Drain*) a)->s) != hipErrorNotReady; };
+      auto stage_ready = [&] { return c->V32.dev && c->C32.dev && c->F.dev && c->stage_ctl.dev; };
+      auto launch = [&](u32& epoch_out) {
+        StageOut a;
+        a.src[0] = (const uint4*) dV; a.src[1] = (const uint4*) dC; a.src[2] = (const uint4*) dF;
+        a.dst[0] = (uint4*) c->V32.dev; a.dst[1] = (uint4*) c->C32.dev; a.dst[2] = (uint4*) c->F.dev;
+        a.totals = d_totals;
+        a.cap_v = std::min(c->V32.cap, c->C32.cap) / 3; a.cap_f = c->F.cap / 3;
+        // one flag per chunk the staging can hold
+        const u32 max_chunks = (u32) ((a.cap_v * 12 + 15) / 16 / kStageWords + 1);
+        const size_t room = (c->stage_ctl.cap - kStageHdrWords) / 2;
+        if (max_chunks > room) a.cap_v = (u64) (room > 1 ? (room - 1) : 0) * kStageChunk / 12;
+        a.hdr = (u64*) c->stage_ctl.dev;
+        a.flags = c->stage_ctl.dev + kStageHdrWords;
+        a.flag_stride = (u32) room;
+        if (++c->stage_epoch == 0) c->stage_epoch = 1;
+        a.epoch = epoch_out = c->stage_epoch;
+        static const int grid = getenv("MRH_STAGE_WGS") ? std::max(1, atoi(getenv("MRH_STAGE_WGS"))) : 64;
+        k_stage_out<<<grid, 256, 0, s>>>(a);
+        return a;
+      };
+      // waits for the header of launch `epoch`; false: the stream ran dry without it (a failed launch)
+      auto wait_hdr = [&](const u32 epoch) {
+        const volatile u64* hdr = (const volatile u64*) c->stage_ctl.data();
+        for (u32 spins = 1;; spins++) {
+          if (hdr[2] == (u64) epoch) break;
+          MRH_CPU_RELAX();
+          if ((spins & 1023u) == 0 && drained(&drain)) { if (hdr[2] == (u64) epoch) break; return false; }
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        return true;
+      };
+      auto widen = [&](const u32 epoch, const size_t nv, const bool flagged) {
+        double* const dst[2] = {c->V.data(), c->C.data()};
+        const float* const src[2] = {c->V32.data(), c->C32.data()};
+        const volatile u32* f0 = (const volatile u32*) c->stage_ctl.data() + kStageHdrWords;
+        const volatile u32* const flags[2] = {flagged ? f0 : nullptr, flagged ? f0 + (c->stage_ctl.cap - kStageHdrWords) / 2 : nullptr};
+        return widen_from_staging(dst, src, flags, epoch, nv * 3, drained, &drain);
+      };
+      bool done_ok = false;
+      size_t nv = 0, nf = 0;
+      double t1 = t0;
+      if (stage_ready() && std::min(c->V32.cap, c->C32.cap) >= 3 && c->F.cap >= 3) {
+        u32 epoch = 0;
+        const StageOut a = launch(epoch);
+        MESH_TRY(hipGetLastError());
+        MESH_TRY(hipMemcpyAsync(c->h_mc + 2, d_totals, 2 * sizeof(u64), hipMemcpyDeviceToHost, s));
+        if (!wait_hdr(epoch)) { MESH_TRY(hipStreamSynchronize(s)); MESH_TRY(hipGetLastError()); rc = fail(c, MRH_ERR_DEVICE, "mesh read-back: the staging kernel did not report"); goto done; }
+        const volatile u64* hdr = (const volatile u64*) c->stage_ctl.data();
+        nv = (size_t) hdr[0]; nf = (size_t) hdr[1];
+        if (nv <= a.cap_v && nf <= a.cap_f) {
+          c->V.resize_discard(nv * 3); c->C.resize_discard(nv * 3);
+          c->F.n = nf * 3;
+          const bool ok = widen(epoch, nv, true);
+          MESH_TRY(hipStreamSynchronize(s));  // the faces, and the end of the launch
+          MESH_TRY(hipGetLastError());
+          if (!ok) { rc = fail(c, MRH_ERR_DEVICE, "mesh read-back: a staged chunk never arrived"); goto done; }
+          done_ok = true;
+        } else {
+          MESH_TRY(hipStreamSynchronize(s));
+        }
+        t1 = now();
+      } else {
+        MESH_TRY(hipMemcpyAsync(c->h_mc + 2, d_totals, 2 * sizeof(u64), hipMemcpyDeviceToHost, s));
+        MESH_TRY(hipStreamSynchronize(s));
+        nv = (size_t) c->h_mc[2]; nf = (size_t) c->h_mc[3];
+        t1 = now();
+      }
+      if (!done_ok) {  // first extraction, or the mesh outgrew the buffers: size them and go again
+        c->V32.resize_discard(nv * 3 + 4); c->C32.resize_discard(nv * 3 + 4);
+        c->F.resize_discard(std::max<size_t>(nf, 1) * 3 + 4);
+        c->F.n = nf * 3;
+        c->stage_ctl.resize_discard(kStageHdrWords + 2 * ((std::min(c->V32.cap, c->C32.cap) * 4 + kStageChunk - 1) / kStageChunk + 2));
+        c->V.resize_discard(nv * 3); c->C.resize_discard(nv * 3);
+        if (stage_ready()) {
+          u32 epoch = 0;
+          const StageOut a = launch(epoch);
+          MESH_TRY(hipGetLastError());
+          bool ok = wait_hdr(epoch) && nv <= a.cap_v && nf <= a.cap_f;
+          if (ok) ok = widen(epoch, nv, true);
+          MESH_TRY(hipStreamSynchronize(s));
+          MESH_TRY(hipGetLastError());
+          if (!ok) { rc = fail(c, MRH_ERR_DEVICE, "mesh read-back: the staged copy did not complete"); goto done; }
+        } else {  // registration refused: plain copies, then the widening
+          MESH_TRY(hipMemcpyAsync(c->V32.data(), dV, nv * 3 * sizeof(float), hipMemcpyDeviceToHost, s));
+          MESH_TRY(hipMemcpyAsync(c->C32.data(), dC, nv * 3 * sizeof(float), hipMemcpyDeviceToHost, s));
+          if (nf) MESH_TRY(hipMemcpyAsync(c->F.data(), dF, nf * 3 * sizeof(int), hipMemcpyDeviceToHost, s));
+          MESH_TRY(hipStreamSynchronize(s));
+          (void) widen(0, nv, false);
+        }
+      }
+      MESH_TRY(hipGetLastError());
+      if (dbg) fprintf(stderr, "[mrhash_hip] mesh post-process: %u soup vertices -> %zu vertices, %zu faces | kernels + fp32 staging + widening %.2f ms, second pass (buffers grown) %.2f (%.1f MB over the link)\n",
+                       n, nv, nf, t1 - t0, now() - t1, (nv * 24 + nf * 12) / 1e6);
     }
-    MESH_TRY(hipGetLastError());
-    if (dbg) fprintf(stderr, "[mrhash_hip] mesh post-process: %u soup vertices -> %zu vertices, %zu faces | kernels%s %.2f ms, second copy (buffers grown) %.2f (%.1f MB)\n",
-                     n, nv, nf, speculative ? " + copy to the host" : "", t1 - t0, now() - t1, (nv * 48 + nf * 12) / 1e6);
   }
 done:
 #undef MESH_TRY
@@ -1050,6 +1224,8 @@ int mrh_create(const mrh_params* p, mrh_ctx** out) {
   if (const char* g = getenv("MRH_PIPE_PERIOD")) { const int v = atoi(g); if (v > 0) c->pipe_period = v; }
   if (const char* g = getenv("MRH_SWEEP_WGS")) { const int v = atoi(g); if (v > 0 && v <= 4096) c->sweep_wgs = v; }
   if (const char* g = getenv("MRH_MESH_HOST")) c->mesh_on_host = atoi(g) ? 1 : 0;
+  if (const char* g = getenv("MRH_MESH_F64_LINK")) c->f64_link = atoi(g) != 0;
+  c->V.pin = c->C.pin = c->f64_link;  // fp32 link: the doubles are written by the host only
   if (const char* g = getenv("MRH_QTREE_LITERAL")) c->qt_literal = atoi(g) ? 1 : 0;
   if (const char* g = getenv("MRH_MR_FUSED")) c->mr_fused = atoi(g) ? 1 : 0;
   if (const char* g = getenv("MRH_LIDAR_SORT_ROCPRIM")) c->lidar_sort_rocprim = atoi(g) ? 1 : 0;
@@ -1161,6 +1337,22 @@ __attribute__((target("avx2"))) void copy_streaming_avx2(void* dst, const void* 
   _mm_sfence();
   if (n & 31) memcpy((char*) dst + v * 32, (const char*) src + v * 32, n & 31);
 }
+// floats -> doubles with non-temporal stores (the doubles are read by the caller later, not by this core)
+__attribute__((target("avx2"))) void widen_floats_avx2(double* dst, const float* src, size_t n) {
+  const size_t v = n / 8;
+  for (size_t i = 0; i < v; i++) {
+    const __m256 f = _mm256_loadu_ps(src + i * 8);
+    _mm256_stream_pd(dst + i * 8, _mm256_cvtps_pd(_mm256_castps256_ps128(f)));
+    _mm256_stream_pd(dst + i * 8 + 4, _mm256_cvtps_pd(_mm256_extractf128_ps(f, 1)));
+  }
+  _mm_sfence();
+  for (size_t i = v * 8; i < n; i++) dst[i] = (double) src[i];
+}
+void widen_floats(double* dst, const float* src, size_t n) {
+  static const bool avx2 = __builtin_cpu_supports("avx2");
+  if (avx2 && ((uintptr_t) dst & 31) == 0) widen_floats_avx2(dst, src, n);
+  else for (size_t i = 0; i < n; i++) dst[i] = (double) src[i];
+}
 void copy_chunk(void* dst, const void* src, size_t n) {
   static const bool avx2 = __builtin_cpu_supports("avx2");
   if (avx2 && n >= (64u << 10) && ((uintptr_t) dst & 31) == 0) copy_streaming_avx2(dst, src, n);
@@ -1174,7 +1366,19 @@ void copy_chunk(void* dst, const void* src, size_t n) {
 // otherwise.  One pool per process, started by the first large upload, MRH_COPY_THREADS=0 turns it off.
 struct CopyPool {
   static constexpr size_t kChunk = 128u << 10;
-  struct Job { std::atomic<char*> dst{nullptr}; std::atomic<const char*> src{nullptr}; std::atomic<size_t> bytes{0}, nchunks{0}; };
+  struct Job {
+    std::atomic<char*> dst{nullptr}; std::atomic<const char*> src{nullptr}; std::atomic<size_t> bytes{0}, nchunks{0};
+    // widening jobs (widen_from_staging): two parts of `bytes` bytes of floats each, chunk i < nchunks / 2 belongs to part 0;
+    // a chunk is taken up when its flag word equals `epoch` (flags == nullptr: at once)
+    std::atomic<int> widen{0};
+    std::atomic<char*> dst2{nullptr}; std::atomic<const char*> src2{nullptr};
+    std::atomic<const volatile uint32_t*> flags{nullptr}, flags2{nullptr};
+    std::atomic<uint32_t> epoch{0};
+  };
+  static constexpr size_t kWidenChunk = 64u << 10;  // = kStageChunk: bytes of floats per flag
+  std::atomic<int> abort_widen{0};
+  std::atomic<int64_t> spin_until_ns{0};  // helpers do not go to sleep before this time (widen_prewake)
+  static int64_t now_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
   std::mutex m;
   std::condition_variable cv;
   std::vector<std::thread> threads;
@@ -1198,9 +1402,99 @@ struct CopyPool {
       if (i >= j.nchunks.load(std::memory_order_relaxed)) break;
       if (!ticket.compare_exchange_weak(cur, cur + 1, std::memory_order_acq_rel, std::memory_order_acquire)) continue;
       // chunk i of job g is ours: the job cannot complete before the done++ below, so its descriptor is stable
+      if (j.widen.load(std::memory_order_relaxed)) {
+        widen_chunk(j, i, nullptr, nullptr);
+        done.fetch_add(1, std::memory_order_acq_rel);
+        continue;
+      }
       const size_t off = i * kChunk, len = std::min(kChunk, j.bytes.load(std::memory_order_relaxed) - off);
       copy_chunk(j.dst.load(std::memory_order_relaxed) + off, j.src.load(std::memory_order_relaxed) + off, len);
       done.fetch_add(1, std::memory_order_acq_rel);
+    }
+  }
+  // one chunk of a widening job; the submitting thread passes `drained` and gives up (abort_widen) when the stream has run dry
+  // without the chunk's flag
+  void widen_chunk(Job& j, const size_t i, bool (*drained)(void*), void* arg) {
+    const size_t half = j.nchunks.load(std::memory_order_relaxed) / 2;
+    const int part = i >= half ? 1 : 0;
+    const size_t lc = i - (part ? half : 0);
+    const volatile uint32_t* fl = part ? j.flags2.load(std::memory_order_relaxed) : j.flags.load(std::memory_order_relaxed);
+    if (fl) {
+      const uint32_t epoch = j.epoch.load(std::memory_order_relaxed);
+      for (uint32_t spins = 1; fl[lc] != epoch; spins++) {
+        if (abort_widen.load(std::memory_order_relaxed)) return;
+        MRH_CPU_RELAX();
+        if (drained && (spins & 1023u) == 0 && drained(arg)) {
+          if (fl[lc] == epoch) break;
+          abort_widen.store(1, std::memory_order_relaxed);
+          return;
+        }
+      }
+      std::atomic_thread_fence(std::memory_order_acquire);
+    }
+    const size_t bytes = j.bytes.load(std::memory_order_relaxed);
+    const size_t off = lc * kWidenChunk, len = std::min(kWidenChunk, bytes - off);
+    const float* src = (const float*) ((part ? j.src2.load(std::memory_order_relaxed) : j.src.load(std::memory_order_relaxed)) + off);
+    double* dst = (double*) ((part ? j.dst2.load(std::memory_order_relaxed) : j.dst.load(std::memory_order_relaxed)) + 2 * off);
+    widen_floats(dst, src, len / sizeof(float));
+  }
+  // both parts of a widening job through the pool (the calling thread works too); false: gave up on a flag
+  bool widen(double* const dst[2], const float* const src[2], const volatile uint32_t* const flags[2], const uint32_t epoch, const size_t nfloat,
+             bool (*drained)(void*), void* arg) {
+    if (!started) start();
+    const size_t bytes = nfloat * sizeof(float);
+    const size_t per = (bytes + kWidenChunk - 1) / kWidenChunk, nc = 2 * per;
+    if (nc == 0) return true;
+    abort_widen.store(0, std::memory_order_relaxed);
+    const uint64_t g = generation.load(std::memory_order_relaxed) + 1;  // one submitter at a time (g_copy_mutex)
+    Job& j = jobs[g & 1];
+    j.dst.store((char*) dst[0], std::memory_order_relaxed); j.src.store((const char*) src[0], std::memory_order_relaxed);
+    j.dst2.store((char*) dst[1], std::memory_order_relaxed); j.src2.store((const char*) src[1], std::memory_order_relaxed);
+    j.flags.store(flags[0], std::memory_order_relaxed); j.flags2.store(flags[1], std::memory_order_relaxed);
+    j.epoch.store(epoch, std::memory_order_relaxed);
+    j.bytes.store(bytes, std::memory_order_relaxed); j.nchunks.store(nc, std::memory_order_relaxed);
+    j.widen.store(1, std::memory_order_relaxed);
+    done.store(0, std::memory_order_relaxed);
+    ticket.store((g & 0xFFFFFFFFull) << 32, std::memory_order_release);
+    generation.store(g, std::memory_order_release);
+    if (sleepers.load(std::memory_order_acquire) > 0) { std::lock_guard<std::mutex> lk(m); cv.notify_all(); }
+    for (;;) {  // work(g) with the stream check in the flag wait
+      uint64_t cur = ticket.load(std::memory_order_acquire);
+      const size_t i = (size_t) (cur & 0xFFFFFFFFull);
+      if (i >= nc) break;
+      if (!ticket.compare_exchange_weak(cur, cur + 1, std::memory_order_acq_rel, std::memory_order_acquire)) continue;
+      widen_chunk(j, i, drained, arg);
+      done.fetch_add(1, std::memory_order_acq_rel);
+    }
+    while (done.load(std::memory_order_acquire) < nc) {
+      MRH_CPU_RELAX();
+      // a helper stuck on a flag that will never come: the stream check is ours to make
+      if (drained && !abort_widen.load(std::memory_order_relaxed)) {
+        static thread_local uint32_t spins = 0;
+        if ((++spins & 4095u) == 0 && drained(arg)) {
+          // everything the launch wrote is visible once the stream is dry: give the helpers a moment, then release them
+          const int64_t t = now_ns();
+          while (done.load(std::memory_order_acquire) < nc && now_ns() - t < 2000000) MRH_CPU_RELAX();
+          if (done.load(std::memory_order_acquire) < nc) abort_widen.store(1, std::memory_order_relaxed);
+        }
+      }
+    }
+    j.widen.store(0, std::memory_order_relaxed);
+    return abort_widen.load(std::memory_order_relaxed) == 0;
+  }
+  // wake the helpers now and keep them spinning for a millisecond: a widening job is on its way
+  void prewake() {
+    if (!started) start();
+    spin_until_ns.store(now_ns() + 1500000, std::memory_order_relaxed);
+    if (sleepers.load(std::memory_order_acquire) > 0) {
+      const uint64_t g = generation.load(std::memory_order_relaxed) + 1;  // an empty job: nothing to claim
+      Job& j = jobs[g & 1];
+      j.widen.store(0, std::memory_order_relaxed);
+      j.bytes.store(0, std::memory_order_relaxed); j.nchunks.store(0, std::memory_order_relaxed);
+      done.store(0, std::memory_order_relaxed);
+      ticket.store((g & 0xFFFFFFFFull) << 32, std::memory_order_release);
+      generation.store(g, std::memory_order_release);
+      std::lock_guard<std::mutex> lk(m); cv.notify_all();
     }
   }
   void helper() {
@@ -1212,7 +1506,8 @@ struct CopyPool {
       int spins = 0;
       while ((g = generation.load(std::memory_order_acquire)) == seen) {
         MRH_CPU_RELAX();
-        if ((++spins & 255) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(150)) {
+        if ((++spins & 255) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(150) &&
+            now_ns() > spin_until_ns.load(std::memory_order_relaxed)) {
           std::unique_lock<std::mutex> lk(m);
           sleepers.fetch_add(1);
           cv.wait(lk, [&] { return generation.load(std::memory_order_acquire) != seen; });
@@ -1242,6 +1537,7 @@ struct CopyPool {
     Job& j = jobs[g & 1];
     j.dst.store((char*) d, std::memory_order_relaxed); j.src.store((const char*) s_, std::memory_order_relaxed);
     j.bytes.store(n, std::memory_order_relaxed); j.nchunks.store(nc, std::memory_order_relaxed);
+    j.widen.store(0, std::memory_order_relaxed);
     done.store(0, std::memory_order_relaxed);  // no ticket of an earlier job is outstanding: they all completed before their copy() returned
     ticket.store((g & 0xFFFFFFFFull) << 32, std::memory_order_release);
     generation.store(g, std::memory_order_release);
@@ -1259,8 +1555,20 @@ void copy_to_staging(void* dst, const void* src, size_t n) {
   std::lock_guard<std::mutex> lk(g_copy_mutex);
   copy_pool()->copy(dst, src, n);
 }
+bool widen_from_staging(double* const dst[2], const float* const src[2], const volatile u32* const flags[2], u32 epoch, size_t nfloat,
+                        bool (*drained)(void*), void* arg) {
+  std::lock_guard<std::mutex> lk(g_copy_mutex);
+  return copy_pool()->widen(dst, src, flags, epoch, nfloat, drained, arg);
+}
+void widen_prewake() {
+  std::lock_guard<std::mutex> lk(g_copy_mutex);
+  copy_pool()->prewake();
+}
 #else
 void copy_to_staging(void* dst, const void* src, size_t n);
+bool widen_from_staging(double* const dst[2], const float* const src[2], const volatile u32* const flags[2], u32 epoch, size_t nfloat,
+                        bool (*drained)(void*), void* arg) { return false; }
+void widen_prewake() {}
 #endif
 
 // one host image into the next slot of its ring: wait until the slot is free, copy into pinned staging (the caller's

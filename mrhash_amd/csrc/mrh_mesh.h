@@ -55,14 +55,50 @@ __device__ __forceinline__ Key96 face_key(const u32* __restrict__ corner, const 
   return k;
 }
 
-__global__ __launch_bounds__(256) void k_mesh_vertex_insert(const float* __restrict__ soup, const u32 n, const double eps, const double inv_eps,
-                                                            u32* __restrict__ table, const u32 mask) {
-  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+// A vertex of the soup occurs about six times, and most of its occurrences lie a few hundred entries apart (the voxels that
+// share the edge belong to one block, and a block's triangles are contiguous): a workgroup first finds the first occurrences
+// inside its own tile of kMeshTile entries in an LDS table (same min-index rule), and only those go to the global table — a
+// later occurrence inside the tile cannot lower the minimum its tile's first occurrence already stands for.  The tile-local
+// representative is left in rep[] for k_mesh_vertex_rep, which uses the same tiles.  (Round 4: 85 + 22 us -> see DESIGN §4.3
+// for 1.6 M soup vertices; every soup vertex used to pay two or three dependent trips to the memory-side atomics.)
+constexpr int kMeshTile = 512;
+constexpr u32 kMeshLocalSlots = 1024;
+__global__ __launch_bounds__(kMeshTile) void k_mesh_vertex_insert(const float* __restrict__ soup, const u32 n, const double eps, const double inv_eps,
+                                                                  u32* __restrict__ table, const u32 mask, u32* __restrict__ rep) {
+  __shared__ u32 s_ka[kMeshTile], s_kb[kMeshTile], s_kc[kMeshTile];
+  __shared__ u32 s_tab[kMeshLocalSlots];
+  const u32 tl = threadIdx.x, i = blockIdx.x * kMeshTile + tl;
+  for (u32 k = tl; k < kMeshLocalSlots; k += kMeshTile) s_tab[k] = kMeshEmpty;
+  bool nan_i = true;
+  Key96 key;
+  key.a = key.b = key.c = 0;
+  if (i < n) key = vertex_key(soup, i, eps, inv_eps, nan_i);
+  s_ka[tl] = key.a; s_kb[tl] = key.b; s_kc[tl] = key.c;
+  __syncthreads();
+  const u32 h = key_hash(key);
+  u32 myslot = kMeshEmpty;
+  if (!nan_i) {
+    u32 s = (h >> 20) & (kMeshLocalSlots - 1);
+    for (;;) {
+      u32 cur = __hip_atomic_load(&s_tab[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (cur == kMeshEmpty) {
+        cur = atomicCAS(&s_tab[s], kMeshEmpty, tl);
+        if (cur == kMeshEmpty) { myslot = s; break; }
+      }
+      if (s_ka[cur] == key.a && s_kb[cur] == key.b && s_kc[cur] == key.c) {  // only indices of ONE key ever replace each other in a slot
+        if (tl < cur) atomicMin(&s_tab[s], tl);
+        myslot = s;
+        break;
+      }
+      s = (s + 1) & (kMeshLocalSlots - 1);
+    }
+  }
+  __syncthreads();
   if (i >= n) return;
-  bool nan_i;
-  const Key96 key = vertex_key(soup, i, eps, inv_eps, nan_i);
-  if (nan_i) return;
-  u32 s = key_hash(key) & mask;
+  const u32 lr = myslot != kMeshEmpty ? s_tab[myslot] : tl;
+  rep[i] = blockIdx.x * kMeshTile + lr;
+  if (lr != tl || nan_i) return;  // a later occurrence within the tile, or a NaN position (its own representative, never in a table)
+  u32 s = h & mask;
   for (;;) {
     u32 cur = __hip_atomic_load(&table[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (cur == kMeshEmpty) {
@@ -77,37 +113,50 @@ __global__ __launch_bounds__(256) void k_mesh_vertex_insert(const float* __restr
     s = (s + 1) & mask;
   }
 }
-__global__ __launch_bounds__(256) void k_mesh_vertex_rep(const float* __restrict__ soup, const u32 n, const double eps, const double inv_eps,
-                                                         const u32* __restrict__ table, const u32 mask, u32* __restrict__ rep, u32* __restrict__ is_first) {
-  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  bool nan_i;
-  const Key96 key = vertex_key(soup, i, eps, inv_eps, nan_i);
+// rep[] comes in holding the tile-local representatives and leaves holding the global ones
+__global__ __launch_bounds__(kMeshTile) void k_mesh_vertex_rep(const float* __restrict__ soup, const u32 n, const double eps, const double inv_eps,
+                                                               const u32* __restrict__ table, const u32 mask, u32* __restrict__ rep, u32* __restrict__ is_first) {
+  __shared__ u32 s_rep[kMeshTile];
+  const u32 tl = threadIdx.x, i = blockIdx.x * kMeshTile + tl;
+  const u32 lr = i < n ? rep[i] : i;
+  const bool local_first = i < n && lr == i;
   u32 r = i;
-  if (!nan_i) {
-    u32 s = key_hash(key) & mask;
-    for (;;) {
-      const u32 cur = table[s];  // never empty before the key's own slot: this vertex was inserted
-      bool nan_c;
-      if (key_eq(vertex_key(soup, cur, eps, inv_eps, nan_c), key)) { r = cur; break; }
-      s = (s + 1) & mask;
+  if (local_first) {
+    bool nan_i;
+    const Key96 key = vertex_key(soup, i, eps, inv_eps, nan_i);
+    if (!nan_i) {
+      u32 s = key_hash(key) & mask;
+      for (;;) {
+        const u32 cur = table[s];  // never empty before the key's own slot: this vertex was inserted
+        bool nan_c;
+        if (key_eq(vertex_key(soup, cur, eps, inv_eps, nan_c), key)) { r = cur; break; }
+        s = (s + 1) & mask;
+      }
     }
   }
+  s_rep[tl] = r;
+  __syncthreads();
+  if (i >= n) return;
+  if (!local_first) r = s_rep[lr - blockIdx.x * kMeshTile];
   rep[i] = r;
   is_first[i] = (r == i) ? 1u : 0u;
 }
 
+// T = float: V and C leave the device as the fp32 values marching cubes computed (the host widens them while the link is still
+// busy, mrh_capi.hip: k_stage_out / widen_from_staging); T = double: widened here (MRH_MESH_F64_LINK=1, the round-3 path)
+template <typename T>
 __global__ __launch_bounds__(256) void k_mesh_emit_vertices(const float* __restrict__ soup, const u32* __restrict__ rep,
                                                             const u32* __restrict__ is_first, const u32* __restrict__ vid, const u32 n,
-                                                            double* __restrict__ V, double* __restrict__ C, u32* __restrict__ corner) {
+                                                            T* __restrict__ V, T* __restrict__ C, u32* __restrict__ corner, u64* __restrict__ totals) {
   const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   corner[i] = vid[rep[i]];
+  if (i == n - 1) totals[0] = (u64) vid[i] + is_first[i];  // unique vertices, for the host and for the copy kernel
   if (is_first[i]) {
     const float* v = soup + (size_t) i * 6;
     const size_t o = (size_t) vid[i] * 3;
-    V[o] = (double) v[0]; V[o + 1] = (double) v[1]; V[o + 2] = (double) v[2];
-    C[o] = (double) v[3]; C[o + 1] = (double) v[4]; C[o + 2] = (double) v[5];
+    V[o] = (T) v[0]; V[o + 1] = (T) v[1]; V[o + 2] = (T) v[2];
+    C[o] = (T) v[3]; C[o + 1] = (T) v[4]; C[o + 2] = (T) v[5];
   }
 }
 
@@ -146,18 +195,13 @@ __global__ __launch_bounds__(256) void k_mesh_face_keep(const u32* __restrict__ 
 }
 
 __global__ __launch_bounds__(256) void k_mesh_emit_faces(const u32* __restrict__ corner, const u32* __restrict__ keep, const u32* __restrict__ fpos,
-                                                         const u32 nt, int* __restrict__ F) {
+                                                         const u32 nt, int* __restrict__ F, u64* __restrict__ totals) {
   const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= nt || !keep[t]) return;
+  if (t >= nt) return;
+  if (t == nt - 1) totals[1] = (u64) fpos[t] + keep[t];  // kept faces
+  if (!keep[t]) return;
   const size_t o = (size_t) fpos[t] * 3;
   F[o] = (int) corner[3 * t]; F[o + 1] = (int) corner[3 * t + 1]; F[o + 2] = (int) corner[3 * t + 2];
-}
-// {unique vertices, kept faces} for the host and for the copy kernel: each as soon as its half of the post-process is done
-__global__ void k_mesh_vertex_total(const u32* __restrict__ vid, const u32* __restrict__ first, const u32 n, u64* __restrict__ out) {
-  out[0] = (u64) vid[n - 1] + first[n - 1];
-}
-__global__ void k_mesh_face_total(const u32* __restrict__ fpos, const u32* __restrict__ keep, const u32 nt, u64* __restrict__ out) {
-  out[1] = (u64) fpos[nt - 1] + keep[nt - 1];
 }
 
 // ---- host driver ------------------------------------------------------------------------------------------

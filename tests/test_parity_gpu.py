@@ -157,13 +157,19 @@ def test_mesh_postprocess_device_equals_host_and_oracle(hip, oracle, monkeypatch
     orc = pu.make_engine(oracle, K, params, 65536)
     monkeypatch.setenv("MRH_MESH_HOST", "1")
     host = pu.make_engine(hip, K, params, 65536)
+    monkeypatch.delenv("MRH_MESH_HOST")
+    # V / C as doubles over the link (the round-3 read-back) against fp32 staging widened by the host (the default)
+    monkeypatch.setenv("MRH_MESH_F64_LINK", "1")
+    f64 = pu.make_engine(hip, K, params, 65536)
+    monkeypatch.delenv("MRH_MESH_F64_LINK")
+    engines = (dev, host, f64, orc)
     scene = synth.scannet_room()
     for t, q in synth.walk_poses(3, seed=11):
         f = synth.render(scene, K, t, q, depth_scaling=5000.0)
-        for e in (dev, orc, host):
+        for e in engines:
             pu.feed(e, f)
     out = []
-    for e in (dev, host, orc):
+    for e in engines:
         tris = e.extract_triangles()
         V, F, C = e.extract_mesh()
         out.append((tris, V, F, C))
@@ -173,12 +179,27 @@ def test_mesh_postprocess_device_equals_host_and_oracle(hip, oracle, monkeypatch
         for a, b in zip(out[0][1:], other[1:]):
             assert a.shape == b.shape and a.tobytes() == b.tobytes()
     assert out[0][1].shape[0] < out[0][0].shape[0] * 3  # something merged
-    # the same mesh when the triangle soup stays on the device (out_triangles == NULL: what GeoWrapper.extractMesh does)
-    for e in (dev, host, orc):
+    # the same mesh when the triangle soup stays on the device (out_triangles == NULL: what GeoWrapper.extractMesh does);
+    # this second extraction goes into the staging buffers of the first (the speculative path)
+    for e in engines:
         assert e.extract_triangles(soup=False) == out[0][0].shape[0]
         for a, b in zip(out[0][1:], e.extract_mesh()):
             assert a.tobytes() == b.tobytes()
-    for e in (dev, orc, host):
+    # a map that outgrows the buffers of its last extraction: the staged copy reports, grows and runs again
+    for yaw in (1.3, 2.6, 3.9):
+        f = synth.render(scene, K, np.zeros(3, np.float32), synth.yaw_quat(yaw), depth_scaling=5000.0)
+        for e in (dev, f64, orc):
+            pu.feed(e, f)
+    grown = []
+    for e in (dev, f64, orc):
+        n = e.extract_triangles(soup=False)
+        grown.append((n,) + tuple(e.extract_mesh()))
+    assert grown[0][0] > out[0][0].shape[0] * 1.3
+    for other in grown[1:]:
+        assert grown[0][0] == other[0]
+        for a, b in zip(grown[0][1:], other[1:]):
+            assert a.shape == b.shape and a.tobytes() == b.tobytes()
+    for e in engines:
         e.close()
 
 
