@@ -544,6 +544,35 @@ __device__ __forceinline__ bool voxel_touches_coarse(const int v, const u32 cmas
   return (cube & cmask) != 0u;
 }
 
+// Class planes of the prescreen: one byte per staged cell, rows of 16 bytes (cell lx of a row at byte lx + kHaloRim; bytes 14,
+// 15 and whatever lies outside the staged rim are masked after the load), so that a row is ONE 16-byte LDS read and the OR over
+// a window along x is three (seven) byte shifts of the 128-bit row — the first version read every cell of every voxel's window
+// as a byte (27 reads per voxel on the narrow window, 21 per output cell on the separable wide one: a fifth of the count pass).
+constexpr int kClsRow = 16;
+constexpr int kClsBytes = kHaloSide * kHaloSide * kClsRow;  // 3136
+struct Row128 { u64 lo, hi; };
+__device__ __forceinline__ Row128 row_load(const uint8_t* base, const int row) {
+  const uint4 r = *(const uint4*) (base + (size_t) row * kClsRow);
+  Row128 o;
+  o.lo = (u64) r.x | ((u64) r.y << 32);
+  o.hi = (u64) r.z | ((u64) r.w << 32);
+  return o;
+}
+__device__ __forceinline__ Row128 row_or(const Row128 a, const Row128 b) { Row128 o; o.lo = a.lo | b.lo; o.hi = a.hi | b.hi; return o; }
+// OR of the row with itself shifted by 1 .. W bytes both ways: byte i of the result = OR of bytes i - W .. i + W
+template <int W>
+__device__ __forceinline__ Row128 row_spread(const Row128 r) {
+  Row128 o = r;
+#pragma unroll
+  for (int k = 1; k <= W; k++) {
+    o.lo |= (r.lo << (8 * k)) | (r.lo >> (8 * k)) | (r.hi << (64 - 8 * k));
+    o.hi |= (r.hi << (8 * k)) | (r.hi >> (8 * k)) | (r.lo >> (64 - 8 * k));
+  }
+  return o;
+}
+// bytes kHaloRim .. kHaloRim + 7 of a row: the eight voxels x = 0 .. 7
+__device__ __forceinline__ u64 row_voxels(const Row128 r) { return (r.lo >> (8 * kHaloRim)) | (r.hi << (64 - 8 * kHaloRim)); }
+
 // The 27-block neighbourhood of every block of the sorted list, resolved by one thread per (block, neighbour): 27 independent
 // probes per block at full occupancy instead of 27 lanes of one wave walking their probe paths at the head of every k_mc
 // workgroup while the other 229 threads wait; both passes read the table.  Layout: nb[e * 32 + i], i = (dz+1)*9 + (dy+1)*3 + (dx+1).
@@ -618,7 +647,11 @@ __global__ __launch_bounds__(kMcThreads) __attribute__((amdgpu_waves_per_eu(4, 4
   __shared__ u32 s_nb[27];
   __shared__ float s_sdf[kHaloCells];
   __shared__ u32 s_rgbw[kHaloCells];
-  __shared__ __attribute__((aligned(16))) uint8_t s_cls[2][kHaloCells];
+  __shared__ __attribute__((aligned(16))) uint8_t s_cls[kClsBytes];  // count pass: class of every staged cell (rows of kClsRow bytes)
+  __shared__ u64 s_px[kHaloSide * kHaloSide];  // wide window: OR along x for the eight voxels of every staged (y, z) row
+  __shared__ u64 s_py[kBlockSide * kHaloSide]; // ... then along y, for y in 0..7 and every staged z
+  __shared__ u64 s_nar[kBlockSide * kBlockSide];  // per voxel (byte v of the array): OR over the 3^3 window
+  __shared__ u64 s_wid[kBlockSide * kBlockSide];  // per voxel: OR over the 7^3 window
   __shared__ unsigned short s_cand[512];
   __shared__ uint8_t s_ntri[512];
   __shared__ u32 s_off[512];
@@ -694,7 +727,7 @@ __global__ __launch_bounds__(kMcThreads) __attribute__((amdgpu_waves_per_eu(4, 4
             uint8_t cls = unseen;
             if ((rw[it] >> 24) != 0) cls = (sv[it] >= lo && sv[it] <= hi) ? 1 : ((sv[it] <= -lo && sv[it] >= -hi) ? 2 : 8);
             else if ((__float_as_uint(sv[it]) & 0x7FFFFFFFu) != 0u) cls |= 16;  // unseen, but a non-zero sdf is stored (weight starved to 0)
-            s_cls[0][idx] = cls;
+            s_cls[((lz + kHaloRim) * kHaloSide + (ly + kHaloRim)) * kClsRow + (lx + kHaloRim)] = cls;
           }
         }
       }
@@ -718,66 +751,60 @@ __global__ __launch_bounds__(kMcThreads) __attribute__((amdgpu_waves_per_eu(4, 4
       for (int v = tid; v < nvox; v += kMcThreads)
         if (per_voxel[(size_t) e * 512 + v] != 0) push(v);
     } else if (staged && sdf_bound > 0.f) {
-      // per voxel: w = 1 window straight from the classes (OR of the one-hot class bits); does it need the wide one?
-      u32 acc1[2] = {0u, 0u};
-      bool wide[2] = {false, false};
+      // OR of the one-hot class bits over every voxel's window, a row of eight voxels at a time (row_load / row_spread):
+      // the 3^3 window of a fine block by threads 192..255 (nine row reads each), the 7^3 window — coarse voxels and fine ones
+      // next to a coarse block — separably: along x for all 14 x 14 staged rows (threads 0..195, next to the narrow rows),
+      // then y, then z
+      const bool any_wide = coarse || cmask != 0u;  // uniform
+      if (!coarse && tid >= 192) {
+        const int r = tid - 192, y = r & 7, z = r >> 3;
+        Row128 acc;
+        acc.lo = acc.hi = 0;
+#pragma unroll
+        for (int dz = -1; dz <= 1; dz++)
+#pragma unroll
+          for (int dy = -1; dy <= 1; dy++) acc = row_or(acc, row_load(s_cls, (z + dz + kHaloRim) * kHaloSide + (y + dy + kHaloRim)));
+        // only the cells lx = -1 .. 8 (bytes 2 .. 11) are part of these windows — and, with a one-cell rim, the only ones staged
+        acc.lo &= 0xFFFFFFFFFFFF0000ull;
+        acc.hi &= 0x00000000FFFFFFFFull;
+        s_nar[r] = row_voxels(row_spread<1>(acc));
+      }
+      if (any_wide && tid < kHaloSide * kHaloSide) {
+        Row128 r = row_load(s_cls, tid);
+        r.hi &= 0x0000FFFFFFFFFFFFull;  // bytes 14, 15 are not cells
+        s_px[tid] = row_voxels(row_spread<kHaloRim>(r));
+      }
+      __syncthreads();
+      if (any_wide) {
+        if (tid < kBlockSide * kHaloSide) {
+          const int y = tid & 7, zz = tid >> 3;
+          u64 acc = 0;
+#pragma unroll
+          for (int d = -kHaloRim; d <= kHaloRim; d++) acc |= s_px[zz * kHaloSide + (y + kHaloRim + d)];
+          s_py[tid] = acc;
+        }
+        __syncthreads();
+        if (tid < kBlockSide * kBlockSide) {
+          const int y = tid & 7, z = tid >> 3;
+          u64 acc = 0;
+#pragma unroll
+          for (int d = -kHaloRim; d <= kHaloRim; d++) acc |= s_py[(z + kHaloRim + d) * kBlockSide + y];
+          s_wid[tid] = acc;
+        }
+        __syncthreads();
+      }
+      const uint8_t* nar8 = (const uint8_t*) s_nar;
+      const uint8_t* wid8 = (const uint8_t*) s_wid;
 #pragma unroll
       for (int h = 0; h < 2; h++) {
         const int v = tid + h * kMcThreads;
         if (v < nvox) {
-          if (coarse) {
-            wide[h] = true;
-          } else {
-            const int x = v & 7, y = (v >> 3) & 7, z = v >> 6;
-            const int base = ((z + kHaloRim) * kHaloSide + (y + kHaloRim)) * kHaloSide + (x + kHaloRim);
-            u32 acc = 0u;
-#pragma unroll
-            for (int dz = -1; dz <= 1; dz++)
-#pragma unroll
-              for (int dy = -1; dy <= 1; dy++)
-#pragma unroll
-                for (int dx = -1; dx <= 1; dx++) acc |= s_cls[0][base + (dz * kHaloSide + dy) * kHaloSide + dx];
-            acc1[h] = acc;
-            wide[h] = voxel_touches_coarse(v, cmask);
-          }
-        }
-      }
-      if (cmask) {  // uniform: separable OR of the class bits over [-3, 3]^3: x, then y, then z
-        __syncthreads();
-        constexpr int w = kHaloRim;
-        for (int c = tid; c < kBlockSide * kHaloSide * kHaloSide; c += kMcThreads) {  // x in 0..7, all staged y, z
-          const int x = c & 7, yz = c >> 3;
-          const int base = yz * kHaloSide + (x + kHaloRim);
-          u32 acc = 0u;
-#pragma unroll
-          for (int d = -w; d <= w; d++) acc |= s_cls[0][base + d];
-          s_cls[1][base] = (uint8_t) acc;
-        }
-        __syncthreads();
-        for (int c = tid; c < kBlockSide * kBlockSide * kHaloSide; c += kMcThreads) {  // x, y in 0..7, all staged z
-          const int x = c & 7, y = (c >> 3) & 7, z = c >> 6;
-          const int base = (z * kHaloSide + (y + kHaloRim)) * kHaloSide + (x + kHaloRim);
-          u32 acc = 0u;
-#pragma unroll
-          for (int d = -w; d <= w; d++) acc |= s_cls[1][base + d * kHaloSide];
-          s_cls[0][base] = (uint8_t) acc;
-        }
-        __syncthreads();
-      }
-#pragma unroll
-      for (int h = 0; h < 2; h++) {
-        const int v = tid + h * kMcThreads;
-        if (v < nvox) {
-          u32 acc = acc1[h];
           bool empty;
-          if (wide[h]) {
+          if (coarse || voxel_touches_coarse(v, cmask)) {
             int x, y, z;
             if (!coarse) { x = v & 7; y = (v >> 3) & 7; z = v >> 6; }
             else { x = 2 * (v & 3); y = 2 * ((v >> 2) & 3); z = 2 * (v >> 4); }
-            const int base = ((z + kHaloRim) * kHaloSide + (y + kHaloRim)) * kHaloSide + (x + kHaloRim);
-            acc = 0u;
-#pragma unroll
-            for (int d = -kHaloRim; d <= kHaloRim; d++) acc |= s_cls[0][base + d * kHaloSide * kHaloSide];
+            const u32 acc = wid8[(z * kBlockSide + y) * kBlockSide + x];
             // A resolution jump blends the sdf of a cell in WITHOUT looking at its weight (vds.cu:268, :296-309: 0.5 pos_sdf +
             // 0.5 np_sdf), so here an unseen cell can contribute a value — but only its stored sdf, and that is +-0 unless the
             // weight was starved away (class bit 16; a missing block reads 0, vds.cu:163-176).  Every SAMPLE of a stencil must
@@ -788,6 +815,7 @@ __global__ __launch_bounds__(kMcThreads) __attribute__((amdgpu_waves_per_eu(4, 4
             // voxel.  Eight corners of one sign: cube index 0 or 255, no triangle.
             empty = (acc & (8u | 16u)) == 0u && (acc & 3u) != 3u;
           } else {
+            const u32 acc = nar8[v];
             // no resolution jump can occur: every corner value is a convex combination of WEIGHTED cells (a sample without
             // weight invalidates the stencil, vds.cu:283-284) or a weighted raw sample — or the voxel returns without a
             // triangle (raw sample below min_weight_threshold).  Unseen cells therefore never contribute a value: without
@@ -823,7 +851,7 @@ __global__ __launch_bounds__(kMcThreads) __attribute__((amdgpu_waves_per_eu(4, 4
       return voxel_to_world(m.vs, pi);
     };
     const int gb = lane & ~7, corner = lane & 7;
-    unsigned short* s_recv = (unsigned short*) &s_cls[1][0];  // voxel of record slot i (the class planes are done with)
+    unsigned short* s_recv = (unsigned short*) s_px;  // voxel of record slot i (the prescreen's planes are done with)
     if (!EMIT) {
       // ---- dense evaluation of the candidates, 8 lanes each; per-voxel counts to LDS
 #pragma unroll 1
