@@ -302,6 +302,8 @@ struct mrh_ctx {
   HostVec<float> V32, C32;     // pinned staging
   HostVec<u32> stage_ctl;      // pinned: [0..5] {vertices, faces, epoch} as three u64, [16..] one flag word per 64 KiB chunk of V32, then of C32
   u32 stage_epoch = 0;
+  void* mesh_clean_base = nullptr;  // arena slot 1 as the last extraction left it: the first mesh_clean_words words are 0xFFFFFFFF
+  size_t mesh_clean_words = 0;
   bool f64_link = false;       // MRH_MESH_F64_LINK=1: V / C widened on the device and copied as doubles (the round-3 path; A/B, tests)
   // profiling
   int profile = 0;
@@ -643,6 +645,7 @@ int arena_get(mrh_ctx* c, const int slot, const size_t bytes, void** out) {
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (c->arena[slot]) HIP_TRY(c, hipFree(c->arena[slot]));
     c->arena[slot] = nullptr; c->arena_cap[slot] = 0;
+    if (slot == 1) c->mesh_clean_words = 0;  // new memory: the post-process's tables are not the empty ones it left behind
     const size_t cap = bytes + bytes / 4;
     HIP_TRY(c, hipMalloc(&c->arena[slot], cap));
     c->arena_cap[slot] = cap;
@@ -694,8 +697,21 @@ struct StageOut {
   u32* flags;            // pinned: chunk c of V32 -> flags[c], of C32 -> flags[flag_stride + c]
   u32 flag_stride;
   u32 epoch;
+  // workgroups copy_wgs .. gridDim.x - 1 do not copy: they refill the post-process's index tables with "empty" for the next
+  // extraction (the link keeps the copying workgroups busy for 0.35 ms; the fills used to cost 2 x 9 us up front)
+  u32 copy_wgs;
+  u32* clear;
+  size_t clear_words;
 };
 __global__ __launch_bounds__(256) void k_stage_out(const StageOut a) {
+  if (blockIdx.x >= a.copy_wgs) {
+    const size_t n4 = a.clear_words / 4, stride = (size_t) (gridDim.x - a.copy_wgs) * 256;
+    uint4* c4 = (uint4*) a.clear;
+    const uint4 ff = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+    for (size_t i = (size_t) (blockIdx.x - a.copy_wgs) * 256 + threadIdx.x; i < n4; i += stride) c4[i] = ff;
+    if (blockIdx.x == a.copy_wgs && threadIdx.x < (a.clear_words & 3)) a.clear[n4 * 4 + threadIdx.x] = 0xFFFFFFFFu;
+    return;
+  }
   const u64 nv = a.totals[0], nf = a.totals[1];
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     a.hdr[0] = nv; a.hdr[1] = nf;
@@ -706,7 +722,7 @@ __global__ __launch_bounds__(256) void k_stage_out(const StageOut a) {
   const u32 nch[3] = {(u32) ((w16[0] + kStageWords - 1) / kStageWords), (u32) ((w16[1] + kStageWords - 1) / kStageWords),
                       (u32) ((w16[2] + kStageWords - 1) / kStageWords)};
   const u32 total = nch[0] + nch[1] + nch[2];
-  for (u32 ch = blockIdx.x; ch < total; ch += gridDim.x) {  // uniform per workgroup
+  for (u32 ch = blockIdx.x; ch < total; ch += a.copy_wgs) {  // uniform per workgroup
     const int p = ch < nch[0] ? 0 : (ch < nch[0] + nch[1] ? 1 : 2);
     const u32 lc = ch - (p > 0 ? nch[0] : 0u) - (p > 1 ? nch[1] : 0u);
     const size_t lo = (size_t) lc * kStageWords, hi = lo + kStageWords < w16[p] ? lo + kStageWords : w16[p];
@@ -748,17 +764,25 @@ int process_triangles_device(mrh_ctx* c, const mrh_triangle* d_tris, const size_
   const double eps = (double) c->p.vertices_merging_threshold;
   const double inv_eps = eps != 0.0 ? 1.0 / eps : 0.0;
   const size_t tmp_bytes = mesh_scan_tmp_bytes(n);
-  const u32 cap = (u32) next_pow2((uint64_t) n * 2);  // load factor <= 1/2; the face table (nt keys) reuses it
+  const u32 cap = (u32) next_pow2((uint64_t) n * 2);  // load factor <= 1/2
+  const u32 fcap = (u32) next_pow2((uint64_t) ntr * 2);
   MeshScratch m;
-  m.bytes = (size_t) n * 4 * 5 + (size_t) cap * 4 + tmp_bytes + 32 * 256;
+  m.bytes = (size_t) n * 4 * 5 + ((size_t) cap + fcap) * 4 + tmp_bytes + 32 * 256;
   {
     const int arc = arena_get(c, 1, m.bytes, &m.base);
     if (arc) return arc;
   }
+  // The two index tables come first, so that they lie where the last extraction's lay: that extraction's read-back kernel left
+  // them empty again (k_stage_out's extra workgroups clear them while the link is busy), and the two fills — 24 MB at the
+  // driver's workload, ahead of the vertex and of the face kernels — are only needed when the scratch moved or grew.
+  u32* table = m.take<u32>(cap);
+  u32* ftable = m.take<u32>(fcap);
+  const size_t clear_words = (size_t) ((ftable + fcap) - (u32*) m.base);
+  const bool tables_clean = !c->f64_link && c->mesh_clean_base == m.base && c->mesh_clean_words >= clear_words && !getenv("MRH_MESH_FILL");
+  c->mesh_clean_words = 0;  // dirty from here on, until a clear is enqueued
   u32* rep = m.take<u32>(n);   u32* first = m.take<u32>(n);   u32* vid = m.take<u32>(n);   u32* corner = m.take<u32>(n);
   u32* keep = m.take<u32>(n);  // faces: keep + fpos share it (nt + nt <= n)
   u32* fpos = keep + ntr;
-  u32* table = m.take<u32>(cap);
   u64* d_totals = m.take<u64>(2);
   void* tmp = m.take<char>(tmp_bytes ? tmp_bytes : 1);
   size_t tb = tmp_bytes;
@@ -787,17 +811,15 @@ int process_triangles_device(mrh_ctx* c, const mrh_triangle* d_tris, const size_
       dF = (int*) ((char*) vcf + 2 * vbytes);
     }
     // ---- vertices
-    MESH_TRY(hipMemsetAsync(table, 0xFF, (size_t) cap * 4, s));
+    if (!tables_clean) MESH_TRY(hipMemsetAsync(m.base, 0xFF, clear_words * 4, s));
     k_mesh_vertex_insert<<<(n + kMeshTile - 1) / kMeshTile, kMeshTile, 0, s>>>(soup, n, eps, inv_eps, table, cap - 1, rep);
     k_mesh_vertex_rep<<<(n + kMeshTile - 1) / kMeshTile, kMeshTile, 0, s>>>(soup, n, eps, inv_eps, table, cap - 1, rep, first);
     MESH_TRY(rocprim::exclusive_scan(tmp, tb, first, vid, 0u, n, rocprim::plus<u32>(), s));
     if (f64) k_mesh_emit_vertices<double><<<gv, 256, 0, s>>>(soup, rep, first, vid, n, (double*) dV, (double*) dC, corner, d_totals);
     else k_mesh_emit_vertices<float><<<gv, 256, 0, s>>>(soup, rep, first, vid, n, (float*) dV, (float*) dC, corner, d_totals);
     // ---- faces
-    const u32 fcap = (u32) next_pow2((uint64_t) ntr * 2);
-    MESH_TRY(hipMemsetAsync(table, 0xFF, (size_t) fcap * 4, s));
-    k_mesh_face_insert<<<gf, 256, 0, s>>>(corner, ntr, table, fcap - 1);
-    k_mesh_face_keep<<<gf, 256, 0, s>>>(corner, ntr, table, fcap - 1, keep);
+    k_mesh_face_insert<<<gf, 256, 0, s>>>(corner, ntr, ftable, fcap - 1);
+    k_mesh_face_keep<<<gf, 256, 0, s>>>(corner, ntr, ftable, fcap - 1, keep);
     MESH_TRY(rocprim::exclusive_scan(tmp, tb, keep, fpos, 0u, ntr, rocprim::plus<u32>(), s));
     k_mesh_emit_faces<<<gf, 256, 0, s>>>(corner, keep, fpos, ntr, dF, d_totals);
     const bool dbg = getenv("MRH_DEBUG") != nullptr;
@@ -850,6 +872,7 @@ int process_triangles_device(mrh_ctx* c, const mrh_triangle* d_tris, const size_
       Drain drain{s};
       auto drained = [](void* a) { return hipStreamQuery(((Drain*) a)->s) != hipErrorNotReady; };
       auto stage_ready = [&] { return c->V32.dev && c->C32.dev && c->F.dev && c->stage_ctl.dev; };
+      bool clear_pending = true;  // the first launch of this extraction also clears the index tables
       auto launch = [&](u32& epoch_out) {
         StageOut a;
         a.src[0] = (const uint4*) dV; a.src[1] = (const uint4*) dC; a.src[2] = (const uint4*) dF;
@@ -866,7 +889,12 @@ int process_triangles_device(mrh_ctx* c, const mrh_triangle* d_tris, const size_
         if (++c->stage_epoch == 0) c->stage_epoch = 1;
         a.epoch = epoch_out = c->stage_epoch;
         static const int grid = getenv("MRH_STAGE_WGS") ? std::max(1, atoi(getenv("MRH_STAGE_WGS"))) : 64;
-        k_stage_out<<<grid, 256, 0, s>>>(a);
+        a.copy_wgs = (u32) grid;
+        a.clear = (u32*) m.base;
+        a.clear_words = clear_pending ? clear_words : 0;
+        k_stage_out<<<grid + (clear_pending ? 256 : 0), 256, 0, s>>>(a);
+        if (clear_pending) { c->mesh_clean_base = m.base; c->mesh_clean_words = clear_words; }
+        clear_pending = false;
         return a;
       };
       // waits for the header of launch `epoch`; false: the stream ran dry without it (a failed launch)
@@ -2839,7 +2867,8 @@ int mrh_extract_triangles(mrh_ctx* c, const mrh_triangle** out_tris, uint64_t* o
     const bool no_rank_sort = getenv("MRH_MC_RADIX_SORT") != nullptr;  // MRH_MC_RADIX_SORT=1: rocPRIM's sort + scan for every list (A/B, tests)
     if (n <= kRankSortMax && !no_rank_sort) {  // canonical order by counting (mrh_mc.h: k_block_rank)
       const int slices = (n + kRankSlice - 1) / kRankSlice;
-      k_block_rank<<<dim3((n + 255) / 256, slices), 256, 0, s>>>(c->tab.compact, n, d_partial);
+      k_list_keys<<<(n + 255) / 256, 256, 0, s>>>(c->tab.compact, n, k_in);
+      k_block_rank<<<dim3((n + 255) / 256, slices), 256, 0, s>>>(k_in, n, d_partial);
       k_block_scatter<<<(n + 255) / 256, 256, 0, s>>>(c->tab.compact, n, d_partial, slices, sorted);
     } else {
       k_list_keys<<<(n + 255) / 256, 256, 0, s>>>(c->tab.compact, n, k_in);

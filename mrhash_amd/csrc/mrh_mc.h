@@ -427,21 +427,17 @@ __global__ __launch_bounds__(256) void k_list_keys(const int4* __restrict__ list
 // kRankSortMax keep the radix sort.
 constexpr int kRankSlice = 512;
 constexpr int kRankSortMax = 32768;
-__global__ __launch_bounds__(256) void k_block_rank(const int4* __restrict__ list, const int n, u32* __restrict__ partial) {
-  __shared__ u64 s_k[kRankSlice];
-  const int s0 = blockIdx.y * kRankSlice;
-  for (int j = threadIdx.x; j < kRankSlice; j += 256) {
-    u64 k = ~0ull;  // padding: never below a key
-    if (s0 + j < n) pack_key(mki3(list[s0 + j].x, list[s0 + j].y, list[s0 + j].z), k);
-    s_k[j] = k;
-  }
+// the slice's keys are the same for every lane: they come through the scalar cache (uniform index into the packed-key array of
+// k_list_keys) and the loop body is a 64-bit compare against a scalar and an add — the first version staged them in LDS and
+// was bound by the LDS return path (a 512-byte broadcast per compare: 21 us for 14 k blocks); packing them inside the loop
+// instead costs ~20 scalar instructions per key (133 us)
+__global__ __launch_bounds__(256) void k_block_rank(const u64* __restrict__ keys, const int n, u32* __restrict__ partial) {
+  const int s0 = blockIdx.y * kRankSlice, s1 = min(n, s0 + kRankSlice);
   const int i = blockIdx.x * 256 + threadIdx.x;
-  u64 key = 0;
-  if (i < n) pack_key(mki3(list[i].x, list[i].y, list[i].z), key);
-  __syncthreads();
+  const u64 key = i < n ? keys[i] : 0ull;
   u32 below = 0;
-#pragma unroll 8
-  for (int j = 0; j < kRankSlice; j++) below += s_k[j] < key ? 1u : 0u;
+#pragma unroll 16
+  for (int j = s0; j < s1; j++) below += keys[j] < key ? 1u : 0u;
   if (i < n) partial[(size_t) blockIdx.y * n + i] = below;  // one row per slice: plain stores, nothing to clear, no atomics
 }
 __global__ __launch_bounds__(256) void k_block_scatter(const int4* __restrict__ list, const int n, const u32* __restrict__ partial, const int slices,
