@@ -357,13 +357,16 @@ struct McCorner {
 template <bool EMIT>
 __device__ __forceinline__ int mc_group(const Map& m, const Tab& t, const Neigh& nb, const f3 pf, const int v, const bool stencil_known,
                                         const int k, const int gb, const bool active, mrh_triangle* out, const int room, McCorner* rec = nullptr) {
-  const float vvs = get_voxel_size_f(m, t, nb, pf);
+  // stencil_known (a fine voxel whose 3^3 cells lie in fine or absent blocks): the voxel's own size is the fine one, and the six
+  // checkVertexVoxels probes — half a voxel along an axis: the voxel itself or its neighbour on that axis — all answer the fine
+  // size (a missing block reads resolution 0, vds.cu:236-240), so no flag can be raised: nothing to look up
+  const float vvs = stencil_known ? m.vs * (float) (1 << 0) : get_voxel_size_f(m, t, nb, pf);
   const float P = vvs * 0.5f;
   const float M = -P;
   f3 sP = mk3(P * 1.f, P * 1.f, P * 1.f);
   f3 sM = mk3(M * 1.f, M * 1.f, M * 1.f);
   u32 vflags = 0;
-  if (t.multi_res) {
+  if (t.multi_res && !stencil_known) {
     // marching_cubes.cu:7-69 checkVertexVoxels: six independent tests, lane j < 6 takes test j (+x, -x, +y, -y, +z, -z)
     bool flag = false;
     if (k < 6) {
@@ -569,6 +572,73 @@ __device__ __forceinline__ Row128 row_spread(const Row128 r) {
 // bytes kHaloRim .. kHaloRim + 7 of a row: the eight voxels x = 0 .. 7
 __device__ __forceinline__ u64 row_voxels(const Row128 r) { return (r.lo >> (8 * kHaloRim)) | (r.hi << (64 - 8 * kHaloRim)); }
 
+// Staging by ROWS (round 4): a thread takes one (y, z) row of the staged region and loads it as 16-byte words — the eight
+// cells inside the block's own x range (SEG 0: two words per plane from a fine block, one from a coarse block, whose four
+// voxels of the row each fill two cells), the rim towards -x (SEG 1: the word holding cells 4..7 of the neighbour's row) and
+// towards +x (SEG 2: cells 0..3) — instead of one cell per thread and round: 588 address computations and ~1 600 wide loads
+// per block with a three-cell rim where the cell loop had 2 744 and 5 488 single-word loads, all in flight at once.
+struct RowLoad {
+  float4 a_sdf, b_sdf;
+  uint4 a_rgbw, b_rgbw;
+  u32 nval;
+};
+template <int SEG>
+__device__ __forceinline__ void row_issue(const Tab& t, const u32* s_nb, const bool active, const int ly, const int lz, RowLoad& r) {
+  r.a_sdf = r.b_sdf = make_float4(0.f, 0.f, 0.f, 0.f);
+  r.a_rgbw = r.b_rgbw = make_uint4(0u, 0u, 0u, 0u);
+  r.nval = kNbAbsent;
+  if (!active) return;
+  const u32 nval = s_nb[((lz >> 3) + 1) * 9 + ((ly >> 3) + 1) * 3 + (SEG == 0 ? 1 : (SEG == 1 ? 0 : 2))];
+  r.nval = nval;
+  if (nval == kNbAbsent) return;  // a missing block reads sdf 0, weight 0 (vds.cu:163-176)
+  const VoxPtr vp = vox_ptr(t, nval);
+  const int fy = ly & 7, fz = lz & 7;
+  const bool cz = (nval & kValCoarseBit) != 0;
+  const u32 off = cz ? (u32) ((fz >> 1) * 16 + (fy >> 1) * 4) : (u32) (fz * 64 + fy * 8 + (SEG == 1 ? 4 : 0));
+  r.a_sdf = *(const float4*) (vp.sdf + off);
+  r.a_rgbw = *(const uint4*) (vp.rgbw + off);
+  if (SEG == 0 && !cz) {
+    r.b_sdf = *(const float4*) (vp.sdf + off + 4);
+    r.b_rgbw = *(const uint4*) (vp.rgbw + off + 4);
+  }
+}
+template <int SEG, bool COUNT>
+__device__ __forceinline__ void row_store(const RowLoad& r, const bool active, const int ly, const int lz, const int rim, const float lo, const float hi,
+                                          const uint8_t unseen, float* s_sdf, u32* s_rgbw, uint8_t* s_cls) {
+  if (!active) return;
+  const bool cz = r.nval != kNbAbsent && (r.nval & kValCoarseBit) != 0;
+  const float fa[8] = {r.a_sdf.x, r.a_sdf.y, r.a_sdf.z, r.a_sdf.w, r.b_sdf.x, r.b_sdf.y, r.b_sdf.z, r.b_sdf.w};
+  const u32 ra[8] = {r.a_rgbw.x, r.a_rgbw.y, r.a_rgbw.z, r.a_rgbw.w, r.b_rgbw.x, r.b_rgbw.y, r.b_rgbw.z, r.b_rgbw.w};
+  const bool wide_rim = rim == kHaloRim;  // uniform
+  const int lx0 = SEG == 0 ? 0 : (SEG == 1 ? -rim : kBlockSide);
+  const int row = (lz + kHaloRim) * kHaloSide + (ly + kHaloRim);
+  const int base = row * kHaloSide + (lx0 + kHaloRim), cbase = row * kClsRow + (lx0 + kHaloRim);
+#pragma unroll
+  for (int j = 0; j < (SEG == 0 ? kBlockSide : kHaloRim); j++) {
+    if (SEG != 0 && j >= rim) break;  // uniform
+    // source word of cell j.  Fine block: the loaded cells are 0..7 (SEG 0), 4..7 (SEG 1; the rim's cells are 8 - rim .. 7) or
+    // 0..3 (SEG 2).  Coarse block: the row's four voxels, voxel fx >> 1 for fine cell fx.
+    float sf, sc;
+    u32 rf, rc;
+    if (SEG == 0) { sf = fa[j]; rf = ra[j]; sc = fa[j >> 1]; rc = ra[j >> 1]; }
+    else if (SEG == 1) {
+      // three-cell rim: cells 5, 6, 7; one-cell rim: cell 7 (j == 0 only)
+      sf = wide_rim ? fa[1 + j] : fa[3]; rf = wide_rim ? ra[1 + j] : ra[3];
+      sc = wide_rim ? fa[(5 + j) >> 1] : fa[3]; rc = wide_rim ? ra[(5 + j) >> 1] : ra[3];
+    } else { sf = fa[j]; rf = ra[j]; sc = fa[j >> 1]; rc = ra[j >> 1]; }
+    const float sv = cz ? sc : sf;
+    const u32 rw = cz ? rc : rf;
+    s_sdf[base + j] = sv;
+    s_rgbw[base + j] = rw;
+    if (COUNT) {
+      uint8_t cls = unseen;
+      if ((rw >> 24) != 0) cls = (sv >= lo && sv <= hi) ? 1 : ((sv <= -lo && sv >= -hi) ? 2 : 8);
+      else if ((__float_as_uint(sv) & 0x7FFFFFFFu) != 0u) cls |= 16;  // unseen, but a non-zero sdf is stored (weight starved to 0)
+      s_cls[cbase + j] = cls;
+    }
+  }
+}
+
 // The 27-block neighbourhood of every block of the sorted list, resolved by one thread per (block, neighbour): 27 independent
 // probes per block at full occupancy instead of 27 lanes of one wave walking their probe paths at the head of every k_mc
 // workgroup while the other 229 threads wait; both passes read the table.  Layout: nb[e * 32 + i], i = (dz+1)*9 + (dy+1)*3 + (dx+1).
@@ -630,7 +700,6 @@ __device__ unsigned int d_mc_trace[2][kMcTraceBlocks][8];
 #define MRH_MC_ACC(slot, a, b) do { } while (0)
 #define MRH_MC_ADD(slot, v) do { } while (0)
 #endif
-constexpr int kMcFillIters = (kHaloCells + kMcThreads - 1) / kMcThreads;  // 11
 template <bool EMIT>
 // 4 waves per SIMD: left alone the allocator takes 147 VGPRs (3 waves); capped at 128 it spills 8-24 bytes and both passes
 // run 10-12 % faster — the staging half of the kernel is a chain of memory round trips and wants the extra workgroup per CU
@@ -686,47 +755,22 @@ __global__ __launch_bounds__(kMcThreads) __attribute__((amdgpu_waves_per_eu(4, 4
 #endif
     if (staged) {
       const int side = kBlockSide + 2 * rim;
-      const int ncell = side * side * side;
-      float sv[kMcFillIters];
-      u32 rw[kMcFillIters];
-#pragma unroll
-      for (int it = 0; it < kMcFillIters; it++) {  // all gathers of a thread in flight before the first LDS store
-        const int c = tid + it * kMcThreads;
-        sv[it] = 0.f;
-        rw[it] = 0;
-        if (c < ncell) {
-          const int lx = c % side - rim, ly = (c / side) % side - rim, lz = c / (side * side) - rim;  // fine cell relative to the block
-          const u32 nval = s_nb[((lz >> 3) + 1) * 9 + ((ly >> 3) + 1) * 3 + ((lx >> 3) + 1)];
-          if (nval != kNbAbsent) {
-            const VoxPtr vp = vox_ptr(t, nval);
-            const int fx = lx & 7, fy = ly & 7, fz = lz & 7;
-            const u32 li = (nval & kValCoarseBit) ? (u32) ((fz >> 1) * 16 + (fy >> 1) * 4 + (fx >> 1)) : (u32) (fz * 64 + fy * 8 + fx);
-            sv[it] = vp.sdf[li];
-            rw[it] = vp.rgbw[li];
-          }
-        }
-      }
+      const bool wide_rim = rim == kHaloRim;  // uniform
+      const bool row_active = tid < side * side;
+      const int ry = wide_rim ? tid % kHaloSide : tid % (kBlockSide + 2), rz = wide_rim ? tid / kHaloSide : tid / (kBlockSide + 2);
+      const int ly = ry - rim, lz = rz - rim;  // the thread's row, relative to the block
+      RowLoad r0, r1, r2;  // all loads of the row in flight before the first LDS store
+      row_issue<0>(t, s_nb, row_active, ly, lz, r0);
+      row_issue<1>(t, s_nb, row_active, ly, lz, r1);
+      row_issue<2>(t, s_nb, row_active, ly, lz, r2);
       const float lo = 1e-3f * sdf_bound, hi = 1.001f * sdf_bound;
       // third class: a cell without an observation (weight 0, or no block).  If a voxel's whole window is unseen, every
       // corner's trilinear stencil meets a weight-0 sample (vds.cu:283-284: invalid) and the raw sample it falls back to has
       // weight 0 < min_weight_threshold (marching_cubes.cu:89-93: return): no triangle.  Needs min_weight_threshold >= 1.
       const uint8_t unseen = m.min_weight_threshold >= 1 ? 4 : 8;  // 8 = "anything else": always a candidate
-#pragma unroll
-      for (int it = 0; it < kMcFillIters; it++) {
-        const int c = tid + it * kMcThreads;
-        if (c < ncell) {
-          const int lx = c % side - rim, ly = (c / side) % side - rim, lz = c / (side * side) - rim;
-          const int idx = ((lz + kHaloRim) * kHaloSide + (ly + kHaloRim)) * kHaloSide + (lx + kHaloRim);
-          s_sdf[idx] = sv[it];
-          s_rgbw[idx] = rw[it];
-          if (!EMIT) {
-            uint8_t cls = unseen;
-            if ((rw[it] >> 24) != 0) cls = (sv[it] >= lo && sv[it] <= hi) ? 1 : ((sv[it] <= -lo && sv[it] >= -hi) ? 2 : 8);
-            else if ((__float_as_uint(sv[it]) & 0x7FFFFFFFu) != 0u) cls |= 16;  // unseen, but a non-zero sdf is stored (weight starved to 0)
-            s_cls[((lz + kHaloRim) * kHaloSide + (ly + kHaloRim)) * kClsRow + (lx + kHaloRim)] = cls;
-          }
-        }
-      }
+      row_store<0, !EMIT>(r0, row_active, ly, lz, rim, lo, hi, unseen, s_sdf, s_rgbw, s_cls);
+      row_store<1, !EMIT>(r1, row_active, ly, lz, rim, lo, hi, unseen, s_sdf, s_rgbw, s_cls);
+      row_store<2, !EMIT>(r2, row_active, ly, lz, rim, lo, hi, unseen, s_sdf, s_rgbw, s_cls);
       __syncthreads();
       nb.halo_sdf = s_sdf;
       nb.halo_rgbw = s_rgbw;
