@@ -475,7 +475,7 @@ def bench_single(args):
     spherical = None
     if not args.no_extras:
         cam = synth.spherical_camera(128, 1024)
-        n_img, w_img = 12, 3
+        n_img, w_img = 24, 4
         scache = os.path.join(tempfile.gettempdir(), f"mrh_bench_sph_{n_img}.npz")
         sposes = synth.drive_poses(n_img, step=0.5)
         if os.path.exists(scache):
@@ -500,12 +500,19 @@ def bench_single(args):
                 se_.set_rgb_device(dc.ptr + i * npx * 3, cam["rows"], cam["cols"])
                 se_.integrate()
 
-        run_imgs(0, w_img)
-        se_.sync()
-        c0 = time.perf_counter()
-        run_imgs(w_img, n_img)
-        se_.sync()
-        dts = time.perf_counter() - c0
+        # three passes over the same drive (the map is reset in between), the median reported: the first pass of a context also
+        # pays for the first use of the spherical instantiations and of the pool (r04: 37.8-43.7 us over 9 frames where
+        # tools/bench_spherical.py measured 27-29 on later passes)
+        pass_s = []
+        for _ in range(3):
+            se_.reset()
+            run_imgs(0, w_img)
+            se_.sync()
+            c0 = time.perf_counter()
+            run_imgs(w_img, n_img)
+            se_.sync()
+            pass_s.append(time.perf_counter() - c0)
+        dts = sorted(pass_s)[1]
         live_sph = int(se_.stats().occupied_fine)
         # the integrate kernel of these frames against the HBM roof, as for the pinhole stream: profiled second pass, U and M from the device
         se_.reset()
@@ -526,6 +533,7 @@ def bench_single(args):
         spherical = {"workload": "128 x 1024 range images of the street scene through mrh_integrate under the spherical camera model "
                                  "(vbr.cfg parameters; the two launches k_front / k_back templated on the camera model, pipelined)",
                      "frames_per_s": (n_img - w_img) / dts, "ms_per_frame": dts / (n_img - w_img) * 1e3, "live_blocks_end": live_sph,
+                     "frames_timed": n_img - w_img, "passes_ms_per_frame": [x / (n_img - w_img) * 1e3 for x in pass_s],
                      "roofline": {"bound": "hbm", "kernel": "k_back<spherical>", "achieved": ach_s, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_s / HBM_PEAK_GBS,
                                   "traffic": None, "algorithmic_bytes_per_launch": alg_s, "kernel_ms_avg": kms, "launches": nk,
                                   "updated_voxels_per_launch": Us, "compact_blocks_per_launch": Ms,

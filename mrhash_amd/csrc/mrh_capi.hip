@@ -2905,9 +2905,10 @@ int mrh_extract_triangles(mrh_ctx* c, const mrh_triangle** out_tris, uint64_t* o
     McRecords none;
     none.ctr = nullptr; none.recs = nullptr; none.base = nullptr; none.count = nullptr; none.cap = 0;
     if (use_records) HIP_TRY(c, hipMemsetAsync(d_rec_ctr, 0, 2 * sizeof(u32), s));
+    const int mc_flags = getenv("MRH_MC_NO_COARSE_KNOWN") ? 2 : 0;  // bit 1: coarse voxels on the literal evaluation only (A/B, tests)
     if (timed) hipExtLaunchKernelGGL((k_mc<false>), dim3(grid), dim3(kMcThreads), 0, s, c->mc_ev[0], c->mc_ev[1], 0u, c->map, c->tab, (const int4*) sorted, n, (const u32*) d_nb,
-                                     (u32*) d_counts, (const u64*) nullptr, (mrh_triangle*) nullptr, (u64) 0, (uint8_t*) d_per_voxel, sdf_bound, 0, R);
-    else k_mc<false><<<grid, kMcThreads, 0, s>>>(c->map, c->tab, sorted, n, d_nb, d_counts, nullptr, nullptr, (u64) 0, d_per_voxel, sdf_bound, 0, R);
+                                     (u32*) d_counts, (const u64*) nullptr, (mrh_triangle*) nullptr, (u64) 0, (uint8_t*) d_per_voxel, sdf_bound, mc_flags, R);
+    else k_mc<false><<<grid, kMcThreads, 0, s>>>(c->map, c->tab, sorted, n, d_nb, d_counts, nullptr, nullptr, (u64) 0, d_per_voxel, sdf_bound, mc_flags, R);
     if (n <= kScanTotalMax && !no_rank_sort) {
       k_mc_scan_total<<<1, 1024, 0, s>>>(d_counts, n, d_offsets, use_records ? d_rec_ctr : nullptr, d_total);
       HIP_TRY(c, hipMemcpyAsync(c->h_mc, d_total, 2 * sizeof(u64), hipMemcpyDeviceToHost, s));
@@ -2924,8 +2925,8 @@ int mrh_extract_triangles(mrh_ctx* c, const mrh_triangle** out_tris, uint64_t* o
         else k_mc_emit_records<<<grid, kMcThreads, 0, s>>>(c->map, c->tab, sorted, n, R, d_offsets, c->d_soup, cap, flag_overflow);
       } else {
         if (timed) hipExtLaunchKernelGGL((k_mc<true>), dim3(grid), dim3(kMcThreads), 0, s, c->mc_ev[2], c->mc_ev[3], 0u, c->map, c->tab, (const int4*) sorted, n, (const u32*) d_nb,
-                                         (u32*) d_counts, (const u64*) d_offsets, (mrh_triangle*) c->d_soup, cap, (uint8_t*) d_per_voxel, 0.f, flag_overflow, none);
-        else k_mc<true><<<grid, kMcThreads, 0, s>>>(c->map, c->tab, sorted, n, d_nb, d_counts, d_offsets, c->d_soup, cap, d_per_voxel, 0.f, flag_overflow, none);
+                                         (u32*) d_counts, (const u64*) d_offsets, (mrh_triangle*) c->d_soup, cap, (uint8_t*) d_per_voxel, 0.f, flag_overflow | mc_flags, none);
+        else k_mc<true><<<grid, kMcThreads, 0, s>>>(c->map, c->tab, sorted, n, d_nb, d_counts, d_offsets, c->d_soup, cap, d_per_voxel, 0.f, flag_overflow | mc_flags, none);
       }
     };
     // The emit pass goes out BEFORE the host knows the total, into the soup buffer of the previous extraction (grow-only, 12 %

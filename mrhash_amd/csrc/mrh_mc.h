@@ -229,6 +229,63 @@ __device__ __forceinline__ bool trilinear_known(const Map& m, const Neigh& nb, c
   return true;
 }
 
+// trilinearInterpolation (vds.cu:260-338) for corner `k` of the COARSE voxel `v` (index in its 4^3 block) of a staged block,
+// when the voxel's 3^3 fine-cell neighbourhood lies in coarse blocks only (the caller checks it), with the sample positions as
+// INTEGERS.  In fine-voxel units the voxel sits at V (even coordinates), the corner at Pk = V + (+-1, +-1, +-1): the corner's
+// block is coarse, so voxel_size = 2 vs and pos_dual = Pk - 1; the eight samples are pos_dual + {0, 2}, the coarser re-sample of a
+// resolution jump (vds.cu:296-309: nvs = 4 vs) reaches Pk - 2 + {0, 4} — all lattice points, within three cells of the voxel,
+// which worldPointToVirtualVoxelPos (round to nearest) cannot miss while the accumulated rounding error of the position
+// arithmetic stays below 0.1 voxel (|coordinate| < 2^18, checked by the workgroup: the argument of trilinear_known).  WHICH
+// cells are read is all that is known beforehand: found / resolution / weight / sdf of every sample, the data-dependent branches
+// and the float arithmetic of the weights are the reference's.  The base-resolution look-up converts the corner with the
+// SAMPLED voxel size (vds.cu:264), which lands on a half-integer of the 2 vs lattice: it keeps the literal conversion.
+__device__ __forceinline__ bool trilinear_coarse_known(const Map& m, const Tab& t, const Neigh& nb, const f3 pos, const int k, const int v, float& dist) {
+  const i3 P = mki3(nb.base.x * kBlockSide + 2 * (v & 3) + ((k & 1) ? 1 : -1), nb.base.y * kBlockSide + 2 * ((v >> 2) & 3) + ((k & 2) ? 1 : -1),
+                    nb.base.z * kBlockSide + 2 * (v >> 4) + ((k & 4) ? 1 : -1));
+  const float voxel_size = m.vs * (float) (1 << 1);
+  const f3 pos_dual = mk3(pos.x - voxel_size * 0.5f, pos.y - voxel_size * 0.5f, pos.z - voxel_size * 0.5f);
+  int base_resolution = 0;
+  {
+    const u32 val = block_val(t, nb, world_to_block(voxel_size, pos));  // note: voxel_size, not vs (vds.cu:264)
+    if (val != kNbAbsent) base_resolution = (val & kValCoarseBit) ? 1 : 0;
+  }
+  dist = 0.f;
+  const float pos_sdf = get_voxel_i(m, t, nb, mki3(P.x - 1, P.y - 1, P.z - 1)).sdf;  // only consumed on resolution jumps
+  const float x0 = pos_dual.x, y0 = pos_dual.y, z0 = pos_dual.z;
+  float x1 = x0, y1 = y0, z1 = z0;
+  float sdf[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int dx = i & 1, dy = (i >> 1) & 1, dz = (i >> 2) & 1;
+    const f3 vp = mk3(pos_dual.x + (float) dx * voxel_size, pos_dual.y + (float) dy * voxel_size, pos_dual.z + (float) dz * voxel_size);
+    const VoxSample s = get_voxel_i(m, t, nb, mki3(P.x - 1 + 2 * dx, P.y - 1 + 2 * dy, P.z - 1 + 2 * dz));
+    if ((s.rgbw >> 24) == 0) return false;
+    if (s.res > base_resolution) {
+      const float np_sdf = get_voxel_i(m, t, nb, mki3(P.x - 2 + 4 * dx, P.y - 2 + 4 * dy, P.z - 2 + 4 * dz)).sdf;
+      const float alpha = 0.5f;
+      sdf[i] = (1 - alpha) * pos_sdf + alpha * np_sdf;
+    } else {
+      sdf[i] = s.sdf;
+    }
+    if (vp.x > x1) x1 = vp.x;
+    if (vp.y > y1) y1 = vp.y;
+    if (vp.z > z1) z1 = vp.z;
+  }
+  const float ddx = (x1 - x0) > 1e-6f ? (pos.x - x0) / (x1 - x0) : 0.5f;
+  const float ddy = (y1 - y0) > 1e-6f ? (pos.y - y0) / (y1 - y0) : 0.5f;
+  const float ddz = (z1 - z0) > 1e-6f ? (pos.z - z0) / (z1 - z0) : 0.5f;
+  const float c0 = sdf[0];
+  const float c1 = (sdf[1] - sdf[0]);
+  const float c2 = (sdf[2] - sdf[0]);
+  const float c3 = (sdf[4] - sdf[0]);
+  const float c4 = (sdf[3] - sdf[2] - sdf[1] + sdf[0]);
+  const float c5 = (sdf[6] - sdf[4] - sdf[2] + sdf[0]);
+  const float c6 = (sdf[5] - sdf[4] - sdf[1] + sdf[0]);
+  const float c7 = (sdf[7] - sdf[6] - sdf[5] - sdf[3] + sdf[1] + sdf[4] + sdf[2] - sdf[0]);
+  dist = c0 + c1 * ddx + c2 * ddy + c3 * ddz + c4 * ddx * ddy + c5 * ddy * ddz + c6 * ddx * ddz + c7 * ddx * ddy * ddz;
+  return true;
+}
+
 // mesh_extractor.cu:6-36
 __device__ __forceinline__ mrh_vertex vertex_interp(f3 p1, f3 p2, float d1, float d2, u32 c1, u32 c2) {
   const float isolevel = 0.f;
@@ -354,13 +411,17 @@ struct McCorner {
   float dist;
   u32 col, flags;
 };
+constexpr int kMcLiteral = 0, kMcFineKnown = 1, kMcCoarseKnown = 2;
 template <bool EMIT>
-__device__ __forceinline__ int mc_group(const Map& m, const Tab& t, const Neigh& nb, const f3 pf, const int v, const bool stencil_known,
+// `mode` (uniform): kMcLiteral, kMcFineKnown (trilinear_known) or kMcCoarseKnown (trilinear_coarse_known)
+__device__ __forceinline__ int mc_group(const Map& m, const Tab& t, const Neigh& nb, const f3 pf, const int v, const int mode,
                                         const int k, const int gb, const bool active, mrh_triangle* out, const int room, McCorner* rec = nullptr) {
+  const bool stencil_known = mode != kMcLiteral;
   // stencil_known (a fine voxel whose 3^3 cells lie in fine or absent blocks): the voxel's own size is the fine one, and the six
   // checkVertexVoxels probes — half a voxel along an axis: the voxel itself or its neighbour on that axis — all answer the fine
   // size (a missing block reads resolution 0, vds.cu:236-240), so no flag can be raised: nothing to look up
-  const float vvs = stencil_known ? m.vs * (float) (1 << 0) : get_voxel_size_f(m, t, nb, pf);
+  // (the same holds for a coarse voxel whose 3^3 fine cells lie in coarse blocks: it and its probes read the coarse size)
+  const float vvs = mode == kMcFineKnown ? m.vs * (float) (1 << 0) : (mode == kMcCoarseKnown ? m.vs * (float) (1 << 1) : get_voxel_size_f(m, t, nb, pf));
   const float P = vvs * 0.5f;
   const float M = -P;
   f3 sP = mk3(P * 1.f, P * 1.f, P * 1.f);
@@ -386,8 +447,13 @@ __device__ __forceinline__ int mc_group(const Map& m, const Tab& t, const Neigh&
   }
   const f3 p = mk3(pf.x + ((k & 1) ? sP.x : sM.x), pf.y + ((k & 2) ? sP.y : sM.y), pf.z + ((k & 4) ? sP.z : sM.z));
   float dist = 0.f;
-  const bool valid = stencil_known ? trilinear_known(m, nb, p, k, v & 7, (v >> 3) & 7, v >> 6, dist) : trilinear(m, t, nb, p, dist);
-  const VoxSample vs_ = get_voxel_f(m, t, nb, p);
+  const bool valid = mode == kMcFineKnown ? trilinear_known(m, nb, p, k, v & 7, (v >> 3) & 7, v >> 6, dist)
+                     : (mode == kMcCoarseKnown ? trilinear_coarse_known(m, t, nb, p, k, v, dist) : trilinear(m, t, nb, p, dist));
+  // the raw sample at the corner: a lattice point for a coarse voxel (V +- 1), a half-integer for a fine one (literal conversion)
+  const VoxSample vs_ = mode == kMcCoarseKnown
+                            ? get_voxel_i(m, t, nb, mki3(nb.base.x * kBlockSide + 2 * (v & 3) + ((k & 1) ? 1 : -1), nb.base.y * kBlockSide + 2 * ((v >> 2) & 3) + ((k & 2) ? 1 : -1),
+                                                         nb.base.z * kBlockSide + 2 * (v >> 4) + ((k & 4) ? 1 : -1)))
+                            : get_voxel_f(m, t, nb, p);
   const u32 col = vs_.rgbw;
   bool bad = false;
   if (!valid) {
@@ -571,6 +637,16 @@ __device__ __forceinline__ Row128 row_spread(const Row128 r) {
 }
 // bytes kHaloRim .. kHaloRim + 7 of a row: the eight voxels x = 0 .. 7
 __device__ __forceinline__ u64 row_voxels(const Row128 r) { return (r.lo >> (8 * kHaloRim)) | (r.hi << (64 - 8 * kHaloRim)); }
+
+// do the 3^3 fine cells around COARSE voxel v (index in its 4^3 block; fine coordinates 2 * index) all lie in coarse blocks?
+// The cells reach the previous block on an axis where the coordinate is 0 and never the next one (coordinate + 1 <= 7).
+__device__ __forceinline__ bool coarse_voxel_in_coarse_cells(const int v, const u32 cmask) {
+  const int x = v & 3, y = (v >> 2) & 3, z = v >> 4;
+  const u32 tx = 2u | (x == 0 ? 1u : 0u), ty = 2u | (y == 0 ? 1u : 0u), tz = 2u | (z == 0 ? 1u : 0u);
+  const u32 plane = ((ty & 1u) ? tx : 0u) | (tx << 3);
+  const u32 cube = ((tz & 1u) ? plane : 0u) | (plane << 9);
+  return (cube & ~cmask) == 0u;
+}
 
 // Staging by ROWS (round 4): a thread takes one (y, z) row of the staged region and loads it as 16-byte words — the eight
 // cells inside the block's own x range (SEG 0: two words per plane from a fine block, one from a coarse block, whose four
@@ -781,8 +857,11 @@ __global__ __launch_bounds__(kMcThreads) __attribute__((amdgpu_waves_per_eu(4, 4
     const bool fine_known = staged && !coarse && (amax + 2) * kBlockSide < (1 << 18);  // uniform
     // ---- candidates, in two groups so that a wave evaluates voxels of ONE kind: the known-stencil evaluation is ~10x shorter
     // than the literal one, and a wave that holds a single literal voxel pays for both
+    // ... and so has a coarse voxel whose 3^3 fine cells lie in coarse blocks (trilinear_coarse_known): the front list of a coarse block
+    const bool coarse_known = staged && coarse && (amax + 2) * kBlockSide < (1 << 18) && !(flag_overflow & 2);  // uniform; bit 1: MRH_MC_NO_COARSE_KNOWN (A/B, tests)
+    const int known_mode = coarse ? kMcCoarseKnown : kMcFineKnown;
     auto push = [&](const int v) {
-      if (fine_known && !voxel_touches_coarse(v, cmask)) s_cand[atomicAdd(&s_ncand[0], 1u)] = (unsigned short) v;
+      if ((fine_known && !voxel_touches_coarse(v, cmask)) || (coarse_known && coarse_voxel_in_coarse_cells(v, cmask))) s_cand[atomicAdd(&s_ncand[0], 1u)] = (unsigned short) v;
       else s_cand[511u - atomicAdd(&s_ncand[1], 1u)] = (unsigned short) v;
     };
     if (!mine) {
@@ -903,7 +982,7 @@ __global__ __launch_bounds__(kMcThreads) __attribute__((amdgpu_waves_per_eu(4, 4
           const int ci = active ? (i >> 3) : 0;
           const int v = s_cand[kind == 0 ? ci : 511 - ci];
           McCorner cr;
-          const int ntri = mc_group<false>(m, t, nb, voxel_position(v), v, kind == 0, corner, gb, active, nullptr, 0, &cr);
+          const int ntri = mc_group<false>(m, t, nb, voxel_position(v), v, kind == 0 ? known_mode : kMcLiteral, corner, gb, active, nullptr, 0, &cr);
           if (active && corner == 0) s_ntri[v] = (uint8_t) ntri;
           if (R.recs && ntri > 0 && s_rec[0] != kMcNoRecords) {  // group-uniform
             u32 slot = 0;
@@ -969,8 +1048,8 @@ __global__ __launch_bounds__(kMcThreads) __attribute__((amdgpu_waves_per_eu(4, 4
           const int v = s_cand[kind == 0 ? ci : 511 - ci];
           const u64 first = offsets[e] + s_off[v];
           const int room = first >= max_tris ? 0 : (int) (max_tris - first < 5 ? max_tris - first : 5);
-          const int ntri = mc_group<true>(m, t, nb, voxel_position(v), v, kind == 0, corner, gb, active, out + first, room);  // straight to the exact offset
-          if (flag_overflow && active && corner == 0 && ntri > room) atomicOr((u32*) &t.ctr[CTR_ERROR], ERR_TRI);
+          const int ntri = mc_group<true>(m, t, nb, voxel_position(v), v, kind == 0 ? known_mode : kMcLiteral, corner, gb, active, out + first, room);  // straight to the exact offset
+          if ((flag_overflow & 1) && active && corner == 0 && ntri > room) atomicOr((u32*) &t.ctr[CTR_ERROR], ERR_TRI);
         }
 #ifdef MRH_MC_TRACE
         if (kind == 0) { __syncthreads(); MRH_MC_TS(tsk); MRH_MC_ACC(2, ts2, tsk); MRH_MC_ACC(3, 0, -tsk); }

@@ -556,6 +556,32 @@ def test_emit_from_corner_records_equals_the_two_pass_emit(hip, monkeypatch, var
     e.close()
 
 
+def test_known_sample_cells_of_coarse_voxels_equal_the_literal_evaluation(hip, monkeypatch):
+    """A coarse voxel whose 3^3 fine cells lie in coarse blocks is evaluated with its sample cells as integers
+    (trilinear_coarse_known: lattice points the reference's rounding cannot miss); MRH_MC_NO_COARSE_KNOWN=1 keeps the literal
+    float conversions for every coarse voxel.  Same soup, byte for byte, from the record path and from the two-pass emit, on a
+    multi-resolution map (far from the origin too: the conversions' error grows with the coordinates)."""
+    params = dict(synth.REPLICA_PARAMS, sdf_var_threshold=0.005, n_frames_invalidate_voxels=10)
+    for offset in ((0.0, 0.0, 0.0), (137.3, -61.7, 44.1)):
+        e = pu.make_engine(hip, synth.REPLICA_640, params, 131072)
+        for f in synth.replica_stream(10):
+            f.t = (f.t + np.asarray(offset, np.float32)).astype(np.float32)
+            pu.feed(e, f)
+        e.sync()
+        assert e.stats().occupied_coarse > 1000
+        known = e.extract_triangles().tobytes()
+        monkeypatch.setenv("MRH_MC_NO_RECORDS", "1")
+        known_two_pass = e.extract_triangles().tobytes()
+        monkeypatch.setenv("MRH_MC_NO_COARSE_KNOWN", "1")
+        literal_two_pass = e.extract_triangles().tobytes()
+        monkeypatch.delenv("MRH_MC_NO_RECORDS")
+        literal = e.extract_triangles().tobytes()
+        monkeypatch.delenv("MRH_MC_NO_COARSE_KNOWN")
+        assert len(literal) > 72 * 100000
+        assert known == literal and known_two_pass == literal and literal_two_pass == literal
+        e.close()
+
+
 def test_block_order_by_counting_equals_the_radix_sort(hip, monkeypatch):
     """The extraction's canonical block order comes from a rank-by-counting pass (k_block_rank) with the offsets from a
     one-workgroup scan; rocPRIM's radix sort + scan stay for long lists (MRH_MC_RADIX_SORT=1 forces them).  Same soup,

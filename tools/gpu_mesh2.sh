@@ -1,7 +1,7 @@
 #!/bin/bash
 # mesh tests + extraction numbers + kernel stats of the extraction leg
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out
-timeout 1200 python -m pytest tests/test_parity_gpu.py tests/test_geowrapper_gpu.py tests/test_sharding_gpu.py -x -q -m gpu -k "mesh or records or counting or extract or gather" 2>&1 | tail -8
+timeout 1200 python -m pytest tests/test_parity_gpu.py tests/test_geowrapper_gpu.py tests/test_sharding_gpu.py -x -q -m gpu -k "mesh or records or counting or extract or gather or known or multires" 2>&1 | tail -8
 for v in "" ""; do
   env $v timeout 600 python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu --no-pmc > gpurun_out/mc_line.json 2> gpurun_out/mc_line.err
   python - "$v" <<PY
