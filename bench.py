@@ -135,27 +135,9 @@ class Resident:
         self.rgb = hipmem.DeviceBuffer.from_numpy(np.stack([f.rgb for f in frames]))
         hipmem.synchronize()
         self.ds, self.rs = K.rows * K.cols * 4, K.rows * K.cols * 3
-        # the four calls of a frame with their arguments converted ONCE: poses as ctypes arrays, image addresses as c_void_p.
-        # The timed loop is the library's entry points, not numpy's argument conversions (set_pose through capi.Engine: two
-        # ascontiguousarray + two data_as per frame, ~5 us of a 34 us frame that tools/host_path_breakdown.py shows host-bound)
-        import ctypes as C
-        self._R = [(C.c_float * 9)(*np.asarray(f.R, np.float32).reshape(9)) for f in frames]
-        self._t = [(C.c_float * 3)(*np.asarray(f.t, np.float32).reshape(3)) for f in frames]
-        self._d = [C.c_void_p(self.depth.ptr + i * self.ds) for i in range(len(frames))]
-        self._c = [C.c_void_p(self.rgb.ptr + i * self.rs) for i in range(len(frames))]
 
     def run(self, engine, lo, hi, integrate=None):
         K = self.K
-        if integrate is None and getattr(engine, "lib", None) is not None and hasattr(engine.lib, "mrh_integrate") and not os.environ.get("MRH_BENCH_SLOW_CALLS"):
-            lib, ctx = engine.lib, engine._ctx
-            set_pose, set_depth, set_rgb, integ = lib.mrh_set_pose, lib.mrh_set_depth_device, lib.mrh_set_rgb_device, lib.mrh_integrate
-            R, t, d, c, rows, cols = self._R, self._t, self._d, self._c, K.rows, K.cols
-            for i in range(lo, hi):
-                rc = set_pose(ctx, R[i], t[i]) or set_depth(ctx, d[i], rows, cols) or set_rgb(ctx, c[i], rows, cols) or integ(ctx, -1)
-                if rc:
-                    engine._check(rc)  # raises with the library's message (a pending exchange cannot occur: single context, unsharded)
-                    raise RuntimeError(f"mrh_integrate returned {rc}")
-            return
         for i in range(lo, hi):
             f = self.frames[i]
             engine.set_pose(f.R, f.t)
