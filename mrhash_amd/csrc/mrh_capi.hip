@@ -294,6 +294,7 @@ struct mrh_ctx {
   const int4* d_tri_sorted = nullptr;
   const u32* d_tri_counts = nullptr;
   u64* h_mc = nullptr;  // pinned: triangle total of the extraction in flight
+  hipEvent_t ev_mc_total = nullptr;  // ... has landed
   u32* d_mc_recs = nullptr; size_t mc_rec_cap = 0;  // corner records of the count pass (mrh_mc.h McRecords), grow-only
   uint64_t mc_rec_fallbacks = 0;                    // extractions whose records did not fit (emitted by k_mc<emit> instead)
   HostVec<double> V, C;
@@ -416,6 +417,7 @@ void free_all(mrh_ctx* c) {
   F(c->d_upd_partials); F(c->d_misc); F(c->d_rcp_w); F(c->d_cfree); F(c->d_zmin); F(c->d_points); F(c->d_pt_counts); F(c->d_pt_offsets); F(c->d_rec_keys[0]); F(c->d_rec_keys[1]); F(c->d_rec_vals[0]); F(c->d_rec_vals[1]); F(c->d_sort_tmp); F(c->scan.vcnt); F(c->scan.bstamp); F(c->scan.touched); F(c->scan.st_meta); F(c->scan.st_sdf); F(c->scan.st_grp); F(c->scan.wgdesc); F(c->scan.rec); F(c->scan.chunks); F(c->d_scan_ctr); F(c->fast.summary); F(c->fast.summary_c); F(c->fast.bbox); F(c->d_cnt_partials);
   F(c->d_pack); F(c->d_halo); F(c->d_taken); F(c->d_cloud); F(c->d_normals); F(c->d_soup); F(c->d_mc_recs);
   for (hipEvent_t e : c->mc_ev) if (e) (void) hipEventDestroy(e);
+  if (c->ev_mc_total) (void) hipEventDestroy(c->ev_mc_total);
   comm_release(c);
   F(c->d_xsend); F(c->d_xrecv); F(c->d_acc);
   for (hipEvent_t e : c->comm_ev) if (e) (void) hipEventDestroy(e);
@@ -2933,8 +2935,12 @@ int mrh_extract_triangles(mrh_ctx* c, const mrh_triangle** out_tris, uint64_t* o
     // head room): a map that is extracted again — the usual case — needs no round trip between the two passes.  Writes beyond
     // the capacity are suppressed by the kernel; if the total turns out larger, the buffer grows and the pass runs again.
     const u64 spec_cap = std::min<u64>(c->soup_cap, c->max_triangles);
+    // the host waits for the TOTAL, not for the emit pass behind it: it sizes and enqueues the post-process while the emit pass
+    // runs (a stream synchronisation here left the GPU idle for the ~20 us of the host's round trip and first launch)
+    if (!c->ev_mc_total) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_mc_total, hipEventDisableTiming));
+    HIP_TRY(c, hipEventRecord(c->ev_mc_total, s));
     if (spec_cap > 0) emit(spec_cap, 0, use_records);
-    HIP_TRY(c, hipStreamSynchronize(s));
+    HIP_TRY(c, hipEventSynchronize(c->ev_mc_total));
     const u64 total = c->h_mc[0];
     const u64 rec_demand = c->h_mc[1] & ~(1ull << 63);
     const bool records_ok = use_records && (c->h_mc[1] >> 63) == 0;
