@@ -115,7 +115,10 @@ struct HostVec {
       // the whole span is kept (the unaligned head stays untouched, i.e. unbacked): one munmap releases it
       char* aligned = (char*) (((uintptr_t) m + (2u << 20) - 1) & ~(uintptr_t) ((2u << 20) - 1));
       (void) madvise(aligned, bytes, MADV_HUGEPAGE);
-      for (size_t o = 0; o < bytes; o += 4096) ((volatile char*) aligned)[o] = 0;  // fault the pages in (as huge pages) before they are pinned
+      // fault the pages in (as huge pages) before they are pinned; a buffer the device never sees is faulted in by whoever
+      // writes it first — the widening threads, side by side (47 MB of V / C at the driver's workload: zeroing them here, on one
+      // thread, was most of a context's first extraction)
+      if (pin) for (size_t o = 0; o < bytes; o += 4096) ((volatile char*) aligned)[o] = 0;
       span = sp;
       head = (size_t) (aligned - (char*) m);
       p = (T*) aligned;
