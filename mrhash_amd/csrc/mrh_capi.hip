@@ -768,11 +768,10 @@ int process_triangles_device(mrh_ctx* c, const mrh_triangle* d_tris, const size_
   const u32 n = (u32) (nt * 3), ntr = (u32) nt;
   const double eps = (double) c->p.vertices_merging_threshold;
   const double inv_eps = eps != 0.0 ? 1.0 / eps : 0.0;
-  const size_t tmp_bytes = mesh_scan_tmp_bytes(n);
   const u32 cap = (u32) next_pow2((uint64_t) n * 2);  // load factor <= 1/2
   const u32 fcap = (u32) next_pow2((uint64_t) ntr * 2);
   MeshScratch m;
-  m.bytes = (size_t) n * 4 * 5 + ((size_t) cap + fcap) * 4 + tmp_bytes + 32 * 256;
+  m.bytes = (size_t) n * 4 * 5 + ((size_t) cap + fcap) * 4 + 32 * 256;
   {
     const int arc = arena_get(c, 1, m.bytes, &m.base);
     if (arc) return arc;
@@ -785,12 +784,12 @@ int process_triangles_device(mrh_ctx* c, const mrh_triangle* d_tris, const size_
   const size_t clear_words = (size_t) ((ftable + fcap) - (u32*) m.base);
   const bool tables_clean = !c->f64_link && c->mesh_clean_base == m.base && c->mesh_clean_words >= clear_words && !getenv("MRH_MESH_FILL");
   c->mesh_clean_words = 0;  // dirty from here on, until a clear is enqueued
-  u32* rep = m.take<u32>(n);   u32* first = m.take<u32>(n);   u32* vid = m.take<u32>(n);   u32* corner = m.take<u32>(n);
-  u32* keep = m.take<u32>(n);  // faces: keep + fpos share it (nt + nt <= n)
-  u32* fpos = keep + ntr;
+  const u32 vtiles = (n + kMeshTile - 1) / kMeshTile, ftiles = (ntr + 255) / 256;
+  u32* rep = m.take<u32>(n);   u32* vloc = m.take<u32>(n);   u32* corner = m.take<u32>(n);
+  u32* floc = m.take<u32>(n);  // faces (nt <= n)
+  u32* tcount = m.take<u32>(vtiles);  u32* toff = m.take<u32>(vtiles);  // first occurrences per vertex tile, and their scan
+  u32* fcount = m.take<u32>(ftiles);  u32* foff = m.take<u32>(ftiles);  // kept faces per face tile
   u64* d_totals = m.take<u64>(2);
-  void* tmp = m.take<char>(tmp_bytes ? tmp_bytes : 1);
-  size_t tb = tmp_bytes;
   const u32 gv = (n + 255) / 256, gf = (ntr + 255) / 256;
   const float* soup = (const float*) d_tris;
   int rc = MRH_OK;
@@ -818,15 +817,15 @@ int process_triangles_device(mrh_ctx* c, const mrh_triangle* d_tris, const size_
     // ---- vertices
     if (!tables_clean) MESH_TRY(hipMemsetAsync(m.base, 0xFF, clear_words * 4, s));
     k_mesh_vertex_insert<<<(n + kMeshTile - 1) / kMeshTile, kMeshTile, 0, s>>>(soup, n, eps, inv_eps, table, cap - 1, rep);
-    k_mesh_vertex_rep<<<(n + kMeshTile - 1) / kMeshTile, kMeshTile, 0, s>>>(soup, n, eps, inv_eps, table, cap - 1, rep, first);
-    MESH_TRY(rocprim::exclusive_scan(tmp, tb, first, vid, 0u, n, rocprim::plus<u32>(), s));
-    if (f64) k_mesh_emit_vertices<double><<<gv, 256, 0, s>>>(soup, rep, first, vid, n, (double*) dV, (double*) dC, corner, d_totals);
-    else k_mesh_emit_vertices<float><<<gv, 256, 0, s>>>(soup, rep, first, vid, n, (float*) dV, (float*) dC, corner, d_totals);
+    k_mesh_vertex_rep<<<vtiles, kMeshTile, 0, s>>>(soup, n, eps, inv_eps, table, cap - 1, rep, vloc, tcount);
+    k_tile_scan<<<1, 1024, 0, s>>>(tcount, vtiles, toff, d_totals);
+    if (f64) k_mesh_emit_vertices<double><<<gv, 256, 0, s>>>(soup, rep, vloc, toff, n, (double*) dV, (double*) dC, corner);
+    else k_mesh_emit_vertices<float><<<gv, 256, 0, s>>>(soup, rep, vloc, toff, n, (float*) dV, (float*) dC, corner);
     // ---- faces
     k_mesh_face_insert<<<gf, 256, 0, s>>>(corner, ntr, ftable, fcap - 1);
-    k_mesh_face_keep<<<gf, 256, 0, s>>>(corner, ntr, ftable, fcap - 1, keep);
-    MESH_TRY(rocprim::exclusive_scan(tmp, tb, keep, fpos, 0u, ntr, rocprim::plus<u32>(), s));
-    k_mesh_emit_faces<<<gf, 256, 0, s>>>(corner, keep, fpos, ntr, dF, d_totals);
+    k_mesh_face_keep<<<gf, 256, 0, s>>>(corner, ntr, ftable, fcap - 1, floc, fcount);
+    k_tile_scan<<<1, 1024, 0, s>>>(fcount, ftiles, foff, d_totals + 1);
+    k_mesh_emit_faces<<<gf, 256, 0, s>>>(corner, floc, foff, ntr, dF);
     const bool dbg = getenv("MRH_DEBUG") != nullptr;
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t0 = now();

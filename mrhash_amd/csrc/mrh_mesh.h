@@ -112,10 +112,53 @@ __global__ __launch_bounds__(kMeshTile) void k_mesh_vertex_insert(const float* _
     s = (s + 1) & mask;
   }
 }
-// rep[] comes in holding the tile-local representatives and leaves holding the global ones
+// exclusive rank of `flag` among the threads of the workgroup (NW waves) in thread order, and the workgroup's total
+template <int NW>
+__device__ __forceinline__ u32 tile_rank(const bool flag, u32* s_w, u32& total) {
+  const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const u64 bal = __ballot(flag);
+  if (lane == 0) s_w[wave] = (u32) __popcll(bal);
+  __syncthreads();
+  u32 before = 0;
+  total = 0;
+#pragma unroll
+  for (int w = 0; w < NW; w++) { if ((u32) w < wave) before += s_w[w]; total += s_w[w]; }
+  return before + (u32) __popcll(bal & ((1ull << lane) - 1ull));
+}
+// The new index of a vertex / the position of a kept face = exclusive scan of a 0 / 1 flag in soup order.  The kernels that
+// produce the flags work in tiles anyway: they leave the rank INSIDE the tile per element and one count per tile, one workgroup
+// scans the tile counts (k_tile_scan; 3 123 tiles for 1.6 M soup vertices) and the consumers add the two — where rocPRIM's
+// device scan took two launches and a pass over the flags each time (2 x 14 us per extraction).
+__global__ __launch_bounds__(1024) void k_tile_scan(const u32* __restrict__ counts, const u32 n, u32* __restrict__ offsets, u64* __restrict__ total_out) {
+  __shared__ u32 s_w[16];
+  const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  u32 carry = 0;
+  for (u32 base = 0; base < n; base += 1024) {
+    const u32 i = base + threadIdx.x;
+    const u32 c = i < n ? counts[i] : 0u;
+    u32 incl = c;
+    for (int off = 1; off < 64; off <<= 1) {
+      const u32 o = __shfl_up(incl, off);
+      if ((int) lane >= off) incl += o;
+    }
+    if (lane == 63) s_w[wave] = incl;
+    __syncthreads();
+    u32 before = 0, all = 0;
+    for (u32 w = 0; w < 16; w++) { if (w < wave) before += s_w[w]; all += s_w[w]; }
+    if (i < n) offsets[i] = carry + before + incl - c;
+    carry += all;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *total_out = (u64) carry;
+}
+
+// rep[] comes in holding the tile-local representatives and leaves holding the global ones; vloc[i] = first occurrences before i
+// inside i's tile, tcount[tile] = first occurrences of the tile
 __global__ __launch_bounds__(kMeshTile) void k_mesh_vertex_rep(const float* __restrict__ soup, const u32 n, const double eps, const double inv_eps,
-                                                               const u32* __restrict__ table, const u32 mask, u32* __restrict__ rep, u32* __restrict__ is_first) {
+                                                               const u32* __restrict__ table, const u32 mask, u32* __restrict__ rep, u32* __restrict__ vloc,
+                                                               u32* __restrict__ tcount) {
   __shared__ u32 s_rep[kMeshTile];
+  __shared__ u32 s_w[kMeshTile / 64];
   const u32 tl = threadIdx.x, i = blockIdx.x * kMeshTile + tl;
   const u32 lr = i < n ? rep[i] : i;
   const bool local_first = i < n && lr == i;
@@ -135,25 +178,29 @@ __global__ __launch_bounds__(kMeshTile) void k_mesh_vertex_rep(const float* __re
   }
   s_rep[tl] = r;
   __syncthreads();
+  if (i < n && !local_first) r = s_rep[lr - blockIdx.x * kMeshTile];
+  u32 total;
+  const u32 rank = tile_rank<kMeshTile / 64>(i < n && r == i, s_w, total);
+  if (tl == 0) tcount[blockIdx.x] = total;
   if (i >= n) return;
-  if (!local_first) r = s_rep[lr - blockIdx.x * kMeshTile];
   rep[i] = r;
-  is_first[i] = (r == i) ? 1u : 0u;
+  vloc[i] = rank;
 }
 
 // T = float: V and C leave the device as the fp32 values marching cubes computed (the host widens them while the link is still
 // busy, mrh_capi.hip: k_stage_out / widen_from_staging); T = double: widened here (MRH_MESH_F64_LINK=1, the round-3 path)
 template <typename T>
 __global__ __launch_bounds__(256) void k_mesh_emit_vertices(const float* __restrict__ soup, const u32* __restrict__ rep,
-                                                            const u32* __restrict__ is_first, const u32* __restrict__ vid, const u32 n,
-                                                            T* __restrict__ V, T* __restrict__ C, u32* __restrict__ corner, u64* __restrict__ totals) {
+                                                            const u32* __restrict__ vloc, const u32* __restrict__ toff, const u32 n,
+                                                            T* __restrict__ V, T* __restrict__ C, u32* __restrict__ corner) {
   const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  corner[i] = vid[rep[i]];
-  if (i == n - 1) totals[0] = (u64) vid[i] + is_first[i];  // unique vertices, for the host and for the copy kernel
-  if (is_first[i]) {
+  const u32 r = rep[i];
+  const u32 id = toff[r / kMeshTile] + vloc[r];  // new index of the representative (k_mesh_vertex_rep's tiles + k_tile_scan)
+  corner[i] = id;
+  if (r == i) {
     const float* v = soup + (size_t) i * 6;
-    const size_t o = (size_t) vid[i] * 3;
+    const size_t o = (size_t) id * 3;
     V[o] = (T) v[0]; V[o + 1] = (T) v[1]; V[o + 2] = (T) v[2];
     C[o] = (T) v[3]; C[o + 1] = (T) v[4]; C[o + 2] = (T) v[5];
   }
@@ -176,27 +223,34 @@ __global__ __launch_bounds__(256) void k_mesh_face_insert(const u32* __restrict_
 }
 // keep = first occurrence of its (a, b, c) triple and not degenerate (mesh_extractor.cpp:57-75, :156-178)
 __global__ __launch_bounds__(256) void k_mesh_face_keep(const u32* __restrict__ corner, const u32 nt, const u32* __restrict__ table, const u32 mask,
-                                                        u32* __restrict__ keep) {
+                                                        u32* __restrict__ floc, u32* __restrict__ fcount) {
+  __shared__ u32 s_w[4];
   const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= nt) return;
-  const Key96 key = face_key(corner, t);
-  u32 s = key_hash(key) & mask, r = t;
-  for (;;) {
-    const u32 cur = table[s];
-    if (key_eq(face_key(corner, cur), key)) { r = cur; break; }
-    s = (s + 1) & mask;
+  bool kept = false;
+  if (t < nt) {
+    const Key96 key = face_key(corner, t);
+    u32 s = key_hash(key) & mask, r = t;
+    for (;;) {
+      const u32 cur = table[s];
+      if (key_eq(face_key(corner, cur), key)) { r = cur; break; }
+      s = (s + 1) & mask;
+    }
+    const bool degenerate = key.a == key.b || key.a == key.c || key.b == key.c;
+    kept = r == t && !degenerate;
   }
-  const bool degenerate = key.a == key.b || key.a == key.c || key.b == key.c;
-  keep[t] = (r == t && !degenerate) ? 1u : 0u;
+  u32 total;
+  const u32 rank = tile_rank<4>(kept, s_w, total);
+  if (threadIdx.x == 0) fcount[blockIdx.x] = total;
+  if (t < nt) floc[t] = rank | (kept ? 0x80000000u : 0u);  // rank inside the 256-face tile | kept
 }
 
-__global__ __launch_bounds__(256) void k_mesh_emit_faces(const u32* __restrict__ corner, const u32* __restrict__ keep, const u32* __restrict__ fpos,
-                                                         const u32 nt, int* __restrict__ F, u64* __restrict__ totals) {
+__global__ __launch_bounds__(256) void k_mesh_emit_faces(const u32* __restrict__ corner, const u32* __restrict__ floc, const u32* __restrict__ foff,
+                                                         const u32 nt, int* __restrict__ F) {
   const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= nt) return;
-  if (t == nt - 1) totals[1] = (u64) fpos[t] + keep[t];  // kept faces
-  if (!keep[t]) return;
-  const size_t o = (size_t) fpos[t] * 3;
+  const u32 fl = floc[t];
+  if (!(fl & 0x80000000u)) return;
+  const size_t o = (size_t) (foff[blockIdx.x] + (fl & 0x7FFFFFFFu)) * 3;
   F[o] = (int) corner[3 * t]; F[o + 1] = (int) corner[3 * t + 1]; F[o + 2] = (int) corner[3 * t + 2];
 }
 
@@ -214,11 +268,6 @@ struct MeshScratch {
   }
 };
 
-inline size_t mesh_scan_tmp_bytes(const u32 n) {
-  size_t d = 0;
-  (void) rocprim::exclusive_scan(nullptr, d, (u32*) nullptr, (u32*) nullptr, 0u, n, rocprim::plus<u32>());
-  return d;
-}
 
 // per-block triangle runs of several ranks -> one buffer in canonical block order (mrh_process_triangle_runs): run r copies
 // count triangles (72 B = 4.5 x uint4, moved as 9 x 8-byte words) from src to dst
