@@ -571,11 +571,14 @@ int compact_all(mrh_ctx* c, int* out_n) {
   hipStream_t s = c->stream;
   HIP_TRY(c, hipMemsetAsync(&c->tab.ctr[CTR_COMPACT], 0, sizeof(int), s));
   k_compact<<<512, 256, 0, s>>>(c->cam, c->map, c->tab, 0);
-  int n = 0;
-  HIP_TRY(c, hipMemcpyAsync(&n, &c->tab.ctr[CTR_COMPACT], sizeof(int), hipMemcpyDeviceToHost, s));
+  if (!c->h_mc) {  // pinned: a copy into a stack variable is staged by the runtime
+    HIP_TRY(c, hipHostMalloc((void**) &c->h_mc, 8 * sizeof(u64), hipHostMallocDefault));
+    memset(c->h_mc, 0, 8 * sizeof(u64));
+  }
+  HIP_TRY(c, hipMemcpyAsync(c->h_mc + 4, &c->tab.ctr[CTR_COMPACT], sizeof(int), hipMemcpyDeviceToHost, s));
   HIP_TRY(c, hipStreamSynchronize(s));
   HIP_TRY(c, hipGetLastError());
-  *out_n = n;
+  *out_n = *(const int*) (c->h_mc + 4);
   return MRH_OK;
 }
 
@@ -796,8 +799,8 @@ int process_triangles_device(mrh_ctx* c, const mrh_triangle* d_tris, const size_
   void *dV = nullptr, *dC = nullptr;  // doubles with f64_link, floats otherwise
   int* dF = nullptr;
   if (!c->h_mc) {
-    HIP_TRY(c, hipHostMalloc((void**) &c->h_mc, 4 * sizeof(u64), hipHostMallocDefault));
-    memset(c->h_mc, 0, 4 * sizeof(u64));
+    HIP_TRY(c, hipHostMalloc((void**) &c->h_mc, 8 * sizeof(u64), hipHostMallocDefault));
+    memset(c->h_mc, 0, 8 * sizeof(u64));
   }
   const bool f64 = c->f64_link;
   if (!f64) widen_prewake();  // the helper threads are awake and spinning by the time the first chunk lands
@@ -2865,8 +2868,8 @@ int mrh_extract_triangles(mrh_ctx* c, const mrh_triangle** out_tris, uint64_t* o
       tmp = a.take<char>(tmp_bytes ? tmp_bytes : 1);
     }
     if (!c->h_mc) {
-      HIP_TRY(c, hipHostMalloc((void**) &c->h_mc, 4 * sizeof(u64), hipHostMallocDefault));
-      memset(c->h_mc, 0, 4 * sizeof(u64));
+      HIP_TRY(c, hipHostMalloc((void**) &c->h_mc, 8 * sizeof(u64), hipHostMallocDefault));
+      memset(c->h_mc, 0, 8 * sizeof(u64));
     }
     const bool no_rank_sort = getenv("MRH_MC_RADIX_SORT") != nullptr;  // MRH_MC_RADIX_SORT=1: rocPRIM's sort + scan for every list (A/B, tests)
     if (n <= kRankSortMax && !no_rank_sort) {  // canonical order by counting (mrh_mc.h: k_block_rank)
