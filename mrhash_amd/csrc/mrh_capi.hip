@@ -910,7 +910,12 @@ int process_triangles_device(mrh_ctx* c, const mrh_triangle* d_tris, const size_
         for (u32 spins = 1;; spins++) {
           if (hdr[2] == (u64) epoch) break;
           MRH_CPU_RELAX();
-          if ((spins & 1023u) == 0 && drained(&drain)) { if (hdr[2] == (u64) epoch) break; return false; }
+          if ((spins & 1023u) == 0 && drained(&drain)) {  // dry: the header is there, or about to be — or the launch failed
+            const auto t = std::chrono::steady_clock::now();
+            while (hdr[2] != (u64) epoch && std::chrono::steady_clock::now() - t < std::chrono::milliseconds(200)) MRH_CPU_RELAX();
+            if (hdr[2] == (u64) epoch) break;
+            return false;
+          }
         }
         std::atomic_thread_fence(std::memory_order_acquire);
         return true;
@@ -1460,6 +1465,9 @@ struct CopyPool {
         if (abort_widen.load(std::memory_order_relaxed)) return;
         MRH_CPU_RELAX();
         if (drained && (spins & 1023u) == 0 && drained(arg)) {
+          // the stream has run dry: everything the launch wrote is visible, or about to be — only a flag that stays away is an error
+          const int64_t t = now_ns();
+          while (fl[lc] != epoch && now_ns() - t < 200000000) MRH_CPU_RELAX();
           if (fl[lc] == epoch) break;
           abort_widen.store(1, std::memory_order_relaxed);
           return;
@@ -1501,16 +1509,29 @@ struct CopyPool {
       widen_chunk(j, i, drained, arg);
       done.fetch_add(1, std::memory_order_acq_rel);
     }
+    bool flags_checked = false;
     while (done.load(std::memory_order_acquire) < nc) {
       MRH_CPU_RELAX();
-      // a helper stuck on a flag that will never come: the stream check is ours to make
-      if (drained && !abort_widen.load(std::memory_order_relaxed)) {
+      // A helper may be stuck on a flag that will never come (a failed launch): the stream check is ours to make.  Once the stream
+      // is dry every flag of a good launch is set; then the helpers are merely still working (or were descheduled, or are faulting
+      // fresh pages in) and there is nothing to do but wait for them — no time limit: the first version gave them 2 ms and failed
+      // an extraction of a healthy run once in a few hundred.
+      if (drained && !flags_checked && !abort_widen.load(std::memory_order_relaxed)) {
         static thread_local uint32_t spins = 0;
         if ((++spins & 4095u) == 0 && drained(arg)) {
-          // everything the launch wrote is visible once the stream is dry: give the helpers a moment, then release them
           const int64_t t = now_ns();
-          while (done.load(std::memory_order_acquire) < nc && now_ns() - t < 2000000) MRH_CPU_RELAX();
-          if (done.load(std::memory_order_acquire) < nc) abort_widen.store(1, std::memory_order_relaxed);
+          bool missing = true;
+          while (missing && now_ns() - t < 200000000) {
+            missing = false;
+            for (int part = 0; part < 2 && !missing; part++) {
+              const volatile uint32_t* fl = flags[part];
+              if (!fl) continue;
+              for (size_t k = 0; k < per; k++) if (fl[k] != epoch) { missing = true; break; }
+            }
+            if (missing) MRH_CPU_RELAX();
+          }
+          if (missing) abort_widen.store(1, std::memory_order_relaxed);
+          flags_checked = true;
         }
       }
     }
