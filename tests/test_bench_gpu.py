@@ -36,6 +36,10 @@ def test_single_gpu_line():
     assert d["pcie_inclusive_frames_per_s"] > 0 and "workload" in d["config"]
     assert d["periodic_frames"]["steady_frame_ms"] > 0 and d["periodic_frames"]["starve_frame_ms"] > d["periodic_frames"]["steady_frame_ms"]
     assert d["spherical_images"]["frames_per_s"] > 0 and d["roofline"]["k_front_ms_avg"] > 0
+    # the parts of the legs that need profile mode run after every timed region and fill these in
+    assert len(d["spherical_images"]["passes_ms_per_frame"]) == 3 and d["spherical_images"]["roofline"]["frac"] > 0
+    assert d["mc"]["k_mc_count_ms"] > 0 and d["mc"]["roofline"]["frac"] > 0 and d["mc"]["first_extract_ms"] >= d["mc"]["extract_ms_in_library"]
+    assert d["lidar"]["roofline"]["frac"] > 0 and d["lidar"]["roofline"]["updated_voxels_per_scan"] > 0
     # the oracle of the cpu_baseline leg also checks the map of the same frames through the timed loop's entry points
     assert d["parity_checked"] is True and c["parity"]["frames"] == 2 and c["parity"]["sdf_bit_exact"] and d["blocks"] == c["parity"]["oracle_blocks"] > 1000
 
