@@ -1,5 +1,6 @@
 """One-off soak on the GPU box: the randomised parity tests with many more seeds than the test suite runs.
-usage: python tests/soak.py [first_seed] [n]"""
+usage: python tests/soak.py [first_seed] [n]
+       python tests/soak.py churn [frames]      the 3 000-frame GC + paging walk of tests/test_churn_gpu.py (12 minutes)"""
 import os
 import sys
 import time
@@ -10,6 +11,16 @@ import parity_utils as pu  # noqa: E402
 import test_lidar_gpu as tl  # noqa: E402
 import test_parity_gpu as tp  # noqa: E402
 from mrhash_amd import capi  # noqa: E402
+
+if len(sys.argv) > 1 and sys.argv[1] == "churn":
+    import test_churn_gpu as tc
+
+    frames = int(sys.argv[2]) if len(sys.argv) > 2 else 3000
+    t0 = time.time()
+    line = tc.walk_with_gc_and_paging(capi.load_hip(), pu.oracle_lib(), frames=frames, pool=tc.POOL, min_paged=50000 * frames // 3000,
+                                      min_rehashes=5 * frames // 3000)
+    print(f"soak churn: OK in {time.time() - t0:.0f} s")
+    sys.exit(0)
 
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 6
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 40

@@ -34,8 +34,8 @@ def one_way_frames(n, step=0.25):
         yield synth.render(scene, K, np.array([0.0, 0.0, step * i], np.float32), np.array([0, 0, 0, 1], np.float32), depth_scaling=5000.0)
 
 
-def engine(lib, **extra):
-    e = capi.Engine(lib, capi.Params(num_sdf_blocks=POOL, **{**PARAMS, **extra}))
+def engine(lib, pool=POOL, **extra):
+    e = capi.Engine(lib, capi.Params(num_sdf_blocks=pool, **{**PARAMS, **extra}))
     e.set_camera(K.fx, K.fy, K.cx, K.cy, K.rows, K.cols, PARAMS["min_depth"], PARAMS["max_depth"])
     return e
 
@@ -45,8 +45,8 @@ class Pager:
     both engines: when fewer than 15 % of the pool are free, blocks farther than `far` from the camera leave; blocks
     within `near` of the camera come back before the frame."""
 
-    def __init__(self, e, near=3.0, far=4.5, keep=True):
-        self.e, self.near, self.far, self.store, self.paged, self.keep = e, near, far, {}, 0, keep
+    def __init__(self, e, pool=POOL, near=3.0, far=4.5, keep=True):
+        self.e, self.pool, self.near, self.far, self.store, self.paged, self.keep = e, pool, near, far, {}, 0, keep
 
     def before_frame(self, cam):
         if self.store:
@@ -57,7 +57,7 @@ class Pager:
                 v = np.stack([self.store.pop(k)[1] for k in keys])
                 self.e.import_blocks(d, v)
         free, _ = self.e.free_blocks()
-        if free <= 0.15 * POOL:
+        if free <= 0.15 * self.pool:
             d, v = self.e.stream_out(cam, self.far)
             for i in range(len(d) if self.keep else 0):
                 self.store[(int(d["x"][i]), int(d["y"][i]), int(d["z"][i]))] = (d[i], v[i])
@@ -65,15 +65,15 @@ class Pager:
             self.last = (d, v)
 
 
-def test_three_thousand_frames_of_gc_and_paging_keep_the_table_healthy(hip, oracle):
-    """3 000 frames, 750 m, GC every frame (starve every 1000th), a 3 072-block pool and the streamer paging behind the
-    camera: ~150 k blocks pass through a 16 384-slot table.  No table error, short probe paths, oracle parity of what is
-    resident at the end and of everything that was paged out on the way."""
-    a, b = engine(hip), engine(oracle)
-    pa, pb = Pager(a, keep=False), Pager(b, keep=False)
+def walk_with_gc_and_paging(hip, oracle, frames, pool, min_paged, min_rehashes, check_every=250):
+    """`frames` frames straight down the corridor, GC every frame (starve every 1000th), a `pool`-block pool and the streamer
+    paging behind the camera, on the HIP engine and the oracle side by side: every paging event must hand out the same blocks,
+    the table stays healthy, and what is resident at the end is the oracle's map and mesh."""
+    a, b = engine(hip, pool), engine(oracle, pool)
+    pa, pb = Pager(a, pool, keep=False), Pager(b, pool, keep=False)
     worst_probe = 0
     n = 0
-    for i, f in enumerate(one_way_frames(3000)):
+    for i, f in enumerate(one_way_frames(frames)):
         cam = f.t.astype(np.float64)
         pa.before_frame(cam)
         pb.before_frame(cam)
@@ -82,19 +82,21 @@ def test_three_thousand_frames_of_gc_and_paging_keep_the_table_healthy(hip, orac
             assert pb.paged == n and np.array_equal(pa.last[0], pb.last[0]) and np.array_equal(pa.last[1].view(np.uint8), pb.last[1].view(np.uint8))
         pu.feed(a, f)
         pu.feed(b, f)
-        if i % 250 == 249:
+        if i % check_every == check_every - 1:
             a.sync()  # raises on ERR_TABLE / ERR_POOL
             s = a.stats()
             worst_probe = max(worst_probe, int(s.max_probe_length))
             assert s.error_flags == 0
     a.sync()
     s = a.stats()
-    print("frames 3000: rehashes", s.rehash_count, "tombstones", s.tombstones, "slots", s.hash_slots, "max probe", max(worst_probe, s.max_probe_length),
-          "paged blocks", pa.paged)
-    assert pa.paged == pb.paged > 50000
-    assert s.rehash_count >= 5, "the walk never triggered a table rebuild: the test does not stress the table"
+    worst_probe = max(worst_probe, int(s.max_probe_length))
+    line = (f"frames {frames} pool {pool}: rehashes {s.rehash_count} tombstones {s.tombstones} slots {s.hash_slots} "
+            f"max probe {worst_probe} paged blocks {pa.paged}")
+    print(line)
+    assert pa.paged == pb.paged > min_paged
+    assert s.rehash_count >= min_rehashes, "the walk never triggered a table rebuild: the test does not stress the table"
     assert s.tombstones <= s.hash_slots // 4 + 64 * 100
-    assert max(worst_probe, int(s.max_probe_length)) <= 64
+    assert worst_probe <= 64
     assert s.error_flags == 0
     r = pu.compare_maps(a, b)
     assert r["blocks"] > 100
@@ -102,6 +104,15 @@ def test_three_thousand_frames_of_gc_and_paging_keep_the_table_healthy(hip, orac
     assert m["triangles"] > 1000
     a.close()
     b.close()
+    return line
+
+
+def test_a_walk_with_gc_and_paging_keeps_the_table_healthy(hip, oracle):
+    """The suite's share of the long walk (the reference's own churn test, mrhash/tests/test_streamer.cu:39-116, is 101 poses):
+    400 frames, 100 m, through the 3 072-block pool and its 16 384-slot table: ~20 k blocks leave (GC + the streamer paging on
+    both sides), which is several times the 4 096 erased slots that trigger a rebuild, inside the suite's time budget.  The 3 000-frame walk of rounds 2-4 is the same function
+    with its old arguments: `python tests/soak.py churn` (its result is kept under profiles/)."""
+    walk_with_gc_and_paging(hip, oracle, frames=400, pool=POOL, min_paged=5000, min_rehashes=2, check_every=50)
 
 
 def test_without_upkeep_the_same_walk_wears_the_table_out(hip, monkeypatch):
