@@ -159,7 +159,8 @@ struct mrh_ctx {
   // wait for the newest copy event, a slot is rewritten only after the last frame that read it (frame_done event).
   UpRing up_depth, up_rgb;
   bool copy_ready = false;             // copy stream and frame marks exist
-  hipEvent_t frame_done[8] = {};       // recorded on the main stream after every frame that read ring slots / when peeks are on
+  hipEvent_t frame_done[8] = {};       // recorded behind the kernels that READ a frame's ring slots (front stream for a pipelined frame): slot reuse
+  hipEvent_t peek_done[8] = {};        // recorded on the main stream behind the k_report of a mark: what the non-blocking peeks query
   uint64_t frame_seq = 1;
   // pool level for the host without a read-back stall (mrh_peek_free_blocks): a 2-int D2H per frame into pinned memory
   int* h_peek = nullptr;               // [8][8] pinned: ctr[0 .. 4] = free-list levels ... error flags per report
@@ -412,6 +413,7 @@ void free_all(mrh_ctx* c) {
       if (u.copied) (void) hipEventDestroy(u.copied);
     }
   for (hipEvent_t e : c->frame_done) if (e) (void) hipEventDestroy(e);
+  for (hipEvent_t e : c->peek_done) if (e) (void) hipEventDestroy(e);
   if (c->h_peek) (void) hipHostFree(c->h_peek);
   if (c->h_mc) (void) hipHostFree(c->h_mc);
   if (c->h_scan) (void) hipHostFree(c->h_scan);
@@ -505,14 +507,14 @@ int drain_events(mrh_ctx* c) {
 }
 
 int check_device_flags(mrh_ctx* c, u32 flags) {
+  // the flags are already cleared on the device (take_device_flags): whatever else is reported first, a scan that left its
+  // bounds has left counters behind, and the next scan must start from zero
+  if (flags & ERR_SCAN) c->scan_dirty = true;
   if (flags & ERR_RANGE) return fail(c, MRH_ERR_OUT_OF_RANGE, "a block coordinate left the packed-key range of +-2^20 blocks");
   if (flags & ERR_POOL) return fail(c, MRH_ERR_CAPACITY, "SDF block pool exhausted (num_sdf_blocks = %llu)", (unsigned long long) c->num_blocks);
   if (flags & ERR_TABLE) return fail(c, MRH_ERR_CAPACITY, "hash table probe limit reached (hash_slots = %llu)", (unsigned long long) c->slots);
   if (flags & ERR_TRI) return fail(c, MRH_ERR_CAPACITY, "triangle buffer full (max_triangles = %llu)", (unsigned long long) c->max_triangles);
-  if (flags & ERR_SCAN) {
-    c->scan_dirty = true;
-    return fail(c, MRH_ERR_DEVICE, "a LiDAR scan left its bounds (voxels per beam, touched blocks or chunks): the map is not usable");
-  }
+  if (flags & ERR_SCAN) return fail(c, MRH_ERR_DEVICE, "a LiDAR scan left its bounds (voxels per beam, touched blocks or chunks): the map is not usable");
   return MRH_OK;
 }
 
@@ -1184,7 +1186,8 @@ int mrh_create(const mrh_params* p, mrh_ctx** out) {
   CREATE_TRY(hipMalloc((void**) &c->d_cnt_partials, (size_t) 32768 * 4 * sizeof(u64)));  // max MRH_FUSED_GRID
   memset(&c->fast, 0, sizeof c->fast);
   CREATE_TRY(hipMalloc((void**) &c->fast.summary, c->num_blocks * sizeof(uint2)));
-  c->fast.compact_cap = (u32) c->num_blocks;
+  c->fast.zlist_cap = (u32) c->num_blocks;
+  if (const char* g = getenv("MRH_ZLIST_CAP")) { const int v = atoi(g); if (v > 0 && (uint64_t) v < c->num_blocks) c->fast.zlist_cap = (u32) v; }
   const size_t list_cap = c->num_blocks * (t.multi_res ? 9 : 1);  // visible / free lists may hold coarse units, too
   CREATE_TRY(hipMalloc((void**) &c->fast.bbox, list_cap * sizeof(int4)));
   if (t.multi_res) CREATE_TRY(hipMalloc((void**) &c->fast.summary_c, c->num_blocks * 8 * sizeof(uint2)));
@@ -1270,6 +1273,7 @@ int mrh_create(const mrh_params* p, mrh_ctx** out) {
   if (const char* g = getenv("MRH_MR_FUSED")) c->mr_fused = atoi(g) ? 1 : 0;
   if (const char* g = getenv("MRH_LIDAR_SORT_ROCPRIM")) c->lidar_sort_rocprim = atoi(g) ? 1 : 0;
   if (const char* g = getenv("MRH_LIDAR_BUCKETS")) c->lidar_buckets = atoi(g) ? 1 : 0;
+  if (const char* g = getenv("MRH_SCAN_SEQ_START")) c->scan2_seq = (u32) strtoul(g, nullptr, 0);  // tests: scans next to the wrap of the block stamps
   if (const char* g = getenv("MRH_REHASH_PERIOD")) { const int v = atoi(g); if (v > 0) c->census_period = v; }
   if (const char* g = getenv("MRH_REHASH_FORCE")) c->census_force = atoi(g) ? 1 : 0;
   if (const char* g = getenv("MRH_REHASH_OFF")) { if (atoi(g)) c->census_period = -1; }  // no upkeep at all (tests: shows what it prevents)
@@ -1684,17 +1688,30 @@ int mark_frame(mrh_ctx* c) {
   if (c->up_rgb.cur >= 0 && c->d_rgb == c->up_rgb.s[c->up_rgb.cur].d) used[1] = &c->up_rgb.s[c->up_rgb.cur];
   if (!used[0] && !used[1] && !c->peek_enabled) return MRH_OK;
   const uint64_t seq = c->frame_seq++;
-  if (c->peek_enabled) {
-    k_report<<<1, 64, 0, c->stream>>>(&c->tab.ctr[CTR_HEAP_FINE], c->h_peek + 8 * (seq % 8));  // ctr[0 .. 4]
-    HIP_TRY(c, hipGetLastError());
-    c->peek_seq[seq % 8] = seq;
-  }
   if (!c->frame_done[0])
     for (hipEvent_t& e : c->frame_done) HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  // the raw images of a pipelined frame are read by its front half, on the front stream (its integration reads the cleaned copy)
-  HIP_TRY(c, hipEventRecord(c->frame_done[seq % 8], (c->last_frame_lazy && c->npend) ? c->stream_front : c->stream));
-  for (UpSlot* u : used) if (u) u->last_seq = seq;
-  if (c->npend && c->last_frame_lazy && c->peek_enabled) c->pendq[c->npend - 1].report_seq = seq;  // written before the deferred integration: refreshed behind it
+  const bool lazy = c->last_frame_lazy && c->npend;  // the frame's integration is not enqueued yet (launch_pending)
+  if (c->peek_enabled) {
+    if (!c->peek_done[0])
+      for (hipEvent_t& e : c->peek_done) HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    if (lazy) {
+      // The report of a pipelined frame is written behind its integration, by launch_pending; until then the mark does not
+      // exist for the peeks (they fall back to an older one and say how many frames behind it is).  A report launched here would
+      // sit behind the integration of an EARLIER frame only, and an event on the front stream says nothing about it at all.
+      c->peek_seq[seq % 8] = 0;
+      c->pendq[c->npend - 1].report_seq = seq;
+    } else {
+      k_report<<<1, 64, 0, c->stream>>>(&c->tab.ctr[CTR_HEAP_FINE], c->h_peek + 8 * (seq % 8));  // ctr[0 .. 4]
+      HIP_TRY(c, hipGetLastError());
+      HIP_TRY(c, hipEventRecord(c->peek_done[seq % 8], c->stream));
+      c->peek_seq[seq % 8] = seq;
+    }
+  }
+  if (used[0] || used[1]) {
+    // the raw images of a pipelined frame are read by its front half, on the front stream (its integration reads the cleaned copy)
+    HIP_TRY(c, hipEventRecord(c->frame_done[seq % 8], lazy ? c->stream_front : c->stream));
+    for (UpSlot* u : used) if (u) u->last_seq = seq;
+  }
   return MRH_OK;
 }
 
@@ -1810,9 +1827,10 @@ int launch_pending(mrh_ctx* c, const bool count_skips = false) {
 #undef MRH_KB
   if (pb.profile) c->ev_pending.push_back(pb.ev);
   if (pb.free_) c->zombies_possible = true;
-  if (pb.report_seq && c->peek_enabled) {  // the frame's pool report was written before its integration: write it again, behind it
+  if (pb.report_seq && c->peek_enabled) {  // the frame's pool report (mark_frame left it to this launch): behind its integration
     k_report<<<1, 64, 0, s>>>(&c->tab.ctr[CTR_HEAP_FINE], c->h_peek + 8 * (pb.report_seq % 8));
-    HIP_TRY(c, hipEventRecord(c->frame_done[pb.report_seq % 8], s));
+    HIP_TRY(c, hipEventRecord(c->peek_done[pb.report_seq % 8], s));
+    c->peek_seq[pb.report_seq % 8] = pb.report_seq;  // from here on the mark exists for the peeks
   }
   HIP_TRY(c, hipGetLastError());
   return MRH_OK;
@@ -2364,8 +2382,9 @@ static int scan_prepare(mrh_ctx* c, const uint64_t n, const uint64_t rec_bound, 
     sc.st_meta = nullptr; sc.st_sdf = nullptr; sc.st_grp = nullptr; sc.rec = nullptr; sc.chunks = nullptr;
     c->scan_rec_cap = 0;
     const uint64_t cap = rec_bound;
-    // chunks: one per touched block + one per 2^16 of weight (<= records / 128) + two per long run
-    const uint64_t chunk_cap = std::min<uint64_t>(c->num_blocks, cap) + cap / 128 + 64;
+    // chunks: one per touched block + one per kScanChunkWeight of weight (a record weighs at least 32: <= records / 256, taken as
+    // records / 128) + two per run beyond kScanLongRun (the run's own chunk and the cut behind it: <= 2 * records / 65)
+    const uint64_t chunk_cap = std::min<uint64_t>(c->num_blocks, cap) + cap / 128 + 2 * cap / (kScanLongRun + 1) + 64;
     HIP_TRY(c, hipMalloc((void**) &sc.st_meta, cap * sizeof(uint2)));
     HIP_TRY(c, hipMalloc((void**) &sc.st_sdf, cap * sizeof(float)));
     HIP_TRY(c, hipMalloc((void**) &sc.st_grp, cap * sizeof(uint4)));
@@ -2453,9 +2472,11 @@ int mrh_integrate_points(mrh_ctx* c, int n_frames_invalidate) {
     auto integrate_scan_buckets = [&]() -> int {
       Scan sc = c->scan;
       sc.seq = ++c->scan2_seq;
-      if (sc.seq == 0) {  // the stamps wrapped
+      if (sc.seq >= 0x80000000u) {  // a block's stamp is seq * 2 + coarse in 32 bits: the sequence restarts at 1 with clean stamps
         HIP_TRY(c, hipMemsetAsync(sc.bstamp, 0, (size_t) c->num_blocks * sizeof(u32), s));
-        sc.seq = ++c->scan2_seq;
+        // ... and with both counter sets at zero: the restart breaks the alternation that lets a scan zero the next one's set
+        HIP_TRY(c, hipMemsetAsync(c->d_scan_ctr, 0, 2 * SC_N * sizeof(u32), s));
+        sc.seq = c->scan2_seq = 1;
       }
       sc.ctr = c->d_scan_ctr + (sc.seq & 1u) * SC_N;
       sc.ctr_next = c->d_scan_ctr + ((sc.seq + 1u) & 1u) * SC_N;
@@ -2735,7 +2756,7 @@ int mrh_peek_free_blocks(mrh_ctx* c, int64_t* out_free_fine, int64_t* out_free_c
   for (uint64_t back = 1; back <= 8 && back < c->frame_seq; back++) {
     const uint64_t seq = c->frame_seq - back;
     if (c->peek_seq[seq % 8] != seq) continue;
-    const hipError_t q = hipEventQuery(c->frame_done[seq % 8]);
+    const hipError_t q = hipEventQuery(c->peek_done[seq % 8]);
     if (q == hipErrorNotReady) continue;
     if (q != hipSuccess) return fail(c, MRH_ERR_DEVICE, "mrh_peek_free_blocks: %s", hipGetErrorString(q));
     if (c->peek_seq[seq % 8] != seq) continue;
@@ -2762,7 +2783,7 @@ int mrh_peek_error_flags(mrh_ctx* c, uint32_t* out_new_flags) {
   for (uint64_t back = 1; back <= 8 && back < c->frame_seq; back++) {
     const uint64_t seq = c->frame_seq - back;
     if (c->peek_seq[seq % 8] != seq) continue;
-    const hipError_t q = hipEventQuery(c->frame_done[seq % 8]);
+    const hipError_t q = hipEventQuery(c->peek_done[seq % 8]);
     if (q == hipErrorNotReady) continue;
     if (q != hipSuccess) return fail(c, MRH_ERR_DEVICE, "mrh_peek_error_flags: %s", hipGetErrorString(q));
     const u32 flags = (u32) c->h_peek[8 * (seq % 8) + CTR_ERROR];

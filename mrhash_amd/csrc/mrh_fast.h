@@ -20,14 +20,14 @@ struct Fast {
   uint2* dcx;          // [rows*cols] {bits of the cleaned depth (depth if in (min_depth, max_depth] else 0), r | g << 8 | b << 16}:
                        // one 8-byte access per pixel, and exactly the element of k_back's LDS footprint tile
   uint2* summary;      // [cap_blocks] {bits of min |sdf| over weighted voxels (FLT_MAX if none), max weight}
-  u32 compact_cap;     // entries in Tab::compact
-  int4* bbox;          // [compact_cap] per VISIBLE compact entry: pixel footprint {col0, row0, w, h}; w == 0: none
+  u32 zlist_cap;       // entries `zlist` holds (= pool blocks; MRH_ZLIST_CAP shrinks it for the overflow test)
+  int4* bbox;          // [pool blocks] per VISIBLE compact entry: pixel footprint {col0, row0, w, h}; w == 0: none
   uint2* summary_c;    // [8 * cap_blocks] the same summary per COARSE unit (multi-resolution maps only)
   u32* want;           // [hash slots] stamp of the last frame whose rays found this slot's key in the table (pipelined frames,
                        // mrh_fast2.h: decides whether a block that the previous frame's garbage collection emptied lives on)
   int4* zlist;         // [cap_blocks] blocks emptied by a pipelined frame's garbage collection and not yet taken out of the table
 #ifdef MRH_TRACE
-  u64* trace;          // [compact_cap * 8] per-block phase timestamps of the last k_back launch (tuning builds only)
+  u64* trace;          // [pool blocks * 8] per-block phase timestamps of the last k_back launch (tuning builds only)
 #endif
 };
 

@@ -539,7 +539,11 @@ __device__ __forceinline__ void wave_zombify(const Tab& t, const Fast& f, const 
   const u32 H = (u32) ent.w;
   if (lane == 0) {
     f.summary[H] = make_uint2(0x7F7FFFFFu, kZombieBit);
-    f.zlist[atomicAdd(&t.ctr[CTR_ZOMBIES], 1)] = ent;
+    // the list holds one entry per pool block; a block can be listed again every frame (emptied, wanted, emptied again), so on a
+    // small pool with heavy churn the count may pass the capacity before the next reclaim: the entry is then left out and
+    // k_reclaim, seeing a count above the capacity, finds the zombies by their flag instead of by the list
+    const int zi = atomicAdd(&t.ctr[CTR_ZOMBIES], 1);
+    if ((u32) zi < f.zlist_cap) f.zlist[zi] = ent;
   }
   uint4* p = (uint4*) (t.pool + (size_t) H * kFineBytes);
   const uint4 z = make_uint4(0, 0, 0, 0);
@@ -851,8 +855,17 @@ __global__ __launch_bounds__(256) void k_back(const Cam c, const Map m, const Ta
 // emptied again) or one that lives again (wanted: its summary was rewritten) is recognised by the flag, cleared atomically.
 __global__ __launch_bounds__(256) void k_reclaim(const Tab t, const Fast f) {
   const int n = t.ctr[CTR_ZOMBIES];
-  for (int e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
-    const int4 ent = f.zlist[e];
+  const bool by_flag = (u32) n > f.zlist_cap;  // the list overflowed (wave_zombify): every block below the high-water mark is a candidate
+  const int total = by_flag ? t.ctr[CTR_HWM_FINE] : n;
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+    int4 ent;
+    if (by_flag) {
+      ent = t.desc_fine[e];
+      if (!(ent.w & 1)) continue;
+      ent.w = e;
+    } else {
+      ent = f.zlist[e];
+    }
     const u32 H = (u32) ent.w;
     const u32 old = atomicAnd(&f.summary[H].y, ~kZombieBit);
     if (!(old & kZombieBit)) continue;

@@ -526,6 +526,9 @@ __global__ __launch_bounds__(256, 6) void k_scan_apply(const Map m, const Tab t,
   const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const u32 n_small = min(sc.ctr[SC_CHUNKS], sc.chunk_cap);
   const u32 n_big = min(sc.ctr[SC_BIG], sc.chunk_cap - n_small);
+  // k_scan_offsets checks each workgroup's reservation against the capacity, but the small chunks grow from the front of the
+  // array and the long runs from its end: two late reservations can each pass and still overlap.  The final totals decide.
+  if (blockIdx.x == 0 && tid == 0 && (u64) sc.ctr[SC_CHUNKS] + (u64) sc.ctr[SC_BIG] > (u64) sc.chunk_cap) atomicOr((u32*) &t.ctr[CTR_ERROR], ERR_SCAN);
   u32 updated = 0;
   ApplyWaveLds& L = s_w[wave];
   for (u32 ci = blockIdx.x * 4u + wave; ci < n_small; ci += gridDim.x * 4u) {

@@ -48,6 +48,21 @@ def test_single_scan_matches_oracle(hip, oracle):
     assert r["blocks"] > 1000 and r["sdf_bit_exact"] and r["sumsq_bit_exact"]
 
 
+def test_scans_across_the_wrap_of_the_block_stamps(hip, oracle, monkeypatch):
+    """a block's stamp is `2 * sequence + coarse` in 32 bits, so the sequence restarts at 2^31 — with clean stamps
+    and both counter sets at zero.  Six scans whose sequence numbers straddle the restart build the oracle's map."""
+    monkeypatch.setenv("MRH_SCAN_SEQ_START", str(0x7FFFFFFC))
+    a, b = _pair(hip, oracle, dict(min_weight_threshold=1))
+    scene = synth.street_canyon()
+    for t, q in synth.drive_poses(6, step=1.0):
+        _feed((a, b), synth.lidar_scan(scene, t, q, rows=32, cols=512), t, q)
+    a.sync()
+    r = pu.compare_maps(a, b)
+    assert r["blocks"] > 1000 and r["sdf_bit_exact"] and r["sumsq_bit_exact"]
+    a.close()
+    b.close()
+
+
 def test_drive_with_noise_dropouts_and_mesh(hip, oracle):
     """8 scans along the street, 2 cm range noise, 5 % missing returns, integration distance shorter than the street so
     that the clipping branches (range > max distance, clipped far end) are exercised; then the mesh."""

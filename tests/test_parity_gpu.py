@@ -1044,11 +1044,46 @@ def test_pipelined_frames_build_the_serial_map(hip, oracle, monkeypatch, period)
         e.close()
 
 
-def test_pipelined_frames_with_a_moving_scene_and_a_small_pool(hip, oracle, monkeypatch):
+def test_peeks_next_to_pipelined_frames_read_reports_that_were_written(hip, oracle):
+    """the pool report of a pipelined frame is written behind its integration (launch_pending), and only
+    then does the mark exist for the non-blocking peeks — an event on the front stream, or a report launched before the
+    integration, would let a peek read a slot nobody has written yet (zeros: "1 free block, no flags") or the report of eight
+    marks earlier while claiming to be 0-1 frames behind."""
+    pool = 16384
+    params = dict(synth.CFG1_PARAMS, n_frames_invalidate_voxels=1000)
+    a, b = _pair(hip, oracle, synth.CFG1, params, pool)
+    levels = {}
+    a.peek_free_blocks()  # switches the reports on
+    for i in range(40):
+        f = synth.cfg1_sphere(zc=1.3 + 0.01 * i)
+        pu.feed(a, f)
+        pu.feed(b, f)
+        levels[i] = b.free_blocks()[0]
+        fine, coarse, behind = a.peek_free_blocks()
+        assert a.peek_error_flags() == 0
+        assert 0 <= behind <= 8
+        # an honest report: the level of a recent frame (blocks emptied by a pipelined frame keep their pool slot until the
+        # reclaim, so the device's free list may be some hundred blocks below the reference's) — not the zeros of an unwritten slot
+        window = [levels[j] for j in range(max(0, i - behind - 3), i + 1)]
+        assert min(window) - 1024 <= fine <= max(window), (i, fine, behind, window)
+    a.sync()
+    fine, coarse, behind = a.peek_free_blocks()
+    assert behind == 0 and (fine, coarse) == a.free_blocks() == b.free_blocks()
+    pu.compare_maps(a, b)
+    a.close()
+    b.close()
+
+
+@pytest.mark.parametrize("zlist_cap", [0, 8])
+def test_pipelined_frames_with_a_moving_scene_and_a_small_pool(hip, oracle, monkeypatch, zlist_cap):
     """The same on the 128x128 case with things that stress the zombie rules: a sphere that jumps back and forth (blocks are
     collected, stay unwanted for some frames, and are wanted again before or after the reclaim), a pool so small that the
-    context leaves the pipelined mode when room gets short (free < pool / 4), and interleaved entry points."""
-    monkeypatch.setenv("MRH_PIPE_PERIOD", "4")
+    context leaves the pipelined mode when room gets short (free < pool / 4), and interleaved entry points.
+    zlist_cap = 8: the list of emptied blocks overflows every few frames (the append is bounded and the reclaim
+    then finds the zombies by their flag)."""
+    monkeypatch.setenv("MRH_PIPE_PERIOD", "4" if not zlist_cap else "16")
+    if zlist_cap:
+        monkeypatch.setenv("MRH_ZLIST_CAP", str(zlist_cap))
     params = dict(synth.CFG1_PARAMS, n_frames_invalidate_voxels=1000)  # GC every frame, no starve
     a, b = _pair(hip, oracle, synth.CFG1, params, 2048)
     rng = np.random.default_rng(11)
