@@ -17,6 +17,7 @@
 #include <array>
 #include <atomic>
 #include <condition_variable>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <chrono>
@@ -604,8 +605,10 @@ struct FaceHash {
 // MeshExtractor::processTriangles for a single extraction (mesh_extractor.cpp:9-76):
 // soup -> vertex merge (exact bit pattern, or floor(v/eps) cells; first occurrence keeps index and colour)
 // -> drop degenerate faces -> drop repeated faces keeping the first.
+void widen_quiesce();
 void process_triangles(mrh_ctx* c) {
   const size_t nt = c->tris.size();
+  widen_quiesce();  // a helper of the last extraction's widening may still be writing the arrays that are about to be replaced
   c->V.clear(); c->C.clear(); c->F.clear();
   if (nt == 0) return;
   std::vector<double> V, C;
@@ -762,10 +765,15 @@ __global__ __launch_bounds__(256) void k_stage_out(const StageOut a) {
 bool widen_from_staging(double* const dst[2], const float* const src[2], const volatile u32* const flags[2], u32 epoch, size_t nfloat,
                         bool (*drained)(void*), void* arg);
 void widen_prewake();
+void widen_quiesce();
+uint64_t widen_redone();
 
 // MeshExtractor::processTriangles on the device (mrh_mesh.h): fills V / C / F from a triangle soup in device memory.
 // MRH_MESH_HOST=1 keeps the host restatement above (same arrays; tests compare the two).
 int process_triangles_device(mrh_ctx* c, const mrh_triangle* d_tris, const size_t nt) {
+  // a helper that lost its core during the last extraction's widening may still be reading the staging this one is about to
+  // rewrite, or writing the arrays it may regrow (CopyPool: the call no longer waits for its helpers)
+  widen_quiesce();
   c->V.clear(); c->C.clear(); c->F.clear();
   if (nt == 0) return MRH_OK;
   if (nt * 3 >= (1ull << 30)) return fail(c, MRH_ERR_CAPACITY, "mesh post-process: %zu triangles exceed the 2^30 soup vertices one index table holds", nt);
@@ -1318,6 +1326,9 @@ int mrh_destroy(mrh_ctx* c) {
     }
   }
 #endif
+  widen_quiesce();  // the result arrays are about to be unmapped
+  if (getenv("MRH_DEBUG") || getenv("MRH_WIDEN_REPORT"))
+    fprintf(stderr, "[mrhash_hip] widening: %llu chunks redone by the calling thread (their helper had not finished 40 us after the chunk landed)\n", (unsigned long long) widen_redone());
   free_all(c);
   delete c;
   return MRH_OK;
@@ -1420,6 +1431,7 @@ struct CopyPool {
     std::atomic<uint32_t> epoch{0};
   };
   static constexpr size_t kWidenChunk = 64u << 10;  // = kStageChunk: bytes of floats per flag
+  static constexpr size_t kMaxStates = 1u << 16;    // chunks of one widening job that carry a state (beyond: the job waits for every helper)
   std::atomic<int> abort_widen{0};
   std::atomic<int64_t> spin_until_ns{0};  // helpers do not go to sleep before this time (widen_prewake)
   static int64_t now_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -1434,31 +1446,59 @@ struct CopyPool {
   std::atomic<uint64_t> ticket{0};
   std::atomic<size_t> done{0};
   std::atomic<int> sleepers{0};
+  // A WIDENING job does not wait for its helpers (round 5): every chunk has a state {0 not done, 2 done}, and when the tickets
+  // have run out the submitting thread REDOES whatever is not done after a short grace — the bytes are the same whoever writes
+  // them ((double) (float) of pinned staging that nothing rewrites meanwhile) —, so a helper that claimed a chunk and then lost
+  // its core costs the call one chunk of work instead of the scheduler's time slice (tools/stress_extract.py: tail of hundreds of
+  // ms with the host oversubscribed).  Such a straggler may still be reading the staging and writing the doubles after the call
+  // has returned: `inflight` counts the helpers between "about to claim" and "finished", and whoever is about to rewrite the
+  // staging, release or regrow the arrays, or publish another job waits for it to reach zero first (quiesce()).
+  // Upload jobs (copy()) keep waiting for every chunk: their source is the CALLER's buffer, which is free on return.
+  std::atomic<int> inflight{0};
+  std::unique_ptr<std::atomic<uint8_t>[]> state{new std::atomic<uint8_t>[kMaxStates]};
+  std::atomic<uint64_t> redone{0};  // chunks the submitting thread redid (MRH_DEBUG / tools/stress_extract.py)
   Job jobs[2];
   bool started = false;
 
-  void work(const uint64_t g) {
-    Job& j = jobs[g & 1];
+  void quiesce() {
+    while (inflight.load(std::memory_order_seq_cst) != 0) MRH_CPU_RELAX();
+  }
+  // claims the next chunk of job g; false: none left (or the tickets belong to another job)
+  bool claim(const uint64_t g, const Job& j, size_t& i) {
+    uint64_t cur = ticket.load(std::memory_order_acquire);
     for (;;) {
-      uint64_t cur = ticket.load(std::memory_order_acquire);
-      if ((cur >> 32) != (g & 0xFFFFFFFFull)) break;  // another job's tickets: not ours to take
-      const size_t i = (size_t) (cur & 0xFFFFFFFFull);
-      if (i >= j.nchunks.load(std::memory_order_relaxed)) break;
-      if (!ticket.compare_exchange_weak(cur, cur + 1, std::memory_order_acq_rel, std::memory_order_acquire)) continue;
-      // chunk i of job g is ours: the job cannot complete before the done++ below, so its descriptor is stable
-      if (j.widen.load(std::memory_order_relaxed)) {
-        widen_chunk(j, i, nullptr, nullptr);
-        done.fetch_add(1, std::memory_order_acq_rel);
-        continue;
-      }
-      const size_t off = i * kChunk, len = std::min(kChunk, j.bytes.load(std::memory_order_relaxed) - off);
-      copy_chunk(j.dst.load(std::memory_order_relaxed) + off, j.src.load(std::memory_order_relaxed) + off, len);
-      done.fetch_add(1, std::memory_order_acq_rel);
+      if ((cur >> 32) != (g & 0xFFFFFFFFull)) return false;  // another job's tickets: not ours to take
+      i = (size_t) (cur & 0xFFFFFFFFull);
+      if (i >= j.nchunks.load(std::memory_order_relaxed)) return false;
+      if (ticket.compare_exchange_weak(cur, cur + 1, std::memory_order_acq_rel, std::memory_order_acquire)) return true;
     }
   }
+  void work(const uint64_t g) {  // helpers
+    Job& j = jobs[g & 1];
+    for (;;) {
+      inflight.fetch_add(1, std::memory_order_seq_cst);  // BEFORE the claim: a submitter that sees zero knows nobody holds a chunk
+      size_t i;
+      if (!claim(g, j, i)) { inflight.fetch_sub(1, std::memory_order_seq_cst); break; }
+      // chunk i of job g is ours: nobody rewrites the descriptor before `inflight` is back at zero
+      if (j.widen.load(std::memory_order_relaxed)) {
+        if (widen_chunk(j, i, nullptr, nullptr) && i < kMaxStates) state[i].store(2, std::memory_order_release);
+      } else {
+        const size_t off = i * kChunk, len = std::min(kChunk, j.bytes.load(std::memory_order_relaxed) - off);
+        copy_chunk(j.dst.load(std::memory_order_relaxed) + off, j.src.load(std::memory_order_relaxed) + off, len);
+      }
+      done.fetch_add(1, std::memory_order_acq_rel);
+      inflight.fetch_sub(1, std::memory_order_seq_cst);
+    }
+  }
+  // has the flag of chunk i of a widening job arrived?
+  static bool chunk_landed(const Job& j, const size_t i) {
+    const size_t half = j.nchunks.load(std::memory_order_relaxed) / 2;
+    const volatile uint32_t* fl = i >= half ? j.flags2.load(std::memory_order_relaxed) : j.flags.load(std::memory_order_relaxed);
+    return !fl || fl[i >= half ? i - half : i] == j.epoch.load(std::memory_order_relaxed);
+  }
   // one chunk of a widening job; the submitting thread passes `drained` and gives up (abort_widen) when the stream has run dry
-  // without the chunk's flag
-  void widen_chunk(Job& j, const size_t i, bool (*drained)(void*), void* arg) {
+  // without the chunk's flag.  false: not widened (given up)
+  bool widen_chunk(Job& j, const size_t i, bool (*drained)(void*), void* arg) {
     const size_t half = j.nchunks.load(std::memory_order_relaxed) / 2;
     const int part = i >= half ? 1 : 0;
     const size_t lc = i - (part ? half : 0);
@@ -1466,7 +1506,7 @@ struct CopyPool {
     if (fl) {
       const uint32_t epoch = j.epoch.load(std::memory_order_relaxed);
       for (uint32_t spins = 1; fl[lc] != epoch; spins++) {
-        if (abort_widen.load(std::memory_order_relaxed)) return;
+        if (abort_widen.load(std::memory_order_relaxed)) return false;
         MRH_CPU_RELAX();
         if (drained && (spins & 1023u) == 0 && drained(arg)) {
           // the stream has run dry: everything the launch wrote is visible, or about to be — only a flag that stays away is an error
@@ -1474,7 +1514,7 @@ struct CopyPool {
           while (fl[lc] != epoch && now_ns() - t < 200000000) MRH_CPU_RELAX();
           if (fl[lc] == epoch) break;
           abort_widen.store(1, std::memory_order_relaxed);
-          return;
+          return false;
         }
       }
       std::atomic_thread_fence(std::memory_order_acquire);
@@ -1484,6 +1524,7 @@ struct CopyPool {
     const float* src = (const float*) ((part ? j.src2.load(std::memory_order_relaxed) : j.src.load(std::memory_order_relaxed)) + off);
     double* dst = (double*) ((part ? j.dst2.load(std::memory_order_relaxed) : j.dst.load(std::memory_order_relaxed)) + 2 * off);
     widen_floats(dst, src, len / sizeof(float));
+    return true;
   }
   // both parts of a widening job through the pool (the calling thread works too); false: gave up on a flag
   bool widen(double* const dst[2], const float* const src[2], const volatile uint32_t* const flags[2], const uint32_t epoch, const size_t nfloat,
@@ -1492,6 +1533,7 @@ struct CopyPool {
     const size_t bytes = nfloat * sizeof(float);
     const size_t per = (bytes + kWidenChunk - 1) / kWidenChunk, nc = 2 * per;
     if (nc == 0) return true;
+    quiesce();  // a straggler of the previous widening job still reads its descriptor
     abort_widen.store(0, std::memory_order_relaxed);
     const uint64_t g = generation.load(std::memory_order_relaxed) + 1;  // one submitter at a time (g_copy_mutex)
     Job& j = jobs[g & 1];
@@ -1501,45 +1543,49 @@ struct CopyPool {
     j.epoch.store(epoch, std::memory_order_relaxed);
     j.bytes.store(bytes, std::memory_order_relaxed); j.nchunks.store(nc, std::memory_order_relaxed);
     j.widen.store(1, std::memory_order_relaxed);
+    const bool stateful = nc <= kMaxStates;
+    for (size_t i = 0; i < std::min(nc, kMaxStates); i++) state[i].store(0, std::memory_order_relaxed);
     done.store(0, std::memory_order_relaxed);
     ticket.store((g & 0xFFFFFFFFull) << 32, std::memory_order_release);
     generation.store(g, std::memory_order_release);
     if (sleepers.load(std::memory_order_acquire) > 0) { std::lock_guard<std::mutex> lk(m); cv.notify_all(); }
-    for (;;) {  // work(g) with the stream check in the flag wait
-      uint64_t cur = ticket.load(std::memory_order_acquire);
-      const size_t i = (size_t) (cur & 0xFFFFFFFFull);
-      if (i >= nc) break;
-      if (!ticket.compare_exchange_weak(cur, cur + 1, std::memory_order_acq_rel, std::memory_order_acquire)) continue;
-      widen_chunk(j, i, drained, arg);
-      done.fetch_add(1, std::memory_order_acq_rel);
-    }
-    bool flags_checked = false;
-    while (done.load(std::memory_order_acquire) < nc) {
-      MRH_CPU_RELAX();
-      // A helper may be stuck on a flag that will never come (a failed launch): the stream check is ours to make.  Once the stream
-      // is dry every flag of a good launch is set; then the helpers are merely still working (or were descheduled, or are faulting
-      // fresh pages in) and there is nothing to do but wait for them — no time limit: the first version gave them 2 ms and failed
-      // an extraction of a healthy run once in a few hundred.
-      if (drained && !flags_checked && !abort_widen.load(std::memory_order_relaxed)) {
-        static thread_local uint32_t spins = 0;
-        if ((++spins & 4095u) == 0 && drained(arg)) {
-          const int64_t t = now_ns();
-          bool missing = true;
-          while (missing && now_ns() - t < 200000000) {
-            missing = false;
-            for (int part = 0; part < 2 && !missing; part++) {
-              const volatile uint32_t* fl = flags[part];
-              if (!fl) continue;
-              for (size_t k = 0; k < per; k++) if (fl[k] != epoch) { missing = true; break; }
-            }
-            if (missing) MRH_CPU_RELAX();
-          }
-          if (missing) abort_widen.store(1, std::memory_order_relaxed);
-          flags_checked = true;
-        }
+    {  // work(g) with the stream check in the flag wait
+      size_t i;
+      while (claim(g, j, i)) {
+        if (widen_chunk(j, i, drained, arg) && i < kMaxStates) state[i].store(2, std::memory_order_release);
+        done.fetch_add(1, std::memory_order_acq_rel);
       }
     }
-    j.widen.store(0, std::memory_order_relaxed);
+    if (stateful) {
+      // The tickets are out; at most one chunk per helper is still under way.  In chunk order: wait for it while it can still be
+      // on its way (the flag has not arrived, or arrived less than a grace of 40 us ago — a chunk is ~10 us of work), then redo it.
+      for (size_t i = 0; i < nc && !abort_widen.load(std::memory_order_relaxed); i++) {
+        int64_t landed_at = 0;
+        uint32_t spins = 0;
+        while (state[i].load(std::memory_order_acquire) != 2) {
+          if (abort_widen.load(std::memory_order_relaxed)) break;
+          if (!chunk_landed(j, i)) {  // nobody can have widened it yet: the wait is for the device (with the stream check)
+            if (drained && (++spins & 1023u) == 0 && drained(arg)) {
+              const int64_t t = now_ns();
+              while (!chunk_landed(j, i) && now_ns() - t < 200000000) MRH_CPU_RELAX();
+              if (!chunk_landed(j, i)) { abort_widen.store(1, std::memory_order_relaxed); break; }
+            }
+            MRH_CPU_RELAX();
+            continue;
+          }
+          const int64_t now = now_ns();
+          if (!landed_at) landed_at = now;
+          if (now - landed_at > 40000) {  // its helper lost its core (or is slow): the same bytes, written here
+            if (widen_chunk(j, i, drained, arg)) { state[i].store(2, std::memory_order_release); redone.fetch_add(1, std::memory_order_relaxed); }
+            break;
+          }
+          MRH_CPU_RELAX();
+        }
+      }
+    } else {
+      while (done.load(std::memory_order_acquire) < nc && !abort_widen.load(std::memory_order_relaxed)) MRH_CPU_RELAX();
+    }
+    // (the descriptor keeps `widen` set: a straggler reads it after this call has returned; the next job rewrites it behind quiesce())
     return abort_widen.load(std::memory_order_relaxed) == 0;
   }
   // wake the helpers now and keep them spinning for a millisecond: a widening job is on its way
@@ -1547,6 +1593,7 @@ struct CopyPool {
     if (!started) start();
     spin_until_ns.store(now_ns() + 1500000, std::memory_order_relaxed);
     if (sleepers.load(std::memory_order_acquire) > 0) {
+      quiesce();
       const uint64_t g = generation.load(std::memory_order_relaxed) + 1;  // an empty job: nothing to claim
       Job& j = jobs[g & 1];
       j.widen.store(0, std::memory_order_relaxed);
@@ -1592,6 +1639,7 @@ struct CopyPool {
   void copy(void* d, const void* s_, size_t n) {
     if (!started) start();
     if (threads.empty() || n < 4 * kChunk) { copy_chunk(d, s_, n); return; }
+    quiesce();  // a straggler of a widening job still reads that job's descriptor
     const size_t nc = (n + kChunk - 1) / kChunk;
     const uint64_t g = generation.load(std::memory_order_relaxed) + 1;  // one submitter at a time (g_copy_mutex)
     Job& j = jobs[g & 1];
@@ -1602,8 +1650,13 @@ struct CopyPool {
     ticket.store((g & 0xFFFFFFFFull) << 32, std::memory_order_release);
     generation.store(g, std::memory_order_release);
     if (sleepers.load(std::memory_order_acquire) > 0) { std::lock_guard<std::mutex> lk(m); cv.notify_all(); }
-    work(g);
-    while (done.load(std::memory_order_acquire) < nc) MRH_CPU_RELAX();
+    size_t i;
+    while (claim(g, j, i)) {
+      const size_t off = i * kChunk, len = std::min(kChunk, n - off);
+      copy_chunk((char*) d + off, (const char*) s_ + off, len);
+      done.fetch_add(1, std::memory_order_acq_rel);
+    }
+    while (done.load(std::memory_order_acquire) < nc) MRH_CPU_RELAX();  // the source is the caller's: nobody may still read it on return
   }
 };
 CopyPool* copy_pool() {
@@ -1624,11 +1677,19 @@ void widen_prewake() {
   std::lock_guard<std::mutex> lk(g_copy_mutex);
   copy_pool()->prewake();
 }
+// no helper is still reading a staging buffer or writing a result array of an earlier widening job (CopyPool: `inflight`)
+void widen_quiesce() {
+  std::lock_guard<std::mutex> lk(g_copy_mutex);
+  copy_pool()->quiesce();
+}
+uint64_t widen_redone() { return copy_pool()->redone.load(std::memory_order_relaxed); }
 #else
 void copy_to_staging(void* dst, const void* src, size_t n);
 bool widen_from_staging(double* const dst[2], const float* const src[2], const volatile u32* const flags[2], u32 epoch, size_t nfloat,
                         bool (*drained)(void*), void* arg) { return false; }
 void widen_prewake() {}
+void widen_quiesce() {}
+uint64_t widen_redone() { return 0; }
 #endif
 
 // one host image into the next slot of its ring: wait until the slot is free, copy into pinned staging (the caller's
