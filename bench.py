@@ -328,6 +328,7 @@ def bench_single(args):
     # any profiled pass: launches that carry start / stop events switch the queue to profiling mode, which slows every
     # later dispatch of the process.
     pcie_fps = None
+    link = None
     if not args.no_extras:
         pe = make_engine(hip, params, Kc)
         for i in range(W):
@@ -341,6 +342,9 @@ def bench_single(args):
         pe.sync()
         pcie_fps = K / (time.perf_counter() - t2)
         pe.close()
+        # ... and what the link gives those 2.15 MB per frame at best (pinned -> device, one stream per image, nothing else on the
+        # device), measured in this run: the ceiling of any per-frame host hand-over
+        link = hipmem.h2d_link_rate()
 
     # Launches that carry events switch the process's queues to their profiling mode, which slows every later dispatch (37.8-43.7 us
     # per spherical image behind the profiled extraction where tools/bench_spherical.py measures 27-29 in a process that never
@@ -688,7 +692,10 @@ def bench_single(args):
                    "hash_table": table},
         "roofline": roof, "roofline_hbm": roof_hbm, "mc": mc, "cpu_baseline": cpu,
         "parity_checked": bool(cpu and cpu["parity"]["ok"]), "blocks": (cpu["parity"]["blocks"] if cpu else None),
-        "lidar": lidar, "splat": splat, "pcie_inclusive_frames_per_s": pcie_fps, "periodic_frames": periodic, "spherical_images": spherical,
+        "lidar": lidar, "splat": splat, "pcie_inclusive_frames_per_s": pcie_fps,
+        "h2d_link_gbs": link["gbs"] if link else None, "h2d_link": link,
+        "pcie_inclusive_frac_of_link": (pcie_fps * link["bytes_per_frame"] / 1e9 / link["gbs"]) if link and pcie_fps else None,
+        "periodic_frames": periodic, "spherical_images": spherical,
     }
     emit(out)
 
@@ -858,11 +865,24 @@ def bench_multi(args):
     if not share and ndev < world:
         raise SystemExit(f"bench.py --gpus {args.gpus}: only {ndev} HIP device(s) visible; refusing to report n_gpus = {args.gpus}")
     hipmem.set_device(device_index)
+    os.environ.setdefault("MRH_COMM_INIT_TIMEOUT_S", "150")  # ncclCommInitRank's watchdog (mrh_comm_create): past it the run goes on over the host group
     grp = Group(hip, rank, world, device_index, backend)
     backend = grp.backend
     devices = sorted(set(int(v) for v in grp.allgather([device_index])[:, 0]))
     n_gpus = 1 if share else len(devices)
     rccl = grp.exchanges and grp.dist is None
+    # what RCCL itself says about the group (mrh_comm_status): the driver reads here that RCCL saw N ranks on N devices
+    if rccl:
+        st = grp.handle.status()
+        seen = grp.allgather([st["rccl_ranks"], st["rccl_rank"], st["rccl_device"], st["async_error"]])
+        rccl_info = {"rccl_ranks": st["rccl_ranks"], "ranks_seen_by_each_rank": [int(v) for v in seen[:, 0]], "rccl_rank_of_each_rank": [int(v) for v in seen[:, 1]],
+                     "rccl_device_of_each_rank": [int(v) for v in seen[:, 2]], "devices": devices,
+                     "async_error_after_init": st["async_error_string"], "async_error_code_of_each_rank": [int(v) for v in seen[:, 3]],
+                     "async_error_after_phases": None, "rccl_version": st["rccl_version"], "library": st["library_path"]}
+    else:
+        rccl_info = {"rccl_ranks": None, "devices": devices, "async_error_after_init": None, "async_error_after_phases": None,
+                     "reason": (grp.note or ("MRH_BENCH_SHARE_DEVICE=1: the ranks share one device, which RCCL refuses; they talk over gloo" if share
+                                             else f"backend {backend} requested (MRH_BENCH_BACKEND)"))}
 
     Kc = synth.SCANNET
     params = capi.Params(num_sdf_blocks=args.blocks, device_id=device_index, **synth.SCANNET_PARAMS)
@@ -897,8 +917,8 @@ def bench_multi(args):
         # sub-map merge + boundary-block exchange), one merge per run of K frames per rank
         "value_definition": "fuse only: frames / max-over-ranks time of the frame-sharded fusion (the exchange phases have not run or are not available)",
         "fuse_only_frames_per_s": world * K / elapsed, "fuse_only_ms_per_step": elapsed / K * 1e3,
-        "backend": backend, "backend_note": grp.note,
-        "phases": None, "merge": None, "tile_sharded": None, "roofline": None, "cpu_baseline": None,
+        "backend": backend, "backend_note": grp.note, "rccl": rccl_info,
+        "phases": None, "full_stream": None, "merge": None, "tile_sharded": None, "roofline": None, "cpu_baseline": None,
     }
 
     # Everything below is reported BESIDE the value.  A collective that never returns (one rank lost, a fabric problem) must
@@ -926,6 +946,11 @@ def bench_multi(args):
             emit(out)
         os._exit(0)  # the other ranks may be inside a collective this rank will never join: their own timers end them
     dog.cancel()
+    if rccl:
+        try:
+            out["rccl"]["async_error_after_phases"] = grp.handle.status()["async_error_string"]
+        except Exception as e:  # noqa: BLE001
+            out["rccl"]["async_error_after_phases"] = f"{type(e).__name__}: {e}"[:200]
     if rank == 0:
         emit(out)
     grp.barrier()
@@ -1014,6 +1039,50 @@ def bench_multi_phases(args, grp, eng, mine, hip, params, Kc, chunk_log2, device
                                        f"{world} tables == the single-GPU map); starve frames run their MIN all-reduce; strong scaling",
                                "frames_per_s": K / tile_elapsed, "ms_per_step": tile_elapsed / K * 1e3, "owned_blocks_rank0": tile_blocks,
                                "chunk_log2": chunk_log2}
+
+    # ---- configs[3] at the cadence the configuration implies: the 500-pose stream cut into `world` contiguous segments, every rank
+    # fuses its 500 / world frames, then ONE merge + ONE boundary-block exchange.  (`value` above amortises the same exchange over
+    # --steps frames per rank: with the driver's 20 steps the all-to-all of whole sub-maps dominates it.)
+    full_n = int(os.environ.get("MRH_BENCH_FULL_STREAM", "500"))
+    if grp.exchanges and full_n >= world:
+        per = full_n // world
+        seg = Resident(render_stream("scannet", per, start=rank * per), Kc)
+        fe = make_engine(hip, params, Kc)
+        if rccl:
+            fe.attach_comm(grp.handle)
+        seg.run(fe, 0, min(W, per))  # warm-up on the segment's first frames, then from an empty map
+        fe.sync()
+        fe.reset()
+        grp.barrier()
+        t4 = time.perf_counter()
+        seg.run(fe, 0, per)
+        fe.sync()
+        grp.barrier()
+        f_fuse = grp.max(time.perf_counter() - t4)
+        f_blocks = int(fe.stats().occupied_fine)
+        grp.barrier()
+        t5 = time.perf_counter()
+        f_info = parallel.merge_submaps(fe, grp.handle, chunk_log2)
+        grp.barrier()
+        f_merge = grp.max(time.perf_counter() - t5)
+        t6 = time.perf_counter()
+        f_halo_n = parallel.exchange_halo(fe, grp.handle)
+        grp.barrier()
+        f_halo = grp.max(time.perf_counter() - t6)
+        allf = grp.allgather([f_blocks, f_info["sent"], f_halo_n])
+        parallel.drop_halo(fe)
+        if rccl:
+            fe.attach_comm(None)
+        fe.close()
+        out["full_stream"] = {"what": f"configs[3] whole: {per * world} poses of the walk in {world} contiguous segments of {per} frames, one per rank, frame-sharded; then one "
+                                      f"mrh_comm_merge_submaps + one mrh_comm_exchange_halo",
+                              "cadence_frames": per, "frames": per * world, "fuse_ms": f_fuse * 1e3, "merge_ms": f_merge * 1e3, "halo_exchange_ms": f_halo * 1e3,
+                              "frames_per_s": per * world / (f_fuse + f_merge + f_halo), "fuse_only_frames_per_s": per * world / f_fuse,
+                              "sub_map_blocks_per_rank": [int(v) for v in allf[:, 0]], "blocks_sent_per_rank": [int(v) for v in allf[:, 1]],
+                              "halo_blocks_taken_per_rank": [int(v) for v in allf[:, 2]]}
+        if merge is not None:
+            merge["cadence_frames"] = K
+            merge["cadence_frames_full_stream"] = per
 
     phase_keys = ("pack_ms", "counts_ms", "collective_ms", "unpack_ms", "bytes_out", "bytes_in")
     out["phases"] = {"what": "HIP-event times on rank 0: the two launches of a frame (profiled pass over rank 0's segment), the phases of the two "

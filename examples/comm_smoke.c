@@ -134,6 +134,13 @@ static int run_rank(int rank, int world, const char* id_file) {
   mrh_comm* comm = NULL;
   CHECKM(NULL, mrh_comm_create(id, rank, world, device, &comm));
   SAY("communicator up (%s)", mrh_version());
+  {
+    mrh_comm_status_info st;
+    CHECKM(comm, mrh_comm_status(comm, &st));
+    SAY("RCCL says: %d ranks, this is rank %d on device %d, version %d, async error %d (%s), library %s", st.rccl_ranks, st.rccl_rank, st.rccl_device,
+        st.rccl_version, st.async_error, st.async_error_string, st.library_path);
+    if (st.rccl_ranks != world || st.rccl_rank != rank) { SAY("FAILED: RCCL's view of the communicator differs from the launch (%d ranks, rank %d)", world, rank); return 1; }
+  }
   CHECKM(comm, mrh_comm_barrier(comm));
   if (rank == 0) unlink(id_file);
 

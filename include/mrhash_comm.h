@@ -40,11 +40,27 @@ typedef struct mrh_comm mrh_comm;
  * (a file on a shared path, MPI, a socket; mrhash_amd/parallel.py uses a file under /tmp keyed by the launcher). */
 int mrh_comm_unique_id(uint8_t out_id[MRH_COMM_ID_BYTES]);
 
-/* ncclCommInitRank on HIP device `device_id`.  Collective; blocks until all `world` ranks have joined. */
+/* ncclCommInitRank on HIP device `device_id`.  Collective; blocks until all `world` ranks have joined — or for
+ * MRH_COMM_INIT_TIMEOUT_S seconds (environment, default 180): past that the call fails with MRH_ERR_DEVICE (a peer never joined)
+ * instead of keeping the process for ever; the caller falls back to a run without RCCL. */
 int mrh_comm_create(const uint8_t id[MRH_COMM_ID_BYTES], int rank, int world, int device_id, mrh_comm** out_comm);
 int mrh_comm_destroy(mrh_comm* comm); /* NULL is a no-op; contexts must be detached (or destroyed) first */
 const char* mrh_comm_last_error(const mrh_comm* comm); /* comm == NULL: last failing mrh_comm_create / _unique_id on this thread */
 int mrh_comm_size(const mrh_comm* comm, int* out_rank, int* out_world);
+
+/* What RCCL itself reports about the communicator: ncclCommCount / ncclCommUserRank / ncclCommCuDevice, the pending asynchronous
+ * error (ncclCommGetAsyncError: 0 = ncclSuccess), ncclGetVersion and the path of the librccl the library opened.  Fields RCCL
+ * cannot answer are -1.  Local (not collective). */
+typedef struct mrh_comm_status_info {
+  int  rccl_ranks;             /* ncclCommCount                                   */
+  int  rccl_rank;              /* ncclCommUserRank                                */
+  int  rccl_device;            /* ncclCommCuDevice (HIP device index)             */
+  int  rccl_version;           /* ncclGetVersion, e.g. 22204                      */
+  int  async_error;            /* ncclResult_t of ncclCommGetAsyncError (0 = none) */
+  char async_error_string[64]; /* ncclGetErrorString of the above                 */
+  char library_path[256];      /* the librccl.so the library opened               */
+} mrh_comm_status_info;
+int mrh_comm_status(mrh_comm* comm, mrh_comm_status_info* out);
 
 /* Host-side helpers for the driver of a multi-rank run (timing brackets, counts): tiny collectives staged through a device
  * buffer on the communicator's own stream.  Blocking. */

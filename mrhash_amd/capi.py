@@ -124,10 +124,15 @@ ABI_SYMBOLS = (
 # every symbol include/mrhash_comm.h declares (the HIP library only: the oracle has no communicator)
 COMM_SYMBOLS = (
     "mrh_comm_unique_id mrh_comm_create mrh_comm_destroy mrh_comm_last_error mrh_comm_size mrh_comm_barrier mrh_comm_allreduce_f64 "
-    "mrh_comm_allgather_bytes mrh_comm_attach mrh_comm_exchange_halo mrh_comm_merge_submaps mrh_comm_gather_mesh mrh_comm_phase_times"
+    "mrh_comm_allgather_bytes mrh_comm_attach mrh_comm_exchange_halo mrh_comm_merge_submaps mrh_comm_gather_mesh mrh_comm_phase_times mrh_comm_status"
 ).split()
 COMM_ID_BYTES = 128
 COMM_SUM, COMM_MAX, COMM_MIN = 0, 1, 2
+
+
+class MrhCommStatus(C.Structure):
+    _fields_ = [("rccl_ranks", C.c_int), ("rccl_rank", C.c_int), ("rccl_device", C.c_int), ("rccl_version", C.c_int), ("async_error", C.c_int),
+                ("async_error_string", C.c_char * 64), ("library_path", C.c_char * 256)]
 
 
 class MrhCommMergeInfo(C.Structure):
@@ -211,6 +216,7 @@ def _declare(lib: C.CDLL) -> C.CDLL:
         lib.mrh_comm_merge_submaps.argtypes = [C.c_void_p, C.c_int, P(MrhCommMergeInfo)]
         lib.mrh_comm_gather_mesh.argtypes = [C.c_void_p, C.c_int, P(C.c_uint64)]
         lib.mrh_comm_phase_times.argtypes = [C.c_void_p, P(MrhCommPhases)]
+        lib.mrh_comm_status.argtypes = [C.c_void_p, P(MrhCommStatus)]
         for name in COMM_SYMBOLS:
             if name != "mrh_comm_last_error":
                 getattr(lib, name).restype = C.c_int
@@ -277,6 +283,14 @@ class Comm:
         out = np.empty((self.world, a.size), dtype=np.int64)
         self._check(self.lib.mrh_comm_allgather_bytes(self._comm, a.ctypes.data, a.nbytes, out.ctypes.data))
         return out
+
+    def status(self) -> dict:
+        """What RCCL itself says about this communicator (mrh_comm_status): ranks it sees, its rank and device, the pending
+        asynchronous error, version and library path."""
+        st = MrhCommStatus()
+        self._check(self.lib.mrh_comm_status(self._comm, C.byref(st)))
+        return {"rccl_ranks": int(st.rccl_ranks), "rccl_rank": int(st.rccl_rank), "rccl_device": int(st.rccl_device), "rccl_version": int(st.rccl_version),
+                "async_error": int(st.async_error), "async_error_string": st.async_error_string.decode(), "library_path": st.library_path.decode()}
 
     def close(self):
         if self._comm:

@@ -42,6 +42,13 @@ struct Rccl {
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  // optional (mrh_comm_status): absent symbols leave their fields at -1
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+  ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
+  ncclResult_t (*CommCuDevice)(const ncclComm_t, int*) = nullptr;
+  ncclResult_t (*CommGetAsyncError)(ncclComm_t, ncclResult_t*) = nullptr;
+  ncclResult_t (*GetVersion)(int*) = nullptr;
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
 };
 
 Rccl* rccl() {
@@ -77,6 +84,14 @@ Rccl* rccl() {
     x->GroupStart = (decltype(x->GroupStart)) sym("ncclGroupStart");
     x->GroupEnd = (decltype(x->GroupEnd)) sym("ncclGroupEnd");
     x->GetErrorString = (decltype(x->GetErrorString)) sym("ncclGetErrorString");
+    if (ok) {
+      x->CommCount = (decltype(x->CommCount)) dlsym(x->handle, "ncclCommCount");
+      x->CommUserRank = (decltype(x->CommUserRank)) dlsym(x->handle, "ncclCommUserRank");
+      x->CommCuDevice = (decltype(x->CommCuDevice)) dlsym(x->handle, "ncclCommCuDevice");
+      x->CommGetAsyncError = (decltype(x->CommGetAsyncError)) dlsym(x->handle, "ncclCommGetAsyncError");
+      x->GetVersion = (decltype(x->GetVersion)) dlsym(x->handle, "ncclGetVersion");
+      x->CommAbort = (decltype(x->CommAbort)) dlsym(x->handle, "ncclCommAbort");
+    }
     if (!ok) { dlclose(x->handle); x->handle = nullptr; }
     else if (getenv("MRH_DEBUG")) fprintf(stderr, "[mrhash_hip] RCCL: %s\n", x->path.c_str());
     return x;
@@ -270,7 +285,42 @@ int mrh_comm_create(const uint8_t id_bytes[MRH_COMM_ID_BYTES], int rank, int wor
   m->rank = rank; m->world = world; m->device = device_id;
   ncclUniqueId id;
   memcpy(&id, id_bytes, sizeof id);
-  ncclResult_t rc = r->CommInitRank(&m->nccl, world, id, rank);
+  // ncclCommInitRank has no time limit of its own: a peer that never joins (a rank that died, a stale id, a fabric problem)
+  // would keep this call — and the run — for ever.  It runs on a thread of its own; past MRH_COMM_INIT_TIMEOUT_S (default 180)
+  // the call reports the failure and leaves that thread behind (there is no communicator to abort before the call returns; the
+  // thread ends with the process), and the caller falls back to whatever it has without RCCL (bench.py: the host group).
+  struct Init {
+    std::mutex m; std::condition_variable cv;
+    bool done = false, abandoned = false;
+    ncclResult_t rc = ncclSuccess; ncclComm_t comm = nullptr;
+  };
+  auto st = std::make_shared<Init>();
+  double limit_s = 180.0;
+  if (const char* e = getenv("MRH_COMM_INIT_TIMEOUT_S")) { const double v = atof(e); if (v > 0) limit_s = v; }
+  std::thread([st, r, world, id, rank, device_id] {
+    ncclComm_t comm = nullptr;
+    ncclResult_t rc = hipSetDevice(device_id) == hipSuccess ? r->CommInitRank(&comm, world, id, rank) : ncclUnhandledCudaError;
+    std::unique_lock<std::mutex> lk(st->m);
+    st->rc = rc; st->comm = comm; st->done = true;
+    if (st->abandoned && rc == ncclSuccess && comm) {  // nobody is waiting any more: the communicator goes away again
+      lk.unlock();
+      if (r->CommAbort) (void) r->CommAbort(comm); else (void) r->CommDestroy(comm);
+      return;
+    }
+    st->cv.notify_all();
+  }).detach();
+  ncclResult_t rc;
+  {
+    std::unique_lock<std::mutex> lk(st->m);
+    if (!st->cv.wait_for(lk, std::chrono::duration<double>(limit_s), [&] { return st->done; })) {
+      st->abandoned = true;
+      comm_fail(nullptr, MRH_ERR_DEVICE, "ncclCommInitRank(rank %d of %d, device %d) did not return within %.0f s (MRH_COMM_INIT_TIMEOUT_S): a peer never joined",
+                rank, world, device_id, limit_s);
+      delete m;
+      return MRH_ERR_DEVICE;
+    }
+    rc = st->rc; m->nccl = st->comm;
+  }
   if (rc != ncclSuccess) {
     comm_fail(nullptr, MRH_ERR_DEVICE, "ncclCommInitRank(rank %d of %d, device %d) failed: %s", rank, world, device_id, r->GetErrorString(rc));
     delete m;
@@ -295,6 +345,28 @@ int mrh_comm_destroy(mrh_comm* m) {
   if (m->d_small) (void) hipFree(m->d_small);
   if (m->stream) (void) hipStreamDestroy(m->stream);
   delete m;
+  return MRH_OK;
+}
+
+// What RCCL itself says about the communicator (bench.py puts it into the N > 1 line: the driver can see that RCCL saw N ranks).
+int mrh_comm_status(mrh_comm* m, mrh_comm_status_info* out) {
+  if (!m || !out) return MRH_ERR_INVALID_ARG;
+  Rccl* r = rccl();
+  memset(out, 0, sizeof *out);
+  out->rccl_ranks = out->rccl_rank = out->rccl_device = out->rccl_version = -1;
+  out->async_error = -1;
+  snprintf(out->async_error_string, sizeof out->async_error_string, "%s", "ncclCommGetAsyncError not available");
+  if (r->CommCount && r->CommCount(m->nccl, &out->rccl_ranks) != ncclSuccess) out->rccl_ranks = -1;
+  if (r->CommUserRank && r->CommUserRank(m->nccl, &out->rccl_rank) != ncclSuccess) out->rccl_rank = -1;
+  if (r->CommCuDevice && r->CommCuDevice(m->nccl, &out->rccl_device) != ncclSuccess) out->rccl_device = -1;
+  if (r->GetVersion && r->GetVersion(&out->rccl_version) != ncclSuccess) out->rccl_version = -1;
+  if (r->CommGetAsyncError) {
+    ncclResult_t ae = ncclSuccess;
+    const ncclResult_t q = r->CommGetAsyncError(m->nccl, &ae);
+    out->async_error = q == ncclSuccess ? (int) ae : (int) q;
+    snprintf(out->async_error_string, sizeof out->async_error_string, "%s", r->GetErrorString(q == ncclSuccess ? ae : q));
+  }
+  snprintf(out->library_path, sizeof out->library_path, "%s", r->path.c_str());
   return MRH_OK;
 }
 

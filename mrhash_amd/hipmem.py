@@ -97,6 +97,51 @@ class DeviceBuffer:
             pass
 
 
+def h2d_link_rate(sizes=(640 * 480 * 4, 640 * 480 * 3), frames: int = 300) -> dict:
+    """What the host -> device link gives a frame's images at best, measured with nothing else on the device: every frame's
+    buffers (`sizes`: the depth and the colour image of a 640x480 frame, 2.15 MB together) go from pinned host memory to device
+    memory with hipMemcpyAsync, one stream per buffer (as mrh_upload_* sends them), `frames` frames back to back, one
+    synchronisation at the end (`gbs`); and with a synchronisation after every frame (`gbs_frame_sync`).  The ceiling of any
+    path that hands host images over per frame (bench.py: pcie_inclusive_frac_of_link)."""
+    import time
+
+    hip = runtime()
+    hip.hipHostMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t, C.c_uint]
+    hip.hipHostFree.argtypes = [C.c_void_p]
+    hip.hipStreamCreateWithFlags.argtypes = [C.POINTER(C.c_void_p), C.c_uint]
+    hip.hipStreamDestroy.argtypes = [C.c_void_p]
+    hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+    hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+    hosts, devs, streams = [], [], []
+    for n in sizes:
+        h, st = C.c_void_p(), C.c_void_p()
+        _check(hip.hipHostMalloc(C.byref(h), n, 0), "hipHostMalloc")
+        C.memset(h, 1, n)
+        _check(hip.hipStreamCreateWithFlags(C.byref(st), 1), "hipStreamCreateWithFlags")  # hipStreamNonBlocking
+        hosts.append(h); devs.append(DeviceBuffer(n)); streams.append(st)
+
+    def loop(sync_each: bool) -> float:
+        t0 = time.perf_counter()
+        for _ in range(frames):
+            for h, d, st, n in zip(hosts, devs, streams, sizes):
+                hip.hipMemcpyAsync(d.ptr, h, n, H2D, st)
+            if sync_each:
+                for st in streams:
+                    hip.hipStreamSynchronize(st)
+        for st in streams:
+            hip.hipStreamSynchronize(st)
+        return time.perf_counter() - t0
+
+    loop(False)  # warm
+    t_pipe = min(loop(False) for _ in range(3))
+    t_sync = min(loop(True) for _ in range(2))
+    for h, d, st in zip(hosts, devs, streams):
+        hip.hipStreamDestroy(st); hip.hipHostFree(h); d.free()
+    total = float(sum(sizes)) * frames
+    return {"bytes_per_frame": int(sum(sizes)), "frames": frames, "gbs": total / t_pipe / 1e9, "us_per_frame": t_pipe / frames * 1e6,
+            "gbs_frame_sync": total / t_sync / 1e9}
+
+
 def read(ptr: int, nbytes: int) -> bytes:
     """`nbytes` at device pointer `ptr` as host bytes."""
     out = np.empty(nbytes, np.uint8)

@@ -49,9 +49,16 @@ def test_n_ranks_on_one_device_line(ranks):
     """The N > 1 code path (self-spawned ranks, frame-sharded value, merge, tile-sharded mode) with all ranks on device 0 over
     gloo — 8 ranks = BASELINE.json configs[3]'s rank count: the 8-way owner function, eight split lists, eight halo segments.
     `n_gpus` counts DEVICES (one here); `ranks` says how many processes shared it."""
-    d = _run(["--gpus", str(ranks), "--steps", "6", "--warmup", "2", "--blocks", "65536"], env={"MRH_BENCH_SHARE_DEVICE": "1"}, timeout=900)
+    d = _run(["--gpus", str(ranks), "--steps", "6", "--warmup", "2", "--blocks", "65536"],
+             env={"MRH_BENCH_SHARE_DEVICE": "1", "MRH_BENCH_FULL_STREAM": str(6 * ranks)}, timeout=900)  # full-stream leg: 6 frames per rank here, 500 / N in a real run
     assert all(k in d for k in KEYS)
     assert d["n_gpus"] == 1 and d["ranks"] == ranks and d["scaling"] == "weak" and d["fuse_only_frames_per_s"] > 1000
+    # RCCL's own view of the group has its place in the line (VERDICT r04 next-7); over gloo it says why it is empty
+    assert d["rccl"]["rccl_ranks"] is None and "gloo" in d["rccl"]["reason"] and d["rccl"]["devices"] == [0]
+    fs = d["full_stream"]
+    assert fs["cadence_frames"] == 6 and fs["frames"] == 6 * ranks and fs["merge_ms"] > 0 and fs["halo_exchange_ms"] > 0
+    assert 0 < fs["frames_per_s"] < fs["fuse_only_frames_per_s"] and len(fs["sub_map_blocks_per_rank"]) == ranks
+    assert d["merge"]["cadence_frames"] == 6 and d["merge"]["cadence_frames_full_stream"] == 6
     # `value` contains the sub-map merge and the boundary-block exchange (here through gloo and host tensors: slow)
     assert 0 < d["value"] < d["fuse_only_frames_per_s"] and "mrh_comm_merge_submaps" in d["value_definition"]
     assert abs(d["value"] * d["ms_per_step"] / 1e3 - ranks) < 1e-6 * ranks
@@ -71,7 +78,7 @@ def test_one_rank_rccl_line():
             f"sys.path.insert(0, {ROOT!r}); import bench; a = bench.parse_args(); "
             "sys.stdout.flush(); bench._RESULT_FD = os.dup(1); os.dup2(2, 1); bench.bench_multi(a)")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900,
-                       env=dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1"))
+                       env=dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MRH_BENCH_FULL_STREAM="40"))
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1
@@ -82,6 +89,11 @@ def test_one_rank_rccl_line():
     assert ph["merge"]["pack_ms"] > 0 and ph["merge"]["unpack_ms"] > 0 and ph["halo"]["pack_ms"] > 0
     assert ph["starve_allreduce_count"] == 0  # one shard: nothing to reduce (tests/test_sharding_gpu.py drives the all-reduce)
     assert "backend rccl" in d["config"]["parallelism"]
+    # what RCCL itself reports (mrh_comm_status): one rank on device 0, no asynchronous error before or after the phases
+    rc = d["rccl"]
+    assert rc["rccl_ranks"] == 1 and rc["ranks_seen_by_each_rank"] == [1] and rc["rccl_device_of_each_rank"] == [0] and rc["devices"] == [0]
+    assert rc["async_error_code_of_each_rank"] == [0] and rc["async_error_after_phases"] == rc["async_error_after_init"] and rc["rccl_version"] > 0
+    assert d["full_stream"]["cadence_frames"] == 40 and d["full_stream"]["frames_per_s"] > 0
 
 
 def test_value_survives_without_a_communicator():

@@ -192,6 +192,29 @@ def test_rccl_entry_points_of_the_c_abi_in_a_one_rank_group(hip, tmp_path, self_
     assert "/opt/rocm" in os.path.realpath(open(out).read().split()[1])
 
 
+def test_comm_create_gives_up_when_a_peer_never_joins(hip, tmp_path):
+    """ncclCommInitRank has no time limit of its own.  Rank 0 of a two-rank group whose second rank never
+    comes: mrh_comm_create must fail after MRH_COMM_INIT_TIMEOUT_S with a message that says so (bench.py then goes on over the
+    host group), instead of keeping the process for ever.  In a process of its own: the abandoned init thread stays behind."""
+    import os
+    import subprocess
+    import sys
+
+    from test_sharding import ROOT
+
+    code = (f"import sys, time; sys.path.insert(0, {ROOT!r})\n"
+            "from mrhash_amd import capi\n"
+            "lib = capi.load_hip(); uid = capi.Comm.unique_id(lib); t0 = time.time()\n"
+            "try:\n"
+            "    capi.Comm(lib, uid, 0, 2, 0)\n"
+            "    print('CREATED')\n"
+            "except capi.MrhError as e:\n"
+            "    print('ERR', round(time.time() - t0, 1), e)\n"
+            "import os; sys.stdout.flush(); os._exit(0)\n")
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, MRH_COMM_INIT_TIMEOUT_S="4"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ERR" in r.stdout and "did not return within 4 s" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_exchange_primitives_match_the_oracle(hip, oracle):
     """mrh_pack_blocks / mrh_unpack_blocks / mrh_drop_blocks on the device against the oracle's host versions: the same
     record sets (order aside), the same merged map."""
