@@ -761,6 +761,16 @@ struct McRecords {
   u32 cap;
 };
 constexpr int kMcThreads = 256;
+// Which block a workgroup starts with.  Workgroups go to the eight XCDs round-robin by their id, and each XCD has its own L2: with
+// block e = workgroup id, the z-neighbours of a block (adjacent in the position-sorted list) are staged by the OTHER seven XCDs,
+// so every block's planes cross the fabric up to 27 times (rocprofv3: 3.4 x the algorithmic bytes).  Workgroup w takes slot
+// (w mod 8) * (grid / 8) + w / 8 instead: the workgroups of one XCD walk a contiguous eighth of the list — a slab of the map —
+// and find their neighbours' rows in their own L2.  The grid is a multiple of 8, so the slots are a permutation of the ids.
+__device__ __forceinline__ int mc_first_block(const int flags) {
+  const int w = (int) blockIdx.x, g = (int) gridDim.x;
+  if ((flags & 4) || (g & 7)) return w;  // bit 2: MRH_MC_NO_XCD_SLABS (A/B)
+  return (w & 7) * (g >> 3) + (w >> 3);
+}
 #ifdef MRH_MC_TRACE
 // tuning builds only (tools/trace_mc.sh): shader-clock cycles of thread 0 per phase, one record per block and pass (no atomics:
 // 14 k workgroups adding to the same few words would time the atomics).  Record: [0] class + 1 (0: fine block, no coarse
@@ -801,7 +811,7 @@ __global__ __launch_bounds__(kMcThreads) __attribute__((amdgpu_waves_per_eu(4, 4
   __shared__ u32 s_rec[2];    // count pass: [0] first record of this block (kMcNoRecords: none), [1] records written
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  for (int e = blockIdx.x; e < n; e += gridDim.x) {
+  for (int e = mc_first_block(flag_overflow); e < n; e += gridDim.x) {
     MRH_MC_TS(ts0);
     const int4 ent = sorted[e];
     const u32 val = (u32) ent.w;
@@ -1078,7 +1088,7 @@ __global__ __launch_bounds__(kMcThreads) void k_mc_emit_records(const Map m, con
                                                                const int flag_overflow) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int gb = lane & ~7, corner = lane & 7;
-  for (int e = blockIdx.x; e < n; e += gridDim.x) {
+  for (int e = mc_first_block(flag_overflow); e < n; e += gridDim.x) {
     const u32 first_rec = R.base[e], nrec = R.count[e];
     if (first_rec == kMcNoRecords || nrec == 0) continue;  // uniform
     const int4 ent = sorted[e];
@@ -1114,7 +1124,7 @@ __global__ __launch_bounds__(kMcThreads) void k_mc_emit_records(const Map m, con
       const u64 first = block_first + voff;
       const int room = first >= max_tris ? 0 : (int) (max_tris - first < 5 ? max_tris - first : 5);
       mc_emit_vertices(pf, sP, sM, dist, col, row, ntri, corner, gb, out + first, room);
-      if (flag_overflow && active && corner == 0 && ntri > room) atomicOr((u32*) &t.ctr[CTR_ERROR], ERR_TRI);
+      if ((flag_overflow & 1) && active && corner == 0 && ntri > room) atomicOr((u32*) &t.ctr[CTR_ERROR], ERR_TRI);
     }
   }
 }
