@@ -401,7 +401,7 @@ void free_all(mrh_ctx* c) {
   if (c->stream_front) (void) hipStreamSynchronize(c->stream_front);
   if (c->stream) (void) hipStreamSynchronize(c->stream);
   auto F = [](void* p) { if (p) (void) hipFree(p); };
-  F(c->dcx_buf); F(c->want_ring); F(c->fast.zlist); F(c->fast.wq);
+  F(c->dcx_buf); F(c->want_ring); F(c->fast.zlist);
   for (int i = 0; i < kPipeRing; i++) { F(c->pipe_dcx[i]); if (i) { F(c->ring_vis[i]); F(c->ring_bbox[i]); F(c->ring_cfree[i]); F(c->ring_zmin[i]); } if (c->ev_front[i]) (void) hipEventDestroy(c->ev_front[i]); }
   if (c->h_levels) (void) hipHostFree(c->h_levels);
   if (c->stream_front) { (void) hipStreamSynchronize(c->stream_front); (void) hipStreamDestroy(c->stream_front); }
@@ -455,7 +455,6 @@ int init_buffers(mrh_ctx* c) {
   c->front_needs_sync = false;
   if (c->h_levels) { c->h_levels[0] = (int) c->num_blocks - 1; c->h_levels[1] = 0; c->h_levels[2] = -1; }
   if (c->want_ring) HIP_TRY(c, hipMemsetAsync(c->want_ring, 0, (size_t) kPipeRing * c->slots * sizeof(u32), s));
-  if (c->fast.wq) HIP_TRY(c, hipMemsetAsync(c->fast.wq, 0, (size_t) kListSets * kWq * kWqStride * sizeof(int), s));
   const Tab& t = c->tab;
   k_init_table<<<1024, 256, 0, s>>>(t.keys, c->slots);
   k_init_heap<<<1024, 256, 0, s>>>(t.heap_fine, (u32) c->num_blocks, getenv("MRH_DEBUG_HEAP_DESCENDING") ? 1 : 0);
@@ -1204,9 +1203,6 @@ int mrh_create(const mrh_params* p, mrh_ctx** out) {
   CREATE_TRY(hipMalloc((void**) &c->fast.trace, c->num_blocks * 8 * sizeof(u64)));
   CREATE_TRY(hipMemset(c->fast.trace, 0, c->num_blocks * 8 * sizeof(u64)));
 #endif
-  if (!getenv("MRH_BACK_STATIC")) {  // MRH_BACK_STATIC=1: k_back's waves take their entries by static striding (A/B)
-    CREATE_TRY(hipMalloc((void**) &c->fast.wq, (size_t) kListSets * kWq * kWqStride * sizeof(int)));
-  }
   CREATE_TRY(hipMalloc((void**) &c->d_cfree, list_cap * sizeof(int4)));
   CREATE_TRY(hipMalloc((void**) &c->d_zmin, list_cap * sizeof(float)));
 #undef CREATE_TRY
@@ -2991,9 +2987,11 @@ int mrh_extract_triangles(mrh_ctx* c, const mrh_triangle** out_tris, uint64_t* o
     }
     k_mc_neighbors<<<(int) (((size_t) n * 32 + 255) / 256), 256, 0, s>>>(c->tab, sorted, n, d_nb);
     if (dbg) { HIP_TRY(c, hipStreamSynchronize(s)); t1 = now(); }
-    // one workgroup per block, rounded up to a multiple of 8: mc_first_block's slots are then a permutation of the workgroup ids
-    // and every XCD walks one contiguous eighth of the list (a grid capped below n would hand the second round to the first XCDs only)
-    const int grid = (n + 7) & ~7;
+    // one workgroup per block, rounded up to a multiple of 8 runs of 2^k blocks: mc_first_block's mapping is then a permutation
+    // of the workgroup ids (workgroups beyond the list leave at once)
+    int slab_log2 = getenv("MRH_MC_SLAB_LOG2") ? std::min(20, std::max(0, atoi(getenv("MRH_MC_SLAB_LOG2")))) : 7;
+    while (slab_log2 > 0 && ((size_t) 8 << slab_log2) > (size_t) n + 8) slab_log2--;  // never more than one run per XCD
+    const int grid = (int) ((((size_t) n + ((size_t) 8 << slab_log2) - 1) >> (slab_log2 + 3)) << (slab_log2 + 3));
     // largest truncation a stored sample can carry (integration clamps to trunc + scale * depth, depth <= the integration distance)
     const float sdf_bound = c->has_camera && !getenv("MRH_MC_NO_PRESCREEN") ? c->map.trunc + c->map.trunc_scale * c->cam.max_int_dist : 0.f;
     c->last_mc_count_ms = c->last_mc_emit_ms = 0.f;
@@ -3022,7 +3020,8 @@ int mrh_extract_triangles(mrh_ctx* c, const mrh_triangle** out_tris, uint64_t* o
     none.ctr = nullptr; none.recs = nullptr; none.base = nullptr; none.count = nullptr; none.cap = 0;
     if (use_records) HIP_TRY(c, hipMemsetAsync(d_rec_ctr, 0, 2 * sizeof(u32), s));
     const int mc_flags = (getenv("MRH_MC_NO_COARSE_KNOWN") ? 2 : 0)   // bit 1: coarse voxels on the literal evaluation only (A/B, tests)
-                         | (getenv("MRH_MC_NO_XCD_SLABS") ? 4 : 0);   // bit 2: block e = workgroup id (A/B)
+                         | (getenv("MRH_MC_NO_XCD_SLABS") ? 4 : 0)    // bit 2: block e = workgroup id (A/B)
+                         | (slab_log2 << 4);                          // bits 4..8: log2 of the run of blocks an XCD takes at a time
     if (timed) hipExtLaunchKernelGGL((k_mc<false>), dim3(grid), dim3(kMcThreads), 0, s, c->mc_ev[0], c->mc_ev[1], 0u, c->map, c->tab, (const int4*) sorted, n, (const u32*) d_nb,
                                      (u32*) d_counts, (const u64*) nullptr, (mrh_triangle*) nullptr, (u64) 0, (uint8_t*) d_per_voxel, sdf_bound, mc_flags, R);
     else k_mc<false><<<grid, kMcThreads, 0, s>>>(c->map, c->tab, sorted, n, d_nb, d_counts, nullptr, nullptr, (u64) 0, d_per_voxel, sdf_bound, mc_flags, R);

@@ -14,8 +14,6 @@ namespace mrh {
 constexpr int CTR_CULLED = 12;  // number of culled compact entries (stored from the back of Tab::compact)
 constexpr int CTR_FREED_EARLY = 13;  // (kept zero: culled blocks are freed by k_back from the CULLED-FREE list)
 constexpr float kFltMax = 3.402823466e+38f;
-constexpr int kWq = 64;        // work queues of an integration launch: wave gw draws from queue gw mod kWq
-constexpr int kWqStride = 32;  // ints between two counters (128 B: every counter in a line — and an L2 channel — of its own)
 constexpr int kTileMaxPx = 576;  // LDS depth+colour tile per wave: 576 px x 8 B = 4.5 KiB (24 x 24 px: blocks beyond ~1.2 m)
 
 struct Fast {
@@ -27,7 +25,6 @@ struct Fast {
   uint2* summary_c;    // [8 * cap_blocks] the same summary per COARSE unit (multi-resolution maps only)
   u32* want;           // [hash slots] stamp of the last frame whose rays found this slot's key in the table (pipelined frames,
                        // mrh_fast2.h: decides whether a block that the previous frame's garbage collection emptied lives on)
-  int* wq;             // [kListSets][kWq] x kWqStride ints: ticket counters of k_back's work queues (mrh_fast2.h: back_range); nullptr: static striding
   int4* zlist;         // [cap_blocks] blocks emptied by a pipelined frame's garbage collection and not yet taken out of the table
 #ifdef MRH_TRACE
   u64* trace;          // [pool blocks * 8] per-block phase timestamps of the last k_back launch (tuning builds only)

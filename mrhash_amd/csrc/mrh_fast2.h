@@ -570,23 +570,10 @@ template <bool FREE, bool PROFILE, bool MULTI, bool SAFEDIV, int LZ = 0, bool SP
 __device__ __forceinline__ void back_range(const Cam& c, const Map& m, const Tab& t, const Fast& f, const Lists& L,
                                            const float trunc_threshold, const int n, const int gw, const int nw, const int lane,
                                            uint2* tile, const float* __restrict__ depth_raw, const uint8_t* __restrict__ rgb_raw,
-                                           u32* __restrict__ deferred, const u32 want_stamp = 0, int* __restrict__ wq = nullptr) {
+                                           u32* __restrict__ deferred, const u32 want_stamp = 0) {
   static_assert(!(MULTI && LZ), "multi-resolution maps are not pipelined");
   static_assert(!(MULTI && SPH), "multi-resolution maps under the spherical model take the general kernels");
-  // Which wave integrates which entry.  Blocks differ in cost by a factor of three (a block behind the surface leaves after its
-  // footprint check, a block in the band updates all 512 voxels, one inserted this frame derives its footprint first), the launch
-  // is ONE resident generation of waves with 3-4 entries each, and with static striding it lasts as long as its unluckiest wave
-  // (rocprofv3: a wave lives 14.5 us on average in a 25 us launch).  So only the first entry of a wave is static (e = gw); every
-  // further one is drawn from one of kWq ticket counters (queue q = gw mod kWq hands out the entries nw + q + k * kWq): the
-  // ticket for the NEXT entry is requested before the current entry's planes, so its round trip hides behind them.  kWq queues
-  // on kWq cache lines, not one: same-address atomics retire at one per 7-10 ns, 10^4 draws per launch would take longer than
-  // the launch.  Which wave integrates an entry changes nothing in the map.
-  const bool dyn = wq != nullptr && (nw & (kWq - 1)) == 0;  // uniform
-  const int gwu = __builtin_amdgcn_readfirstlane(gw);
-  int* const my_q = dyn ? wq + (gwu & (kWq - 1)) * kWqStride : nullptr;
-  int ticket = 0;
-  for (int e = gwu; e < n; e = dyn ? nw + (gwu & (kWq - 1)) + __builtin_amdgcn_readfirstlane(ticket) * kWq : e + nw) {
-    if (dyn && lane == 0) ticket = atomicAdd(my_q, 1);
+  for (int e = __builtin_amdgcn_readfirstlane(gw); e < n; e += nw) {
     MRH_TS(0);
     int4 ent, bb;
     float zmin;
@@ -813,9 +800,8 @@ __device__ __forceinline__ void free_candidates(const Tab& t, const Fast& f, con
 }
 
 // end of a frame: the counters of set `zero_set` are zeroed for a later frame's appends; stats mirror for the host
-__device__ __forceinline__ void frame_epilogue(const Tab& t, const Fast& f, const int zero_set, const int n_integrated, const int n_culled, const int lane, const int seq) {
+__device__ __forceinline__ void frame_epilogue(const Tab& t, const int zero_set, const int n_integrated, const int n_culled, const int lane, const int seq) {
   if (lane < 4) t.ctr[CTR_SET0 + 4 * zero_set + lane] = 0;
-  if (f.wq) f.wq[(zero_set * kWq + lane) * kWqStride] = 0;  // ... and its kWq = 64 ticket counters, one per lane
   if (lane == 0 && t.h_levels) {  // for the host's choice of the next launch (pinned memory): pool level and zombie count as this
     t.h_levels[0] = t.ctr[CTR_HEAP_FINE];  // launch found them, and the sequence number of the frame whose integration has now
     t.h_levels[1] = t.ctr[CTR_ZOMBIES];    // STARTED — every earlier integration is complete, its buffers are free
@@ -841,9 +827,8 @@ __device__ __forceinline__ void back_role(const Cam& c, const Map& m, const Tab&
   const int nvis = t.ctr[cs + 0];
   const int ncfree = FREE ? t.ctr[cs + 2] : 0;
   const int nkept = t.ctr[cs + 1];
-  if (gw == 0) frame_epilogue(t, f, zero_set, nvis, nkept + t.ctr[cs + 2], lane, seq);
-  back_range<FREE, PROFILE, MULTI, SAFEDIV, LZ, SPH>(c, m, t, f, L, trunc_threshold, nvis, gw, nw, lane, tile, depth_raw, rgb_raw, deferred, want_stamp,
-                                                     f.wq ? f.wq + set * kWq * kWqStride : nullptr);
+  if (gw == 0) frame_epilogue(t, zero_set, nvis, nkept + t.ctr[cs + 2], lane, seq);
+  back_range<FREE, PROFILE, MULTI, SAFEDIV, LZ, SPH>(c, m, t, f, L, trunc_threshold, nvis, gw, nw, lane, tile, depth_raw, rgb_raw, deferred, want_stamp);
   if (FREE) {
     // a zombie-aware launch takes every culled-list entry as a candidate: the list may come from a sweep that could not decide
     // (front_sweep<DEFER>), and for one that did decide the then-stable summary gives the same answer again

@@ -761,15 +761,19 @@ struct McRecords {
   u32 cap;
 };
 constexpr int kMcThreads = 256;
-// Which block a workgroup starts with.  Workgroups go to the eight XCDs round-robin by their id, and each XCD has its own L2: with
+// Which block a workgroup takes.  Workgroups go to the eight XCDs round-robin by their id, and each XCD has its own L2: with
 // block e = workgroup id, the z-neighbours of a block (adjacent in the position-sorted list) are staged by the OTHER seven XCDs,
-// so every block's planes cross the fabric up to 27 times (rocprofv3: 3.4 x the algorithmic bytes).  Workgroup w takes slot
-// (w mod 8) * (grid / 8) + w / 8 instead: the workgroups of one XCD walk a contiguous eighth of the list — a slab of the map —
-// and find their neighbours' rows in their own L2.  The grid is a multiple of 8, so the slots are a permutation of the ids.
+// so every block's planes cross the fabric up to 27 times (rocprofv3: 3.4 x the algorithmic bytes).  Instead the list is cut into
+// runs of 2^k blocks dealt to the XCDs in turn, and the j-th workgroup of an XCD takes the j-th block of that XCD's runs: a
+// block's z- and y-neighbours are staged by the same XCD and found in its L2.  (One run per XCD — an eighth of the list each —
+// halves the traffic again but costs 40 % of the kernel: the slabs of a room differ in their share of coarse blocks, and the
+// launch lasts as long as its slowest XCD.)  The grid is a multiple of 8 * 2^k, so the mapping is a permutation of the ids.
+// flags: bit 2 = block e = workgroup id (MRH_MC_NO_XCD_SLABS, A/B); bits 4..8 = k.
 __device__ __forceinline__ int mc_first_block(const int flags) {
-  const int w = (int) blockIdx.x, g = (int) gridDim.x;
-  if ((flags & 4) || (g & 7)) return w;  // bit 2: MRH_MC_NO_XCD_SLABS (A/B)
-  return (w & 7) * (g >> 3) + (w >> 3);
+  const int w = (int) blockIdx.x, k = (flags >> 4) & 31;
+  if ((flags & 4) || ((int) gridDim.x & ((8 << k) - 1))) return w;
+  const int x = w & 7, j = w >> 3;
+  return ((((j >> k) << 3) + x) << k) + (j & ((1 << k) - 1));
 }
 #ifdef MRH_MC_TRACE
 // tuning builds only (tools/trace_mc.sh): shader-clock cycles of thread 0 per phase, one record per block and pass (no atomics:

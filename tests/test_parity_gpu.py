@@ -1011,6 +1011,28 @@ def test_contexts_release_their_device_memory(hip):
     assert free0 - free1 < 32 << 20, f"device memory shrank by {(free0 - free1) >> 20} MiB over 25 create/destroy cycles"
 
 
+_PIPE40 = {}
+
+
+def _pipe40_reference(hip, oracle, monkeypatch):
+    """The 40 frames of the 640x480 orbit through the oracle and through the library fusing serially (MRH_PIPE=0), once for the
+    three reclaim periods below (the oracle's 40 frames are most of a test's time): the two engines, kept open, and their pool
+    levels after frame 17."""
+    if not _PIPE40:
+        monkeypatch.setenv("MRH_PIPE", "0")
+        s = pu.make_engine(hip, synth.REPLICA_640, synth.REPLICA_PARAMS, 131072)
+        monkeypatch.delenv("MRH_PIPE")
+        b = pu.make_engine(oracle, synth.REPLICA_640, synth.REPLICA_PARAMS, 131072)
+        frames = list(synth.replica_stream(40))
+        for i, f in enumerate(frames):
+            pu.feed(s, f)
+            pu.feed(b, f)
+            if i == 17:
+                _PIPE40["level17"] = (s.free_blocks(), b.free_blocks())
+        _PIPE40.update(s=s, b=b, frames=frames, ss=s.stats(), sb=b.stats())  # statistics before anything else compacts the block list
+    return _PIPE40
+
+
 @pytest.mark.parametrize("period", ["2", "5", "1000"])
 def test_pipelined_frames_build_the_serial_map(hip, oracle, monkeypatch, period):
     """Pipelined frames (mrh_capi.hip integrate_lazy: front half on a second stream next to the integrations before it, lazy
@@ -1019,20 +1041,15 @@ def test_pipelined_frames_build_the_serial_map(hip, oracle, monkeypatch, period)
     every frame — the blocks of the truncation band's near edge are collected and wanted again every single frame, blocks that
     leave the band stay zombies until the reclaim.  Occupancy, payload and mesh must be the serial ones, bit for bit; the
     statistics too (blocks freed / inserted are counted where the reference frees / inserts)."""
+    ref = _pipe40_reference(hip, oracle, monkeypatch)
+    s, b = ref["s"], ref["b"]
     monkeypatch.setenv("MRH_PIPE_PERIOD", period)
     a = pu.make_engine(hip, synth.REPLICA_640, synth.REPLICA_PARAMS, 131072)
-    monkeypatch.setenv("MRH_PIPE", "0")
-    s = pu.make_engine(hip, synth.REPLICA_640, synth.REPLICA_PARAMS, 131072)
-    monkeypatch.delenv("MRH_PIPE")
-    b = pu.make_engine(oracle, synth.REPLICA_640, synth.REPLICA_PARAMS, 131072)
-    frames = list(synth.replica_stream(40))
-    for i, f in enumerate(frames):
+    for i, f in enumerate(ref["frames"]):
         pu.feed(a, f)
-        pu.feed(s, f)
-        pu.feed(b, f)
         if i == 17:  # an entry point in the middle of the pipeline: the pending integration and the reclaim come first
-            assert a.free_blocks() == s.free_blocks() == b.free_blocks()
-    sa, ss, sb = a.stats(), s.stats(), b.stats()  # before anything else compacts the block list
+            assert a.free_blocks() == ref["level17"][0] == ref["level17"][1]
+    sa, ss, sb = a.stats(), ref["ss"], ref["sb"]
     for k in ("occupied_fine", "free_fine", "frames_integrated", "last_compact_blocks", "error_flags"):
         assert getattr(sa, k) == getattr(ss, k) == getattr(sb, k), (k, getattr(sa, k), getattr(ss, k), getattr(sb, k))
     r = pu.compare_maps(a, b)
@@ -1040,8 +1057,7 @@ def test_pipelined_frames_build_the_serial_map(hip, oracle, monkeypatch, period)
     pu.compare_maps(a, s)
     m = pu.compare_meshes(a, b)
     assert m["triangles"] > 400000 and m["pos_bit_exact"]
-    for e in (a, s, b):
-        e.close()
+    a.close()
 
 
 def test_peeks_next_to_pipelined_frames_read_reports_that_were_written(hip, oracle):
