@@ -95,6 +95,7 @@ def parse_args():
     ap.add_argument("--pmc-inner-big", action="store_true", help=argparse.SUPPRESS)  # the roofline_hbm workload alone
     ap.add_argument("--pmc-inner-mc", action="store_true", help=argparse.SUPPRESS)  # the multi-resolution map + two extractions
     ap.add_argument("--pmc-inner-lidar", action="store_true", help=argparse.SUPPRESS)  # the LiDAR scans alone
+    ap.add_argument("--pmc-inner-sph", action="store_true", help=argparse.SUPPRESS)  # the spherical images alone
     ap.add_argument("--frames-cache", default="", help=argparse.SUPPRESS)
     return ap.parse_args()
 
@@ -261,6 +262,43 @@ def lidar_setup(hip, blocks):
     return le, scans, d_scans, run_scans
 
 
+SPH_IMAGES, SPH_WARMUP = 24, 4
+
+
+def spherical_setup(hip, blocks):
+    """The image path under the spherical camera model: engine + 128 x 1024 range images of the street drive resident in HBM + the
+    loop that feeds them."""
+    from mrhash_amd import capi, hipmem, synth
+
+    cam = synth.spherical_camera(128, 1024)
+    n_img, w_img = SPH_IMAGES, SPH_WARMUP
+    scache = os.path.join(tempfile.gettempdir(), f"mrh_bench_sph_{n_img}.npz")
+    sposes = synth.drive_poses(n_img, step=0.5)
+    if os.path.exists(scache):
+        z = np.load(scache)
+        imgs = [(z["d"][i], z["c"][i]) for i in range(n_img)]
+    else:
+        scene = synth.street_canyon()
+        imgs = [synth.spherical_range_image(scene, t, q, cam) for t, q in sposes]
+        np.savez(scache, d=np.stack([a for a, _ in imgs]), c=np.stack([b for _, b in imgs]))
+    dd = hipmem.DeviceBuffer.from_numpy(np.stack([a for a, _ in imgs]).astype(np.float32))
+    dc = hipmem.DeviceBuffer.from_numpy(np.stack([b for _, b in imgs]).astype(np.uint8))
+    sp = dict(synth.VBR_PARAMS, n_frames_invalidate_voxels=100)
+    se_ = capi.Engine(hip, capi.Params(num_sdf_blocks=blocks, device_id=0, **sp))
+    se_.set_camera(cam["fx"], cam["fy"], cam["cx"], cam["cy"], cam["rows"], cam["cols"], sp["min_depth"], 100.0, model=1)
+    npx = cam["rows"] * cam["cols"]
+
+    def run_imgs(lo, hi):
+        for i in range(lo, hi):
+            t, q = sposes[i]
+            se_.set_pose(synth.quat_to_rot(q), t)
+            se_.set_depth_device(dd.ptr + i * npx * 4, cam["rows"], cam["cols"])
+            se_.set_rgb_device(dc.ptr + i * npx * 3, cam["rows"], cam["cols"])
+            se_.integrate()
+
+    return se_, run_imgs, n_img, w_img, npx, (dd, dc)
+
+
 # ---- N = 1 ---------------------------------------------------------------------------------------------------------
 
 def bench_single(args):
@@ -279,6 +317,12 @@ def bench_single(args):
         rb.run(be, 0, total)
         be.sync()
         be.close()
+        return
+    if args.pmc_inner_sph:  # the spherical images alone (under rocprofv3 --pmc): warm-up + timed images, once
+        se_, run_imgs, n_img, w_img, npx, _bufs = spherical_setup(hip, args.blocks)
+        run_imgs(0, n_img)
+        se_.sync()
+        se_.close()
         return
     if args.pmc_inner_lidar:  # configs[4]: the scans alone (under rocprofv3 --pmc)
         le, scans, d_scans, run_scans = lidar_setup(hip, args.blocks)
@@ -415,10 +459,10 @@ def bench_single(args):
                              "truncation 0.40 m, projective SDF), scans resident in HBM",
                  "scans_per_s": (n_scans - w_scans) / dt, "us_per_scan": us_scan, "points_per_s": npts / dt,
                  "points_per_scan": int(len(scans[0])), "live_blocks_end": live_end,
-                 "roofline": {"bound": "hbm", "kernel": "one scan: k_alloc3d + k_scan_walk + k_scan_collect + k_scan_offsets + k_scan_place + k_scan_apply (mrh_scan.h: voxel buckets, no sort)", "achieved": None,
+                 "roofline": {"bound": "hbm", "kernel": "one scan: k_alloc3d + k_scan_walk + k_scan_offsets + k_scan_place + k_scan_apply (mrh_scan.h: voxel buckets, no sort)", "achieved": None,
                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
                               "algorithmic_bytes_per_scan": None, "updated_voxels_per_scan": None,
-                              "note": "12 B per point read + 24 B per updated voxel (12 B read + 12 B write); a scan is a chain of six latency-bound "
+                              "note": "12 B per point read + 24 B per updated voxel (12 B read + 12 B write); a scan is a chain of five latency-bound "
                                       "launches over ~10^5 points and ~10^6 records (each record written twice and read twice), two orders of "
                                       "magnitude below the HBM roof"}}
 
@@ -497,31 +541,7 @@ def bench_single(args):
     # ---- the image path under the SPHERICAL camera model (general kernels, mrh_softmath.h): 128 x 1024 range images of the street
     spherical = None
     if not args.no_extras:
-        cam = synth.spherical_camera(128, 1024)
-        n_img, w_img = 24, 4
-        scache = os.path.join(tempfile.gettempdir(), f"mrh_bench_sph_{n_img}.npz")
-        sposes = synth.drive_poses(n_img, step=0.5)
-        if os.path.exists(scache):
-            z = np.load(scache)
-            imgs = [(z["d"][i], z["c"][i]) for i in range(n_img)]
-        else:
-            scene = synth.street_canyon()
-            imgs = [synth.spherical_range_image(scene, t, q, cam) for t, q in sposes]
-            np.savez(scache, d=np.stack([a for a, _ in imgs]), c=np.stack([b for _, b in imgs]))
-        dd = hipmem.DeviceBuffer.from_numpy(np.stack([a for a, _ in imgs]).astype(np.float32))
-        dc = hipmem.DeviceBuffer.from_numpy(np.stack([b for _, b in imgs]).astype(np.uint8))
-        sp = dict(synth.VBR_PARAMS, n_frames_invalidate_voxels=100)
-        se_ = capi.Engine(hip, capi.Params(num_sdf_blocks=args.blocks, device_id=0, **sp))
-        se_.set_camera(cam["fx"], cam["fy"], cam["cx"], cam["cy"], cam["rows"], cam["cols"], sp["min_depth"], 100.0, model=1)
-        npx = cam["rows"] * cam["cols"]
-
-        def run_imgs(lo, hi):
-            for i in range(lo, hi):
-                t, q = sposes[i]
-                se_.set_pose(synth.quat_to_rot(q), t)
-                se_.set_depth_device(dd.ptr + i * npx * 4, cam["rows"], cam["cols"])
-                se_.set_rgb_device(dc.ptr + i * npx * 3, cam["rows"], cam["cols"])
-                se_.integrate()
+        se_, run_imgs, n_img, w_img, npx, _sph_buffers = spherical_setup(hip, args.blocks)
 
         # three passes over the same drive (the map is reset in between), the median reported: the first pass of a context also
         # pays for the first use of the spherical instantiations and of the pool (r04: 37.8-43.7 us over 9 frames where
@@ -547,7 +567,7 @@ def bench_single(args):
                                   "note": "24 B per updated voxel + 24 B per compact block + 7 B per pixel; every voxel projects through sqrt / atan2 / asin of "
                                           "the shared fp32 library (mrh_softmath.h): the kernel is arithmetic-bound far below the HBM roof"}}
 
-        def spherical_profiled(se_=se_, spherical=spherical, run_imgs=run_imgs, dd=dd, dc=dc):
+        def spherical_profiled(se_=se_, spherical=spherical, run_imgs=run_imgs, keep=_sph_buffers):
             # the integrate kernel of these frames against the HBM roof, as for the pinhole stream: profiled pass, U and M from the device
             se_.reset()
             run_imgs(0, w_img)
@@ -623,6 +643,8 @@ def bench_single(args):
     if mc is not None and not args.no_pmc:  # HBM bytes of the two k_mc launches of one extraction (two extractions in the sub-process)
         mc["roofline"]["traffic"], mc["roofline"]["traffic_note"] = pmc_traffic(args, ("mrh::k_mc<", "mrh::k_mc_emit_records"), cache, "--pmc-inner-mc", per_run_of=2)
 
+    if spherical is not None and not args.no_pmc:  # HBM bytes of the spherical integration launches (the timed images of one pass)
+        spherical["roofline"]["traffic"], spherical["roofline"]["traffic_note"] = pmc_traffic(args, "mrh::k_back<", cache, "--pmc-inner-sph", steps=SPH_IMAGES - SPH_WARMUP, warmup=SPH_WARMUP)
     if lidar is not None and not args.no_pmc:  # HBM bytes of all kernels of a scan (every mrh:: launch of the sub-process / scans)
         lidar["roofline"]["traffic"], lidar["roofline"]["traffic_note"] = pmc_traffic(args, ("mrh::k_alloc3d", "mrh::k_points_", "mrh::k_sort_", "mrh::k_scan_"), cache, "--pmc-inner-lidar", per_run_of=LIDAR_SCANS)
 
@@ -1113,7 +1135,7 @@ def main():
             procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
         rcs = [p.wait() for p in procs]
         raise SystemExit(max(abs(rc) for rc in rcs))
-    if not (args.pmc_inner or args.pmc_inner_big or args.pmc_inner_mc or args.pmc_inner_lidar):
+    if not (args.pmc_inner or args.pmc_inner_big or args.pmc_inner_mc or args.pmc_inner_lidar or args.pmc_inner_sph):
         global _RESULT_FD
         sys.stdout.flush()
         _RESULT_FD = os.dup(1)

@@ -61,6 +61,7 @@ struct UpSlot {
   size_t cap = 0;
   hipEvent_t copied = nullptr;  // H2D out of `h` done (copy stream)
   bool copied_rec = false;
+  uint64_t issue_ticket = 0;    // IssueThread ticket of the transfer out of `h` (0: issued by the caller itself)
   uint64_t last_seq = 0;        // newest frame_done mark of a frame that read `d` (0: none)
 };
 struct UpRing {
@@ -68,6 +69,7 @@ struct UpRing {
   int cur = -1;                 // slot holding the current image; -1: none, or a caller's device pointer
   hipStream_t stream = nullptr; // this ring's copy stream
   hipEvent_t last_copy = nullptr;  // newest copy event of this ring
+  uint64_t last_ticket = 0;        // ... and the IssueThread ticket that records it (0: recorded already)
   bool waited[2] = {false, false}; // ... has been waited for by {main, front} stream
 };
 
@@ -393,11 +395,14 @@ uint64_t next_pow2(uint64_t v) {
   return r;
 }
 
+hipError_t upload_issue_wait(uint64_t ticket);  // IssueThread::wait (defined with the upload path)
 void free_all(mrh_ctx* c) {
   if (!c) return;
   (void) hipSetDevice(c->device);
-  for (UpRing* r : {&c->up_depth, &c->up_rgb})
+  for (UpRing* r : {&c->up_depth, &c->up_rgb}) {
+    for (UpSlot& u : r->s) if (u.issue_ticket) { (void) upload_issue_wait(u.issue_ticket); u.issue_ticket = 0; }  // no transfer of this context is still to be issued
     if (r->stream) { (void) hipStreamSynchronize(r->stream); (void) hipStreamDestroy(r->stream); }
+  }
   if (c->stream_front) (void) hipStreamSynchronize(c->stream_front);
   if (c->stream) (void) hipStreamSynchronize(c->stream);
   auto F = [](void* p) { if (p) (void) hipFree(p); };
@@ -420,7 +425,7 @@ void free_all(mrh_ctx* c) {
   if (c->h_scan) (void) hipHostFree(c->h_scan);
   for (void* a : c->arena) if (a) (void) hipFree(a);
   F(c->d_decision); F(c->d_zbuf); F(c->d_realloc); F(c->d_reint); F(c->d_flag);
-  F(c->d_upd_partials); F(c->d_misc); F(c->d_rcp_w); F(c->d_cfree); F(c->d_zmin); F(c->d_points); F(c->d_pt_counts); F(c->d_pt_offsets); F(c->d_rec_keys[0]); F(c->d_rec_keys[1]); F(c->d_rec_vals[0]); F(c->d_rec_vals[1]); F(c->d_sort_tmp); F(c->scan.vcnt); F(c->scan.bstamp); F(c->scan.touched); F(c->scan.st_meta); F(c->scan.st_sdf); F(c->scan.st_grp); F(c->scan.wgdesc); F(c->scan.rec); F(c->scan.chunks); F(c->d_scan_ctr); F(c->fast.summary); F(c->fast.summary_c); F(c->fast.bbox); F(c->d_cnt_partials);
+  F(c->d_upd_partials); F(c->d_misc); F(c->d_rcp_w); F(c->d_cfree); F(c->d_zmin); F(c->d_points); F(c->d_pt_counts); F(c->d_pt_offsets); F(c->d_rec_keys[0]); F(c->d_rec_keys[1]); F(c->d_rec_vals[0]); F(c->d_rec_vals[1]); F(c->d_sort_tmp); F(c->scan.vcnt); F(c->scan.bstamp); F(c->scan.st_meta); F(c->scan.st_sdf); F(c->scan.st_grp); F(c->scan.wgdesc); F(c->scan.rec); F(c->scan.chunks); F(c->d_scan_ctr); F(c->fast.summary); F(c->fast.summary_c); F(c->fast.bbox); F(c->d_cnt_partials);
   F(c->d_pack); F(c->d_halo); F(c->d_taken); F(c->d_cloud); F(c->d_normals); F(c->d_soup); F(c->d_mc_recs);
   for (hipEvent_t e : c->mc_ev) if (e) (void) hipEventDestroy(e);
   if (c->ev_mc_total) (void) hipEventDestroy(c->ev_mc_total);
@@ -1692,6 +1697,77 @@ void widen_quiesce() {}
 uint64_t widen_redone() { return 0; }
 #endif
 
+// The transfer of a staged image is ISSUED by a thread of its own (round 5).  A frame from host memory costs the caller ~63 us —
+// two staging copies (~25 us with the pool), and ~25 us inside hipMemcpyAsync / hipEventRecord / the launches —, more than the
+// link needs for its 2.15 MB (43 us idle, ~57 next to the kernels): the host bounds the path.  The two runtime calls of an upload
+// (copy + event record, ~8-10 us per image) therefore run on this thread while the caller is already back in its own code
+// staging the next image; whoever needs the event to have been RECORDED — the frame's stream wait, the reuse of the slot, the
+// end of the context — waits for the ticket (a spin of a few microseconds at worst: the thread is awake while frames arrive).
+// One thread per process, started by the first large upload; MRH_ISSUE_THREAD=0 keeps the calls on the caller's thread.
+struct IssueThread {
+  struct Job { int device; void* dst; const void* src; size_t bytes; hipStream_t stream; hipEvent_t ev; };
+  static constexpr uint64_t kRing = 64;
+  Job ring[kRing];
+  std::atomic<uint64_t> pushed{0}, done{0};  // tickets: job t lives in ring[t % kRing]; done = tickets completed
+  std::atomic<int> error{0};                 // first hipError_t of a failed call (sticky until read)
+  std::mutex m;                              // producers (contexts on different host threads)
+  std::mutex sleep_m;
+  std::condition_variable cv;
+  std::atomic<int> sleeping{0};
+  bool started = false, enabled = true;
+  void run() {
+    uint64_t next = 1;
+    int dev = -1;
+    for (;;) {
+      const auto t0 = std::chrono::steady_clock::now();
+      int spins = 0;
+      while (pushed.load(std::memory_order_acquire) < next) {
+        MRH_CPU_RELAX();
+        if ((++spins & 255) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(300)) {
+          std::unique_lock<std::mutex> lk(sleep_m);
+          sleeping.store(1, std::memory_order_seq_cst);
+          cv.wait(lk, [&] { return pushed.load(std::memory_order_acquire) >= next; });
+          sleeping.store(0, std::memory_order_seq_cst);
+        }
+      }
+      const Job j = ring[next % kRing];
+      hipError_t e = hipSuccess;
+      if (j.device != dev) { e = hipSetDevice(j.device); dev = j.device; }
+      if (e == hipSuccess) e = hipMemcpyAsync(j.dst, j.src, j.bytes, hipMemcpyHostToDevice, j.stream);
+      if (e == hipSuccess) e = hipEventRecord(j.ev, j.stream);
+      if (e != hipSuccess) { int z = 0; error.compare_exchange_strong(z, (int) e); (void) hipGetLastError(); }
+      done.store(next, std::memory_order_release);
+      next++;
+    }
+  }
+  uint64_t push(const Job& j) {
+    std::lock_guard<std::mutex> lk(m);
+    if (!started) {
+      started = true;
+      if (const char* e = getenv("MRH_ISSUE_THREAD")) enabled = atoi(e) != 0;
+      if (enabled) std::thread([this] { run(); }).detach();
+    }
+    if (!enabled) return 0;
+    const uint64_t t = pushed.load(std::memory_order_relaxed) + 1;
+    while (t - done.load(std::memory_order_acquire) >= kRing) MRH_CPU_RELAX();  // ring full: the thread is kRing jobs behind
+    ring[t % kRing] = j;
+    pushed.store(t, std::memory_order_seq_cst);
+    if (sleeping.load(std::memory_order_seq_cst)) { std::lock_guard<std::mutex> lk2(sleep_m); cv.notify_one(); }
+    return t;
+  }
+  // the calls of ticket t have been made; returns the first error of any job so far (and clears it)
+  hipError_t wait(const uint64_t t) {
+    if (t) while (done.load(std::memory_order_acquire) < t) MRH_CPU_RELAX();
+    const int e = error.exchange(0);
+    return (hipError_t) e;
+  }
+};
+IssueThread* issue_thread() {
+  static IssueThread* it = new IssueThread();  // never destroyed: the detached thread may be parked on it at exit
+  return it;
+}
+hipError_t upload_issue_wait(uint64_t ticket) { return issue_thread()->wait(ticket); }
+
 // one host image into the next slot of its ring: wait until the slot is free, copy into pinned staging (the caller's
 // buffer is free on return), enqueue the H2D on the copy stream
 int upload_image(mrh_ctx* c, UpRing& ring, const void* src, const size_t bytes, const void** out_dev) {
@@ -1708,6 +1784,7 @@ int upload_image(mrh_ctx* c, UpRing& ring, const void* src, const size_t bytes, 
   const int next = (ring.cur + 1) % 3;
   UpSlot& u = ring.s[next];
   if (u.last_seq) HIP_TRY(c, hipEventSynchronize(c->frame_done[u.last_seq % 8]));  // this mark or a later one of the same stream
+  if (u.issue_ticket) { HIP_TRY(c, issue_thread()->wait(u.issue_ticket)); u.issue_ticket = 0; }  // the record of its last transfer has been made
   if (u.copied_rec) HIP_TRY(c, hipEventSynchronize(u.copied));
   if (bytes > u.cap) {
     if (u.h) HIP_TRY(c, hipHostFree(u.h));
@@ -1719,11 +1796,15 @@ int upload_image(mrh_ctx* c, UpRing& ring, const void* src, const size_t bytes, 
     if (!u.copied) HIP_TRY(c, hipEventCreateWithFlags(&u.copied, hipEventDisableTiming));
   }
   copy_to_staging(u.h, src, bytes);
-  HIP_TRY(c, hipMemcpyAsync(u.d, u.h, bytes, hipMemcpyHostToDevice, ring.stream));
-  HIP_TRY(c, hipEventRecord(u.copied, ring.stream));
+  u.issue_ticket = bytes >= (256u << 10) ? issue_thread()->push({c->device, u.d, u.h, bytes, ring.stream, u.copied}) : 0;
+  if (!u.issue_ticket) {  // small images (or MRH_ISSUE_THREAD=0): the two calls cost less than the hand-over
+    HIP_TRY(c, hipMemcpyAsync(u.d, u.h, bytes, hipMemcpyHostToDevice, ring.stream));
+    HIP_TRY(c, hipEventRecord(u.copied, ring.stream));
+  }
   u.copied_rec = true;
   u.last_seq = 0;
   ring.last_copy = u.copied;  // a ring's copies are ordered on its stream: the newest event covers the earlier ones
+  ring.last_ticket = u.issue_ticket;
   ring.waited[0] = ring.waited[1] = false;
   ring.cur = next;
   *out_dev = u.d;
@@ -1736,6 +1817,7 @@ int send_uploads(mrh_ctx* c, hipStream_t reader) {
   const int w = (reader == c->stream) ? 0 : 1;
   for (UpRing* r : {&c->up_depth, &c->up_rgb})
     if (r->last_copy && !r->waited[w]) {
+      if (r->last_ticket) { HIP_TRY(c, issue_thread()->wait(r->last_ticket)); r->last_ticket = 0; }  // a wait on an event that is not recorded yet is no wait
       HIP_TRY(c, hipStreamWaitEvent(reader, r->last_copy, 0));
       r->waited[w] = true;
     }
@@ -2414,17 +2496,15 @@ static int scan_prepare(mrh_ctx* c, const uint64_t n, const uint64_t rec_bound, 
     const size_t nb = (size_t) c->num_blocks;
     bool ok = hipMalloc((void**) &sc.vcnt, nb * 512 * sizeof(u32)) == hipSuccess;
     ok = ok && hipMalloc((void**) &sc.bstamp, nb * sizeof(u32)) == hipSuccess;
-    ok = ok && hipMalloc((void**) &sc.touched, nb * sizeof(u32)) == hipSuccess;
     ok = ok && hipMalloc((void**) &c->d_scan_ctr, 2 * SC_N * sizeof(u32)) == hipSuccess;
     if (!ok) {  // one counter per voxel slot does not fit next to this map
       (void) hipGetLastError();
       auto F = [](void* p) { if (p) (void) hipFree(p); };
-      F(sc.vcnt); F(sc.bstamp); F(sc.touched); F(c->d_scan_ctr);
-      sc.vcnt = sc.bstamp = sc.touched = c->d_scan_ctr = nullptr;
+      F(sc.vcnt); F(sc.bstamp); F(c->d_scan_ctr);
+      sc.vcnt = sc.bstamp = c->d_scan_ctr = nullptr;
       c->scan_state = -1;
       return 1;
     }
-    sc.touched_cap = (u32) nb;
     HIP_TRY(c, hipMemsetAsync(sc.vcnt, 0, nb * 512 * sizeof(u32), s));
     HIP_TRY(c, hipMemsetAsync(sc.bstamp, 0, nb * sizeof(u32), s));
     HIP_TRY(c, hipMemsetAsync(c->d_scan_ctr, 0, 2 * SC_N * sizeof(u32), s));
@@ -2544,8 +2624,8 @@ int mrh_integrate_points(mrh_ctx* c, int n_frames_invalidate) {
       sc.ord_shift = t.multi_res ? 5 : 0;
       const size_t lds = (size_t) (2 * slots * 256 + 2 * kScanSetSize) * sizeof(u32);
       k_scan_walk<<<grid, 256, lds, s>>>(k, m, t, pts, normals, np, sc, (int) slots);
-      k_scan_collect<<<std::min<u32>(256u, (u32) ((c->num_blocks + 1023) / 1024)), 1024, 0, s>>>(t, sc, t.multi_res ? (u32) c->num_blocks : 0u);
-      k_scan_offsets<<<256, 1024, 0, s>>>(t, sc);
+      // the touched blocks are found by their stamps inside k_scan_offsets: windows of kScanWindow blocks, a workgroup each
+      k_scan_offsets<<<std::min<u32>(1024u, (u32) ((c->num_blocks + kScanWindow - 1) / kScanWindow)), 1024, 0, s>>>(t, sc, t.multi_res ? (u32) c->num_blocks : 0u);
       k_scan_place<<<grid, 256, 0, s>>>(sc, (int) slots);
       k_scan_apply<<<1536, 256, 0, s>>>(m, t, sc, np << sc.ord_shift, c->profile);
       HIP_TRY(c, hipGetLastError());
@@ -2987,11 +3067,16 @@ int mrh_extract_triangles(mrh_ctx* c, const mrh_triangle** out_tris, uint64_t* o
     }
     k_mc_neighbors<<<(int) (((size_t) n * 32 + 255) / 256), 256, 0, s>>>(c->tab, sorted, n, d_nb);
     if (dbg) { HIP_TRY(c, hipStreamSynchronize(s)); t1 = now(); }
-    // one workgroup per block, rounded up to a multiple of 8 runs of 2^k blocks: mc_first_block's mapping is then a permutation
-    // of the workgroup ids (workgroups beyond the list leave at once)
-    int slab_log2 = getenv("MRH_MC_SLAB_LOG2") ? std::min(20, std::max(0, atoi(getenv("MRH_MC_SLAB_LOG2")))) : 7;
+    // One workgroup per block, block e = workgroup id: the eight XCDs walk the position-sorted list side by side, so a block's
+    // neighbours are staged by other XCDs at about the same time and their rows come out of the memory-side Infinity Cache
+    // (rocprofv3 counts 3.3 x the algorithmic bytes on the L2 -> fabric side).  Round 5 measured the alternative — runs of 2^k
+    // blocks dealt to the XCDs in turn, so that neighbours share an L2 (mc_first_block; MRH_MC_SLAB_LOG2=k switches it on): the
+    // fabric traffic falls to 261 / 253 / 217 / 172 / 160 MB for k = 3 / 5 / 7 / 9 / one run per XCD, and the count pass gets
+    // SLOWER with every step, 0.246 -> 0.258 / 0.263 / 0.284 / 0.350 / 0.347 ms (profiles/r05/README.md): the re-reads are
+    // Infinity Cache hits, not HBM traffic, and they are not what the kernel waits for.  Off by default.
+    int slab_log2 = getenv("MRH_MC_SLAB_LOG2") ? std::min(20, std::max(0, atoi(getenv("MRH_MC_SLAB_LOG2")))) : -1;
     while (slab_log2 > 0 && ((size_t) 8 << slab_log2) > (size_t) n + 8) slab_log2--;  // never more than one run per XCD
-    const int grid = (int) ((((size_t) n + ((size_t) 8 << slab_log2) - 1) >> (slab_log2 + 3)) << (slab_log2 + 3));
+    const int grid = slab_log2 < 0 ? n : (int) ((((size_t) n + ((size_t) 8 << slab_log2) - 1) >> (slab_log2 + 3)) << (slab_log2 + 3));
     // largest truncation a stored sample can carry (integration clamps to trunc + scale * depth, depth <= the integration distance)
     const float sdf_bound = c->has_camera && !getenv("MRH_MC_NO_PRESCREEN") ? c->map.trunc + c->map.trunc_scale * c->cam.max_int_dist : 0.f;
     c->last_mc_count_ms = c->last_mc_emit_ms = 0.f;
@@ -3020,8 +3105,7 @@ int mrh_extract_triangles(mrh_ctx* c, const mrh_triangle** out_tris, uint64_t* o
     none.ctr = nullptr; none.recs = nullptr; none.base = nullptr; none.count = nullptr; none.cap = 0;
     if (use_records) HIP_TRY(c, hipMemsetAsync(d_rec_ctr, 0, 2 * sizeof(u32), s));
     const int mc_flags = (getenv("MRH_MC_NO_COARSE_KNOWN") ? 2 : 0)   // bit 1: coarse voxels on the literal evaluation only (A/B, tests)
-                         | (getenv("MRH_MC_NO_XCD_SLABS") ? 4 : 0)    // bit 2: block e = workgroup id (A/B)
-                         | (slab_log2 << 4);                          // bits 4..8: log2 of the run of blocks an XCD takes at a time
+                         | (slab_log2 < 0 ? 4 : (slab_log2 << 4));    // bit 2: block e = workgroup id; else bits 4..8: log2 of an XCD's run of blocks
     if (timed) hipExtLaunchKernelGGL((k_mc<false>), dim3(grid), dim3(kMcThreads), 0, s, c->mc_ev[0], c->mc_ev[1], 0u, c->map, c->tab, (const int4*) sorted, n, (const u32*) d_nb,
                                      (u32*) d_counts, (const u64*) nullptr, (mrh_triangle*) nullptr, (u64) 0, (uint8_t*) d_per_voxel, sdf_bound, mc_flags, R);
     else k_mc<false><<<grid, kMcThreads, 0, s>>>(c->map, c->tab, sorted, n, d_nb, d_counts, nullptr, nullptr, (u64) 0, d_per_voxel, sdf_bound, mc_flags, R);

@@ -761,14 +761,11 @@ struct McRecords {
   u32 cap;
 };
 constexpr int kMcThreads = 256;
-// Which block a workgroup takes.  Workgroups go to the eight XCDs round-robin by their id, and each XCD has its own L2: with
-// block e = workgroup id, the z-neighbours of a block (adjacent in the position-sorted list) are staged by the OTHER seven XCDs,
-// so every block's planes cross the fabric up to 27 times (rocprofv3: 3.4 x the algorithmic bytes).  Instead the list is cut into
-// runs of 2^k blocks dealt to the XCDs in turn, and the j-th workgroup of an XCD takes the j-th block of that XCD's runs: a
-// block's z- and y-neighbours are staged by the same XCD and found in its L2.  (One run per XCD — an eighth of the list each —
-// halves the traffic again but costs 40 % of the kernel: the slabs of a room differ in their share of coarse blocks, and the
-// launch lasts as long as its slowest XCD.)  The grid is a multiple of 8 * 2^k, so the mapping is a permutation of the ids.
-// flags: bit 2 = block e = workgroup id (MRH_MC_NO_XCD_SLABS, A/B); bits 4..8 = k.
+// Which block a workgroup takes: its own id (flags bit 2, the default), or — MRH_MC_SLAB_LOG2=k, an experiment kept for the record
+// (mrh_capi.hip: mrh_extract_triangles has the numbers) — the list cut into runs of 2^k blocks dealt to the eight XCDs in turn
+// (workgroups go to the XCDs round-robin by id), the j-th workgroup of an XCD taking the j-th block of that XCD's runs, so that a
+// block's neighbours are staged through the same L2.  The grid is then a multiple of 8 * 2^k: a permutation of the ids.
+// flags: bit 2 = block e = workgroup id; bits 4..8 = k.
 __device__ __forceinline__ int mc_first_block(const int flags) {
   const int w = (int) blockIdx.x, k = (flags >> 4) & 31;
   if ((flags & 4) || ((int) gridDim.x & ((8 << k) - 1))) return w;

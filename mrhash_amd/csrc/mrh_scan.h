@@ -11,8 +11,8 @@
 //                   group's size to the voxel's counter (neighbouring beams hit the same voxels: the hot voxels next to the
 //                   sensor take 10-30 x fewer atomics than records), marks the voxel's block as touched by this scan, and the
 //                   records + groups are parked in a stash (one allocation per workgroup, order irrelevant).
-//   k_scan_collect  the blocks this scan touched, from their stamps.
-//   k_scan_offsets  one wave per touched block: its 512 counters become offsets (the bases of 16 blocks from one atomic on the
+//   k_scan_offsets  the blocks this scan touched, from their stamps (a window of 128 blocks per workgroup); one wave per touched
+//                   block: its 512 counters become offsets (the bases of 16 blocks from one atomic on the
 //                   record cursor — the order of the blocks in the buffer does not matter), and its voxels are cut into chunks
 //                   of bounded work for the last kernel (< 512 records and a bounded sum of squared run lengths; a run longer
 //                   than kScanLongRun gets a chunk of its own).
@@ -50,16 +50,15 @@ enum ScanCtr : int { SC_TOUCHED = 0, SC_PLACED = 1, SC_CHUNKS = 2, SC_BIG = 3, S
 struct Scan {
   u32* vcnt;      // [pool blocks * 512] all zero between scans
   u32* bstamp;    // [pool blocks] 2 * sequence number of the last scan that touched the block + 1 if it holds coarse units
-  u32* touched;   // [touched_cap] block | kScanCoarse
   u32* ctr;       // this scan's counters [SC_N]
-  u32* ctr_next;  // the next scan's (zeroed by k_scan_collect)
+  u32* ctr_next;  // the next scan's (zeroed by k_scan_offsets)
   uint2* st_meta; // stash of walk workgroup w at w * 256 * slots: {group | rank in group << 13, lane << 5 | ordinal along the beam}
   float* st_sdf;
   uint4* st_grp;  // stash: {voxel id, records, records of the voxel that arrived before this group, 0}
   uint2* wgdesc;  // per walk workgroup {records, groups}
   uint4* rec;     // placed records: {point index << ord_shift | ordinal, sdf, the voxel's index in its block, 0}
   uint4* chunks;  // {block | coarse, v0 | v1 << 16, r0, r1}; runs beyond kScanWaveRecs from the END of the array downwards
-  u32 rec_cap, chunk_cap, touched_cap, seq;
+  u32 rec_cap, chunk_cap, seq;
   int ord_shift;  // 5 on variance-adaptive maps (a beam can cross several fine cells of one coarse voxel), else 0
 };
 
@@ -174,45 +173,47 @@ __global__ __launch_bounds__(256) void k_scan_walk(const Cam c, const Map m, con
   if (tid == 0) sc.wgdesc[blockIdx.x] = make_uint2(R, s_ng);
 }
 
-// The blocks this scan touched, from their stamps (no list is kept while the beams walk): 1024 blocks per workgroup, one
-// append per workgroup that found any.
-__global__ __launch_bounds__(1024) void k_scan_collect(const Tab t, const Scan sc, const u32 n_blocks_or_0) {
-  __shared__ u32 s_w[16];
-  __shared__ u32 s_base;
-  const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (blockIdx.x == 0 && tid < (u32) SC_N) sc.ctr_next[tid] = 0;
-  const u32 nb = n_blocks_or_0 ? n_blocks_or_0 : (u32) t.ctr[CTR_HWM_FINE];
-  for (u32 h0 = blockIdx.x * 1024u; h0 < nb; h0 += gridDim.x * 1024u) {
-    const u32 H = h0 + tid;
-    const u32 st = H < nb ? sc.bstamp[H] : 0u;
-    const bool hit = (st >> 1) == sc.seq;
-    const u64 bal = __ballot(hit);
-    if (lane == 0) s_w[wave] = (u32) __popcll(bal);
-    __syncthreads();
-    u32 before = 0, all = 0;
-    for (u32 w = 0; w < 16; w++) { if (w < wave) before += s_w[w]; all += s_w[w]; }
-    if (tid == 0 && all) s_base = atomicAdd(&sc.ctr[SC_TOUCHED], all);
-    __syncthreads();
-    if (hit) {
-      const u32 ti = s_base + before + (u32) __popcll(bal & lanemask_lt());
-      if (ti < sc.touched_cap) sc.touched[ti] = H | ((st & 1u) << 31);
-    }
-    __syncthreads();
-  }
-}
-
-// One wave per touched block, 16 blocks per workgroup: counters -> offsets, chunks for k_scan_apply.  The 16 blocks reserve their
-// records and their chunk slots with ONE atomic each per workgroup.
-__global__ __launch_bounds__(1024) void k_scan_offsets(const Tab t, const Scan sc) {
+// The blocks this scan touched are found by their stamps (no list is kept while the beams walk), by the kernel that needs them:
+// a workgroup of k_scan_offsets reads a window of kScanWindow stamps, lists the hits in LDS and turns their counters into offsets,
+// one wave per touched block, 16 blocks per round: counters -> offsets, chunks for k_scan_apply.  The 16 blocks reserve their
+// records and their chunk slots with ONE atomic each per round.  (Until round 4 a launch of its own collected the touched blocks
+// into a global list first: 5 us of a 98 us scan and one more crossing of HBM.)
+constexpr u32 kScanWindow = 128;
+__global__ __launch_bounds__(1024) void k_scan_offsets(const Tab t, const Scan sc, const u32 n_blocks_or_0) {
   __shared__ u32 s_excl[16][513];
   __shared__ unsigned short s_start[16][514];
   __shared__ u32 s_tot[16], s_nch[16], s_nbig[16], s_rbase, s_cbase, s_bbase;
+  __shared__ u32 s_hit[kScanWindow], s_hw[kScanWindow / 64];
   const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const u32 nt = min(sc.ctr[SC_TOUCHED], sc.touched_cap);
-  for (u32 t0 = blockIdx.x * 16u; t0 < nt; t0 += gridDim.x * 16u) {
+  if (blockIdx.x == 0 && tid < (u32) SC_N) sc.ctr_next[tid] = 0;  // the next scan's counters (this scan's walk is complete)
+  const u32 nb = n_blocks_or_0 ? n_blocks_or_0 : (u32) t.ctr[CTR_HWM_FINE];
+  for (u32 h0 = blockIdx.x * kScanWindow; h0 < nb; h0 += gridDim.x * kScanWindow) {
+    // ---- the window's touched blocks, in block order (waves 0 and 1 read the stamps)
+    u32 hit_val = 0;
+    bool hit = false;
+    u64 bal = 0;
+    if (tid < kScanWindow) {
+      const u32 Hs = h0 + tid;
+      const u32 st = Hs < nb ? sc.bstamp[Hs] : 0u;
+      hit = (st >> 1) == sc.seq;
+      hit_val = Hs | ((st & 1u) << 31);
+      bal = __ballot(hit);
+      if (lane == 0) s_hw[wave] = (u32) __popcll(bal);
+    }
+    __syncthreads();
+    if (hit) {
+      u32 before = 0;
+      for (u32 w = 0; w < wave; w++) before += s_hw[w];
+      s_hit[before + (u32) __popcll(bal & lanemask_lt())] = hit_val;
+    }
+    __syncthreads();
+    u32 nt = 0;
+    for (u32 w = 0; w < kScanWindow / 64; w++) nt += s_hw[w];
+    if (tid == 0 && nt) atomicAdd(&sc.ctr[SC_TOUCHED], nt);  // statistics only (MRH_DEBUG)
+  for (u32 t0 = 0; t0 < nt; t0 += 16u) {
     const u32 ti = t0 + wave;
     const bool have = ti < nt;
-    const u32 Hc = have ? sc.touched[ti] : 0u, H = Hc & ~kScanCoarse;
+    const u32 Hc = have ? s_hit[ti] : 0u, H = Hc & ~kScanCoarse;
     uint4* p = (uint4*) (sc.vcnt + (size_t) H * 512 + lane * 8);
     uint4 a = make_uint4(0, 0, 0, 0), b = a;
     if (have) { a = p[0]; b = p[1]; }
@@ -314,6 +315,8 @@ __global__ __launch_bounds__(1024) void k_scan_offsets(const Tab t, const Scan s
       }
     }
     __syncthreads();
+  }
+    __syncthreads();  // s_hit / s_hw are rewritten by the next window
   }
 }
 

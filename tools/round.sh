@@ -43,7 +43,7 @@ if has stats; then
   stats_leg driver_cmd python bench.py --pmc-inner --steps 20 --warmup 5
   stats_leg driver_cmd_mc python bench.py --pmc-inner-mc --steps 20 --warmup 5
   stats_leg lidar python bench.py --pmc-inner-lidar
-  MRH_PIPE=0 stats_leg sph python tools/bench_spherical.py 40 2
+  stats_leg sph python bench.py --pmc-inner-sph
 fi
 if has framepmc; then
   # what the two launches of a frame do with their cycles, pipelined and serial, at the driver's step count
@@ -58,7 +58,7 @@ if has framepmc; then
   cat $OUT/frame_pmc.txt | cut -c1-400
 fi
 if has pmc; then  # raw FETCH_SIZE / WRITE_SIZE passes behind the bench line's `traffic` figures
-  for leg in "driver --pmc-inner --steps 20 --warmup 5" "mc --pmc-inner-mc --steps 20 --warmup 5" "lidar --pmc-inner-lidar"; do
+  for leg in "driver --pmc-inner --steps 20 --warmup 5" "mc --pmc-inner-mc --steps 20 --warmup 5" "lidar --pmc-inner-lidar" "sph --pmc-inner-sph"; do
     set -- $leg; name=$1; shift
     for ctr in FETCH_SIZE WRITE_SIZE; do
       rocprofv3 --pmc $ctr --output-format csv -d $OUT/pmc_${name}_$ctr/pmc_fetch -o p -- python bench.py "$@" > $OUT/pmc_${name}_$ctr.log 2>&1
@@ -66,7 +66,6 @@ if has pmc; then  # raw FETCH_SIZE / WRITE_SIZE passes behind the bench line's `
       rm -rf $OUT/pmc_${name}_$ctr
     done
   done
-  MRH_PIPE=0 bash -c "for ctr in FETCH_SIZE WRITE_SIZE; do rocprofv3 --pmc \$ctr --output-format csv -d $OUT/pmc_sph_\$ctr/pmc_fetch -o p -- python tools/bench_spherical.py 40 1 > $OUT/pmc_sph_\$ctr.log 2>&1; python tools/summarize_pmc.py $OUT/pmc_sph_\$ctr > $OUT/traffic_sph_\$ctr.txt 2>&1; rm -rf $OUT/pmc_sph_\$ctr; done"
   grep -h -A1 "k_back<\|k_mc<\|k_scan_walk" $OUT/traffic_*.txt | cut -c1-200 | head -40
 fi
 if has stress; then
