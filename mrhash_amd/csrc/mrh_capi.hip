@@ -1318,7 +1318,7 @@ int mrh_destroy(mrh_ctx* c) {
     (void) hipStreamSynchronize(c->stream);
     (void) hipMemcpy(h, c->d_scan_ctr, sizeof(h), hipMemcpyDeviceToHost);
     const u32* k = h + (c->scan2_seq & 1u) * SC_N;
-    fprintf(stderr, "[mrhash_hip] last scan: %u touched blocks, %u records, %u chunks + %u runs beyond a wave\n", k[SC_TOUCHED], k[SC_PLACED], k[SC_CHUNKS], k[SC_BIG]);
+    fprintf(stderr, "[mrhash_hip] last scan: %u records, %u chunks + %u runs beyond a wave\n", k[SC_PLACED], k[SC_CHUNKS], k[SC_BIG]);
   }
 #ifdef MRH_TRACE
   if (const char* path = getenv("MRH_TRACE_FILE")) {  // tuning builds: phase timestamps of the last k_back launch
@@ -1999,7 +1999,11 @@ int ensure_pipe_buffers(mrh_ctx* c, const size_t npix) {
     const size_t cap = c->num_blocks;
     // (a high-priority front stream, a ring of eight and integrations deferred by two calls were measured: no difference)
     HIP_TRY(c, hipStreamCreateWithFlags(&c->stream_front, hipStreamNonBlocking));
-    for (hipEvent_t& e : c->ev_front) HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    // The front half's event orders two streams of ONE device: it needs no system-scope fence, and the default one costs a cache
+    // writeback + invalidation at every record — next to a running integration whose working set lives in those caches
+    // (hip_runtime_api.h: hipEventDisableSystemFence).  MRH_EVENT_FENCE=1 keeps the default (A/B).
+    const unsigned ev_flags = hipEventDisableTiming | (getenv("MRH_EVENT_FENCE") ? 0u : (unsigned) hipEventDisableSystemFence);
+    for (hipEvent_t& e : c->ev_front) HIP_TRY(c, hipEventCreateWithFlags(&e, ev_flags));
     c->ring_vis[0] = c->tab.compact; c->ring_bbox[0] = c->fast.bbox; c->ring_cfree[0] = c->d_cfree; c->ring_zmin[0] = c->d_zmin;
     for (int i = 1; i < kPipeRing; i++) {
       HIP_TRY(c, hipMalloc((void**) &c->ring_vis[i], cap * sizeof(int4)));
@@ -2625,7 +2629,7 @@ int mrh_integrate_points(mrh_ctx* c, int n_frames_invalidate) {
       const size_t lds = (size_t) (2 * slots * 256 + 2 * kScanSetSize) * sizeof(u32);
       k_scan_walk<<<grid, 256, lds, s>>>(k, m, t, pts, normals, np, sc, (int) slots);
       // the touched blocks are found by their stamps inside k_scan_offsets: windows of kScanWindow blocks, a workgroup each
-      k_scan_offsets<<<std::min<u32>(1024u, (u32) ((c->num_blocks + kScanWindow - 1) / kScanWindow)), 1024, 0, s>>>(t, sc, t.multi_res ? (u32) c->num_blocks : 0u);
+      k_scan_offsets<<<std::min<u32>(2048u, (u32) ((c->num_blocks + kScanWindow - 1) / kScanWindow)), 1024, 0, s>>>(t, sc, t.multi_res ? (u32) c->num_blocks : 0u);
       k_scan_place<<<grid, 256, 0, s>>>(sc, (int) slots);
       k_scan_apply<<<1536, 256, 0, s>>>(m, t, sc, np << sc.ord_shift, c->profile);
       HIP_TRY(c, hipGetLastError());

@@ -45,7 +45,7 @@ constexpr u32 kScanLongRun = 64;          // a run longer than this is a chunk o
 constexpr u32 kScanBigRecs = 2048;        // a run beyond a wave's slice is sorted by a whole workgroup (<= this: bitonic; beyond: windows)
 constexpr u32 kScanEmpty = 0xFFFFFFFFu;
 constexpr u32 kScanCoarse = 0x80000000u;  // voxel id of a coarse unit
-enum ScanCtr : int { SC_TOUCHED = 0, SC_PLACED = 1, SC_CHUNKS = 2, SC_BIG = 3, SC_N = 4 };
+enum ScanCtr : int { SC_UNUSED = 0, SC_PLACED = 1, SC_CHUNKS = 2, SC_BIG = 3, SC_N = 4 };
 
 struct Scan {
   u32* vcnt;      // [pool blocks * 512] all zero between scans
@@ -178,38 +178,29 @@ __global__ __launch_bounds__(256) void k_scan_walk(const Cam c, const Map m, con
 // one wave per touched block, 16 blocks per round: counters -> offsets, chunks for k_scan_apply.  The 16 blocks reserve their
 // records and their chunk slots with ONE atomic each per round.  (Until round 4 a launch of its own collected the touched blocks
 // into a global list first: 5 us of a 98 us scan and one more crossing of HBM.)
-constexpr u32 kScanWindow = 128;
+constexpr u32 kScanWindow = 16;  // = the blocks of one round: a scan touches most of the blocks near the sensor, so a window is
+                                 // mostly hits and is done in ONE round (with 128-block windows a workgroup walked six rounds in a row)
 __global__ __launch_bounds__(1024) void k_scan_offsets(const Tab t, const Scan sc, const u32 n_blocks_or_0) {
   __shared__ u32 s_excl[16][513];
   __shared__ unsigned short s_start[16][514];
   __shared__ u32 s_tot[16], s_nch[16], s_nbig[16], s_rbase, s_cbase, s_bbase;
-  __shared__ u32 s_hit[kScanWindow], s_hw[kScanWindow / 64];
+  __shared__ u32 s_hit[kScanWindow], s_nhit;
+  static_assert(kScanWindow <= 64, "one wave reads the window's stamps");
   const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (blockIdx.x == 0 && tid < (u32) SC_N) sc.ctr_next[tid] = 0;  // the next scan's counters (this scan's walk is complete)
   const u32 nb = n_blocks_or_0 ? n_blocks_or_0 : (u32) t.ctr[CTR_HWM_FINE];
   for (u32 h0 = blockIdx.x * kScanWindow; h0 < nb; h0 += gridDim.x * kScanWindow) {
-    // ---- the window's touched blocks, in block order (waves 0 and 1 read the stamps)
-    u32 hit_val = 0;
-    bool hit = false;
-    u64 bal = 0;
-    if (tid < kScanWindow) {
-      const u32 Hs = h0 + tid;
-      const u32 st = Hs < nb ? sc.bstamp[Hs] : 0u;
-      hit = (st >> 1) == sc.seq;
-      hit_val = Hs | ((st & 1u) << 31);
-      bal = __ballot(hit);
-      if (lane == 0) s_hw[wave] = (u32) __popcll(bal);
+    // ---- the window's touched blocks, in block order (wave 0 reads the stamps)
+    if (wave == 0) {
+      const u32 Hs = h0 + lane;
+      const u32 st = (lane < kScanWindow && Hs < nb) ? sc.bstamp[Hs] : 0u;
+      const bool hit = lane < kScanWindow && (st >> 1) == sc.seq;
+      const u64 bal = __ballot(hit);
+      if (hit) s_hit[(u32) __popcll(bal & lanemask_lt())] = Hs | ((st & 1u) << 31);
+      if (lane == 0) s_nhit = (u32) __popcll(bal);
     }
     __syncthreads();
-    if (hit) {
-      u32 before = 0;
-      for (u32 w = 0; w < wave; w++) before += s_hw[w];
-      s_hit[before + (u32) __popcll(bal & lanemask_lt())] = hit_val;
-    }
-    __syncthreads();
-    u32 nt = 0;
-    for (u32 w = 0; w < kScanWindow / 64; w++) nt += s_hw[w];
-    if (tid == 0 && nt) atomicAdd(&sc.ctr[SC_TOUCHED], nt);  // statistics only (MRH_DEBUG)
+    const u32 nt = s_nhit;
   for (u32 t0 = 0; t0 < nt; t0 += 16u) {
     const u32 ti = t0 + wave;
     const bool have = ti < nt;
