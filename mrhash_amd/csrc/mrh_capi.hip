@@ -61,7 +61,6 @@ struct UpSlot {
   size_t cap = 0;
   hipEvent_t copied = nullptr;  // H2D out of `h` done (copy stream)
   bool copied_rec = false;
-  uint64_t issue_ticket = 0;    // IssueThread ticket of the transfer out of `h` (0: issued by the caller itself)
   uint64_t last_seq = 0;        // newest frame_done mark of a frame that read `d` (0: none)
 };
 struct UpRing {
@@ -69,7 +68,6 @@ struct UpRing {
   int cur = -1;                 // slot holding the current image; -1: none, or a caller's device pointer
   hipStream_t stream = nullptr; // this ring's copy stream
   hipEvent_t last_copy = nullptr;  // newest copy event of this ring
-  uint64_t last_ticket = 0;        // ... and the IssueThread ticket that records it (0: recorded already)
   bool waited[2] = {false, false}; // ... has been waited for by {main, front} stream
 };
 
@@ -395,14 +393,11 @@ uint64_t next_pow2(uint64_t v) {
   return r;
 }
 
-hipError_t upload_issue_wait(uint64_t ticket);  // IssueThread::wait (defined with the upload path)
 void free_all(mrh_ctx* c) {
   if (!c) return;
   (void) hipSetDevice(c->device);
-  for (UpRing* r : {&c->up_depth, &c->up_rgb}) {
-    for (UpSlot& u : r->s) if (u.issue_ticket) { (void) upload_issue_wait(u.issue_ticket); u.issue_ticket = 0; }  // no transfer of this context is still to be issued
+  for (UpRing* r : {&c->up_depth, &c->up_rgb})
     if (r->stream) { (void) hipStreamSynchronize(r->stream); (void) hipStreamDestroy(r->stream); }
-  }
   if (c->stream_front) (void) hipStreamSynchronize(c->stream_front);
   if (c->stream) (void) hipStreamSynchronize(c->stream);
   auto F = [](void* p) { if (p) (void) hipFree(p); };
@@ -1697,77 +1692,6 @@ void widen_quiesce() {}
 uint64_t widen_redone() { return 0; }
 #endif
 
-// The transfer of a staged image is ISSUED by a thread of its own (round 5).  A frame from host memory costs the caller ~63 us —
-// two staging copies (~25 us with the pool), and ~25 us inside hipMemcpyAsync / hipEventRecord / the launches —, more than the
-// link needs for its 2.15 MB (43 us idle, ~57 next to the kernels): the host bounds the path.  The two runtime calls of an upload
-// (copy + event record, ~8-10 us per image) therefore run on this thread while the caller is already back in its own code
-// staging the next image; whoever needs the event to have been RECORDED — the frame's stream wait, the reuse of the slot, the
-// end of the context — waits for the ticket (a spin of a few microseconds at worst: the thread is awake while frames arrive).
-// One thread per process, started by the first large upload; MRH_ISSUE_THREAD=0 keeps the calls on the caller's thread.
-struct IssueThread {
-  struct Job { int device; void* dst; const void* src; size_t bytes; hipStream_t stream; hipEvent_t ev; };
-  static constexpr uint64_t kRing = 64;
-  Job ring[kRing];
-  std::atomic<uint64_t> pushed{0}, done{0};  // tickets: job t lives in ring[t % kRing]; done = tickets completed
-  std::atomic<int> error{0};                 // first hipError_t of a failed call (sticky until read)
-  std::mutex m;                              // producers (contexts on different host threads)
-  std::mutex sleep_m;
-  std::condition_variable cv;
-  std::atomic<int> sleeping{0};
-  bool started = false, enabled = true;
-  void run() {
-    uint64_t next = 1;
-    int dev = -1;
-    for (;;) {
-      const auto t0 = std::chrono::steady_clock::now();
-      int spins = 0;
-      while (pushed.load(std::memory_order_acquire) < next) {
-        MRH_CPU_RELAX();
-        if ((++spins & 255) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(300)) {
-          std::unique_lock<std::mutex> lk(sleep_m);
-          sleeping.store(1, std::memory_order_seq_cst);
-          cv.wait(lk, [&] { return pushed.load(std::memory_order_acquire) >= next; });
-          sleeping.store(0, std::memory_order_seq_cst);
-        }
-      }
-      const Job j = ring[next % kRing];
-      hipError_t e = hipSuccess;
-      if (j.device != dev) { e = hipSetDevice(j.device); dev = j.device; }
-      if (e == hipSuccess) e = hipMemcpyAsync(j.dst, j.src, j.bytes, hipMemcpyHostToDevice, j.stream);
-      if (e == hipSuccess) e = hipEventRecord(j.ev, j.stream);
-      if (e != hipSuccess) { int z = 0; error.compare_exchange_strong(z, (int) e); (void) hipGetLastError(); }
-      done.store(next, std::memory_order_release);
-      next++;
-    }
-  }
-  uint64_t push(const Job& j) {
-    std::lock_guard<std::mutex> lk(m);
-    if (!started) {
-      started = true;
-      if (const char* e = getenv("MRH_ISSUE_THREAD")) enabled = atoi(e) != 0;
-      if (enabled) std::thread([this] { run(); }).detach();
-    }
-    if (!enabled) return 0;
-    const uint64_t t = pushed.load(std::memory_order_relaxed) + 1;
-    while (t - done.load(std::memory_order_acquire) >= kRing) MRH_CPU_RELAX();  // ring full: the thread is kRing jobs behind
-    ring[t % kRing] = j;
-    pushed.store(t, std::memory_order_seq_cst);
-    if (sleeping.load(std::memory_order_seq_cst)) { std::lock_guard<std::mutex> lk2(sleep_m); cv.notify_one(); }
-    return t;
-  }
-  // the calls of ticket t have been made; returns the first error of any job so far (and clears it)
-  hipError_t wait(const uint64_t t) {
-    if (t) while (done.load(std::memory_order_acquire) < t) MRH_CPU_RELAX();
-    const int e = error.exchange(0);
-    return (hipError_t) e;
-  }
-};
-IssueThread* issue_thread() {
-  static IssueThread* it = new IssueThread();  // never destroyed: the detached thread may be parked on it at exit
-  return it;
-}
-hipError_t upload_issue_wait(uint64_t ticket) { return issue_thread()->wait(ticket); }
-
 // one host image into the next slot of its ring: wait until the slot is free, copy into pinned staging (the caller's
 // buffer is free on return), enqueue the H2D on the copy stream
 int upload_image(mrh_ctx* c, UpRing& ring, const void* src, const size_t bytes, const void** out_dev) {
@@ -1784,7 +1708,6 @@ int upload_image(mrh_ctx* c, UpRing& ring, const void* src, const size_t bytes, 
   const int next = (ring.cur + 1) % 3;
   UpSlot& u = ring.s[next];
   if (u.last_seq) HIP_TRY(c, hipEventSynchronize(c->frame_done[u.last_seq % 8]));  // this mark or a later one of the same stream
-  if (u.issue_ticket) { HIP_TRY(c, issue_thread()->wait(u.issue_ticket)); u.issue_ticket = 0; }  // the record of its last transfer has been made
   if (u.copied_rec) HIP_TRY(c, hipEventSynchronize(u.copied));
   if (bytes > u.cap) {
     if (u.h) HIP_TRY(c, hipHostFree(u.h));
@@ -1796,15 +1719,15 @@ int upload_image(mrh_ctx* c, UpRing& ring, const void* src, const size_t bytes, 
     if (!u.copied) HIP_TRY(c, hipEventCreateWithFlags(&u.copied, hipEventDisableTiming));
   }
   copy_to_staging(u.h, src, bytes);
-  u.issue_ticket = bytes >= (256u << 10) ? issue_thread()->push({c->device, u.d, u.h, bytes, ring.stream, u.copied}) : 0;
-  if (!u.issue_ticket) {  // small images (or MRH_ISSUE_THREAD=0): the two calls cost less than the hand-over
-    HIP_TRY(c, hipMemcpyAsync(u.d, u.h, bytes, hipMemcpyHostToDevice, ring.stream));
-    HIP_TRY(c, hipEventRecord(u.copied, ring.stream));
-  }
+  // (Round 5 measured the two runtime calls below on a thread of their own, so that the caller is back in its code ~10 us earlier:
+  // uploads alone 56 -> 43 us per frame, but a FRAME stays at 62-64 us — mrh_integrate then waits for that thread to have
+  // recorded the event before it can enqueue the stream wait, and the chain staging -> copy call -> stream wait -> launches is
+  // on the caller's critical path whoever makes the calls.  Removed again; profiles/r05/README.md.)
+  HIP_TRY(c, hipMemcpyAsync(u.d, u.h, bytes, hipMemcpyHostToDevice, ring.stream));
+  HIP_TRY(c, hipEventRecord(u.copied, ring.stream));
   u.copied_rec = true;
   u.last_seq = 0;
   ring.last_copy = u.copied;  // a ring's copies are ordered on its stream: the newest event covers the earlier ones
-  ring.last_ticket = u.issue_ticket;
   ring.waited[0] = ring.waited[1] = false;
   ring.cur = next;
   *out_dev = u.d;
@@ -1817,7 +1740,6 @@ int send_uploads(mrh_ctx* c, hipStream_t reader) {
   const int w = (reader == c->stream) ? 0 : 1;
   for (UpRing* r : {&c->up_depth, &c->up_rgb})
     if (r->last_copy && !r->waited[w]) {
-      if (r->last_ticket) { HIP_TRY(c, issue_thread()->wait(r->last_ticket)); r->last_ticket = 0; }  // a wait on an event that is not recorded yet is no wait
       HIP_TRY(c, hipStreamWaitEvent(reader, r->last_copy, 0));
       r->waited[w] = true;
     }
@@ -1999,11 +1921,8 @@ int ensure_pipe_buffers(mrh_ctx* c, const size_t npix) {
     const size_t cap = c->num_blocks;
     // (a high-priority front stream, a ring of eight and integrations deferred by two calls were measured: no difference)
     HIP_TRY(c, hipStreamCreateWithFlags(&c->stream_front, hipStreamNonBlocking));
-    // The front half's event orders two streams of ONE device: it needs no system-scope fence, and the default one costs a cache
-    // writeback + invalidation at every record — next to a running integration whose working set lives in those caches
-    // (hip_runtime_api.h: hipEventDisableSystemFence).  MRH_EVENT_FENCE=1 keeps the default (A/B).
-    const unsigned ev_flags = hipEventDisableTiming | (getenv("MRH_EVENT_FENCE") ? 0u : (unsigned) hipEventDisableSystemFence);
-    for (hipEvent_t& e : c->ev_front) HIP_TRY(c, hipEventCreateWithFlags(&e, ev_flags));
+    // (hipEventDisableSystemFence on these events — they order two streams of one device — was measured in round 5: no difference)
+    for (hipEvent_t& e : c->ev_front) HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     c->ring_vis[0] = c->tab.compact; c->ring_bbox[0] = c->fast.bbox; c->ring_cfree[0] = c->d_cfree; c->ring_zmin[0] = c->d_zmin;
     for (int i = 1; i < kPipeRing; i++) {
       HIP_TRY(c, hipMalloc((void**) &c->ring_vis[i], cap * sizeof(int4)));
