@@ -1120,6 +1120,19 @@ int mrh_debug_mc_trace(uint32_t* out, int clear) {  // out: 2 x 65536 x 8 words
 }
 #endif
 
+#ifdef MRH_SCAN_TRACE
+// tuning builds only (tools/trace_scan.sh): read (and optionally clear) the phase stamps of the scan kernels
+int mrh_debug_scan_trace(unsigned long long* out, int clear) {  // out: 4 x kScanTraceWgs x 8 words
+  if (hipDeviceSynchronize() != hipSuccess) return MRH_ERR_DEVICE;
+  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(d_scan_trace), sizeof(d_scan_trace)) != hipSuccess) return MRH_ERR_DEVICE;
+  if (clear) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(d_scan_trace)) != hipSuccess || hipMemset(p, 0, sizeof(d_scan_trace)) != hipSuccess) return MRH_ERR_DEVICE;
+  }
+  return MRH_OK;
+}
+#endif
+
 const char* mrh_last_error(const mrh_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 
 int mrh_create(const mrh_params* p, mrh_ctx** out) {
@@ -2547,8 +2560,9 @@ int mrh_integrate_points(mrh_ctx* c, int n_frames_invalidate) {
       sc.ord_shift = t.multi_res ? 5 : 0;
       const size_t lds = (size_t) (2 * slots * 256 + 2 * kScanSetSize) * sizeof(u32);
       k_scan_walk<<<grid, 256, lds, s>>>(k, m, t, pts, normals, np, sc, (int) slots);
-      // the touched blocks are found by their stamps inside k_scan_offsets: windows of kScanWindow blocks, a workgroup each
-      k_scan_offsets<<<std::min<u32>(2048u, (u32) ((c->num_blocks + kScanWindow - 1) / kScanWindow)), 1024, 0, s>>>(t, sc, t.multi_res ? (u32) c->num_blocks : 0u);
+      // the touched blocks are found by their stamps inside k_scan_offsets, windows of kScanWindow blocks; 512 workgroups walk the
+      // windows (2 048 of these 1 024-thread workgroups took 9 us to DISPATCH for ~1 us of work each, tools/trace_scan.py)
+      k_scan_offsets<<<std::min<u32>(512u, (u32) ((c->num_blocks + kScanWindow - 1) / kScanWindow)), 1024, 0, s>>>(t, sc, t.multi_res ? (u32) c->num_blocks : 0u);
       k_scan_place<<<grid, 256, 0, s>>>(sc, (int) slots);
       k_scan_apply<<<1536, 256, 0, s>>>(m, t, sc, np << sc.ord_shift, c->profile);
       HIP_TRY(c, hipGetLastError());

@@ -66,6 +66,16 @@ struct Scan {
 // list counter = 45 us of a kernel), so nothing here takes one per block or per workgroup: the stash is addressed by workgroup,
 // the touched blocks are found by their stamps, block bases and chunk slots are reserved 16 blocks at a time.
 
+#ifdef MRH_SCAN_TRACE
+// tuning builds only (tools/trace_scan.sh): wall-clock stamps (100 MHz) of thread 0 of every workgroup at its phase boundaries;
+// [kernel][workgroup][slot], kernels: 0 walk, 1 offsets, 2 place, 3 apply
+constexpr int kScanTraceWgs = 4096;
+__device__ unsigned long long d_scan_trace[4][kScanTraceWgs][8];
+#define MRH_SC_TS(kern, slot) do { if (threadIdx.x == 0 && blockIdx.x < kScanTraceWgs) d_scan_trace[kern][blockIdx.x][slot] = wall_clock64(); } while (0)
+#else
+#define MRH_SC_TS(kern, slot) do { } while (0)
+#endif
+
 __global__ __launch_bounds__(256) void k_scan_walk(const Cam c, const Map m, const Tab t, const float* __restrict__ pts,
                                                    const float* __restrict__ normals, const u32 n, const Scan sc, const int slots) {
   extern __shared__ u32 s_dyn[];
@@ -76,6 +86,7 @@ __global__ __launch_bounds__(256) void k_scan_walk(const Cam c, const Map m, con
   __shared__ u32 s_part[4];
   __shared__ u32 s_ng;
   const u32 tid = threadIdx.x;
+  MRH_SC_TS(0, 0);
   for (u32 i = tid; i < kScanSetSize; i += 256) { s_key[i] = kScanEmpty; s_cnt[i] = 0; }
   if (tid == 0) s_ng = 0;
   const u32 i = blockIdx.x * 256 + tid;
@@ -89,6 +100,7 @@ __global__ __launch_bounds__(256) void k_scan_walk(const Cam c, const Map m, con
     else over = true;
   });
   if (over) atomicOr((u32*) &t.ctr[CTR_ERROR], ERR_SCAN);  // the host's bound on the voxels of a beam did not hold: the call fails
+  MRH_SC_TS(0, 1);
   // this beam's place among the workgroup's records
   u32 incl = cnt;
   const u32 lane = tid & 63, wave = tid >> 6;
@@ -98,6 +110,7 @@ __global__ __launch_bounds__(256) void k_scan_walk(const Cam c, const Map m, con
   }
   if (lane == 63) s_part[wave] = incl;
   __syncthreads();  // the set is initialised, the wave totals are there
+  MRH_SC_TS(0, 2);
   u32 lane_off = incl - cnt, R = 0;
   for (u32 w = 0; w < 4; w++) { if (w < wave) lane_off += s_part[w]; R += s_part[w]; }
   // A: group by voxel
@@ -116,6 +129,7 @@ __global__ __launch_bounds__(256) void k_scan_walk(const Cam c, const Map m, con
     else ovf |= 1u << j;  // set saturated: the record becomes a group of its own
   }
   __syncthreads();
+  MRH_SC_TS(0, 3);
   const u32 off = blockIdx.x * 256u * (u32) slots;  // this workgroup's part of the stash (the host sizes it by the bound: points * slots)
   // B: one group per occupied set slot.  The atomic that adds the group to its voxel's counter returns what was there: the group's
   // place inside the voxel's run (arrival order — the run is put into point order later, in LDS).
@@ -142,6 +156,7 @@ __global__ __launch_bounds__(256) void k_scan_walk(const Cam c, const Map m, con
       }
   }
   __syncthreads();
+  MRH_SC_TS(0, 4);
   // C: the records, each wave's in its own part of the workgroup's stash, ordinal-major (the lanes that have a j-th record
   // store it side by side: coalesced)
   {
@@ -171,6 +186,7 @@ __global__ __launch_bounds__(256) void k_scan_walk(const Cam c, const Map m, con
   }
   __syncthreads();
   if (tid == 0) sc.wgdesc[blockIdx.x] = make_uint2(R, s_ng);
+  MRH_SC_TS(0, 5);
 }
 
 // The blocks this scan touched are found by their stamps (no list is kept while the beams walk), by the kernel that needs them:
@@ -188,6 +204,7 @@ __global__ __launch_bounds__(1024) void k_scan_offsets(const Tab t, const Scan s
   static_assert(kScanWindow <= 64, "one wave reads the window's stamps");
   const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (blockIdx.x == 0 && tid < (u32) SC_N) sc.ctr_next[tid] = 0;  // the next scan's counters (this scan's walk is complete)
+  MRH_SC_TS(1, 0);
   const u32 nb = n_blocks_or_0 ? n_blocks_or_0 : (u32) t.ctr[CTR_HWM_FINE];
   for (u32 h0 = blockIdx.x * kScanWindow; h0 < nb; h0 += gridDim.x * kScanWindow) {
     // ---- the window's touched blocks, in block order (wave 0 reads the stamps)
@@ -307,8 +324,9 @@ __global__ __launch_bounds__(1024) void k_scan_offsets(const Tab t, const Scan s
     }
     __syncthreads();
   }
-    __syncthreads();  // s_hit / s_hw are rewritten by the next window
+    __syncthreads();  // s_hit is rewritten by the next window
   }
+  MRH_SC_TS(1, 1);
 }
 
 // Records of one walk workgroup -> their voxels' runs: slot = start of the run (k_scan_offsets) + the records that had arrived
@@ -316,6 +334,7 @@ __global__ __launch_bounds__(1024) void k_scan_offsets(const Tab t, const Scan s
 __global__ __launch_bounds__(256) void k_scan_place(const Scan sc, const int slots) {
   __shared__ u32 s_base[256 * kScanMaxSlots];
   __shared__ unsigned short s_li[256 * kScanMaxSlots];
+  MRH_SC_TS(2, 0);
   const uint2 d = sc.wgdesc[blockIdx.x];
   const u32 off = blockIdx.x * 256u * (u32) slots, R = d.x, G = d.y;
   for (u32 g = threadIdx.x; g < G; g += 256) {
@@ -333,6 +352,7 @@ __global__ __launch_bounds__(256) void k_scan_place(const Scan sc, const int slo
       sc.rec[slot] = make_uint4(sc.ord_shift ? (pidx << 5) | (meta.y & 31u) : pidx, __float_as_uint(sdf), s_li[meta.x & 0x1FFFu], 0u);
     }
   }
+  MRH_SC_TS(2, 1);
 }
 
 // The fold of one voxel's run, record by record in the order they are pushed: k_points_apply's chain (see there for why each
@@ -417,6 +437,27 @@ struct VoxFold {
       const u32 nt = min(clamp_at, n - 1);
       for (; i < nt; i++) s = div_cr(s * a[i] + x[i], a[i] + w1f, r[i]);
       const float aw = (float) wmax, dw = (float) (int) (wmax + w1), rw = rcp_refined(dw);
+      // The clamped weight sum of the shipped configurations is a power of two (255 + 1): dividing by it is a multiplication by
+      // an exact reciprocal, ONE rounding — the IEEE quotient in every case, subnormal results included — so the chain of a
+      // record is multiply, add, multiply instead of multiply, add and the three operations of div_cr (which return that
+      // same value: q is exact, the residual is zero).  The longest run of a scan is what its last launch waits for.
+      const u32 dwi = wmax + w1;
+      if ((dwi & (dwi - 1u)) == 0u && i + 4 < n) {
+        float x0 = x[i], x1 = x[i + 1], x2 = x[i + 2], x3 = x[i + 3];
+        for (; i + 8 < n; i += 4) {
+          const float y0 = x[i + 4], y1 = x[i + 5], y2 = x[i + 6], y3 = x[i + 7];
+          s = (s * aw + x0) * rw;
+          s = (s * aw + x1) * rw;
+          s = (s * aw + x2) * rw;
+          s = (s * aw + x3) * rw;
+          x0 = y0; x1 = y1; x2 = y2; x3 = y3;
+        }
+        s = (s * aw + x0) * rw;
+        s = (s * aw + x1) * rw;
+        s = (s * aw + x2) * rw;
+        s = (s * aw + x3) * rw;
+        i += 4;
+      }
       if (i + 4 < n) {  // four records in registers while the four before them are folded: no step waits for the LDS
         float x0 = x[i], x1 = x[i + 1], x2 = x[i + 2], x3 = x[i + 3];
         for (; i + 8 < n; i += 4) {
@@ -524,8 +565,16 @@ __global__ __launch_bounds__(256, 6) void k_scan_apply(const Map m, const Tab t,
   // array and the long runs from its end: two late reservations can each pass and still overlap.  The final totals decide.
   if (blockIdx.x == 0 && tid == 0 && (u64) sc.ctr[SC_CHUNKS] + (u64) sc.ctr[SC_BIG] > (u64) sc.chunk_cap) atomicOr((u32*) &t.ctr[CTR_ERROR], ERR_SCAN);
   u32 updated = 0;
+  MRH_SC_TS(3, 0);
   ApplyWaveLds& L = s_w[wave];
-  for (u32 ci = blockIdx.x * 4u + wave; ci < n_small; ci += gridDim.x * 4u) {
+  // Runs beyond a wave's slice are the longest chains of the launch (a sort by the whole workgroup, then ONE lane folds up to a
+  // few thousand records, ~17 ns each): the workgroups [0, nb_wg) take them, and nothing else, from the first cycle on; the chunks
+  // of a wave's size go to the other workgroups.  (Until round 5 every workgroup walked its chunks first and the long runs started
+  // 5-10 us into the launch: the launch lasted 26 us with 90 % of its workgroups done after 15, tools/trace_scan.py.)
+  const u32 nb_wg = n_big < gridDim.x / 2 ? n_big : 0u;  // uniform; 0: more long runs than spare workgroups — everybody does both
+  const bool big_only = blockIdx.x < nb_wg;
+  const u32 small_wgs = gridDim.x - nb_wg;
+  for (u32 ci = big_only ? n_small : (blockIdx.x - nb_wg) * 4u + wave; ci < n_small; ci += small_wgs * 4u) {
     const uint4 ch = sc.chunks[ci];
     const u32 H = ch.x & ~kScanCoarse, v0 = ch.y & 0xFFFFu, v1 = ch.y >> 16, r0 = ch.z, nr = ch.w - ch.z, nv = v1 - v0;
     const bool coarse = (ch.x & kScanCoarse) != 0;
@@ -634,11 +683,12 @@ __global__ __launch_bounds__(256, 6) void k_scan_apply(const Map m, const Tab t,
   }
   // runs beyond a wave's slice: one workgroup each, over the same LDS
   __syncthreads();
+  MRH_SC_TS(3, 1);
   u32* s_tag = (u32*) &s_w[0];
   float* s_sdf = (float*) (s_tag + kScanBigRecs);
   float* s_sorted = s_sdf + kScanBigRecs;  // windows only; the tables of the bitonic path lie here
   constexpr int PER = kScanBigRecs / 256;
-  for (u32 bi = blockIdx.x; bi < n_big; bi += gridDim.x) {
+  for (u32 bi = nb_wg ? (big_only ? blockIdx.x : n_big) : blockIdx.x; bi < n_big; bi += nb_wg ? nb_wg : gridDim.x) {
     const uint4 ch = sc.chunks[sc.chunk_cap - 1u - bi];
     const u32 H = ch.x & ~kScanCoarse, v0 = ch.y & 0xFFFFu, r0 = ch.z, nr = ch.w - ch.z;
     const bool coarse = (ch.x & kScanCoarse) != 0;
@@ -694,6 +744,7 @@ __global__ __launch_bounds__(256, 6) void k_scan_apply(const Map m, const Tab t,
     __syncthreads();
   }
   if (count_updates && updated) atomicAdd(&t.prof[PROF_UPDATED], (u64) updated);  // profile mode: voxels this scan updated
+  MRH_SC_TS(3, 2);
 }
 
 }  // namespace mrh

@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Tuning aid: phase stamps of the LiDAR scan kernels (build with -DMRH_SCAN_TRACE, see tools/trace_scan.sh): for the last scan of
+the bench's drive, per kernel: when its workgroups start and end relative to the first one, and how long each phase takes."""
+import ctypes as C, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench
+from mrhash_amd import capi
+capi.HIP_LIB_PATH = os.path.join(ROOT, "mrhash_amd", "csrc", "libmrhash_trace.so")
+hip = capi.load_hip()
+le, scans, d_scans, run_scans = bench.lidar_setup(hip, 262144)
+run_scans(0, bench.LIDAR_SCANS - 1)
+le.sync()
+W = 4096
+buf = (C.c_uint64 * (4 * W * 8))()
+hip.mrh_debug_scan_trace(None, 1)
+run_scans(bench.LIDAR_SCANS - 1, bench.LIDAR_SCANS)
+le.sync()
+hip.mrh_debug_scan_trace(buf, 0)
+a = np.frombuffer(buf, dtype=np.uint64).astype(np.int64).reshape(4, W, 8)
+tick = 0.01  # us per tick (100 MHz)
+names = {0: ("walk", ["start", "beams walked", "set ready", "grouped (A)", "atomics + groups (B)", "records stored (C)"]),
+         1: ("offsets", ["start", "end"]), 2: ("place", ["start", "end"]), 3: ("apply", ["start", "chunks done", "end"])}
+t0_all = a[:, :, 0][a[:, :, 0] > 0].min()
+for k, (nm, slots) in names.items():
+    r = a[k][a[k][:, 0] > 0]
+    if not len(r):
+        continue
+    k0 = r[:, 0].min()
+    line = [f"{nm}: {len(r)} workgroups, first starts {(k0 - t0_all) * tick:.1f} us after the scan's first stamp"]
+    for s, sn in enumerate(slots):
+        v = (r[:, s] - k0) * tick
+        v = v[r[:, s] > 0]
+        line.append(f"  {sn:24s} min {v.min():6.1f}  median {np.median(v):6.1f}  p90 {np.percentile(v, 90):6.1f}  max {v.max():6.1f}  (us after the kernel's first workgroup)")
+    if len(slots) > 2:
+        for s in range(1, len(slots)):
+            ok = (r[:, s] > 0) & (r[:, s - 1] > 0)
+            d = (r[ok, s] - r[ok, s - 1]) * tick
+            line.append(f"  phase {slots[s - 1]} -> {slots[s]}: median {np.median(d):.1f} us, p90 {np.percentile(d, 90):.1f}, max {d.max():.1f}")
+    print("\n".join(line))
+le.close()
