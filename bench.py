@@ -389,6 +389,28 @@ def bench_single(args):
         # ... and what the link gives those 2.15 MB per frame at best (pinned -> device, one stream per image, nothing else on the
         # device), measured in this run: the ceiling of any per-frame host hand-over
         link = hipmem.h2d_link_rate()
+        # ... and what it gives them NEXT TO the kernels of resident frames (a second context fusing the stream on another host
+        # thread meanwhile): the transfers of a host-fed loop share HBM and the fabric with the integration of the frame before
+        import threading
+
+        le2 = make_engine(hip, params, Kc)
+        res.run(le2, 0, W)
+        le2.sync()
+        stop_load = [False]
+
+        def _load():
+            while not stop_load[0]:
+                res.run(le2, W, total)
+
+        th = threading.Thread(target=_load)
+        th.start()
+        time.sleep(0.003)
+        link_loaded = hipmem.h2d_link_rate(frames=200)
+        stop_load[0] = True
+        th.join()
+        le2.sync()
+        le2.close()
+        link["gbs_next_to_resident_frames"] = link_loaded["gbs"]
 
     # Launches that carry events switch the process's queues to their profiling mode, which slows every later dispatch (37.8-43.7 us
     # per spherical image behind the profiled extraction where tools/bench_spherical.py measures 27-29 in a process that never
@@ -717,6 +739,8 @@ def bench_single(args):
         "lidar": lidar, "splat": splat, "pcie_inclusive_frames_per_s": pcie_fps,
         "h2d_link_gbs": link["gbs"] if link else None, "h2d_link": link,
         "pcie_inclusive_frac_of_link": (pcie_fps * link["bytes_per_frame"] / 1e9 / link["gbs"]) if link and pcie_fps else None,
+        "h2d_link_gbs_under_load": link.get("gbs_next_to_resident_frames") if link else None,
+        "pcie_inclusive_frac_of_link_under_load": (pcie_fps * link["bytes_per_frame"] / 1e9 / link["gbs_next_to_resident_frames"]) if link and pcie_fps and link.get("gbs_next_to_resident_frames") else None,
         "periodic_frames": periodic, "spherical_images": spherical,
     }
     emit(out)

@@ -144,52 +144,10 @@ struct HostVec {
   }
 };
 
-// ---- frames from host memory: the runtime calls of a frame on a thread of their own (round 5) -----------------------------
-// A frame that arrives as host images costs the caller ~63 us: two staging copies (~25-35 us with the copy pool) and ~25 us
-// inside the runtime — two hipMemcpyAsync + event records, two stream waits, two launches, the frame mark —, more than the
-// link needs for the 2.15 MB (43 us idle) or the GPU for the frame (41 us): the caller's thread bounds the path.  With
-// MRH_ASYNC_FRAMES (default on) the four per-frame entry points — mrh_set_pose, mrh_upload_depth, mrh_upload_rgb,
-// mrh_integrate — do on the caller's thread only what must happen before they return (argument checks, the copy of the image
-// into pinned staging: the caller's buffer is free on return) and hand the rest, as a command, to ONE worker thread per
-// context, which executes the commands in order: everything that touches the context's state or the runtime for a frame
-// happens on that thread, in program order, exactly as the caller's thread would have done it.  Every other entry point waits
-// for the queue to drain first (frames_drain, from ensure_device), so nothing outside a frame loop ever runs next to the
-// worker; an error of a queued command is returned by the next call.  Tile-sharded contexts (their starve frames stop for the
-// host's reduction) and contexts fed with device pointers never use the worker.
-struct FrameCmd {
-  int kind;  // 0 pose, 1 upload, 2 integrate, 3 stop
-  float R[9], t[3];
-  int which, rows, cols, n_inval;
-  void* stage;
-  size_t bytes;
-  hipEvent_t stage_ev;
-};
-struct FrameWorker {
-  static constexpr uint64_t kQ = 16;
-  FrameCmd q[kQ];
-  std::atomic<uint64_t> pushed{0}, done{0};  // tickets: command t lives in q[t % kQ]
-  std::thread th;
-  std::mutex sleep_m;
-  std::condition_variable cv;
-  std::atomic<int> sleeping{0};
-  std::atomic<int> rc{0};   // first error of a queued command (sticky until a call returns it)
-  std::string err;          // its message (written by the worker before rc, read by the caller after it)
-  struct Stage { void* h = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; uint64_t ticket = 0; };
-  Stage stage[2][4];        // pinned staging of the caller's thread: [depth | rgb][ring of four]
-  int next_stage[2] = {0, 0};
-  bool on = false;          // caller's thread: the frame calls are being forwarded (until the next drain)
-  int sh_rows[2] = {0, 0}, sh_cols[2] = {0, 0};  // what the queued uploads will leave behind: mrh_integrate validates
-  bool sh_have[2] = {false, false};              // before it forwards, so that argument errors are still returned at once
-};
-
 }  // namespace
 
 struct mrh_ctx {
   mrh_params p;
-  FrameWorker* fw = nullptr;
-  int async_frames = 1;                     // MRH_ASYNC_FRAMES=0: every call runs on the caller's thread
-  std::mutex peek_m;                        // the frame marks (worker) against the non-blocking peeks (caller)
-  std::atomic<int> dirty_from_peek{0};      // mrh_peek_error_flags saw ERR_POOL: census before the next frame (folded in by integrate_frame)
   int device = 0;
   hipStream_t stream = nullptr;
   Cam cam;
@@ -394,8 +352,6 @@ struct mrh_ctx {
   std::string err;
 };
 
-static int frames_drain(mrh_ctx* c);                          // the frame worker (defined with the upload path)
-static int frames_push(mrh_ctx* c, const FrameCmd& cmd);
 static int comm_allreduce_zbuf(mrh_ctx* c, mrh::u64* buf, size_t n);  // mrh_comm.h
 static void comm_release(mrh_ctx* c);
 static bool comm_matches_sharding(const mrh_ctx* c, int* comm_rank, int* comm_world);
@@ -597,10 +553,6 @@ int maintain_table(mrh_ctx* c, bool force_census) {
 
 int ensure_device(mrh_ctx* c, const char* who) {
   if (!c) return MRH_ERR_INVALID_ARG;
-  {  // whatever the frame worker still has queued happens first; an error of a queued command is this call's error
-    const int arc = frames_drain(c);
-    if (arc) return arc;
-  }
   hipError_t e = hipSetDevice(c->device);
   if (e != hipSuccess) return fail(c, MRH_ERR_DEVICE, "%s: hipSetDevice failed: %s", who, hipGetErrorString(e));
   return MRH_OK;
@@ -1329,7 +1281,6 @@ int mrh_create(const mrh_params* p, mrh_ctx** out) {
     const int v = atoi(g);
     if (v > 0 && v <= 32768) c->fused_grid = v;
   }
-  if (const char* g = getenv("MRH_ASYNC_FRAMES")) c->async_frames = atoi(g) ? 1 : 0;
   if (const char* g = getenv("MRH_PIPE")) c->pipe = atoi(g) ? 1 : 0;
   if (const char* g = getenv("MRH_PIPE_GRID")) { const int v = atoi(g); if (v > 0 && v <= 32768) c->pipe_grid = v; }
   if (const char* g = getenv("MRH_PIPE_DEFER")) { const int v = atoi(g); if (v >= 1 && v < mrh_ctx::kPendMax) c->pipe_defer = v; }
@@ -1388,21 +1339,6 @@ int mrh_destroy(mrh_ctx* c) {
     }
   }
 #endif
-  if (c->fw) {  // the frame worker finishes its queue and leaves
-    (void) frames_drain(c);
-    FrameCmd stop{};
-    stop.kind = 3;
-    (void) frames_push(c, stop);
-    if (c->fw->th.joinable()) c->fw->th.join();
-    (void) hipSetDevice(c->device);
-    for (auto& kind : c->fw->stage)
-      for (FrameWorker::Stage& st : kind) {
-        if (st.h) (void) hipHostFree(st.h);
-        if (st.ev) (void) hipEventDestroy(st.ev);
-      }
-    delete c->fw;
-    c->fw = nullptr;
-  }
   widen_quiesce();  // the result arrays are about to be unmapped
   if (getenv("MRH_DEBUG") || getenv("MRH_WIDEN_REPORT"))
     fprintf(stderr, "[mrhash_hip] widening: %llu chunks redone by the calling thread (their helper had not finished 40 us after the chunk landed)\n", (unsigned long long) widen_redone());
@@ -1422,7 +1358,6 @@ int mrh_reset(mrh_ctx* c) {
 
 int mrh_set_camera(mrh_ctx* c, float fx, float fy, float cx, float cy, int rows, int cols, float min_depth, float max_depth, int model) {
   if (!c) return MRH_ERR_INVALID_ARG;
-  { const int arc = frames_drain(c); if (arc) return arc; }  // queued frames see the camera they were issued under
   if (rows <= 0 || cols <= 0 || (model != MRH_CAMERA_PINHOLE && model != MRH_CAMERA_SPHERICAL))
     return fail(c, MRH_ERR_INVALID_ARG, "mrh_set_camera: bad rows/cols/model");
   Cam& k = c->cam;
@@ -1439,19 +1374,8 @@ int mrh_set_camera(mrh_ctx* c, float fx, float fy, float cx, float cy, int rows,
   return MRH_OK;
 }
 
-static int set_pose_now(mrh_ctx* c, const float R[9], const float t[3]);
 int mrh_set_pose(mrh_ctx* c, const float R[9], const float t[3]) {
   if (!c || !R || !t) return MRH_ERR_INVALID_ARG;
-  if (c->fw && c->fw->on) {  // inside a loop of host-fed frames: the pose takes its place in the worker's queue
-    FrameCmd cmd{};
-    cmd.kind = 0;
-    memcpy(cmd.R, R, 36);
-    memcpy(cmd.t, t, 12);
-    return frames_push(c, cmd);
-  }
-  return set_pose_now(c, R, t);
-}
-static int set_pose_now(mrh_ctx* c, const float R[9], const float t[3]) {
   Cam& k = c->cam;
   memcpy(k.R, R, 36);
   memcpy(k.t, t, 12);
@@ -1841,7 +1765,6 @@ int mark_frame(mrh_ctx* c) {
   if (c->up_depth.cur >= 0 && c->d_depth == c->up_depth.s[c->up_depth.cur].d) used[0] = &c->up_depth.s[c->up_depth.cur];
   if (c->up_rgb.cur >= 0 && c->d_rgb == c->up_rgb.s[c->up_rgb.cur].d) used[1] = &c->up_rgb.s[c->up_rgb.cur];
   if (!used[0] && !used[1] && !c->peek_enabled) return MRH_OK;
-  std::lock_guard<std::mutex> peek_lock(c->peek_m);  // the non-blocking peeks may run on the caller's thread next to the frame worker
   const uint64_t seq = c->frame_seq++;
   if (!c->frame_done[0])
     for (hipEvent_t& e : c->frame_done) HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -1872,164 +1795,7 @@ int mark_frame(mrh_ctx* c) {
 
 }  // namespace
 
-static int integrate_frame(mrh_ctx* c, int n_frames_invalidate);
-extern "C++" {
-namespace {
-// one staged image (pinned memory of the frame worker's caller side) into the next device slot of its ring: upload_image without
-// the staging copy; `stage_ev` is recorded behind the transfer for the caller's reuse of the staging buffer
-int upload_staged(mrh_ctx* c, UpRing& ring, const void* staged, const size_t bytes, const void** out_dev, hipEvent_t stage_ev) {
-  if (!c->copy_ready) {
-    for (UpRing* r : {&c->up_depth, &c->up_rgb}) HIP_TRY(c, hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking));
-    for (hipEvent_t& e : c->frame_done) HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    c->copy_ready = true;
-  }
-  const int next = (ring.cur + 1) % 3;
-  UpSlot& u = ring.s[next];
-  if (u.last_seq) HIP_TRY(c, hipEventSynchronize(c->frame_done[u.last_seq % 8]));
-  if (u.copied_rec) HIP_TRY(c, hipEventSynchronize(u.copied));
-  if (bytes > u.cap) {
-    if (u.h) HIP_TRY(c, hipHostFree(u.h));
-    if (u.d) HIP_TRY(c, hipFree(u.d));
-    u.h = u.d = nullptr; u.cap = 0;
-    HIP_TRY(c, hipHostMalloc(&u.h, bytes, hipHostMallocDefault));  // (unused on this path; the slot stays usable by upload_image)
-    HIP_TRY(c, hipMalloc(&u.d, bytes));
-    u.cap = bytes;
-    if (!u.copied) HIP_TRY(c, hipEventCreateWithFlags(&u.copied, hipEventDisableTiming));
-  }
-  HIP_TRY(c, hipMemcpyAsync(u.d, staged, bytes, hipMemcpyHostToDevice, ring.stream));
-  HIP_TRY(c, hipEventRecord(u.copied, ring.stream));
-  HIP_TRY(c, hipEventRecord(stage_ev, ring.stream));
-  u.copied_rec = true;
-  u.last_seq = 0;
-  ring.last_copy = u.copied;
-  ring.waited[0] = ring.waited[1] = false;
-  ring.cur = next;
-  *out_dev = u.d;
-  return MRH_OK;
-}
-
-int frames_exec(mrh_ctx* c, const FrameCmd& cmd) {
-  if (cmd.kind == 0) return set_pose_now(c, cmd.R, cmd.t);
-  if (cmd.kind == 1) {
-    const void* dev = nullptr;
-    const int rc = upload_staged(c, cmd.which ? c->up_rgb : c->up_depth, cmd.stage, cmd.bytes, &dev, cmd.stage_ev);
-    if (rc) return rc;
-    if (cmd.which) { c->d_rgb = (const uint8_t*) dev; c->rgb_rows = cmd.rows; c->rgb_cols = cmd.cols; }
-    else { c->d_depth = (const float*) dev; c->depth_rows = cmd.rows; c->depth_cols = cmd.cols; }
-    return MRH_OK;
-  }
-  if (cmd.kind == 2) {
-    const int rc = integrate_frame(c, cmd.n_inval);
-    if (rc < 0) return rc;
-    return mark_frame(c);
-  }
-  return MRH_OK;
-}
-
-void frames_main(mrh_ctx* c) {
-  FrameWorker* w = c->fw;
-  (void) hipSetDevice(c->device);
-  for (uint64_t next = 1;; next++) {
-    const auto t0 = std::chrono::steady_clock::now();
-    int spins = 0;
-    while (w->pushed.load(std::memory_order_acquire) < next) {
-      MRH_CPU_RELAX();
-      if ((++spins & 255) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(400)) {
-        std::unique_lock<std::mutex> lk(w->sleep_m);
-        w->sleeping.store(1, std::memory_order_seq_cst);
-        w->cv.wait(lk, [&] { return w->pushed.load(std::memory_order_acquire) >= next; });
-        w->sleeping.store(0, std::memory_order_seq_cst);
-      }
-    }
-    const FrameCmd cmd = w->q[next % FrameWorker::kQ];
-    if (cmd.kind == 3) { w->done.store(next, std::memory_order_release); return; }
-    const int rc = frames_exec(c, cmd);
-    if (rc < 0 && w->rc.load(std::memory_order_relaxed) == 0) {
-      w->err = c->err;  // before rc: whoever sees rc != 0 reads a complete message
-      w->rc.store(rc, std::memory_order_release);
-    }
-    w->done.store(next, std::memory_order_release);
-  }
-}
-
-// may the per-frame calls of this context go through the worker?
-bool frames_async(const mrh_ctx* c) { return c->async_frames && c->p.shard_count <= 1 && !c->profile && !c->pending && !c->comm; }
-
-// the error a queued command left behind, returned once
-int frames_take_error(mrh_ctx* c) {
-  FrameWorker* w = c->fw;
-  const int rc = w->rc.load(std::memory_order_acquire);
-  if (!rc) return MRH_OK;
-  c->err = w->err;
-  w->rc.store(0, std::memory_order_release);
-  return rc;
-}
-}  // namespace
-
-// every queued frame command has been executed; from here on (until the next forwarded upload) the caller's thread owns the context
-static int frames_drain(mrh_ctx* c) {
-  FrameWorker* w = c->fw;
-  if (!w) return MRH_OK;
-  const uint64_t last = w->pushed.load(std::memory_order_relaxed);
-  while (w->done.load(std::memory_order_acquire) < last) MRH_CPU_RELAX();
-  w->on = false;
-  return frames_take_error(c);
-}
-
-static int frames_push(mrh_ctx* c, const FrameCmd& cmd) {
-  FrameWorker* w = c->fw;
-  if (w->rc.load(std::memory_order_acquire)) return frames_drain(c);  // a queued command failed: this call reports it
-  const uint64_t t = w->pushed.load(std::memory_order_relaxed) + 1;
-  while (t - w->done.load(std::memory_order_acquire) >= FrameWorker::kQ) MRH_CPU_RELAX();  // queue full: the worker is kQ commands behind
-  w->q[t % FrameWorker::kQ] = cmd;
-  w->pushed.store(t, std::memory_order_seq_cst);
-  if (w->sleeping.load(std::memory_order_seq_cst)) { std::lock_guard<std::mutex> lk(w->sleep_m); w->cv.notify_one(); }
-  return (int) 0;
-}
-
-namespace {
-int frames_upload(mrh_ctx* c, const int which, const void* src, const int rows, const int cols, const size_t bytes) {
-  if (hipSetDevice(c->device) != hipSuccess) { (void) frames_drain(c); return fail(c, MRH_ERR_DEVICE, "mrh_upload: hipSetDevice failed"); }
-  if (!c->fw) {
-    c->fw = new FrameWorker();
-    c->fw->th = std::thread([c] { frames_main(c); });
-  }
-  FrameWorker* w = c->fw;
-  if (!w->on) {  // the queue is empty and the worker idle (the last call drained): the shadows start from the context's state
-    w->sh_have[0] = c->d_depth != nullptr; w->sh_rows[0] = c->depth_rows; w->sh_cols[0] = c->depth_cols;
-    w->sh_have[1] = c->d_rgb != nullptr; w->sh_rows[1] = c->rgb_rows; w->sh_cols[1] = c->rgb_cols;
-    w->on = true;
-  }
-  FrameWorker::Stage& st = w->stage[which][w->next_stage[which]];
-  w->next_stage[which] = (w->next_stage[which] + 1) % 4;
-  if (st.ticket) {  // its last transfer has been issued (the worker got that far) and has left the buffer
-    while (w->done.load(std::memory_order_acquire) < st.ticket) MRH_CPU_RELAX();
-    if (hipEventSynchronize(st.ev) != hipSuccess) { (void) hipGetLastError(); (void) frames_drain(c); return fail(c, MRH_ERR_DEVICE, "mrh_upload: staging event"); }
-  }
-  if (bytes > st.cap) {
-    if (st.h) (void) hipHostFree(st.h);
-    st.h = nullptr; st.cap = 0;
-    if (hipHostMalloc(&st.h, bytes, hipHostMallocDefault) != hipSuccess || (!st.ev && hipEventCreateWithFlags(&st.ev, hipEventDisableTiming) != hipSuccess)) {
-      (void) hipGetLastError();
-      (void) frames_drain(c);
-      return fail(c, MRH_ERR_DEVICE, "mrh_upload: pinned staging of %zu bytes", bytes);
-    }
-    st.cap = bytes;
-  }
-  copy_to_staging(st.h, src, bytes);
-  FrameCmd cmd{};
-  cmd.kind = 1; cmd.which = which; cmd.rows = rows; cmd.cols = cols; cmd.stage = st.h; cmd.bytes = bytes; cmd.stage_ev = st.ev;
-  const int rc = frames_push(c, cmd);
-  if (rc) return rc;
-  st.ticket = w->pushed.load(std::memory_order_relaxed);
-  w->sh_have[which] = true; w->sh_rows[which] = rows; w->sh_cols[which] = cols;
-  return MRH_OK;
-}
-}  // namespace
-}  // extern "C++"
-
 int mrh_upload_depth(mrh_ctx* c, const float* depth, int rows, int cols) {
-  if (c && depth && rows > 0 && cols > 0 && frames_async(c)) return frames_upload(c, 0, depth, rows, cols, (size_t) rows * cols * sizeof(float));
   int rc = ensure_device(c, "mrh_upload_depth");
   if (rc) return rc;
   if (!depth || rows <= 0 || cols <= 0) return fail(c, MRH_ERR_INVALID_ARG, "mrh_upload_depth: bad argument");
@@ -2042,7 +1808,6 @@ int mrh_upload_depth(mrh_ctx* c, const float* depth, int rows, int cols) {
 }
 
 int mrh_upload_rgb(mrh_ctx* c, const uint8_t* rgb, int rows, int cols) {
-  if (c && rgb && rows > 0 && cols > 0 && frames_async(c)) return frames_upload(c, 1, rgb, rows, cols, (size_t) rows * cols * 3);
   int rc = ensure_device(c, "mrh_upload_rgb");
   if (rc) return rc;
   if (!rgb || rows <= 0 || cols <= 0) return fail(c, MRH_ERR_INVALID_ARG, "mrh_upload_rgb: bad argument");
@@ -2056,7 +1821,6 @@ int mrh_upload_rgb(mrh_ctx* c, const uint8_t* rgb, int rows, int cols) {
 
 int mrh_set_depth_device(mrh_ctx* c, const float* d_depth, int rows, int cols) {
   if (!c || !d_depth || rows <= 0 || cols <= 0) return fail(c, MRH_ERR_INVALID_ARG, "mrh_set_depth_device: bad argument");
-  { const int arc = frames_drain(c); if (arc) return arc; }
   c->d_depth = d_depth; c->depth_rows = rows; c->depth_cols = cols;
   c->up_depth.cur = -1;
   return MRH_OK;
@@ -2064,7 +1828,6 @@ int mrh_set_depth_device(mrh_ctx* c, const float* d_depth, int rows, int cols) {
 
 int mrh_set_rgb_device(mrh_ctx* c, const uint8_t* d_rgb, int rows, int cols) {
   if (!c || !d_rgb || rows <= 0 || cols <= 0) return fail(c, MRH_ERR_INVALID_ARG, "mrh_set_rgb_device: bad argument");
-  { const int arc = frames_drain(c); if (arc) return arc; }
   c->d_rgb = d_rgb; c->rgb_rows = rows; c->rgb_cols = cols;
   c->up_rgb.cur = -1;
   return MRH_OK;
@@ -2074,19 +1837,6 @@ int mrh_set_rgb_device(mrh_ctx* c, const uint8_t* d_rgb, int rows, int cols) {
 static int integrate_frame(mrh_ctx* c, int n_frames_invalidate);
 
 int mrh_integrate(mrh_ctx* c, int n_frames_invalidate) {
-  if (c && c->fw && c->fw->on && frames_async(c)) {
-    // a frame of host images: forwarded if what integrate_frame would reject can be ruled out here (the camera and the states
-    // below only change through calls that drain the queue; the image shapes are those the queued uploads will leave)
-    const FrameWorker* w = c->fw;
-    const Cam& k = c->cam;
-    const bool ok = !c->pending && !c->halo_upper && c->has_camera && w->sh_have[0] && w->sh_have[1] && w->sh_rows[0] == k.rows && w->sh_cols[0] == k.cols &&
-                    w->sh_rows[1] == k.rows && w->sh_cols[1] == k.cols;
-    if (ok) {
-      FrameCmd cmd{};
-      cmd.kind = 2; cmd.n_inval = n_frames_invalidate;
-      return frames_push(c, cmd);
-    }
-  }
   int rc = ensure_device(c, "mrh_integrate");
   if (rc) return rc;
   rc = integrate_frame(c, n_frames_invalidate);
@@ -2156,7 +1906,6 @@ int launch_pending(mrh_ctx* c, const bool count_skips = false) {
   if (pb.profile) c->ev_pending.push_back(pb.ev);
   if (pb.free_) c->zombies_possible = true;
   if (pb.report_seq && c->peek_enabled) {  // the frame's pool report (mark_frame left it to this launch): behind its integration
-    std::lock_guard<std::mutex> peek_lock(c->peek_m);
     k_report<<<1, 64, 0, s>>>(&c->tab.ctr[CTR_HEAP_FINE], c->h_peek + 8 * (pb.report_seq % 8));
     HIP_TRY(c, hipEventRecord(c->peek_done[pb.report_seq % 8], s));
     c->peek_seq[pb.report_seq % 8] = pb.report_seq;  // from here on the mark exists for the peeks
@@ -2379,7 +2128,6 @@ int integrate_lazy(mrh_ctx* c, const int max_num_frames, const bool starve_now) 
 
 static int integrate_frame(mrh_ctx* c, int n_frames_invalidate) {
   int rc = MRH_OK;
-  if (c->dirty_from_peek.exchange(0, std::memory_order_relaxed)) c->table_dirty = true;  // mrh_peek_error_flags reported ERR_POOL
   if (c->pending) return fail(c, MRH_ERR_STATE, "mrh_integrate: an exchange is pending (call mrh_integrate_resume)");
   if (c->halo_upper) return fail(c, MRH_ERR_STATE, "mrh_integrate: halo blocks of other shards are present (call mrh_drop_blocks(MRH_DROP_HALO) after the extraction)");
   if (!c->has_camera) return fail(c, MRH_ERR_STATE, "mrh_integrate: set_camera has not been called");
@@ -2941,7 +2689,6 @@ int mrh_integrate_resume(mrh_ctx* c) {
 }
 
 int mrh_exchange_buffer(mrh_ctx* c, void** out_ptr, uint64_t* out_n, int* out_is_device) {
-  if (c) { const int arc = frames_drain(c); if (arc) return arc; }  // not next to the frame worker
   if (!c || !out_ptr || !out_n) return MRH_ERR_INVALID_ARG;
   if (c->pending == 0) return fail(c, MRH_ERR_STATE, "mrh_exchange_buffer: no exchange is pending");
   const size_t npix = (size_t) c->cam.rows * c->cam.cols;
@@ -3053,7 +2800,6 @@ int mrh_splat_seeds(mrh_ctx* c, float qtree_thresh, int qtree_min_pixel_size, co
 }
 
 int mrh_get_qtree_leaves(mrh_ctx* c, const mrh_qtree_leaf** out, uint64_t* out_n) {
-  if (c) { const int arc = frames_drain(c); if (arc) return arc; }  // not next to the frame worker
   if (!c || !out || !out_n) return MRH_ERR_INVALID_ARG;
   if (!c->qt_leaves_on_host) {
     c->qt_leaves.resize(c->qt_n_leaves);
@@ -3077,72 +2823,53 @@ int mrh_get_free_blocks(mrh_ctx* c, int64_t* out_free_fine, int64_t* out_free_co
   return MRH_OK;
 }
 
-// The two peeks read what the frame marks left behind (frame_seq, peek_seq, the report events, the pinned reports) under
-// peek_m and never wait for the device; inside a loop of host-fed frames they do not wait for the frame worker either.
-static int peek_prologue(mrh_ctx* c, const char* who, bool* just_enabled) {
-  *just_enabled = false;
-  if (!c) return MRH_ERR_INVALID_ARG;
-  if (c->peek_enabled && c->fw && c->fw->on) return MRH_OK;  // the worker owns the context: look, do not touch
-  const int rc = ensure_device(c, who);
+int mrh_peek_free_blocks(mrh_ctx* c, int64_t* out_free_fine, int64_t* out_free_coarse, uint64_t* out_frames_behind) {
+  int rc = ensure_device(c, "mrh_peek_free_blocks");
   if (rc) return rc;
-  if (!c->peek_enabled) {  // first call: reports start with the next frame
+  if (!c->peek_enabled) {  // first call: reports start with the next frame; answer this one the blocking way
     HIP_TRY(c, hipHostMalloc((void**) &c->h_peek, 64 * sizeof(int), hipHostMallocDefault));
     memset(c->h_peek, 0, 64 * sizeof(int));
     c->peek_enabled = true;
-    *just_enabled = true;
   }
-  return MRH_OK;
-}
-
-int mrh_peek_free_blocks(mrh_ctx* c, int64_t* out_free_fine, int64_t* out_free_coarse, uint64_t* out_frames_behind) {
-  bool fresh = false;
-  int rc = peek_prologue(c, "mrh_peek_free_blocks", &fresh);
-  if (rc) return rc;
-  hipError_t bad = hipSuccess;
-  {
-    std::lock_guard<std::mutex> lk(c->peek_m);
-    for (uint64_t back = 1; back <= 8 && back < c->frame_seq; back++) {
-      const uint64_t seq = c->frame_seq - back;
-      if (c->peek_seq[seq % 8] != seq) continue;
-      const hipError_t q = hipEventQuery(c->peek_done[seq % 8]);
-      if (q == hipErrorNotReady) continue;
-      if (q != hipSuccess) { bad = q; break; }
-      if (out_free_fine) *out_free_fine = (int64_t) c->h_peek[8 * (seq % 8)] + 1;
-      if (out_free_coarse) *out_free_coarse = (int64_t) c->h_peek[8 * (seq % 8) + 1] + 1;
-      if (out_frames_behind) *out_frames_behind = back - 1;
-      return MRH_OK;
-    }
+  for (uint64_t back = 1; back <= 8 && back < c->frame_seq; back++) {
+    const uint64_t seq = c->frame_seq - back;
+    if (c->peek_seq[seq % 8] != seq) continue;
+    const hipError_t q = hipEventQuery(c->peek_done[seq % 8]);
+    if (q == hipErrorNotReady) continue;
+    if (q != hipSuccess) return fail(c, MRH_ERR_DEVICE, "mrh_peek_free_blocks: %s", hipGetErrorString(q));
+    if (c->peek_seq[seq % 8] != seq) continue;
+    if (out_free_fine) *out_free_fine = (int64_t) c->h_peek[8 * (seq % 8)] + 1;
+    if (out_free_coarse) *out_free_coarse = (int64_t) c->h_peek[8 * (seq % 8) + 1] + 1;
+    if (out_frames_behind) *out_frames_behind = back - 1;
+    return MRH_OK;
   }
-  if (bad != hipSuccess) { (void) frames_drain(c); return fail(c, MRH_ERR_DEVICE, "mrh_peek_free_blocks: %s", hipGetErrorString(bad)); }
   if (out_frames_behind) *out_frames_behind = 0;
-  return mrh_get_free_blocks(c, out_free_fine, out_free_coarse);  // no report yet: the blocking way (waits for the worker, too)
+  return mrh_get_free_blocks(c, out_free_fine, out_free_coarse);
 }
 
 int mrh_peek_error_flags(mrh_ctx* c, uint32_t* out_new_flags) {
+  int rc = ensure_device(c, "mrh_peek_error_flags");
+  if (rc) return rc;
   if (!out_new_flags) return MRH_ERR_INVALID_ARG;
   *out_new_flags = 0;
-  bool fresh = false;
-  int rc = peek_prologue(c, "mrh_peek_error_flags", &fresh);
-  if (rc) return rc;
-  if (fresh) return MRH_OK;
-  hipError_t bad = hipSuccess;
-  {
-    std::lock_guard<std::mutex> lk(c->peek_m);
-    for (uint64_t back = 1; back <= 8 && back < c->frame_seq; back++) {
-      const uint64_t seq = c->frame_seq - back;
-      if (c->peek_seq[seq % 8] != seq) continue;
-      const hipError_t q = hipEventQuery(c->peek_done[seq % 8]);
-      if (q == hipErrorNotReady) continue;
-      if (q != hipSuccess) { bad = q; break; }
-      const u32 flags = (u32) c->h_peek[8 * (seq % 8) + CTR_ERROR];
-      *out_new_flags = flags & ~c->flags_peeked;
-      // as in take_device_flags: the keys without storage are dropped before the next frame (integrate_frame folds the request in)
-      if (*out_new_flags & ERR_POOL) c->dirty_from_peek.store(1, std::memory_order_relaxed);
-      c->flags_peeked = flags;  // the device clears its flags only in mrh_sync: what is set now has been reported
-      return MRH_OK;
-    }
+  if (!c->peek_enabled) {  // reports start with the next frame
+    HIP_TRY(c, hipHostMalloc((void**) &c->h_peek, 64 * sizeof(int), hipHostMallocDefault));
+    memset(c->h_peek, 0, 64 * sizeof(int));
+    c->peek_enabled = true;
+    return MRH_OK;
   }
-  if (bad != hipSuccess) { (void) frames_drain(c); return fail(c, MRH_ERR_DEVICE, "mrh_peek_error_flags: %s", hipGetErrorString(bad)); }
+  for (uint64_t back = 1; back <= 8 && back < c->frame_seq; back++) {
+    const uint64_t seq = c->frame_seq - back;
+    if (c->peek_seq[seq % 8] != seq) continue;
+    const hipError_t q = hipEventQuery(c->peek_done[seq % 8]);
+    if (q == hipErrorNotReady) continue;
+    if (q != hipSuccess) return fail(c, MRH_ERR_DEVICE, "mrh_peek_error_flags: %s", hipGetErrorString(q));
+    const u32 flags = (u32) c->h_peek[8 * (seq % 8) + CTR_ERROR];
+    *out_new_flags = flags & ~c->flags_peeked;
+    if (*out_new_flags & ERR_POOL) c->table_dirty = true;  // as in take_device_flags: drop the keys without storage before the next frame
+    c->flags_peeked = flags;  // the device clears its flags only in mrh_sync: what is set now has been reported
+    return MRH_OK;
+  }
   return MRH_OK;
 }
 
@@ -3438,7 +3165,6 @@ int mrh_extract_triangles(mrh_ctx* c, const mrh_triangle** out_tris, uint64_t* o
 // repeated faces keeping the first" are order-preserving filters, so applying them to a prefix first changes nothing
 // (tests/test_geowrapper_gpu.py compares with the oracle, which restates the incremental form literally).
 int mrh_mesh_merge_begin(mrh_ctx* c) {
-  if (c) { const int arc = frames_drain(c); if (arc) return arc; }  // not next to the frame worker
   if (!c) return MRH_ERR_INVALID_ARG;
   c->merge_on = true;
   c->acc_n = 0;
@@ -3468,7 +3194,6 @@ int mrh_mesh_merge_end(mrh_ctx* c, uint64_t* out_total_triangles) {
 }
 
 int mrh_extract_mesh(mrh_ctx* c, const double** v, uint64_t* nv, const int32_t** f, uint64_t* nf, const double** col) {
-  if (c) { const int arc = frames_drain(c); if (arc) return arc; }  // not next to the frame worker
   if (!c || !v || !nv || !f || !nf || !col) return MRH_ERR_INVALID_ARG;
   *v = c->V.empty() ? nullptr : c->V.data();
   *nv = c->V.size() / 3;
@@ -3802,7 +3527,6 @@ int mrh_drop_blocks(mrh_ctx* c, int mode, uint64_t* out_dropped) {
 }
 
 int mrh_get_triangle_blocks(mrh_ctx* c, const mrh_block_desc** out_descs, const uint32_t** out_counts, uint64_t* out_n) {
-  if (c) { const int arc = frames_drain(c); if (arc) return arc; }  // not next to the frame worker
   if (!c || !out_descs || !out_counts || !out_n) return MRH_ERR_INVALID_ARG;
   if (c->tri_dev_n > 0) {  // the list and the counts of the last extraction are still where the kernels left them
     const size_t n = (size_t) c->tri_dev_n;
@@ -3835,7 +3559,6 @@ int mrh_process_triangles(mrh_ctx* c, const mrh_triangle* triangles, uint64_t n)
 }
 
 int mrh_get_triangles_device(mrh_ctx* c, const mrh_triangle** out, uint64_t* out_n, int* out_is_device_memory) {
-  if (c) { const int arc = frames_drain(c); if (arc) return arc; }  // not next to the frame worker
   if (!c || !out || !out_n) return MRH_ERR_INVALID_ARG;
   *out = c->soup_n ? c->d_soup : nullptr;
   *out_n = c->soup_n;

@@ -67,6 +67,7 @@ def main():
     t_enq = time.perf_counter() - t0
     e2.sync()
     t_tot = time.perf_counter() - t0
+    e.close()  # MRH_DEBUG=1: the frame worker's own account of the host-fed loop
     print(f"resident inputs: enqueue {t_enq / (n // 20 * 20) * 1e6:.1f} us per frame of host time, {t_tot / (n // 20 * 20) * 1e6:.1f} us per frame to completion")
 
 

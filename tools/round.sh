@@ -36,7 +36,7 @@ d=json.load(open('$OUT/bench_line_driver_command.json'))
 mc=d.get('mc') or {}; li=d.get('lidar') or {}
 print('value', round(d['value']), 'frac', d['roofline']['frac'], 'traffic', d['roofline'].get('traffic'))
 print('mc extract', mc.get('extract_ms_in_library'), mc.get('extract_ms_runs'), 'k_mc', mc.get('k_mc_count_ms'), mc.get('k_mc_emit_ms'), 'traffic', (mc.get('roofline') or {}).get('traffic'))
-print('lidar us', li.get('us_per_scan'), 'traffic', (li.get('roofline') or {}).get('traffic'), 'pcie', d.get('pcie_inclusive_frames_per_s'), 'link', d.get('h2d_link_gbs'), d.get('pcie_inclusive_frac_of_link'))
+print('lidar us', li.get('us_per_scan'), 'traffic', (li.get('roofline') or {}).get('traffic'), 'pcie', d.get('pcie_inclusive_frames_per_s'), 'link', d.get('h2d_link_gbs'), d.get('pcie_inclusive_frac_of_link'), 'under load', d.get('h2d_link_gbs_under_load'), d.get('pcie_inclusive_frac_of_link_under_load'))
 PY
 fi
 if has stats; then
