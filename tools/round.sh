@@ -1,7 +1,7 @@
 #!/bin/bash
 # The round's evidence from ONE build, on the GPU box (through gpurun).  Every file lands under gpurun_out/<tag>/ with the commit
 # hash of the build in MANIFEST.txt; the files to be judged are copied into profiles/<tag>/ afterwards (tools/README.md).
-#   usage: tools/round.sh <tag> <commit> [sections...]     sections: suite bench stats pmc framepmc stress soak multi trace churn
+#   usage: tools/round.sh <tag> <commit> [sections...]     sections: suite bench default stats pmc framepmc stress soak multi trace churn
 #   default sections: bench stats pmc framepmc
 TAG=${1:-r05}; COMMIT=${2:-unknown}; shift 2
 SECTIONS=${*:-bench stats pmc framepmc}
@@ -38,6 +38,11 @@ print('value', round(d['value']), 'frac', d['roofline']['frac'], 'traffic', d['r
 print('mc extract', mc.get('extract_ms_in_library'), mc.get('extract_ms_runs'), 'k_mc', mc.get('k_mc_count_ms'), mc.get('k_mc_emit_ms'), 'traffic', (mc.get('roofline') or {}).get('traffic'))
 print('lidar us', li.get('us_per_scan'), 'traffic', (li.get('roofline') or {}).get('traffic'), 'pcie', d.get('pcie_inclusive_frames_per_s'), 'link', d.get('h2d_link_gbs'), d.get('pcie_inclusive_frac_of_link'), 'under load', d.get('h2d_link_gbs_under_load'), d.get('pcie_inclusive_frac_of_link_under_load'))
 PY
+fi
+if has default; then  # the bench with no flags (100 steps, 10 warm-up: census and starve frames inside)
+  timeout 1200 python bench.py > $OUT/bench_line_default_run.json 2> $OUT/bench_default.err
+  python -c "import json; d=json.load(open('$OUT/bench_line_default_run.json')); print('default run: value', round(d['value']), 'steps', d['steps'], 'parity', d.get('parity_checked'))"
+  MRH_PIPE=0 timeout 600 python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-pmc --no-cpu --no-extras > $OUT/bench_line_driver_command_serial.json 2>/dev/null
 fi
 if has stats; then
   stats_leg driver_cmd python bench.py --pmc-inner --steps 20 --warmup 5
