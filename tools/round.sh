@@ -1,7 +1,7 @@
 #!/bin/bash
 # The round's evidence from ONE build, on the GPU box (through gpurun).  Every file lands under gpurun_out/<tag>/ with the commit
 # hash of the build in MANIFEST.txt; the files to be judged are copied into profiles/<tag>/ afterwards (tools/README.md).
-#   usage: tools/round.sh <tag> <commit> [sections...]     sections: suite bench default stats pmc framepmc stress soak multi trace churn
+#   usage: tools/round.sh <tag> <commit> [sections...]     sections: suite bench default stats pmc framepmc stress soak multi trace tracebuilds churn
 #   default sections: bench stats pmc framepmc
 TAG=${1:-r05}; COMMIT=${2:-unknown}; shift 2
 SECTIONS=${*:-bench stats pmc framepmc}
@@ -86,6 +86,11 @@ if has churn; then
 fi
 if has trace; then
   STEPS=100 WARM=10 tools/trace_pipe2.sh > $OUT/pipeline_trace_110_frames.txt 2>&1; head -3 $OUT/pipeline_trace_110_frames.txt
+fi
+if has tracebuilds; then  # the two tracing variants of the library (never shipped): LiDAR scan phases, k_front / k_back phases alone on the chip
+  tools/trace_scan.sh > $OUT/scan_trace.txt 2>&1; grep -c workgroups $OUT/scan_trace.txt
+  MRH_PIPE=0 tools/trace_kback.sh 30 2>&1 | grep -v "warning\|hipDeviceSynchronize\|hipMemcpy(h.data\|\^~\|generated when\|amdgpu.ids" > $OUT/kfront_kback_trace_serial.txt; head -8 $OUT/kfront_kback_trace_serial.txt
+  rm -f mrhash_amd/csrc/libmrhash_trace.so
 fi
 if has multi; then
   MRH_BENCH_SHARE_DEVICE=1 timeout 900 python bench.py --gpus 8 --steps 30 --warmup 5 --blocks 65536 > $OUT/bench_8ranks_one_device_gloo.json 2> $OUT/bench_8ranks.err
