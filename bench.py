@@ -379,12 +379,16 @@ def bench_single(args):
             f = frames[i]
             pe.set_pose(f.R, f.t); pe.upload_depth(f.depth); pe.upload_rgb(f.rgb); pe.integrate()
         pe.sync()
+        # at least 100 frames (the timed frames again and again when --steps is smaller): a host-fed loop needs a few frames to
+        # reach its cadence (helper threads awake, rings turning), and 20 frames are 1.3 ms
+        pcie_passes = max(1, -(-100 // K))
         t2 = time.perf_counter()
-        for i in range(W, total):
-            f = frames[i]
-            pe.set_pose(f.R, f.t); pe.upload_depth(f.depth); pe.upload_rgb(f.rgb); pe.integrate()
+        for _ in range(pcie_passes):
+            for i in range(W, total):
+                f = frames[i]
+                pe.set_pose(f.R, f.t); pe.upload_depth(f.depth); pe.upload_rgb(f.rgb); pe.integrate()
         pe.sync()
-        pcie_fps = K / (time.perf_counter() - t2)
+        pcie_fps = pcie_passes * K / (time.perf_counter() - t2)
         pe.close()
         # ... and what the link gives those 2.15 MB per frame at best (pinned -> device, one stream per image, nothing else on the
         # device), measured in this run: the ceiling of any per-frame host hand-over
@@ -736,7 +740,7 @@ def bench_single(args):
                    "hash_table": table},
         "roofline": roof, "roofline_hbm": roof_hbm, "mc": mc, "cpu_baseline": cpu,
         "parity_checked": bool(cpu and cpu["parity"]["ok"]), "blocks": (cpu["parity"]["blocks"] if cpu else None),
-        "lidar": lidar, "splat": splat, "pcie_inclusive_frames_per_s": pcie_fps,
+        "lidar": lidar, "splat": splat, "pcie_inclusive_frames_per_s": pcie_fps, "pcie_inclusive_frames_timed": (max(1, -(-100 // K)) * K) if pcie_fps else None,
         "h2d_link_gbs": link["gbs"] if link else None, "h2d_link": link,
         "pcie_inclusive_frac_of_link": (pcie_fps * link["bytes_per_frame"] / 1e9 / link["gbs"]) if link and pcie_fps else None,
         "h2d_link_gbs_under_load": link.get("gbs_next_to_resident_frames") if link else None,
