@@ -159,6 +159,20 @@ struct mrh_ctx {
   // device buffer — on a second stream, so the copy of frame N+1 overlaps the kernels of frame N; the frame's kernels
   // wait for the newest copy event, a slot is rewritten only after the last frame that read it (frame_done event).
   UpRing up_depth, up_rgb;
+  // A frame of host images is LAUNCHED one mrh_integrate late (round 5): by then its two transfers have completed and the frame's
+  // kernels need no cross-stream wait — a wait that is enqueued while its event is still pending costs the waiting stream ~6 us
+  // of idle time, and a host-fed frame had two of them in front of its 41 us of kernels.  mrh_integrate checks what it can,
+  // keeps {pose, image pointers, ring state} and returns; the next mrh_integrate — or whichever other entry point needs the map
+  // (ensure_ready) — runs the frame first, with those inputs swapped in.  MRH_DEFER_UPLOADS=0 launches at once.
+  struct DeferredFrame {
+    bool on = false;
+    int n_inval = 0;
+    Cam cam;
+    const float* d_depth = nullptr; const uint8_t* d_rgb = nullptr;
+    int depth_rows = 0, depth_cols = 0, rgb_rows = 0, rgb_cols = 0;
+    struct Ring { int cur; hipEvent_t last_copy; bool waited[2]; } ring[2];
+  } deferred;
+  int defer_uploads = 1;
   bool copy_ready = false;             // copy stream and frame marks exist
   hipEvent_t frame_done[8] = {};       // recorded behind the kernels that READ a frame's ring slots (front stream for a pipelined frame): slot reuse
   hipEvent_t peek_done[8] = {};        // recorded on the main stream behind the k_report of a mark: what the non-blocking peeks query
@@ -561,9 +575,12 @@ int strict_point(mrh_ctx* c);
 // every entry point except the per-frame ones (setters, mrh_integrate, the non-blocking peeks): behind the pipelined frames issued
 // so far, the zombies nobody wanted leave the table, so that whatever the call reads, changes or waits for is exactly the map two
 // serial launches per frame would have left
+int flush_deferred(mrh_ctx* c);
 int ensure_ready(mrh_ctx* c, const char* who) {
-  const int rc = ensure_device(c, who);
+  int rc = ensure_device(c, who);
   if (rc) return rc;
+  rc = flush_deferred(c);  // a host-fed frame that mrh_integrate kept back runs before anything else looks at the map
+  if (rc < 0) return rc;
   if (c->stream_front) c->front_needs_sync = true;  // whatever this call does to the map, the front stream must see it before its next launch
   c->flushed_since_frame = true;
   return strict_point(c);
@@ -1281,6 +1298,7 @@ int mrh_create(const mrh_params* p, mrh_ctx** out) {
     const int v = atoi(g);
     if (v > 0 && v <= 32768) c->fused_grid = v;
   }
+  if (const char* g = getenv("MRH_DEFER_UPLOADS")) c->defer_uploads = atoi(g) ? 1 : 0;
   if (const char* g = getenv("MRH_PIPE")) c->pipe = atoi(g) ? 1 : 0;
   if (const char* g = getenv("MRH_PIPE_GRID")) { const int v = atoi(g); if (v > 0 && v <= 32768) c->pipe_grid = v; }
   if (const char* g = getenv("MRH_PIPE_DEFER")) { const int v = atoi(g); if (v >= 1 && v < mrh_ctx::kPendMax) c->pipe_defer = v; }
@@ -1339,6 +1357,7 @@ int mrh_destroy(mrh_ctx* c) {
     }
   }
 #endif
+  if (c->deferred.on) { (void) hipSetDevice(c->device); (void) flush_deferred(c); }  // the frame mrh_integrate accepted last
   widen_quiesce();  // the result arrays are about to be unmapped
   if (getenv("MRH_DEBUG") || getenv("MRH_WIDEN_REPORT"))
     fprintf(stderr, "[mrhash_hip] widening: %llu chunks redone by the calling thread (their helper had not finished 40 us after the chunk landed)\n", (unsigned long long) widen_redone());
@@ -1360,6 +1379,12 @@ int mrh_set_camera(mrh_ctx* c, float fx, float fy, float cx, float cy, int rows,
   if (!c) return MRH_ERR_INVALID_ARG;
   if (rows <= 0 || cols <= 0 || (model != MRH_CAMERA_PINHOLE && model != MRH_CAMERA_SPHERICAL))
     return fail(c, MRH_ERR_INVALID_ARG, "mrh_set_camera: bad rows/cols/model");
+  if (c->deferred.on) {  // a frame kept back by mrh_integrate was issued under the old camera
+    const int frc = ensure_device(c, "mrh_set_camera");
+    if (frc) return frc;
+    const int drc = flush_deferred(c);
+    if (drc < 0) return drc;
+  }
   Cam& k = c->cam;
   // camera.cuh:19-34
   k.fx = fx; k.fy = fy; k.ifx = 1.f / fx; k.ify = 1.f / fy; k.cx = cx; k.cy = cy;
@@ -1719,6 +1744,11 @@ int upload_image(mrh_ctx* c, UpRing& ring, const void* src, const size_t bytes, 
     c->copy_ready = true;
   }
   const int next = (ring.cur + 1) % 3;
+  // a frame that mrh_integrate kept back (flush_deferred) has not marked its slots yet: before the ring comes round to one of them, it runs
+  if (c->deferred.on && next == c->deferred.ring[&ring == &c->up_rgb ? 1 : 0].cur) {
+    const int frc = flush_deferred(c);
+    if (frc < 0) return frc;
+  }
   UpSlot& u = ring.s[next];
   if (u.last_seq) HIP_TRY(c, hipEventSynchronize(c->frame_done[u.last_seq % 8]));  // this mark or a later one of the same stream
   if (u.copied_rec) HIP_TRY(c, hipEventSynchronize(u.copied));
@@ -1753,7 +1783,14 @@ int send_uploads(mrh_ctx* c, hipStream_t reader) {
   const int w = (reader == c->stream) ? 0 : 1;
   for (UpRing* r : {&c->up_depth, &c->up_rgb})
     if (r->last_copy && !r->waited[w]) {
-      HIP_TRY(c, hipStreamWaitEvent(reader, r->last_copy, 0));
+      // a transfer the host already sees complete needs no wait packet (a kernel launched from here on reads what it wrote)
+      const hipError_t q = hipEventQuery(r->last_copy);
+      if (q == hipErrorNotReady) {
+        (void) hipGetLastError();
+        HIP_TRY(c, hipStreamWaitEvent(reader, r->last_copy, 0));
+      } else if (q != hipSuccess) {
+        return fail(c, MRH_ERR_DEVICE, "image transfer: %s", hipGetErrorString(q));
+      }
       r->waited[w] = true;
     }
   return MRH_OK;
@@ -1821,6 +1858,7 @@ int mrh_upload_rgb(mrh_ctx* c, const uint8_t* rgb, int rows, int cols) {
 
 int mrh_set_depth_device(mrh_ctx* c, const float* d_depth, int rows, int cols) {
   if (!c || !d_depth || rows <= 0 || cols <= 0) return fail(c, MRH_ERR_INVALID_ARG, "mrh_set_depth_device: bad argument");
+  if (c->deferred.on) { (void) hipSetDevice(c->device); const int drc = flush_deferred(c); if (drc < 0) return drc; }
   c->d_depth = d_depth; c->depth_rows = rows; c->depth_cols = cols;
   c->up_depth.cur = -1;
   return MRH_OK;
@@ -1828,6 +1866,7 @@ int mrh_set_depth_device(mrh_ctx* c, const float* d_depth, int rows, int cols) {
 
 int mrh_set_rgb_device(mrh_ctx* c, const uint8_t* d_rgb, int rows, int cols) {
   if (!c || !d_rgb || rows <= 0 || cols <= 0) return fail(c, MRH_ERR_INVALID_ARG, "mrh_set_rgb_device: bad argument");
+  if (c->deferred.on) { (void) hipSetDevice(c->device); const int drc = flush_deferred(c); if (drc < 0) return drc; }
   c->d_rgb = d_rgb; c->rgb_rows = rows; c->rgb_cols = cols;
   c->up_rgb.cur = -1;
   return MRH_OK;
@@ -1836,14 +1875,71 @@ int mrh_set_rgb_device(mrh_ctx* c, const uint8_t* d_rgb, int rows, int cols) {
 // voxel_data_structures.cpp:90-110 VoxelContainer::integrate, as one sync-free kernel chain
 static int integrate_frame(mrh_ctx* c, int n_frames_invalidate);
 
+static int integrate_checks(mrh_ctx* c);
 int mrh_integrate(mrh_ctx* c, int n_frames_invalidate) {
   int rc = ensure_device(c, "mrh_integrate");
   if (rc) return rc;
+  rc = flush_deferred(c);  // the frame of the previous call: its images have landed meanwhile
+  if (rc < 0) return rc;
+  // is this a frame of host images whose transfers are still on their way?
+  const bool up_d = c->up_depth.cur >= 0 && c->d_depth == c->up_depth.s[c->up_depth.cur].d && !c->up_depth.waited[0] && !c->up_depth.waited[1];
+  const bool up_c = c->up_rgb.cur >= 0 && c->d_rgb == c->up_rgb.s[c->up_rgb.cur].d && !c->up_rgb.waited[0] && !c->up_rgb.waited[1];
+  if (c->defer_uploads && (up_d || up_c) && c->p.shard_count <= 1 && !c->comm && !c->profile) {
+    rc = integrate_checks(c);  // what can be wrong with the call is reported by the call
+    if (rc) return rc;
+    mrh_ctx::DeferredFrame& d = c->deferred;
+    d.on = true;
+    d.n_inval = n_frames_invalidate;
+    d.cam = c->cam;
+    d.d_depth = c->d_depth; d.d_rgb = c->d_rgb;
+    d.depth_rows = c->depth_rows; d.depth_cols = c->depth_cols; d.rgb_rows = c->rgb_rows; d.rgb_cols = c->rgb_cols;
+    const UpRing* rings[2] = {&c->up_depth, &c->up_rgb};
+    for (int i = 0; i < 2; i++) d.ring[i] = {rings[i]->cur, rings[i]->last_copy, {rings[i]->waited[0], rings[i]->waited[1]}};
+    return MRH_OK;
+  }
   rc = integrate_frame(c, n_frames_invalidate);
   if (rc < 0) return rc;
   const int mrc = mark_frame(c);
   return mrc ? mrc : rc;
 }
+
+extern "C++" {
+namespace {
+// runs the frame mrh_integrate kept back, with the inputs it was issued under; the context's current inputs (the next frame's
+// pose and images may have arrived meanwhile) are put back afterwards
+int flush_deferred(mrh_ctx* c) {
+  mrh_ctx::DeferredFrame& d = c->deferred;
+  if (!d.on) return MRH_OK;
+  d.on = false;
+  UpRing* rings[2] = {&c->up_depth, &c->up_rgb};
+  mrh_ctx::DeferredFrame now;
+  now.cam = c->cam;
+  now.d_depth = c->d_depth; now.d_rgb = c->d_rgb;
+  now.depth_rows = c->depth_rows; now.depth_cols = c->depth_cols; now.rgb_rows = c->rgb_rows; now.rgb_cols = c->rgb_cols;
+  for (int i = 0; i < 2; i++) now.ring[i] = {rings[i]->cur, rings[i]->last_copy, {rings[i]->waited[0], rings[i]->waited[1]}};
+  c->cam = d.cam;
+  c->d_depth = d.d_depth; c->d_rgb = d.d_rgb;
+  c->depth_rows = d.depth_rows; c->depth_cols = d.depth_cols; c->rgb_rows = d.rgb_rows; c->rgb_cols = d.rgb_cols;
+  for (int i = 0; i < 2; i++) { rings[i]->cur = d.ring[i].cur; rings[i]->last_copy = d.ring[i].last_copy; rings[i]->waited[0] = d.ring[i].waited[0]; rings[i]->waited[1] = d.ring[i].waited[1]; }
+  int rc = integrate_frame(c, d.n_inval);
+  if (rc >= 0) {
+    const int mrc = mark_frame(c);
+    if (mrc) rc = mrc;
+  }
+  c->cam = now.cam;
+  c->d_depth = now.d_depth; c->d_rgb = now.d_rgb;
+  c->depth_rows = now.depth_rows; c->depth_cols = now.depth_cols; c->rgb_rows = now.rgb_rows; c->rgb_cols = now.rgb_cols;
+  for (int i = 0; i < 2; i++) {
+    rings[i]->cur = now.ring[i].cur;
+    if (now.ring[i].last_copy != d.ring[i].last_copy) {  // a newer image of this kind has arrived: its transfer has not been waited for
+      rings[i]->last_copy = now.ring[i].last_copy;
+      rings[i]->waited[0] = now.ring[i].waited[0]; rings[i]->waited[1] = now.ring[i].waited[1];
+    }  // else: the same transfer, and what the frame has waited for stays waited for
+  }
+  return rc;
+}
+}  // namespace
+}  // extern "C++"
 
 extern "C++" {
 namespace {
@@ -2126,8 +2222,8 @@ int integrate_lazy(mrh_ctx* c, const int max_num_frames, const bool starve_now) 
 }  // namespace
 }  // extern "C++"
 
-static int integrate_frame(mrh_ctx* c, int n_frames_invalidate) {
-  int rc = MRH_OK;
+// what mrh_integrate rejects before it touches the device
+static int integrate_checks(mrh_ctx* c) {
   if (c->pending) return fail(c, MRH_ERR_STATE, "mrh_integrate: an exchange is pending (call mrh_integrate_resume)");
   if (c->halo_upper) return fail(c, MRH_ERR_STATE, "mrh_integrate: halo blocks of other shards are present (call mrh_drop_blocks(MRH_DROP_HALO) after the extraction)");
   if (!c->has_camera) return fail(c, MRH_ERR_STATE, "mrh_integrate: set_camera has not been called");
@@ -2141,6 +2237,13 @@ static int integrate_frame(mrh_ctx* c, int n_frames_invalidate) {
   const Cam& k = c->cam;
   if (c->depth_rows != k.rows || c->depth_cols != k.cols || c->rgb_rows != k.rows || c->rgb_cols != k.cols)
     return fail(c, MRH_ERR_INVALID_ARG, "mrh_integrate: image shape does not match the camera");
+  return MRH_OK;
+}
+
+static int integrate_frame(mrh_ctx* c, int n_frames_invalidate) {
+  int rc = integrate_checks(c);
+  if (rc) return rc;
+  const Cam& k = c->cam;
   const int max_num_frames = n_frames_invalidate < 0 ? c->p.n_frames_invalidate_voxels : n_frames_invalidate;
   hipStream_t s = c->stream;
   const Tab& t = c->tab;

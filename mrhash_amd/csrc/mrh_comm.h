@@ -412,6 +412,7 @@ int mrh_comm_allgather_bytes(mrh_comm* m, const void* send, uint64_t bytes, void
 
 int mrh_comm_attach(mrh_ctx* c, mrh_comm* m) {
   if (!c) return MRH_ERR_INVALID_ARG;
+  if (c->deferred.on) { (void) hipSetDevice(c->device); const int drc = flush_deferred(c); if (drc < 0) return drc; }
   if (c->pending) return fail(c, MRH_ERR_STATE, "mrh_comm_attach: an exchange is pending (call mrh_integrate_resume)");
   if (m && m->device != c->device) return fail(c, MRH_ERR_INVALID_ARG, "mrh_comm_attach: communicator on device %d, context on device %d", m->device, c->device);
   if (c->comm == m) return MRH_OK;
