@@ -200,7 +200,10 @@ int mrh_set_rgb_device(mrh_ctx* ctx, const uint8_t* d_rgb, int rows, int cols);
  * (camera.cu:21-26, voxel_data_structures.cpp:90-110): block allocation along every pixel
  * ray, frustum compaction, depth->TSDF integration, optional variance-driven coarsening,
  * optional starve + garbage collection.  n_frames_invalidate < 0 uses the constructor value.
- * Enqueues on the context stream and returns without waiting. */
+ * Enqueues on the context stream and returns without waiting.  A frame whose images came through mrh_upload_* is checked
+ * here (state, shapes) but its kernels are enqueued by the NEXT mrh_integrate — or by whichever other call needs the map
+ * first —, with the pose and images it was issued under: its transfers have landed by then and its kernels need no
+ * cross-stream wait.  A device error of such a frame is therefore returned one call late (MRH_DEFER_UPLOADS=0: at once). */
 int mrh_integrate(mrh_ctx* ctx, int n_frames_invalidate);
 
 /* Tile-sharded contexts (shard_count > 1) only.  On a starve frame (voxel_data_structures.cpp:139) the per-pixel

@@ -891,10 +891,15 @@ def test_plain_c_program_drives_the_abi(hip, tmp_path):
     assert got["free_fine"] == 16384 - case["blocks"]
 
 
-def test_upload_ring_semantics(hip, oracle):
+@pytest.mark.parametrize("defer", ["1", "0"])
+def test_upload_ring_semantics(hip, oracle, monkeypatch, defer):
     """Host uploads go through three-slot rings on a copy stream: an image uploaded once stays current over several
     frames, an upload that is overwritten before any frame used it is harmless, caller-owned device pointers and uploads
-    mix, and a burst of frames without any synchronisation reuses slots only after the frame that read them."""
+    mix, and a burst of frames without any synchronisation reuses slots only after the frame that read them.
+    defer = 1 (the default): a frame of host images is launched one mrh_integrate late, with the pose and the images it was
+    issued under (flush_deferred) — the ring that wraps before any frame, the frame that keeps an old colour image and the
+    pose that changes in between are exactly what that has to survive; defer = 0 launches at once."""
+    monkeypatch.setenv("MRH_DEFER_UPLOADS", defer)
     K = synth.CFG1
     a = pu.make_engine(hip, K, synth.CFG1_PARAMS, 16384)
     b = pu.make_engine(oracle, K, synth.CFG1_PARAMS, 16384)
