@@ -251,6 +251,7 @@ def lidar_setup(hip, blocks):
     d_scans = [hipmem.DeviceBuffer.from_numpy(np.ascontiguousarray(sc, dtype=np.float32)) for sc in scans]
     le = capi.Engine(hip, capi.Params(num_sdf_blocks=blocks, device_id=0, **synth.VBR_PARAMS))
     le.set_camera(1, 1, 0, 0, 1, 1, 0.2, 100.0, model=1)
+    le.set_scan_layout(1024)  # the scans lie in HBM (not looked at): 128 rows of 1 024 points, as the sensor delivers them
 
     def run_scans(lo, hi):
         for i in range(lo, hi):
@@ -483,6 +484,7 @@ def bench_single(args):
         us_scan = dt / (n_scans - w_scans) * 1e6
         lidar = {"workload": "VBR stand-in (configs[4], LiDAR half): 128 x 1024 scans along a 100 m street, vbr.cfg parameters (voxel 0.20 m, "
                              "truncation 0.40 m, projective SDF), scans resident in HBM",
+                 "scan_layout": "organised, 1 024 points per row, said through mrh_set_scan_layout (clouds in device memory are not looked at; host clouds are: mrh_detect_scan_layout)",
                  "scans_per_s": (n_scans - w_scans) / dt, "us_per_scan": us_scan, "points_per_s": npts / dt,
                  "points_per_scan": int(len(scans[0])), "live_blocks_end": live_end,
                  "roofline": {"bound": "hbm", "kernel": "one scan: k_alloc3d + k_scan_walk + k_scan_offsets + k_scan_place + k_scan_apply (mrh_scan.h: voxel buckets, no sort)", "achieved": None,

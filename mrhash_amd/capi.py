@@ -113,7 +113,7 @@ assert TRI_DTYPE.itemsize == 24
 ABI_SYMBOLS = (
     "mrh_create mrh_destroy mrh_reset mrh_last_error mrh_set_camera mrh_set_pose mrh_upload_depth "
     "mrh_upload_rgb mrh_set_depth_device mrh_set_rgb_device mrh_integrate mrh_integrate_resume mrh_exchange_buffer mrh_sync "
-    "mrh_upload_points mrh_upload_normals mrh_set_points_device mrh_integrate_points mrh_stream_out mrh_get_free_blocks "
+    "mrh_upload_points mrh_upload_normals mrh_set_points_device mrh_integrate_points mrh_set_scan_layout mrh_detect_scan_layout mrh_stream_out mrh_get_free_blocks "
     "mrh_splat_seeds mrh_get_qtree_leaves mrh_peek_free_blocks mrh_peek_error_flags "
     "mrh_set_sharding mrh_pack_blocks mrh_unpack_blocks mrh_drop_blocks "
     "mrh_extract_triangles mrh_extract_mesh mrh_mesh_merge_begin mrh_mesh_merge_end mrh_get_stats mrh_set_profile mrh_dump_blocks "
@@ -168,6 +168,8 @@ def _declare(lib: C.CDLL) -> C.CDLL:
     lib.mrh_upload_normals.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
     lib.mrh_set_points_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
     lib.mrh_integrate_points.argtypes = [C.c_void_p, C.c_int]
+    lib.mrh_set_scan_layout.argtypes = [C.c_void_p, C.c_int]
+    lib.mrh_detect_scan_layout.argtypes = [C.c_void_p, C.c_uint64]
     lib.mrh_get_free_blocks.argtypes = [C.c_void_p, P(C.c_int64), P(C.c_int64)]
     lib.mrh_peek_free_blocks.argtypes = [C.c_void_p, P(C.c_int64), P(C.c_int64), P(C.c_uint64)]
     lib.mrh_stream_out.argtypes = [C.c_void_p, P(C.c_float), C.c_float, C.c_void_p, C.c_void_p, C.c_uint64, P(C.c_uint64)]
@@ -423,6 +425,10 @@ class Engine:
 
     def set_points_device(self, ptr: int, n: int):
         self._check(self.lib.mrh_set_points_device(self._ctx, ptr, n))
+
+    def set_scan_layout(self, row_len: int):
+        """Points per row of the caller's organised scans (0: look at host clouds, < 0: never): a hint for the beam order, never for the result."""
+        self._check(self.lib.mrh_set_scan_layout(self._ctx, int(row_len)))
 
     def integrate_points(self, n_frames_invalidate: int = -1) -> bool:
         """One scan.  Returns True when a sharded context stopped for the starve z-buffer reduction (see integrate())."""

@@ -283,6 +283,9 @@ struct mrh_ctx {
   std::vector<mrh_qtree_leaf> qt_leaves;
   uint64_t qt_n_leaves = 0;            // leaves of the last mrh_splat_seeds, still on the device (d_qt_leaves) until someone asks
   bool qt_leaves_on_host = true;
+  int scan_layout_hint = 0;    // mrh_set_scan_layout / MRH_SCAN_ROW_LEN: > 0 points per row of the caller's organised scans, 0 find out (host clouds), < 0 none
+  int scan_row_len = 0;        // ... of the CURRENT cloud (0: not organised, or not known)
+  int scan_patch_log2 = 4;     // MRH_SCAN_PATCH_LOG2: columns (log2) of the beam patch a walk workgroup takes from an organised scan; 8 = 256 consecutive points
   int lidar_sort_rocprim = 0;  // MRH_LIDAR_SORT_ROCPRIM=1: the record sort of a scan through rocPRIM's onesweep instead of mrh_sort.h (cross-check)
   int mr_fused = 1;          // MRH_MR_FUSED=0: multi-resolution maps always through the general kernels (mrh_kernels.h)
   bool mr_next_general = true;    // the next multi-resolution frame must take the general path (frame 0 / after a starve frame / after an import)
@@ -1311,6 +1314,8 @@ int mrh_create(const mrh_params* p, mrh_ctx** out) {
   if (const char* g = getenv("MRH_QTREE_LITERAL")) c->qt_literal = atoi(g) ? 1 : 0;
   if (const char* g = getenv("MRH_MR_FUSED")) c->mr_fused = atoi(g) ? 1 : 0;
   if (const char* g = getenv("MRH_LIDAR_SORT_ROCPRIM")) c->lidar_sort_rocprim = atoi(g) ? 1 : 0;
+  if (const char* g = getenv("MRH_SCAN_ROW_LEN")) c->scan_layout_hint = atoi(g);
+  if (const char* g = getenv("MRH_SCAN_PATCH_LOG2")) { const int v = atoi(g); if (v >= 0 && v <= 8) c->scan_patch_log2 = v; }
   if (const char* g = getenv("MRH_LIDAR_BUCKETS")) c->lidar_buckets = atoi(g) ? 1 : 0;
   if (const char* g = getenv("MRH_SCAN_SEQ_START")) c->scan2_seq = (u32) strtoul(g, nullptr, 0);  // tests: scans next to the wrap of the block stamps
   if (const char* g = getenv("MRH_REHASH_PERIOD")) { const int v = atoi(g); if (v > 0) c->census_period = v; }
@@ -2424,6 +2429,53 @@ static int integrate_frame(mrh_ctx* c, int n_frames_invalidate) {
   return starve_and_tail(c, max_num_frames);
 }
 
+}  // extern "C"
+
+namespace {
+// Is this cloud an organised scan — rows of L points each, row-major, neighbours in the array neighbours in direction both along a
+// row and from one row to the next?  A few dozen point pairs decide: the candidate L (a power of two that leaves a multiple of 16
+// rows) whose points i and i + L lie closest in direction, if that and the step to i + 1 are within a few degrees.  Only a hint
+// for the order in which k_scan_walk takes the beams (mrh_scan.h: Scan::patch_log2): a wrong answer costs time, never a bit.
+int detect_scan_row_len(const float* xyz, const uint64_t n) {
+  if (n < 4096 || n % 256) return 0;
+  auto cos_between = [&](uint64_t a, uint64_t b, double* out) {
+    const float *p = xyz + 3 * a, *q = xyz + 3 * b;
+    const double pp = (double) p[0] * p[0] + (double) p[1] * p[1] + (double) p[2] * p[2], qq = (double) q[0] * q[0] + (double) q[1] * q[1] + (double) q[2] * q[2];
+    if (!(pp > 0.0) || !(qq > 0.0)) return false;  // a missing return
+    *out = ((double) p[0] * q[0] + (double) p[1] * q[1] + (double) p[2] * q[2]) / std::sqrt(pp * qq);
+    return true;
+  };
+  constexpr int kSamples = 96;
+  const double cos_limit = 0.99756;  // 4 degrees (a 16-beam sensor's rows are 2-3 degrees apart)
+  int best = 0;
+  double best_cos = cos_limit;
+  for (uint64_t L = 16; L <= 8192 && L * 16 <= n; L <<= 1) {
+    if (n % L || (n / L) % 16) continue;
+    double sum_row = 0.0, sum_next = 0.0;
+    int ok = 0;
+    for (int k = 0; k < kSamples; k++) {
+      const uint64_t i = (uint64_t) ((double) k * (double) (n - L - 2) / kSamples);
+      double a, b;
+      if ((i % L) + 1 < L && cos_between(i, i + 1, &a) && cos_between(i, i + L, &b)) { sum_next += a; sum_row += b; ok++; }
+    }
+    if (ok < kSamples / 4) continue;
+    if (sum_next / ok > cos_limit && sum_row / ok > best_cos) { best_cos = sum_row / ok; best = (int) L; }
+  }
+  return best;
+}
+}  // namespace
+
+extern "C" {
+
+int mrh_detect_scan_layout(const float* xyz, uint64_t n) { return xyz ? detect_scan_row_len(xyz, n) : 0; }
+
+int mrh_set_scan_layout(mrh_ctx* c, int row_len) {
+  if (!c) return MRH_ERR_INVALID_ARG;
+  c->scan_layout_hint = row_len;
+  c->scan_row_len = row_len > 0 ? row_len : 0;
+  return MRH_OK;
+}
+
 int mrh_upload_points(mrh_ctx* c, const float* xyz, uint64_t n) {
   int rc = ensure_ready(c, "mrh_upload_points");
   if (rc) return rc;
@@ -2439,6 +2491,7 @@ int mrh_upload_points(mrh_ctx* c, const float* xyz, uint64_t n) {
   HIP_TRY(c, hipStreamSynchronize(c->stream));  // the caller's buffer is free on return (GeoWrapper::setPointCloud copies)
   c->d_points_cur = c->d_points;
   c->num_points = n;
+  c->scan_row_len = c->scan_layout_hint > 0 ? c->scan_layout_hint : c->scan_layout_hint == 0 && n ? detect_scan_row_len(xyz, n) : 0;
   return MRH_OK;
 }
 
@@ -2448,6 +2501,7 @@ int mrh_set_points_device(mrh_ctx* c, const float* d_xyz, uint64_t n) {
   if (n && !d_xyz) return fail(c, MRH_ERR_INVALID_ARG, "mrh_set_points_device: null argument");
   c->d_points_cur = d_xyz;
   c->num_points = n;
+  c->scan_row_len = c->scan_layout_hint > 0 ? c->scan_layout_hint : 0;  // a cloud in device memory is not looked at: mrh_set_scan_layout says how it is laid out
   return MRH_OK;
 }
 
@@ -2661,6 +2715,15 @@ int mrh_integrate_points(mrh_ctx* c, int n_frames_invalidate) {
       sc.ctr = c->d_scan_ctr + (sc.seq & 1u) * SC_N;
       sc.ctr_next = c->d_scan_ctr + ((sc.seq + 1u) & 1u) * SC_N;
       sc.ord_shift = t.multi_res ? 5 : 0;
+      // an organised scan (one point per pixel of the spherical camera, row-major) is walked in 2-D patches of beams (mrh_scan.h: Scan)
+      sc.patch_log2 = 8; sc.patches_per_row = 1; sc.row_len = 256;
+      {
+        const int want = c->scan_patch_log2;
+        const uint64_t row_len = c->scan_row_len > 0 ? (uint64_t) c->scan_row_len : ((uint64_t) k.rows * (uint64_t) k.cols == n ? (uint64_t) k.cols : 0);
+        if (want < 8 && row_len > 0 && n % row_len == 0 && row_len % (1u << want) == 0 && (n / row_len) % (256u >> want) == 0) {
+          sc.patch_log2 = (u32) want; sc.patches_per_row = (u32) (row_len >> want); sc.row_len = (u32) row_len;
+        }
+      }
       const size_t lds = (size_t) (2 * slots * 256 + 2 * kScanSetSize) * sizeof(u32);
       k_scan_walk<<<grid, 256, lds, s>>>(k, m, t, pts, normals, np, sc, (int) slots);
       // the touched blocks are found by their stamps inside k_scan_offsets, windows of kScanWindow blocks; 512 workgroups walk the

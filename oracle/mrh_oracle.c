@@ -1593,6 +1593,9 @@ int mrh_upload_points(mrh_ctx* c, const float* xyz, uint64_t n) {
   return MRH_OK;
 }
 int mrh_set_points_device(mrh_ctx* c, const float* xyz, uint64_t n) { return mrh_upload_points(c, xyz, n); }
+/* a hint for the order in which the HIP path takes the beams; the restatement walks the points one by one in index order */
+int mrh_set_scan_layout(mrh_ctx* c, int row_len) { (void) row_len; return c ? MRH_OK : MRH_ERR_INVALID_ARG; }
+int mrh_detect_scan_layout(const float* xyz, uint64_t n) { (void) xyz; (void) n; return 0; }
 int mrh_upload_normals(mrh_ctx* c, const float* nxyz, uint64_t n) {
   if (!c || (n && !nxyz)) return fail(c, MRH_ERR_INVALID_ARG, "mrh_upload_normals: bad argument");
   free(c->normals);

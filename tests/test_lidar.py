@@ -256,3 +256,29 @@ def test_spherical_depth_image_fuses_like_the_same_points_would_project(oracle):
             checked += 1
     assert checked > 100
     e.close()
+
+
+def test_scan_layout_detection_is_host_code_and_finds_the_row_length():
+    """mrh_detect_scan_layout (what mrh_upload_points concludes about a host cloud; pure host code, no device): organised scans
+    of the usual sensors are recognised through their row length — also with missing returns, also stored column by column —,
+    shuffled or small clouds are not.  The answer only orders the beams of the HIP path (tests/test_lidar_gpu.py: same map)."""
+    hip = capi.load_hip()
+    scene = synth.street_canyon()
+    (t, q), = synth.drive_poses(1)
+
+    def detect(pts):
+        a = np.ascontiguousarray(pts, dtype=np.float32)
+        return hip.mrh_detect_scan_layout(a.ctypes.data, a.shape[0])
+
+    for rows, cols in ((128, 1024), (64, 2048), (32, 512), (16, 1024)):
+        pts = synth.lidar_scan(scene, t, q, rows=rows, cols=cols)
+        assert detect(pts) == cols, (rows, cols)
+    pts = synth.lidar_scan(scene, t, q, rows=128, cols=1024, dropout=0.3, rng=np.random.default_rng(3))
+    assert detect(pts) == 1024
+    col_major = np.ascontiguousarray(synth.lidar_scan(scene, t, q, rows=128, cols=1024).reshape(128, 1024, 3).transpose(1, 0, 2)).reshape(-1, 3)
+    assert detect(col_major) == 128  # rows of the array = columns of the sensor: organised all the same
+    rng = np.random.default_rng(5)
+    assert detect(rng.permutation(synth.lidar_scan(scene, t, q, rows=128, cols=1024))) == 0
+    assert detect(rng.normal(size=(131072, 3))) == 0
+    assert detect(synth.lidar_scan(scene, t, q, rows=8, cols=256)) == 0  # too small to bother
+    assert detect(np.zeros((16384, 3), np.float32)) == 0  # no returns at all

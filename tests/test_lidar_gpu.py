@@ -48,6 +48,43 @@ def test_single_scan_matches_oracle(hip, oracle):
     assert r["blocks"] > 1000 and r["sdf_bit_exact"] and r["sumsq_bit_exact"]
 
 
+@pytest.mark.parametrize("var_threshold", [0.0, 0.05])
+def test_scan_layout_is_a_hint_for_the_beam_order_only(hip, oracle, var_threshold):
+    """mrh_set_scan_layout / the look at host clouds (mrh_detect_scan_layout) decide which 256 beams a walk workgroup takes — 16 x 16
+    patches of an organised scan instead of 256 in a row.  Whatever is said, true or false, the map is the oracle's: a voxel's
+    records are put into point order before they are folded."""
+    from mrhash_amd import hipmem
+
+    scene = synth.street_canyon()
+    poses = synth.drive_poses(3, step=1.5)
+    scans = [synth.lidar_scan(scene, t, q, rows=32, cols=512) for t, q in poses]
+    assert hip.mrh_detect_scan_layout(np.ascontiguousarray(scans[0]).ctypes.data, len(scans[0])) == 512
+    p = dict(synth.VBR_PARAMS, sdf_var_threshold=var_threshold)
+    ref = capi.Engine(oracle, capi.Params(num_sdf_blocks=131072, **p))
+    ref.set_camera(K1.fx, K1.fy, K1.cx, K1.cy, K1.rows, K1.cols, p["min_depth"], 100.0, model=1)
+    for (t, q), pts in zip(poses, scans):
+        _feed((ref,), pts, t, q)
+    for hint, on_device in ((0, False), (-1, False), (512, True), (0, True), (256, True), (2048, False), (16, True), (4096, True)):
+        e = capi.Engine(hip, capi.Params(num_sdf_blocks=131072, **p))
+        e.set_camera(K1.fx, K1.fy, K1.cx, K1.cy, K1.rows, K1.cols, p["min_depth"], 100.0, model=1)
+        e.set_scan_layout(hint)
+        for (t, q), pts in zip(poses, scans):
+            e.set_pose(synth.quat_to_rot(q), t)
+            if on_device:
+                d_pts = hipmem.DeviceBuffer.from_numpy(np.ascontiguousarray(pts, dtype=np.float32))
+                e.set_points_device(d_pts.ptr, len(pts))
+                e.integrate_points()
+                e.sync()
+            else:
+                e.upload_points(pts)
+                e.integrate_points()
+        e.sync()
+        r = pu.compare_maps(e, ref)
+        assert r["blocks"] > 1000 and r["sdf_bit_exact"] and r["sumsq_bit_exact"], (hint, on_device)
+        e.close()
+    ref.close()
+
+
 def test_scans_across_the_wrap_of_the_block_stamps(hip, oracle, monkeypatch):
     """a block's stamp is `2 * sequence + coarse` in 32 bits, so the sequence restarts at 2^31 — with clean stamps
     and both counter sets at zero.  Six scans whose sequence numbers straddle the restart build the oracle's map."""

@@ -10,6 +10,8 @@ import bench  # noqa: E402
 from mrhash_amd import capi  # noqa: E402
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+if os.environ.get("BENCH_LIB"):  # another build of the library (A/B on one box)
+    capi.HIP_LIB_PATH = os.path.abspath(os.environ["BENCH_LIB"])
 hip = capi.load_hip()
 le, scans, d_scans, run_scans = bench.lidar_setup(hip, 262144)
 n, w = bench.LIDAR_SCANS, bench.LIDAR_WARMUP

@@ -39,4 +39,10 @@ for k, (nm, slots) in names.items():
             d = (r[ok, s] - r[ok, s - 1]) * tick
             line.append(f"  phase {slots[s - 1]} -> {slots[s]}: median {np.median(d):.1f} us, p90 {np.percentile(d, 90):.1f}, max {d.max():.1f}")
     print("\n".join(line))
+    if k == 0:  # the walk's slowest workgroups, phase by phase (us): who the launch waits for
+        idx = np.nonzero(a[k][:, 0] > 0)[0]
+        order = idx[np.argsort(-a[k][idx, 5])][:12]
+        for w in order:
+            ph = np.diff(a[k][w, :6]) * tick
+            print(f"  slow wg {w:4d}: start {(a[k][w, 0] - k0) * tick:5.1f} end {(a[k][w, 5] - k0) * tick:5.1f} | walk {ph[0]:5.1f} set {ph[1]:4.1f} A {ph[2]:5.1f} B {ph[3]:5.1f} C {ph[4]:4.1f}")
 le.close()
