@@ -2679,7 +2679,18 @@ int mrh_integrate_points(mrh_ctx* c, int n_frames_invalidate) {
       k_refill_decide<<<1, 64, 0, s>>>(t, c->low_blocks_to_allocate, c->d_flag);
       k_refill<<<(c->low_blocks_to_allocate + 255) / 256, 256, 0, s>>>(t, c->low_blocks_to_allocate, c->d_flag);
     }
-    k_alloc3d<<<grid, 256, 0, s>>>(k, m, t, c->fast, pts, normals, np, stamp);
+    // an organised scan is taken in 2-D patches of beams (mrh_lidar.h: BeamOrder); its row length: mrh_set_scan_layout, the look
+    // at a host cloud (mrh_upload_points), or the spherical camera's columns if it has one pixel per point
+    BeamOrder order;
+    order.patch_log2 = 8; order.patches_per_row = 1; order.row_len = 256;
+    {
+      const int want = c->scan_patch_log2;
+      const uint64_t row_len = c->scan_row_len > 0 ? (uint64_t) c->scan_row_len : (c->scan_layout_hint == 0 && (uint64_t) k.rows * (uint64_t) k.cols == n ? (uint64_t) k.cols : 0);
+      if (want < 8 && row_len > 0 && n % row_len == 0 && row_len % (1u << want) == 0 && (n / row_len) % (256u >> want) == 0) {
+        order.patch_log2 = (u32) want; order.patches_per_row = (u32) (row_len >> want); order.row_len = (u32) row_len;
+      }
+    }
+    k_alloc3d<<<grid, 256, 0, s>>>(k, m, t, c->fast, pts, normals, np, stamp, order);
     // ---- integrate3D (vds.cu:1215-1410): records of every (point, voxel) in point-major order -> stable sort by voxel -> fold.
     // The record buffers are sized by a bound the host can compute (a beam crosses at most `slots` voxels), so the emit pass
     // needs nothing from the host and runs WHILE the host picks up the scan's one report (record count, high-water mark: they
@@ -2715,15 +2726,7 @@ int mrh_integrate_points(mrh_ctx* c, int n_frames_invalidate) {
       sc.ctr = c->d_scan_ctr + (sc.seq & 1u) * SC_N;
       sc.ctr_next = c->d_scan_ctr + ((sc.seq + 1u) & 1u) * SC_N;
       sc.ord_shift = t.multi_res ? 5 : 0;
-      // an organised scan (one point per pixel of the spherical camera, row-major) is walked in 2-D patches of beams (mrh_scan.h: Scan)
-      sc.patch_log2 = 8; sc.patches_per_row = 1; sc.row_len = 256;
-      {
-        const int want = c->scan_patch_log2;
-        const uint64_t row_len = c->scan_row_len > 0 ? (uint64_t) c->scan_row_len : ((uint64_t) k.rows * (uint64_t) k.cols == n ? (uint64_t) k.cols : 0);
-        if (want < 8 && row_len > 0 && n % row_len == 0 && row_len % (1u << want) == 0 && (n / row_len) % (256u >> want) == 0) {
-          sc.patch_log2 = (u32) want; sc.patches_per_row = (u32) (row_len >> want); sc.row_len = (u32) row_len;
-        }
-      }
+      sc.order = order;
       const size_t lds = (size_t) (2 * slots * 256 + 2 * kScanSetSize) * sizeof(u32);
       k_scan_walk<<<grid, 256, lds, s>>>(k, m, t, pts, normals, np, sc, (int) slots);
       // the touched blocks are found by their stamps inside k_scan_offsets, windows of kScanWindow blocks; 512 workgroups walk the

@@ -37,8 +37,23 @@ __device__ __forceinline__ i3 voxel_to_block_fast(const Map& m, const i3 v) {
 // record key = voxel id: fine block index * 512 + local index; on a coarse unit u = 8 H + k: (H * 512 + k * 64 + local index) | coarse bit,
 // coarse bit = 1 << (9 + bits of the pool capacity) — the host picks the key width (32 or 64 bits) from it.
 
+// Which 256 beams a workgroup takes.  An ORGANISED scan (rows of row_len points, row-major: what a LiDAR driver delivers) is taken
+// in patches of (256 >> patch_log2) rows x (1 << patch_log2) columns instead of 256 consecutive points of one row: beams that leave
+// the sensor side by side — in BOTH directions of the scan image — end in the same blocks and voxels, so a workgroup has several
+// times fewer distinct ones to insert, group and count.  patch_log2 = 8: 256 consecutive points (any other cloud).  The order is a
+// matter of speed only: a record carries its point index, and a voxel's records are put into point order before they are folded.
+struct BeamOrder {
+  u32 patch_log2, patches_per_row, row_len;
+  __device__ __forceinline__ u32 point(const u32 wg, const u32 tid) const {
+    if (patch_log2 >= 8u) return wg * 256u + tid;
+    const u32 pr = wg / patches_per_row, pc = wg - pr * patches_per_row;
+    const u32 r = (pr << (8u - patch_log2)) + (tid >> patch_log2), col = (pc << patch_log2) + (tid & ((1u << patch_log2) - 1u));
+    return r * row_len + col;
+  }
+};
+
 __global__ __launch_bounds__(256) void k_alloc3d(const Cam c, const Map m, const Tab t, const Fast f, const float* __restrict__ pts,
-                                                 const float* __restrict__ normals, const u32 n, const u32 stamp) {
+                                                 const float* __restrict__ normals, const u32 n, const u32 stamp, const BeamOrder order) {
   __shared__ FrontShared sh;
   constexpr int NT = 256;
   const int tid = threadIdx.x;
@@ -52,7 +67,7 @@ __global__ __launch_bounds__(256) void k_alloc3d(const Cam c, const Map m, const
     if (slot < 0) return;
     (void) commit_block(t, f, slot, atomicSub(&t.ctr[CTR_HEAP_FINE], 1), cur, stamp, hwm0);
   };
-  const u32 i = blockIdx.x * NT + tid;
+  const u32 i = order.point(blockIdx.x, (u32) tid);
   if (i < n) {
     const f3 pcam = mk3(pts[3 * (size_t) i], pts[3 * (size_t) i + 1], pts[3 * (size_t) i + 2]);
     const float range = norm3(pcam);

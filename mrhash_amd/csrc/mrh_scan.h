@@ -64,24 +64,12 @@ struct Scan {
   uint4* chunks;  // {block | coarse, v0 | v1 << 16, r0, r1}; runs beyond kScanWaveRecs from the END of the array downwards
   u32 rec_cap, chunk_cap, seq;
   int ord_shift;  // 5 on variance-adaptive maps (a beam can cross several fine cells of one coarse voxel), else 0
-  // An ORGANISED scan (points = rows x row_len of the spherical camera, row-major) is walked in patches of (256 >> patch_log2) rows
-  // x (1 << patch_log2) columns per workgroup instead of 256 consecutive points of one row: neighbouring beams of BOTH image
-  // directions end in the same voxels, so a workgroup has several times fewer distinct voxels — and a returning global atomic
-  // per distinct voxel is what its walk waits for longest.  patch_log2 = 8: 256 consecutive points (any other cloud).
-  u32 patch_log2, patches_per_row, row_len;
+  BeamOrder order;  // which 256 beams a walk workgroup takes (mrh_lidar.h)
 };
 
 // Same-address atomics with a return value cost ~15 ns each on this chip whoever issues them (measured: 3 000 appends to one
 // list counter = 45 us of a kernel), so nothing here takes one per block or per workgroup: the stash is addressed by workgroup,
 // the touched blocks are found by their stamps, block bases and chunk slots are reserved 16 blocks at a time.
-
-// point index of thread `tid` of walk workgroup `wg` (k_scan_walk and k_scan_place agree on it: it is the records' order tag)
-__device__ __forceinline__ u32 scan_point_index(const Scan& sc, const u32 wg, const u32 tid) {
-  if (sc.patch_log2 >= 8u) return wg * 256u + tid;
-  const u32 pr = wg / sc.patches_per_row, pc = wg - pr * sc.patches_per_row;
-  const u32 r = (pr << (8u - sc.patch_log2)) + (tid >> sc.patch_log2), col = (pc << sc.patch_log2) + (tid & ((1u << sc.patch_log2) - 1u));
-  return r * sc.row_len + col;
-}
 
 #ifdef MRH_SCAN_TRACE
 // tuning builds only (tools/trace_scan.sh): wall-clock stamps (100 MHz) of thread 0 of every workgroup at its phase boundaries;
@@ -106,7 +94,7 @@ __global__ __launch_bounds__(256) void k_scan_walk(const Cam c, const Map m, con
   MRH_SC_TS(0, 0);
   for (u32 i = tid; i < kScanSetSize; i += 256) { s_key[i] = kScanEmpty; s_cnt[i] = 0; }
   if (tid == 0) s_ng = 0;
-  const u32 i = scan_point_index(sc, blockIdx.x, tid);
+  const u32 i = sc.order.point(blockIdx.x, tid);
   u32 cnt = 0;
   bool over = false;
   walk_beam(c, m, t, pts, normals, i, i < n, [&](const u32 val, const int res, const u32 li, const float sdf) {
@@ -365,7 +353,7 @@ __global__ __launch_bounds__(256) void k_scan_place(const Scan sc, const int slo
     const float sdf = sc.st_sdf[off + r];
     const u32 slot = s_base[meta.x & 0x1FFFu] + (meta.x >> 13);
     if (slot < sc.rec_cap) {
-      const u32 pidx = scan_point_index(sc, blockIdx.x, meta.y >> 5);
+      const u32 pidx = sc.order.point(blockIdx.x, meta.y >> 5);
       sc.rec[slot] = make_uint4(sc.ord_shift ? (pidx << 5) | (meta.y & 31u) : pidx, __float_as_uint(sdf), s_li[meta.x & 0x1FFFu], 0u);
     }
   }
