@@ -77,8 +77,11 @@ struct Scan {
 constexpr int kScanTraceWgs = 4096;
 __device__ unsigned long long d_scan_trace[4][kScanTraceWgs][8];
 #define MRH_SC_TS(kern, slot) do { if (threadIdx.x == 0 && blockIdx.x < kScanTraceWgs) d_scan_trace[kern][blockIdx.x][slot] = wall_clock64(); } while (0)
+// per wave: lane 0 of every wave, the stamp's low 44 bits + 20 bits of what the wave worked on
+#define MRH_SC_TSW(kern, slot, info) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < kScanTraceWgs) d_scan_trace[kern][blockIdx.x][slot] = (wall_clock64() & ((1ull << 44) - 1)) | ((unsigned long long) (info) << 44); } while (0)
 #else
 #define MRH_SC_TS(kern, slot) do { } while (0)
+#define MRH_SC_TSW(kern, slot, info) do { } while (0)
 #endif
 
 __global__ __launch_bounds__(256) void k_scan_walk(const Cam c, const Map m, const Tab t, const float* __restrict__ pts,
@@ -440,6 +443,28 @@ struct VoxFold {
     u32 i = 0;
     if (!two && clamp_at <= kTable) {
       const u32 nt = min(clamp_at, n - 1);
+      // until the clamp the weight before step i is W + i w1 (< wmax: a small integer, exact in fp32 — the table's a[i], counted
+      // up here instead of loaded); the records and the reciprocals of four steps are in registers while the four before them
+      // are folded, so the chain of a record is its arithmetic, not an LDS round trip per step (a new voxel's run of ~150 records
+      // is what the launch waited for: 24 of its 25 us, tools/trace_scan.py)
+      if (i + 4 <= nt) {
+        float aw_i = (float) W, x0 = x[i], x1 = x[i + 1], x2 = x[i + 2], x3 = x[i + 3], q0 = r[i], q1 = r[i + 1], q2 = r[i + 2], q3 = r[i + 3];
+        for (; i + 8 <= nt; i += 4) {
+          const float y0 = x[i + 4], y1 = x[i + 5], y2 = x[i + 6], y3 = x[i + 7], p0 = r[i + 4], p1 = r[i + 5], p2 = r[i + 6], p3 = r[i + 7];
+          float an = aw_i + w1f;
+          s = div_cr(s * aw_i + x0, an, q0); aw_i = an; an += w1f;
+          s = div_cr(s * aw_i + x1, an, q1); aw_i = an; an += w1f;
+          s = div_cr(s * aw_i + x2, an, q2); aw_i = an; an += w1f;
+          s = div_cr(s * aw_i + x3, an, q3); aw_i = an;
+          x0 = y0; x1 = y1; x2 = y2; x3 = y3; q0 = p0; q1 = p1; q2 = p2; q3 = p3;
+        }
+        float an = aw_i + w1f;
+        s = div_cr(s * aw_i + x0, an, q0); aw_i = an; an += w1f;
+        s = div_cr(s * aw_i + x1, an, q1); aw_i = an; an += w1f;
+        s = div_cr(s * aw_i + x2, an, q2); aw_i = an; an += w1f;
+        s = div_cr(s * aw_i + x3, an, q3);
+        i += 4;
+      }
       for (; i < nt; i++) s = div_cr(s * a[i] + x[i], a[i] + w1f, r[i]);
       const float aw = (float) wmax, dw = (float) (int) (wmax + w1), rw = rcp_refined(dw);
       // The clamped weight sum of the shipped configurations is a power of two (255 + 1): dividing by it is a multiplication by
@@ -521,7 +546,7 @@ __device__ __forceinline__ void wave_sync() {  // LDS written by the lanes of th
 // the LDS, without workgroup barriers: 6 000 waves are resident, so all chunks of a scan are in flight at once and the kernel
 // lasts as long as its longest chain (a long run: sort + fold), not as long as a queue of chunks.  The few runs beyond a
 // wave's slice follow, a workgroup each.
-struct ApplyWaveLds {
+struct alignas(16) ApplyWaveLds {
   u32 tag[kScanWaveRecs];
   float sdf[kScanWaveRecs];
   union {
@@ -591,18 +616,43 @@ __global__ __launch_bounds__(256, 6) void k_scan_apply(const Map m, const Tab t,
         if (lane + 64u * r < nv) pc[64 * r] = 0;
       if (nr == 0) continue;
     }
-    if (long_run) {  // one long run: bitonic network over the tags, then one lane folds
-      u32 N = 128;
-      while (N < nr) N <<= 1;
-      for (u32 q = lane; q < N; q += 64) {
-        const uint4 rc = q < nr ? sc.rec[r0 + q] : make_uint4(kScanEmpty, 0u, 0u, 0u);
-        L.tag[q] = rc.x;
-        L.sdf[q] = __uint_as_float(rc.y);
-      }
+    if (long_run) {  // one long run: its records into point order (tags are distinct), then one lane folds
       VoxFold f;
-      f.begin(m, t, H, coarse, v0);  // every lane (one address): the tables start from the voxel's weight
-      wave_sync();
-      bitonic_lds<64>(L.tag, L.sdf, N, lane, [] { wave_sync(); });
+      if (nr <= 256) {
+        // up to four records a lane: a record's place is the number of smaller tags, counted over the run's tags in LDS four at
+        // a time (every lane reads the same words: broadcasts) — a third of the instructions of the network's 28-36 stages
+        u32 tg[4], rank[4];
+        float sv[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const u32 q = lane + 64u * r;
+          const uint4 rc = q < nr ? sc.rec[r0 + q] : make_uint4(kScanEmpty, 0u, 0u, 0u);
+          tg[r] = rc.x; sv[r] = __uint_as_float(rc.y); rank[r] = 0;
+          L.tag[q] = rc.x;  // the padding (all ones) is larger than any tag: it counts for nobody
+        }
+        f.begin(m, t, H, coarse, v0);  // every lane (one address): the tables start from the voxel's weight
+        wave_sync();
+        const u32 n4 = (nr + 3u) & ~3u;
+        for (u32 j = 0; j < n4; j += 4) {
+          const uint4 o = *(const uint4*) &L.tag[j];
+#pragma unroll
+          for (int r = 0; r < 4; r++) rank[r] += (o.x < tg[r] ? 1u : 0u) + (o.y < tg[r] ? 1u : 0u) + (o.z < tg[r] ? 1u : 0u) + (o.w < tg[r] ? 1u : 0u);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+          if (lane + 64u * r < nr) L.sdf[rank[r]] = sv[r];
+        wave_sync();
+      } else {
+        u32 N = 512;
+        for (u32 q = lane; q < N; q += 64) {
+          const uint4 rc = q < nr ? sc.rec[r0 + q] : make_uint4(kScanEmpty, 0u, 0u, 0u);
+          L.tag[q] = rc.x;
+          L.sdf[q] = __uint_as_float(rc.y);
+        }
+        f.begin(m, t, H, coarse, v0);
+        wave_sync();
+        bitonic_lds<64>(L.tag, L.sdf, N, lane, [] { wave_sync(); });
+      }
       f.fill_tables<64>(lane, L.sdf, L.a, L.r, nr);
       wave_sync();
       if (lane == 0) {
@@ -611,6 +661,7 @@ __global__ __launch_bounds__(256, 6) void k_scan_apply(const Map m, const Tab t,
         updated++;
       }
       wave_sync();
+      MRH_SC_TSW(3, 3 + wave, min(nr, 1023u) | (1u << 19));
       continue;
     }
     // all loads of the chunk first (a store in between would order them): where the runs start, the records
@@ -685,6 +736,7 @@ __global__ __launch_bounds__(256, 6) void k_scan_apply(const Map m, const Tab t,
       updated++;
     }
     wave_sync();
+    MRH_SC_TSW(3, 3 + wave, min(nr, 1023u) | (min(nv, 511u) << 10));
   }
   // runs beyond a wave's slice: one workgroup each, over the same LDS
   __syncthreads();

@@ -18,7 +18,7 @@ hip.mrh_debug_scan_trace(None, 1)
 run_scans(bench.LIDAR_SCANS - 1, bench.LIDAR_SCANS)
 le.sync()
 hip.mrh_debug_scan_trace(buf, 0)
-a = np.frombuffer(buf, dtype=np.uint64).astype(np.int64).reshape(4, W, 8)
+a = np.frombuffer(buf, dtype=np.uint64).astype(np.int64).reshape(4, W, 8)  # (apply's slots 3..6 carry 20 bits of info above bit 44: read back as uint64 below)
 tick = 0.01  # us per tick (100 MHz)
 names = {0: ("walk", ["start", "beams walked", "set ready", "grouped (A)", "atomics + groups (B)", "records stored (C)"]),
          1: ("offsets", ["start", "end"]), 2: ("place", ["start", "end"]), 3: ("apply", ["start", "chunks done", "end"])}
@@ -39,6 +39,23 @@ for k, (nm, slots) in names.items():
             d = (r[ok, s] - r[ok, s - 1]) * tick
             line.append(f"  phase {slots[s - 1]} -> {slots[s]}: median {np.median(d):.1f} us, p90 {np.percentile(d, 90):.1f}, max {d.max():.1f}")
     print("\n".join(line))
+    if k == 3:  # apply: its waves one by one (slots 3..6: end stamp | records << 44 | voxels << 54 | long run << 63 of the wave's LAST chunk)
+        raw = a[k].view(np.uint64) if a[k].dtype != np.uint64 else a[k]
+        w = raw[:, 3:7].reshape(-1)
+        w = w[w > 0]
+        st = (w & np.uint64((1 << 44) - 1)).astype(np.int64)
+        info = (w >> np.uint64(44)).astype(np.int64)
+        nr, nv, lng = info & 1023, (info >> 10) & 511, (info >> 19) & 1
+        end = (st - (k0 & ((1 << 44) - 1))) * tick
+        print(f"  waves with a chunk: {len(w)} (long runs {int(lng.sum())}); wave end median {np.median(end):.1f} p90 {np.percentile(end, 90):.1f} max {end.max():.1f}")
+        for name, sel in (("long runs", lng == 1), ("chunks", lng == 0)):
+            if sel.any():
+                print(f"    {name}: {int(sel.sum())} waves, end median {np.median(end[sel]):.1f} p90 {np.percentile(end[sel], 90):.1f} max {end[sel].max():.1f}; records median {np.median(nr[sel]):.0f} max {nr[sel].max()}")
+        for i in np.argsort(-end)[:12]:
+            print(f"    slow wave: end {end[i]:5.1f} us  records {nr[i]:4d} voxels {nv[i]:3d} long {lng[i]}")
+        order = np.argsort(-end)
+        top = order[: max(1, len(order) // 20)]
+        print(f"    slowest 5 % of waves: records median {np.median(nr[top]):.0f}, voxels median {np.median(nv[top]):.0f}, long {int(lng[top].sum())} of {len(top)}")
     if k == 0:  # the walk's slowest workgroups, phase by phase (us): who the launch waits for
         idx = np.nonzero(a[k][:, 0] > 0)[0]
         order = idx[np.argsort(-a[k][idx, 5])][:12]
