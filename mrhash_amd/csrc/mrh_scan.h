@@ -49,7 +49,7 @@ constexpr u32 kScanLongRun = 64;          // a run longer than this is a chunk o
 constexpr u32 kScanBigRecs = 2048;        // a run beyond a wave's slice is sorted by a whole workgroup (<= this: bitonic; beyond: windows)
 constexpr u32 kScanEmpty = 0xFFFFFFFFu;
 constexpr u32 kScanCoarse = 0x80000000u;  // voxel id of a coarse unit
-enum ScanCtr : int { SC_UNUSED = 0, SC_PLACED = 1, SC_CHUNKS = 2, SC_BIG = 3, SC_N = 4 };
+enum ScanCtr : int { SC_PLACED = 0, SC_CHUNKS = 1, SC_BIG = 2, SC_UNUSED = 3, SC_N = 4 };  // PLACED | CHUNKS: one 64-bit word (k_scan_offsets reserves both with ONE atomic)
 
 struct Scan {
   u32* vcnt;      // [pool blocks * 512] all zero between scans
@@ -210,6 +210,7 @@ __global__ __launch_bounds__(1024) void k_scan_offsets(const Tab t, const Scan s
   __shared__ u32 s_tot[16], s_nch[16], s_nbig[16], s_rbase, s_cbase, s_bbase;
   __shared__ u32 s_hit[kScanWindow], s_nhit;
   static_assert(kScanWindow <= 64, "one wave reads the window's stamps");
+  static_assert(SC_PLACED == 0 && SC_CHUNKS == 1, "one 64-bit word");
   const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (blockIdx.x == 0 && tid < (u32) SC_N) sc.ctr_next[tid] = 0;  // the next scan's counters (this scan's walk is complete)
   MRH_SC_TS(1, 0);
@@ -293,12 +294,20 @@ __global__ __launch_bounds__(1024) void k_scan_offsets(const Tab t, const Scan s
     }
     if (lane == 0) { s_tot[wave] = total; s_nch[wave] = nch - nbig; s_nbig[wave] = nbig; }
     __syncthreads();
-    if (tid == 0 || tid == 64 || tid == 128) {  // three counters, three lanes: the round trips overlap
-      const u32* src = tid == 0 ? s_tot : tid == 64 ? s_nch : s_nbig;
+    // Every workgroup with touched blocks reserves here, at the same time, from the same counters: returning atomics on one
+    // address are served one after the other (~15 ns each), 250 workgroups x 2 counters were 7 of this launch's 10 us.  Records
+    // and chunks are reserved with ONE 64-bit add (neither half can carry: the host bounds both below 2^32); the runs beyond a
+    // wave's slice — rare — keep their own, on a second lane so that the round trips overlap.
+    if (tid == 0) {
+      u32 rec_sum = 0, ch_sum = 0;
+      for (int k = 0; k < 16; k++) { rec_sum += s_tot[k]; ch_sum += s_nch[k]; }
+      const u64 add = (u64) rec_sum | ((u64) ch_sum << 32);
+      const u64 got = add ? atomicAdd((unsigned long long*) &sc.ctr[SC_PLACED], (unsigned long long) add) : 0ull;
+      s_rbase = (u32) got; s_cbase = (u32) (got >> 32);
+    } else if (tid == 64) {
       u32 sum = 0;
-      for (int k = 0; k < 16; k++) sum += src[k];
-      const u32 got = sum ? atomicAdd(&sc.ctr[tid == 0 ? SC_PLACED : tid == 64 ? SC_CHUNKS : SC_BIG], sum) : 0u;
-      if (tid == 0) s_rbase = got; else if (tid == 64) s_cbase = got; else s_bbase = got;
+      for (int k = 0; k < 16; k++) sum += s_nbig[k];
+      s_bbase = sum ? atomicAdd(&sc.ctr[SC_BIG], sum) : 0u;
     }
     __syncthreads();
     if (total) {
