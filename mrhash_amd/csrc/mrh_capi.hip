@@ -2726,6 +2726,7 @@ int mrh_integrate_points(mrh_ctx* c, int n_frames_invalidate) {
       sc.ctr = c->d_scan_ctr + (sc.seq & 1u) * SC_N;
       sc.ctr_next = c->d_scan_ctr + ((sc.seq + 1u) & 1u) * SC_N;
       sc.ord_shift = t.multi_res ? 5 : 0;
+      sc.narrow = ((uint64_t) np << sc.ord_shift) <= (1ull << 23) && !getenv("MRH_SCAN_WIDE_RECORDS") ? 1 : 0;  // tag + 9 bits of voxel index in one word (MRH_SCAN_WIDE_RECORDS=1: tests)
       sc.order = order;
       const size_t lds = (size_t) (2 * slots * 256 + 2 * kScanSetSize) * sizeof(u32);
       k_scan_walk<<<grid, 256, lds, s>>>(k, m, t, pts, normals, np, sc, (int) slots);

@@ -60,16 +60,31 @@ struct Scan {
   float* st_sdf;
   uint4* st_grp;  // stash: {voxel id, records, records of the voxel that arrived before this group, 0}
   uint2* wgdesc;  // per walk workgroup {records, groups}
-  uint4* rec;     // placed records: {point index << ord_shift | ordinal, sdf, the voxel's index in its block, 0}
+  uint4* rec;     // placed records: {point index << ord_shift | ordinal, sdf, the voxel's index in its block, 0} — or, when the tag
+                  // leaves room for the voxel's 9 bits (narrow: tags below 2^23, every scan up to 8 M points; 256 k on variance-adaptive
+                  // maps), 8 bytes: {tag << 9 | index, sdf}: the records cross HBM twice, as k_scan_place's output and k_scan_apply's input
   uint4* chunks;  // {block | coarse, v0 | v1 << 16, r0, r1}; runs beyond kScanWaveRecs from the END of the array downwards
   u32 rec_cap, chunk_cap, seq;
   int ord_shift;  // 5 on variance-adaptive maps (a beam can cross several fine cells of one coarse voxel), else 0
+  int narrow;     // 8-byte records (see rec)
   BeamOrder order;  // which 256 beams a walk workgroup takes (mrh_lidar.h)
 };
 
 // Same-address atomics with a return value cost ~15 ns each on this chip whoever issues them (measured: 3 000 appends to one
 // list counter = 45 us of a kernel), so nothing here takes one per block or per workgroup: the stash is addressed by workgroup,
 // the touched blocks are found by their stamps, block bases and chunk slots are reserved 16 blocks at a time.
+
+__device__ __forceinline__ uint4 scan_load_rec(const Scan& sc, const u32 i) {  // -> {tag, sdf bits, voxel index in the block, 0}
+  if (sc.narrow) {
+    const uint2 v = ((const uint2*) sc.rec)[i];
+    return make_uint4(v.x >> 9, v.y, v.x & 511u, 0u);
+  }
+  return sc.rec[i];
+}
+__device__ __forceinline__ void scan_store_rec(const Scan& sc, const u32 i, const u32 tag, const float sdf, const u32 li) {
+  if (sc.narrow) ((uint2*) sc.rec)[i] = make_uint2((tag << 9) | li, __float_as_uint(sdf));
+  else sc.rec[i] = make_uint4(tag, __float_as_uint(sdf), li, 0u);
+}
 
 #ifdef MRH_SCAN_TRACE
 // tuning builds only (tools/trace_scan.sh): wall-clock stamps (100 MHz) of thread 0 of every workgroup at its phase boundaries;
@@ -366,7 +381,7 @@ __global__ __launch_bounds__(256) void k_scan_place(const Scan sc, const int slo
     const u32 slot = s_base[meta.x & 0x1FFFu] + (meta.x >> 13);
     if (slot < sc.rec_cap) {
       const u32 pidx = sc.order.point(blockIdx.x, meta.y >> 5);
-      sc.rec[slot] = make_uint4(sc.ord_shift ? (pidx << 5) | (meta.y & 31u) : pidx, __float_as_uint(sdf), s_li[meta.x & 0x1FFFu], 0u);
+      scan_store_rec(sc, slot, sc.ord_shift ? (pidx << 5) | (meta.y & 31u) : pidx, sdf, s_li[meta.x & 0x1FFFu]);
     }
   }
   MRH_SC_TS(2, 1);
@@ -635,7 +650,7 @@ __global__ __launch_bounds__(256, 6) void k_scan_apply(const Map m, const Tab t,
 #pragma unroll
         for (int r = 0; r < 4; r++) {
           const u32 q = lane + 64u * r;
-          const uint4 rc = q < nr ? sc.rec[r0 + q] : make_uint4(kScanEmpty, 0u, 0u, 0u);
+          const uint4 rc = q < nr ? scan_load_rec(sc, r0 + q) : make_uint4(kScanEmpty, 0u, 0u, 0u);
           tg[r] = rc.x; sv[r] = __uint_as_float(rc.y); rank[r] = 0;
           L.tag[q] = rc.x;  // the padding (all ones) is larger than any tag: it counts for nobody
         }
@@ -654,7 +669,7 @@ __global__ __launch_bounds__(256, 6) void k_scan_apply(const Map m, const Tab t,
       } else {
         u32 N = 512;
         for (u32 q = lane; q < N; q += 64) {
-          const uint4 rc = q < nr ? sc.rec[r0 + q] : make_uint4(kScanEmpty, 0u, 0u, 0u);
+          const uint4 rc = q < nr ? scan_load_rec(sc, r0 + q) : make_uint4(kScanEmpty, 0u, 0u, 0u);
           L.tag[q] = rc.x;
           L.sdf[q] = __uint_as_float(rc.y);
         }
@@ -681,7 +696,7 @@ __global__ __launch_bounds__(256, 6) void k_scan_apply(const Map m, const Tab t,
       stv[r] = lane + 64u * r < nv ? pc[64 * r] : 0u;
       const u32 q = lane + 64u * r;
       tg[r] = 0; li[r] = 0; sv[r] = 0.f;
-      if (q < nr) { const uint4 rc = sc.rec[r0 + q]; tg[r] = rc.x; sv[r] = __uint_as_float(rc.y); li[r] = rc.z; }
+      if (q < nr) { const uint4 rc = scan_load_rec(sc, r0 + q); tg[r] = rc.x; sv[r] = __uint_as_float(rc.y); li[r] = rc.z; }
     }
 #pragma unroll
     for (int r = 0; r < 8; r++) {
@@ -765,7 +780,7 @@ __global__ __launch_bounds__(256, 6) void k_scan_apply(const Map m, const Tab t,
       u32 N = 1024;
       while (N < nr) N <<= 1;
       for (u32 q = tid; q < N; q += 256) {
-        const uint4 rc = q < nr ? sc.rec[r0 + q] : make_uint4(kScanEmpty, 0u, 0u, 0u);
+        const uint4 rc = q < nr ? scan_load_rec(sc, r0 + q) : make_uint4(kScanEmpty, 0u, 0u, 0u);
         s_tag[q] = rc.x;
         s_sdf[q] = __uint_as_float(rc.y);
       }
@@ -779,7 +794,7 @@ __global__ __launch_bounds__(256, 6) void k_scan_apply(const Map m, const Tab t,
         for (u32 q = tid; q < kScanBigRecs; q += 256) s_tag[q] = 0;
         __syncthreads();
         for (u32 q = tid; q < nr; q += 256) {
-          const uint4 rc = sc.rec[r0 + q];
+          const uint4 rc = scan_load_rec(sc, r0 + q);
           const u32 d = rc.x - w0;
           if (d < kScanBigRecs) { s_sdf[d] = __uint_as_float(rc.y); s_tag[d] = 1; }
         }

@@ -85,6 +85,20 @@ def test_scan_layout_is_a_hint_for_the_beam_order_only(hip, oracle, var_threshol
     ref.close()
 
 
+@pytest.mark.parametrize("var_threshold", [0.0, 0.05])
+def test_wide_records_build_the_same_map(hip, oracle, monkeypatch, var_threshold):
+    """The placed records are 8 bytes when the order tag leaves room for the voxel's 9 bits (every test above), 16 otherwise
+    (scans beyond 8 M points; 256 k on variance-adaptive maps): MRH_SCAN_WIDE_RECORDS=1 sends a small scan through the wide form."""
+    monkeypatch.setenv("MRH_SCAN_WIDE_RECORDS", "1")
+    a, b = _pair(hip, oracle, dict(sdf_var_threshold=var_threshold))
+    scene = synth.street_canyon()
+    for t, q in synth.drive_poses(3, step=1.5):
+        _feed((a, b), synth.lidar_scan(scene, t, q, rows=32, cols=512), t, q)
+    a.sync()
+    r = pu.compare_maps(a, b)
+    assert r["blocks"] > 1000 and r["sdf_bit_exact"] and r["sumsq_bit_exact"]
+
+
 def test_scans_across_the_wrap_of_the_block_stamps(hip, oracle, monkeypatch):
     """a block's stamp is `2 * sequence + coarse` in 32 bits, so the sequence restarts at 2^31 — with clean stamps
     and both counter sets at zero.  Six scans whose sequence numbers straddle the restart build the oracle's map."""
