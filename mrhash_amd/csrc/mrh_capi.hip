@@ -2621,7 +2621,7 @@ static int scan_prepare(mrh_ctx* c, const uint64_t n, const uint64_t rec_bound, 
     const uint64_t chunk_cap = std::min<uint64_t>(c->num_blocks, cap) + cap / 128 + 2 * cap / (kScanLongRun + 1) + 64;
     HIP_TRY(c, hipMalloc((void**) &sc.st_meta, cap * sizeof(uint2)));
     HIP_TRY(c, hipMalloc((void**) &sc.st_sdf, cap * sizeof(float)));
-    HIP_TRY(c, hipMalloc((void**) &sc.st_grp, cap * sizeof(uint4)));
+    HIP_TRY(c, hipMalloc((void**) &sc.st_grp, cap * sizeof(uint2)));
     HIP_TRY(c, hipMalloc((void**) &sc.rec, cap * sizeof(uint4)));
     HIP_TRY(c, hipMalloc((void**) &sc.chunks, chunk_cap * sizeof(uint4)));
     sc.rec_cap = (u32) std::min<uint64_t>(cap, 0xFFFFFFF0ull);

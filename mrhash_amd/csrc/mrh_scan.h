@@ -56,9 +56,10 @@ struct Scan {
   u32* bstamp;    // [pool blocks] 2 * sequence number of the last scan that touched the block + 1 if it holds coarse units
   u32* ctr;       // this scan's counters [SC_N]
   u32* ctr_next;  // the next scan's (zeroed by k_scan_offsets)
-  uint2* st_meta; // stash of walk workgroup w at w * 256 * slots: {group | rank in group << 13, lane << 5 | ordinal along the beam}
+  uint2* st_meta; // stash of walk workgroup w at w * 256 * slots: {group | rank in group << 13, lane << 5 | ordinal along the beam}; on fine
+                  // maps (ord_shift 0) ONE word a record: group | rank << 13 | lane << 21
   float* st_sdf;
-  uint4* st_grp;  // stash: {voxel id, records, records of the voxel that arrived before this group, 0}
+  uint2* st_grp;  // stash: {voxel id, records of the voxel that arrived before this group}
   uint2* wgdesc;  // per walk workgroup {records, groups}
   uint4* rec;     // placed records: {point index << ord_shift | ordinal, sdf, the voxel's index in its block, 0} — or, when the tag
                   // leaves room for the voxel's 9 bits (narrow: tags below 2^23, every scan up to 8 M points; 256 k on variance-adaptive
@@ -173,7 +174,7 @@ __global__ __launch_bounds__(256) void k_scan_walk(const Cam c, const Map m, con
 #pragma unroll
     for (int k = 0; k < PER; k++)
       if (key[k] != kScanEmpty) {
-        sc.st_grp[off + g[k]] = make_uint4(key[k], cv[k], prev[k], 0u);
+        sc.st_grp[off + g[k]] = make_uint2(key[k], prev[k]);
         const u32 H = (key[k] & ~kScanCoarse) >> 9, stamp = sc.seq * 2u + (key[k] >> 31);
         sc.bstamp[H] = stamp;  // every writer stores the same value (a test first would cost a dependent load per group)
       }
@@ -194,14 +195,15 @@ __global__ __launch_bounds__(256) void k_scan_walk(const Cam c, const Map m, con
         if ((ovf >> j) & 1u) {
           const u32 g = atomicAdd(&s_ng, 1u);
           const u32 prev = atomicAdd(&sc.vcnt[v & ~kScanCoarse], 1u);
-          sc.st_grp[off + g] = make_uint4(v, 1u, prev, 0u);
+          sc.st_grp[off + g] = make_uint2(v, prev);
           sc.bstamp[(v & ~kScanCoarse) >> 9] = sc.seq * 2u + (v >> 31);
           meta = g;
         } else {
           meta = s_cnt[v & 0xFFFu] | ((v >> 12) << 13);  // v = set slot (< 4096) | rank << 12
         }
         const u32 at = off + pos + (u32) __popcll(bal & lanemask_lt());
-        sc.st_meta[at] = make_uint2(meta, (tid << 5) | j);
+        if (sc.ord_shift) sc.st_meta[at] = make_uint2(meta, (tid << 5) | j);
+        else ((u32*) sc.st_meta)[at] = meta | (tid << 21);  // fine maps: a beam meets a voxel once — the rank fits 8 bits, the ordinal is not needed
         sc.st_sdf[at] = s_sdf[j * 256 + tid];
       }
       pos += (u32) __popcll(bal);
@@ -370,13 +372,15 @@ __global__ __launch_bounds__(256) void k_scan_place(const Scan sc, const int slo
   const uint2 d = sc.wgdesc[blockIdx.x];
   const u32 off = blockIdx.x * 256u * (u32) slots, R = d.x, G = d.y;
   for (u32 g = threadIdx.x; g < G; g += 256) {
-    const uint4 grp = sc.st_grp[off + g];
-    s_base[g] = sc.vcnt[grp.x & ~kScanCoarse] + grp.z;
+    const uint2 grp = sc.st_grp[off + g];
+    s_base[g] = sc.vcnt[grp.x & ~kScanCoarse] + grp.y;
     s_li[g] = (unsigned short) (grp.x & 511u);
   }
   __syncthreads();
   for (u32 r = threadIdx.x; r < R; r += 256) {
-    const uint2 meta = sc.st_meta[off + r];
+    uint2 meta;
+    if (sc.ord_shift) meta = sc.st_meta[off + r];
+    else { const u32 w = ((const u32*) sc.st_meta)[off + r]; meta = make_uint2(w & 0x1FFFFFu, (w >> 21) << 5); }
     const float sdf = sc.st_sdf[off + r];
     const u32 slot = s_base[meta.x & 0x1FFFu] + (meta.x >> 13);
     if (slot < sc.rec_cap) {
