@@ -276,7 +276,6 @@ struct mrh_ctx {
   QSum* d_qt_sums = nullptr; u32* d_qt_flags = nullptr; u32* d_qt_unc = nullptr; u64* d_qt_marks = nullptr; u64* d_qt_pos = nullptr;
   mrh_splat_seed* d_qt_parked = nullptr; mrh_splat_seed* d_qt_seeds = nullptr; mrh_qtree_leaf* d_qt_leaves = nullptr;
   u64* d_qt_misc = nullptr;  // [0] totals (leaves | seeds << 32), [1] uncertain-node counter (low word)
-  void* d_qt_tmp = nullptr; size_t qt_tmp_bytes = 0;
   int qt_literal = 0;        // MRH_QTREE_LITERAL=1: every node error through the reference's summation order (cross-check)
   uint32_t qt_last_literal = 0;
   std::vector<mrh_splat_seed> seeds;
@@ -286,7 +285,6 @@ struct mrh_ctx {
   int scan_layout_hint = 0;    // mrh_set_scan_layout / MRH_SCAN_ROW_LEN: > 0 points per row of the caller's organised scans, 0 find out (host clouds), < 0 none
   int scan_row_len = 0;        // ... of the CURRENT cloud (0: not organised, or not known)
   int scan_patch_log2 = 4;     // MRH_SCAN_PATCH_LOG2: columns (log2) of the beam patch a walk workgroup takes from an organised scan; 8 = 256 consecutive points
-  int lidar_sort_rocprim = 0;  // MRH_LIDAR_SORT_ROCPRIM=1: the record sort of a scan through rocPRIM's onesweep instead of mrh_sort.h (cross-check)
   int mr_fused = 1;          // MRH_MR_FUSED=0: multi-resolution maps always through the general kernels (mrh_kernels.h)
   bool mr_next_general = true;    // the next multi-resolution frame must take the general path (frame 0 / after a starve frame / after an import)
   bool mr_summaries_valid = false;  // fast.summary / summary_c describe every live block (the general kernels do not maintain them)
@@ -446,7 +444,7 @@ void free_all(mrh_ctx* c) {
   for (hipEvent_t e : c->comm_ev) if (e) (void) hipEventDestroy(e);
   for (auto& e : c->comm_ev_pool) { (void) hipEventDestroy(e.a); (void) hipEventDestroy(e.b); }
   for (auto& e : c->comm_ev_pending) { (void) hipEventDestroy(e.a); (void) hipEventDestroy(e.b); }
-  F(c->d_qt_sums); F(c->d_qt_flags); F(c->d_qt_unc); F(c->d_qt_marks); F(c->d_qt_pos); F(c->d_qt_parked); F(c->d_qt_seeds); F(c->d_qt_leaves); F(c->d_qt_misc); F(c->d_qt_tmp);
+  F(c->d_qt_sums); F(c->d_qt_flags); F(c->d_qt_unc); F(c->d_qt_marks); F(c->d_qt_pos); F(c->d_qt_parked); F(c->d_qt_seeds); F(c->d_qt_leaves); F(c->d_qt_misc);
   for (int i = 0; i < c->npend; i++) if (c->pendq[i].profile) c->ev_pool.push_back(c->pendq[i].ev);
   c->npend = 0;
   for (auto& e : c->ev_pool) { (void) hipEventDestroy(e.a); (void) hipEventDestroy(e.b); }
@@ -1313,7 +1311,6 @@ int mrh_create(const mrh_params* p, mrh_ctx** out) {
   c->V.pin = c->C.pin = c->f64_link;  // fp32 link: the doubles are written by the host only
   if (const char* g = getenv("MRH_QTREE_LITERAL")) c->qt_literal = atoi(g) ? 1 : 0;
   if (const char* g = getenv("MRH_MR_FUSED")) c->mr_fused = atoi(g) ? 1 : 0;
-  if (const char* g = getenv("MRH_LIDAR_SORT_ROCPRIM")) c->lidar_sort_rocprim = atoi(g) ? 1 : 0;
   if (const char* g = getenv("MRH_SCAN_ROW_LEN")) c->scan_layout_hint = atoi(g);
   if (const char* g = getenv("MRH_SCAN_PATCH_LOG2")) { const int v = atoi(g); if (v >= 0 && v <= 8) c->scan_patch_log2 = v; }
   if (const char* g = getenv("MRH_LIDAR_BUCKETS")) c->lidar_buckets = atoi(g) ? 1 : 0;
@@ -2526,34 +2523,14 @@ int mrh_upload_normals(mrh_ctx* c, const float* nxyz, uint64_t n) {
 
 namespace {
 // stable radix sort of the scan's (voxel id, sdf) records on key bits [0, end_bit): the padding key (all ones) ends up last,
-// equal ids keep their point-major order
-template <typename Config, typename K>
-int lidar_sort_with(mrh_ctx* c, K* k0, K* k1, float* v0, float* v1, const size_t n, const int end_bit) {
-  hipStream_t s = c->stream;
-  size_t need = 0;
-  HIP_TRY(c, rocprim::radix_sort_pairs<Config>(nullptr, need, k0, k1, v0, v1, n, 0, end_bit, s));
-  if (need > c->sort_tmp_bytes) {
-    HIP_TRY(c, hipStreamSynchronize(s));
-    if (c->d_sort_tmp) HIP_TRY(c, hipFree(c->d_sort_tmp));
-    c->d_sort_tmp = nullptr;
-    HIP_TRY(c, hipMalloc(&c->d_sort_tmp, need));
-    c->sort_tmp_bytes = need;
-  }
-  size_t tb = c->sort_tmp_bytes;
-  HIP_TRY(c, rocprim::radix_sort_pairs<Config>(c->d_sort_tmp, tb, k0, k1, v0, v1, n, 0, end_bit, s));
-  return MRH_OK;
-}
+// equal ids keep their point-major order (mrh_sort.h)
 // *out_buf = which of the two buffer pairs holds the sorted records
 template <typename K>
 int lidar_sort(mrh_ctx* c, K* k0, K* k1, float* v0, float* v1, const size_t n, const int end_bit, int* out_buf) {
   const u32 ntiles = (u32) ((n + kSortTile - 1) / kSortTile);
   const u32 total = 256u * ntiles;
-  if (c->lidar_sort_rocprim || total > kSortScanMax) {
-    // merge-sort limit 0: always the onesweep path (rocPRIM would sort up to 2^20 items with block sort + ~10 merge passes)
-    using Cfg = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 0>;
-    *out_buf = 1;
-    return lidar_sort_with<Cfg>(c, k0, k1, v0, v1, n, end_bit);
-  }
+  if (total > kSortScanMax)
+    return fail(c, MRH_ERR_CAPACITY, "mrh_integrate_points: %zu records in one scan through the sorted path (limit %llu)", n, (unsigned long long) kSortScanMax * 4ull);
   // the scan-sized sort of mrh_sort.h: per 8-bit digit a tile histogram, a one-workgroup scan, a stable scatter
   hipStream_t s = c->stream;
   if ((size_t) total * sizeof(u32) + 1024 > c->sort_tmp_bytes) {
@@ -2918,13 +2895,6 @@ int mrh_splat_seeds(mrh_ctx* c, float qtree_thresh, int qtree_min_pixel_size, co
     HIP_TRY(c, hipMalloc((void**) &c->d_qt_seeds, n * sizeof(mrh_splat_seed)));
     HIP_TRY(c, hipMalloc((void**) &c->d_qt_leaves, n * sizeof(mrh_qtree_leaf)));
     HIP_TRY(c, hipMalloc((void**) &c->d_qt_misc, 2 * sizeof(u64)));
-    size_t need = 0;
-    HIP_TRY(c, rocprim::exclusive_scan(nullptr, need, c->d_qt_marks, c->d_qt_pos, (u64) 0, n, rocprim::plus<u64>(), s));
-    if (need > c->qt_tmp_bytes) {
-      F(c->d_qt_tmp);
-      HIP_TRY(c, hipMalloc(&c->d_qt_tmp, need));
-      c->qt_tmp_bytes = need;
-    }
   }
   c->qt = qt;
   rc = send_uploads(c, c->stream);
@@ -2942,8 +2912,7 @@ int mrh_splat_seeds(mrh_ctx* c, float qtree_thresh, int qtree_min_pixel_size, co
   k_qt_decide<<<grid, 256, 0, s>>>(qt, qtree_thresh, c->d_qt_sums, c->qt_literal, c->d_qt_flags, c->d_qt_unc, unc_count);
   k_qt_literal<<<512, 256, 0, s>>>(qt, c->d_rgb, qtree_thresh, c->d_qt_unc, unc_count, c->d_qt_flags);
   k_qt_emit<<<grid, 256, 0, s>>>(qt, c->cam, c->map, c->tab, c->d_depth, c->d_rgb, c->d_qt_flags, c->d_qt_marks, c->d_qt_parked);
-  size_t tb = c->qt_tmp_bytes;
-  HIP_TRY(c, rocprim::exclusive_scan(c->d_qt_tmp, tb, c->d_qt_marks, c->d_qt_pos, (u64) 0, (size_t) qt.total, rocprim::plus<u64>(), s));
+  k_chain_scan_u64<<<1, 1024, 0, s>>>(c->d_qt_marks, (u32) qt.total, c->d_qt_pos);
   k_qt_scatter<<<grid, 256, 0, s>>>(qt, c->d_qt_marks, c->d_qt_pos, c->d_qt_parked, c->d_qt_leaves, c->d_qt_seeds, c->d_qt_misc);
   rc = mark_frame(c);
   if (rc) return rc;
@@ -3133,21 +3102,22 @@ int mrh_extract_triangles(mrh_ctx* c, const mrh_triangle** out_tris, uint64_t* o
   if (n > 0) {
     // Everything between the block count and the triangle total stays on the device: canonical order by a radix sort of the
     // packed keys (key order == (x, y, z) order), the 27-block neighbourhoods resolved by one thread per (block, neighbour),
-    // per-block triangle counts -> exclusive scan (rocPRIM) -> exact offsets, the emit pass launched right behind it.  The
+    // per-block triangle counts -> exclusive scan (k_mc_scan_total) -> exact offsets, the emit pass launched right behind it.  The
     // sorted list and the counts are read back only if somebody asks (mrh_get_triangle_blocks).
     u64 *k_in, *k_out, *d_offsets, *d_total;
     int4* sorted;
     u32 *d_counts, *d_nb, *d_rec_base, *d_rec_n, *d_rec_ctr, *d_partial;
     uint8_t* d_per_voxel;  // triangles per voxel from the count pass: k_mc<emit> (the fallback of the record pass) skips the empty ones
     void* tmp;
-    size_t sort_bytes = 0, scan_bytes = 0;
-    HIP_TRY(c, rocprim::radix_sort_pairs(nullptr, sort_bytes, (u64*) nullptr, (u64*) nullptr, (int4*) nullptr, (int4*) nullptr, (size_t) n, 0, 63, s));
-    HIP_TRY(c, rocprim::exclusive_scan(nullptr, scan_bytes, (u32*) nullptr, (u64*) nullptr, (u64) 0, (size_t) n, rocprim::plus<u64>(), s));
-    const size_t tmp_bytes = std::max(sort_bytes, scan_bytes);
+    int4* sorted2 = nullptr;
+    const bool no_rank_sort = getenv("MRH_MC_RADIX_SORT") != nullptr;  // MRH_MC_RADIX_SORT=1: the radix sort of mrh_sort.h for every list (A/B, tests)
+    const bool radix = n > kRankSortMax || no_rank_sort;
+    const u32 sort_tiles = (u32) ((n + kSortTile - 1) / kSortTile);
+    const size_t tmp_bytes = radix ? ((size_t) 256 * sort_tiles + 256) * sizeof(u32) : 0;  // digit totals + the tile histogram of a pass
     {
       MeshScratch a;
-      const size_t rank_words = n <= kRankSortMax ? (size_t) n * (size_t) ((n + kRankSlice - 1) / kRankSlice) : 1;  // k_block_rank: one row of partial ranks per slice
-      a.bytes = (size_t) n * (8 * 3 + 16 + 4 + 4 * kMcNbStride + 512 + 8) + rank_words * 4 + tmp_bytes + 32 * 256;
+      const size_t rank_words = !radix ? (size_t) n * (size_t) ((n + kRankSlice - 1) / kRankSlice) : 1;  // k_block_rank: one row of partial ranks per slice
+      a.bytes = (size_t) n * (8 * 3 + 16 + 4 + 4 * kMcNbStride + 512 + 8) + rank_words * 4 + tmp_bytes + (radix ? (size_t) n * sizeof(int4) + 256 : 0) + 32 * 256;
       rc = arena_get(c, 0, a.bytes, &a.base);
       if (rc) return rc;
       k_in = a.take<u64>((size_t) n); k_out = a.take<u64>((size_t) n); d_offsets = a.take<u64>((size_t) n);
@@ -3156,21 +3126,34 @@ int mrh_extract_triangles(mrh_ctx* c, const mrh_triangle** out_tris, uint64_t* o
       d_rec_base = a.take<u32>((size_t) n); d_rec_n = a.take<u32>((size_t) n); d_rec_ctr = a.take<u32>(2);
       d_partial = a.take<u32>(rank_words);
       tmp = a.take<char>(tmp_bytes ? tmp_bytes : 1);
+      if (radix) sorted2 = a.take<int4>((size_t) n);
     }
     if (!c->h_mc) {
       HIP_TRY(c, hipHostMalloc((void**) &c->h_mc, 8 * sizeof(u64), hipHostMallocDefault));
       memset(c->h_mc, 0, 8 * sizeof(u64));
     }
-    const bool no_rank_sort = getenv("MRH_MC_RADIX_SORT") != nullptr;  // MRH_MC_RADIX_SORT=1: rocPRIM's sort + scan for every list (A/B, tests)
-    if (n <= kRankSortMax && !no_rank_sort) {  // canonical order by counting (mrh_mc.h: k_block_rank)
+    if (!radix) {  // canonical order by counting (mrh_mc.h: k_block_rank)
       const int slices = (n + kRankSlice - 1) / kRankSlice;
       k_list_keys<<<(n + 255) / 256, 256, 0, s>>>(c->tab.compact, n, k_in);
       k_block_rank<<<dim3((n + 255) / 256, slices), 256, 0, s>>>(k_in, n, d_partial);
       k_block_scatter<<<(n + 255) / 256, 256, 0, s>>>(c->tab.compact, n, d_partial, slices, sorted);
     } else {
+      // lists beyond the counting rank: the stable byte-wise radix sort of mrh_sort.h over the 64-bit position keys, the list
+      // entries riding along (eight passes of histogram / scan / scatter; the first reads the list itself, the last lands in `sorted`)
       k_list_keys<<<(n + 255) / 256, 256, 0, s>>>(c->tab.compact, n, k_in);
-      size_t bytes = tmp_bytes;
-      HIP_TRY(c, rocprim::radix_sort_pairs(tmp, bytes, k_in, k_out, c->tab.compact, sorted, (size_t) n, 0, 63, s));
+      u32* totals = (u32*) tmp;
+      u32* hist = totals + 256;
+      u64* ks[2] = {k_in, k_out};
+      int4* vs[2] = {sorted, sorted2};
+      int src = 0;
+      for (int shift = 0; shift < 64; shift += 8) {
+        k_sort_hist<u64><<<sort_tiles, kSortThreads, 0, s>>>(ks[src], (u32) n, shift, hist, sort_tiles);
+        k_sort_scan<<<256, 256, 0, s>>>(hist, sort_tiles, totals);
+        k_sort_scatter<u64, int4><<<sort_tiles, kSortThreads, 0, s>>>(ks[src], shift == 0 ? (const int4*) c->tab.compact : (const int4*) vs[src], ks[src ^ 1], vs[src ^ 1], (u32) n, shift,
+                                                                      hist, sort_tiles, totals);
+        src ^= 1;
+      }
+      static_assert((64 / 8) % 2 == 0, "an even number of passes ends in the first buffer pair");
     }
     k_mc_neighbors<<<(int) (((size_t) n * 32 + 255) / 256), 256, 0, s>>>(c->tab, sorted, n, d_nb);
     if (dbg) { HIP_TRY(c, hipStreamSynchronize(s)); t1 = now(); }
@@ -3216,15 +3199,10 @@ int mrh_extract_triangles(mrh_ctx* c, const mrh_triangle** out_tris, uint64_t* o
     if (timed) hipExtLaunchKernelGGL((k_mc<false>), dim3(grid), dim3(kMcThreads), 0, s, c->mc_ev[0], c->mc_ev[1], 0u, c->map, c->tab, (const int4*) sorted, n, (const u32*) d_nb,
                                      (u32*) d_counts, (const u64*) nullptr, (mrh_triangle*) nullptr, (u64) 0, (uint8_t*) d_per_voxel, sdf_bound, mc_flags, R);
     else k_mc<false><<<grid, kMcThreads, 0, s>>>(c->map, c->tab, sorted, n, d_nb, d_counts, nullptr, nullptr, (u64) 0, d_per_voxel, sdf_bound, mc_flags, R);
-    if (n <= kScanTotalMax && !no_rank_sort) {
-      k_mc_scan_total<<<1, 1024, 0, s>>>(d_counts, n, d_offsets, use_records ? d_rec_ctr : nullptr, d_total);
-      HIP_TRY(c, hipMemcpyAsync(c->h_mc, d_total, 2 * sizeof(u64), hipMemcpyDeviceToHost, s));
-    } else {
-      size_t bytes = tmp_bytes;
-      HIP_TRY(c, rocprim::exclusive_scan(tmp, bytes, d_counts, d_offsets, (u64) 0, (size_t) n, rocprim::plus<u64>(), s));
-      k_mc_total<<<1, 1, 0, s>>>(d_offsets, d_counts, n, use_records ? d_rec_ctr : nullptr, d_total);
-      HIP_TRY(c, hipMemcpyAsync(c->h_mc, d_total, 2 * sizeof(u64), hipMemcpyDeviceToHost, s));
-    }
+    // exact offsets + the total: one workgroup chains tiles of 8 192 counts through a carry (10^6 blocks: 122 tiles, ~0.2 ms
+    // next to the ~20 ms of their count pass)
+    k_mc_scan_total<<<1, 1024, 0, s>>>(d_counts, n, d_offsets, use_records ? d_rec_ctr : nullptr, d_total);
+    HIP_TRY(c, hipMemcpyAsync(c->h_mc, d_total, 2 * sizeof(u64), hipMemcpyDeviceToHost, s));
     auto emit = [&](const u64 cap, const int flag_overflow, const bool from_records) {
       if (from_records) {
         if (timed) hipExtLaunchKernelGGL(k_mc_emit_records, dim3(grid), dim3(kMcThreads), 0, s, c->mc_ev[2], c->mc_ev[3], 0u, c->map, c->tab, (const int4*) sorted, n, R,

@@ -10,14 +10,13 @@
 //                    the reference updates a voxel with a non-atomic read-modify-write per point.  Here a point's
 //                    VOXEL-level DDA only produces (voxel id, clamped sdf) records — counted, prefix-summed and written at
 //                    exact offsets in point-major order, no atomics.  The records are sorted by voxel id with a STABLE radix
-//                    sort (rocPRIM onesweep over the id's significant bits), which keeps every voxel's records in ascending
+//                    sort (mrh_sort.h, over the id's significant bits), which keeps every voxel's records in ascending
 //                    point index, and
 //   k_points_apply   folds each voxel's run in that order (combineVoxel, vhu.cuh:167-181, and the variance term) — the
 //                    oracle's sequential order (D6).  A workgroup stages a chunk of the sorted records in LDS; the lane at
 //                    the head of a run walks it there instead of through dependent global loads (round 2: 57 us per scan).
 #pragma once
 
-#include <rocprim/rocprim.hpp>
 
 #include "mrh_fast2.h"
 

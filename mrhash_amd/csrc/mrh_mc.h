@@ -493,7 +493,7 @@ __global__ __launch_bounds__(256) void k_list_keys(const int4* __restrict__ list
 // are smaller, and adds that to the block's rank; k_block_scatter then moves the entries.  n^2 comparisons — 5 x 10^7 for the
 // 7 000 blocks of a 640 x 480 room, a few microseconds of the whole chip — against rocPRIM's radix sort of 64-bit keys, which
 // for a list this small is one workgroup working for 74 us (profiles/r04/driver_cmd_mc_kernel_stats.csv).  Lists beyond
-// kRankSortMax keep the radix sort.
+// kRankSortMax take the radix sort of mrh_sort.h.
 constexpr int kRankSlice = 512;
 constexpr int kRankSortMax = 32768;
 // the slice's keys are the same for every lane: they come through the scalar cache (uniform index into the packed-key array of
@@ -521,8 +521,7 @@ __global__ __launch_bounds__(256) void k_block_scatter(const int4* __restrict__ 
 // per-block triangle counts -> exact offsets, the total and the record demand for the host: one workgroup.  The counts go
 // through LDS a tile at a time (coalesced loads; the first version gave every thread a contiguous piece of the list in global
 // memory: 2 x 14 dependent loads per thread, 17.6 us for 14 k blocks), every thread scans eight neighbours of the tile, the
-// tiles chain through a running carry.  Lists beyond kScanTotalMax blocks keep rocPRIM's scan + k_mc_total.
-constexpr int kScanTotalMax = 65536;
+// tiles chain through a running carry (a list of any length: 10^6 blocks are 122 tiles).
 constexpr int kScanTile = 8192;
 __global__ __launch_bounds__(1024) void k_mc_scan_total(const u32* __restrict__ counts, const int n, u64* __restrict__ offsets,
                                                         const u32* __restrict__ rec_ctr, u64* __restrict__ total) {
@@ -737,12 +736,6 @@ __global__ __launch_bounds__(256) void k_mc_neighbors(const Tab t, const int4* _
     }
   }
   nb[e * kMcNbStride + i] = val;
-}
-// triangle total of an extraction = last exclusive offset + last count
-__global__ void k_mc_total(const u64* __restrict__ offsets, const u32* __restrict__ counts, const int n, const u32* __restrict__ rec_ctr,
-                           u64* __restrict__ total) {
-  total[0] = offsets[n - 1] + counts[n - 1];
-  total[1] = rec_ctr ? ((u64) rec_ctr[0] | ((u64) (rec_ctr[1] & 1u) << 63)) : (1ull << 63);  // records asked for | did not fit
 }
 
 // The count pass evaluates every candidate's eight corner values anyway; for the voxels that produce triangles it parks them

@@ -22,7 +22,6 @@
 // sharded extraction and mrh_process_triangles (soup uploaded).
 #pragma once
 
-#include <rocprim/rocprim.hpp>
 
 #include "mrh_device.h"
 

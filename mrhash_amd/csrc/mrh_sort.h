@@ -1,4 +1,5 @@
-// mrh_sort.h — stable LSD radix sort of the (voxel id, sdf) records of one LiDAR scan (mrh_lidar.h).
+// mrh_sort.h — stable LSD radix sort of the (voxel id, sdf) records of one LiDAR scan (mrh_lidar.h) and of the (position key,
+// list entry) pairs of an extraction beyond k_block_rank's reach (mrh_mc.h).
 //
 // Why not rocPRIM here: a scan has ~10^5 .. 10^6 records and ~21 significant key bits.  rocPRIM's onesweep sort is built for
 // 10^7+ items: at this size each of its three passes is a latency-bound chain (decoupled look-back over ~300 tiles, 26 us
@@ -22,7 +23,7 @@ namespace mrh {
 constexpr int kSortTile = 1024;     // records per workgroup: a scan has ~10^6 records, smaller tiles mean more workgroups (640 for 0.65 M) and a short chain each
 constexpr int kSortThreads = 256;   // 4 waves x 4 rounds x 64 lanes
 constexpr int kSortRounds = kSortTile / kSortThreads;
-constexpr u32 kSortScanMax = 1u << 22;  // histogram entries (16 k tiles = 16 M records); beyond: rocPRIM
+constexpr u32 kSortScanMax = 1u << 24;  // histogram entries (64 k tiles = 67 M records, 64 MB of table); beyond: the call fails
 
 __device__ __forceinline__ u32 sort_lane() { return (u32) __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
@@ -70,9 +71,9 @@ __global__ __launch_bounds__(256) void k_sort_scan(u32* __restrict__ hist, const
   if (threadIdx.x == 0) totals[blockIdx.x] = carry;
 }
 
-template <typename K>
-__global__ __launch_bounds__(kSortThreads) void k_sort_scatter(const K* __restrict__ keys_in, const float* __restrict__ vals_in, K* __restrict__ keys_out,
-                                                               float* __restrict__ vals_out, const u32 n, const int shift,
+template <typename K, typename V = float>
+__global__ __launch_bounds__(kSortThreads) void k_sort_scatter(const K* __restrict__ keys_in, const V* __restrict__ vals_in, K* __restrict__ keys_out,
+                                                               V* __restrict__ vals_out, const u32 n, const int shift,
                                                                const u32* __restrict__ hist_scanned, const u32 ntiles,
                                                                const u32* __restrict__ totals) {
   constexpr int NW = kSortThreads / 64;
@@ -99,14 +100,14 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_scatter(const K* __restri
   // wave w takes records [t0 + w * (tile / 4), + tile / 4) in rounds of 64 consecutive records
   const u32 w0 = tile * kSortTile + wave * (kSortTile / NW);
   K key[kSortRounds];
-  float val[kSortRounds];
+  V val[kSortRounds];
   u32 rank[kSortRounds];  // digit in the low 8 bits, rank among the wave's records of that digit above
 #pragma unroll
   for (int r = 0; r < kSortRounds; r++) {
     const u32 i = w0 + r * 64 + lane;
     const bool valid = i < n;
     key[r] = valid ? keys_in[i] : (K) 0;
-    val[r] = valid ? vals_in[i] : 0.f;
+    if (valid) val[r] = vals_in[i];
     const u32 d = (u32) (key[r] >> shift) & 255u;
     u64 peers = __ballot(valid);
 #pragma unroll
@@ -146,6 +147,49 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_scatter(const K* __restri
       keys_out[pos] = key[r];
       vals_out[pos] = val[r];
     }
+  }
+}
+
+// Exclusive scan of n 64-bit words by ONE workgroup: tiles of 4 096 words (four neighbours a thread, through LDS so that the loads
+// and stores stay coalesced) chained through a running carry.  For the ~10^5 marks of a quad-tree (mrh_splat.h: two 32-bit
+// counters in one word) that is some twenty tiles, ~20 us — what a device-wide scan spends on its launches alone.
+constexpr int kChainTile = 4096;
+__global__ __launch_bounds__(1024) void k_chain_scan_u64(const u64* __restrict__ in, const u32 n, u64* __restrict__ out) {
+  __shared__ u64 s_v[kChainTile];
+  __shared__ u64 s_w[16];
+  const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int PER = kChainTile / 1024;
+  u64 carry = 0;
+  for (u32 base = 0; base < n; base += kChainTile) {
+    const u32 m = min((u32) kChainTile, n - base);
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+      const u32 i = k * 1024 + threadIdx.x;
+      s_v[i] = i < m ? in[base + i] : 0ull;
+    }
+    __syncthreads();
+    u64 v[PER], mine = 0;
+#pragma unroll
+    for (int k = 0; k < PER; k++) { v[k] = s_v[threadIdx.x * PER + k]; mine += v[k]; }
+    u64 incl = mine;
+    for (int off = 1; off < 64; off <<= 1) {
+      const u64 o = __shfl_up(incl, off);
+      if ((int) lane >= off) incl += o;
+    }
+    if (lane == 63) s_w[wave] = incl;
+    __syncthreads();
+    u64 run = carry + (incl - mine), all = 0;
+    for (u32 w = 0; w < 16; w++) { if (w < wave) run += s_w[w]; all += s_w[w]; }
+#pragma unroll
+    for (int k = 0; k < PER; k++) { s_v[threadIdx.x * PER + k] = run; run += v[k]; }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+      const u32 i = k * 1024 + threadIdx.x;
+      if (i < m) out[base + i] = s_v[i];
+    }
+    carry += all;
+    __syncthreads();
   }
 }
 

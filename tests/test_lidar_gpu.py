@@ -217,15 +217,13 @@ def _drive(engines, n, rows, cols, step=1.5, normals=False, noise=0.0, seed=0):
             assert not e.integrate_points()
 
 
-@pytest.mark.parametrize("sort", ["buckets", "own", "rocprim"])
+@pytest.mark.parametrize("sort", ["buckets", "own"])
 def test_full_size_vbr_scans_match_oracle(hip, oracle, monkeypatch, sort):
     """BASELINE configs[4] at its stated size: 128 x 1024 = 131 072 points per scan, vbr.cfg parameters, three scans of a
     drive; occupancy, payload and mesh against the oracle — through the voxel buckets of mrh_scan.h (the default), through
-    the sorted records of mrh_lidar.h with the scan-sized sort of mrh_sort.h (MRH_LIDAR_BUCKETS=0) and, as a cross-check of
-    that sort, with rocPRIM's (MRH_LIDAR_SORT_ROCPRIM=1): the fold is order-dependent, so a path that did not keep a voxel's
-    records in point order (or lost a record) would show up in the payload."""
+    the sorted records of mrh_lidar.h with the scan-sized sort of mrh_sort.h (MRH_LIDAR_BUCKETS=0): the fold is order-dependent,
+    so a path that did not keep a voxel's records in point order (or lost a record) would show up in the payload."""
     monkeypatch.setenv("MRH_LIDAR_BUCKETS", "1" if sort == "buckets" else "0")
-    monkeypatch.setenv("MRH_LIDAR_SORT_ROCPRIM", "1" if sort == "rocprim" else "0")
     a, b = _scan_pair(hip, oracle, dict(min_weight_threshold=1), blocks=262144)
     _drive((a, b), 3, 128, 1024, step=2.0, noise=0.02)
     a.sync()

@@ -584,8 +584,8 @@ def test_known_sample_cells_of_coarse_voxels_equal_the_literal_evaluation(hip, m
 
 def test_block_order_by_counting_equals_the_radix_sort(hip, monkeypatch):
     """The extraction's canonical block order comes from a rank-by-counting pass (k_block_rank) with the offsets from a
-    one-workgroup scan; rocPRIM's radix sort + scan stay for long lists (MRH_MC_RADIX_SORT=1 forces them).  Same soup,
-    same V / F / C, byte for byte."""
+    one-workgroup scan; lists beyond 32 k blocks take the byte-wise radix sort of mrh_sort.h over the 64-bit position keys
+    (MRH_MC_RADIX_SORT=1 forces it).  Same soup, same V / F / C, byte for byte."""
     e = pu.make_engine(hip, synth.REPLICA_640, synth.REPLICA_PARAMS, 131072)
     for f in synth.replica_stream(8):
         pu.feed(e, f)
