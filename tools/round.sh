@@ -1,7 +1,7 @@
 #!/bin/bash
 # The round's evidence from ONE build, on the GPU box (through gpurun).  Every file lands under gpurun_out/<tag>/ with the commit
 # hash of the build in MANIFEST.txt; the files to be judged are copied into profiles/<tag>/ afterwards (tools/README.md).
-#   usage: tools/round.sh <tag> <commit> [sections...]     sections: suite bench default stats pmc framepmc stress soak multi trace tracebuilds churn
+#   usage: tools/round.sh <tag> <commit> [sections...]     sections: suite bench default stats pmc framepmc stress soak multi trace tracebuilds churn bigmap
 #   default sections: bench stats pmc framepmc
 TAG=${1:-r05}; COMMIT=${2:-unknown}; shift 2
 SECTIONS=${*:-bench stats pmc framepmc}
@@ -91,6 +91,21 @@ if has tracebuilds; then  # the two tracing variants of the library (never shipp
   tools/trace_scan.sh > $OUT/scan_trace.txt 2>&1; grep -c workgroups $OUT/scan_trace.txt
   MRH_PIPE=0 tools/trace_kback.sh 30 2>&1 | grep -v "warning\|hipDeviceSynchronize\|hipMemcpy(h.data\|\^~\|generated when\|amdgpu.ids" > $OUT/kfront_kback_trace_serial.txt; head -8 $OUT/kfront_kback_trace_serial.txt
   rm -f mrhash_amd/csrc/libmrhash_trace.so
+fi
+if has bigmap; then  # extraction around and beyond k_block_rank's 32 k blocks: what the canonical order costs
+  for v in 0.0068 0.005 0.0035; do
+    rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/tr_big -o t -- python tools/bench_big_map.py $v 4 > $OUT/big_$v.log 2>&1
+    grep "^voxel" $OUT/big_$v.log
+    python - <<PY
+import csv
+for r in csv.DictReader(open("$OUT/tr_big/t_kernel_stats.csv")):
+    n = r["Name"]
+    if any(k in n for k in ("k_block_rank", "k_sort_", "k_mc_scan_total", "k_block_scatter", "k_list_keys", "k_mc<", "k_mc_neigh", "k_mc_emit")):
+        print("   %-40s calls %3s avg %9.1f us" % (n.split("(")[0][-40:], r["Calls"], float(r["AverageNs"]) / 1e3))
+PY
+    rm -rf $OUT/tr_big
+  done > $OUT/big_map.txt 2>&1
+  cat $OUT/big_map.txt
 fi
 if has multi; then
   MRH_BENCH_SHARE_DEVICE=1 timeout 900 python bench.py --gpus 8 --steps 30 --warmup 5 --blocks 65536 > $OUT/bench_8ranks_one_device_gloo.json 2> $OUT/bench_8ranks.err
