@@ -19,7 +19,9 @@ def _run(args, env=None, timeout=600):
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, f"stdout must hold exactly the result line, got {len(lines)} lines"
-    return json.loads(lines[0])
+    d = json.loads(lines[0])
+    d["_stderr_failures"] = [ln for ln in r.stderr.splitlines() if "failed" in ln or "Error" in ln or "error" in ln][-12:]
+    return d
 
 
 def test_single_gpu_line():
@@ -49,9 +51,23 @@ def test_n_ranks_on_one_device_line(ranks):
     """The N > 1 code path (self-spawned ranks, frame-sharded value, merge, tile-sharded mode) with all ranks on device 0 over
     gloo — 8 ranks = BASELINE.json configs[3]'s rank count: the 8-way owner function, eight split lists, eight halo segments.
     `n_gpus` counts DEVICES (one here); `ranks` says how many processes shared it."""
-    d = _run(["--gpus", str(ranks), "--steps", "6", "--warmup", "2", "--blocks", "65536"],
-             env={"MRH_BENCH_SHARE_DEVICE": "1", "MRH_BENCH_FULL_STREAM": str(6 * ranks)}, timeout=900)  # full-stream leg: 6 frames per rank here, 500 / N in a real run
-    assert all(k in d for k in KEYS)
+    import warnings
+
+    first = None
+    for attempt in range(2):
+        d = _run(["--gpus", str(ranks), "--steps", "6", "--warmup", "2", "--blocks", "65536"],
+                 env={"MRH_BENCH_SHARE_DEVICE": "1", "MRH_BENCH_FULL_STREAM": str(6 * ranks)}, timeout=900)  # full-stream leg: 6 frames per rank here, 500 / N in a real run
+        assert all(k in d for k in KEYS)
+        err = d.get("phases_error")  # an exception inside the exchange phases is reported in the line, not as an exit code
+        # Seen twice in ~30 runs of round 5 with eight processes on the one device: gloo's TCP transport drops a pair in the middle of
+        # the host-staged all-to-all ("Connection closed by peer").  That is the stand-in transport of this test, not the path under
+        # test: ONE retry, for that message only, with what the ranks wrote to stderr kept in a warning; anything else fails at once.
+        if err and attempt == 0 and "gloo" in err and "Connection" in err:
+            first = (err, d["_stderr_failures"])
+            warnings.warn(f"test_n_ranks_on_one_device_line[{ranks}]: gloo transport error, retrying once: {first}")
+            continue
+        assert err is None, (err, d["_stderr_failures"], first)
+        break
     assert d["n_gpus"] == 1 and d["ranks"] == ranks and d["scaling"] == "weak" and d["fuse_only_frames_per_s"] > 1000
     # RCCL's own view of the group has its place in the line (VERDICT r04 next-7); over gloo it says why it is empty
     assert d["rccl"]["rccl_ranks"] is None and "gloo" in d["rccl"]["reason"] and d["rccl"]["devices"] == [0]
