@@ -2890,7 +2890,7 @@ int mrh_splat_seeds(mrh_ctx* c, float qtree_thresh, int qtree_min_pixel_size, co
     HIP_TRY(c, hipMalloc((void**) &c->d_qt_flags, n * sizeof(u32)));
     HIP_TRY(c, hipMalloc((void**) &c->d_qt_unc, n * sizeof(u32)));
     HIP_TRY(c, hipMalloc((void**) &c->d_qt_marks, n * sizeof(u64)));
-    HIP_TRY(c, hipMalloc((void**) &c->d_qt_pos, n * sizeof(u64)));
+    HIP_TRY(c, hipMalloc((void**) &c->d_qt_pos, (n + (n + kChainTile - 1) / kChainTile + 1) * sizeof(u64)));  // + the tile sums of the marks' scan
     HIP_TRY(c, hipMalloc((void**) &c->d_qt_parked, n * sizeof(mrh_splat_seed)));
     HIP_TRY(c, hipMalloc((void**) &c->d_qt_seeds, n * sizeof(mrh_splat_seed)));
     HIP_TRY(c, hipMalloc((void**) &c->d_qt_leaves, n * sizeof(mrh_qtree_leaf)));
@@ -2912,7 +2912,11 @@ int mrh_splat_seeds(mrh_ctx* c, float qtree_thresh, int qtree_min_pixel_size, co
   k_qt_decide<<<grid, 256, 0, s>>>(qt, qtree_thresh, c->d_qt_sums, c->qt_literal, c->d_qt_flags, c->d_qt_unc, unc_count);
   k_qt_literal<<<512, 256, 0, s>>>(qt, c->d_rgb, qtree_thresh, c->d_qt_unc, unc_count, c->d_qt_flags);
   k_qt_emit<<<grid, 256, 0, s>>>(qt, c->cam, c->map, c->tab, c->d_depth, c->d_rgb, c->d_qt_flags, c->d_qt_marks, c->d_qt_parked);
-  k_chain_scan_u64<<<1, 1024, 0, s>>>(c->d_qt_marks, (u32) qt.total, c->d_qt_pos);
+  {  // exclusive scan of the marks (mrh_sort.h): tile sums (parked behind the positions), then every tile on its own
+    const u32 tiles = (u32) ((qt.total + kChainTile - 1) / kChainTile);
+    k_tile_sums_u64<<<tiles, 1024, 0, s>>>(c->d_qt_marks, (u32) qt.total, c->d_qt_pos + qt.total);
+    k_tile_scan_u64<<<tiles, 1024, 0, s>>>(c->d_qt_marks, (u32) qt.total, c->d_qt_pos + qt.total, c->d_qt_pos);
+  }
   k_qt_scatter<<<grid, 256, 0, s>>>(qt, c->d_qt_marks, c->d_qt_pos, c->d_qt_parked, c->d_qt_leaves, c->d_qt_seeds, c->d_qt_misc);
   rc = mark_frame(c);
   if (rc) return rc;

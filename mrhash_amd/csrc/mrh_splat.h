@@ -18,7 +18,7 @@
 //                   tree; a wave per node when the node has <= 256 pixels) -> the decision the oracle takes
 //   k_qt_emit       one thread per potential node: live (all ancestors split) and leaf -> the seed test of
 //                   processNodesKernel; flags for a scan
-//   k_chain_scan_u64 + k_qt_scatter      leaves and seeds in canonical order (level, then path = the order in which a
+//   k_tile_sums_u64, k_tile_scan_u64 + k_qt_scatter      leaves and seeds in canonical order (level, then path = the order in which a
 //                                     sequential level-by-level subdivision appends them; oracle header D7)
 // No level loop, no host round trip before the final counts, and bit-identical decisions: only `err <= threshold`
 // leaves the error computation, never the error itself.
