@@ -284,6 +284,8 @@ struct mrh_ctx {
   bool qt_leaves_on_host = true;
   int scan_layout_hint = 0;    // mrh_set_scan_layout / MRH_SCAN_ROW_LEN: > 0 points per row of the caller's organised scans, 0 find out (host clouds), < 0 none
   int scan_row_len = 0;        // ... of the CURRENT cloud (0: not organised, or not known)
+  uint64_t scan_detect_n = 0;  // the look at a host cloud is repeated when the cloud's size changes and every 64th upload (a sensor keeps its layout;
+  int scan_detect_len = 0, scan_detect_age = 0;  // the look itself costs the calling thread ~20 us of cache misses, more than the order wins per scan)
   int scan_patch_log2 = 4;     // MRH_SCAN_PATCH_LOG2: columns (log2) of the beam patch a walk workgroup takes from an organised scan; 8 = 256 consecutive points
   int mr_fused = 1;          // MRH_MR_FUSED=0: multi-resolution maps always through the general kernels (mrh_kernels.h)
   bool mr_next_general = true;    // the next multi-resolution frame must take the general path (frame 0 / after a starve frame / after an import)
@@ -2470,6 +2472,7 @@ int mrh_set_scan_layout(mrh_ctx* c, int row_len) {
   if (!c) return MRH_ERR_INVALID_ARG;
   c->scan_layout_hint = row_len;
   c->scan_row_len = row_len > 0 ? row_len : 0;
+  c->scan_detect_n = 0;
   return MRH_OK;
 }
 
@@ -2488,7 +2491,15 @@ int mrh_upload_points(mrh_ctx* c, const float* xyz, uint64_t n) {
   HIP_TRY(c, hipStreamSynchronize(c->stream));  // the caller's buffer is free on return (GeoWrapper::setPointCloud copies)
   c->d_points_cur = c->d_points;
   c->num_points = n;
-  c->scan_row_len = c->scan_layout_hint > 0 ? c->scan_layout_hint : c->scan_layout_hint == 0 && n ? detect_scan_row_len(xyz, n) : 0;
+  if (c->scan_layout_hint > 0) c->scan_row_len = c->scan_layout_hint;
+  else if (c->scan_layout_hint == 0 && n) {
+    if (n != c->scan_detect_n || ++c->scan_detect_age >= 64) {
+      c->scan_detect_len = detect_scan_row_len(xyz, n);
+      c->scan_detect_n = n;
+      c->scan_detect_age = 0;
+    }
+    c->scan_row_len = c->scan_detect_len;
+  } else c->scan_row_len = 0;
   return MRH_OK;
 }
 

@@ -15,6 +15,17 @@ if os.environ.get("BENCH_LIB"):  # another build of the library (A/B on one box)
 hip = capi.load_hip()
 le, scans, d_scans, run_scans = bench.lidar_setup(hip, 262144)
 n, w = bench.LIDAR_SCANS, bench.LIDAR_WARMUP
+if os.environ.get("HOST_CLOUDS"):  # the drop-in hand-over: host arrays through mrh_upload_points (looked at: mrh_detect_scan_layout); HOST_CLOUDS=-1: not looked at
+    from mrhash_amd import synth
+    le.set_scan_layout(0 if os.environ["HOST_CLOUDS"] != "-1" else -1)
+    poses = synth.drive_poses(n, step=0.5)
+
+    def run_scans(lo, hi):  # noqa: F811
+        for i in range(lo, hi):
+            t, q = poses[i]
+            le.set_pose(synth.quat_to_rot(q), t)
+            le.upload_points(scans[i])
+            le.integrate_points()
 times = []
 digest = None
 for r in range(reps):
