@@ -97,6 +97,8 @@ def parse_args():
     ap.add_argument("--pmc-inner-lidar", action="store_true", help=argparse.SUPPRESS)  # the LiDAR scans alone
     ap.add_argument("--pmc-inner-sph", action="store_true", help=argparse.SUPPRESS)  # the spherical images alone
     ap.add_argument("--frames-cache", default="", help=argparse.SUPPRESS)
+    ap.add_argument("--multi", action="store_true", help="--gpus 1 through the N-rank function (one rank, RCCL communicator of size 1): its value must "
+                                                         "equal the N = 1 line's, which is what makes value(N) / (N x value(1)) meaningful")
     return ap.parse_args()
 
 
@@ -888,12 +890,6 @@ class Group:
             self.dist.destroy_process_group()
 
 
-def _scannet_params():
-    from mrhash_amd import synth
-
-    return synth.SCANNET_PARAMS
-
-
 def bench_multi(args):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -936,12 +932,17 @@ def bench_multi(args):
                      "reason": (grp.note or ("MRH_BENCH_SHARE_DEVICE=1: the ranks share one device, which RCCL refuses; they talk over gloo" if share
                                              else f"backend {backend} requested (MRH_BENCH_BACKEND)"))}
 
-    Kc = synth.SCANNET
-    params = capi.Params(num_sdf_blocks=args.blocks, device_id=device_index, **synth.SCANNET_PARAMS)
+    # `value` is the weak-scaled N = 1 line: the SAME workload (configs[1]'s stream and parameters), rank r fusing frames
+    # [r * total, (r + 1) * total) of the orbit (8 ranks x 25 frames x 1.8 degrees = once round the room), so that the driver's
+    # value(N) / (N x value(1)) compares like with like — with one rank this function runs the job of bench_single
+    # (tests/test_bench_gpu.py::test_one_rank_multi_line_agrees_with_the_single_gpu_line).  configs[3] as BASELINE.json words it
+    # (the ScanNet stream cut into N segments, one merge + one boundary-block exchange) is `full_stream` below.
+    Kc = synth.REPLICA_640
+    params = capi.Params(num_sdf_blocks=args.blocks, device_id=device_index, **synth.REPLICA_PARAMS)
     chunk_log2 = 3
 
-    # ---- frame-sharded fusion (value): this rank's own segment of the walk
-    mine = Resident(render_stream("scannet", total, start=rank * total), Kc)
+    # ---- frame-sharded fusion (value): this rank's own segment of the orbit
+    mine = Resident(render_stream("replica", total, start=rank * total), Kc)
     eng = make_engine(hip, params, Kc)
     if rccl:
         eng.attach_comm(grp.handle)
@@ -951,8 +952,10 @@ def bench_multi(args):
     t0 = time.perf_counter()
     mine.run(eng, W, total)
     eng.sync()
+    hipmem.synchronize()
+    own = time.perf_counter() - t0  # this rank's K frames, device idle on both sides; the closing barrier is not one of the steps
     grp.barrier()
-    elapsed = grp.max(time.perf_counter() - t0)
+    elapsed = grp.max(own)
     sub_blocks = int(eng.stats().occupied_fine)
     sub_all = grp.allgather([sub_blocks])[:, 0]
 
@@ -960,8 +963,9 @@ def bench_multi(args):
         "metric": "depth frames/sec integrated (640x480)",
         "value": world * K / elapsed, "unit": "frames/s", "n_gpus": n_gpus, "ranks": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "scannet-scene0000 stand-in 640x480 (furnished 8x3x6 m room, hand-held walk), single-resolution hash TSDF "
-                               "integrate (alloc+compact+integrate+GC per frame, scannet.cfg params), frames resident in HBM",
+        "config": {"workload": "replica-room0 stand-in 640x480 (the N = 1 line's stream, weak-scaled: rank r fuses its own segment of the orbit), "
+                               "single-resolution hash TSDF integrate (alloc+compact+integrate+GC per frame, replica.cfg params), frames resident in HBM; "
+                               "configs[3] (scannet-scene0000 stand-in, 500 poses in N segments) is full_stream",
                    "frames_per_gpu": K, "voxel_size_m": 0.01, "truncation_m": 0.07,
                    "parallelism": f"FRAME-SHARDED: {world} ranks x {K} own frames into {world} sub-maps (backend {backend}, devices {devices})",
                    "sub_map_blocks_per_rank": [int(v) for v in sub_all]},
@@ -1010,7 +1014,7 @@ def bench_multi(args):
 
 
 def bench_multi_phases(args, grp, eng, mine, hip, params, Kc, chunk_log2, device_index, out, rccl, sub_blocks):
-    from mrhash_amd import capi, parallel
+    from mrhash_amd import capi, parallel, synth
 
     rank, world = grp.rank, grp.world
     K, W = args.steps, args.warmup
@@ -1043,11 +1047,19 @@ def bench_multi_phases(args, grp, eng, mine, hip, params, Kc, chunk_log2, device
         # configs[3] as stated — "frame-sharded ... with RCCL boundary-voxel all-gather": the collectives are part of the job, so they
         # are part of `value`.  Each term is a max over ranks between barriers.
         fuse_s = out["fuse_only_ms_per_step"] * K / 1e3
-        out["value"] = world * K / (fuse_s + merge_s + halo_s)
-        out["ms_per_step"] = (fuse_s + merge_s + halo_s) / K * 1e3
-        out["value_definition"] = (f"frames / (frame-sharded fusion + mrh_comm_merge_submaps + mrh_comm_exchange_halo): {world} x {K} frames, one merge and one "
-                                   f"boundary-block exchange per run; fusion {fuse_s * 1e3:.2f} ms + merge {merge_s * 1e3:.2f} ms + halo {halo_s * 1e3:.2f} ms "
-                                   f"(fuse_only_frames_per_s is the fusion alone; tile_sharded the result-identical mode)")
+        if world > 1 or os.environ.get("MRH_COMM_SELF_LOOP"):
+            out["value"] = world * K / (fuse_s + merge_s + halo_s)
+            out["ms_per_step"] = (fuse_s + merge_s + halo_s) / K * 1e3
+            out["value_definition"] = (f"frames / (frame-sharded fusion + mrh_comm_merge_submaps + mrh_comm_exchange_halo): {world} x {K} frames, one merge and one "
+                                       f"boundary-block exchange per run; fusion {fuse_s * 1e3:.2f} ms + merge {merge_s * 1e3:.2f} ms + halo {halo_s * 1e3:.2f} ms "
+                                       f"(fuse_only_frames_per_s is the fusion alone; tile_sharded the result-identical mode)")
+        else:
+            # one rank: its sub-map is the map — there is no second sub-map to merge and no neighbour to exchange with, so the job
+            # is the N = 1 line's job and `value` must be that line's value.  The two calls still ran (above) and are reported in
+            # `merge` / `phases` as what they cost when they move nothing; MRH_COMM_SELF_LOOP=1 counts them as at N > 1.
+            out["value_definition"] = (f"one rank: frames / time of the fusion ({K} frames; the job of the N = 1 line); mrh_comm_merge_submaps "
+                                       f"({merge_s * 1e3:.2f} ms) and mrh_comm_exchange_halo ({halo_s * 1e3:.2f} ms) ran with nothing to move and are not part of it")
+            merge["cadence"] += "; one rank: not part of `value`"
     if rccl:
         eng.attach_comm(None)
     eng.close()
@@ -1057,7 +1069,7 @@ def bench_multi_phases(args, grp, eng, mine, hip, params, Kc, chunk_log2, device
     roof = None
     if rank == 0:
         pe = make_engine(hip, params, Kc)
-        roof = profiled_roofline(pe, mine, W, total, f"configs[3], rank 0's segment of the frame-sharded stream ({K} frames)")
+        roof = profiled_roofline(pe, mine, W, total, f"rank 0's segment of the frame-sharded stream ({K} frames; the N = 1 line's workload)")
         roof["cache_note"] = "per-frame working set inside the 256 MiB Infinity Cache (see the N = 1 line's roofline_hbm for the kernel outside it)"
         pe.close()
     out["roofline"] = roof
@@ -1065,9 +1077,9 @@ def bench_multi_phases(args, grp, eng, mine, hip, params, Kc, chunk_log2, device
 
     # ---- tile-sharded fusion of ONE stream (rank 0's segment) by all ranks
     if grp.exchanges:
-        shared = mine if rank == 0 else Resident(render_stream("scannet", total, start=0), Kc)
+        shared = mine if rank == 0 else Resident(render_stream("replica", total, start=0), Kc)
         tp = capi.Params(num_sdf_blocks=args.blocks, device_id=device_index, shard_rank=rank, shard_count=world, shard_chunk_log2=chunk_log2,
-                         **_scannet_params())
+                         **synth.REPLICA_PARAMS)
         te = make_engine(hip, tp, Kc)
         if rccl:
             te.attach_comm(grp.handle)  # starve frames: the two MIN all-reduces run inside mrh_integrate
@@ -1098,8 +1110,9 @@ def bench_multi_phases(args, grp, eng, mine, hip, params, Kc, chunk_log2, device
     full_n = int(os.environ.get("MRH_BENCH_FULL_STREAM", "500"))
     if grp.exchanges and full_n >= world:
         per = full_n // world
-        seg = Resident(render_stream("scannet", per, start=rank * per), Kc)
-        fe = make_engine(hip, params, Kc)
+        Ks = synth.SCANNET
+        seg = Resident(render_stream("scannet", per, start=rank * per), Ks)
+        fe = make_engine(hip, capi.Params(num_sdf_blocks=args.blocks, device_id=device_index, **synth.SCANNET_PARAMS), Ks)
         if rccl:
             fe.attach_comm(grp.handle)
         seg.run(fe, 0, min(W, per))  # warm-up on the segment's first frames, then from an empty map
@@ -1175,7 +1188,7 @@ def main():
     # tools/bench_tile_shards.py).  Nothing here builds reference cycles that matter.
     gc.collect()
     gc.disable()
-    if args.gpus > 1:
+    if args.gpus > 1 or args.multi:
         bench_multi(args)
     else:
         if int(os.environ.get("WORLD_SIZE", "1")) != 1:

@@ -10,7 +10,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
-from dataclasses import dataclass
+from dataclasses import dataclass, replace
 from typing import Optional, Tuple
 
 import numpy as np
@@ -349,7 +349,9 @@ class Engine:
 
     def __init__(self, lib: C.CDLL, params: Params):
         self.lib = lib
-        self.params = params
+        # a private copy: set_sharding / comm_merge_submaps record the context's sharding here, and a caller that builds
+        # several engines from one Params object must not find the later ones sharded like the first
+        self.params = replace(params)
         self._ctx = C.c_void_p()
         cp = params.to_c()
         rc = lib.mrh_create(C.byref(cp), C.byref(self._ctx))

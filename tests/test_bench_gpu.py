@@ -24,8 +24,19 @@ def _run(args, env=None, timeout=600):
     return d
 
 
+_SINGLE = {}
+
+
+def _single_line(steps, warmup, extra=()):
+    """The N = 1 line at the given step counts, run once per module (the N > 1 tests compare their rank 0 with it)."""
+    key = (steps, warmup, tuple(extra))
+    if key not in _SINGLE:
+        _SINGLE[key] = _run(["--gpus", "1", "--steps", str(steps), "--warmup", str(warmup), "--no-pmc"] + list(extra))
+    return _SINGLE[key]
+
+
 def test_single_gpu_line():
-    d = _run(["--gpus", "1", "--steps", "6", "--warmup", "2", "--no-pmc", "--cpu-frames", "2"])
+    d = _single_line(6, 2, ("--cpu-frames", "2"))
     assert all(k in d for k in KEYS)
     assert d["n_gpus"] == 1 and d["steps"] == 6 and d["warmup"] == 2 and d["unit"] == "frames/s" and d["higher_is_better"] is True
     assert d["value"] > 1000 and abs(d["value"] * d["ms_per_step"] / 1e3 - 1.0) < 1e-6
@@ -84,21 +95,34 @@ def test_n_ranks_on_one_device_line(ranks):
     assert d["tile_sharded"]["frames_per_s"] > 0
     assert d["roofline"]["launches"] == 6 and d["cpu_baseline"] is None
     assert d["phases"]["k_front_ms"] > 0 and d["phases"]["k_back_ms"] > 0
+    # every engine of the N > 1 line after the first merge used to be built tile-sharded 1-of-N (a shared
+    # Params object that Engine.set_sharding wrote into).  The full-stream leg must move blocks between all ranks, its sub-maps
+    # must be whole sub-maps, and the roofline pass on rank 0 must be a whole frame's integration: rank 0's segment IS the
+    # N = 1 line's stream, so the updated voxels per launch are the same number.
+    assert all(v > 0 for v in fs["blocks_sent_per_rank"]) and all(v > 0 for v in fs["halo_blocks_taken_per_rank"])
+    assert all(v > 3000 for v in fs["sub_map_blocks_per_rank"]), fs["sub_map_blocks_per_rank"]
+    assert all(v > 3000 for v in d["config"]["sub_map_blocks_per_rank"])
+    one = _single_line(6, 2, ("--cpu-frames", "2"))
+    u1, un = one["roofline"]["updated_voxels_per_launch"], d["roofline"]["updated_voxels_per_launch"]
+    assert abs(un - u1) <= 0.2 * u1 and un == u1, (un, u1)
+    assert d["roofline"]["compact_blocks_per_launch"] == one["roofline"]["compact_blocks_per_launch"]
+
+
+def _multi_one_rank(steps, warmup, env=None, full=40):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--multi", "--steps", str(steps), "--warmup", str(warmup), "--blocks", "65536"],
+                       capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MRH_BENCH_FULL_STREAM=str(full), **(env or {})))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    return json.loads(lines[0])
 
 
 def test_one_rank_rccl_line():
     """bench.py --gpus N as the driver launches it (RANK / LOCAL_RANK / WORLD_SIZE in the environment), over RCCL behind the C
-    ABI — with the one rank this box's one GPU allows.  --gpus 1 with WORLD_SIZE=1 is the single-GPU line, so the multi-rank
-    function is entered directly."""
-    code = ("import os, sys; sys.argv = ['bench.py', '--gpus', '1', '--steps', '12', '--warmup', '2', '--blocks', '65536']; "
-            f"sys.path.insert(0, {ROOT!r}); import bench; a = bench.parse_args(); "
-            "sys.stdout.flush(); bench._RESULT_FD = os.dup(1); os.dup2(2, 1); bench.bench_multi(a)")
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900,
-                       env=dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MRH_BENCH_FULL_STREAM="40"))
-    assert r.returncode == 0, r.stderr[-3000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
-    assert len(lines) == 1
-    d = json.loads(lines[0])
+    ABI — with the one rank this box's one GPU allows: `--gpus 1 --multi` enters the N-rank function.  MRH_COMM_SELF_LOOP=1: the
+    rank's own sub-map travels through ncclSend / ncclRecv to itself and the exchange is counted in `value` as at N > 1."""
+    d = _multi_one_rank(12, 2, env={"MRH_COMM_SELF_LOOP": "1"})
     assert d["n_gpus"] == 1 and d["ranks"] == 1 and d["fuse_only_frames_per_s"] > 1000 and 100 < d["value"] < d["fuse_only_frames_per_s"]
     assert "mrh_comm_exchange_halo" in d["value_definition"]
     ph = d["phases"]
@@ -107,9 +131,29 @@ def test_one_rank_rccl_line():
     assert "backend rccl" in d["config"]["parallelism"]
     # what RCCL itself reports (mrh_comm_status): one rank on device 0, no asynchronous error before or after the phases
     rc = d["rccl"]
-    assert rc["rccl_ranks"] == 1 and rc["ranks_seen_by_each_rank"] == [1] and rc["rccl_device_of_each_rank"] == [0] and rc["devices"] == [0]
+    assert rc["rccl_ranks"] == 1 == d["ranks"] and rc["ranks_seen_by_each_rank"] == [1] and rc["rccl_device_of_each_rank"] == [0] and rc["devices"] == [0]
     assert rc["async_error_code_of_each_rank"] == [0] and rc["async_error_after_phases"] == rc["async_error_after_init"] and rc["rccl_version"] > 0
     assert d["full_stream"]["cadence_frames"] == 40 and d["full_stream"]["frames_per_s"] > 0
+    assert d["full_stream"]["sub_map_blocks_per_rank"][0] > 3000 and d["merge"]["owned_blocks_after_merge_per_rank"][0] > 3000
+
+
+def test_one_rank_multi_line_agrees_with_the_single_gpu_line():
+    """the driver divides value(N) by N x value(1), and value(1) comes from bench_single.  The N-rank
+    function with ONE rank must therefore be the same job with the same number: same stream, same parameters, same timed loop,
+    nothing to exchange — within 5 % at the driver's step counts (best of three pairs: both sides are 0.7 ms samples)."""
+    best = None
+    for _ in range(3):
+        one = _run(["--gpus", "1", "--steps", "20", "--warmup", "5", "--no-pmc", "--no-cpu", "--no-extras"])
+        d = _multi_one_rank(20, 5, full=0)
+        assert d["ranks"] == 1 and d["rccl"]["rccl_ranks"] == 1 and d["value_definition"].startswith("one rank")
+        assert d["value"] == d["fuse_only_frames_per_s"] and d["config"]["workload"].startswith("replica-room0 stand-in 640x480")
+        assert d["roofline"]["updated_voxels_per_launch"] == one["roofline"]["updated_voxels_per_launch"]
+        assert d["config"]["sub_map_blocks_per_rank"] == [one["config"]["live_blocks_end"]]
+        ratio = d["value"] / one["value"]
+        best = ratio if best is None or abs(ratio - 1) < abs(best - 1) else best
+        if abs(ratio - 1) <= 0.05:
+            break
+    assert abs(best - 1) <= 0.05, best
 
 
 def test_value_survives_without_a_communicator():

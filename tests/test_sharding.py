@@ -34,6 +34,30 @@ def test_frame_sharding_covers_the_stream():
     assert got == list(range(100))
 
 
+def test_an_engine_keeps_its_sharding_to_itself(oracle):
+    """Engine.set_sharding used to write shard_rank / shard_count into the caller's Params object, so every
+    engine built from that object afterwards was created tile-sharded (bench.py's roofline and full-stream engines)."""
+    p = capi.Params(num_sdf_blocks=4096, **synth.CFG1_PARAMS)
+    a = capi.Engine(oracle, p)
+    a.set_sharding(3, 8, 2)
+    assert (p.shard_rank, p.shard_count, p.shard_chunk_log2) == (0, 1, 0)
+    assert (a.params.shard_rank, a.params.shard_count, a.params.shard_chunk_log2) == (3, 8, 2)
+    b = capi.Engine(oracle, p)  # a second engine from the same object: a whole map
+    for e in (a, b):
+        e.set_camera(synth.CFG1.fx, synth.CFG1.fy, synth.CFG1.cx, synth.CFG1.cy, synth.CFG1.rows, synth.CFG1.cols, p.min_depth, p.max_depth)
+        f = synth.cfg1_sphere()
+        e.set_pose(f.R, f.t)
+        e.upload_depth(f.depth)
+        e.upload_rgb(f.rgb)
+        pending = e.integrate()
+        while pending:
+            pending = e.integrate_resume()
+    na, nb = len(a.dump_blocks()[0]), len(b.dump_blocks()[0])
+    assert 0 < na < nb and nb > 50
+    a.close()
+    b.close()
+
+
 def test_union_of_tile_shards_equals_single_map(oracle):
     """No communication needed for the map itself: shard r keeps exactly the blocks it owns."""
     frames = [synth.cfg1_sphere(), synth.cfg1_sphere(zc=1.51)]
