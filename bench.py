@@ -1011,6 +1011,12 @@ def bench_multi(args):
         emit(out)
     grp.barrier()
     grp.close()
+    if grp.note and grp.note.startswith("RCCL communicator not created"):
+        # mrh_comm_create may have timed out: its init thread is then still inside ncclCommInitRank (include/mrhash_comm.h) and
+        # RCCL's / HIP's static teardown must not run under it
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
 
 
 def bench_multi_phases(args, grp, eng, mine, hip, params, Kc, chunk_log2, device_index, out, rccl, sub_blocks):

@@ -42,7 +42,11 @@ int mrh_comm_unique_id(uint8_t out_id[MRH_COMM_ID_BYTES]);
 
 /* ncclCommInitRank on HIP device `device_id`.  Collective; blocks until all `world` ranks have joined — or for
  * MRH_COMM_INIT_TIMEOUT_S seconds (environment, default 180): past that the call fails with MRH_ERR_DEVICE (a peer never joined)
- * instead of keeping the process for ever; the caller falls back to a run without RCCL. */
+ * instead of keeping the process for ever; the caller falls back to a run without RCCL.  After such a timeout the init thread is
+ * still inside ncclCommInitRank and stays there for the life of the process: do NOT create another communicator with the same id
+ * in this process, and leave through _exit() (or quick_exit) rather than through static destructors — RCCL's and HIP's teardown
+ * must not run under a thread that is still inside RCCL (bench.py does exactly that; tests let the timeout fire in a process of
+ * its own). */
 int mrh_comm_create(const uint8_t id[MRH_COMM_ID_BYTES], int rank, int world, int device_id, mrh_comm** out_comm);
 int mrh_comm_destroy(mrh_comm* comm); /* NULL is a no-op; contexts must be detached (or destroyed) first */
 const char* mrh_comm_last_error(const mrh_comm* comm); /* comm == NULL: last failing mrh_comm_create / _unique_id on this thread */

@@ -331,7 +331,10 @@ int mrh_get_free_blocks(mrh_ctx* ctx, int64_t* out_free_fine, int64_t* out_free_
  * of the free-list levels into pinned host memory; the call returns the newest report that has arrived and how many
  * frames it is behind (0 = the last enqueued frame has already finished).  The very first call, and a call with no
  * report in flight, answer through mrh_get_free_blocks.  Lets a host keep the reference's per-frame paging test
- * (geowrapper.cpp:137) without serialising upload and compute on it. */
+ * (geowrapper.cpp:137) without serialising upload and compute on it.  A host-fed frame that mrh_integrate has kept back
+ * for one call (see mrh_integrate) is counted in *out_frames_behind; its pool level and error flags appear only after the
+ * call that launches it (the next mrh_integrate, mrh_sync, or any call that reads the map): a loop that ONLY peeks after its
+ * last frame never sees that frame — end such a loop with mrh_sync. */
 int mrh_peek_free_blocks(mrh_ctx* ctx, int64_t* out_free_fine, int64_t* out_free_coarse, uint64_t* out_frames_behind);
 
 /* 1 = bracket the integrate kernel with HIP events and count updated voxels / inserted /

@@ -72,6 +72,7 @@ GeoWrapper::GeoWrapper(float sdf_truncation, float sdf_truncation_scale, int int
   if (const char* e = std::getenv("MRHASH_DEVICE")) p.device_id = std::atoi(e);
   device_id_ = p.device_id;
   if (const char* e = std::getenv("MRHASH_STREAM")) streaming_enabled_ = std::atoi(e) != 0;
+  if (const char* e = std::getenv("MRH_SYNC_COMPUTE")) sync_compute_ = std::atoi(e) != 0;
   p.shard_count = 1;
   int rc = mrh_create(&p, &ctx_);
   if (rc != MRH_OK) throw std::runtime_error(std::string("GeoWrapper::GeoWrapper | ") + mrh_last_error(nullptr));
@@ -260,7 +261,18 @@ void GeoWrapper::compute() {
     // the affected blocks.  Same here, without a stall: the flags of a frame that finished a moment ago arrive with the
     // pool-level report; each is announced once.
     uint32_t flags = 0;
-    if (mrh_peek_error_flags(ctx_, &flags) == MRH_OK && flags) {
+    if (sync_compute_) {
+      // MRH_SYNC_COMPUTE=1 / _setSyncCompute(true): compute() as the reference's — blocking (geowrapper.cpp:118-148 ends in
+      // cudaDeviceSynchronize), the frame's own capacity flags announced in this call, a device error thrown by it.
+      const int rc = mrh_sync(ctx_);
+      if (rc != MRH_OK && rc != MRH_ERR_CAPACITY && rc != MRH_ERR_OUT_OF_RANGE) check(rc, "compute");
+      mrh_stats st;
+      check(mrh_get_stats(ctx_, &st), "compute");
+      flags = st.error_flags & ~flags_announced_;
+      flags_announced_ |= st.error_flags;
+      last_compute_flags_ = flags;
+    }
+    if (sync_compute_ ? flags != 0 : (mrh_peek_error_flags(ctx_, &flags) == MRH_OK && flags)) {
       if (flags & 1u) std::cerr << "GeoWrapper::compute | SDF block pool exhausted: blocks of recent frames were skipped" << std::endl;
       if (flags & 2u) std::cerr << "GeoWrapper::compute | hash table probe limit reached: blocks of recent frames were skipped" << std::endl;
       if (flags & 4u) std::cerr << "GeoWrapper::compute | block coordinates left the +-2^20 key range" << std::endl;
@@ -502,6 +514,7 @@ void GeoWrapper::clearBuffers() {
   std::cout << "clearing buffers..." << std::endl;
   cacheMesh();  // the mesh of the last extractMesh outlives the map, as the reference's host matrices do
   check(mrh_reset(ctx_), "clearBuffers");
+  flags_announced_ = last_compute_flags_ = 0;
   grid_.clear();  // Streamer::clearGrid (geowrapper.cpp:555)
 }
 

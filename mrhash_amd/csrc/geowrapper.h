@@ -78,7 +78,9 @@ public:
   // Streamer::stream (streamer.cpp:333-354): blocks farther than `radius` from `camera_position` leave the device for the
   // host chunk grid, chunks inside the sphere come back.  compute() calls it when the pool runs low (geowrapper.cpp:137-138).
   void stream(const std::array<float, 3>& camera_position, float radius);
-  size_t hostGridBlocks() const;  // blocks currently held by the host chunk grid
+  size_t hostGridBlocks() const;
+  void setSyncCompute(bool on) { sync_compute_ = on; }
+  uint32_t lastComputeFlags() const { return last_compute_flags_; }  // sync mode: flags the last compute() raised (1 pool, 2 table, 4 key range)  // blocks currently held by the host chunk grid
   void clearBuffers();
   void serializeData(const std::string& filename_hash, const std::string& filename_voxel);
   void serializeGrid(const std::string& filename);
@@ -120,6 +122,8 @@ private:
   uint64_t streamInSphereRef(const std::array<float, 3>& center, float radius);
   std::map<std::array<int, 3>, std::vector<HostBlock>> grid_;
   bool streaming_enabled_ = true;  // MRHASH_STREAM=0 turns the per-frame test off
+  bool sync_compute_ = false;      // MRH_SYNC_COMPUTE=1: compute() blocks and reports its own frame's flags (the reference's contract)
+  uint32_t flags_announced_ = 0, last_compute_flags_ = 0;
   float max_depth_ = 0.f;
   float reach_ = 0.f;  // farthest distance from the camera centre at which a frame can touch a block (set by setCamera)
 

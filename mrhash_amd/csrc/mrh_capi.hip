@@ -2540,8 +2540,8 @@ template <typename K>
 int lidar_sort(mrh_ctx* c, K* k0, K* k1, float* v0, float* v1, const size_t n, const int end_bit, int* out_buf) {
   const u32 ntiles = (u32) ((n + kSortTile - 1) / kSortTile);
   const u32 total = 256u * ntiles;
-  if (total > kSortScanMax)
-    return fail(c, MRH_ERR_CAPACITY, "mrh_integrate_points: %zu records in one scan through the sorted path (limit %llu)", n, (unsigned long long) kSortScanMax * 4ull);
+  if (n > 0xFFFFFFFFull - kSortTile || (uint64_t) 256u * ntiles > kSortScanMax)  // records and histogram entries are indexed in 32 bits
+    return fail(c, MRH_ERR_CAPACITY, "mrh_integrate_points: %zu records in one scan through the sorted path (limit 2^32 - %d)", n, kSortTile + 1);
   // the scan-sized sort of mrh_sort.h: per 8-bit digit a tile histogram, a one-workgroup scan, a stable scatter
   hipStream_t s = c->stream;
   if ((size_t) total * sizeof(u32) + 1024 > c->sort_tmp_bytes) {
@@ -2994,11 +2994,12 @@ int mrh_peek_free_blocks(mrh_ctx* c, int64_t* out_free_fine, int64_t* out_free_c
     if (c->peek_seq[seq % 8] != seq) continue;
     if (out_free_fine) *out_free_fine = (int64_t) c->h_peek[8 * (seq % 8)] + 1;
     if (out_free_coarse) *out_free_coarse = (int64_t) c->h_peek[8 * (seq % 8) + 1] + 1;
-    if (out_frames_behind) *out_frames_behind = back - 1;
+    // a host-fed frame that mrh_integrate has kept back (flush_deferred) has no sequence number yet: it counts as one more frame behind
+    if (out_frames_behind) *out_frames_behind = back - 1 + (c->deferred.on ? 1 : 0);
     return MRH_OK;
   }
   if (out_frames_behind) *out_frames_behind = 0;
-  return mrh_get_free_blocks(c, out_free_fine, out_free_coarse);
+  return mrh_get_free_blocks(c, out_free_fine, out_free_coarse);  // blocking: runs a kept-back frame first (ensure_ready)
 }
 
 int mrh_peek_error_flags(mrh_ctx* c, uint32_t* out_new_flags) {

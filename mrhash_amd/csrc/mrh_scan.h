@@ -11,7 +11,7 @@
 //                   group's size to the voxel's counter (neighbouring beams hit the same voxels: the hot voxels next to the
 //                   sensor take 10-30 x fewer atomics than records), marks the voxel's block as touched by this scan, and the
 //                   records + groups are parked in a stash (one allocation per workgroup, order irrelevant).
-//   k_scan_offsets  the blocks this scan touched, from their stamps (a window of 128 blocks per workgroup); one wave per touched
+//   k_scan_offsets  the blocks this scan touched, from their stamps (windows of kScanWindow = 16 blocks per workgroup); one wave per touched
 //                   block: its 512 counters become offsets (the bases of 16 blocks from one atomic on the
 //                   record cursor — the order of the blocks in the buffer does not matter), and its voxels are cut into chunks
 //                   of bounded work for the last kernel (< 512 records and a bounded sum of squared run lengths; a run longer
@@ -40,8 +40,9 @@ namespace mrh {
 #endif
 constexpr u32 kScanSetSize = MRH_SCAN_SET;        // LDS set of a walk workgroup (distinct voxels of 256 beams: typically 600-1000)
 constexpr int kScanSetProbe = 16;
-constexpr int kScanSetShift = kScanSetSize == 4096 ? 20 : kScanSetSize == 2048 ? 21 : 22;
-static_assert(kScanSetSize <= 4096 && (kScanSetSize & (kScanSetSize - 1)) == 0, "a set slot is kept in 12 bits");
+constexpr int kScanSetShift = kScanSetSize == 4096 ? 20 : kScanSetSize == 2048 ? 21 : 22;  // 32 - log2(size): the hash's top bits
+static_assert(kScanSetSize >= 1024 && kScanSetSize <= 4096 && (kScanSetSize & (kScanSetSize - 1)) == 0,
+              "MRH_SCAN_SET: 1024, 2048 or 4096 (a set slot is kept in 12 bits; the shift above knows these three sizes)");
 constexpr int kScanMaxSlots = 32;         // records per beam this path accepts (LDS of the walk: slots * 2 KB + 32 KB)
 constexpr u32 kScanWaveRecs = 512;        // records of a chunk: one WAVE of k_scan_apply holds them in its slice of the LDS
 constexpr u32 kScanChunkWeight = 1u << 13;  // work bound of a chunk: sum of cnt * max(cnt, 32) stays below twice this (so: < 512 records)

@@ -23,7 +23,8 @@ namespace mrh {
 constexpr int kSortTile = 1024;     // records per workgroup: a scan has ~10^6 records, smaller tiles mean more workgroups (640 for 0.65 M) and a short chain each
 constexpr int kSortThreads = 256;   // 4 waves x 4 rounds x 64 lanes
 constexpr int kSortRounds = kSortTile / kSortThreads;
-constexpr u32 kSortScanMax = 1u << 24;  // histogram entries (64 k tiles = 67 M records, 64 MB of table); beyond: the call fails
+constexpr u32 kSortScanMax = 1u << 30;  // histogram entries: 256 per tile, indexed in 32 bits like the records themselves (4 M tiles = every n < 2^32; the table
+                                        // is sized from the scan, 1 KiB per 1 024 records); beyond: the call fails with MRH_ERR_CAPACITY
 
 __device__ __forceinline__ u32 sort_lane() { return (u32) __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 

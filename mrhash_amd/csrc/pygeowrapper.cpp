@@ -125,6 +125,8 @@ PYBIND11_MODULE(pygeowrapper, m) {
       g.stream({pos.data()[0], pos.data()[1], pos.data()[2]}, radius);
     })
     .def("_hostGridBlocks", &GeoWrapper::hostGridBlocks)
+    .def("_setSyncCompute", &GeoWrapper::setSyncCompute)
+    .def("_lastComputeFlags", &GeoWrapper::lastComputeFlags)
     // multi-GPU (include/mrhash_comm.h, no reference counterpart): RCCL behind the C ABI, one GeoWrapper per rank
     .def_static("_commUniqueId", []() {
       const auto id = GeoWrapper::commUniqueId();

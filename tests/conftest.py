@@ -18,6 +18,7 @@ os.environ.setdefault("MRH_PIPE_UPLOADS", "1")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "soak: long-running GPU gates outside the suite's time budget (MRH_SOAK=1 python -m pytest tests -m soak)")
 
 
 @pytest.fixture(scope="session")

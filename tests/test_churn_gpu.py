@@ -3,6 +3,8 @@ free-space blocks of the truncation band every frame and the streamer pages bloc
 (tombstones) pile up unless the table is rebuilt from time to time (mrh_kernels.h: k_table_census / k_rehash_*).
 The reference's buckets return slots to FREE (vds.cu:1727-1824); here the census + rebuild keep probe paths short.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -113,6 +115,14 @@ def test_a_walk_with_gc_and_paging_keeps_the_table_healthy(hip, oracle):
     both sides), three times the 4 096 erased slots that trigger a rebuild (at least one must happen), inside the suite's time budget.  The 3 000-frame walk of rounds 2-4 is the same function
     with its old arguments: `python tests/soak.py churn` (its result is kept under profiles/)."""
     walk_with_gc_and_paging(hip, oracle, frames=260, pool=POOL, min_paged=3000, min_rehashes=1, check_every=50)
+
+
+@pytest.mark.soak
+@pytest.mark.skipif(os.environ.get("MRH_SOAK") != "1", reason="the 12-minute walk: MRH_SOAK=1 python -m pytest tests -m soak (tools/round.sh churn runs and asserts it)")
+def test_the_long_walk_rebuilds_the_table_many_times(hip, oracle):
+    """the 3 000-frame walk of rounds 2-4 (> 50 k blocks paged, >= 5 table rebuilds) as a pytest case, so that it is an
+    automated gate of the round script and not a script somebody has to remember."""
+    walk_with_gc_and_paging(hip, oracle, frames=3000, pool=POOL, min_paged=50000, min_rehashes=5)
 
 
 def test_without_upkeep_the_same_walk_wears_the_table_out(hip, monkeypatch):

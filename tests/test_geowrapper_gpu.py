@@ -86,6 +86,35 @@ def test_getters_setters_and_errors(geowrapper_cls):
     g.clearBuffers()
 
 
+def test_sync_compute_reports_a_frames_own_flags(monkeypatch, capfd):
+    """compute() enqueues (and keeps a host-fed frame back for one call), so an exhausted pool is announced a
+    frame or two late through the peeks.  MRH_SYNC_COMPUTE=1 (or _setSyncCompute) gives the reference's contract back
+    (geowrapper.cpp:118-148 ends in cudaDeviceSynchronize): compute() blocks, and the flags ITS frame raised are announced and
+    readable in the same call.  A pool of 64 blocks cannot hold a 128x128 sphere view: bit 0 on the very first compute()."""
+    monkeypatch.setenv("MRHASH_NUM_SDF_BLOCKS", "64")
+    monkeypatch.setenv("MRH_SYNC_COMPUTE", "1")
+    from mrhash.src.pygeowrapper import GeoWrapper
+
+    K, f = synth.CFG1, synth.cfg1_sphere()
+    g = _make(GeoWrapper)
+    g.setCamera(K.fx, K.fy, K.cx, K.cy, K.rows, K.cols, 0.01, 30.0, 0)
+    g.setCurrPose(f.t, f.q); g.setDepthImage(f.depth); g.setRGBImage(f.rgb)
+    capfd.readouterr()
+    g.compute()
+    assert g._lastComputeFlags() & 1 and "SDF block pool exhausted" in capfd.readouterr().err
+    g.setCurrPose(f.t, f.q); g.setDepthImage(f.depth); g.setRGBImage(f.rgb); g.compute()
+    assert g._lastComputeFlags() == 0  # announced once; the map stays usable
+    # the default (asynchronous) wrapper: the same frame's flag is NOT known when its compute() returns ...
+    monkeypatch.delenv("MRH_SYNC_COMPUTE")
+    h = _make(GeoWrapper)
+    h.setCamera(K.fx, K.fy, K.cx, K.cy, K.rows, K.cols, 0.01, 30.0, 0)
+    h.setCurrPose(f.t, f.q); h.setDepthImage(f.depth); h.setRGBImage(f.rgb); h.compute()
+    assert h._lastComputeFlags() == 0
+    h._setSyncCompute(True)  # ... and switching over at run time reports it with the next frame
+    h.setCurrPose(f.t, f.q); h.setDepthImage(f.depth); h.setRGBImage(f.rgb); h.compute()
+    assert h._lastComputeFlags() & 1
+
+
 def test_serialize_outputs(geowrapper_cls, tmp_path):
     g = _make(geowrapper_cls, n_frames_invalidate_voxels=0)
     K = synth.CFG1

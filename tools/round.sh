@@ -82,7 +82,9 @@ if has soak; then
   python tests/soak.py 900 ${SOAK_SEEDS:-100} > $OUT/soak.txt 2>&1; tail -3 $OUT/soak.txt
 fi
 if has churn; then
-  python tests/soak.py churn > $OUT/soak_churn.txt 2>&1; tail -3 $OUT/soak_churn.txt
+  # the 3 000-frame walk as a pytest gate: fails the section if the walk, its rebuild count or the parity at its end fails
+  { sha256sum mrhash_amd/csrc/libmrhash_hip.so | cut -c1-16; MRH_SOAK=1 timeout 2400 python -m pytest tests/test_churn_gpu.py -m soak -q -s 2>&1 | tail -6; } > $OUT/soak_churn.txt 2>&1
+  tail -3 $OUT/soak_churn.txt; grep -q " passed" $OUT/soak_churn.txt || echo "CHURN GATE FAILED"
 fi
 if has trace; then
   STEPS=100 WARM=10 tools/trace_pipe2.sh > $OUT/pipeline_trace_110_frames.txt 2>&1; head -3 $OUT/pipeline_trace_110_frames.txt
@@ -112,5 +114,8 @@ if has multi; then
   head -c 600 $OUT/bench_8ranks_one_device_gloo.json; echo
   gcc -std=c11 -O1 -Iinclude examples/comm_smoke.c -o /tmp/comm_smoke -Lmrhash_amd/csrc -lmrhash_hip -Wl,-rpath,$PWD/mrhash_amd/csrc -lm
   MRH_COMM_SELF_LOOP=1 /tmp/comm_smoke 1 > $OUT/comm_smoke_1rank_self_loop.txt 2>&1; tail -3 $OUT/comm_smoke_1rank_self_loop.txt
+  # one rank through the N-rank function over RCCL: its value is the N = 1 line's
+  RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 timeout 600 python bench.py --gpus 1 --multi --steps 20 --warmup 5 > $OUT/bench_1rank_rccl_multi.json 2> $OUT/bench_1rank.err
+  python -c "import json; d=json.load(open('$OUT/bench_1rank_rccl_multi.json')); print('one rank through bench_multi: value', round(d['value']), d['value_definition'][:80])"
 fi
 rm -f $OUT/*.log
