@@ -51,6 +51,17 @@ def build_hip(force: bool = False, verbose: bool = True) -> str:
     return HIP_LIB
 
 
+def build_variant(name: str, extra_flags, verbose: bool = True) -> str:
+    """A tuning build of the same sources under another name (libmrhash_<name>.so, e.g. with -DMRH_BACK_WAVES=6), for A/B runs
+    on one box through tools/bench_with_lib.py / tools/abn.sh.  Never loaded by the product path."""
+    out = os.path.join(CSRC, f"libmrhash_{name}.so")
+    cmd = [hipcc()] + HIPCC_FLAGS + list(extra_flags) + ["-o", out, os.path.join(CSRC, "mrh_capi.hip")]
+    if verbose:
+        print("[build]", " ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True, cwd=CSRC)
+    return out
+
+
 def build_oracle(verbose: bool = True) -> str:
     """Test infrastructure only (see oracle/mrh_oracle.c header)."""
     subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=True, stdout=None if verbose else subprocess.DEVNULL)
@@ -95,4 +106,7 @@ def build_all(force: bool = False):
 
 
 if __name__ == "__main__":
-    build_all(force="--force" in sys.argv)
+    if len(sys.argv) > 2 and sys.argv[1] == "variant":  # python -m mrhash_amd.build variant <name> [-D...]
+        build_variant(sys.argv[2], sys.argv[3:])
+    else:
+        build_all(force="--force" in sys.argv)

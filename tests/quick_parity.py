@@ -7,6 +7,8 @@ import numpy as np
 from mrhash_amd import capi, synth
 import parity_utils as pu
 
+if os.environ.get("MRH_LIB"):  # a tuning build of the library (mrhash_amd/build.py variant ...)
+    capi.HIP_LIB_PATH = os.path.abspath(os.environ["MRH_LIB"])
 hip = capi.load_hip(); orc = pu.oracle_lib()
 print(hip.mrh_version(), orc.mrh_version())
 
@@ -31,7 +33,7 @@ which = sys.argv[1:] or ["plane", "sphere", "replica", "starve", "multires"]
 if "plane" in which: run("cfg1-plane", synth.CFG1, synth.CFG1_PARAMS, [synth.cfg1_plane()])
 if "sphere" in which: run("cfg1-sphere", synth.CFG1, synth.CFG1_PARAMS, [synth.cfg1_sphere()] * 3)
 if "replica" in which:
-    fr = list(synth.replica_stream(3))
+    fr = list(synth.replica_stream(int(os.environ.get("MRH_QP_FRAMES", "3"))))
     run("replica-640", synth.REPLICA_640, synth.REPLICA_PARAMS, fr, nb=131072, mesh=False)
 if "starve" in which:
     p = dict(synth.CFG1_PARAMS); p["n_frames_invalidate_voxels"] = 2

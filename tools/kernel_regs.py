@@ -7,9 +7,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from mrhash_amd import build as b  # noqa: E402
 
-out = "/tmp/mrh_regs"
+out = os.environ.get("MRH_REGS_DIR", "/tmp/mrh_regs")
 os.makedirs(out, exist_ok=True)
-flags = [f for f in b.HIPCC_FLAGS if not f.startswith("-W")]
+flags = [f for f in b.HIPCC_FLAGS if not f.startswith("-W")] + os.environ.get("MRH_EXTRA_FLAGS", "").split()  # e.g. MRH_EXTRA_FLAGS="-DMRH_BACK_WAVES=5"
 subprocess.run([b.hipcc()] + flags + ["-save-temps", "-o", os.path.join(out, "x.so"), os.path.join(b.CSRC, "mrh_capi.hip")], cwd=out, check=True,
                stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
 txt = open(glob.glob(os.path.join(out, "*gfx950*.s"))[0]).read()
