@@ -561,9 +561,32 @@ def bench_single(args):
             st_ms = (time.perf_counter() - c0) * 1e3
         steady = float(np.median(per[8:64])) if n_leg > 16 else float(np.median(per))
         census = per[64] if n_leg > 64 else None
+        # what a starve frame costs INSIDE the pipeline (round 6: it no longer flushes it): the same frames twice from the same start,
+        # no synchronisation inside, the second pass with one starve frame in the middle; median of three differences
+        never = 1 << 30
+        lo_p, hi_p = min(5, total // 4), total
+        mid_p = (lo_p + hi_p) // 2
+
+        def pipelined_pass(starve_at):
+            pf.reset()
+            res.run(pf, 0, lo_p, integrate=lambda e: e.integrate(never))
+            pf.sync()
+            c1 = time.perf_counter()
+            for i in range(lo_p, hi_p):
+                res.run(pf, i, i + 1, integrate=(lambda e, i=i: e.integrate(i)) if i == starve_at else (lambda e: e.integrate(never)))
+            pf.sync()
+            return (time.perf_counter() - c1) * 1e3
+
+        extra = None
+        if hi_p - lo_p >= 8:
+            pipelined_pass(-1)
+            diffs = sorted(pipelined_pass(mid_p) - pipelined_pass(-1) for _ in range(3))
+            extra = diffs[1]
         periodic = {"what": "single frames, each bracketed by mrh_sync (one synchronisation of overhead in every figure)",
                     "steady_frame_ms": steady, "census_frame_ms": census, "starve_frame_ms": st_ms, "census_period": 64,
                     "starve_period": int(synth.REPLICA_PARAMS["n_frames_invalidate_voxels"]),
+                    "starve_frame_extra_ms_in_pipeline": extra, "starve_frame_extra_what": f"{hi_p - lo_p} resident frames without a synchronisation, "
+                    f"with and without a starve frame at frame {mid_p}: difference of the two wall times (median of three)",
                     "amortised_extra_ms_per_frame": (((census - steady) / 64 if census else 0.0) +
                                                      ((st_ms - steady) / synth.REPLICA_PARAMS["n_frames_invalidate_voxels"] if st_ms else 0.0))}
         pf.close()

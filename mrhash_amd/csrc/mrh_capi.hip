@@ -192,6 +192,14 @@ struct mrh_ctx {
   u32* d_decision = nullptr;
   u64* d_zbuf = nullptr;  // 2 * npix
   size_t zbuf_n = 0;
+  // starve frames on the two-launch path (mrh_fast2.h: k_starve_z / k_starve_tail): two PAIRS of z-buffers, the tail launch of
+  // one starve frame puts the other pair back to "empty" for the next
+  u64* d_zfused = nullptr;  // 2 pairs x 2 x npix
+  size_t zfused_n = 0;
+  bool zfused_clean[2] = {false, false};
+  int zfused_next = 0;
+  bool starve_fused = true;  // MRH_STARVE_FUSED=0: the eight launches of rounds 1-5 (k_starve<0,1,2>, k_summarize_visible, k_free_lists)
+  uint64_t n_starve_fused = 0;
   int4* d_realloc = nullptr;
   int4* d_reint = nullptr;
   int* d_flag = nullptr;
@@ -239,6 +247,7 @@ struct mrh_ctx {
     u32 stamp = 0;
     float thr = 0.f;
     bool free_ = false, profile = false, safe_div = false, count_zombies = false, sph = false;
+    bool starve = false;  // a starve frame: behind the integration (which collects nothing) the three fused starve launches
     EvPair ev = {nullptr, nullptr};
     uint64_t report_seq = 0;  // frame mark whose pool report was written before this integration ran (refreshed behind it)
   };
@@ -436,7 +445,7 @@ void free_all(mrh_ctx* c) {
   if (c->h_mc) (void) hipHostFree(c->h_mc);
   if (c->h_scan) (void) hipHostFree(c->h_scan);
   for (void* a : c->arena) if (a) (void) hipFree(a);
-  F(c->d_decision); F(c->d_zbuf); F(c->d_realloc); F(c->d_reint); F(c->d_flag);
+  F(c->d_decision); F(c->d_zbuf); F(c->d_zfused); F(c->d_realloc); F(c->d_reint); F(c->d_flag);
   F(c->d_upd_partials); F(c->d_misc); F(c->d_rcp_w); F(c->d_cfree); F(c->d_zmin); F(c->d_points); F(c->d_pt_counts); F(c->d_pt_offsets); F(c->d_rec_keys[0]); F(c->d_rec_keys[1]); F(c->d_rec_vals[0]); F(c->d_rec_vals[1]); F(c->d_sort_tmp); F(c->scan.vcnt); F(c->scan.bstamp); F(c->scan.st_meta); F(c->scan.st_sdf); F(c->scan.st_grp); F(c->scan.wgdesc); F(c->scan.rec); F(c->scan.chunks); F(c->d_scan_ctr); F(c->fast.summary); F(c->fast.summary_c); F(c->fast.bbox); F(c->d_cnt_partials);
   F(c->d_pack); F(c->d_halo); F(c->d_taken); F(c->d_cloud); F(c->d_normals); F(c->d_soup); F(c->d_mc_recs);
   for (hipEvent_t e : c->mc_ev) if (e) (void) hipEventDestroy(e);
@@ -1045,6 +1054,41 @@ int ensure_zbuf(mrh_ctx* c, size_t npix) {
   return MRH_OK;
 }
 
+// A starve frame of a single-resolution, unsharded map on the two-launch path: behind the frame's k_back<FREE = false>, the two
+// min-passes and the tail (pass 2 + summaries + garbage collection + the other z-buffer pair cleared) — three launches on the main
+// stream, nothing of the pipeline flushed.  lz: 2 = a pipelined frame (collected blocks become zombies), 0 = a serial frame.
+int launch_starve_fused(mrh_ctx* c, const Cam& k, const Fast& f, const Lists& L, const int set, const float thr, const u32 stamp, const int lz) {
+  const size_t npix = (size_t) k.rows * k.cols;
+  hipStream_t s = c->stream;
+  if (c->zfused_n < npix) {
+    HIP_TRY(c, hipStreamSynchronize(s));
+    if (c->d_zfused) HIP_TRY(c, hipFree(c->d_zfused));
+    c->d_zfused = nullptr; c->zfused_n = 0;
+    HIP_TRY(c, hipMalloc((void**) &c->d_zfused, 4 * npix * sizeof(u64)));
+    c->zfused_n = npix;
+    c->zfused_clean[0] = c->zfused_clean[1] = false;
+  }
+  const int p = c->zfused_next, q = p ^ 1;
+  u64* z0 = c->d_zfused + (size_t) p * 2 * c->zfused_n;
+  u64* z1 = z0 + npix;
+  u64* other = c->d_zfused + (size_t) q * 2 * c->zfused_n;
+  // "empty" = INT64_MAX: above every key (depth bits of a finite positive float < 0x7F800000)
+  if (!c->zfused_clean[p]) k_fill_u64<<<256, 256, 0, s>>>(z0, 2 * npix, 0x7FFFFFFFFFFFFFFFull);
+  c->zfused_clean[p] = false;
+  k_starve_z<0><<<c->integrate_grid, 512, 0, s>>>(k, c->map, c->tab, f, L.vis, set, z0, z1);
+  k_starve_z<1><<<c->integrate_grid, 512, 0, s>>>(k, c->map, c->tab, f, L.vis, set, z0, z1);
+  if (lz == 2) k_starve_tail<2><<<c->integrate_grid, 512, 0, s>>>(k, c->map, c->tab, f, L, set, thr, stamp, z0, z1, other, 2 * npix);
+  else k_starve_tail<0><<<c->integrate_grid, 512, 0, s>>>(k, c->map, c->tab, f, L, set, thr, stamp, z0, z1, other, 2 * npix);
+  HIP_TRY(c, hipGetLastError());
+  c->zfused_clean[q] = true;
+  c->zfused_next = q;
+  c->n_starve_fused++;
+  return MRH_OK;
+}
+// may this frame's starve step take the three fused launches?  (tile-sharded maps reduce the z-buffers over the ranks between the
+// passes, multi-resolution and general frames walk lists of another kind: they keep k_starve<0,1,2>)
+bool starve_fused_ok(const mrh_ctx* c) { return c->starve_fused && c->p.shard_count <= 1 && !c->tab.multi_res && !c->frame_general; }
+
 // one of the three starve passes over the current compact (fast path: visible) list
 int launch_starve(mrh_ctx* c, int pass) {
   const Cam& k = c->cam;
@@ -1303,6 +1347,7 @@ int mrh_create(const mrh_params* p, mrh_ctx** out) {
   }
   if (const char* g = getenv("MRH_DEFER_UPLOADS")) c->defer_uploads = atoi(g) ? 1 : 0;
   if (const char* g = getenv("MRH_PIPE")) c->pipe = atoi(g) ? 1 : 0;
+  if (const char* g = getenv("MRH_STARVE_FUSED")) c->starve_fused = atoi(g) != 0;
   if (const char* g = getenv("MRH_PIPE_GRID")) { const int v = atoi(g); if (v > 0 && v <= 32768) c->pipe_grid = v; }
   if (const char* g = getenv("MRH_PIPE_DEFER")) { const int v = atoi(g); if (v >= 1 && v < mrh_ctx::kPendMax) c->pipe_defer = v; }
   if (const char* g = getenv("MRH_PIPE_UPLOADS")) c->pipe_uploads = atoi(g) ? 1 : 0;
@@ -2005,6 +2050,11 @@ int launch_pending(mrh_ctx* c, const bool count_skips = false) {
 #undef MRH_KB
   if (pb.profile) c->ev_pending.push_back(pb.ev);
   if (pb.free_) c->zombies_possible = true;
+  if (pb.starve) {
+    const int src = launch_starve_fused(c, pb.cam, pb.f, pb.L, pb.set, pb.thr, pb.stamp, 2);
+    if (src) return src;
+    c->zombies_possible = true;
+  }
   if (pb.report_seq && c->peek_enabled) {  // the frame's pool report (mark_frame left it to this launch): behind its integration
     k_report<<<1, 64, 0, s>>>(&c->tab.ctr[CTR_HEAP_FINE], c->h_peek + 8 * (pb.report_seq % 8));
     HIP_TRY(c, hipEventRecord(c->peek_done[pb.report_seq % 8], s));
@@ -2105,7 +2155,10 @@ int integrate_lazy(mrh_ctx* c, const int max_num_frames, const bool starve_now) 
   // only add to the host's bill (measured: 77 us per frame pipelined, 64 serial) — such frames are fused serially unless
   // MRH_PIPE_UPLOADS=1 says otherwise (the test-suite sets it, so that its upload-fed streams exercise the pipeline)
   const bool resident_inputs = c->up_depth.cur < 0 && c->up_rgb.cur < 0;
-  const bool lazy = c->pipe && !starve_now && roomy && c->lazy_run < c->pipe_period && c->sync_streak < 3 && (resident_inputs || c->pipe_uploads) &&
+  // a starve frame stays a frame of the pipeline when its starve step can take the fused launches (round 6; before: every starve
+  // frame flushed the pipeline, ran serially and left a host synchronisation in front of the next pipelined frame)
+  const bool starve_in_pipe = starve_now && starve_fused_ok(c) && !getenv("MRH_STARVE_SERIAL");
+  const bool lazy = c->pipe && (!starve_now || starve_in_pipe) && roomy && c->lazy_run < c->pipe_period && c->sync_streak < 3 && (resident_inputs || c->pipe_uploads) &&
                     !getenv("MRH_PIPE_SERIAL");
   if (!lazy) {
     rc = strict_point(c);
@@ -2186,6 +2239,7 @@ int integrate_lazy(mrh_ctx* c, const int max_num_frames, const bool starve_now) 
     pb.set = set; pb.zero_set = zero_set; pb.ring = ring; pb.seq = seq; pb.stamp = stamp; pb.thr = gc_thr;
     pb.free_ = c->frame_gc_inline; pb.profile = c->profile != 0; pb.safe_div = safe_div; pb.sph = sph;
     pb.count_zombies = zombies_before || c->zombies_possible || c->frame_gc_inline;
+    pb.starve = starve_now;
     pb.ev = ev;
     pb.report_seq = 0;
     c->last_frame_lazy = true;
@@ -2220,6 +2274,12 @@ int integrate_lazy(mrh_ctx* c, const int max_num_frames, const bool starve_now) 
 #undef MRH_KB
   c->front_needs_sync = true;  // direct frees on the main stream
   if (c->profile) c->ev_pending.push_back(ev);
+  if (starve_now && starve_fused_ok(c)) {
+    rc = launch_starve_fused(c, k, f, L, set, gc_thr, stamp, 0);
+    if (rc) return rc;
+    c->frames++;  // frame_tail's bookkeeping: the summaries and the garbage collection ran inside the tail launch
+    return MRH_OK;
+  }
   return starve_and_tail(c, max_num_frames);
 }
 
@@ -2276,6 +2336,17 @@ static int integrate_frame(mrh_ctx* c, int n_frames_invalidate) {
     c->refill_flag_valid = false;
   }
   const bool pipe_frame = (c->pipe || c->spherical) && !c->frame_general && !t.multi_res;  // integrate_lazy also carries the spherical model's serial frames
+  if (max_num_frames > 0 && starve_fused_ok(c) && c->zfused_n < (size_t) k.rows * k.cols) {
+    // the z-buffers of the starve frames, both pairs empty, while the context is still allocating (not inside its first starve frame)
+    const size_t npix = (size_t) k.rows * k.cols;
+    HIP_TRY(c, hipStreamSynchronize(s));
+    if (c->d_zfused) HIP_TRY(c, hipFree(c->d_zfused));
+    c->d_zfused = nullptr; c->zfused_n = 0;
+    HIP_TRY(c, hipMalloc((void**) &c->d_zfused, 4 * npix * sizeof(u64)));
+    c->zfused_n = npix;
+    k_fill_u64<<<512, 256, 0, s>>>(c->d_zfused, 4 * npix, 0x7FFFFFFFFFFFFFFFull);
+    c->zfused_clean[0] = c->zfused_clean[1] = true;
+  }
   if (!pipe_frame) {  // a frame of another kind follows pipelined ones
     rc = strict_point(c);
     if (rc) return rc;
@@ -2373,6 +2444,12 @@ static int integrate_frame(mrh_ctx* c, int n_frames_invalidate) {
 #undef MRH_K_BACK
 #undef MRH_K_BACK_V
     if (c->profile) c->ev_pending.push_back(ev);
+    if (starve_now && starve_fused_ok(c)) {
+      rc = launch_starve_fused(c, k, f, L, parity, gc_thr, stamp, 0);
+      if (rc) return rc;
+      c->frames++;
+      return MRH_OK;
+    }
     return starve_and_tail(c, max_num_frames);
   }
 

@@ -1086,6 +1086,41 @@ def test_pipelined_frames_build_the_serial_map(hip, oracle, monkeypatch, period)
     a.close()
 
 
+@pytest.mark.parametrize("mode", ["pipelined", "serial-fused", "pipelined-old-starve", "synced-every-frame"])
+def test_starve_frames_stay_in_the_pipeline(hip, oracle, monkeypatch, mode):
+    """Round 6: a starve frame (voxel_data_structures.cpp:139) no longer flushes the pipeline — behind its integration (which
+    collects nothing) run the two min-passes of the z-buffer and one tail launch (the winner's weight, the block summaries, the
+    garbage collection through zombies, the other z-buffer pair cleared): k_starve_z / k_starve_tail, mrh_fast2.h.  Period 3 on
+    the moving-camera walk at 160x120: every third frame starves while the front half of the next frame runs next to it, blocks
+    are collected by starve frames and wanted again, zombies meet the z-buffer passes (they must not take part).  Against the
+    oracle, bit for bit, in four ways of running the same frames: pipelined, serial with the fused launches (MRH_PIPE=0), pipelined
+    with the eight launches of rounds 1-5 (MRH_STARVE_FUSED=0: those frames flush the pipeline), and with a synchronisation after
+    every frame (the library falls back to serial frames after three)."""
+    if mode == "serial-fused":
+        monkeypatch.setenv("MRH_PIPE", "0")
+    if mode == "pipelined-old-starve":
+        monkeypatch.setenv("MRH_STARVE_FUSED", "0")
+    K = synth.Intrinsics(160.0, 160.0, 79.5, 59.5, 120, 160)
+    params = dict(synth.REPLICA_PARAMS, virtual_voxel_size=0.02, sdf_truncation=0.08, n_frames_invalidate_voxels=3)
+    a, b = _pair(hip, oracle, K, params, 65536)
+    scene = synth.scannet_room()
+    for i, (t, q) in enumerate(synth.walk_poses(20, seed=11)):
+        f = synth.render(scene, K, t, q, depth_scaling=5000.0)
+        pu.feed(a, f)
+        pu.feed(b, f)
+        if mode == "synced-every-frame":
+            a.sync()
+    a.sync()
+    sa, sb = a.stats(), b.stats()
+    for k in ("occupied_fine", "free_fine", "frames_integrated", "error_flags"):
+        assert getattr(sa, k) == getattr(sb, k), (k, getattr(sa, k), getattr(sb, k))
+    r = pu.compare_maps(a, b)
+    assert r["blocks"] > 500 and r["sdf_bit_exact"] and r["sumsq_bit_exact"]
+    pu.compare_meshes(a, b)
+    a.close()
+    b.close()
+
+
 def test_peeks_next_to_pipelined_frames_read_reports_that_were_written(hip, oracle):
     """the pool report of a pipelined frame is written behind its integration (launch_pending), and only
     then does the mark exist for the non-blocking peeks — an event on the front stream, or a report launched before the
