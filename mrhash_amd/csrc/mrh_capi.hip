@@ -1075,10 +1075,18 @@ int launch_starve_fused(mrh_ctx* c, const Cam& k, const Fast& f, const Lists& L,
   // "empty" = INT64_MAX: above every key (depth bits of a finite positive float < 0x7F800000)
   if (!c->zfused_clean[p]) k_fill_u64<<<256, 256, 0, s>>>(z0, 2 * npix, 0x7FFFFFFFFFFFFFFFull);
   c->zfused_clean[p] = false;
-  k_starve_z<0><<<c->integrate_grid, 512, 0, s>>>(k, c->map, c->tab, f, L.vis, set, z0, z1);
-  k_starve_z<1><<<c->integrate_grid, 512, 0, s>>>(k, c->map, c->tab, f, L.vis, set, z0, z1);
-  if (lz == 2) k_starve_tail<2><<<c->integrate_grid, 512, 0, s>>>(k, c->map, c->tab, f, L, set, thr, stamp, z0, z1, other, 2 * npix);
-  else k_starve_tail<0><<<c->integrate_grid, 512, 0, s>>>(k, c->map, c->tab, f, L, set, thr, stamp, z0, z1, other, 2 * npix);
+  const int grid = 2048;  // x 4 waves, one block each per round
+  if (k.model) {
+    k_starve_z<0, true><<<grid, 256, 0, s>>>(k, c->map, c->tab, f, L.vis, set, z0, z1);
+    k_starve_z<1, true><<<grid, 256, 0, s>>>(k, c->map, c->tab, f, L.vis, set, z0, z1);
+    if (lz == 2) k_starve_tail<2, true><<<grid, 256, 0, s>>>(k, c->map, c->tab, f, L, set, thr, stamp, z0, z1, other, 2 * npix);
+    else k_starve_tail<0, true><<<grid, 256, 0, s>>>(k, c->map, c->tab, f, L, set, thr, stamp, z0, z1, other, 2 * npix);
+  } else {
+    k_starve_z<0, false><<<grid, 256, 0, s>>>(k, c->map, c->tab, f, L.vis, set, z0, z1);
+    k_starve_z<1, false><<<grid, 256, 0, s>>>(k, c->map, c->tab, f, L.vis, set, z0, z1);
+    if (lz == 2) k_starve_tail<2, false><<<grid, 256, 0, s>>>(k, c->map, c->tab, f, L, set, thr, stamp, z0, z1, other, 2 * npix);
+    else k_starve_tail<0, false><<<grid, 256, 0, s>>>(k, c->map, c->tab, f, L, set, thr, stamp, z0, z1, other, 2 * npix);
+  }
   HIP_TRY(c, hipGetLastError());
   c->zfused_clean[q] = true;
   c->zfused_next = q;

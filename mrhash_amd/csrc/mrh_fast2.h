@@ -948,87 +948,130 @@ __global__ __launch_bounds__(256) void k_summarize_all(const Tab t, const Fast f
 // k_front, k_back<no free>, zbuf fill, three passes, k_summarize_visible, k_free_lists — eight launches, 0.2-0.4 ms, and a host
 // synchronisation in front of the next pipelined frame.  Here the frame stays a frame of the pipeline:
 //   k_back<FREE = false>      integrates, collects nothing (the front half of the next frame runs next to all of this as usual)
-//   k_starve_z<0>, <1>        the two min-passes over the frame's own visible list (ring slot), skipping the entries the integration
+//   k_starve_z<0>, <1>        the two min-passes over the frame's own visible list (ring slot), one wave per block, skipping the entries the integration
 //                             skipped: a zombie nobody wanted still carries its flag, a wanted one had its summary rewritten
 //   k_starve_tail<LZ>         pass 2 (the winner's weight), the block's summary from its planes as they now are, the GC decision
 //                             (visible list by that summary, culled list as free_candidates / free_range do) — zombies under
 //                             LZ = 2, frees on a serial frame —, and the OTHER pair of z-buffers back to "empty" for the next
 //                             starve frame (the pair in use is still being read by other workgroups)
 // Same keys, same winner, same decrement, same summaries, same decisions as the eight launches.
-__device__ __forceinline__ bool starve_key(const Cam& c, const Map& m, const int4 ent, const int v, size_t& pix, u64& hi, u64& lo) {
-  // fine delinearisation for every block, as the reference does (vds.cu:1606-1607)
-  const i3 pi = mki3(ent.x * kBlockSide + (v & 7), ent.y * kBlockSide + ((v >> 3) & 7), ent.z * kBlockSide + (v >> 6));
-  const f3 pcam = se3_apply(c.Ri, c.ti, voxel_to_world(m.vs, pi));
-  const float dep = get_depth(c, pcam);
-  if (dep < c.min_depth) return false;
-  int row, col;
-  if (!project_point_m<false>(c, pcam, row, col)) return false;
-  u64 key;
-  pack_key(mki3(ent.x, ent.y, ent.z), key);
-  hi = ((u64) __float_as_uint(dep) << 32) | (key >> 31);  // top 32 bits of the 72-bit (key63 << 9 | v)
-  lo = ((key & 0x7FFFFFFFull) << 9) | (u64) v;            // low 40 bits
-  pix = (size_t) row * c.cols + col;
-  return true;
+// One wave per block, eight voxels per lane, through project4 / project4_sph — integrate_voxel's arithmetic, which IS the starve
+// kernel's: the same se3_apply association, the same IEEE quotients (div_rr), `depth_ok && in image` == `!(dep < min_depth) &&
+// projectPoint` (camera.cuh:131-164) — at a third of the instructions of one thread per voxel with compiler divisions.
+// Voxel q * 4 + k of float4-group q: its linear index in the block IS 4 q + k (x + 8 y + 64 z), the `v` of the 72-bit key.
+struct StarveKeys {
+  u32 pix[4];  // pixel index (valid voxels only)
+  u32 dep[4];  // depth bits
+  u32 mask;
+};
+template <bool SPH>
+__device__ __forceinline__ StarveKeys starve_keys4(const Cam& c, const Map& m, const int4 ent, const int q) {
+  const Proj4 P = SPH ? project4_sph(c, m, ent, q) : project4(c, m, ent, q);
+  StarveKeys k;
+  k.mask = P.mask;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    k.pix[i] = ((P.mask >> i) & 1u) ? (u32) (__mul24(P.row[i], c.cols) + P.col[i]) : 0u;
+    k.dep[i] = __float_as_uint(P.pcz[i]);
+  }
+  return k;
 }
-template <int PASS>
-__global__ __launch_bounds__(512) void k_starve_z(const Cam c, const Map m, const Tab t, const Fast f, const int4* __restrict__ vis, const int set,
+// (Pass 0 is ~1 M successful min-updates of 0.3 M words — 80 of the step's 125 us.  One copy of the buffer per XCD, indexed by
+// HW_REG_XCC_ID and updated with L2-local atomics, then folded by a merge launch, was measured in round 6: each atomic is three
+// times cheaper, but a pixel sees a new minimum 1.7 times per XCD instead of 3.6 times in all, i.e. there are four times as many
+// of them: 92 + 9 us.)
+template <int PASS, bool SPH>
+__global__ __launch_bounds__(256) void k_starve_z(const Cam c, const Map m, const Tab t, const Fast f, const int4* __restrict__ vis, const int set,
                                                   u64* __restrict__ zbuf0, u64* __restrict__ zbuf1) {
   const int count = t.ctr[CTR_SET0 + 4 * set];
-  const int v = threadIdx.x;
-  for (int e = blockIdx.x; e < count; e += gridDim.x) {
+  const int lane = threadIdx.x & 63;
+  const int gw = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
+  for (int e = __builtin_amdgcn_readfirstlane(gw); e < count; e += nw) {
     const int4 ent = vis[e];
-    if (f.summary[ent.w].y & kZombieBit) continue;  // not a block of this frame (mrh_fast2.h: lazy garbage collection)
-    size_t pix;
-    u64 hi, lo;
-    if (!starve_key(c, m, ent, v, pix, hi, lo)) continue;
-    // the values only fall: a plain look first saves the atomic for every voxel that is not in front of what the pixel already
-    // holds (most of them; a stale look costs an atomic that changes nothing)
-    if (PASS == 0) { if (zbuf0[pix] > hi) atomicMin(&zbuf0[pix], hi); }
-    else if (zbuf0[pix] == hi && zbuf1[pix] > lo) atomicMin(&zbuf1[pix], lo);
+    if (f.summary[ent.w].y & kZombieBit) continue;  // not a block of this frame (lazy garbage collection); wave-uniform
+    u64 key;
+    pack_key(mki3(ent.x, ent.y, ent.z), key);
+    const u32 key_hi = (u32) (key >> 31);              // with the depth bits: the top 64 of the 72-bit (depth, key63 << 9 | v)
+    const u64 key_lo = (key & 0x7FFFFFFFull) << 9;     // the low 40 bits, before `| v`
+#pragma unroll
+    for (int b = 0; b < 2; b++) {
+      const int q = lane + 64 * b;
+      const StarveKeys k = starve_keys4<SPH>(c, m, ent, q);
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        if (!((k.mask >> i) & 1u)) continue;
+        const u64 hi = ((u64) k.dep[i] << 32) | key_hi;
+        // the values only fall: a plain look first saves the atomic for every voxel that is not in front of what the pixel
+        // already holds (most of them; a stale look costs an atomic that changes nothing)
+        if (PASS == 0) {
+          if (zbuf0[k.pix[i]] > hi) atomicMin(&zbuf0[k.pix[i]], hi);
+        } else if (zbuf0[k.pix[i]] == hi) {
+          const u64 lo = key_lo | (u64) (q * 4 + i);
+          if (zbuf1[k.pix[i]] > lo) atomicMin(&zbuf1[k.pix[i]], lo);
+        }
+      }
+    }
   }
 }
-template <int LZ>
-__global__ __launch_bounds__(512) void k_starve_tail(const Cam c, const Map m, const Tab t, const Fast f, const Lists L, const int set,
+template <int LZ, bool SPH>
+__global__ __launch_bounds__(256) void k_starve_tail(const Cam c, const Map m, const Tab t, const Fast f, const Lists L, const int set,
                                                      const float trunc_threshold, const u32 want_stamp, const u64* __restrict__ zbuf0,
                                                      const u64* __restrict__ zbuf1, u64* __restrict__ clear, const size_t n_clear) {
-  __shared__ u32 s_mn[8], s_mx[8];
   const int cs = CTR_SET0 + 4 * set;
   const int nvis = t.ctr[cs + 0], ncfree = t.ctr[cs + 2];
-  const int v = threadIdx.x, lane = v & 63, w = v >> 6;
-  for (int e = blockIdx.x; e < nvis; e += gridDim.x) {
+  const int lane = threadIdx.x & 63;
+  const int gw = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
+  for (int e = __builtin_amdgcn_readfirstlane(gw); e < nvis; e += nw) {
     const int4 ent = L.vis[e];
     const u32 H = (u32) ent.w;
-    if (f.summary[H].y & kZombieBit) continue;  // workgroup-uniform
-    const VoxPtr vp = vox_ptr(t, H);
-    u32 rw = vp.rgbw[v];
-    size_t pix;
-    u64 hi, lo;
-    if (starve_key(c, m, ent, v, pix, hi, lo) && zbuf0[pix] == hi && zbuf1[pix] == lo) {  // pass 2: the unique winner of its pixel
-      const u32 wk = rw >> 24;
-      rw = (rw & 0x00FFFFFFu) | ((wk > 0 ? wk - 1 : 0) << 24);
-      vp.rgbw[v] = rw;
-    }
-    const u32 wk = rw >> 24;
-    const u32 mnw = wave_min_u32(umin_(0x7F7FFFFFu, wk != 0 ? (__float_as_uint(vp.sdf[v]) & 0x7FFFFFFFu) : 0xFFFFFFFFu));
-    const u32 mxw = wave_max_u32(wk);
-    if (lane == 0) { s_mn[w] = mnw; s_mx[w] = mxw; }
-    __syncthreads();
-    u32 mn = s_mn[0], mx = s_mx[0];
+    if (f.summary[H].y & kZombieBit) continue;  // wave-uniform
+    float4* ps = (float4*) (t.pool + (size_t) H * kFineBytes);
+    uint4* pw = (uint4*) (ps + 256);
+    u64 key;
+    pack_key(mki3(ent.x, ent.y, ent.z), key);
+    const u32 key_hi = (u32) (key >> 31);
+    const u64 key_lo = (key & 0x7FFFFFFFull) << 9;
+    u32 mnb = 0x7F7FFFFFu, mx = 0;
 #pragma unroll
-    for (int i = 1; i < 8; i++) { mn = umin_(mn, s_mn[i]); mx = umax_(mx, s_mx[i]); }
-    __syncthreads();  // the next block's partials may land
-    if (v == 0) f.summary[H] = make_uint2(mn, mx);
-    if (w == 0 && (__uint_as_float(mn) >= trunc_threshold || mx == 0)) {  // vds.cu:1708-1711
+    for (int b = 0; b < 2; b++) {
+      const int q = lane + 64 * b;
+      const float4 S = ps[q];
+      uint4 W = pw[q];
+      const StarveKeys k = starve_keys4<SPH>(c, m, ent, q);
+      u32 w[4] = {W.x, W.y, W.z, W.w};
+      u32 won = 0;
+#pragma unroll
+      for (int i = 0; i < 4; i++) {  // pass 2: the unique winner of its pixel loses one unit of weight (vds.cu:1640-1647)
+        if (!((k.mask >> i) & 1u)) continue;
+        const u64 hi = ((u64) k.dep[i] << 32) | key_hi;
+        if (zbuf0[k.pix[i]] == hi && zbuf1[k.pix[i]] == (key_lo | (u64) (q * 4 + i))) {
+          const u32 wk = w[i] >> 24;
+          w[i] = (w[i] & 0x00FFFFFFu) | ((wk > 0 ? wk - 1 : 0) << 24);
+          won |= 1u << i;
+        }
+      }
+      if (won) pw[q] = make_uint4(w[0], w[1], w[2], w[3]);
+      const float s[4] = {S.x, S.y, S.z, S.w};
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const u32 wk = w[i] >> 24;
+        mnb = umin_(mnb, wk != 0 ? (__float_as_uint(s[i]) & 0x7FFFFFFFu) : 0xFFFFFFFFu);
+        mx = umax_(mx, wk);
+      }
+    }
+    const u32 mn = wave_min_u32(mnb);
+    mx = wave_max_u32(mx);
+    if (lane == 0) f.summary[H] = make_uint2(mn, mx);
+    if (__uint_as_float(mn) >= trunc_threshold || mx == 0) {  // vds.cu:1708-1711
       if (LZ == 2) wave_zombify(t, f, ent, lane);
       else wave_free_block(t, ent, lane);
       if (lane == 0) atomicAdd(&t.prof[PROF_FREED], 1ull);
     }
   }
   // the culled list: candidates under lazy garbage collection, decided entries on a serial frame
-  const int gw = blockIdx.x * 8 + w, nw = gridDim.x * 8;
   if (LZ) free_candidates<true, LZ>(t, f, L, trunc_threshold, ncfree, gw, nw, lane, want_stamp);
   else free_range<true, false>(t, L, ncfree, gw, nw, lane, nullptr);
-  for (size_t i = (size_t) blockIdx.x * 512 + v; i < n_clear; i += (size_t) gridDim.x * 512) clear[i] = 0x7FFFFFFFFFFFFFFFull;
+  for (size_t i = (size_t) blockIdx.x * 256 + threadIdx.x; i < n_clear; i += (size_t) gridDim.x * 256) clear[i] = 0x7FFFFFFFFFFFFFFFull;
 }
 
 // starve frames: GC after the weights changed — visible list by refreshed summary, plus the culled-free list
