@@ -979,7 +979,9 @@ __device__ __forceinline__ StarveKeys starve_keys4(const Cam& c, const Map& m, c
 // (Pass 0 is ~1 M successful min-updates of 0.3 M words — 80 of the step's 125 us.  One copy of the buffer per XCD, indexed by
 // HW_REG_XCC_ID and updated with L2-local atomics, then folded by a merge launch, was measured in round 6: each atomic is three
 // times cheaper, but a pixel sees a new minimum 1.7 times per XCD instead of 3.6 times in all, i.e. there are four times as many
-// of them: 92 + 9 us.)
+// of them: 92 + 9 us.  Pass 0 riding on the frame's integration (the voxels are projected there anyway: k_back<FREE = false> with the
+// look + atomic per voxel) was measured, too: 109 us for the one launch against 31 + 79 for the two — the atomics are the time,
+// and nothing of them hides under the integration's arithmetic.)
 template <int PASS, bool SPH>
 __global__ __launch_bounds__(256) void k_starve_z(const Cam c, const Map m, const Tab t, const Fast f, const int4* __restrict__ vis, const int set,
                                                   u64* __restrict__ zbuf0, u64* __restrict__ zbuf1) {
