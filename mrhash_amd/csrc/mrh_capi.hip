@@ -197,6 +197,7 @@ struct mrh_ctx {
   u64* d_zfused = nullptr;  // 2 pairs x 2 x npix
   size_t zfused_n = 0;
   bool zfused_clean[2] = {false, false};
+  size_t zfused_clean_npix = 0;  // the image size the clean pairs were cleared for (a pair holds zbuf0 | zbuf1 at THAT size)
   int zfused_next = 0;
   bool starve_fused = true;  // MRH_STARVE_FUSED=0: the eight launches of rounds 1-5 (k_starve<0,1,2>, k_summarize_visible, k_free_lists)
   uint64_t n_starve_fused = 0;
@@ -336,6 +337,19 @@ struct mrh_ctx {
   u32 stage_epoch = 0;
   void* mesh_clean_base = nullptr;  // arena slot 1 as the last extraction left it: the first mesh_clean_words words are 0xFFFFFFFF
   size_t mesh_clean_words = 0;
+  // The host side of a context's FIRST extraction — four pinned mappings (mmap + first touch + hipHostRegister: ~0.9 ms for the
+  // 20 MB of a 0.5 M-triangle mesh) and the 24 MB of doubles the caller sees — used to be paid inside that call, after a
+  // synchronisation that told it the sizes: 2.8 ms where every later extraction takes 0.85, and a one-shot extractMesh (what
+  // every runner of the reference does) only ever makes the first.  A context that fuses frames will be asked for its mesh: at
+  // its 8th, 64th, 512th ... frame — while no extraction has happened yet — a helper thread sizes those buffers from the live
+  // blocks the device last reported (64 vertices a block: twice what the rooms of the benchmarks yield, so a map that keeps
+  // growing still fits), behind the frame loop's back.  The first extraction then finds its staging ready and runs like any
+  // other; if the estimate was short, it grows the buffers as before.  Nothing is touched once an extraction has handed
+  // pointers to the caller.  MRH_PREWARM=0 switches it off.
+  std::thread prewarm_thr;
+  bool prewarm_on = true;
+  uint64_t n_extractions = 0;
+  uint64_t prewarm_vertices = 0;  // what the staging was last prepared for
   bool f64_link = false;       // MRH_MESH_F64_LINK=1: V / C widened on the device and copied as doubles (the round-3 path; A/B, tests)
   // profiling
   int profile = 0;
@@ -588,9 +602,13 @@ int strict_point(mrh_ctx* c);
 // so far, the zombies nobody wanted leave the table, so that whatever the call reads, changes or waits for is exactly the map two
 // serial launches per frame would have left
 int flush_deferred(mrh_ctx* c);
+void prewarm_join(mrh_ctx* c) {
+  if (c->prewarm_thr.joinable()) c->prewarm_thr.join();
+}
 int ensure_ready(mrh_ctx* c, const char* who) {
   int rc = ensure_device(c, who);
   if (rc) return rc;
+  prewarm_join(c);  // whatever the call does with the result buffers, nobody else is sizing them
   rc = flush_deferred(c);  // a host-fed frame that mrh_integrate kept back runs before anything else looks at the map
   if (rc < 0) return rc;
   if (c->stream_front) c->front_needs_sync = true;  // whatever this call does to the map, the front stream must see it before its next launch
@@ -1068,6 +1086,8 @@ int launch_starve_fused(mrh_ctx* c, const Cam& k, const Fast& f, const Lists& L,
     c->zfused_n = npix;
     c->zfused_clean[0] = c->zfused_clean[1] = false;
   }
+  if (c->zfused_clean_npix != npix) c->zfused_clean[0] = c->zfused_clean[1] = false;  // the camera changed size since the pairs were cleared
+  c->zfused_clean_npix = npix;
   const int p = c->zfused_next, q = p ^ 1;
   u64* z0 = c->d_zfused + (size_t) p * 2 * c->zfused_n;
   u64* z1 = z0 + npix;
@@ -1356,6 +1376,7 @@ int mrh_create(const mrh_params* p, mrh_ctx** out) {
   if (const char* g = getenv("MRH_DEFER_UPLOADS")) c->defer_uploads = atoi(g) ? 1 : 0;
   if (const char* g = getenv("MRH_PIPE")) c->pipe = atoi(g) ? 1 : 0;
   if (const char* g = getenv("MRH_STARVE_FUSED")) c->starve_fused = atoi(g) != 0;
+  if (const char* g = getenv("MRH_PREWARM")) c->prewarm_on = atoi(g) != 0;
   if (const char* g = getenv("MRH_PIPE_GRID")) { const int v = atoi(g); if (v > 0 && v <= 32768) c->pipe_grid = v; }
   if (const char* g = getenv("MRH_PIPE_DEFER")) { const int v = atoi(g); if (v >= 1 && v < mrh_ctx::kPendMax) c->pipe_defer = v; }
   if (const char* g = getenv("MRH_PIPE_UPLOADS")) c->pipe_uploads = atoi(g) ? 1 : 0;
@@ -1414,6 +1435,7 @@ int mrh_destroy(mrh_ctx* c) {
     }
   }
 #endif
+  prewarm_join(c);
   if (c->deferred.on) { (void) hipSetDevice(c->device); (void) flush_deferred(c); }  // the frame mrh_integrate accepted last
   widen_quiesce();  // the result arrays are about to be unmapped
   if (getenv("MRH_DEBUG") || getenv("MRH_WIDEN_REPORT"))
@@ -2104,7 +2126,7 @@ int ensure_pipe_buffers(mrh_ctx* c, const size_t npix) {
     HIP_TRY(c, hipMalloc((void**) &c->fast.zlist, cap * sizeof(int4)));
     HIP_TRY(c, hipMalloc((void**) &c->want_ring, (size_t) kPipeRing * c->slots * sizeof(u32)));
     HIP_TRY(c, hipMemsetAsync(c->want_ring, 0, (size_t) kPipeRing * c->slots * sizeof(u32), c->stream));  // stamps start at 1
-    HIP_TRY(c, hipHostMalloc((void**) &c->h_levels, 4 * sizeof(int), hipHostMallocDefault));
+    if (!c->h_levels) HIP_TRY(c, hipHostMalloc((void**) &c->h_levels, 4 * sizeof(int), hipHostMallocDefault));  // (the prewarm may have asked for the report first)
     c->h_levels[0] = (int) c->num_blocks - 1; c->h_levels[1] = 0; c->h_levels[2] = -1;
     c->tab.h_levels = c->h_levels;
     c->front_needs_sync = true;  // the memset above
@@ -2312,9 +2334,47 @@ static int integrate_checks(mrh_ctx* c) {
   return MRH_OK;
 }
 
+// see mrh_ctx::prewarm_thr
+static void prewarm_maybe(mrh_ctx* c) {
+  if (!c->prewarm_on || c->n_extractions || c->f64_link || c->mesh_on_host) return;
+  const uint64_t f = c->frames;
+  if (!c->h_levels) {  // not a pipelining context: ask its integration launches for the same report of the pool level (frame_epilogue)
+    if (f < 1) return;
+    if (hipHostMalloc((void**) &c->h_levels, 4 * sizeof(int), hipHostMallocDefault) != hipSuccess) { (void) hipGetLastError(); c->h_levels = nullptr; return; }
+    c->h_levels[0] = (int) c->num_blocks - 1; c->h_levels[1] = 0; c->h_levels[2] = -1;
+    c->tab.h_levels = c->h_levels;
+    return;
+  }
+  if (f < 8 || (f & (f - 1)) != 0 || (f != 8 && f != 64 && f != 512 && f < 4096)) return;  // 8, 64, 512, then every power of two
+  const int64_t free_known = (int64_t) ((volatile int*) c->h_levels)[0] + 1;
+  const uint64_t live = (uint64_t) std::max<int64_t>((int64_t) c->num_blocks - free_known, 0);
+  const uint64_t nv = live * 64;
+  if (nv < 4096 || nv <= c->prewarm_vertices) return;
+  prewarm_join(c);
+  c->prewarm_vertices = nv;
+  c->prewarm_thr = std::thread([c, nv] {
+    (void) hipSetDevice(c->device);
+    try {
+      const size_t nf = (size_t) (nv + nv / 4);  // faces: a little above the vertices (closed surfaces: twice; what is seen of a room: ~1.1 x)
+      c->V32.resize_discard((size_t) nv * 3 + 4); c->C32.resize_discard((size_t) nv * 3 + 4);
+      c->F.resize_discard(nf * 3 + 4);
+      c->stage_ctl.resize_discard(kStageHdrWords + 2 * ((std::min(c->V32.cap, c->C32.cap) * 4 + kStageChunk - 1) / kStageChunk + 2));
+      if (c->stage_ctl.data()) memset(c->stage_ctl.data(), 0, c->stage_ctl.cap * sizeof(u32));  // no epoch, no flag of an earlier life
+      c->V.resize_discard((size_t) nv * 3); c->C.resize_discard((size_t) nv * 3);
+      for (HostVec<double>* h : {&c->V, &c->C})  // the doubles are written by the widening threads: faulted in here instead of there
+        for (size_t o = 0; o < h->cap * sizeof(double); o += 4096) ((volatile char*) h->data())[o] = 0;
+      c->V32.clear(); c->C32.clear(); c->F.clear(); c->V.clear(); c->C.clear();  // capacity, not content: the getters still answer "no mesh"
+    } catch (...) {
+      // no memory for it: the first extraction sizes its buffers itself, as it always did
+    }
+    (void) hipGetLastError();
+  });
+}
+
 static int integrate_frame(mrh_ctx* c, int n_frames_invalidate) {
   int rc = integrate_checks(c);
   if (rc) return rc;
+  prewarm_maybe(c);
   const Cam& k = c->cam;
   const int max_num_frames = n_frames_invalidate < 0 ? c->p.n_frames_invalidate_voxels : n_frames_invalidate;
   hipStream_t s = c->stream;
@@ -2354,6 +2414,7 @@ static int integrate_frame(mrh_ctx* c, int n_frames_invalidate) {
     c->zfused_n = npix;
     k_fill_u64<<<512, 256, 0, s>>>(c->d_zfused, 4 * npix, 0x7FFFFFFFFFFFFFFFull);
     c->zfused_clean[0] = c->zfused_clean[1] = true;
+    c->zfused_clean_npix = npix;
   }
   if (!pipe_frame) {  // a frame of another kind follows pipelined ones
     rc = strict_point(c);
@@ -3193,6 +3254,7 @@ int mrh_extract_triangles(mrh_ctx* c, const mrh_triangle** out_tris, uint64_t* o
   int n = 0;
   rc = compact_all(c, &n);  // the one scalar the host needs up front: it sizes the sort and the launches
   if (rc) return rc;
+  c->n_extractions++;  // from here on the caller may hold pointers into the result buffers: the prewarm leaves them alone
   c->tris.clear();
   c->tri_blocks.clear();
   c->tri_counts.clear();
@@ -3415,6 +3477,8 @@ int mrh_extract_triangles(mrh_ctx* c, const mrh_triangle** out_tris, uint64_t* o
 // (tests/test_geowrapper_gpu.py compares with the oracle, which restates the incremental form literally).
 int mrh_mesh_merge_begin(mrh_ctx* c) {
   if (!c) return MRH_ERR_INVALID_ARG;
+  prewarm_join(c);
+  c->n_extractions++;
   c->merge_on = true;
   c->acc_n = 0;
   c->V.clear(); c->C.clear(); c->F.clear();
@@ -3444,6 +3508,8 @@ int mrh_mesh_merge_end(mrh_ctx* c, uint64_t* out_total_triangles) {
 
 int mrh_extract_mesh(mrh_ctx* c, const double** v, uint64_t* nv, const int32_t** f, uint64_t* nf, const double** col) {
   if (!c || !v || !nv || !f || !nf || !col) return MRH_ERR_INVALID_ARG;
+  prewarm_join(c);
+  c->n_extractions++;  // the caller holds these pointers until the next extraction
   *v = c->V.empty() ? nullptr : c->V.data();
   *nv = c->V.size() / 3;
   *f = c->F.empty() ? nullptr : c->F.data();
