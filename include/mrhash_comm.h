@@ -93,8 +93,8 @@ typedef struct mrh_comm_merge_info {
 } mrh_comm_merge_info;
 /* Frame-sharded sub-maps -> one tile-sharded map.  Sets the context's sharding to (rank, world, chunk_log2); packs, per
  * destination, the blocks that rank owns; all-to-all with true split sizes (grouped ncclSend / ncclRecv); empties the
- * local map; folds the incoming sub-maps in rank order with combineVoxel's arithmetic (MRH_UNPACK_MERGE).  Single-resolution
- * maps only. */
+ * local map; folds the incoming sub-maps in rank order with combineVoxel's arithmetic (MRH_UNPACK_MERGE; variance-adaptive
+ * maps: a position at two resolutions ends up coarse, see mrh_unpack_mode). */
 int mrh_comm_merge_submaps(mrh_ctx* ctx, int chunk_log2, mrh_comm_merge_info* out_info);
 
 /* Sharded extraction: every rank runs marching cubes over the blocks it owns (call mrh_comm_exchange_halo first), the

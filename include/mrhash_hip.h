@@ -416,7 +416,11 @@ typedef enum mrh_unpack_mode {
   MRH_UNPACK_MERGE = 1  /* weighted merge into the map, voxel by voxel, with combineVoxel's arithmetic
                            (vhu.cuh:167-181): sdf = (s0 w0 + s1 w1) / (w0 + w1), weight = min(max, w0 + w1),
                            colour = u8(0.5 c0 + 0.5 c1 + 0.5); a voxel with weight 0 on one side takes the other
-                           side unchanged; absent blocks are inserted.  Single-resolution maps only.             */
+                           side unchanged; absent blocks are inserted.  Variance-adaptive maps (round 6): a position
+                           that is fine on one side and coarse on the other ends up COARSE — the coarse side wins, the fine
+                           side's observations are dropped, as reallocBlock drops them when it coarsens a block
+                           (vds.cu:627-755); the result does not depend on the order of the sub-maps.  *out_taken counts
+                           the records that were merged or inserted (a fine record onto a coarse block is not).           */
 } mrh_unpack_mode;
 /* `records` is a device pointer iff is_device_memory != 0 (what a RCCL collective leaves behind).  Blocks.
  * The records of ONE call must carry distinct block positions (the blocks of one rank's map do): every record is handled by

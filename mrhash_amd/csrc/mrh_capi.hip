@@ -3639,6 +3639,26 @@ void map_changed_in_bulk(mrh_ctx* c) {
 }
 }  // namespace
 
+// room on the coarse free list for `need` coarse blocks, in allocateMemoryLow's portions (vds.cu:860-871: k_refill): an import or a
+// merge into a context whose frames have not refilled the list yet (vds.cu:885-891 does it at the start of a frame).  Blocks.
+static int ensure_coarse_units(mrh_ctx* c, const uint64_t need) {
+  if (!c->tab.multi_res || need == 0) return MRH_OK;
+  hipStream_t s = c->stream;
+  int lev[2] = {0, 0};  // CTR_HEAP_FINE, CTR_HEAP_COARSE are adjacent: stack tops, free count = top + 1
+  HIP_TRY(c, hipMemcpyAsync(lev, &c->tab.ctr[CTR_HEAP_FINE], 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+  HIP_TRY(c, hipStreamSynchronize(s));
+  int64_t fine_free = (int64_t) lev[0] + 1, coarse_free = (int64_t) lev[1] + 1;
+  while (coarse_free < (int64_t) need && c->low_blocks_to_allocate > 0 && fine_free > (int64_t) c->low_blocks_to_allocate) {
+    HIP_TRY(c, hipMemsetAsync(c->d_flag, 0xFF, sizeof(int), s));  // any non-zero flag: refill
+    k_refill<<<(c->low_blocks_to_allocate + 255) / 256, 256, 0, s>>>(c->tab, c->low_blocks_to_allocate, c->d_flag);
+    fine_free -= c->low_blocks_to_allocate;
+    coarse_free += 8 * (int64_t) c->low_blocks_to_allocate;
+  }
+  c->refill_flag_valid = false;
+  HIP_TRY(c, hipGetLastError());
+  return MRH_OK;
+}
+
 int mrh_import_blocks(mrh_ctx* c, const mrh_block_desc* descs, const mrh_voxel* voxels, uint64_t n) {
   int rc = ensure_ready(c, "mrh_import_blocks");
   if (rc) return rc;
@@ -3647,6 +3667,12 @@ int mrh_import_blocks(mrh_ctx* c, const mrh_block_desc* descs, const mrh_voxel* 
   if (c->pending) return fail(c, MRH_ERR_STATE, "mrh_import_blocks: an exchange is pending (call mrh_integrate_resume)");
   rc = set_aside_flags(c);
   if (rc) return rc;
+  if (c->tab.multi_res) {
+    uint64_t need = 0;
+    for (uint64_t k = 0; k < n; k++) need += descs[k].resolution != 0;
+    rc = ensure_coarse_units(c, need);
+    if (rc) return rc;
+  }
   map_changed_in_bulk(c);
   // two staging buffers, the copies on their own stream: the host-to-device copy of chunk i + 1 (the caller's memory is
   // pageable: the runtime stages it) runs under the insert kernel of chunk i; one synchronisation at the end
@@ -3772,7 +3798,6 @@ int mrh_unpack_blocks(mrh_ctx* c, int mode, const mrh_block_record* records, uin
   if (!records) return fail(c, MRH_ERR_INVALID_ARG, "mrh_unpack_blocks: null argument");
   if (n > 0x7FFFFFFFull) return fail(c, MRH_ERR_CAPACITY, "mrh_unpack_blocks: %llu records in one call", (unsigned long long) n);
   if (c->pending) return fail(c, MRH_ERR_STATE, "mrh_unpack_blocks: an exchange is pending (call mrh_integrate_resume)");
-  if (mode == MRH_UNPACK_MERGE && c->tab.multi_res) return fail(c, MRH_ERR_UNSUPPORTED, "mrh_unpack_blocks: merging variance-adaptive (multi-resolution) maps is not supported");
   rc = set_aside_flags(c);
   if (rc) return rc;
   hipStream_t s = c->stream;
@@ -3798,11 +3823,27 @@ int mrh_unpack_blocks(mrh_ctx* c, int mode, const mrh_block_record* records, uin
   map_changed_in_bulk(c);
   const int grid = (int) (n < 4096 ? n : 4096);
   const size_t stride = sizeof(mrh_block_record);
+  // a merge into a variance-adaptive map: room on the coarse free list for every coarse record of the call, in
+  // allocateMemoryLow's portions (vds.cu:860-871: k_refill), and a list for the fine slots that make way for coarse records
+  DevBuf<u32> released;
+  if (mode == MRH_UNPACK_MERGE && c->tab.multi_res) {
+    HIP_TRY(c, released.alloc((size_t) n + 1));
+    HIP_TRY(c, hipMemsetAsync(released, 0, sizeof(u32), s));
+    k_count_coarse_records<<<64, 256, 0, s>>>(d_rec, stride, (int) n, c->d_taken);  // d_taken doubles as the counter, zeroed again below
+    u32 need = 0;
+    HIP_TRY(c, hipMemcpyAsync(&need, c->d_taken, sizeof(u32), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    HIP_TRY(c, hipMemsetAsync(c->d_taken, 0, sizeof(u32), s));
+    rc = ensure_coarse_units(c, need);
+    if (rc) return rc;
+  }
   if (mode == MRH_UNPACK_HALO) {
     k_import<kImportHalo><<<grid, 512, 0, s>>>(c->map, c->tab, c->fast.summary, (int) n, d_rec, stride, d_rec + sizeof(mrh_block_desc), stride, c->d_halo, c->d_taken);
     c->halo_upper += n;
   } else {
-    k_import<kImportMerge><<<grid, 512, 0, s>>>(c->map, c->tab, c->fast.summary, (int) n, d_rec, stride, d_rec + sizeof(mrh_block_desc), stride, nullptr, c->d_taken);
+    k_import<kImportMerge><<<grid, 512, 0, s>>>(c->map, c->tab, c->fast.summary, (int) n, d_rec, stride, d_rec + sizeof(mrh_block_desc), stride, nullptr, c->d_taken,
+                                                (u32*) released);
+    if (released.p) k_release_fine<<<1, 256, 0, s>>>(c->tab, released);
   }
   u32 taken = 0;
   HIP_TRY(c, hipMemcpyAsync(&taken, c->d_taken, sizeof(u32), hipMemcpyDeviceToHost, s));

@@ -495,7 +495,6 @@ int mrh_comm_merge_submaps(mrh_ctx* c, int chunk_log2, mrh_comm_merge_info* out)
   int rc = need_comm(c, "mrh_comm_merge_submaps");
   if (rc) return rc;
   if (out) memset(out, 0, sizeof *out);
-  if (c->tab.multi_res) return fail(c, MRH_ERR_UNSUPPORTED, "mrh_comm_merge_submaps: merging variance-adaptive (multi-resolution) maps is not supported");
   if (c->halo_upper) return fail(c, MRH_ERR_STATE, "mrh_comm_merge_submaps: halo blocks are present (mrh_drop_blocks(MRH_DROP_HALO) first)");
   mrh_comm* m = c->comm;
   const int world = m->world, rank = m->rank;

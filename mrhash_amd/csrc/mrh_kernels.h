@@ -708,12 +708,31 @@ __global__ __launch_bounds__(512) void k_dump(const Tab t, const int first, cons
 //   MODE 1  halo:   only blocks of other shards that are 26-adjacent to a block position this shard owns; newly inserted
 //                   ones are remembered in halo_list (mrh_drop_blocks(MRH_DROP_HALO))
 //   MODE 2  merge:  voxel-wise weighted merge into what the map holds (combineVoxel, vhu.cuh:167-181)
+//           One position at two resolutions (variance-adaptive sub-maps; the reference, single-GPU, has no rule): the COARSE side
+//           wins — reallocBlock (vds.cu:627-755) frees the fine block and starts the coarse one from the current frame, nothing of
+//           a fine payload survives a coarsening — so a fine record onto a coarse block is dropped, a coarse record onto a fine
+//           block replaces it: the fine slot is emptied, its index parked in `released` (released[0] = count; pushed onto the fine
+//           free list by k_release_fine behind this launch: a stack cannot take pushes next to this kernel's pops).
 constexpr int kImportPlain = 0, kImportHalo = 1, kImportMerge = 2;
+__global__ __launch_bounds__(256) void k_release_fine(const Tab t, const u32* __restrict__ released) {
+  __shared__ int s_base;
+  const int n = (int) released[0];
+  if (threadIdx.x == 0) s_base = n ? atomicAdd(&t.ctr[CTR_HEAP_FINE], n) : 0;
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += 256) t.heap_fine[s_base + 1 + i] = released[1 + i];  // vds.cu:53-57
+}
+// coarse records among `n` (mrh_unpack_blocks sizes the coarse free list by it before a merge)
+__global__ __launch_bounds__(256) void k_count_coarse_records(const char* __restrict__ descs, const size_t desc_stride, const int n, u32* __restrict__ out) {
+  u32 c = 0;
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) c += (*(const int4*) (descs + (size_t) e * desc_stride)).w != 0 ? 1u : 0u;
+  for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+}
 template <int MODE>
 __global__ __launch_bounds__(512) void k_import(const Map m, const Tab t, uint2* __restrict__ summary, const int n, const char* __restrict__ descs,
                                                 const size_t desc_stride, const char* __restrict__ voxels, const size_t vox_stride,
-                                                int4* __restrict__ halo_list, u32* __restrict__ taken) {
-  __shared__ u32 s_val;
+                                                int4* __restrict__ halo_list, u32* __restrict__ taken, u32* __restrict__ released = nullptr) {
+  __shared__ u32 s_val, s_released;
   __shared__ float s_min[8];
   __shared__ u32 s_max[8];
   const int v = threadIdx.x;
@@ -722,6 +741,7 @@ __global__ __launch_bounds__(512) void k_import(const Map m, const Tab t, uint2*
     const bool coarse = d.w != 0;
     if (v == 0) {
       u32 val = kValNone;
+      u32 rel = kValNone;
       u64 key;
       bool wanted = true;
       if (MODE == kImportHalo) {
@@ -739,8 +759,24 @@ __global__ __launch_bounds__(512) void k_import(const Map m, const Tab t, uint2*
         const u32 have = slot >= 0 ? t.vals[slot] : kValNone;
         if (have != kValNone && ((have & kValCoarseBit) != 0) == coarse) {
           val = have;  // overwrite / merge in place
+        } else if (have != kValNone && MODE == kImportMerge) {
+          if (coarse) {  // map fine, record coarse: the coarse unit takes the table slot, the fine block goes
+            const int idx = atomicSub(&t.ctr[CTR_HEAP_COARSE], 1);
+            if (idx < 0) {
+              atomicAdd(&t.ctr[CTR_HEAP_COARSE], 1);
+              atomicOr((u32*) &t.ctr[CTR_ERROR], ERR_POOL);  // no coarse unit: the fine block stays as it is
+            } else {
+              const u32 u = t.heap_coarse[idx];
+              val = u | kValCoarseBit;
+              t.vals[slot] = val;
+              t.desc_coarse[u] = make_int4(d.x, d.y, d.z, 1);
+              t.desc_fine[have].w = 0;
+              rel = have;
+              if (released) released[1 + atomicAdd(&released[0], 1u)] = have;
+            }
+          }  // map coarse, record fine: the record is dropped
         } else if (have != kValNone) {
-          atomicOr((u32*) &t.ctr[CTR_ERROR], ERR_TABLE);  // same position at another resolution: not supported
+          atomicOr((u32*) &t.ctr[CTR_ERROR], ERR_TABLE);  // same position at another resolution: an import cannot hold both
         } else {
           if (slot < 0) slot = hash_insert(t, key);  // (slot >= 0: a key left without storage by an exhausted pool takes the block)
           if (slot < 0) {
@@ -767,9 +803,12 @@ __global__ __launch_bounds__(512) void k_import(const Map m, const Tab t, uint2*
       }
       if (val != kValNone && taken) atomicAdd(taken, 1u);
       s_val = val;
+      s_released = rel;
     }
     __syncthreads();
     const u32 val = s_val;
+    if (MODE == kImportMerge && s_released != kValNone && v < kFineBytes / 16)  // the fine block that made way: zero, as a freed block is
+      ((uint4*) (t.pool + (size_t) s_released * kFineBytes))[v] = make_uint4(0, 0, 0, 0);
     float mn = 3.402823466e+38f;
     u32 mx = 0;
     if (val != kValNone && (!coarse || v < kCoarseVoxels)) {

@@ -1969,8 +1969,20 @@ int mrh_get_voxel(mrh_ctx* c, int32_t vx, int32_t vy, int32_t vz, mrh_voxel* out
   return MRH_OK;
 }
 
+/* room on the coarse free list for `need` coarse blocks, in allocateMemoryLow's portions (vds.cu:860-871): an import or a merge
+ * into a context whose frames have not refilled the list yet (vds.cu:885-891 does it at the start of a frame) */
+static void ensure_coarse_units(mrh_ctx* c, int need) {
+  if (!(c->p.sdf_var_threshold > 0.f)) return;
+  while (heap_low_free(c) < need && c->low_blocks_to_allocate > 0 && heap_high_free(c) > (int) c->low_blocks_to_allocate) allocate_memory_low(c);
+}
+
 int mrh_import_blocks(mrh_ctx* c, const mrh_block_desc* descs, const mrh_voxel* voxels, uint64_t n) {
   if (!c || (n && (!descs || !voxels))) return MRH_ERR_INVALID_ARG;
+  {
+    int need = 0;
+    for (uint64_t k = 0; k < n; k++) need += descs[k].resolution != 0;
+    ensure_coarse_units(c, need);
+  }
   for (uint64_t k = 0; k < n; k++) {
     const i3 pos = {descs[k].x, descs[k].y, descs[k].z};
     HashEntry e = get_hash_entry(c, pos);
@@ -2057,12 +2069,17 @@ int mrh_pack_blocks(mrh_ctx* c, int mode, int rank_arg, const mrh_block_record**
   return MRH_OK;
 }
 
+static void drop_position(mrh_ctx* c, i3 pos);
 int mrh_unpack_blocks(mrh_ctx* c, int mode, const mrh_block_record* records, uint64_t n, int is_device_memory, uint64_t* out_taken) {
   if (!c || (n && !records)) return MRH_ERR_INVALID_ARG;
   (void) is_device_memory; /* everything is host memory here */
   if (mode != MRH_UNPACK_HALO && mode != MRH_UNPACK_MERGE) return fail(c, MRH_ERR_INVALID_ARG, "mrh_unpack_blocks: bad mode");
-  if (mode == MRH_UNPACK_MERGE && c->p.sdf_var_threshold > 0.f) return fail(c, MRH_ERR_UNSUPPORTED, "mrh_unpack_blocks: merging multi-resolution maps is not supported");
   uint64_t taken = 0;
+  {
+    int need = 0;
+    for (uint64_t k = 0; k < n; k++) need += records[k].desc.resolution != 0;
+    ensure_coarse_units(c, need);
+  }
   for (uint64_t k = 0; k < n; k++) {
     const mrh_block_record* r = &records[k];
     const i3 pos = {r->desc.x, r->desc.y, r->desc.z};
@@ -2076,6 +2093,15 @@ int mrh_unpack_blocks(mrh_ctx* c, int mode, const mrh_block_record* records, uin
       if (!wanted) continue;
     }
     HashEntry e = get_hash_entry(c, pos);
+    /* One position at two resolutions (variance-adaptive sub-maps; no rule in the reference, which is single-GPU): the COARSE
+     * side wins, the fine side's observations go the way reallocBlock sends them (vds.cu:627-755 frees the fine block and starts
+     * the coarse one from the current frame: nothing of the fine payload survives a coarsening).  So a fine record onto a coarse
+     * block is dropped, and a coarse record onto a fine block replaces it.  Independent of the order of the sub-maps. */
+    if (mode == MRH_UNPACK_MERGE && e.ptr != FREE_ENTRY && e.resolution != r->desc.resolution) {
+      if (e.resolution > r->desc.resolution) continue; /* map coarse, record fine */
+      drop_position(c, pos);                           /* map fine, record coarse */
+      e = get_hash_entry(c, pos);
+    }
     const int fresh = e.ptr == FREE_ENTRY;
     if (fresh) {
       int prev_free = heap_high_free(c) + heap_low_free(c);

@@ -293,6 +293,110 @@ def test_eight_rank_merge_and_fold(oracle, tmp_path):
     check_merged_against_single(oracle, tmp_path, got, world=8, frames=[synth.cfg1_sphere(zc=1.5 + 0.005 * k) for k in range(8)], min_same=0.3)
 
 
+def _multires_submaps(lib, make=None):
+    """Two variance-adaptive sub-maps of the 128x128 sphere whose resolutions disagree both ways round (8 positions coarse in the
+    first and fine in the second, 13 the other way)."""
+    p = dict(synth.CFG1_PARAMS, sdf_var_threshold=0.5, n_frames_invalidate_voxels=3)
+    a = pu.make_engine(lib, synth.CFG1, p, 16384)
+    b = pu.make_engine(lib, synth.CFG1, p, 16384)
+    for f in (synth.cfg1_sphere(), synth.cfg1_sphere(zc=1.52), synth.cfg1_sphere(zc=1.49), synth.cfg1_sphere()):
+        pu.feed(a, f)
+    for f in (synth.cfg1_sphere(zc=1.55), synth.cfg1_sphere(zc=1.56), synth.cfg1_sphere(zc=1.55)):
+        pu.feed(b, f)
+    return a, b
+
+
+def _records_of(e):
+    """every block of the engine as mrh_block_record[] (host copy), sorted by position"""
+    import ctypes
+
+    from mrhash_amd import hipmem
+
+    e.set_sharding(0, 1, 0)
+    ptr, n, on_dev = e.pack_blocks(capi.PACK_OWNER, 0)
+    if on_dev:
+        raw = np.frombuffer(hipmem.read(ptr, n * capi.RECORD_BYTES), dtype=np.uint8).copy()
+    else:
+        raw = np.frombuffer((ctypes.c_char * (n * capi.RECORD_BYTES)).from_address(ptr), dtype=np.uint8).copy()
+    r = raw.view(capi.RECORD_DTYPE)
+    return r[np.lexsort((r["desc"]["z"], r["desc"]["y"], r["desc"]["x"]))]
+
+
+def check_mixed_resolution_merge(lib):
+    """VERDICT r05 missing-3: merging variance-adaptive sub-maps.  Rule (include/mrhash_hip.h, mrh_unpack_mode): a position that
+    is fine in one sub-map and coarse in the other ends up coarse, with the coarse side's payload; same-resolution positions
+    merge voxel by voxel; everything else is inserted.  The result must not depend on which sub-map is folded into which."""
+    a, b = _multires_submaps(lib)
+    ra, rb = _records_of(a), _records_of(b)
+    key = lambda r: list(zip(r["desc"]["x"].tolist(), r["desc"]["y"].tolist(), r["desc"]["z"].tolist()))  # noqa: E731
+    res_a, res_b = dict(zip(key(ra), ra["desc"]["resolution"].tolist())), dict(zip(key(rb), rb["desc"]["resolution"].tolist()))
+    both = set(res_a) & set(res_b)
+    mixed = [k for k in both if res_a[k] != res_b[k]]
+    assert len(mixed) >= 10 and len(both) >= 30, (len(mixed), len(both))
+    assert any(res_a[k] for k in mixed) and any(res_b[k] for k in mixed)  # both directions occur
+    taken_ab = b.unpack_blocks(capi.UNPACK_MERGE, ra.ctypes.data, len(ra), False)  # a into b
+    taken_ba = a.unpack_blocks(capi.UNPACK_MERGE, rb.ctypes.data, len(rb), False)  # b into a
+    fine_onto_coarse_ab = sum(1 for k in mixed if res_a[k] == 0)  # a's fine records that met a coarse block of b: dropped
+    fine_onto_coarse_ba = sum(1 for k in mixed if res_b[k] == 0)
+    assert taken_ab == len(ra) - fine_onto_coarse_ab and taken_ba == len(rb) - fine_onto_coarse_ba
+    (da, va), (db, vb) = a.dump_blocks(), b.dump_blocks()
+    assert np.array_equal(da, db) and len(da) == len(set(res_a) | set(res_b))
+    got = dict(zip(list(zip(da["x"].tolist(), da["y"].tolist(), da["z"].tolist())), da["resolution"].tolist()))
+    for k, r in got.items():
+        assert r == max(res_a.get(k, 0), res_b.get(k, 0)), k  # coarse wherever either side was coarse
+    # the payload is the same both ways round (sum_squared aside: it is the later sub-map's term, as in the single-resolution merge)
+    bits = lambda x: np.ascontiguousarray(x).view(np.uint8)  # noqa: E731
+    assert np.array_equal(va["weight"], vb["weight"])
+    seen = va["weight"] > 0  # a voxel neither side observed keeps whatever the receiving side held
+    assert seen.sum() > 1000 and np.array_equal(va["sdf"][seen].view(np.uint32), vb["sdf"][seen].view(np.uint32))
+    assert np.array_equal(va["rgb"][seen], vb["rgb"][seen])
+    # a mixed position carries the coarse side's voxels, untouched
+    idx = {k: i for i, k in enumerate(zip(da["x"].tolist(), da["y"].tolist(), da["z"].tolist()))}
+    src = {True: (ra, dict(zip(key(ra), range(len(ra))))), False: (rb, dict(zip(key(rb), range(len(rb)))))}
+    for k in mixed[:40]:
+        recs, where = src[res_a[k] == 1]
+        want = recs["voxels"][where[k]][:64]
+        assert np.array_equal(bits(va[idx[k]][:64]["sdf"]), bits(want["sdf"])) and np.array_equal(va[idx[k]][:64]["weight"], want["weight"])
+    assert a.stats().error_flags == 0 and b.stats().error_flags == 0
+    # the merged maps keep fusing (the frame after a bulk change goes through the general kernels); the two contexts have different
+    # frame counters, so their starve frames differ from here on: only that each of them carries on cleanly
+    n_before = len(da)
+    for e in (a, b):
+        pu.feed(e, synth.cfg1_sphere(zc=1.5))
+        assert e.stats().error_flags == 0 and len(e.dump_blocks()[0]) >= n_before - 40
+    return a, b
+
+
+def test_merging_variance_adaptive_submaps_coarse_wins(oracle):
+    a, b = check_mixed_resolution_merge(oracle)
+    a.close()
+    b.close()
+
+
+def test_two_rank_merge_of_variance_adaptive_submaps(oracle, tmp_path):
+    """The whole frame-sharded protocol (merge_submaps -> exchange_halo -> gather_mesh) on two gloo ranks whose sub-maps are
+    variance-adaptive and disagree about resolutions: every rank ends up owning exactly its tiles, a position is coarse in the merged
+    map iff it was coarse in a sub-map, and the mesh over the merged shards is the mesh a single context extracts from the same
+    merged blocks."""
+    worker = (MERGE_WORKER
+              .replace("dict(synth.CFG1_PARAMS)", "dict(synth.CFG1_PARAMS, sdf_var_threshold=0.5, n_frames_invalidate_voxels=3)")
+              .replace("for f in frames[rank::world]:", "for f in frames[3 * rank: 3 * rank + (4 if rank == 0 else 3)]:")
+              .replace("merge_frames()", "[synth.cfg1_sphere(zc=z) for z in (1.5, 1.52, 1.49, 1.5, 1.55, 1.56, 1.55)]"))
+    # (rank 0: frames 0-3, rank 1: frames 3-5 of the list above, i.e. zc 1.5, 1.55, 1.56 -> two different sub-maps)
+    got = run_two_ranks(tmp_path, use_hip=False, worker=worker)
+    parts = [np.load(str(tmp_path / "rank0.npz") + f".{r}.npz") for r in range(2)]
+    d = np.concatenate([p["d"] for p in parts])
+    assert len(d) > 60 and len(np.unique(d[["x", "y", "z"]])) == len(d)  # one owner per position
+    assert 0 < int((d["resolution"] != 0).sum()) < len(d)
+    assert all(int(p["sent"]) > 0 and int(p["received"]) > 0 for p in parts)
+    # the gathered mesh == the mesh of ONE context holding the merged blocks
+    v = np.concatenate([p["v"] for p in parts]).view(capi.VOXEL_DTYPE).reshape(len(d), 512)
+    single = pu.make_engine(oracle, synth.CFG1, dict(synth.CFG1_PARAMS, sdf_var_threshold=0.5, n_frames_invalidate_voxels=3), 16384)
+    single.import_blocks(d, v)
+    t = single.extract_triangles()
+    assert len(t) > 300 and np.array_equal(got["tris"], t.view(np.uint8))
+
+
 def test_pack_unpack_drop_single_process(oracle):
     """The exchange primitives without a process group: pack by owner, empty the map, fold the records back."""
     import ctypes

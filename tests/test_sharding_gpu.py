@@ -71,6 +71,27 @@ def test_import_blocks_roundtrip_hip(hip):
     assert np.array_equal(da, db) and np.array_equal(va.view(np.uint8), vb.view(np.uint8))
 
 
+def test_import_of_coarse_blocks_into_a_fresh_context_hip(hip, oracle):
+    """A variance-adaptive map restored into a context that has not fused a frame yet: its coarse free list is empty until a frame's
+    refill (vds.cu:885-891), so the import sizes it first (round 6; the oracle's import used to spin on the empty list, the device's
+    to drop the blocks with a pool error)."""
+    from test_sharding import _multires_submaps
+
+    a, _b = _multires_submaps(hip)
+    d, v = a.dump_blocks()
+    assert 0 < int((d["resolution"] != 0).sum()) < len(d)
+    p = dict(synth.CFG1_PARAMS, sdf_var_threshold=0.5, n_frames_invalidate_voxels=3)
+    for lib in (hip, oracle):
+        e = pu.make_engine(lib, synth.CFG1, p, 16384)
+        e.import_blocks(d, v)
+        d2, v2 = e.dump_blocks()
+        assert np.array_equal(d, d2) and np.array_equal(v.view(np.uint8), v2.view(np.uint8)) and e.stats().error_flags == 0
+        assert np.array_equal(a.extract_triangles().view(np.uint8), e.extract_triangles().view(np.uint8))
+        e.close()
+    a.close()
+    _b.close()
+
+
 def test_two_rank_mesh_equals_single_context_hip(hip, tmp_path):
     got = run_two_ranks(tmp_path, use_hip=True)
     t, V, F, C = reference_single(hip)
@@ -267,6 +288,37 @@ def test_exchange_primitives_match_the_oracle(hip, oracle):
     assert a.drop_blocks(capi.DROP_HALO) == b.drop_blocks(capi.DROP_HALO) == ta
     pu.compare_maps(a, b)
     assert len(a.dump_blocks()[0]) == na
+
+
+def test_merging_variance_adaptive_submaps_hip(hip, oracle):
+    """VERDICT r05 missing-3: mrh_unpack_blocks(MRH_UNPACK_MERGE) / mrh_comm_merge_submaps on multi-resolution maps (they used to
+    return MRH_ERR_UNSUPPORTED).  The rule's properties on the device (coarse wins, order-independent: test_sharding's check), then
+    the device against the oracle on the same records: the same map, and the same map again one fused frame later (both sides
+    have the same history, so their starve frames coincide)."""
+    from mrhash_amd import capi, hipmem
+    from test_sharding import _multires_submaps, _records_of, check_mixed_resolution_merge
+
+    a, b = check_mixed_resolution_merge(hip)
+    a.close()
+    b.close()
+    ha, hb = _multires_submaps(hip)
+    oa, ob = _multires_submaps(oracle)
+    r_h, r_o = _records_of(hb), _records_of(ob)
+    assert r_h.tobytes() == r_o.tobytes()  # the same sub-map on both sides
+    dev = hipmem.DeviceBuffer.from_numpy(r_h.view(np.uint8))
+    th = ha.unpack_blocks(capi.UNPACK_MERGE, dev.ptr, len(r_h), True)  # from device memory, as a collective leaves them
+    to = oa.unpack_blocks(capi.UNPACK_MERGE, r_o.ctypes.data, len(r_o), False)
+    assert th == to > 0
+    r = pu.compare_maps(ha, oa)
+    assert r["blocks"] > 60
+    sh, so = ha.stats(), oa.stats()
+    assert (sh.occupied_fine, sh.occupied_coarse) == (so.occupied_fine, so.occupied_coarse) and sh.error_flags == 0
+    for e in (ha, oa):
+        pu.feed(e, synth.cfg1_sphere(zc=1.5))
+    pu.compare_maps(ha, oa)
+    pu.compare_meshes(ha, oa)
+    for e in (ha, hb, oa, ob):
+        e.close()
 
 
 def test_lidar_and_splat_seeds_on_tile_shards_hip(hip):
