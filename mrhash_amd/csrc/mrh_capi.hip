@@ -104,37 +104,58 @@ struct HostVec {
   bool empty() const { return n == 0; }
   void clear() { n = 0; }
   const T& operator[](size_t i) const { return p[i]; }
+  bool pin_pending = false;  // mapped and faulted in by reserve_unpinned, not registered yet: the next resize_discard registers it
+  // the mapping alone: mmap + huge-page advice + first touch.  No HIP call — safe on a helper thread next to a frame loop (a
+  // hipHostRegister on another thread holds the runtime's lock for its whole 1-2 ms: round 6 measured the frame loop at a quarter
+  // of its rate with the registration on a helper thread)
+  void map_(const size_t count, const bool touch) {
+    release();
+    const size_t want = count + count / 8;  // head room: a map that grows a little keeps its buffer
+    const size_t bytes = ((want * sizeof(T) + (2u << 20) - 1) >> 21) << 21;
+    const size_t sp = bytes + (2u << 20);
+    void* m = mmap(nullptr, sp, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (m == MAP_FAILED) throw std::bad_alloc();
+    // the whole span is kept (the unaligned head stays untouched, i.e. unbacked): one munmap releases it
+    char* aligned = (char*) (((uintptr_t) m + (2u << 20) - 1) & ~(uintptr_t) ((2u << 20) - 1));
+    (void) madvise(aligned, bytes, MADV_HUGEPAGE);
+    // fault the pages in (as huge pages) before they are pinned; a buffer the device never sees is faulted in by whoever
+    // writes it first — the widening threads, side by side (47 MB of V / C at the driver's workload: zeroing them here, on one
+    // thread, was most of a context's first extraction) — unless the prewarm asks for it
+    if (touch) for (size_t o = 0; o < bytes; o += 4096) ((volatile char*) aligned)[o] = 0;
+    span = sp;
+    head = (size_t) (aligned - (char*) m);
+    p = (T*) aligned;
+    dev = nullptr;
+    cap = bytes / sizeof(T);
+  }
+  void register_() {
+    pin_pending = false;
+    void* d = nullptr;
+    const size_t bytes = cap * sizeof(T);
+    if (hipHostRegister((void*) p, bytes, hipHostRegisterDefault) == hipSuccess && hipHostGetDevicePointer(&d, (void*) p, 0) == hipSuccess && d) {
+      dev = (T*) d;
+    } else {
+      (void) hipGetLastError();
+      (void) hipHostUnregister((void*) p);
+      (void) hipGetLastError();
+      dev = nullptr;
+    }
+  }
+  // capacity for `count` elements, faulted in, registration left to the first resize_discard (helper thread: no HIP call)
+  void reserve_unpinned(const size_t count) {
+    if (count <= cap) return;
+    map_(count, true);
+    pin_pending = pin;
+    n = 0;
+  }
   // contents are NOT preserved when the buffer grows
   void resize_discard(size_t count) {
     if (count > cap) {
-      release();
-      const size_t want = count + count / 8;  // head room: a map that grows a little keeps its buffer
-      const size_t bytes = ((want * sizeof(T) + (2u << 20) - 1) >> 21) << 21;
-      const size_t sp = bytes + (2u << 20);
-      void* m = mmap(nullptr, sp, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
-      if (m == MAP_FAILED) throw std::bad_alloc();
-      // the whole span is kept (the unaligned head stays untouched, i.e. unbacked): one munmap releases it
-      char* aligned = (char*) (((uintptr_t) m + (2u << 20) - 1) & ~(uintptr_t) ((2u << 20) - 1));
-      (void) madvise(aligned, bytes, MADV_HUGEPAGE);
-      // fault the pages in (as huge pages) before they are pinned; a buffer the device never sees is faulted in by whoever
-      // writes it first — the widening threads, side by side (47 MB of V / C at the driver's workload: zeroing them here, on one
-      // thread, was most of a context's first extraction)
-      if (pin) for (size_t o = 0; o < bytes; o += 4096) ((volatile char*) aligned)[o] = 0;
-      span = sp;
-      head = (size_t) (aligned - (char*) m);
-      p = (T*) aligned;
-      void* d = nullptr;
-      if (!pin) {
-        dev = nullptr;
-      } else if (hipHostRegister(aligned, bytes, hipHostRegisterDefault) == hipSuccess && hipHostGetDevicePointer(&d, aligned, 0) == hipSuccess && d) {
-        dev = (T*) d;
-      } else {
-        (void) hipGetLastError();
-        (void) hipHostUnregister(aligned);
-        (void) hipGetLastError();
-        dev = nullptr;
-      }
-      cap = bytes / sizeof(T);
+      map_(count, pin);
+      pin_pending = false;
+      if (pin) register_();
+    } else if (pin_pending) {
+      register_();
     }
     n = count;
   }
@@ -341,15 +362,13 @@ struct mrh_ctx {
   // 20 MB of a 0.5 M-triangle mesh) and the 24 MB of doubles the caller sees — used to be paid inside that call, after a
   // synchronisation that told it the sizes: 2.8 ms where every later extraction takes 0.85, and a one-shot extractMesh (what
   // every runner of the reference does) only ever makes the first.  A context that fuses frames will be asked for its mesh: at
-  // its 8th, 64th, 512th ... frame — while no extraction has happened yet — a helper thread sizes those buffers from the live
-  // blocks the device last reported (64 vertices a block: twice what the rooms of the benchmarks yield, so a map that keeps
-  // growing still fits), behind the frame loop's back.  The first extraction then finds its staging ready and runs like any
-  // other; if the estimate was short, it grows the buffers as before.  Nothing is touched once an extraction has handed
-  // pointers to the caller.  MRH_PREWARM=0 switches it off.
-  std::thread prewarm_thr;
-  bool prewarm_on = true;
+  // the end of its THIRD mrh_integrate — a context is still allocating and warming up there — those buffers are sized from the
+  // live blocks (64 vertices a block: twice what the rooms of the benchmarks yield, so a map that keeps growing still fits).
+  // The first extraction then finds its staging ready and runs like any other; if the estimate was short, it grows the
+  // buffers as before.  Done in the calling thread, once: a helper thread was built first (round 6) and slowed the frame loop
+  // by 8 % for as long as it was faulting pages in, at whichever frame it was started.  MRH_PREWARM=0 switches it off.
+  bool prewarm_on = true, prewarm_done = false;
   uint64_t n_extractions = 0;
-  uint64_t prewarm_vertices = 0;  // what the staging was last prepared for
   bool f64_link = false;       // MRH_MESH_F64_LINK=1: V / C widened on the device and copied as doubles (the round-3 path; A/B, tests)
   // profiling
   int profile = 0;
@@ -602,13 +621,9 @@ int strict_point(mrh_ctx* c);
 // so far, the zombies nobody wanted leave the table, so that whatever the call reads, changes or waits for is exactly the map two
 // serial launches per frame would have left
 int flush_deferred(mrh_ctx* c);
-void prewarm_join(mrh_ctx* c) {
-  if (c->prewarm_thr.joinable()) c->prewarm_thr.join();
-}
 int ensure_ready(mrh_ctx* c, const char* who) {
   int rc = ensure_device(c, who);
   if (rc) return rc;
-  prewarm_join(c);  // whatever the call does with the result buffers, nobody else is sizing them
   rc = flush_deferred(c);  // a host-fed frame that mrh_integrate kept back runs before anything else looks at the map
   if (rc < 0) return rc;
   if (c->stream_front) c->front_needs_sync = true;  // whatever this call does to the map, the front stream must see it before its next launch
@@ -1435,7 +1450,6 @@ int mrh_destroy(mrh_ctx* c) {
     }
   }
 #endif
-  prewarm_join(c);
   if (c->deferred.on) { (void) hipSetDevice(c->device); (void) flush_deferred(c); }  // the frame mrh_integrate accepted last
   widen_quiesce();  // the result arrays are about to be unmapped
   if (getenv("MRH_DEBUG") || getenv("MRH_WIDEN_REPORT"))
@@ -1955,6 +1969,7 @@ int mrh_set_rgb_device(mrh_ctx* c, const uint8_t* d_rgb, int rows, int cols) {
 static int integrate_frame(mrh_ctx* c, int n_frames_invalidate);
 
 static int integrate_checks(mrh_ctx* c);
+static void prewarm_maybe(mrh_ctx* c);
 int mrh_integrate(mrh_ctx* c, int n_frames_invalidate) {
   int rc = ensure_device(c, "mrh_integrate");
   if (rc) return rc;
@@ -1979,6 +1994,7 @@ int mrh_integrate(mrh_ctx* c, int n_frames_invalidate) {
   rc = integrate_frame(c, n_frames_invalidate);
   if (rc < 0) return rc;
   const int mrc = mark_frame(c);
+  if (!mrc && rc == MRH_OK) prewarm_maybe(c);
   return mrc ? mrc : rc;
 }
 
@@ -2126,7 +2142,7 @@ int ensure_pipe_buffers(mrh_ctx* c, const size_t npix) {
     HIP_TRY(c, hipMalloc((void**) &c->fast.zlist, cap * sizeof(int4)));
     HIP_TRY(c, hipMalloc((void**) &c->want_ring, (size_t) kPipeRing * c->slots * sizeof(u32)));
     HIP_TRY(c, hipMemsetAsync(c->want_ring, 0, (size_t) kPipeRing * c->slots * sizeof(u32), c->stream));  // stamps start at 1
-    if (!c->h_levels) HIP_TRY(c, hipHostMalloc((void**) &c->h_levels, 4 * sizeof(int), hipHostMallocDefault));  // (the prewarm may have asked for the report first)
+    if (!c->h_levels) HIP_TRY(c, hipHostMalloc((void**) &c->h_levels, 4 * sizeof(int), hipHostMallocDefault));
     c->h_levels[0] = (int) c->num_blocks - 1; c->h_levels[1] = 0; c->h_levels[2] = -1;
     c->tab.h_levels = c->h_levels;
     c->front_needs_sync = true;  // the memset above
@@ -2334,47 +2350,35 @@ static int integrate_checks(mrh_ctx* c) {
   return MRH_OK;
 }
 
-// see mrh_ctx::prewarm_thr
+// see mrh_ctx::prewarm_on
 static void prewarm_maybe(mrh_ctx* c) {
-  if (!c->prewarm_on || c->n_extractions || c->f64_link || c->mesh_on_host) return;
-  const uint64_t f = c->frames;
-  if (!c->h_levels) {  // not a pipelining context: ask its integration launches for the same report of the pool level (frame_epilogue)
-    if (f < 1) return;
-    if (hipHostMalloc((void**) &c->h_levels, 4 * sizeof(int), hipHostMallocDefault) != hipSuccess) { (void) hipGetLastError(); c->h_levels = nullptr; return; }
-    c->h_levels[0] = (int) c->num_blocks - 1; c->h_levels[1] = 0; c->h_levels[2] = -1;
-    c->tab.h_levels = c->h_levels;
+  if (!c->prewarm_on || c->prewarm_done || c->frames != 3 || c->n_extractions || c->f64_link || c->mesh_on_host || c->pending) return;
+  c->prewarm_done = true;
+  int lev = 0;
+  if (hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(&lev, &c->tab.ctr[CTR_HEAP_FINE], sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) {
+    (void) hipGetLastError();
     return;
   }
-  if (f < 8 || (f & (f - 1)) != 0 || (f != 8 && f != 64 && f != 512 && f < 4096)) return;  // 8, 64, 512, then every power of two
-  const int64_t free_known = (int64_t) ((volatile int*) c->h_levels)[0] + 1;
-  const uint64_t live = (uint64_t) std::max<int64_t>((int64_t) c->num_blocks - free_known, 0);
+  const uint64_t live = (uint64_t) std::max<int64_t>((int64_t) c->num_blocks - ((int64_t) lev + 1), 0);  // fine slots in use (coarse units live in fine slots)
   const uint64_t nv = live * 64;
-  if (nv < 4096 || nv <= c->prewarm_vertices) return;
-  prewarm_join(c);
-  c->prewarm_vertices = nv;
-  c->prewarm_thr = std::thread([c, nv] {
-    (void) hipSetDevice(c->device);
-    try {
-      const size_t nf = (size_t) (nv + nv / 4);  // faces: a little above the vertices (closed surfaces: twice; what is seen of a room: ~1.1 x)
-      c->V32.resize_discard((size_t) nv * 3 + 4); c->C32.resize_discard((size_t) nv * 3 + 4);
-      c->F.resize_discard(nf * 3 + 4);
-      c->stage_ctl.resize_discard(kStageHdrWords + 2 * ((std::min(c->V32.cap, c->C32.cap) * 4 + kStageChunk - 1) / kStageChunk + 2));
-      if (c->stage_ctl.data()) memset(c->stage_ctl.data(), 0, c->stage_ctl.cap * sizeof(u32));  // no epoch, no flag of an earlier life
-      c->V.resize_discard((size_t) nv * 3); c->C.resize_discard((size_t) nv * 3);
-      for (HostVec<double>* h : {&c->V, &c->C})  // the doubles are written by the widening threads: faulted in here instead of there
-        for (size_t o = 0; o < h->cap * sizeof(double); o += 4096) ((volatile char*) h->data())[o] = 0;
-      c->V32.clear(); c->C32.clear(); c->F.clear(); c->V.clear(); c->C.clear();  // capacity, not content: the getters still answer "no mesh"
-    } catch (...) {
-      // no memory for it: the first extraction sizes its buffers itself, as it always did
-    }
-    (void) hipGetLastError();
-  });
+  if (nv < 65536) return;  // a mesh this small costs its first extraction next to nothing
+  try {
+    const size_t nf = (size_t) (nv + nv / 4);  // faces: a little above the vertices (closed surfaces: twice; what is seen of a room: ~1.1 x)
+    c->V32.resize_discard((size_t) nv * 3 + 4); c->C32.resize_discard((size_t) nv * 3 + 4);
+    c->F.resize_discard(nf * 3 + 4);
+    c->stage_ctl.resize_discard(kStageHdrWords + 2 * ((std::min(c->V32.cap, c->C32.cap) * 4 + kStageChunk - 1) / kStageChunk + 2));
+    if (c->stage_ctl.data()) memset(c->stage_ctl.data(), 0, c->stage_ctl.cap * sizeof(u32));  // no epoch, no flag of an earlier life
+    c->V.reserve_unpinned((size_t) nv * 3); c->C.reserve_unpinned((size_t) nv * 3);  // never pinned: mapped and faulted in
+    c->V32.clear(); c->C32.clear(); c->F.clear(); c->V.clear(); c->C.clear();  // capacity, not content: the getters still answer "no mesh"
+  } catch (...) {
+    // no memory for it: the first extraction sizes its buffers itself, as it always did
+  }
+  (void) hipGetLastError();
 }
 
 static int integrate_frame(mrh_ctx* c, int n_frames_invalidate) {
   int rc = integrate_checks(c);
   if (rc) return rc;
-  prewarm_maybe(c);
   const Cam& k = c->cam;
   const int max_num_frames = n_frames_invalidate < 0 ? c->p.n_frames_invalidate_voxels : n_frames_invalidate;
   hipStream_t s = c->stream;
@@ -3477,7 +3481,6 @@ int mrh_extract_triangles(mrh_ctx* c, const mrh_triangle** out_tris, uint64_t* o
 // (tests/test_geowrapper_gpu.py compares with the oracle, which restates the incremental form literally).
 int mrh_mesh_merge_begin(mrh_ctx* c) {
   if (!c) return MRH_ERR_INVALID_ARG;
-  prewarm_join(c);
   c->n_extractions++;
   c->merge_on = true;
   c->acc_n = 0;
@@ -3508,7 +3511,6 @@ int mrh_mesh_merge_end(mrh_ctx* c, uint64_t* out_total_triangles) {
 
 int mrh_extract_mesh(mrh_ctx* c, const double** v, uint64_t* nv, const int32_t** f, uint64_t* nf, const double** col) {
   if (!c || !v || !nv || !f || !nf || !col) return MRH_ERR_INVALID_ARG;
-  prewarm_join(c);
   c->n_extractions++;  // the caller holds these pointers until the next extraction
   *v = c->V.empty() ? nullptr : c->V.data();
   *nv = c->V.size() / 3;

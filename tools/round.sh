@@ -1,7 +1,7 @@
 #!/bin/bash
 # The round's evidence from ONE build, on the GPU box (through gpurun).  Every file lands under gpurun_out/<tag>/ with the commit
 # hash of the build in MANIFEST.txt; the files to be judged are copied into profiles/<tag>/ afterwards (tools/README.md).
-#   usage: tools/round.sh <tag> <commit> [sections...]     sections: suite bench default stats pmc framepmc stress soak multi trace tracebuilds churn bigmap
+#   usage: tools/round.sh <tag> <commit> [sections...]     sections: suite bench default stats pmc framepmc stress soak multi trace tracebuilds churn bigmap starve
 #   default sections: bench stats pmc framepmc
 TAG=${1:-r05}; COMMIT=${2:-unknown}; shift 2
 SECTIONS=${*:-bench stats pmc framepmc}
@@ -85,6 +85,11 @@ if has churn; then
   # the 3 000-frame walk as a pytest gate: fails the section if the walk, its rebuild count or the parity at its end fails
   { sha256sum mrhash_amd/csrc/libmrhash_hip.so | cut -c1-16; MRH_SOAK=1 timeout 2400 python -m pytest tests/test_churn_gpu.py -m soak -q -s 2>&1 | tail -6; } > $OUT/soak_churn.txt 2>&1
   tail -3 $OUT/soak_churn.txt; grep -q " passed" $OUT/soak_churn.txt || echo "CHURN GATE FAILED"
+fi
+if has starve; then  # the kernels of starve frames inside the pipeline (every 5th of 50 resident frames) + the frame rates with and without them
+  tools/rocprof_cmd.sh starve tools/bench_starve.py 60 5 > $OUT/starve_kernel_stats.txt 2>&1
+  grep "period" gpurun_out/st_starve.log >> $OUT/starve_kernel_stats.txt; rm -rf gpurun_out/st_starve gpurun_out/st_starve.log
+  grep "starve\|period" $OUT/starve_kernel_stats.txt
 fi
 if has trace; then
   STEPS=100 WARM=10 tools/trace_pipe2.sh > $OUT/pipeline_trace_110_frames.txt 2>&1; head -3 $OUT/pipeline_trace_110_frames.txt
