@@ -2066,7 +2066,8 @@ int launch_pending(mrh_ctx* c, const bool count_skips = false) {
   for (int i = 1; i < c->npend; i++) c->pendq[i - 1] = c->pendq[i];
   c->npend--;
   hipStream_t s = c->stream;
-  const hipError_t q = hipEventQuery(c->ev_front[pb.ring]);
+  static const bool always_wait = getenv("MRH_PIPE_ALWAYS_WAIT") != nullptr;  // A/B: the wait packet whatever the query says
+  const hipError_t q = always_wait ? hipErrorNotReady : hipEventQuery(c->ev_front[pb.ring]);
   if (q == hipErrorNotReady) {
     (void) hipGetLastError();
     HIP_TRY(c, hipStreamWaitEvent(s, c->ev_front[pb.ring], 0));
