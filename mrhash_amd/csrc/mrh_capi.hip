@@ -241,7 +241,9 @@ struct mrh_ctx {
                                             // second generation competes with the front half's workgroups for the slots the first one frees: 37.3 against
                                             // 34.8 us per frame (MRH_PIPE_GRID; the serial launch keeps 2048)
   int pipe_uploads = 0;                     // MRH_PIPE_UPLOADS=1: pipeline frames whose images came through mrh_upload_* too
-  int pipe_period = 32;                     // the reclaim (and one serial frame) every so many pipelined frames; MRH_PIPE_PERIOD
+  int pipe_period = 64;                     // the reclaim (and one serial frame) every so many pipelined frames; MRH_PIPE_PERIOD.  (32 until
+                                            // round 6: a period boundary costs the pipeline ~60 us, the zombies it bounds are also bounded by the
+                                            // pool test below (zombies <= pool / 8); 64 — the census period — gave +4 % at 100 steps, 128 no more)
   hipStream_t stream_front = nullptr;
   hipEvent_t ev_front[kPipeRing] = {};
   uint2* pipe_dcx[kPipeRing] = {};
