@@ -2121,6 +2121,16 @@ int strict_point(mrh_ctx* c) {
   if (!c->zombies_possible) return MRH_OK;
   k_reclaim<<<64, 256, 0, c->stream>>>(c->tab, c->fast);
   k_reclaim_done<<<1, 1, 0, c->stream>>>(c->tab);
+  // the pool report of the newest mark now understates the free list by the zombies that have just left: written again behind the
+  // reclaim, so that a peek after mrh_sync (or after any other flush) reads the level the flush left (with the reclaim period at 64
+  // frames the difference is no longer a handful of blocks)
+  if (c->peek_enabled && c->frame_seq > 1) {
+    const uint64_t seq = c->frame_seq - 1;
+    if (c->peek_seq[seq % 8] == seq && c->peek_done[seq % 8]) {
+      k_report<<<1, 64, 0, c->stream>>>(&c->tab.ctr[CTR_HEAP_FINE], c->h_peek + 8 * (seq % 8));
+      HIP_TRY(c, hipEventRecord(c->peek_done[seq % 8], c->stream));
+    }
+  }
   c->zombies_possible = false;
   c->lazy_run = 0;
   c->front_needs_sync = true;
