@@ -307,11 +307,15 @@ struct mrh_ctx {
   // 3DGS splat seeds (mrh_splat.h): sized for one (image shape, min pixel size)
   QTree qt = {0, 0, 0, 0, 0};
   QSum* d_qt_sums = nullptr; u32* d_qt_flags = nullptr; u32* d_qt_unc = nullptr; u64* d_qt_marks = nullptr; u64* d_qt_pos = nullptr;
-  mrh_splat_seed* d_qt_parked = nullptr; mrh_splat_seed* d_qt_seeds = nullptr; mrh_qtree_leaf* d_qt_leaves = nullptr;
+  mrh_splat_seed* d_qt_parked = nullptr; mrh_qtree_leaf* d_qt_leaves = nullptr;
+  // what the caller takes from a seeding call is written by its last launch straight into pinned host memory (a few hundred to a few
+  // thousand 20-byte seeds and two counters): one synchronisation, no transfer calls (they were two pageable read-backs, each behind
+  // a synchronisation of its own: ~35 of the call's 135 us)
+  mrh_splat_seed* h_qt_seeds = nullptr; u32 qt_seed_cap = 0;
+  u64* h_qt_out = nullptr;   // [0] totals (leaves | seeds << 32), [1] literal evaluations
   u64* d_qt_misc = nullptr;  // [0] totals (leaves | seeds << 32), [1] uncertain-node counter (low word)
   int qt_literal = 0;        // MRH_QTREE_LITERAL=1: every node error through the reference's summation order (cross-check)
   uint32_t qt_last_literal = 0;
-  std::vector<mrh_splat_seed> seeds;
   std::vector<mrh_qtree_leaf> qt_leaves;
   uint64_t qt_n_leaves = 0;            // leaves of the last mrh_splat_seeds, still on the device (d_qt_leaves) until someone asks
   bool qt_leaves_on_host = true;
@@ -490,7 +494,9 @@ void free_all(mrh_ctx* c) {
   for (hipEvent_t e : c->comm_ev) if (e) (void) hipEventDestroy(e);
   for (auto& e : c->comm_ev_pool) { (void) hipEventDestroy(e.a); (void) hipEventDestroy(e.b); }
   for (auto& e : c->comm_ev_pending) { (void) hipEventDestroy(e.a); (void) hipEventDestroy(e.b); }
-  F(c->d_qt_sums); F(c->d_qt_flags); F(c->d_qt_unc); F(c->d_qt_marks); F(c->d_qt_pos); F(c->d_qt_parked); F(c->d_qt_seeds); F(c->d_qt_leaves); F(c->d_qt_misc);
+  F(c->d_qt_sums); F(c->d_qt_flags); F(c->d_qt_unc); F(c->d_qt_marks); F(c->d_qt_pos); F(c->d_qt_parked); F(c->d_qt_leaves); F(c->d_qt_misc);
+  if (c->h_qt_seeds) (void) hipHostFree(c->h_qt_seeds);
+  if (c->h_qt_out) (void) hipHostFree(c->h_qt_out);
   for (int i = 0; i < c->npend; i++) if (c->pendq[i].profile) c->ev_pool.push_back(c->pendq[i].ev);
   c->npend = 0;
   for (auto& e : c->ev_pool) { (void) hipEventDestroy(e.a); (void) hipEventDestroy(e.b); }
@@ -3058,7 +3064,8 @@ int mrh_splat_seeds(mrh_ctx* c, float qtree_thresh, int qtree_min_pixel_size, co
     HIP_TRY(c, hipStreamSynchronize(s));
     auto F = [](auto*& p) { if (p) (void) hipFree(p); p = nullptr; };
     // only the quad-tree buffers are sized by qt.total: nothing else of the context is released here
-    F(c->d_qt_sums); F(c->d_qt_flags); F(c->d_qt_unc); F(c->d_qt_marks); F(c->d_qt_pos); F(c->d_qt_parked); F(c->d_qt_seeds); F(c->d_qt_leaves); F(c->d_qt_misc);
+    F(c->d_qt_sums); F(c->d_qt_flags); F(c->d_qt_unc); F(c->d_qt_marks); F(c->d_qt_pos); F(c->d_qt_parked); F(c->d_qt_leaves); F(c->d_qt_misc);
+    if (c->h_qt_seeds) { (void) hipHostFree(c->h_qt_seeds); c->h_qt_seeds = nullptr; }
     const size_t n = qt.total;
     HIP_TRY(c, hipMalloc((void**) &c->d_qt_sums, n * sizeof(QSum)));
     HIP_TRY(c, hipMalloc((void**) &c->d_qt_flags, n * sizeof(u32)));
@@ -3066,7 +3073,9 @@ int mrh_splat_seeds(mrh_ctx* c, float qtree_thresh, int qtree_min_pixel_size, co
     HIP_TRY(c, hipMalloc((void**) &c->d_qt_marks, n * sizeof(u64)));
     HIP_TRY(c, hipMalloc((void**) &c->d_qt_pos, (n + (n + kChainTile - 1) / kChainTile + 1) * sizeof(u64)));  // + the tile sums of the marks' scan
     HIP_TRY(c, hipMalloc((void**) &c->d_qt_parked, n * sizeof(mrh_splat_seed)));
-    HIP_TRY(c, hipMalloc((void**) &c->d_qt_seeds, n * sizeof(mrh_splat_seed)));
+    c->qt_seed_cap = (u32) std::min<size_t>(n, (size_t) 1 << 20);  // seeds <= leaves <= 1 000 000 (checked below), or the call fails
+    HIP_TRY(c, hipHostMalloc((void**) &c->h_qt_seeds, (size_t) c->qt_seed_cap * sizeof(mrh_splat_seed), hipHostMallocDefault));
+    if (!c->h_qt_out) HIP_TRY(c, hipHostMalloc((void**) &c->h_qt_out, 2 * sizeof(u64), hipHostMallocDefault));
     HIP_TRY(c, hipMalloc((void**) &c->d_qt_leaves, n * sizeof(mrh_qtree_leaf)));
     HIP_TRY(c, hipMalloc((void**) &c->d_qt_misc, 2 * sizeof(u64)));
   }
@@ -3075,28 +3084,27 @@ int mrh_splat_seeds(mrh_ctx* c, float qtree_thresh, int qtree_min_pixel_size, co
   if (rc) return rc;
   const u32 grid = (qt.total + 255) / 256;
   u32* unc_count = (u32*) (c->d_qt_misc + 1);
-  HIP_TRY(c, hipMemsetAsync(c->d_qt_misc, 0, 2 * sizeof(u64), s));
   // exact statistics of every potential node, four tree levels per launch
   int L = qt.D, T = L < 4 ? L : 4;
-  k_qt_sums_bottom<<<1u << (2 * (L - T)), 256, 0, s>>>(qt, c->d_rgb, c->d_qt_sums, T);
+  k_qt_sums_bottom<<<1u << (2 * (L - T)), 256, 0, s>>>(qt, c->d_rgb, c->d_qt_sums, T, c->d_qt_misc);
   for (L -= T; L > 0; L -= T) {
     T = L < 4 ? L : 4;
     k_qt_sums_up<<<1u << (2 * (L - T)), 256, 0, s>>>(qt, c->d_qt_sums, L, T);
   }
-  k_qt_decide<<<grid, 256, 0, s>>>(qt, qtree_thresh, c->d_qt_sums, c->qt_literal, c->d_qt_flags, c->d_qt_unc, unc_count);
+  // exclusive scan of the marks (mrh_sort.h): the tile sums (parked behind the positions) are cleared by k_qt_decide and added up by
+  // k_qt_emit's workgroups, then every tile scans on its own
+  const u32 tiles = (u32) ((qt.total + kChainTile - 1) / kChainTile);
+  static_assert(kChainTile % 256 == 0, "a workgroup of k_qt_emit lies inside one scan tile");
+  k_qt_decide<<<grid, 256, 0, s>>>(qt, qtree_thresh, c->d_qt_sums, c->qt_literal, c->d_qt_flags, c->d_qt_unc, unc_count, c->d_qt_pos + qt.total, tiles);
   k_qt_literal<<<512, 256, 0, s>>>(qt, c->d_rgb, qtree_thresh, c->d_qt_unc, unc_count, c->d_qt_flags);
-  k_qt_emit<<<grid, 256, 0, s>>>(qt, c->cam, c->map, c->tab, c->d_depth, c->d_rgb, c->d_qt_flags, c->d_qt_marks, c->d_qt_parked);
-  {  // exclusive scan of the marks (mrh_sort.h): tile sums (parked behind the positions), then every tile on its own
-    const u32 tiles = (u32) ((qt.total + kChainTile - 1) / kChainTile);
-    k_tile_sums_u64<<<tiles, 1024, 0, s>>>(c->d_qt_marks, (u32) qt.total, c->d_qt_pos + qt.total);
-    k_tile_scan_u64<<<tiles, 1024, 0, s>>>(c->d_qt_marks, (u32) qt.total, c->d_qt_pos + qt.total, c->d_qt_pos);
-  }
-  k_qt_scatter<<<grid, 256, 0, s>>>(qt, c->d_qt_marks, c->d_qt_pos, c->d_qt_parked, c->d_qt_leaves, c->d_qt_seeds, c->d_qt_misc);
+  k_qt_emit<<<grid, 256, 0, s>>>(qt, c->cam, c->map, c->tab, c->d_depth, c->d_rgb, c->d_qt_flags, c->d_qt_marks, c->d_qt_parked, c->d_qt_pos + qt.total);
+  k_tile_scan_u64<<<tiles, 1024, 0, s>>>(c->d_qt_marks, (u32) qt.total, c->d_qt_pos + qt.total, c->d_qt_pos);
+  k_qt_scatter<<<grid, 256, 0, s>>>(qt, c->d_qt_marks, c->d_qt_pos, c->d_qt_parked, c->d_qt_leaves, c->h_qt_seeds, c->qt_seed_cap, c->d_qt_misc, c->h_qt_out);
+  HIP_TRY(c, hipGetLastError());
   rc = mark_frame(c);
   if (rc) return rc;
-  u64 h_misc[2] = {0, 0};
-  HIP_TRY(c, hipMemcpyAsync(h_misc, c->d_qt_misc, sizeof h_misc, hipMemcpyDeviceToHost, s));
   HIP_TRY(c, hipStreamSynchronize(s));
+  const u64 h_misc[2] = {((volatile u64*) c->h_qt_out)[0], ((volatile u64*) c->h_qt_out)[1]};
   const uint64_t n_leaves = h_misc[0] & 0xFFFFFFFFull, n_seeds = h_misc[0] >> 32;
   c->qt_last_literal = (uint32_t) h_misc[1];
   if (n_leaves > 1000000ull) return fail(c, MRH_ERR_CAPACITY, "mrh_splat_seeds: %llu leaves, above the reference's capacity of 1000000 (params.h:20-23)", (unsigned long long) n_leaves);
@@ -3104,14 +3112,11 @@ int mrh_splat_seeds(mrh_ctx* c, float qtree_thresh, int qtree_min_pixel_size, co
   c->qt_n_leaves = n_leaves;
   c->qt_leaves_on_host = n_leaves == 0;
   c->qt_leaves.clear();
-  c->seeds.resize(n_seeds);
-  if (n_seeds) HIP_TRY(c, hipMemcpyAsync(c->seeds.data(), c->d_qt_seeds, n_seeds * sizeof(mrh_splat_seed), hipMemcpyDeviceToHost, s));
-  HIP_TRY(c, hipStreamSynchronize(s));
   if (getenv("MRH_DEBUG")) {
     fprintf(stderr, "[mrh] splat seeds: %u potential nodes, %u literal evaluations, %llu leaves, %llu seeds\n", qt.total,
             c->qt_last_literal, (unsigned long long) n_leaves, (unsigned long long) n_seeds);
   }
-  *out = c->seeds.data();
+  *out = c->h_qt_seeds;
   *out_n = n_seeds;
   return MRH_OK;
 }

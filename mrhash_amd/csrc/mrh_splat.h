@@ -17,11 +17,13 @@
 //   k_qt_literal    only listed nodes: the reference's summation order literally (256 strided partial sums + halving
 //                   tree; a wave per node when the node has <= 256 pixels) -> the decision the oracle takes
 //   k_qt_emit       one thread per potential node: live (all ancestors split) and leaf -> the seed test of
-//                   processNodesKernel; flags for a scan
-//   k_tile_sums_u64, k_tile_scan_u64 + k_qt_scatter      leaves and seeds in canonical order (level, then path = the order in which a
-//                                     sequential level-by-level subdivision appends them; oracle header D7)
-// No level loop, no host round trip before the final counts, and bit-identical decisions: only `err <= threshold`
-// leaves the error computation, never the error itself.
+//                   processNodesKernel; flags for a scan, and the workgroup's share of its scan tile's sum
+//   k_tile_scan_u64 + k_qt_scatter    leaves and seeds in canonical order (level, then path = the order in which a
+//                                     sequential level-by-level subdivision appends them; oracle header D7); the seeds and
+//                                     the two counts land in pinned host memory
+// No level loop, ONE host synchronisation (behind the last launch; round 6: the counters are cleared by the first launch, the
+// tile sums come from k_qt_emit, seeds and counts need no transfer call — nine launches + a memset + two read-backs became
+// eight launches), and bit-identical decisions: only `err <= threshold` leaves the error computation, never the error itself.
 #pragma once
 
 #include "mrh_mc.h"
@@ -130,8 +132,11 @@ __device__ __forceinline__ void qt_fold(const QTree& qt, const uint8_t* __restri
   }
 }
 
-__global__ __launch_bounds__(256) void k_qt_sums_bottom(const QTree qt, const uint8_t* __restrict__ rgb, QSum* __restrict__ sums, const int T) {
+// (the first launch of a seeding call also clears the call's counters: a memset in front of it is a launch of its own)
+__global__ __launch_bounds__(256) void k_qt_sums_bottom(const QTree qt, const uint8_t* __restrict__ rgb, QSum* __restrict__ sums, const int T,
+                                                        u64* __restrict__ misc) {
   __shared__ QFold f;
+  if (blockIdx.x == 0 && threadIdx.x < 2) misc[threadIdx.x] = 0ull;
   qt_fold<true>(qt, rgb, sums, qt.D, T, f);
 }
 __global__ __launch_bounds__(256) void k_qt_sums_up(const QTree qt, QSum* __restrict__ sums, const int L, const int T) {
@@ -166,8 +171,10 @@ __device__ __forceinline__ void qt_exact_error(const QTree& qt, const QSum& s, c
 }
 
 __global__ __launch_bounds__(256) void k_qt_decide(const QTree qt, const float thr, const QSum* __restrict__ sums, const int force_literal,
-                                                   u32* __restrict__ flags, u32* __restrict__ unc_list, u32* __restrict__ unc_count) {
+                                                   u32* __restrict__ flags, u32* __restrict__ unc_list, u32* __restrict__ unc_count,
+                                                   u64* __restrict__ tile_sums, const u32 tiles) {
   const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < tiles) tile_sums[i] = 0ull;  // k_qt_emit adds its workgroups' sums of marks to them (the first half of the scan)
   if (i >= qt.total) return;
   const int l = qt_level_of(qt, i);
   const QRect r = qt_rect(qt, l, i - qt_level_offset(l));
@@ -330,11 +337,10 @@ __device__ __forceinline__ bool splat_seed_of(const Cam& c, const Map& m, const 
 // marks[i] = leaf | seed << 32 for the scan; seeds are parked at their potential index
 __global__ __launch_bounds__(256) void k_qt_emit(const QTree qt, const Cam c, const Map m, const Tab t, const float* __restrict__ depth,
                                                  const uint8_t* __restrict__ rgb, const u32* __restrict__ flags, u64* __restrict__ marks,
-                                                 mrh_splat_seed* __restrict__ parked) {
+                                                 mrh_splat_seed* __restrict__ parked, u64* __restrict__ tile_sums) {
   const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= qt.total) return;
   u64 mark = 0;
-  if (flags[i] == kQtLeaf) {
+  if (i < qt.total && flags[i] == kQtLeaf) {
     const int l = qt_level_of(qt, i);
     const u32 path = i - qt_level_offset(l);
     bool live = true;
@@ -348,23 +354,37 @@ __global__ __launch_bounds__(256) void k_qt_emit(const QTree qt, const Cam c, co
       }
     }
   }
-  marks[i] = mark;
+  if (i < qt.total) marks[i] = mark;
+  // this workgroup's share of its scan tile's sum (kChainTile = 16 workgroups): (leaves, seeds) as two 32-bit counts in one word
+  __shared__ u64 s_sum[4];
+  u64 acc = mark;
+  for (int off = 32; off > 0; off >>= 1) acc += (u64) __shfl_down((unsigned long long) acc, off);
+  if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const u64 all = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
+    if (all) atomicAdd((unsigned long long*) &tile_sums[(blockIdx.x * 256u) / kChainTile], (unsigned long long) all);
+  }
 }
 
 __global__ __launch_bounds__(256) void k_qt_scatter(const QTree qt, const u64* __restrict__ marks, const u64* __restrict__ pos,
                                                     const mrh_splat_seed* __restrict__ parked, mrh_qtree_leaf* __restrict__ leaves,
-                                                    mrh_splat_seed* __restrict__ seeds, u64* __restrict__ totals) {
+                                                    mrh_splat_seed* __restrict__ seeds, const u32 seed_cap, const u64* __restrict__ misc,
+                                                    u64* __restrict__ host_out) {
   const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= qt.total) return;
   const u64 mark = marks[i], at = pos[i];
-  if (i == qt.total - 1) totals[0] = at + mark;  // (leaves | seeds << 32) of the whole tree
+  if (i == qt.total - 1) {  // for the host (pinned): (leaves | seeds << 32) of the whole tree, the literal evaluations of this call
+    host_out[0] = at + mark;
+    host_out[1] = misc[1];
+  }
   if (!(mark & 1ull)) return;
   const int l = qt_level_of(qt, i);
   const QRect r = qt_rect(qt, l, i - qt_level_offset(l));
   mrh_qtree_leaf o;
   o.x0 = r.x0; o.y0 = r.y0; o.width = r.w; o.height = r.h;
   leaves[(u32) at] = o;
-  if (mark >> 32) seeds[at >> 32] = parked[i];
+  if ((mark >> 32) && (u32) (at >> 32) < seed_cap) seeds[at >> 32] = parked[i];  // `seeds` is pinned host memory (beyond the cap the call fails)
 }
 
 }  // namespace mrh
