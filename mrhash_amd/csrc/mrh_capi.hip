@@ -823,6 +823,9 @@ __global__ __launch_bounds__(256) void k_stage_out(const StageOut a) {
       if (i < hi) dst[i] = r[k];
     }
     if (p < 2) {
+      // (the fence is needed — plain stores to the pinned buffer sit in the XCD's L2: with "stores acknowledged, then the flag" alone
+      // tools/stress_extract.py read a torn mesh within 50 extractions — and it is not what the kernel waits for: write-through stores
+      // (sc0 sc1) + acknowledgement + flag, no fence, gave the same 0.83-0.87 ms per extraction; profiles/r06/ab_stage_out_fences.txt)
       __threadfence_system();
       __syncthreads();
       if (threadIdx.x == 0) __hip_atomic_store(&a.flags[(p ? a.flag_stride : 0u) + lc], a.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);

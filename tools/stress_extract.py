@@ -8,6 +8,8 @@ from mrhash_amd import capi, synth
 
 n_ext = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 n_busy = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+if os.environ.get("MRH_LIB"):  # a tuning build of the library (mrhash_amd/build.py variant ...)
+    capi.HIP_LIB_PATH = os.path.abspath(os.environ["MRH_LIB"])
 hip = capi.load_hip()
 K = synth.REPLICA_640
 frames = bench.render_stream("replica", 25)
